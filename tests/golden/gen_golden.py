@@ -1,0 +1,149 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own Python model code.
+
+Runs only in the build container (needs /root/reference).  The reference's four CUDA extension
+modules are replaced by the C oracle through oracle/install_stubs.py (the reference has no CPU
+path of its own); everything else executed is the reference's code:
+FourierGrid_model.FourierGridModel / FourierGrid_grid.FourierGrid / grid.DenseGrid /
+dvgo.Raw2Alpha, Alphas2Weights / masked_adam.MaskedAdam.
+
+Inputs are regenerated from seeds (tests/synth.py); the fixtures hold reference OUTPUTS only.
+
+    python tests/golden/gen_golden.py        # rewrites tests/golden/*.npz
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import synth  # noqa: E402
+from oracle import install_stubs  # noqa: E402
+
+# (name, seed, G, F, C, viewbase_pe, contracted_norm, stepsize, R, thres, dens_mean, dens_std)
+FG_CASES = [
+    ("fg_inf_f3_c12", 11, 16, 3, 12, 4, "inf", 0.5, 96, 1e-4, -3.0, 8.0),
+    ("fg_l2_f2_c3", 12, 12, 2, 3, 2, "l2", 0.7, 64, 1e-4, -2.0, 6.0),
+    ("fg_inf_f4_c12_dense", 13, 10, 4, 12, 4, "inf", 0.5, 48, 1e-4, 8.0, 12.0),
+    ("fg_norgbnet", 14, 12, 3, 0, 4, "inf", 0.5, 64, 1e-4, 5.0, 12.0),
+    ("fg_inf_f3_c12_medium", 15, 14, 3, 12, 4, "inf", 1.31, 80, 1e-4, 4.0, 12.0),
+]
+# NB: fast_color_thres == 0 is not a usable mode of the reference model: forward() then hands the
+# 2-D [R,S] alpha to alpha2weight and crashes on `weights * s` (FourierGrid_model.py:600-614,667).
+
+
+def build_reference_model(mod, G, F, C, viewbase_pe, norm, thres, params):
+    model = mod.FourierGridModel(
+        xyz_min=[-1, -1, -1], xyz_max=[1, 1, 1],
+        num_voxels_density=G ** 3, num_voxels_base_density=G ** 3,
+        num_voxels_rgb=G ** 3, num_voxels_base_rgb=G ** 3, num_voxels_viewdir=-1,
+        alpha_init=1e-4, fast_color_thres=thres, contracted_norm=norm,
+        fourier_freq_num=F, rgbnet_dim=C, viewbase_pe=viewbase_pe)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in params.items():
+            assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
+            sd[k].copy_(torch.from_numpy(v))
+    assert int(model.world_len_density) == G
+    return model
+
+
+def gen_fouriergrid():
+    mod = install_stubs.import_reference("FourierGrid_model")
+    for name, seed, G, F, C, pe, norm, stepsize, R, thres, dm, ds in FG_CASES:
+        params = synth.fouriergrid_params(seed, G, F, C, viewbase_pe=pe, dens_mean=dm, dens_std=ds)
+        model = build_reference_model(mod, G, F, C, pe, norm, thres, params)
+        o, d, v = [torch.from_numpy(a) for a in synth.rays(seed, R)]
+        with torch.no_grad():
+            out = model(o, d, v, stepsize=stepsize, render_depth=True)
+        keep = {k: out[k].numpy() for k in ("alphainv_last", "weights", "rgb_marched", "raw_density", "raw_alpha",
+                                            "raw_rgb", "ray_id", "step_id", "t", "s", "depth")}
+        keep["n_max"] = np.int64(out["n_max"])
+        keep["interval"] = np.float32(float(stepsize * model.voxel_size_ratio_density))
+        keep["act_shift"] = model.act_shift.numpy()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **keep)
+        print(name, "M=%d" % out["weights"].numel(), "rgb max %.4f" % float(out["rgb_marched"].max()),
+              "terminated %d/%d" % (int((out["alphainv_last"] < 1e-3).sum()), R))
+
+
+def gen_grid_query():
+    """FourierGrid_grid.FourierGrid.forward and grid.DenseGrid.forward on points in and out of bounds."""
+    fg = install_stubs.import_reference("FourierGrid_grid")
+    dg = install_stubs.import_reference("grid")
+    res = {}
+    n = 257
+    pts = torch.from_numpy(synth.uniform(31, n * 3, -1.5, 1.5).reshape(n, 3))
+    pts[:8] = torch.tensor([[-1.2, -1.2, -1.2], [1.2, 1.2, 1.2], [0, 0, 0], [1.2, -1.2, 0.3],
+                            [1.3, 0, 0], [0, -1.25, 0], [0.1, 0.2, 1.2000001], [-1.2, 1.2, -1.2]])
+    for C, F in ((1, 3), (12, 3), (3, 2)):
+        G = (9, 7, 5)
+        m = fg.FourierGrid(channels=C, world_size=torch.tensor(G), xyz_min=[-1.2] * 3, xyz_max=[1.2] * 3,
+                           use_nerf_pos=True, fourier_freq_num=F, config={})
+        g = synth.normal(40 + C, (1 + 2 * F) * C * G[0] * G[1] * G[2]).reshape(1 + 2 * F, C, *G)
+        with torch.no_grad():
+            m.grid.copy_(torch.from_numpy(g))
+            res["fourier_c%d_f%d" % (C, F)] = m(pts).numpy()
+    for C in (1, 4):
+        G = (6, 8, 11)
+        m = dg.DenseGrid(channels=C, world_size=torch.tensor(G), xyz_min=[-1.0, -0.5, -2.0], xyz_max=[1.0, 1.5, 1.0])
+        g = synth.normal(50 + C, C * G[0] * G[1] * G[2]).reshape(1, C, *G)
+        with torch.no_grad():
+            m.grid.copy_(torch.from_numpy(g))
+            res["dense_c%d" % C] = m(pts).numpy()
+    np.savez_compressed(os.path.join(HERE, "grid_query.npz"), **res)
+    print("grid_query", {k: v.shape for k, v in res.items()})
+
+
+def gen_autograd_and_adam():
+    """dvgo.Raw2Alpha / Raw2Alpha_nonuni / Alphas2Weights forward+backward and masked_adam.MaskedAdam
+    (host-side dispatch logic of the reference, kernels = C oracle)."""
+    dvgo = install_stubs.import_reference("dvgo")
+    madam = install_stubs.import_reference("masked_adam")
+    res = {}
+    n, R = 300, 17
+    dens = torch.from_numpy(synth.normal(61, n, 5.0, 6.0)).requires_grad_(True)
+    shift = torch.tensor([-9.21024])
+    alpha = dvgo.Raw2Alpha.apply(dens, shift, 0.5)
+    ray_id = torch.from_numpy(np.sort((synth.uniform(62, n) * R).astype(np.int64)))
+    w, last = dvgo.Alphas2Weights.apply(alpha, ray_id, R)
+    gw = torch.from_numpy(synth.normal(63, n))
+    gl = torch.from_numpy(synth.normal(64, R))
+    (w * gw).sum().add((last * gl).sum()).backward()
+    res.update(a2w_alpha=alpha.detach().numpy(), a2w_w=w.detach().numpy(), a2w_last=last.detach().numpy(),
+               a2w_grad_density=dens.grad.numpy(), a2w_ray_id=ray_id.numpy())
+    dens2 = torch.from_numpy(synth.normal(65, n, 5.0, 6.0)).requires_grad_(True)
+    itv = torch.from_numpy(synth.uniform(66, n, 0.1, 1.0))
+    a2 = dvgo.Raw2Alpha_nonuni.apply(dens2, shift, itv)
+    (a2 * gw).sum().backward()
+    res.update(nonuni_alpha=a2.detach().numpy(), nonuni_grad=dens2.grad.numpy())
+
+    # MaskedAdam: 3 steps over a masked grid param, a dense param and a per-voxel-lr param
+    shape = (1, 2, 4, 5, 6)
+    p_grid = torch.nn.Parameter(torch.from_numpy(synth.normal(70, 240).reshape(shape)))
+    p_dense = torch.nn.Parameter(torch.from_numpy(synth.normal(71, 33)))
+    opt = madam.MaskedAdam([
+        {'params': [p_grid], 'lr': 0.1, 'skip_zero_grad': True},
+        {'params': [p_dense], 'lr': 1e-3, 'skip_zero_grad': False}])
+    for step in range(3):
+        g = synth.normal(80 + step, 240).reshape(shape)
+        g[np.abs(g) < 0.8] = 0.0
+        p_grid.grad = torch.from_numpy(g)
+        p_dense.grad = torch.from_numpy(synth.normal(90 + step, 33))
+        if step == 2:
+            opt.set_pervoxel_lr(torch.from_numpy(synth.uniform(95, 240, 0.0, 9.0).reshape(shape)).floor())
+        opt.step()
+    res.update(adam_grid=p_grid.detach().numpy(), adam_dense=p_dense.detach().numpy(),
+               adam_grid_m=opt.state[p_grid]['exp_avg'].numpy(), adam_grid_v=opt.state[p_grid]['exp_avg_sq'].numpy())
+    np.savez_compressed(os.path.join(HERE, "autograd_adam.npz"), **res)
+    print("autograd_adam", {k: v.shape for k, v in res.items()})
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)  # deterministic reduction order in F.linear / grid_sample
+    gen_fouriergrid()
+    gen_grid_query()
+    gen_autograd_and_adam()

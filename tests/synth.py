@@ -1,0 +1,72 @@
+"""Deterministic, library-version-independent synthetic data for tests, golden fixtures and bench.
+
+splitmix64 -> uniform(0,1) -> Box-Muller normal, all in numpy integer/float64 arithmetic, so the
+same (seed, n) gives the same fp32 array in the build container and on the GPU box regardless of
+torch/numpy RNG implementation details.  Fixtures in tests/golden store only reference OUTPUTS;
+inputs are regenerated from seeds through this file.
+"""
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(idx, seed):
+    with np.errstate(over='ignore'):
+        z = (idx.astype(np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        return z ^ (z >> np.uint64(31))
+
+
+def uniform(seed, n, lo=0.0, hi=1.0, chunk=1 << 24):
+    """n fp32 numbers in [lo,hi)."""
+    out = np.empty(n, dtype=np.float32)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        bits = _splitmix64(np.arange(s, e, dtype=np.uint64), seed)
+        u = (bits >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        out[s:e] = (lo + (hi - lo) * u).astype(np.float32)
+    return out
+
+
+def normal(seed, n, mean=0.0, std=1.0, chunk=1 << 24):
+    """n fp32 N(mean, std^2) numbers (Box-Muller on two decorrelated splitmix streams)."""
+    out = np.empty(n, dtype=np.float32)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        idx = np.arange(s, e, dtype=np.uint64)
+        b1 = _splitmix64(idx, seed)
+        b2 = _splitmix64(idx, seed ^ 0x5DEECE66D)
+        u1 = ((b1 >> np.uint64(11)).astype(np.float64) + 1.0) * (1.0 / 9007199254740993.0)
+        u2 = (b2 >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+        z = np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+        out[s:e] = (mean + std * z).astype(np.float32)
+    return out
+
+
+def fouriergrid_params(seed, G, F, C, width=128, depth=3, viewbase_pe=4, dens_mean=-3.0, dens_std=8.0):
+    """Synthetic FourierGridModel parameters as numpy arrays (fp32), keyed like the reference
+    checkpoint.  C==0 -> no rgbnet, 3-channel single-level k0."""
+    P = 1 + 2 * F
+    p = {'density.grid': normal(seed + 1, P * G ** 3, dens_mean, dens_std).reshape(P, 1, G, G, G)}
+    if C > 0:
+        p['k0.grid'] = normal(seed + 2, P * C * G ** 3).reshape(P, C, G, G, G)
+        dims = [C + 3 + 6 * viewbase_pe] + [width] * (depth - 1) + [3]
+        names = ['rgbnet.0'] + ['rgbnet.%d.0' % i for i in range(2, depth)] + ['rgbnet.%d' % depth]
+        for li, name in enumerate(names):
+            fan_in, fan_out = dims[li], dims[li + 1]
+            b = 1.0 / np.sqrt(fan_in)
+            p[name + '.weight'] = uniform(seed + 10 + li, fan_out * fan_in, -b, b).reshape(fan_out, fan_in)
+            p[name + '.bias'] = uniform(seed + 20 + li, fan_out, -b, b)
+    else:
+        p['k0.grid'] = normal(seed + 2, 3 * G ** 3).reshape(1, 3, G, G, G)
+    return p
+
+
+def rays(seed, R, origin_scale=0.3):
+    """Random camera-ish rays: origins near the scene centre, arbitrary (non-unit) directions."""
+    o = normal(seed + 100, R * 3, 0.0, origin_scale).reshape(R, 3)
+    d = normal(seed + 101, R * 3).reshape(R, 3)
+    d = d * uniform(seed + 102, R, 0.5, 2.0).reshape(R, 1)
+    v = d / np.linalg.norm(d.astype(np.float64), axis=-1, keepdims=True)
+    return o.astype(np.float32), d.astype(np.float32), v.astype(np.float32)

@@ -1,0 +1,119 @@
+"""Pins the oracle (oracle/model_oracle.py + oracle/ref_ops.c) against the golden vectors produced
+by the reference's own Python code (tests/golden/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import model_oracle, ref_ops
+
+FG_CASES = [
+    # name, seed, G, F, C, pe, norm, stepsize, R, thres, dens_mean, dens_std   (== gen_golden.FG_CASES)
+    ("fg_inf_f3_c12", 11, 16, 3, 12, 4, "inf", 0.5, 96, 1e-4, -3.0, 8.0),
+    ("fg_l2_f2_c3", 12, 12, 2, 3, 2, "l2", 0.7, 64, 1e-4, -2.0, 6.0),
+    ("fg_inf_f4_c12_dense", 13, 10, 4, 12, 4, "inf", 0.5, 48, 1e-4, 8.0, 12.0),
+    ("fg_norgbnet", 14, 12, 3, 0, 4, "inf", 0.5, 64, 1e-4, 5.0, 12.0),
+    ("fg_inf_f3_c12_medium", 15, 14, 3, 12, 4, "inf", 1.31, 80, 1e-4, 4.0, 12.0),
+]
+
+
+def make_state(seed, G, F, C, pe, norm, thres, dm, ds):
+    """Plain-tensor model state equivalent to FourierGridModel(xyz_min=-1, xyz_max=1, num_voxels=G^3,
+    alpha_init=1e-4, bg_len=0.2) with synthetic parameters."""
+    p = synth.fouriergrid_params(seed, G, F, C, viewbase_pe=pe, dens_mean=dm, dens_std=ds)
+    names = ['rgbnet.0'] + ['rgbnet.%d.0' % i for i in range(2, 3)] + ['rgbnet.3']
+    ws = [torch.from_numpy(p[n + '.weight']) for n in names] if C > 0 else []
+    bs = [torch.from_numpy(p[n + '.bias']) for n in names] if C > 0 else []
+    return {
+        'density_grid': torch.from_numpy(p['density.grid']), 'k0_grid': torch.from_numpy(p['k0.grid']),
+        'rgbnet_weights': ws, 'rgbnet_biases': bs,
+        'scene_center': torch.zeros(3), 'scene_radius': torch.ones(3),
+        'xyz_min': torch.full((3,), -1.2), 'xyz_max': torch.full((3,), 1.2),
+        'bg_len': 0.2, 'fourier_freq_num': F, 'viewbase_pe': pe,
+        'act_shift': float(model_oracle.act_shift_from_alpha_init(1e-4)), 'voxel_size_ratio': 1.0,
+        'fast_color_thres': thres, 'contracted_norm': norm, 'world_len': G,
+    }
+
+
+@pytest.mark.parametrize("case", FG_CASES, ids=[c[0] for c in FG_CASES])
+def test_fouriergrid_render_matches_reference(case, golden_dir):
+    name, seed, G, F, C, pe, norm, stepsize, R, thres, dm, ds = case
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    torch.set_num_threads(1)
+    state = make_state(seed, G, F, C, pe, norm, thres, dm, ds)
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(seed, R)]
+    out = model_oracle.fouriergrid_render(state, o, d, v, stepsize, render_depth=True)
+    assert out['n_max'] == int(gold['n_max'])
+    # index outputs: bit-exact
+    assert np.array_equal(out['ray_id'].numpy(), gold['ray_id'])
+    assert np.array_equal(out['step_id'].numpy(), gold['step_id'])
+    # float outputs: the restatement issues the same torch ops in the same order -> bit-exact
+    for k in ("alphainv_last", "weights", "rgb_marched", "raw_density", "raw_alpha", "raw_rgb", "t", "s", "depth"):
+        np.testing.assert_array_equal(out[k].numpy(), gold[k], err_msg=k)
+
+
+def test_grid_query_matches_reference(golden_dir):
+    gold = np.load(os.path.join(golden_dir, "grid_query.npz"))
+    n = 257
+    pts = torch.from_numpy(synth.uniform(31, n * 3, -1.5, 1.5).reshape(n, 3))
+    pts[:8] = torch.tensor([[-1.2, -1.2, -1.2], [1.2, 1.2, 1.2], [0, 0, 0], [1.2, -1.2, 0.3],
+                            [1.3, 0, 0], [0, -1.25, 0], [0.1, 0.2, 1.2000001], [-1.2, 1.2, -1.2]])
+    lo, hi = torch.full((3,), -1.2), torch.full((3,), 1.2)
+    for C, F in ((1, 3), (12, 3), (3, 2)):
+        G = (9, 7, 5)
+        g = torch.from_numpy(synth.normal(40 + C, (1 + 2 * F) * C * G[0] * G[1] * G[2]).reshape(1 + 2 * F, C, *G))
+        got = model_oracle.fourier_grid_query(g, pts, lo, hi, F)
+        np.testing.assert_array_equal(got.numpy(), gold["fourier_c%d_f%d" % (C, F)])
+    lo, hi = torch.tensor([-1.0, -0.5, -2.0]), torch.tensor([1.0, 1.5, 1.0])
+    for C in (1, 4):
+        G = (6, 8, 11)
+        g = torch.from_numpy(synth.normal(50 + C, C * G[0] * G[1] * G[2]).reshape(1, C, *G))
+        got = model_oracle.fourier_grid_query(g, pts, lo, hi, 0)
+        np.testing.assert_array_equal(got.numpy(), gold["dense_c%d" % C])
+
+
+def test_oracle_ops_invariants():
+    """Known-answer / property checks of the C restatement (the reference holds no vectors for it)."""
+    # alpha2weight: sum(w) + alphainv_last == 1 for rays that never hit the early stop
+    n, R = 1000, 40
+    alpha = torch.from_numpy(synth.uniform(5, n, 0.0, 0.05))
+    ray_id = torch.from_numpy(np.sort((synth.uniform(6, n) * R).astype(np.int64)))
+    w, T, last, i_s, i_e = ref_ops.alpha2weight(alpha, ray_id, R)
+    tot = torch.zeros(R).index_add_(0, ray_id, w) + last
+    assert torch.all(last > 1e-3)
+    np.testing.assert_allclose(tot.numpy(), 1.0, atol=2e-6)
+    # early stop: the crossing sample keeps its weight, later ones get w=0, T=1 (render_utils_kernel.cu:597)
+    alpha = torch.tensor([0.5, 0.9, 0.99, 0.5, 0.5, 0.3])
+    ray_id = torch.tensor([0, 0, 0, 0, 0, 2])
+    w, T, last, i_s, i_e = ref_ops.alpha2weight(alpha, ray_id, 3)
+    assert w[2] > 0 and w[3] == 0 and w[4] == 0 and T[3] == 1 and T[4] == 1
+    assert i_e[0] == 3 and last[1] == 1 and i_s[1] == 0 and i_e[1] == 0
+    assert abs(float(last[0]) - 0.5 * 0.1 * 0.01) < 1e-9 and float(last[2]) == pytest.approx(0.7)
+    # maskcache: C round() is half away from zero (torch.round is half-to-even)
+    world = torch.zeros(4, 4, 4, dtype=torch.bool)
+    world[1, 3, 0] = True
+    xyz = torch.tensor([[0.5, 2.5, -0.4], [1.49, 3.4, 0.49], [4.0, 0, 0], [-0.6, 0, 0]])
+    out = ref_ops.maskcache_lookup(world, xyz, torch.ones(3), torch.zeros(3))
+    assert out.tolist() == [True, True, False, False]
+    # raw2alpha: exp overflow -> alpha exactly 1, backward clamps exp at 1e10
+    e, a = ref_ops.raw2alpha(torch.tensor([200.0, -200.0]), 0.0, 0.5)
+    assert torch.isinf(e[0]) and a[0] == 1 and a[1] == 0
+    # masked adam leaves zero-grad entries bit-identical
+    p = torch.from_numpy(synth.normal(7, 64)); p0 = p.clone()
+    g = torch.from_numpy(synth.normal(8, 64)); g[::2] = 0
+    m = torch.zeros(64); v = torch.zeros(64)
+    ref_ops.masked_adam_upd(p, g, m, v, 1, 0.9, 0.99, 0.1, 1e-8)
+    assert torch.equal(p[::2], p0[::2]) and torch.all(p[1::2] != p0[1::2]) and torch.all(m[::2] == 0)
+    # first Adam step moves every touched entry by ~lr
+    np.testing.assert_allclose((p0 - p)[1::2].abs().numpy(), 0.1, rtol=1e-4)
+    # TV quirk: wx is ignored, the x-axis term uses wz (total_variation_kernel.cu:31-32)
+    prm = torch.from_numpy(synth.normal(9, 2 * 3 * 4 * 5).reshape(1, 2, 3, 4, 5))
+    g1 = torch.zeros_like(prm); g2 = torch.zeros_like(prm)
+    ref_ops.total_variation_add_grad(prm, g1, 1.0, 2.0, 3.0, True)
+    ref_ops.total_variation_add_grad(prm, g2, 77.0, 2.0, 3.0, True)
+    assert torch.equal(g1, g2) and g1.abs().sum() > 0
+    # cumdist: running sum resets only when it exceeds the threshold
+    mask = ref_ops.cumdist_thres(torch.tensor([[0.4, 0.4, 0.4, 0.4, 0.4]]), 1.0)
+    assert mask.tolist() == [[False, False, True, False, False]]
