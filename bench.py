@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X FourierGrid render path (BASELINE.json metric).
+
+Workload (SURVEY.md section 8d "S1", BASELINE.json configs[1]): one synthetic Mip-NeRF-360-'garden'-shaped
+frame -- 1920x1080 rays x 256 samples/ray through a FourierGridModel with G=200^3 voxels, F=3 (P=7 Fourier
+levels), C=12 feature channels, rgbnet 39->128->128->3, contracted unbounded scene, stepsize 1.31,
+fast_color_thres 1e-4.  A "step" = one full frame: ray march (density query + alpha + compositing scan)
++ shade (k0 query + rgbnet + weighted sum), inputs (rays, grids) already resident in HBM.
+
+  python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
+
+Prints ONE JSON line on rank 0.  value = Msamples/s = N * R * S / t_step (all generated samples, before
+thresholding); scaling is weak: every rank renders its own frame (own camera) and the rendered tiles
+[R,5] are exchanged with one RCCL all-gather inside the timed step.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
+
+# S1 scene statistics (white-noise grids; calibrated with the CPU oracle so that ~5% of samples survive both
+# thresholds, see DESIGN.md "synthetic scene")
+DENS_MEAN, DENS_STD = -8.5, 24.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--grid", type=int, default=200)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-chunks", type=int, default=4, help="8192-ray chunks timed for the CPU baseline")
+    return ap.parse_args()
+
+
+def make_state(G, device, seed):
+    """Synthetic FourierGridModel parameters generated ON the device (no dataset / checkpoint in the image):
+    density.grid ~ N(mu, sigma^2), k0.grid ~ N(0,1), rgbnet with nn.Linear's default init."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    F, C, pe = 3, 12, 4
+    P = 1 + 2 * F
+    dens = torch.empty(P, 1, G, G, G, device=device).normal_(DENS_MEAN, DENS_STD, generator=g)
+    k0 = torch.empty(P, C, G, G, G, device=device).normal_(0.0, 1.0, generator=g)
+    dims = [C + 3 + 6 * pe, 128, 128, 3]
+    ws, bs = [], []
+    for i in range(3):
+        b = 1.0 / math.sqrt(dims[i])
+        ws.append(torch.empty(dims[i + 1], dims[i], device=device).uniform_(-b, b, generator=g))
+        bs.append(torch.empty(dims[i + 1], device=device).uniform_(-b, b, generator=g))
+    bs[2].zero_()  # nn.init.constant_(rgbnet[-1].bias, 0)  (FourierGrid_model.py:241)
+    return {
+        "density_grid": dens, "k0_grid": k0, "rgbnet_weights": ws, "rgbnet_biases": bs,
+        "scene_center": torch.zeros(3), "scene_radius": torch.ones(3),
+        "xyz_min": torch.Tensor([-1, -1, -1]) - 0.2, "xyz_max": torch.Tensor([1, 1, 1]) + 0.2,
+        "bg_len": 0.2, "fourier_freq_num": F, "viewbase_pe": pe,
+        "act_shift": float(torch.FloatTensor([math.log(1 / (1 - 1e-4) - 1)])), "voxel_size_ratio": 1.0,
+        "fast_color_thres": 1e-4, "contracted_norm": "inf", "world_len": G,
+    }
+
+
+def camera(rank, device):
+    """Look-at-origin pinhole camera; each rank gets its own azimuth so weak-scaled frames differ."""
+    ang = 0.35 * rank
+    eye = torch.tensor([0.3 * math.cos(ang) - 0.2 * math.sin(ang), 0.3 * math.sin(ang) + 0.2 * math.cos(ang), 0.4])
+    fwd = -eye / eye.norm()
+    up = torch.tensor([0.0, 0.0, 1.0])
+    right = torch.linalg.cross(fwd, up)
+    right = right / right.norm()
+    up2 = torch.linalg.cross(right, fwd)
+    c2w = torch.stack([right, up2, -fwd, eye], dim=1)  # OpenGL-style: camera looks along -z
+    return c2w.to(device)
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer, get_rays_of_a_view
+
+    H, W, G = args.height, args.width, args.grid
+    stepsize = 1.31 * G / 200.0 if G != 200 else 1.31
+    state = make_state(G, device, seed=0)  # same model on every rank (replicated read-only grids)
+    rend = FourierGridRenderer(state, device)
+    cpu_state = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_state = {k: ([x.cpu() for x in v] if isinstance(v, list) else (v.cpu() if torch.is_tensor(v) else v))
+                     for k, v in state.items()}
+    del state
+    torch.cuda.empty_cache()
+
+    K = [[1600.0 * W / 1920.0, 0, W / 2.0], [0, 1600.0 * W / 1920.0, H / 2.0], [0, 0, 1]]
+    ro, rd, vd = get_rays_of_a_view(H, W, K, camera(rank, device))
+    ro, rd, vd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous(), vd.reshape(-1, 3).contiguous()
+    R = ro.shape[0]
+    S = rend.tables(stepsize)[2]
+    gathered = torch.empty(world * R, 5, device=device) if world > 1 else None
+
+    def step(timing=None):
+        out = rend(ro, rd, vd, stepsize=stepsize, render_depth=True, timing=timing)
+        if world > 1:
+            tile = torch.cat([out["rgb_marched"], out["depth"][:, None], out["alphainv_last"][:, None]], dim=1)
+            dist.all_gather_into_tensor(gathered, tile)
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    timing = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step(timing)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel durations from HIP events recorded on the launch stream inside the timed region
+    n_chunks = len(timing) // max(1, args.steps)
+    march_ms = sum(ev[0].elapsed_time(ev[1]) for ev, _ in timing) / args.steps
+    shade_ms = sum(ev[1].elapsed_time(ev[2]) for ev, _ in timing) / args.steps
+    # survivors of the frame (one extra, untimed frame so every chunk's list can be counted)
+    M = 0
+    chunk = rend.rays_per_chunk(S)
+    for b in range(0, R, chunk):
+        e = min(R, b + chunk)
+        rend(ro[b:e], rd[b:e], vd[b:e], stepsize=stepsize)
+        M += rend.survivors_of_last_chunk(e - b, S)
+    term_frac = float((out["alphainv_last"] < 1e-3).float().mean())
+
+    if rank == 0:
+        ms_step = dt / args.steps * 1e3
+        samples = world * R * S
+        bytes_march = R * S * 224 + R * 32          # 8 corners x 7 levels x 4 B per sample + rays in / (depth, alphainv) out
+        bytes_shade = M * 2688 + R * 24             # x 12 channels per survivor + viewdirs in / rgb out
+        kern = {"render_march": {"ms": march_ms, "algorithmic_bytes": bytes_march},
+                "render_shade": {"ms": shade_ms, "algorithmic_bytes": bytes_shade}}
+        dom = "render_march" if march_ms >= shade_ms else "render_shade"
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        achieved = kern[dom]["algorithmic_bytes"] / (kern[dom]["ms"] * 1e-3) / 1e9
+        res = {
+            "metric": "Msamples/sec (Mip-360 garden-shaped 1920x1080x256 frame, FourierGrid render)",
+            "value": samples / (dt / args.steps) / 1e6, "unit": "Msamples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rays_per_sec": world * R / (dt / args.steps),
+            "config": {"workload": "S1: FourierGridModel render, R=%dx%d rays x S=%d samples, G=%d^3, F=3 (P=7), C=12, "
+                                   "rgbnet 39-128-128-3, stepsize %.3g, thres 1e-4, white-noise grids N(%g,%g^2)"
+                                   % (W, H, S, G, stepsize, DENS_MEAN, DENS_STD),
+                       "rays": R, "samples_per_ray": S, "survivors_M": M, "survivor_frac": M / float(R * S),
+                       "terminated_ray_frac": term_frac, "chunks_per_frame": n_chunks,
+                       "parallelism": "ray-sharded replicas x%d, 1 all-gather of [R,5] tiles" % world},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "frame_bytes_formula": "R*S*224 + M*2688 + R*56 = %d" % (bytes_march + bytes_shade),
+                         "frame_frac": (bytes_march + bytes_shade) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
+            "kernels": kern,
+        }
+        if cpu_state is not None:
+            res["cpu_baseline"] = cpu_baseline(cpu_state, ro, rd, vd, out, stepsize, S, args.cpu_chunks)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cpu_state, ro, rd, vd, gpu_out, stepsize, S, n_chunks):
+    """The oracle (CPU restatement of the reference's pure-PyTorch F.grid_sample forward, kind='port') timed on
+    this box's host cores on a bounded sample of the same frame: n_chunks x 8192 rays spread over the image."""
+    from oracle import model_oracle
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    R = ro.shape[0]
+    chunk = 8192
+    starts = [int(i * (R - chunk) / max(1, n_chunks - 1)) // 64 * 64 for i in range(n_chunks)] if n_chunks > 1 else [0]
+    worst = 0.0
+    t_total, n_samples = 0.0, 0
+    for i, b in enumerate([starts[0]] + starts):  # first pass = warm-up, not timed
+        o, d, v = ro[b:b + chunk].cpu(), rd[b:b + chunk].cpu(), vd[b:b + chunk].cpu()
+        t0 = time.perf_counter()
+        ref = model_oracle.fouriergrid_render(cpu_state, o, d, v, stepsize, render_depth=True, return_margin=True)
+        t1 = time.perf_counter()
+        if i == 0:
+            continue
+        t_total += t1 - t0
+        n_samples += chunk * S
+        safe = ref["margin"] > 1e-4
+        for k in ("rgb_marched", "depth", "alphainv_last"):
+            err = (gpu_out[k][b:b + chunk].cpu() - ref[k]).abs()
+            err = err.amax(dim=1) if err.dim() == 2 else err
+            worst = max(worst, float(err[safe].max()))
+    return {"value": n_samples / t_total / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+            "sample": "%d chunks x 8192 rays x %d samples of the same frame (oracle/model_oracle.py, torch CPU "
+                      "grid_sample path), 1 warm-up chunk" % (n_chunks, S),
+            "rays_per_sec": n_chunks * chunk / t_total, "gpu_vs_oracle_linf_on_sample": worst}
+
+
+if __name__ == "__main__":
+    main()

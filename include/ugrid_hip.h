@@ -1,0 +1,206 @@
+/*
+ * ugrid_hip.h -- C ABI of libugrid_hip.so: the MI355X (gfx950) hot path of
+ * sjtuytc/UnboundedNeRFPytorch's FourierGrid/DVGO renderer.
+ *
+ * Boundary rules
+ *   - extern "C", plain device pointers + sizes, no torch types.  fp32 data, int64 indices,
+ *     bool masks as uint8_t (torch.bool layout).  All pointers are DEVICE pointers of the
+ *     current HIP device unless the parameter name starts with h_ (host).
+ *   - every function enqueues on `stream` (a hipStream_t passed as void*; NULL = default
+ *     stream), never synchronises unless documented, and returns a hipError_t as int (0 = ok).
+ *   - outputs are caller-allocated; "init" notes say what the function itself writes.
+ *
+ * Each entry point names the reference interface it replaces (paths relative to
+ * /root/reference/FourierGrid/cuda/).  The reference binds these through pybind11
+ * (render_utils.cpp:170-184, total_variation.cpp:23, ub360_utils.cpp:21, adam_upd.cpp:79-86);
+ * INTEGRATION.md shows the binding a maintainer adds to call this library instead.
+ */
+#ifndef UGRID_HIP_H
+#define UGRID_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *ugrid_stream_t; /* hipStream_t */
+
+/* ABI version of this header (bumped on any signature change). */
+int ugrid_abi_version(void);
+/* "gfx950" -- the only architecture the code objects are built for. */
+const char *ugrid_target_arch(void);
+
+/* ------------------------------------------------------------------ render_utils_cuda */
+
+/* replaces infer_t_minmax (render_utils.cpp:170 -> render_utils_kernel.cu:12-35,82-104).
+ * rays_o, rays_d [n_rays,3]; xyz_min, xyz_max [3]; t_min, t_max [n_rays] written. */
+int ugrid_infer_t_minmax(const float *rays_o, const float *rays_d, const float *xyz_min,
+                         const float *xyz_max, float near, float far, int64_t n_rays,
+                         float *t_min, float *t_max, ugrid_stream_t stream);
+
+/* replaces infer_n_samples (render_utils.cpp:171 -> render_utils_kernel.cu:38-55,106-121). */
+int ugrid_infer_n_samples(const float *rays_d, const float *t_min, const float *t_max,
+                          float stepdist, int64_t n_rays, int64_t *n_samples, ugrid_stream_t stream);
+
+/* replaces infer_ray_start_dir (render_utils.cpp:172 -> render_utils_kernel.cu:58-79,123-139). */
+int ugrid_infer_ray_start_dir(const float *rays_o, const float *rays_d, const float *t_min,
+                              int64_t n_rays, float *rays_start, float *rays_dir, ugrid_stream_t stream);
+
+/* replaces sample_pts_on_rays (render_utils.cpp:173 -> render_utils_kernel.cu:144-242), split in
+ * the two halves the reference separates with its N_steps.sum().item() host sync:
+ *   _count: writes t_min,t_max [n_rays], n_steps [n_rays], the inclusive prefix sum
+ *           n_steps_cumsum [n_rays] and *d_total (device int64) = total sample count.
+ *           scan_ws: device scratch of ugrid_scan_ws_bytes(n_rays) bytes.
+ *   _fill:  given total_len (read back by the caller from d_total) writes rays_pts [total,3],
+ *           mask_outbbox [total] (uint8 bool), ray_id, step_id [total] (int64). */
+int64_t ugrid_scan_ws_bytes(int64_t n);
+int ugrid_sample_pts_on_rays_count(const float *rays_o, const float *rays_d, const float *xyz_min,
+                                   const float *xyz_max, float near, float far, float stepdist,
+                                   int64_t n_rays, float *t_min, float *t_max, int64_t *n_steps,
+                                   int64_t *n_steps_cumsum, int64_t *d_total, void *scan_ws,
+                                   ugrid_stream_t stream);
+int ugrid_sample_pts_on_rays_fill(const float *rays_o, const float *rays_d, const float *xyz_min,
+                                  const float *xyz_max, const float *t_min,
+                                  const int64_t *n_steps_cumsum, float stepdist, int64_t n_rays,
+                                  int64_t total_len, float *rays_pts, uint8_t *mask_outbbox,
+                                  int64_t *ray_id, int64_t *step_id, ugrid_stream_t stream);
+
+/* replaces sample_ndc_pts_on_rays (render_utils.cpp:174 -> render_utils_kernel.cu:245-293). */
+int ugrid_sample_ndc_pts_on_rays(const float *rays_o, const float *rays_d, const float *xyz_min,
+                                 const float *xyz_max, int64_t n_samples, int64_t n_rays,
+                                 float *rays_pts, uint8_t *mask_outbbox, ugrid_stream_t stream);
+
+/* replaces sample_bg_pts_on_rays (render_utils.cpp:175 -> render_utils_kernel.cu:301-360). */
+int ugrid_sample_bg_pts_on_rays(const float *rays_o, const float *rays_d, const float *t_max,
+                                float bg_preserve, int64_t n_samples, int64_t n_rays,
+                                float *rays_pts, ugrid_stream_t stream);
+
+/* replaces maskcache_lookup (render_utils.cpp:176 -> render_utils_kernel.cu:367-424).
+ * world [sz_i,sz_j,sz_k] uint8 bool; xyz [n_pts,3]; out [n_pts] fully written (0 when out of range). */
+int ugrid_maskcache_lookup(const uint8_t *world, const float *xyz, const float *xyz2ijk_scale,
+                           const float *xyz2ijk_shift, int64_t sz_i, int64_t sz_j, int64_t sz_k,
+                           int64_t n_pts, uint8_t *out, ugrid_stream_t stream);
+
+/* replaces raw2alpha / raw2alpha_nonuni (render_utils.cpp:177-178 -> render_utils_kernel.cu:431-504).
+ * interval_arr == NULL: uniform `interval`; else per-point intervals [n]. */
+int ugrid_raw2alpha(const float *density, float shift, float interval, const float *interval_arr,
+                    int64_t n, float *exp_d, float *alpha, ugrid_stream_t stream);
+
+/* replaces raw2alpha_backward / raw2alpha_nonuni_backward (render_utils.cpp:179-180 ->
+ * render_utils_kernel.cu:507-574). */
+int ugrid_raw2alpha_backward(const float *exp_d, const float *grad_back, float interval,
+                             const float *interval_arr, int64_t n, float *grad, ugrid_stream_t stream);
+
+/* replaces alpha2weight (render_utils.cpp:181 -> render_utils_kernel.cu:577-651).
+ * alpha [n]; ray_id [n] int64 sorted non-decreasing, values in [0,n_rays).  Writes EVERY element of
+ * weight,T [n] (0 / 1 past the early stop), alphainv_last [n_rays] (1 for empty rays) and
+ * i_start,i_end [n_rays] (0 for empty rays; i_end truncated at the early stop).  No host sync. */
+int ugrid_alpha2weight(const float *alpha, const int64_t *ray_id, int64_t n, int64_t n_rays,
+                       float *weight, float *T, float *alphainv_last, int64_t *i_start,
+                       int64_t *i_end, ugrid_stream_t stream);
+
+/* replaces alpha2weight_backward (render_utils.cpp:182 -> render_utils_kernel.cu:654-707).
+ * grad [n] fully written (0 outside [i_start,i_end)). */
+int ugrid_alpha2weight_backward(const float *alpha, const float *weight, const float *T,
+                                const float *alphainv_last, const int64_t *i_start,
+                                const int64_t *i_end, int64_t n, int64_t n_rays,
+                                const float *grad_weights, const float *grad_last, float *grad,
+                                ugrid_stream_t stream);
+
+/* ------------------------------------------------------------------ total_variation_cuda */
+
+/* replaces total_variation_add_grad (total_variation.cpp:23 -> total_variation_kernel.cu:14-67).
+ * param, grad: N = (leading dims) * sz_i*sz_j*sz_k contiguous floats; grad updated in place.
+ * wx is accepted and ignored exactly like the reference (its x-axis term uses wz). */
+int ugrid_total_variation_add_grad(const float *param, float *grad, float wx, float wy, float wz,
+                                   int dense_mode, int64_t sz_i, int64_t sz_j, int64_t sz_k,
+                                   int64_t N, ugrid_stream_t stream);
+
+/* ------------------------------------------------------------------ ub360_utils_cuda */
+
+/* replaces cumdist_thres (ub360_utils.cpp:21 -> ub360_utils_kernel.cu:13-47). dist [n_rays,n_pts]. */
+int ugrid_cumdist_thres(const float *dist, float thres, int64_t n_rays, int64_t n_pts,
+                        uint8_t *mask, ugrid_stream_t stream);
+
+/* ------------------------------------------------------------------ adam_upd_cuda */
+
+/* replaces adam_upd / masked_adam_upd / adam_upd_with_perlr (adam_upd.cpp:79-86 ->
+ * adam_upd_kernel.cu:9-132).  mode: 0 dense, 1 masked (skip grad==0), 2 per-voxel lr (perlr != NULL).
+ * param, exp_avg, exp_avg_sq updated in place. */
+int ugrid_adam_upd(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
+                   const float *perlr, int64_t N, int step, float beta1, float beta2, float lr,
+                   float eps, int mode, ugrid_stream_t stream);
+
+/* ------------------------------------------------------------------ fused render path
+ * New entry points (no native counterpart in the reference): they replace the torch-op chain of
+ * FourierGridModel.forward (FourierGrid_model.py:554-672) and FourierGrid.forward
+ * (FourierGrid_grid.py:60-78) for inference.  See DESIGN.md for layouts. */
+
+/* Fourier / dense grid query: replaces FourierGrid.forward (FourierGrid_grid.py:60-78) and
+ * DenseGrid.forward (grid.py:50-61) = F.grid_sample(bilinear, align_corners=True, zeros) + mean over
+ * levels.  grid [P,C,X,Y,Z] canonical layout; xyz [n,3] world coords; out [n,C].  freq_num = F
+ * (P must be 1+2F) or 0 for a single-level grid. */
+int ugrid_grid_query(const float *grid, int P, int C, int X, int Y, int Z, const float *xyz,
+                     const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
+                     float *out, ugrid_stream_t stream);
+
+/* Brick packing: canonical [P,C,X,Y,Z] -> cell-major 2x2x2 bricks, one contiguous record per
+ * trilinear cell: [P*(X-1)(Y-1)(Z-1)][H halves][8 corners][CH channels] with
+ *   C == 1 (density)        : H = 1, CH = 1            (32 B / cell)
+ *   C  > 1 (rgbnet features): H = 2, CH = ceil(C/2)    (zero padded; 384 B / cell at C = 12)
+ *   direct != 0 (no rgbnet, C == 3): H = 1, CH = 4     (128 B / cell)
+ * ugrid_brick_bytes returns the size of the packed array. */
+int64_t ugrid_brick_bytes(int P, int C, int X, int Y, int Z, int direct);
+int ugrid_pack_bricks(const float *grid, int P, int C, int X, int Y, int Z, int direct, float *bricks,
+                      ugrid_stream_t stream);
+
+/* Parameters of the fused FourierGrid render (HOST struct, passed by pointer). */
+typedef struct ugrid_render_params {
+  int64_t n_rays;
+  int32_t n_samples;              /* S = len(t) */
+  int32_t freq_num;               /* F; P = 1+2F levels (1..5) */
+  int32_t grid_x, grid_y, grid_z; /* density == k0 resolution */
+  int32_t k0_channels;            /* C (12, or 3) */
+  int32_t mlp_in;                 /* C + 3 + 6*viewbase_pe; 0 => no rgbnet (rgb = sigmoid(k0), C==3) */
+  int32_t mlp_width;              /* 128 */
+  int32_t viewbase_pe;
+  int32_t norm_l2;                /* 0: inf-norm contraction, 1: l2 */
+  float scene_center[3], scene_radius[3];
+  float xyz_min[3], xyz_max[3];   /* contracted bounds (-1-bg .. 1+bg) as the fp32 buffers hold them */
+  double bg_len;                  /* python float, e.g. 0.2 */
+  float act_shift, interval, thres;
+} ugrid_render_params;
+
+/* Bytes of the survivor work list (worst case: every sample survives) for n_rays x n_samples. */
+int64_t ugrid_render_ws_bytes(int64_t n_rays, int32_t n_samples);
+
+/* Fused march: rays -> contracted samples -> P-level density bricks -> raw2alpha -> threshold ->
+ * front-to-back scan with early stop -> threshold; writes alphainv_last [R], depth [R] and per-tile
+ * (64 rays) survivor lists into ws.  t_table, s_table [S] device floats (sample distances t and
+ * s = 1-1/(1+t), FourierGrid_model.py:524-532,649). */
+int ugrid_render_march(const ugrid_render_params *h_params, const float *rays_o, const float *rays_d,
+                       const float *t_table, const float *s_table, const float *density_bricks,
+                       float *alphainv_last, float *depth, void *ws, ugrid_stream_t stream);
+
+/* Fused shade: survivors -> P-level k0 bricks -> [k0, viewdir emb] -> rgbnet (fp32 MFMA) -> sigmoid
+ * -> weighted per-ray sum in sample order; writes rgb_marched [R,3].  mlp_packed: ugrid_pack_mlp(). */
+int ugrid_render_shade(const ugrid_render_params *h_params, const float *viewdirs,
+                       const float *k0_bricks, const float *mlp_packed, void *ws,
+                       float *rgb_marched, ugrid_stream_t stream);
+
+/* rgbnet packing for the MFMA shade kernel: w0 [128, C+3+6pe], b0 [128], w1 [128,128], b1 [128],
+ * w2 [3,128], b2 [3] (nn.Linear layout, FourierGrid_model.py:233-241) -> packed device array. */
+int64_t ugrid_mlp_packed_bytes(int32_t k0_channels, int32_t viewbase_pe);
+int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1, const float *b1,
+                   const float *w2, const float *b2, int32_t k0_channels, int32_t viewbase_pe,
+                   int32_t width, float *packed, ugrid_stream_t stream);
+
+/* Total survivors of the last march on this ws -> *d_stats (device int64). */
+int ugrid_render_stats(void *ws, int64_t n_rays, int32_t n_samples, int64_t *d_stats,
+                       ugrid_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UGRID_HIP_H */

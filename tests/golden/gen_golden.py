@@ -142,8 +142,26 @@ def gen_autograd_and_adam():
     print("autograd_adam", {k: v.shape for k, v in res.items()})
 
 
+def gen_rays_view():
+    """dvgo.get_rays_of_a_view (dvgo.py:493-521,554-559) for a small view and three flag combinations."""
+    dvgo = install_stubs.import_reference("dvgo")
+    K = np.array([[9.0, 0, 3.5], [0, 8.0, 2.5], [0, 0, 1]], dtype=np.float32)
+    ang = 0.7
+    c2w = np.array([[np.cos(ang), 0, np.sin(ang), 0.3], [0.1, 1.0, 0, -0.2], [-np.sin(ang), 0, np.cos(ang), 0.4]],
+                   dtype=np.float32)
+    res = {"K": K, "c2w": c2w}
+    for tag, kw in (("a", dict(inverse_y=False, flip_x=False, flip_y=False)),
+                    ("b", dict(inverse_y=True, flip_x=True, flip_y=False)),
+                    ("c", dict(inverse_y=False, flip_x=False, flip_y=True))):
+        o, d, v = dvgo.get_rays_of_a_view(H=5, W=7, K=K, c2w=torch.from_numpy(c2w), ndc=False, mode='center', **kw)
+        res[tag + "_o"], res[tag + "_d"], res[tag + "_v"] = o.numpy(), d.numpy(), v.numpy()
+    np.savez_compressed(os.path.join(HERE, "rays_view.npz"), **res)
+    print("rays_view", o.shape)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)  # deterministic reduction order in F.linear / grid_sample
     gen_fouriergrid()
     gen_grid_query()
     gen_autograd_and_adam()
+    gen_rays_view()

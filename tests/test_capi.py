@@ -1,0 +1,84 @@
+"""CPU checks of the drop-in boundary: libugrid_hip.so builds for gfx950, loads, and exports every symbol
+that include/ugrid_hip.h declares (no compute calls -- there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    import __graft_entry__
+    __graft_entry__.build()
+    return os.path.join(ROOT, "unboundednerfpytorch_amd", "libugrid_hip.so")
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "ugrid_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ugrid_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib_path):
+    names = declared_functions()
+    assert len(names) >= 25
+    lib = ctypes.CDLL(lib_path)
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_python_binding_table_matches_header(lib_path):
+    from unboundednerfpytorch_amd import _lib
+    assert sorted(_lib.EXPORTED_SYMBOLS) == declared_functions()
+    lib = _lib.load()
+    assert lib.ugrid_abi_version() == _lib.ABI_VERSION
+    assert lib.ugrid_target_arch() == b"gfx950"
+    # size helpers are pure host arithmetic: S1 numbers from DESIGN.md
+    assert lib.ugrid_brick_bytes(7, 1, 200, 200, 200, 0) == 7 * 199 ** 3 * 32
+    assert lib.ugrid_brick_bytes(7, 12, 200, 200, 200, 0) == 7 * 199 ** 3 * 384
+    assert lib.ugrid_brick_bytes(1, 3, 160, 160, 160, 1) == 159 ** 3 * 128
+    assert lib.ugrid_mlp_packed_bytes(12, 4) == 4 * (20 * 256 + 64 * 256 + 128 + 128 + 512 + 4)
+    assert lib.ugrid_render_ws_bytes(64, 256) >= 64 * 256 * 17
+
+
+def test_code_object_is_gfx950_only(lib_path):
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", lib_path], capture_output=True, text=True)
+    # the fat binary is embedded; roc-obj-ls style check through strings
+    blob = open(lib_path, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_90", b"nvptx"):
+        assert other not in blob, other
+
+
+def test_reference_module_names_and_signatures():
+    """The four drop-in modules expose exactly the reference's m.def names (render_utils.cpp:170-184,
+    total_variation.cpp:23, ub360_utils.cpp:21, adam_upd.cpp:79-86) with the same positional parameters."""
+    import inspect
+    from unboundednerfpytorch_amd import adam_upd_cuda, compat, render_utils_cuda, total_variation_cuda, ub360_utils_cuda
+    want = {
+        render_utils_cuda: {
+            "infer_t_minmax": 6, "infer_n_samples": 4, "infer_ray_start_dir": 3, "sample_pts_on_rays": 7,
+            "sample_ndc_pts_on_rays": 5, "sample_bg_pts_on_rays": 5, "maskcache_lookup": 4, "raw2alpha": 3,
+            "raw2alpha_backward": 3, "raw2alpha_nonuni": 3, "raw2alpha_nonuni_backward": 3, "alpha2weight": 3,
+            "alpha2weight_backward": 9},
+        total_variation_cuda: {"total_variation_add_grad": 6},
+        ub360_utils_cuda: {"cumdist_thres": 2},
+        adam_upd_cuda: {"adam_upd": 9, "masked_adam_upd": 9, "adam_upd_with_perlr": 10},
+    }
+    for mod, fns in want.items():
+        for name, nargs in fns.items():
+            assert len(inspect.signature(getattr(mod, name)).parameters) == nargs, name
+    import sys
+    names = compat.install_as_reference_extensions()
+    for n in names:
+        assert n in sys.modules
+    import render_utils_cuda as r2  # the name the reference imports
+    assert r2 is render_utils_cuda
+    # the ops refuse host tensors exactly like the reference's CHECK_INPUT
+    import torch
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        render_utils_cuda.raw2alpha(torch.zeros(3), 0.0, 0.5)

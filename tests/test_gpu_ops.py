@@ -1,0 +1,335 @@
+"""GPU parity of the drop-in ops (through the C ABI) against the CPU oracle on seeded inputs.
+
+Bit-exact for everything that is integer / index work or pure IEEE add-mul-div-sqrt arithmetic
+(both sides are compiled with FMA contraction off); exp/pow differ between glibc and the device
+libm, so raw2alpha & co. are compared at a few-ulp tolerance stated next to each test.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import ref_ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mods():
+    from unboundednerfpytorch_amd import adam_upd_cuda, render_utils_cuda, total_variation_cuda, ub360_utils_cuda
+    return render_utils_cuda, total_variation_cuda, ub360_utils_cuda, adam_upd_cuda
+
+
+def dev(*ts):
+    return [t.cuda() if t is not None else None for t in ts]
+
+
+def rays_case(seed, R, with_zero_dirs=True):
+    o = torch.from_numpy(synth.normal(seed, R * 3, 0.0, 1.5).reshape(R, 3))
+    d = torch.from_numpy(synth.normal(seed + 1, R * 3).reshape(R, 3))
+    if with_zero_dirs and R >= 8:
+        d[1, 0] = 0.0
+        d[2] = torch.tensor([0.0, 0.0, 1.0])
+        d[3, 2] = -0.0
+    lo = torch.tensor([-1.0, -0.9, -1.1])
+    hi = torch.tensor([1.0, 1.2, 0.8])
+    return o, d, lo, hi
+
+
+@pytest.mark.parametrize("R", [1, 63, 64, 4097])
+def test_infer_and_sample_pts_bit_exact(mods, R):
+    ru = mods[0]
+    o, d, lo, hi = rays_case(100 + R, R)
+    near, far, stepdist = 0.2, 1e9, 0.0173
+    go, gd, glo, ghi = dev(o, d, lo, hi)
+    t_ref = ref_ops.infer_t_minmax(o, d, lo, hi, near, far)
+    t_gpu = ru.infer_t_minmax(go, gd, glo, ghi, near, far)
+    for a, b in zip(t_ref, t_gpu):
+        np.testing.assert_array_equal(a.numpy(), b.cpu().numpy())
+    n_ref = ref_ops.infer_n_samples(d, t_ref[0], t_ref[1], stepdist)
+    n_gpu = ru.infer_n_samples(gd, t_gpu[0], t_gpu[1], stepdist)
+    np.testing.assert_array_equal(n_ref.numpy(), n_gpu.cpu().numpy())
+    s_ref = ref_ops.infer_ray_start_dir(o, d, t_ref[0])
+    s_gpu = ru.infer_ray_start_dir(go, gd, t_gpu[0])
+    for a, b in zip(s_ref, s_gpu):
+        np.testing.assert_array_equal(a.numpy(), b.cpu().numpy())
+    full_ref = ref_ops.sample_pts_on_rays(o, d, lo, hi, near, far, stepdist)
+    full_gpu = ru.sample_pts_on_rays(go, gd, glo, ghi, near, far, stepdist)
+    assert len(full_gpu) == 7
+    for a, b in zip(full_ref, full_gpu):
+        assert a.dtype == b.dtype and a.shape == b.shape
+        np.testing.assert_array_equal(a.numpy(), b.cpu().numpy())
+    # ray_id monotone, step_id restarts at 0
+    rid = full_gpu[2].cpu()
+    assert torch.all(rid[1:] >= rid[:-1])
+
+
+def test_sample_pts_many_rays_scan(mods):
+    """> 1024*256 rays exercises the multi-block scan; totals must match the oracle exactly."""
+    ru = mods[0]
+    R = 300_001
+    o, d, lo, hi = rays_case(7, R, with_zero_dirs=False)
+    ref = ref_ops.sample_pts_on_rays(o, d, lo, hi, 0.0, 1e9, 0.21)
+    gpu = ru.sample_pts_on_rays(*dev(o, d, lo, hi), 0.0, 1e9, 0.21)
+    assert gpu[0].shape == ref[0].shape
+    for a, b in zip(ref, gpu):
+        np.testing.assert_array_equal(a.numpy(), b.cpu().numpy())
+
+
+def test_empty_inputs(mods):
+    ru, tv, ub, ad = mods
+    z3 = torch.zeros(0, 3, device="cuda")
+    lo, hi = torch.tensor([-1.0, -1, -1]).cuda(), torch.tensor([1.0, 1, 1]).cuda()
+    out = ru.sample_pts_on_rays(z3, z3, lo, hi, 0.0, 1.0, 0.1)
+    assert out[0].shape == (0, 3) and out[4].shape == (0,)
+    e, a = ru.raw2alpha(torch.zeros(0, device="cuda"), 0.0, 0.5)
+    assert e.numel() == 0 and a.numel() == 0
+    w, T, last, i_s, i_e = ru.alpha2weight(torch.zeros(0, device="cuda"), torch.zeros(0, dtype=torch.int64, device="cuda"), 5)
+    assert w.numel() == 0 and torch.all(last == 1) and torch.all(i_s == 0) and torch.all(i_e == 0)
+    m = ru.maskcache_lookup(torch.ones(2, 2, 2, dtype=torch.bool, device="cuda"), z3, lo, hi)
+    assert m.shape == (0,)
+
+
+def test_sample_ndc_and_bg_bit_exact(mods):
+    ru = mods[0]
+    R, N = 513, 37
+    o, d, lo, hi = rays_case(11, R)
+    ref = ref_ops.sample_ndc_pts_on_rays(o, d, lo, hi, N)
+    gpu = ru.sample_ndc_pts_on_rays(*dev(o, d, lo, hi), N)
+    for a, b in zip(ref, gpu):
+        np.testing.assert_array_equal(a.numpy(), b.cpu().numpy())
+    t_max = torch.from_numpy(synth.uniform(12, R, 0.5, 3.0))
+    refb = ref_ops.sample_bg_pts_on_rays(o, d, t_max, 0.3, N)
+    gpub = ru.sample_bg_pts_on_rays(*dev(o, d, t_max), 0.3, N)
+    np.testing.assert_array_equal(refb.numpy(), gpub.cpu().numpy())
+
+
+def test_maskcache_lookup_bit_exact(mods):
+    ru = mods[0]
+    world = torch.from_numpy(synth.uniform(20, 9 * 7 * 5) > 0.5).reshape(9, 7, 5)
+    n = 20_000
+    xyz = torch.from_numpy(synth.uniform(21, n * 3, -1.6, 1.6).reshape(n, 3))
+    xyz[:4] = torch.tensor([[-1.2, -1.2, -1.2], [1.2, 1.2, 1.2], [float("nan"), 0, 0], [1e30, 0, 0]])
+    lo, hi = torch.full((3,), -1.2), torch.full((3,), 1.2)
+    scale = (torch.tensor([9.0, 7.0, 5.0]) - 1) / (hi - lo)
+    shift = -lo * scale
+    # exact .5 positions exercise round-half-away-from-zero
+    xyz[4:40, 0] = ((torch.arange(36) * 0.5 - 2.0) - shift[0]) / scale[0]
+    ref = ref_ops.maskcache_lookup(world, xyz, scale, shift)
+    gpu = ru.maskcache_lookup(*dev(world, xyz, scale, shift))
+    np.testing.assert_array_equal(ref.numpy(), gpu.cpu().numpy())
+
+
+def ulp_diff(a, b):
+    a = np.asarray(a, np.float32)
+    b = np.asarray(b, np.float32)
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    ai = np.where(ai < 0, np.int64(-2 ** 31) - ai, ai)
+    bi = np.where(bi < 0, np.int64(-2 ** 31) - bi, bi)
+    return np.abs(ai - bi)
+
+
+def test_raw2alpha_and_backward(mods):
+    """exp/pow come from different libms: tolerance 4 ulp on exp, and on alpha = 1 - pow(..) an absolute
+    3e-7 (the subtraction from 1 amplifies pow's ulp when alpha is small)."""
+    ru = mods[0]
+    n = 100_003
+    dens = torch.from_numpy(synth.normal(30, n, 4.0, 8.0))
+    dens[:3] = torch.tensor([200.0, -200.0, 0.0])
+    shift, interval = -9.21024, 0.5
+    e_ref, a_ref = ref_ops.raw2alpha(dens, shift, interval)
+    e_gpu, a_gpu = ru.raw2alpha(dens.cuda(), torch.tensor([shift]).cuda(), torch.tensor(interval))
+    fin = torch.isfinite(e_ref).numpy()
+    assert np.array_equal(fin, torch.isfinite(e_gpu).cpu().numpy())
+    assert ulp_diff(e_ref.numpy()[fin], e_gpu.cpu().numpy()[fin]).max() <= 4
+    np.testing.assert_allclose(a_gpu.cpu().numpy(), a_ref.numpy(), rtol=0, atol=3e-7)
+    assert a_gpu[0] == 1 and a_gpu[1] == 0
+    gb = torch.from_numpy(synth.normal(31, n))
+    g_ref = ref_ops.raw2alpha_backward(e_ref, gb, interval)
+    g_gpu = ru.raw2alpha_backward(e_ref.cuda(), gb.cuda(), interval)
+    np.testing.assert_allclose(g_gpu.cpu().numpy(), g_ref.numpy(), rtol=2e-6, atol=1e-30)
+    itv = torch.from_numpy(synth.uniform(32, n, 0.05, 1.5))
+    e2_ref, a2_ref = ref_ops.raw2alpha_nonuni(dens, shift, itv)
+    e2_gpu, a2_gpu = ru.raw2alpha_nonuni(dens.cuda(), shift, itv.cuda())
+    np.testing.assert_allclose(a2_gpu.cpu().numpy(), a2_ref.numpy(), rtol=0, atol=3e-7)
+    g2_ref = ref_ops.raw2alpha_nonuni_backward(e2_ref, gb, itv)
+    g2_gpu = ru.raw2alpha_nonuni_backward(e2_ref.cuda(), gb.cuda(), itv.cuda())
+    np.testing.assert_allclose(g2_gpu.cpu().numpy(), g2_ref.numpy(), rtol=2e-6, atol=1e-30)
+
+
+def a2w_case(seed, n, R, amax):
+    alpha = torch.from_numpy(synth.uniform(seed, n, 0.0, amax))
+    rid = np.sort((synth.uniform(seed + 1, n) * R).astype(np.int64))
+    rid[rid == 3] = 4  # leave some rays empty
+    return alpha, torch.from_numpy(np.sort(rid))
+
+
+@pytest.mark.parametrize("n,R,amax", [(1, 1, 0.5), (64, 1, 0.01), (65, 2, 0.2), (5000, 37, 0.05), (200_000, 513, 0.3),
+                                      (30_000, 7, 0.002)])
+def test_alpha2weight_bit_exact(mods, n, R, amax):
+    ru = mods[0]
+    alpha, rid = a2w_case(40 + n, n, R, amax)
+    ref = ref_ops.alpha2weight(alpha, rid, R)
+    gpu = ru.alpha2weight(alpha.cuda(), rid.cuda(), R)
+    names = ["weight", "T", "alphainv_last", "i_start", "i_end"]
+    for nm, a, b in zip(names, ref, gpu):
+        np.testing.assert_array_equal(a.numpy(), b.cpu().numpy(), err_msg=nm)
+    gw = torch.from_numpy(synth.normal(41, n))
+    gl = torch.from_numpy(synth.normal(42, R))
+    g_ref = ref_ops.alpha2weight_backward(alpha, *ref, R, gw, gl)
+    g_gpu = ru.alpha2weight_backward(alpha.cuda(), *gpu, R, gw.cuda(), gl.cuda())
+    np.testing.assert_array_equal(g_ref.numpy(), g_gpu.cpu().numpy())
+
+
+def test_alpha2weight_properties_large(mods):
+    """Size-independent properties at a frame-sized input: sum(w)+alphainv_last == 1 for unterminated rays,
+    terminated rays stop below 1e-3, weights are 0 / T is 1 after the stop."""
+    ru = mods[0]
+    R, S = 8192, 668
+    alpha = torch.from_numpy(synth.uniform(50, R * S, 0.0, 0.01)).cuda()
+    alpha[: 100 * S] *= 50  # some rays terminate
+    rid = torch.arange(R, device="cuda").repeat_interleave(S)
+    w, T, last, i_s, i_e = ru.alpha2weight(alpha, rid, R)
+    tot = torch.zeros(R, device="cuda").index_add_(0, rid, w) + last
+    unterminated = last >= 1e-3
+    assert torch.all((tot[unterminated] - 1).abs() < 5e-6)
+    assert torch.all(i_e[unterminated] == i_s[unterminated] + S)
+    assert (~unterminated).sum() > 10
+    pos = torch.arange(R * S, device="cuda")
+    after = pos >= i_e[rid]
+    assert torch.all(w[after] == 0) and torch.all(T[after] == 1)
+
+
+@pytest.mark.parametrize("dense", [True, False])
+def test_total_variation_bit_exact(mods, dense):
+    tv = mods[1]
+    shape = (3, 2, 9, 6, 11)
+    n = int(np.prod(shape))
+    prm = torch.from_numpy(synth.normal(60, n, 0.0, 2.0).reshape(shape))
+    g = synth.normal(61, n).reshape(shape)
+    g[np.abs(g) < 0.7] = 0
+    g_ref = torch.from_numpy(g.copy())
+    g_gpu = torch.from_numpy(g.copy()).cuda()
+    ref_ops.total_variation_add_grad(prm, g_ref, 0.3, 0.2, 0.1, dense)
+    ret = tv.total_variation_add_grad(prm.cuda(), g_gpu, 0.3, 0.2, 0.1, dense)
+    assert ret is None
+    np.testing.assert_array_equal(g_ref.numpy(), g_gpu.cpu().numpy())
+    if not dense:
+        assert torch.all(g_gpu.cpu()[torch.from_numpy(g) == 0] == 0)
+
+
+def test_cumdist_thres_bit_exact(mods):
+    ub = mods[2]
+    R, K = 301, 667
+    dist = torch.from_numpy(synth.uniform(70, R * K, 0.0, 0.02).reshape(R, K))
+    ref = ref_ops.cumdist_thres(dist, 0.0114)
+    gpu = ub.cumdist_thres(dist.cuda(), 0.0114)
+    np.testing.assert_array_equal(ref.numpy(), gpu.cpu().numpy())
+
+
+@pytest.mark.parametrize("n", [5, 4096, 1_000_003])
+def test_adam_family_bit_exact(mods, n):
+    ad = mods[3]
+    for mode in (0, 1, 2):
+        p = torch.from_numpy(synth.normal(80, n))
+        g = synth.normal(81, n)
+        g[np.abs(g) < 1.0] = 0
+        g = torch.from_numpy(g)
+        m = torch.from_numpy(synth.normal(82, n, 0, 0.1))
+        v = torch.from_numpy(synth.uniform(83, n, 0, 0.01))
+        lr_ = torch.from_numpy(synth.uniform(84, n))
+        ref = [p.clone(), m.clone(), v.clone()]
+        gpu = [p.cuda(), m.cuda(), v.cuda()]
+        args = (3, 0.9, 0.99, 0.1, 1e-8)
+        if mode == 0:
+            ref_ops.adam_upd(ref[0], g, ref[1], ref[2], *args)
+            ad.adam_upd(gpu[0], g.cuda(), gpu[1], gpu[2], *args)
+        elif mode == 1:
+            ref_ops.masked_adam_upd(ref[0], g, ref[1], ref[2], *args)
+            ad.masked_adam_upd(gpu[0], g.cuda(), gpu[1], gpu[2], *args)
+        else:
+            ref_ops.adam_upd_with_perlr(ref[0], g, ref[1], ref[2], lr_, *args)
+            ad.adam_upd_with_perlr(gpu[0], g.cuda(), gpu[1], gpu[2], lr_.cuda(), *args)
+        for a, b in zip(ref, gpu):
+            np.testing.assert_array_equal(a.numpy(), b.cpu().numpy(), err_msg="mode %d" % mode)
+
+
+def test_adam_unaligned_views(mods):
+    """Views starting at a 4-byte offset take the scalar path; result identical to the vector path."""
+    ad = mods[3]
+    n = 1001
+    vals = [torch.from_numpy(synth.normal(90 + i, n)) for i in range(4)]
+    vals[3] = vals[3].abs() * 0.01
+    vals[1][::3] = 0
+    al = [v.cuda().clone() for v in vals]
+    un = []
+    for v in vals:
+        buf = torch.empty(n + 1, device="cuda")
+        buf[1:] = v.cuda()
+        un.append(buf[1:])
+    for t in un:
+        assert t.data_ptr() % 16 != 0
+    ad.masked_adam_upd(al[0], al[1], al[2], al[3], 2, 0.9, 0.99, 0.1, 1e-8)
+    ad.masked_adam_upd(un[0], un[1], un[2], un[3], 2, 0.9, 0.99, 0.1, 1e-8)
+    for a, b in zip(al, un):
+        assert torch.equal(a, b)
+
+
+def test_error_behaviour(mods):
+    ru = mods[0]
+    with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
+        ru.raw2alpha(torch.zeros(4), 0.0, 0.5)
+    x = torch.zeros(8, 3, device="cuda")[:, :2]
+    with pytest.raises(RuntimeError, match="must be contiguous"):
+        ru.infer_ray_start_dir(x, x, torch.zeros(8, device="cuda"))
+    with pytest.raises(RuntimeError, match="float32"):
+        ru.raw2alpha(torch.zeros(4, dtype=torch.float64, device="cuda"), 0.0, 0.5)
+
+
+def test_autograd_and_masked_adam_match_reference_golden(mods, golden_dir):
+    """Host logic (autograd wiring, per-parameter optimizer dispatch) against vectors produced by the
+    reference's own dvgo.Raw2Alpha / Alphas2Weights / masked_adam.MaskedAdam classes."""
+    from unboundednerfpytorch_amd.masked_adam import MaskedAdam
+    from unboundednerfpytorch_amd.ops import Alphas2Weights, Raw2Alpha, Raw2Alpha_nonuni
+    gold = np.load(os.path.join(golden_dir, "autograd_adam.npz"))
+    n, R = 300, 17
+    dens = torch.from_numpy(synth.normal(61, n, 5.0, 6.0)).cuda().requires_grad_(True)
+    shift = torch.tensor([-9.21024]).cuda()
+    alpha = Raw2Alpha.apply(dens, shift, 0.5)
+    ray_id = torch.from_numpy(gold["a2w_ray_id"]).cuda()
+    w, last = Alphas2Weights.apply(alpha, ray_id, R)
+    gw = torch.from_numpy(synth.normal(63, n)).cuda()
+    gl = torch.from_numpy(synth.normal(64, R)).cuda()
+    (w * gw).sum().add((last * gl).sum()).backward()
+    np.testing.assert_allclose(alpha.detach().cpu().numpy(), gold["a2w_alpha"], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(w.detach().cpu().numpy(), gold["a2w_w"], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(last.detach().cpu().numpy(), gold["a2w_last"], rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(dens.grad.cpu().numpy(), gold["a2w_grad_density"], rtol=2e-4, atol=1e-6)
+    dens2 = torch.from_numpy(synth.normal(65, n, 5.0, 6.0)).cuda().requires_grad_(True)
+    itv = torch.from_numpy(synth.uniform(66, n, 0.1, 1.0)).cuda()
+    a2 = Raw2Alpha_nonuni.apply(dens2, shift, itv)
+    (a2 * gw).sum().backward()
+    np.testing.assert_allclose(a2.detach().cpu().numpy(), gold["nonuni_alpha"], rtol=0, atol=3e-7)
+    np.testing.assert_allclose(dens2.grad.cpu().numpy(), gold["nonuni_grad"], rtol=2e-5, atol=1e-7)
+
+    shape = (1, 2, 4, 5, 6)
+    p_grid = torch.nn.Parameter(torch.from_numpy(synth.normal(70, 240).reshape(shape)).cuda())
+    p_dense = torch.nn.Parameter(torch.from_numpy(synth.normal(71, 33)).cuda())
+    opt = MaskedAdam([{'params': [p_grid], 'lr': 0.1, 'skip_zero_grad': True},
+                      {'params': [p_dense], 'lr': 1e-3, 'skip_zero_grad': False}])
+    for step in range(3):
+        g = synth.normal(80 + step, 240).reshape(shape)
+        g[np.abs(g) < 0.8] = 0.0
+        p_grid.grad = torch.from_numpy(g).cuda()
+        p_dense.grad = torch.from_numpy(synth.normal(90 + step, 33)).cuda()
+        if step == 2:
+            opt.set_pervoxel_lr(torch.from_numpy(synth.uniform(95, 240, 0.0, 9.0).reshape(shape)).floor().cuda())
+        opt.step()
+    # Adam arithmetic is IEEE-only -> bit-exact against the reference run
+    np.testing.assert_array_equal(p_grid.detach().cpu().numpy(), gold["adam_grid"])
+    np.testing.assert_array_equal(p_dense.detach().cpu().numpy(), gold["adam_dense"])
+    np.testing.assert_array_equal(opt.state[p_grid]['exp_avg'].cpu().numpy(), gold["adam_grid_m"])
+    np.testing.assert_array_equal(opt.state[p_grid]['exp_avg_sq'].cpu().numpy(), gold["adam_grid_v"])

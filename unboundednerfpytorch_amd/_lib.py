@@ -1,0 +1,125 @@
+"""ctypes binding of libugrid_hip.so (C ABI declared in include/ugrid_hip.h).
+
+The shared library is the product: if it is missing or fails to load, importing any op module of
+this package raises -- there is NO CPU / eager fallback (oracle/ is test infrastructure and is never
+imported from here).
+
+torch is imported first on purpose: libugrid_hip.so needs `libamdhip64.so.7`; PyTorch-ROCm ships its
+own copy with that SONAME, and loading it first makes the dynamic loader bind our library to the
+SAME HIP runtime instance torch uses, so torch's device pointers and streams are valid in our launches.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libugrid_hip.so")
+ABI_VERSION = 1
+
+_c = ctypes
+_P = _c.c_void_p
+_F = _c.c_float
+_I = _c.c_int
+_L = _c.c_int64
+
+
+class RenderParams(_c.Structure):
+    """Mirror of `ugrid_render_params` (include/ugrid_hip.h)."""
+    _fields_ = [
+        ("n_rays", _c.c_int64),
+        ("n_samples", _c.c_int32), ("freq_num", _c.c_int32),
+        ("grid_x", _c.c_int32), ("grid_y", _c.c_int32), ("grid_z", _c.c_int32),
+        ("k0_channels", _c.c_int32), ("mlp_in", _c.c_int32), ("mlp_width", _c.c_int32),
+        ("viewbase_pe", _c.c_int32), ("norm_l2", _c.c_int32),
+        ("scene_center", _c.c_float * 3), ("scene_radius", _c.c_float * 3),
+        ("xyz_min", _c.c_float * 3), ("xyz_max", _c.c_float * 3),
+        ("bg_len", _c.c_double),
+        ("act_shift", _c.c_float), ("interval", _c.c_float), ("thres", _c.c_float),
+    ]
+
+
+# name -> (restype, argtypes); every int-returning entry point returns a hipError_t
+_SIGNATURES = {
+    "ugrid_abi_version": (_I, []),
+    "ugrid_target_arch": (_c.c_char_p, []),
+    "ugrid_infer_t_minmax": (_I, [_P, _P, _P, _P, _F, _F, _L, _P, _P, _P]),
+    "ugrid_infer_n_samples": (_I, [_P, _P, _P, _F, _L, _P, _P]),
+    "ugrid_infer_ray_start_dir": (_I, [_P, _P, _P, _L, _P, _P, _P]),
+    "ugrid_scan_ws_bytes": (_L, [_L]),
+    "ugrid_sample_pts_on_rays_count": (_I, [_P, _P, _P, _P, _F, _F, _F, _L, _P, _P, _P, _P, _P, _P, _P]),
+    "ugrid_sample_pts_on_rays_fill": (_I, [_P, _P, _P, _P, _P, _P, _F, _L, _L, _P, _P, _P, _P, _P]),
+    "ugrid_sample_ndc_pts_on_rays": (_I, [_P, _P, _P, _P, _L, _L, _P, _P, _P]),
+    "ugrid_sample_bg_pts_on_rays": (_I, [_P, _P, _P, _F, _L, _L, _P, _P]),
+    "ugrid_maskcache_lookup": (_I, [_P, _P, _P, _P, _L, _L, _L, _L, _P, _P]),
+    "ugrid_raw2alpha": (_I, [_P, _F, _F, _P, _L, _P, _P, _P]),
+    "ugrid_raw2alpha_backward": (_I, [_P, _P, _F, _P, _L, _P, _P]),
+    "ugrid_alpha2weight": (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _P, _P]),
+    "ugrid_alpha2weight_backward": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P]),
+    "ugrid_total_variation_add_grad": (_I, [_P, _P, _F, _F, _F, _I, _L, _L, _L, _L, _P]),
+    "ugrid_cumdist_thres": (_I, [_P, _F, _L, _L, _P, _P]),
+    "ugrid_adam_upd": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _I, _P]),
+    "ugrid_grid_query": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _L, _P, _P]),
+    "ugrid_brick_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
+    "ugrid_pack_bricks": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
+    "ugrid_render_ws_bytes": (_L, [_L, _c.c_int32]),
+    "ugrid_render_march": (_I, [_c.POINTER(RenderParams), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ugrid_render_shade": (_I, [_c.POINTER(RenderParams), _P, _P, _P, _P, _P, _P]),
+    "ugrid_mlp_packed_bytes": (_L, [_c.c_int32, _c.c_int32]),
+    "ugrid_pack_mlp": (_I, [_P, _P, _P, _P, _P, _P, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P]),
+    "ugrid_render_stats": (_I, [_P, _L, _c.c_int32, _P, _P]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes handle.  Raises if the HIP library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libugrid_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or unboundednerfpytorch_amd/csrc/build.sh.  There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    if lib.ugrid_abi_version() != ABI_VERSION:
+        raise ImportError("libugrid_hip.so ABI %d != expected %d" % (lib.ugrid_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(err, what):
+    if err != 0:
+        raise RuntimeError("%s failed: hipError_t %d" % (what, err))
+
+
+def ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def stream_of(t):
+    """Current torch stream of t's device as a hipStream_t value."""
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def require_cuda(*named):
+    """Mirror of the reference's CHECK_INPUT (render_utils.cpp:46-48): RuntimeError on host or
+    non-contiguous tensors, with the same wording."""
+    for name, t in named:
+        if not t.is_cuda:
+            raise RuntimeError("%s must be a CUDA tensor" % name)
+        if not t.is_contiguous():
+            raise RuntimeError("%s must be contiguous" % name)
+
+
+def require_f32(*named):
+    for name, t in named:
+        if t.dtype != torch.float32:
+            raise RuntimeError("%s: only float32 is implemented by the MI355X path (got %s); the reference "
+                               "also dispatches double, which its hot path never uses" % (name, t.dtype))

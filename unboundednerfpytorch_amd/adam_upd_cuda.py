@@ -1,0 +1,31 @@
+"""MI355X drop-in for `adam_upd_cuda` (/root/reference/FourierGrid/cuda/adam_upd.cpp:79-86).
+All three functions mutate param / exp_avg / exp_avg_sq in place and return None."""
+import torch
+
+from . import _lib
+
+_L = _lib.load()
+
+
+def _run(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps, mode, what):
+    named = [("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)]
+    if perlr is not None:
+        named.append(("perlr", perlr))
+    _lib.require_cuda(*named)
+    _lib.require_f32(*named)
+    with torch.cuda.device(param.device):
+        _lib.check(_L.ugrid_adam_upd(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
+                                     _lib.ptr(perlr), param.numel(), int(step), float(beta1), float(beta2),
+                                     float(lr), float(eps), mode, _lib.stream_of(param)), what)
+
+
+def adam_upd(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2, lr, eps):
+    _run(param, grad, exp_avg, exp_avg_sq, None, step, beta1, beta2, lr, eps, 0, "adam_upd")
+
+
+def masked_adam_upd(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2, lr, eps):
+    _run(param, grad, exp_avg, exp_avg_sq, None, step, beta1, beta2, lr, eps, 1, "masked_adam_upd")
+
+
+def adam_upd_with_perlr(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps):
+    _run(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps, 2, "adam_upd_with_perlr")

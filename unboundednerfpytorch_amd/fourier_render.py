@@ -1,0 +1,261 @@
+"""FourierGridRenderer: the inference forward of the reference's FourierGridModel
+(/root/reference/FourierGrid/FourierGrid_model.py:554-672) as two fused HIP kernels.
+
+Host-side mirror of the reference interface: `forward(rays_o, rays_d, viewdirs, **render_kwargs)`
+takes the same arguments (`stepsize`, `render_depth`, ...) and returns a dict with the keys the
+render program consumes -- `rgb_marched [R,3]`, `depth [R]`, `alphainv_last [R]`
+(run_render.py:46).  The training-only per-sample keys (`weights`, `raw_rgb`, `ray_id`, ...) are not
+materialised by the fused path; training goes through the drop-in ops (ops.py) instead.
+
+Device data owned by the renderer (all fp32):
+  density bricks  [P*(G-1)^3][8]            32 B per trilinear cell
+  k0 bricks       [P*(G-1)^3][2][8][C/2]    384 B per cell at C = 12
+  packed rgbnet   A1 | A2 | biases | W3     (MFMA A-operand order, 89 KB)
+  t / s tables    [S]
+  work list       worst-case survivor list per 64-ray tile (ugrid_render_ws_bytes)
+"""
+import math
+
+import torch
+
+from . import _lib
+
+_L = _lib.load()
+_p = _lib.ptr
+
+
+def sample_table(world_len, stepsize, bg_len, t_boundary=1.5):
+    """Sample distances t [S] and s = 1 - 1/(1+t), computed with the same torch ops as the reference
+    (FourierGrid_model.py:524-532,649) on the host; shared by every ray."""
+    n_inner = int(2 / (2 + 2 * bg_len) * world_len / stepsize) + 1
+    b_in = torch.linspace(0, t_boundary, n_inner + 1)
+    b_out = t_boundary / torch.linspace(1, 1 / 128, n_inner + 1)
+    t = torch.cat([(b_in[1:] + b_in[:-1]) * 0.5, (b_out[1:] + b_out[:-1]) * 0.5])
+    s = 1 - 1 / (1 + t)
+    return t, s
+
+
+class FourierGridRenderer:
+    """Fused render of a trained FourierGridModel.
+
+    state: dict with
+      density_grid [P,1,G,G,G], k0_grid [P,C,G,G,G] (or [1,3,G,G,G] when there is no rgbnet),
+      rgbnet_weights / rgbnet_biases: lists of 3 nn.Linear tensors (or empty),
+      scene_center[3], scene_radius[3], xyz_min[3], xyz_max[3] (contracted bounds, fp32 tensors),
+      bg_len, fourier_freq_num, viewbase_pe, act_shift, voxel_size_ratio, fast_color_thres,
+      contracted_norm ('inf' | 'l2'), world_len.
+    """
+
+    def __init__(self, state, device, max_ws_bytes=16 << 30):
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("FourierGridRenderer needs a HIP device (no CPU path)")
+        self.device = dev
+        self.max_ws_bytes = int(max_ws_bytes)
+        dg = state["density_grid"].to(dev, torch.float32).contiguous()
+        kg = state["k0_grid"].to(dev, torch.float32).contiguous()
+        self.F = int(state["fourier_freq_num"])
+        P = 1 + 2 * self.F
+        if dg.shape[0] != P or dg.shape[1] != 1:
+            raise RuntimeError("density_grid must be [1+2F, 1, X, Y, Z]")
+        self.G = tuple(int(x) for x in dg.shape[2:])
+        if tuple(kg.shape[2:]) != self.G:
+            raise RuntimeError("density and k0 grids must share a resolution in the fused path")
+        self.has_mlp = len(state["rgbnet_weights"]) > 0
+        self.C = int(kg.shape[1])
+        self.pe = int(state["viewbase_pe"])
+        self.bg_len = float(state["bg_len"])
+        self.world_len = int(state["world_len"])
+        self.thres = float(state["fast_color_thres"])
+        self.act_shift = float(state["act_shift"])
+        self.voxel_size_ratio = float(state["voxel_size_ratio"])
+        self.norm_l2 = {"inf": 0, "l2": 1}[state.get("contracted_norm", "inf")]
+        self._vec = {k: [float(v) for v in state[k]] for k in ("scene_center", "scene_radius", "xyz_min", "xyz_max")}
+        if self.thres <= 0:
+            raise RuntimeError("fast_color_thres must be > 0 (the reference forward is not usable at 0 either, "
+                               "FourierGrid_model.py:600-614)")
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            X, Y, Z = self.G
+            self.density_bricks = torch.empty(_L.ugrid_brick_bytes(P, 1, X, Y, Z, 0) // 4, dtype=torch.float32, device=dev)
+            _lib.check(_L.ugrid_pack_bricks(_p(dg), P, 1, X, Y, Z, 0, _p(self.density_bricks), st), "pack density")
+            if self.has_mlp:
+                if kg.shape[0] != P:
+                    raise RuntimeError("k0_grid must have 1+2F levels when an rgbnet is present")
+                self.k0_bricks = torch.empty(_L.ugrid_brick_bytes(P, self.C, X, Y, Z, 0) // 4, dtype=torch.float32, device=dev)
+                _lib.check(_L.ugrid_pack_bricks(_p(kg), P, self.C, X, Y, Z, 0, _p(self.k0_bricks), st), "pack k0")
+                ws_, bs_ = state["rgbnet_weights"], state["rgbnet_biases"]
+                if len(ws_) != 3 or ws_[1].shape != (128, 128) or ws_[2].shape[0] != 3:
+                    raise RuntimeError("fused shade supports rgbnet_depth=3, rgbnet_width=128 "
+                                       "(configs/default.py:104-105)")
+                self.mlp_in = int(ws_[0].shape[1])
+                if self.mlp_in != self.C + 3 + 6 * self.pe:
+                    raise RuntimeError("rgbnet input width must be C + 3 + 6*viewbase_pe")
+                t = [x.to(dev, torch.float32).contiguous() for x in (ws_[0], bs_[0], ws_[1], bs_[1], ws_[2], bs_[2])]
+                self.mlp_packed = torch.empty(_L.ugrid_mlp_packed_bytes(self.C, self.pe) // 4, dtype=torch.float32, device=dev)
+                _lib.check(_L.ugrid_pack_mlp(*[_p(x) for x in t], self.C, self.pe, 128, _p(self.mlp_packed), st), "pack mlp")
+            else:
+                if kg.shape[0] != 1 or self.C != 3:
+                    raise RuntimeError("without an rgbnet k0 must be a single-level 3-channel grid")
+                self.mlp_in = 0
+                self.k0_bricks = torch.empty(_L.ugrid_brick_bytes(1, 3, X, Y, Z, 1) // 4, dtype=torch.float32, device=dev)
+                _lib.check(_L.ugrid_pack_bricks(_p(kg), 1, 3, X, Y, Z, 1, _p(self.k0_bricks), st), "pack k0")
+                self.mlp_packed = None
+            torch.cuda.current_stream(dev).synchronize()  # dg/kg temporaries may now be freed
+        self._tables = {}
+        self._ws = None
+        self.last_timing = None
+
+    # -- helpers ---------------------------------------------------------------------------------
+    def tables(self, stepsize):
+        key = float(stepsize)
+        if key not in self._tables:
+            t, s = sample_table(self.world_len, key, self.bg_len)
+            self._tables[key] = (t.to(self.device), s.to(self.device), int(t.numel()))
+        return self._tables[key]
+
+    def interval(self, stepsize):
+        # python float * 0-d fp32 tensor -> fp32 product (FourierGrid_model.py:572)
+        return float(torch.tensor(self.voxel_size_ratio, dtype=torch.float32) * stepsize)
+
+    def _params(self, n_rays, S, stepsize):
+        p = _lib.RenderParams()
+        p.n_rays, p.n_samples, p.freq_num = n_rays, S, self.F
+        p.grid_x, p.grid_y, p.grid_z = self.G
+        p.k0_channels, p.mlp_in, p.mlp_width = self.C, self.mlp_in, 128
+        p.viewbase_pe, p.norm_l2 = self.pe, self.norm_l2
+        for k in ("scene_center", "scene_radius", "xyz_min", "xyz_max"):
+            for i in range(3):
+                getattr(p, k)[i] = self._vec[k][i]
+        p.bg_len = self.bg_len
+        p.act_shift, p.interval, p.thres = self.act_shift, self.interval(stepsize), self.thres
+        return p
+
+    def rays_per_chunk(self, S):
+        per_ray = 17 * S + 8
+        n = max(64, (self.max_ws_bytes // per_ray) // 64 * 64)
+        return n
+
+    def _workspace(self, n_rays, S):
+        need = _L.ugrid_render_ws_bytes(n_rays, S)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = None
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # -- the reference-shaped entry point ----------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, rays_o, rays_d, viewdirs, global_step=None, is_train=False, **render_kwargs):
+        """Volume rendering of R rays.  render_kwargs: stepsize (required), render_depth (depth is always
+        produced by the fused kernel; the key is returned when requested, like the reference)."""
+        if is_train or global_step is not None:
+            raise RuntimeError("the fused renderer is inference-only; train through unboundednerfpytorch_amd.ops")
+        assert rays_o.dim() == 2 and rays_o.shape[-1] == 3, "Only support point queries in [N, 3] format"
+        _lib.require_cuda(("rays_o", rays_o), ("rays_d", rays_d), ("viewdirs", viewdirs))
+        _lib.require_f32(("rays_o", rays_o), ("rays_d", rays_d), ("viewdirs", viewdirs))
+        stepsize = render_kwargs["stepsize"]
+        t_tab, s_tab, S = self.tables(stepsize)
+        R = rays_o.shape[0]
+        dev = self.device
+        rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
+        depth = torch.empty(R, dtype=torch.float32, device=dev)
+        last = torch.empty(R, dtype=torch.float32, device=dev)
+        chunk = self.rays_per_chunk(S)
+        timing = render_kwargs.get("timing")  # optional list collecting (march_ev0, march_ev1, shade_ev1)
+        with torch.cuda.device(dev):
+            st = torch.cuda.current_stream(dev).cuda_stream
+            ws = self._workspace(min(R, chunk), S)
+            for b in range(0, R, chunk):
+                e = min(R, b + chunk)
+                n = e - b
+                p = self._params(n, S, stepsize)
+                o_, d_, v_ = rays_o[b:e], rays_d[b:e], viewdirs[b:e]
+                if timing is not None:
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                    ev[0].record()
+                _lib.check(_L.ugrid_render_march(p, _p(o_), _p(d_), _p(t_tab), _p(s_tab), _p(self.density_bricks),
+                                                 _p(last[b:e]), _p(depth[b:e]), _p(ws), st), "render_march")
+                if timing is not None:
+                    ev[1].record()
+                _lib.check(_L.ugrid_render_shade(p, _p(v_), _p(self.k0_bricks), _p(self.mlp_packed), _p(ws),
+                                                 _p(rgb[b:e]), st), "render_shade")
+                if timing is not None:
+                    ev[2].record()
+                    timing.append((ev, n))
+        out = {"alphainv_last": last, "rgb_marched": rgb, "n_max": S}
+        if render_kwargs.get("render_depth", False):
+            out["depth"] = depth
+        return out
+
+    __call__ = forward
+
+    @torch.no_grad()
+    def survivors_of_last_chunk(self, n_rays, S):
+        """Number of surviving samples M in the work list of the most recent march (host sync)."""
+        out = torch.zeros(1, dtype=torch.int64, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(_L.ugrid_render_stats(_p(self._ws), n_rays, S, _p(out),
+                                             torch.cuda.current_stream(self.device).cuda_stream), "render_stats")
+        return int(out.item())
+
+    # -- constructors ------------------------------------------------------------------------------
+    @classmethod
+    def from_reference_checkpoint(cls, ckpt, device, **kw):
+        """ckpt: the dict the reference saves (`model_kwargs`, `model_state_dict`;
+        FourierGrid_ckpt_manager.py:44-51).  Derived quantities are recomputed with the reference's own
+        formulas (FourierGrid_model.py:100-122,173,335-349)."""
+        mk, sd = ckpt["model_kwargs"], ckpt["model_state_dict"]
+        bg_len = float(mk.get("bg_len", 0.2))
+        lo = torch.Tensor([-1, -1, -1]) - bg_len
+        hi = torch.Tensor([1, 1, 1]) + bg_len
+        vol = (hi - lo).prod()
+        vs = (vol / mk["num_voxels_density"]).pow(1 / 3)
+        vs_base = (vol / mk["num_voxels_base_density"]).pow(1 / 3)
+        world = ((hi - lo) / vs).long()
+        ws_, bs_ = [], []
+        if any(k.startswith("rgbnet.") for k in sd):
+            names = sorted({k.rsplit(".", 1)[0] for k in sd if k.startswith("rgbnet.")},
+                           key=lambda n: [int(x) for x in n.split(".")[1:]])
+            ws_ = [sd[n + ".weight"] for n in names]
+            bs_ = [sd[n + ".bias"] for n in names]
+        state = {
+            "density_grid": sd["density.grid"], "k0_grid": sd["k0.grid"],
+            "rgbnet_weights": ws_, "rgbnet_biases": bs_,
+            "scene_center": sd["scene_center"], "scene_radius": sd["scene_radius"],
+            "xyz_min": sd.get("xyz_min", lo), "xyz_max": sd.get("xyz_max", hi),
+            "bg_len": bg_len, "fourier_freq_num": int(mk.get("fourier_freq_num", 5)),
+            "viewbase_pe": int(mk.get("viewbase_pe", 4)),
+            "act_shift": float(sd["act_shift"]) if "act_shift" in sd else math.log(1 / (1 - mk["alpha_init"]) - 1),
+            "voxel_size_ratio": float(vs / vs_base),
+            "fast_color_thres": mk.get("fast_color_thres", 0),
+            "contracted_norm": mk.get("contracted_norm", "inf"),
+            "world_len": int(world[0]),
+        }
+        if isinstance(state["fast_color_thres"], dict):
+            state["fast_color_thres"] = state["fast_color_thres"][max(state["fast_color_thres"])]
+        return cls(state, device, **kw)
+
+
+def get_rays_of_a_view(H, W, K, c2w, inverse_y=False, flip_x=False, flip_y=False, mode="center"):
+    """Pinhole rays of one view, pixel centres (+0.5): rays_o, rays_d, viewdirs, each [H,W,3], on c2w's
+    device.  Same conventions as the reference (dvgo.py:493-521,554-559; no NDC)."""
+    dev = c2w.device
+    K = torch.as_tensor(K, dtype=torch.float32, device=dev)
+    jj, ii = torch.meshgrid(torch.linspace(0, H - 1, H, device=dev), torch.linspace(0, W - 1, W, device=dev),
+                            indexing="ij")
+    if mode == "center":
+        ii, jj = ii + 0.5, jj + 0.5
+    elif mode != "lefttop":
+        raise NotImplementedError(mode)
+    if flip_x:
+        ii = ii.flip((1,))
+    if flip_y:
+        jj = jj.flip((0,))
+    if inverse_y:
+        dirs = torch.stack([(ii - K[0][2]) / K[0][0], (jj - K[1][2]) / K[1][1], torch.ones_like(ii)], -1)
+    else:
+        dirs = torch.stack([(ii - K[0][2]) / K[0][0], -(jj - K[1][2]) / K[1][1], -torch.ones_like(ii)], -1)
+    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
+    rays_o = c2w[:3, 3].expand(rays_d.shape)
+    viewdirs = rays_d / rays_d.norm(dim=-1, keepdim=True)
+    return rays_o.contiguous(), rays_d.contiguous(), viewdirs.contiguous()

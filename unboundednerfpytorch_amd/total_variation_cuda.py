@@ -1,0 +1,20 @@
+"""MI355X drop-in for `total_variation_cuda` (/root/reference/FourierGrid/cuda/total_variation.cpp:23)."""
+import torch
+
+from . import _lib
+
+_L = _lib.load()
+
+
+def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
+    """grad += TV gradient of param, in place; sizes from param.size(2..4) like the reference
+    (total_variation_kernel.cu:39-41), so [P,C,X,Y,Z] grids work.  Returns None."""
+    _lib.require_cuda(("param", param), ("grad", grad))
+    _lib.require_f32(("param", param), ("grad", grad))
+    if param.dim() != 5 or param.shape != grad.shape:
+        raise RuntimeError("param/grad must be 5-D tensors of equal shape")
+    with torch.cuda.device(param.device):
+        _lib.check(_L.ugrid_total_variation_add_grad(_lib.ptr(param), _lib.ptr(grad), float(wx), float(wy), float(wz),
+                                                     1 if dense_mode else 0, param.size(2), param.size(3),
+                                                     param.size(4), param.numel(), _lib.stream_of(param)),
+                   "total_variation_add_grad")
