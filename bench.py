@@ -208,7 +208,9 @@ def cpu_baseline(cpu_state, ro, rd, vd, gpu_out, stepsize, S, n_chunks):
     """The oracle (CPU restatement of the reference's pure-PyTorch F.grid_sample forward, kind='port') timed on
     this box's host cores on a bounded sample of the same frame: n_chunks x 8192 rays spread over the image."""
     from oracle import model_oracle
-    cores = os.cpu_count() or 1
+    # torch's intra-op threading stops scaling early on this op mix: on the 256-core GPU-box host 8 threads
+    # gave 8.6 Msamples/s, 64 -> 5.4, 256 -> 0.13 (tools/cpu_threads_sweep.py); use the fastest setting.
+    cores = min(8, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     R = ro.shape[0]
     chunk = 8192

