@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--grid", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], help="key=value speed knob (ugrid_tune), repeatable")
     ap.add_argument("--cpu-chunks", type=int, default=4, help="8192-ray chunks timed for the CPU baseline")
     return ap.parse_args()
 
@@ -104,7 +105,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer, get_rays_of_a_view
+    from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer, get_rays_of_a_view, tune
+    for kv in args.tune:
+        k, v = kv.split("=")
+        tune(k, int(v))
 
     H, W, G = args.height, args.width, args.grid
     stepsize = 1.31 * G / 200.0 if G != 200 else 1.31

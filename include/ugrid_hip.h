@@ -196,6 +196,9 @@ int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1, const floa
                    const float *w2, const float *b2, int32_t k0_channels, int32_t viewbase_pe,
                    int32_t width, float *packed, ugrid_stream_t stream);
 
+/* Tuning knobs (speed only, never results).  "shade_waves": 8 | 12 waves per shade workgroup. */
+int ugrid_tune(const char *key, int value);
+
 /* Total survivors of the last march on this ws -> *d_stats (device int64). */
 int ugrid_render_stats(void *ws, int64_t n_rays, int32_t n_samples, int64_t *d_stats,
                        ugrid_stream_t stream);

@@ -23,8 +23,11 @@
 // Compiled with -ffp-contract=off: every a*b+c below that must match torch's separate
 // multiply/add is written as such; fmaf is explicit where torch's CPU kernels use FMA.
 #include "ugrid_common.h"
+#include "ugrid_math.h"
+#include <string.h>
 
 #define UG_MAX_F 5  // fourier_freq_num <= 5  (P <= 11 levels)
+
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -243,9 +246,30 @@ struct ug_march_args {
   int32_t S, X, Y, Z;
   float cx, cy, cz, rx, ry, rz;        // scene centre / radius
   float lox, loy, loz, hix, hiy, hiz;  // contracted bounds
+  float ex, ey, ez, irx, iry, irz;     // extent hi-lo and RN(1/extent) per axis (host computed)
   float B, A;                          // 1+bg_len, bg_len (as fp32)
   float shift, interval, thres;
 };
+
+// one density level: in-range cell set-up + one 32-byte brick + trilinear in grid_sample's order.
+// `lvl` is the (wave-uniform) base of this level's bricks; the per-lane offset stays 32-bit.
+__device__ __forceinline__ float ug_density_level(const char *__restrict__ lvl, float cx, float cy, float cz,
+                                                  int X, int Y, int Z) {
+  const ug_axis_fast ax = ug_axis_inrange(cx, X), ay = ug_axis_inrange(cy, Y), az = ug_axis_inrange(cz, Z);
+  const unsigned rec = ((unsigned)ax.cell * (unsigned)(Y - 1) + (unsigned)ay.cell) * (unsigned)(Z - 1) + (unsigned)az.cell;
+  const float4 *b = (const float4 *)(lvl + (size_t)(rec * 32u));
+  const float4 v0 = b[0], v1 = b[1];
+  const float w00 = az.wlo * ay.wlo, w01 = az.whi * ay.wlo, w10 = az.wlo * ay.whi, w11 = az.whi * ay.whi;
+  float acc = v0.x * (w00 * ax.wlo);
+  acc += v0.y * (w01 * ax.wlo);
+  acc += v0.z * (w10 * ax.wlo);
+  acc += v0.w * (w11 * ax.wlo);
+  acc += v1.x * (w00 * ax.whi);
+  acc += v1.y * (w01 * ax.whi);
+  acc += v1.z * (w10 * ax.whi);
+  acc += v1.w * (w11 * ax.whi);
+  return acc;
+}
 
 template <int F, bool L2>
 __global__ void __launch_bounds__(256)
@@ -271,8 +295,8 @@ k_march(ug_march_args a, const float *__restrict__ rays_o, const float *__restri
     dx = rdx / dn; dy = rdy / dn; dz = rdz / dn;
   }
 
-  const int64_t cells = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1);
-  const float4 *__restrict__ bk = (const float4 *)bricks;  // 2 x float4 per record
+  const size_t lvl_bytes = (size_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1) * 32;  // < 4 GiB per level (G <= 512)
+  const char *__restrict__ bkb = (const char *)bricks;
   float4 *__restrict__ ent = ws.ent + tile * ws.cap;
   uint8_t *__restrict__ slot = ws.slot + tile * ws.cap;
 
@@ -284,32 +308,36 @@ k_march(ug_march_args a, const float *__restrict__ rays_o, const float *__restri
     if (__ballot(!done) == 0ull) break;  // every ray of this wave has terminated
     bool surv = false;
     float w = 0.f;
-    ug_vec3 p = {0.f, 0.f, 0.f};
+    float px = 0.f, py = 0.f, pz = 0.f;
     if (!done) {
       const float t = t_table[j];
-      p.x = ox + dx * t; p.y = oy + dy * t; p.z = oz + dz * t;
-      p = ug_contract<L2>(p, a.B, a.A);
-      const float ux = ug_unorm(p.x, a.lox, a.hix), uy = ug_unorm(p.y, a.loy, a.hiy),
-                  uz = ug_unorm(p.z, a.loz, a.hiz);
-      const ug_levels<F> L = ug_pe<F>(ux, uy, uz);
-      float dens = 0.f;
+      px = ox + dx * t; py = oy + dy * t; pz = oz + dz * t;
+      // contraction p/|p| * (B - A/|p|) outside the unit cube / ball (FourierGrid_model.py:534-548)
+      const float nrm = L2 ? ug_norm3_torch(px, py, pz) : fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz)));
+      if (!(nrm <= 1.0f)) {
+        const float rn = ug_rcp_refined(nrm);
+        const float sc = a.B - ug_div_r(a.A, nrm, rn);
+        px = ug_div_r(px, nrm, rn) * sc;
+        py = ug_div_r(py, nrm, rn) * sc;
+        pz = ug_div_r(pz, nrm, rn) * sc;
+      }
+      // ((p - lo) / (hi - lo)) * 2 - 1
+      const float ux = ug_div_r(px - a.lox, a.ex, a.irx) * 2.f - 1.f;
+      const float uy = ug_div_r(py - a.loy, a.ey, a.iry) * 2.f - 1.f;
+      const float uz = ug_div_r(pz - a.loz, a.ez, a.irz) * 2.f - 1.f;
+      float dens = ug_density_level(bkb, ux, uy, uz, a.X, a.Y, a.Z);
 #pragma unroll
-      for (int l = 0; l < P; ++l) {
-        const ug_cellw cw = ug_cell_setup(L.cx[l], L.cy[l], L.cz[l], a.X, a.Y, a.Z, (int64_t)l * cells);
-        const float4 v0 = bk[cw.rec * 2], v1 = bk[cw.rec * 2 + 1];
-        float acc = v0.x * cw.w[0];
-        acc += v0.y * cw.w[1];
-        acc += v0.z * cw.w[2];
-        acc += v0.w * cw.w[3];
-        acc += v1.x * cw.w[4];
-        acc += v1.y * cw.w[5];
-        acc += v1.z * cw.w[6];
-        acc += v1.w * cw.w[7];
-        dens = (l == 0) ? acc : dens + acc;
+      for (int k = 0; k < F; ++k) {
+        const float f = (float)(1 << k);
+        float sx, cx_, sy, cy_, sz, cz_;
+        ug_sincos(f * ux, &sx, &cx_);
+        ug_sincos(f * uy, &sy, &cy_);
+        ug_sincos(f * uz, &sz, &cz_);
+        dens += ug_density_level(bkb + (size_t)(2 * k + 1) * lvl_bytes, sx, sy, sz, a.X, a.Y, a.Z);
+        dens += ug_density_level(bkb + (size_t)(2 * k + 2) * lvl_bytes, cx_, cy_, cz_, a.X, a.Y, a.Z);
       }
       dens = dens / (float)P;
-      const float e = expf(dens + a.shift);
-      const float alpha = 1 - powf(1 + e, -a.interval);
+      const float alpha = ug_alpha(dens + a.shift, a.interval);
       if (alpha > a.thres) {
         w = T * alpha;
         T = (float)((double)T * (1. - (double)alpha));
@@ -325,7 +353,7 @@ k_march(ug_march_args a, const float *__restrict__ rays_o, const float *__restri
       if (surv) {
         const int idx = nsurv + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
                                                           __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        ent[idx] = make_float4(p.x, p.y, p.z, w);
+        ent[idx] = make_float4(px, py, pz, w);
         slot[idx] = (uint8_t)lane;
       }
       nsurv += __popcll(m);
@@ -411,50 +439,61 @@ struct ug_shade_args {
   int64_t n_rays;
   int32_t X, Y, Z;
   float lox, loy, loz, hix, hiy, hiz;
+  float ex, ey, ez, irx, iry, irz;  // extent hi-lo and RN(1/extent)
 };
 
-// level coordinate computed on the fly (keeps the level loop rolled: no per-level register arrays)
-__device__ __forceinline__ float ug_level_coord(float u, int l) {
-  if (l == 0) return u;
-  const float f = (float)(1 << ((l - 1) >> 1));
-  float s, c;
-  sincosf(f * u, &s, &c);
-  return ((l - 1) & 1) ? c : s;
+// one k0 level for one survivor half: in-range cell set-up + one contiguous (8*CH)-float half-brick,
+// trilinear per channel in grid_sample's corner order; adds into feat[] (first = level 0 initialises).
+template <int CH>
+__device__ __forceinline__ void ug_k0_level(const float *__restrict__ k0b, int h, int64_t level_base, float cx,
+                                            float cy, float cz, int X, int Y, int Z, bool first, float (&feat)[CH]) {
+  const ug_axis_fast ax = ug_axis_inrange(cx, X), ay = ug_axis_inrange(cy, Y), az = ug_axis_inrange(cz, Z);
+  const int64_t rec = level_base + ((int64_t)ax.cell * (Y - 1) + ay.cell) * (Z - 1) + az.cell;
+  const float *rec_p = k0b + (rec * 2 + h) * (8 * CH);
+  float v[8 * CH];
+  if constexpr ((8 * CH) % 4 == 0) {
+    const float4 *r4 = (const float4 *)rec_p;
+#pragma unroll
+    for (int q = 0; q < 2 * CH; ++q) {
+      const float4 t = r4[q];
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8 * CH; ++q) v[q] = rec_p[q];
+  }
+  const float w00 = az.wlo * ay.wlo, w01 = az.whi * ay.wlo, w10 = az.wlo * ay.whi, w11 = az.whi * ay.whi;
+  const float w[8] = {w00 * ax.wlo, w01 * ax.wlo, w10 * ax.wlo, w11 * ax.wlo,
+                      w00 * ax.whi, w01 * ax.whi, w10 * ax.whi, w11 * ax.whi};
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+    float acc = v[ch] * w[0];
+#pragma unroll
+    for (int c = 1; c < 8; ++c) acc += v[c * CH + ch] * w[c];
+    feat[ch] = first ? acc : feat[ch] + acc;
+  }
 }
 
-// k0 half-brick gather for one survivor: CH channels of half h, mean over P levels
+// k0 half-brick gather for one survivor: CH channels of half h, mean over P = 1+2F levels
+// (level order u, sin u, cos u, sin 2u, cos 2u, ... -- FourierGrid_grid.py:70)
 template <int F, int CH>
-__device__ __forceinline__ void ug_k0_gather(const float *__restrict__ k0b, int h, ug_vec3 p,
+__device__ __forceinline__ void ug_k0_gather(const float *__restrict__ k0b, int h, float px, float py, float pz,
                                              const ug_shade_args &a, float (&feat)[CH]) {
   constexpr int P = 2 * F + 1;
-  const float ux = ug_unorm(p.x, a.lox, a.hix), uy = ug_unorm(p.y, a.loy, a.hiy), uz = ug_unorm(p.z, a.loz, a.hiz);
+  const float ux = ug_div_r(px - a.lox, a.ex, a.irx) * 2.f - 1.f;
+  const float uy = ug_div_r(py - a.loy, a.ey, a.iry) * 2.f - 1.f;
+  const float uz = ug_div_r(pz - a.loz, a.ez, a.irz) * 2.f - 1.f;
   const int64_t cells = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1);
-#pragma unroll
-  for (int ch = 0; ch < CH; ++ch) feat[ch] = 0.f;
+  ug_k0_level<CH>(k0b, h, 0, ux, uy, uz, a.X, a.Y, a.Z, true, feat);
 #pragma unroll 1
-  for (int l = 0; l < P; ++l) {
-    const ug_cellw cw = ug_cell_setup(ug_level_coord(ux, l), ug_level_coord(uy, l), ug_level_coord(uz, l),
-                                      a.X, a.Y, a.Z, (int64_t)l * cells);
-    const float *rec = k0b + (cw.rec * 2 + h) * (8 * CH);
-    float v[8 * CH];
-    if constexpr ((8 * CH) % 4 == 0) {
-      const float4 *r4 = (const float4 *)rec;
-#pragma unroll
-      for (int q = 0; q < 2 * CH; ++q) {
-        const float4 t = r4[q];
-        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 8 * CH; ++q) v[q] = rec[q];
-    }
-#pragma unroll
-    for (int ch = 0; ch < CH; ++ch) {
-      float acc = v[ch] * cw.w[0];
-#pragma unroll
-      for (int c = 1; c < 8; ++c) acc += v[c * CH + ch] * cw.w[c];
-      feat[ch] = (l == 0) ? acc : feat[ch] + acc;
-    }
+  for (int k = 0; k < F; ++k) {
+    const float f = (float)(1 << k);
+    float sx, cx_, sy, cy_, sz, cz_;
+    ug_sincos(f * ux, &sx, &cx_);
+    ug_sincos(f * uy, &sy, &cy_);
+    ug_sincos(f * uz, &sz, &cz_);
+    ug_k0_level<CH>(k0b, h, (int64_t)(2 * k + 1) * cells, sx, sy, sz, a.X, a.Y, a.Z, false, feat);
+    ug_k0_level<CH>(k0b, h, (int64_t)(2 * k + 2) * cells, cx_, cy_, cz_, a.X, a.Y, a.Z, false, feat);
   }
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch) feat[ch] = feat[ch] / (float)P;
@@ -463,8 +502,8 @@ __device__ __forceinline__ void ug_k0_gather(const float *__restrict__ k0b, int 
 __device__ __forceinline__ float ug_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
 // C = 2*CH or 2*CH-1 k0 channels, PE view-direction frequencies; rgbnet 128 wide, 3 layers.
-template <int F, int C, int PE>
-__global__ void __launch_bounds__(512, 2)
+template <int F, int C, int PE, int NW>
+__global__ void __launch_bounds__(NW * 64, NW / 4)
 k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
             const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
             int32_t *__restrict__ tile_counter) {
@@ -484,14 +523,24 @@ k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__
   const int lane = ug_lane();
   const int h = lane >> 5, sv = lane & 31;
 
+  // dynamic tile scheduling with XCD affinity: the tile range is cut into 8 contiguous eighths (the same
+  // eighths k_march assigned to the XCDs), one atomic counter each; a workgroup (XCD = blockIdx % 8) drains
+  // its own eighth first, then steals from the others.  Placement only affects speed, never results.
+  const int64_t per = (ws.n_tiles + 7) / 8;
+  const int home = blockIdx.x & 7;
+  int victim = 0;
   for (;;) {
-    // dynamic tile scheduling: one returning atomic per tile, taken by lane 0 and broadcast
-    int tile_i = 0;
-    if (lane == 0) tile_i = atomicAdd(tile_counter, 1);
-    tile_i = __builtin_amdgcn_readfirstlane(tile_i);
-    // walk tiles in the same XCD-contiguous order as the march kernel wrote them
-    const int64_t tile = tile_i;
-    if (tile >= ws.n_tiles) break;
+    int64_t tile = -1;
+    while (victim < 8) {
+      const int q = (home + victim) & 7;
+      int t = 0;
+      if (lane == 0) t = atomicAdd(tile_counter + q, 1);
+      t = __builtin_amdgcn_readfirstlane(t);
+      const int64_t cand = (int64_t)q * per + t;
+      if (t < per && cand < ws.n_tiles) { tile = cand; break; }
+      ++victim;
+    }
+    if (tile < 0) break;
     const int count = ws.count[tile];
     const float4 *__restrict__ ent = ws.ent + tile * ws.cap;
     const uint8_t *__restrict__ slot = ws.slot + tile * ws.cap;
@@ -507,7 +556,7 @@ k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__
       float x[KL];
       {
         float feat[CH];
-        ug_k0_gather<F, CH>(k0b, h, ug_vec3{en.x, en.y, en.z}, a, feat);
+        ug_k0_gather<F, CH>(k0b, h, en.x, en.y, en.z, a, feat);
 #pragma unroll
         for (int s = 0; s < CH; ++s) x[s] = (h * CH + s < C) ? feat[s] : 0.f;
         int64_t ray = tile * UG_WAVE + sl;
@@ -521,7 +570,7 @@ k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__
 #pragma unroll
           for (int k = 0; k < PE; ++k) {
             float s_, c_;
-            sincosf(v * (float)(1 << k), &s_, &c_);
+            ug_sincos(v * (float)(1 << k), &s_, &c_);
             emb[3 + ax * PE + k] = s_;
             emb[3 + 3 * PE + ax * PE + k] = c_;
           }
@@ -615,7 +664,9 @@ k_shade_direct(ug_shade_args a, const float *__restrict__ k0b, ug_ws_view ws,
     float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
     int sl = 0;
     if (ok) { en = ent[e]; sl = slot[e]; }
-    const float ux = ug_unorm(en.x, a.lox, a.hix), uy = ug_unorm(en.y, a.loy, a.hiy), uz = ug_unorm(en.z, a.loz, a.hiz);
+    const float ux = ug_div_r(en.x - a.lox, a.ex, a.irx) * 2.f - 1.f;
+    const float uy = ug_div_r(en.y - a.loy, a.ey, a.iry) * 2.f - 1.f;
+    const float uz = ug_div_r(en.z - a.loz, a.ez, a.irz) * 2.f - 1.f;
     const ug_cellw cw = ug_cell_setup(ux, uy, uz, a.X, a.Y, a.Z, 0);
     const float4 *rec = (const float4 *)(k0b + cw.rec * 32);
     float f0 = 0.f, f1 = 0.f, f2 = 0.f;
@@ -736,6 +787,8 @@ extern "C" int ugrid_render_march(const ugrid_render_params *p, const float *ray
   a.rx = p->scene_radius[0]; a.ry = p->scene_radius[1]; a.rz = p->scene_radius[2];
   a.lox = p->xyz_min[0]; a.loy = p->xyz_min[1]; a.loz = p->xyz_min[2];
   a.hix = p->xyz_max[0]; a.hiy = p->xyz_max[1]; a.hiz = p->xyz_max[2];
+  a.ex = a.hix - a.lox; a.ey = a.hiy - a.loy; a.ez = a.hiz - a.loz;   // fp32, like (xyz_max - xyz_min)
+  a.irx = 1.0f / a.ex; a.iry = 1.0f / a.ey; a.irz = 1.0f / a.ez;       // IEEE RN(1/extent)
   // python: B = 1 + bg_len, A = B*1 - 1 (doubles) then cast to fp32 when they meet the tensor
   const double Bd = 1.0 + (double)p->bg_len;
   a.B = (float)Bd; a.A = (float)(Bd * 1.0 - 1.0);
@@ -750,23 +803,39 @@ extern "C" int ugrid_render_march(const ugrid_render_params *p, const float *ray
   }
 }
 
-template <int F, int C, int PE>
-static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
-                           ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
+static int g_shade_waves = 12;  // waves per shade workgroup: 8 (2/SIMD, no spills) or 12 (3/SIMD)
+
+extern "C" int ugrid_tune(const char *key, int value) {
+  if (!key) return (int)hipErrorInvalidValue;
+  if (!strcmp(key, "shade_waves") && (value == 8 || value == 12)) { g_shade_waves = value; return 0; }
+  return (int)hipErrorInvalidValue;
+}
+
+template <int F, int C, int PE, int NW>
+static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
+                              ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
   const int lds_bytes = (int)sizeof(float) * ug_mlp_lay(C, 3 + 6 * PE).total;
   static bool attr_set = false;
   if (!attr_set) {
-    UG_HIP(hipFuncSetAttribute((const void *)k_shade_mlp<F, C, PE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    UG_HIP(hipFuncSetAttribute((const void *)k_shade_mlp<F, C, PE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
-  UG_HIP(hipMemsetAsync(counter, 0, sizeof(int32_t), st));
-  // persistent: one 512-thread workgroup per CU (LDS holds the 87 KB packed rgbnet), 8 waves each
-  int64_t wgs = (ws.n_tiles + 7) / 8;
+  UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
+  // persistent: one workgroup per CU (LDS holds the 89 KB packed rgbnet)
+  int64_t wgs = (ws.n_tiles + NW - 1) / NW;
   if (wgs > 256) wgs = 256;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_mlp<F, C, PE>), dim3((unsigned)wgs), dim3(512), lds_bytes, st, a,
+  wgs = (wgs + 7) / 8 * 8;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_mlp<F, C, PE, NW>), dim3((unsigned)wgs), dim3(NW * 64), lds_bytes, st, a,
                      viewdirs, k0b, mlp, ws, rgb, counter);
   UG_LAUNCH_CHECK();
   return 0;
+}
+
+template <int F, int C, int PE>
+static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
+                           ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
+  if (g_shade_waves == 8) return ug_shade_launch_nw<F, C, PE, 8>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  return ug_shade_launch_nw<F, C, PE, 12>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
 }
 
 extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *viewdirs, const float *k0_bricks,
@@ -777,6 +846,8 @@ extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *vie
   a.n_rays = p->n_rays; a.X = p->grid_x; a.Y = p->grid_y; a.Z = p->grid_z;
   a.lox = p->xyz_min[0]; a.loy = p->xyz_min[1]; a.loz = p->xyz_min[2];
   a.hix = p->xyz_max[0]; a.hiy = p->xyz_max[1]; a.hiz = p->xyz_max[2];
+  a.ex = a.hix - a.lox; a.ey = a.hiy - a.loy; a.ez = a.hiz - a.loz;
+  a.irx = 1.0f / a.ex; a.iry = 1.0f / a.ey; a.irz = 1.0f / a.ez;
   if (p->mlp_in == 0) {
     if (p->k0_channels != 3) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_shade_direct, dim3(ug_blocks(ws.n_tiles * UG_WAVE, 256)), dim3(256), 0, ST(s), a,

@@ -24,6 +24,11 @@ _L = _lib.load()
 _p = _lib.ptr
 
 
+def tune(key, value):
+    """Speed-only tuning knobs of the fused kernels (ugrid_tune): 'shade_waves' in (8, 12)."""
+    _lib.check(_L.ugrid_tune(key.encode(), int(value)), "ugrid_tune(%s)" % key)
+
+
 def sample_table(world_len, stepsize, bg_len, t_boundary=1.5):
     """Sample distances t [S] and s = 1 - 1/(1+t), computed with the same torch ops as the reference
     (FourierGrid_model.py:524-532,649) on the host; shared by every ray."""
