@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--grid", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--single-launch", action="store_true", help="single persistent launch instead of march + shade")
     ap.add_argument("--tune", action="append", default=[], help="key=value speed knob (ugrid_tune), repeatable")
     ap.add_argument("--cpu-chunks", type=int, default=4, help="8192-ray chunks timed for the CPU baseline")
     return ap.parse_args()
@@ -100,10 +101,12 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("UGRID_BENCH_FORCE_DIST") == "1")
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
 
     from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer, get_rays_of_a_view, tune
     for kv in args.tune:
@@ -113,7 +116,7 @@ def main():
     H, W, G = args.height, args.width, args.grid
     stepsize = 1.31 * G / 200.0 if G != 200 else 1.31
     state = make_state(G, device, seed=0)  # same model on every rank (replicated read-only grids)
-    rend = FourierGridRenderer(state, device)
+    rend = FourierGridRenderer(state, device, fused=args.single_launch)
     cpu_state = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_state = {k: ([x.cpu() for x in v] if isinstance(v, list) else (v.cpu() if torch.is_tensor(v) else v))
@@ -126,17 +129,18 @@ def main():
     ro, rd, vd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous(), vd.reshape(-1, 3).contiguous()
     R = ro.shape[0]
     S = rend.tables(stepsize)[2]
-    gathered = torch.empty(world * R, 5, device=device) if world > 1 else None
+    gathered = torch.empty(world * R, 5, device=device) if use_dist else None
 
     def step(timing=None):
         out = rend(ro, rd, vd, stepsize=stepsize, render_depth=True, timing=timing)
-        if world > 1:
+        if use_dist:
+            # the one exchange step of the path: rendered tiles [R,5] = rgb(3), depth, alphainv_last -> every rank
             tile = torch.cat([out["rgb_marched"], out["depth"][:, None], out["alphainv_last"][:, None]], dim=1)
             dist.all_gather_into_tensor(gathered, tile)
         return out
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -149,22 +153,31 @@ def main():
         out = step(timing)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        # sanity of the exchange: this rank's tile must sit at its slot of the gathered frame set
+        mine = gathered[rank * R:(rank + 1) * R]
+        assert torch.equal(mine[:, 0:3], out["rgb_marched"]) and torch.equal(mine[:, 4], out["alphainv_last"])
 
     # per-kernel durations from HIP events recorded on the launch stream inside the timed region
     n_chunks = len(timing) // max(1, args.steps)
-    march_ms = sum(ev[0].elapsed_time(ev[1]) for ev, _ in timing) / args.steps
-    shade_ms = sum(ev[1].elapsed_time(ev[2]) for ev, _ in timing) / args.steps
-    # survivors of the frame (one extra, untimed frame so every chunk's list can be counted)
-    M = 0
-    chunk = rend.rays_per_chunk(S)
-    for b in range(0, R, chunk):
-        e = min(R, b + chunk)
-        rend(ro[b:e], rd[b:e], vd[b:e], stepsize=stepsize)
-        M += rend.survivors_of_last_chunk(e - b, S)
+    if not args.single_launch:
+        march_ms = sum(ev[0].elapsed_time(ev[1]) for ev, _ in timing) / args.steps
+        shade_ms = sum(ev[1].elapsed_time(ev[2]) for ev, _ in timing) / args.steps
+    else:
+        fused_ms = sum(ev[0].elapsed_time(ev[1]) for ev, _ in timing) / args.steps
+    # survivors of the frame (one extra, untimed frame)
+    if not args.single_launch:
+        M = 0
+        chunk = rend.rays_per_chunk(S)
+        for b in range(0, R, chunk):
+            e = min(R, b + chunk)
+            rend(ro[b:e], rd[b:e], vd[b:e], stepsize=stepsize)
+            M += rend.survivors_of_last_chunk()
+    else:
+        M = rend.survivors_of_last_chunk()
     term_frac = float((out["alphainv_last"] < 1e-3).float().mean())
 
     if rank == 0:
@@ -172,9 +185,13 @@ def main():
         samples = world * R * S
         bytes_march = R * S * 224 + R * 32          # 8 corners x 7 levels x 4 B per sample + rays in / (depth, alphainv) out
         bytes_shade = M * 2688 + R * 24             # x 12 channels per survivor + viewdirs in / rgb out
-        kern = {"render_march": {"ms": march_ms, "algorithmic_bytes": bytes_march},
-                "render_shade": {"ms": shade_ms, "algorithmic_bytes": bytes_shade}}
-        dom = "render_march" if march_ms >= shade_ms else "render_shade"
+        if not args.single_launch:
+            kern = {"render_march": {"ms": march_ms, "algorithmic_bytes": bytes_march},
+                    "render_shade": {"ms": shade_ms, "algorithmic_bytes": bytes_shade}}
+            dom = "render_march" if march_ms >= shade_ms else "render_shade"
+        else:
+            kern = {"render_fused": {"ms": fused_ms, "algorithmic_bytes": bytes_march + bytes_shade}}
+            dom = "render_fused"
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
@@ -204,7 +221,7 @@ def main():
         if cpu_state is not None:
             res["cpu_baseline"] = cpu_baseline(cpu_state, ro, rd, vd, out, stepsize, S, args.cpu_chunks)
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -189,6 +189,20 @@ int ugrid_render_shade(const ugrid_render_params *h_params, const float *viewdir
                        const float *k0_bricks, const float *mlp_packed, void *ws,
                        float *rgb_marched, ugrid_stream_t stream);
 
+/* Single-launch render (march + shade fused in one persistent kernel; models with an rgbnet).  Every
+ * persistent wave marches a 64-ray tile and immediately shades its survivors from a private scratch slot,
+ * so the work list is only ugrid_render_fused_ws_bytes(S) (3072 wave slots x 64*S entries, independent of
+ * the ray count) and the VALU-bound march of some waves overlaps the MFMA-bound rgbnet of others.
+ * Same results, bit for bit, as ugrid_render_march + ugrid_render_shade. */
+int64_t ugrid_render_fused_ws_bytes(int32_t n_samples);
+int ugrid_render_fused(const ugrid_render_params *h_params, const float *rays_o, const float *rays_d,
+                       const float *viewdirs, const float *t_table, const float *s_table,
+                       const float *density_bricks, const float *k0_bricks, const float *mlp_packed,
+                       float *alphainv_last, float *depth, float *rgb_marched, void *ws,
+                       ugrid_stream_t stream);
+/* total survivors of the last ugrid_render_fused on this ws -> *d_stats (device int64) */
+int ugrid_render_fused_stats(const void *ws, int64_t *d_stats, ugrid_stream_t stream);
+
 /* rgbnet packing for the MFMA shade kernel: w0 [128, C+3+6pe], b0 [128], w1 [128,128], b1 [128],
  * w2 [3,128], b2 [3] (nn.Linear layout, FourierGrid_model.py:233-241) -> packed device array. */
 int64_t ugrid_mlp_packed_bytes(int32_t k0_channels, int32_t viewbase_pe);

@@ -207,3 +207,76 @@ def state_from_reference_model(model):
         'fast_color_thres': float(model.fast_color_thres), 'contracted_norm': model.contracted_norm,
         'world_len': int(model.world_len_density),
     }
+
+
+# ---------------------------------------------------------------------------------------------
+# Training-mode forward (autograd), device-agnostic: used by tests to run ONE reference-shaped
+# train step (FourierGrid/run_train.py:185-296) on CPU with the oracle ops and on the GPU with the
+# product's drop-in ops, and compare the updated parameters.
+# ---------------------------------------------------------------------------------------------
+def make_autograd_ops(backend):
+    """Raw2Alpha / Alphas2Weights autograd Functions (dvgo.py:430-488) over an extension-module backend
+    (`backend.raw2alpha`, `.raw2alpha_backward`, `.alpha2weight`, `.alpha2weight_backward`)."""
+
+    class Raw2Alpha(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, density, shift, interval):
+            exp, alpha = backend.raw2alpha(density, shift, interval)
+            if density.requires_grad:
+                ctx.save_for_backward(exp)
+                ctx.interval = interval
+            return alpha
+
+        @staticmethod
+        @torch.autograd.function.once_differentiable
+        def backward(ctx, grad_back):
+            return backend.raw2alpha_backward(ctx.saved_tensors[0], grad_back.contiguous(), ctx.interval), None, None
+
+    class Alphas2Weights(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, alpha, ray_id, N):
+            weights, T, alphainv_last, i_start, i_end = backend.alpha2weight(alpha, ray_id, N)
+            if alpha.requires_grad:
+                ctx.save_for_backward(alpha, weights, T, alphainv_last, i_start, i_end)
+                ctx.n_rays = N
+            return weights, alphainv_last
+
+        @staticmethod
+        @torch.autograd.function.once_differentiable
+        def backward(ctx, grad_weights, grad_last):
+            alpha, weights, T, alphainv_last, i_start, i_end = ctx.saved_tensors
+            grad = backend.alpha2weight_backward(alpha, weights, T, alphainv_last, i_start, i_end, ctx.n_rays,
+                                                 grad_weights.contiguous(), grad_last.contiguous())
+            return grad, None, None
+
+    return Raw2Alpha, Alphas2Weights
+
+
+def fouriergrid_train_forward(params, cfg, rays_o, rays_d, viewdirs, stepsize, Raw2Alpha, Alphas2Weights):
+    """FourierGridModel.forward in training mode (FourierGrid_model.py:554-672) on params' device.
+    params: dict of leaf tensors density_grid, k0_grid, w0,b0,w1,b1,w2,b2; cfg: the non-learned `state` fields."""
+    dev = rays_o.device
+    R = rays_o.shape[0]
+    F_num, thres = int(cfg['fourier_freq_num']), float(cfg['fast_color_thres'])
+    t = sample_t(int(cfg['world_len']), stepsize, float(cfg['bg_len'])).to(dev)
+    S = t.numel()
+    pts, _ = contracted_sample_ray(rays_o, rays_d, cfg['scene_center'].to(dev), cfg['scene_radius'].to(dev), t,
+                                   float(cfg['bg_len']), cfg.get('contracted_norm', 'inf'))
+    interval = float(torch.tensor(float(cfg['voxel_size_ratio']), dtype=torch.float32) * stepsize)
+    ray_id = torch.arange(R, device=dev).view(-1, 1).expand(R, S).flatten()
+    lo, hi = cfg['xyz_min'].to(dev), cfg['xyz_max'].to(dev)
+    density = fourier_grid_query(params['density_grid'], pts, lo, hi, F_num)
+    alpha = Raw2Alpha.apply(density.flatten(), float(cfg['act_shift']), interval).reshape(density.shape)
+    m1 = alpha > thres
+    pts, alpha, tt = pts[m1], alpha[m1], t[None].repeat(R, 1)[m1]
+    ray_id = ray_id[m1.flatten()]
+    weights, alphainv_last = Alphas2Weights.apply(alpha, ray_id, R)
+    m2 = weights > thres
+    pts, weights, ray_id, tt = pts[m2], weights[m2], ray_id[m2], tt[m2]
+    k0 = fourier_grid_query(params['k0_grid'], pts, lo, hi, F_num)
+    emb = viewdir_embedding(viewdirs.cpu(), int(cfg['viewbase_pe'])).to(dev)[ray_id]
+    rgb = torch.sigmoid(rgbnet_apply([params['w0'], params['w1'], params['w2']],
+                                     [params['b0'], params['b1'], params['b2']], torch.cat([k0, emb], -1)))
+    rgb_marched = torch.zeros(R, 3, device=dev).index_add_(0, ray_id, weights.unsqueeze(-1) * rgb)
+    return {'rgb_marched': rgb_marched, 'alphainv_last': alphainv_last, 'weights': weights, 'ray_id': ray_id,
+            'n_kept': int(weights.numel())}

@@ -63,7 +63,7 @@ def test_fused_render_matches_reference_golden(fr, case, golden_dir):
                        "alphainv_last": torch.from_numpy(gold["alphainv_last"]), "margin": ref["margin"]}, R)
     # survivor count = M of the reference (exact unless a threshold flip happened)
     S = out["n_max"]
-    M = rend.survivors_of_last_chunk(R, S)
+    M = rend.survivors_of_last_chunk()
     assert abs(M - gold["weights"].shape[0]) <= 2
 
 
@@ -88,7 +88,7 @@ def test_fused_render_vs_oracle(fr, G, F, C, pe, norm, R, stepsize, dm, ds):
     term = float((ref["alphainv_last"] < 1e-3).float().mean())
     print("G=%d F=%d C=%d: M=%d terminated=%.2f worst=%s" % (G, F, C, ref["weights"].numel(), term, worst))
     assert ref["weights"].numel() > R  # the case must actually exercise the shade kernel
-    M = rend.survivors_of_last_chunk(R, out["n_max"])
+    M = rend.survivors_of_last_chunk()
     assert abs(M - ref["weights"].numel()) <= max(3, int(2e-4 * M))
 
 
@@ -101,14 +101,19 @@ def test_fused_render_deterministic_chunk_and_order_invariant(fr):
     rend = fr.FourierGridRenderer(state, "cuda:0")
     a = rend(o, d, v, stepsize=0.5, render_depth=True)
     b = rend(o, d, v, stepsize=0.5, render_depth=True)
-    small = fr.FourierGridRenderer(state, "cuda:0", max_ws_bytes=4 << 20)
+    # two-kernel path (march -> work list -> shade) with a tiny work list, i.e. many chunks
+    small = fr.FourierGridRenderer(state, "cuda:0", max_ws_bytes=4 << 20, fused=False)
     assert small.rays_per_chunk(a["n_max"]) < R
     c = small(o, d, v, stepsize=0.5, render_depth=True)
+    single = fr.FourierGridRenderer(state, "cuda:0", fused=True)   # single persistent launch
+    c2 = single(o, d, v, stepsize=0.5, render_depth=True)
+    assert rend.survivors_of_last_chunk() == single.survivors_of_last_chunk()
     perm = torch.from_numpy(np.random.RandomState(0).permutation(R)).cuda()
     e = rend(o[perm].contiguous(), d[perm].contiguous(), v[perm].contiguous(), stepsize=0.5, render_depth=True)
     for k in ("rgb_marched", "depth", "alphainv_last"):
         assert torch.equal(a[k], b[k]), k
-        assert torch.equal(a[k], c[k]), k
+        assert torch.equal(a[k], c[k]), k      # any chunking of the work list; single launch == two kernels
+        assert torch.equal(a[k], c2[k]), k
         assert torch.equal(a[k][perm], e[k]), k
     assert float(a["rgb_marched"].min()) >= 0 and float(a["rgb_marched"].max()) <= 1 + 1e-5
     assert float(a["alphainv_last"].min()) >= 0 and float(a["alphainv_last"].max()) <= 1

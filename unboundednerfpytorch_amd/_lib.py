@@ -14,7 +14,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libugrid_hip.so")
+LIB_PATH = os.environ.get("UGRID_LIB") or os.path.join(_HERE, "libugrid_hip.so")  # UGRID_LIB: A/B builds only
 ABI_VERSION = 1
 
 _c = ctypes
@@ -65,6 +65,9 @@ _SIGNATURES = {
     "ugrid_render_ws_bytes": (_L, [_L, _c.c_int32]),
     "ugrid_render_march": (_I, [_c.POINTER(RenderParams), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ugrid_render_shade": (_I, [_c.POINTER(RenderParams), _P, _P, _P, _P, _P, _P]),
+    "ugrid_render_fused_ws_bytes": (_L, [_c.c_int32]),
+    "ugrid_render_fused": (_I, [_c.POINTER(RenderParams)] + [_P] * 13),
+    "ugrid_render_fused_stats": (_I, [_P, _P, _P]),
     "ugrid_mlp_packed_bytes": (_L, [_c.c_int32, _c.c_int32]),
     "ugrid_pack_mlp": (_I, [_P, _P, _P, _P, _P, _P, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P]),
     "ugrid_tune": (_I, [_c.c_char_p, _I]),

@@ -1,6 +1,15 @@
 #!/bin/bash
 # Build libugrid_hip.so for gfx950 (MI355X).  Usage: csrc/build.sh [extra hipcc flags]
+#   UG_OUT=path   alternative output (A/B builds)
 set -e
 cd "$(dirname "$0")"
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -ffp-contract=off -I../../include \
-  -o ../libugrid_hip.so ugrid_ops.hip ugrid_fused.hip "$@"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include"
+mkdir -p ../../build/obj
+O=../../build/obj
+hipcc $FLAGS -c ugrid_ops.hip -o $O/ugrid_ops.o "$@" &
+# packed fp32 VALU (v_pk_*_f32 from the SLP vectoriser) runs at half rate on gfx950 and needs extra moves:
+# the VALU-bound march kernel is 16 % faster without it (profiles/r01 notes in DESIGN.md)
+hipcc $FLAGS -fno-slp-vectorize -c ugrid_march.hip -o $O/ugrid_march.o "$@" &
+hipcc $FLAGS -c ugrid_shade.hip -o $O/ugrid_shade.o "$@" &
+wait
+hipcc --offload-arch=gfx950 -shared -fPIC -o ${UG_OUT:-../libugrid_hip.so} $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o

@@ -1,0 +1,196 @@
+// libugrid_hip.so -- march half of the fused render path + grid packing/query kernels.
+// Built with -fno-slp-vectorize (see ugrid_render.h header note and csrc/build.sh).
+#include "ugrid_render.h"
+
+// ----------------------------------------------------------------------------------------------
+// brick packing: canonical [P,C,X,Y,Z] -> [P*(X-1)(Y-1)(Z-1)] records of [H halves][8 corners][CH]
+// ----------------------------------------------------------------------------------------------
+__global__ void k_pack_bricks(const float *__restrict__ grid, int P, int C, int X, int Y, int Z, int H,
+                              int CH, float *__restrict__ out, int64_t total) {
+  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total;
+       o += (int64_t)gridDim.x * blockDim.x) {
+    int64_t q = o;
+    const int ch = (int)(q % CH); q /= CH;
+    const int c = (int)(q % 8); q /= 8;
+    const int h = (int)(q % H); q /= H;
+    const int k = (int)(q % (Z - 1)); q /= (Z - 1);
+    const int j = (int)(q % (Y - 1)); q /= (Y - 1);
+    const int i = (int)(q % (X - 1)); q /= (X - 1);
+    const int l = (int)q;
+    const int chan = h * CH + ch;
+    float v = 0.f;
+    if (chan < C) {
+      const int ii = i + (c >> 2), jj = j + ((c >> 1) & 1), kk = k + (c & 1);
+      v = grid[((((int64_t)l * C + chan) * X + ii) * Y + jj) * Z + kk];
+    }
+    out[o] = v;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// stand-alone grid query on the canonical layout (FourierGrid.forward / DenseGrid.forward).
+// 1 lane per point; corner taps are z-pairs in the [.., Z] fastest dimension.
+// ----------------------------------------------------------------------------------------------
+__device__ __forceinline__ float ug_tap(const float *__restrict__ g, int X, int Y, int Z, float cx, float cy,
+                                        float cz) {
+  // generic zero-padded trilinear tap at normalised (cx->X axis, cy->Y, cz->Z)
+  const float ix = ((cx + 1.f) / 2.f) * (float)(X - 1);
+  const float iy = ((cy + 1.f) / 2.f) * (float)(Y - 1);
+  const float iz = ((cz + 1.f) / 2.f) * (float)(Z - 1);
+  const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+  const float wx0 = (fx + 1.f) - ix, wx1 = ix - fx;
+  const float wy0 = (fy + 1.f) - iy, wy1 = iy - fy;
+  const float wz0 = (fz + 1.f) - iz, wz1 = iz - fz;
+  const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)X), y0 = (int)fminf(fmaxf(fy, -2.f), (float)Y),
+            z0 = (int)fminf(fmaxf(fz, -2.f), (float)Z);
+  float acc = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int xi = x0 + (c >> 2), yi = y0 + ((c >> 1) & 1), zi = z0 + (c & 1);
+    if (xi >= 0 && xi < X && yi >= 0 && yi < Y && zi >= 0 && zi < Z) {
+      const float w = ((c & 1) ? wz1 : wz0) * (((c >> 1) & 1) ? wy1 : wy0) * ((c >> 2) ? wx1 : wx0);
+      acc += g[((int64_t)xi * Y + yi) * Z + zi] * w;
+    }
+  }
+  return acc;
+}
+
+__global__ void k_grid_query(const float *__restrict__ grid, int P, int C, int X, int Y, int Z,
+                             const float *__restrict__ xyz, const float *__restrict__ xyz_min,
+                             const float *__restrict__ xyz_max, int F, int64_t n, float *__restrict__ out) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n) return;
+  const float ux = ug_unorm(xyz[3 * p], xyz_min[0], xyz_max[0]);
+  const float uy = ug_unorm(xyz[3 * p + 1], xyz_min[1], xyz_max[1]);
+  const float uz = ug_unorm(xyz[3 * p + 2], xyz_min[2], xyz_max[2]);
+  const int64_t vol = (int64_t)X * Y * Z;
+  for (int ch = 0; ch < C; ++ch) {
+    float acc = 0.f;
+    for (int l = 0; l < P; ++l) {
+      float cx = ux, cy = uy, cz = uz;
+      if (l > 0) {
+        const float f = (float)(1 << ((l - 1) >> 1));
+        if ((l - 1) & 1) { cx = cosf(f * ux); cy = cosf(f * uy); cz = cosf(f * uz); }
+        else { cx = sinf(f * ux); cy = sinf(f * uy); cz = sinf(f * uz); }
+      }
+      const float v = ug_tap(grid + ((int64_t)l * C + ch) * vol, X, Y, Z, cx, cy, cz);
+      acc = (l == 0) ? v : acc + v;
+    }
+    out[p * C + ch] = (F > 0) ? acc / (float)P : acc;
+  }
+}
+
+template <int F, bool L2, int W>
+__global__ void __launch_bounds__(256, W)
+k_march(ug_march_args a, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+        const float *__restrict__ t_table, const float *__restrict__ s_table,
+        const float *__restrict__ bricks, float *__restrict__ alphainv_last, float *__restrict__ depth,
+        ug_ws_view ws, int64_t nblocks) {
+  const int64_t blk = ug_xcd_remap(blockIdx.x, nblocks);
+  if (blk >= nblocks) return;
+  const int64_t tile = blk * 4 + (threadIdx.x >> 6);
+  if (tile >= ws.n_tiles) return;
+  const int n = ug_march_tile<F, L2>(a, rays_o, rays_d, t_table, s_table, bricks, alphainv_last, depth, tile,
+                                     ws.ent + tile * ws.cap, ws.slot + tile * ws.cap);
+  if (ug_lane() == 0) ws.count[tile] = n;
+}
+
+
+// ----------------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------------
+extern "C" int64_t ugrid_render_ws_bytes(int64_t n_rays, int32_t S) {
+  const int64_t n_tiles = (n_rays + UG_WAVE - 1) / UG_WAVE, cap = (int64_t)UG_WAVE * S;
+  return 256 + ug_align256(n_tiles * 4) + ug_align256(n_tiles * cap * 16) + ug_align256(n_tiles * cap);
+}
+
+extern "C" int ugrid_grid_query(const float *grid, int P, int C, int X, int Y, int Z, const float *xyz,
+                                const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
+                                float *out, ugrid_stream_t s) {
+  if (n <= 0) return 0;
+  if (P != (freq_num > 0 ? 2 * freq_num + 1 : 1)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_grid_query, dim3(ug_blocks(n, 256)), dim3(256), 0, ST(s), grid, P, C, X, Y, Z, xyz,
+                     xyz_min, xyz_max, freq_num, n, out);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+static inline int ug_brick_ch(int C, int *H) {
+  // density (C==1): 1 half x 1 channel; rgbnet-less k0 (C==3 handled by caller via halves=1, CH=4);
+  // feature grids: 2 halves x ceil(C/2)
+  if (C == 1) { *H = 1; return 1; }
+  *H = 2;
+  return (C + 1) / 2;
+}
+
+extern "C" int64_t ugrid_brick_bytes(int P, int C, int X, int Y, int Z, int direct) {
+  int H, CH = ug_brick_ch(C, &H);
+  if (direct) { H = 1; CH = 4; }
+  return (int64_t)P * (X - 1) * (Y - 1) * (Z - 1) * H * 8 * CH * (int64_t)sizeof(float);
+}
+
+extern "C" int ugrid_pack_bricks(const float *grid, int P, int C, int X, int Y, int Z, int direct,
+                                 float *bricks, ugrid_stream_t s) {
+  if (X < 2 || Y < 2 || Z < 2 || P < 1 || C < 1) return (int)hipErrorInvalidValue;
+  int H, CH = ug_brick_ch(C, &H);
+  if (direct) { H = 1; CH = 4; }
+  const int64_t total = (int64_t)P * (X - 1) * (Y - 1) * (Z - 1) * H * 8 * CH;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 256 * 64) blocks = 256 * 64;
+  hipLaunchKernelGGL(k_pack_bricks, dim3((unsigned)blocks), dim3(256), 0, ST(s), grid, P, C, X, Y, Z, H, CH,
+                     bricks, total);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+static int g_march_waves = 5;
+extern "C" int ug_set_march_waves(int w) { if (w < 4 || w > 6) return 1; g_march_waves = w; return 0; }
+  // min waves/SIMD the march kernel is compiled for (register cap 512/W)
+
+template <int F, int W>
+static int ug_march_launch_w(const ugrid_render_params *p, const ug_march_args &a, const float *rays_o,
+                             const float *rays_d, const float *t_table, const float *s_table,
+                             const float *bricks, float *alphainv_last, float *depth, ug_ws_view ws,
+                             hipStream_t st) {
+  const int64_t nblocks = (ws.n_tiles + 3) / 4;
+  const int64_t grid = ((nblocks + 7) / 8) * 8;  // room for the XCD remap
+  if (p->norm_l2)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_march<F, true, W>), dim3((unsigned)grid), dim3(256), 0, st, a, rays_o,
+                       rays_d, t_table, s_table, bricks, alphainv_last, depth, ws, nblocks);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_march<F, false, W>), dim3((unsigned)grid), dim3(256), 0, st, a, rays_o,
+                       rays_d, t_table, s_table, bricks, alphainv_last, depth, ws, nblocks);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int F>
+static int ug_march_launch(const ugrid_render_params *p, const ug_march_args &a, const float *rays_o,
+                           const float *rays_d, const float *t_table, const float *s_table,
+                           const float *bricks, float *alphainv_last, float *depth, ug_ws_view ws,
+                           hipStream_t st) {
+  switch (g_march_waves) {
+    case 4: return ug_march_launch_w<F, 4>(p, a, rays_o, rays_d, t_table, s_table, bricks, alphainv_last, depth, ws, st);
+    case 6: return ug_march_launch_w<F, 6>(p, a, rays_o, rays_d, t_table, s_table, bricks, alphainv_last, depth, ws, st);
+    default: return ug_march_launch_w<F, 5>(p, a, rays_o, rays_d, t_table, s_table, bricks, alphainv_last, depth, ws, st);
+  }
+}
+
+extern "C" int ugrid_render_march(const ugrid_render_params *p, const float *rays_o, const float *rays_d,
+                                  const float *t_table, const float *s_table, const float *density_bricks,
+                                  float *alphainv_last, float *depth, void *ws_mem, ugrid_stream_t s) {
+  if (p->n_rays <= 0) return 0;
+  ug_march_args a;
+  const int rc = ug_fill_march_args(p, a);
+  if (rc) return rc;
+  ug_ws_view ws = ug_ws_make(ws_mem, p->n_rays, p->n_samples);
+  switch (p->freq_num) {
+    case 1: return ug_march_launch<1>(p, a, rays_o, rays_d, t_table, s_table, density_bricks, alphainv_last, depth, ws, ST(s));
+    case 2: return ug_march_launch<2>(p, a, rays_o, rays_d, t_table, s_table, density_bricks, alphainv_last, depth, ws, ST(s));
+    case 3: return ug_march_launch<3>(p, a, rays_o, rays_d, t_table, s_table, density_bricks, alphainv_last, depth, ws, ST(s));
+    case 4: return ug_march_launch<4>(p, a, rays_o, rays_d, t_table, s_table, density_bricks, alphainv_last, depth, ws, ST(s));
+    case 5: return ug_march_launch<5>(p, a, rays_o, rays_d, t_table, s_table, density_bricks, alphainv_last, depth, ws, ST(s));
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+

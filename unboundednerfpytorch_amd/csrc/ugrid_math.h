@@ -78,15 +78,15 @@ __device__ __forceinline__ float ug_alpha(float dens_plus_shift, float interval)
 struct ug_axis_fast { int cell; float wlo, whi; };
 
 __device__ __forceinline__ ug_axis_fast ug_axis_inrange(float c, int n) {
-  c = fminf(fmaxf(c, -1.0f), 1.0f);  // NaN -> -1: never an out-of-bounds address
   const float ix = ((c + 1.0f) * 0.5f) * (float)(n - 1);
-  const float f0 = floorf(ix);
-  const float wlo = (f0 + 1.0f) - ix;
-  const float whi = ix - f0;
-  const bool top = f0 > (float)(n - 2);  // ix == n-1 exactly: use cell n-2 with the weights swapped
+  // cell = floor(ix) clamped to [0, n-2].  For ix < n-1 this is torch's floor and the weights below are
+  // torch's (x1 - ix), (ix - x0) bit for bit; at ix == n-1 exactly (c == 1) the clamp moves to cell n-2 and the
+  // same two expressions give (0, 1): the live corner n-1 with weight 1, as torch computes it from cell n-1.
+  // NaN -> med3 returns 0 -> cell 0 (never an out-of-bounds address), weights NaN (sample is dropped).
+  const float cf = __builtin_amdgcn_fmed3f(floorf(ix), 0.0f, (float)(n - 2));
   ug_axis_fast a;
-  a.cell = (int)fminf(f0, (float)(n - 2));
-  a.wlo = top ? whi : wlo;
-  a.whi = top ? wlo : whi;
+  a.cell = (int)cf;
+  a.wlo = (cf + 1.0f) - ix;
+  a.whi = ix - cf;
   return a;
 }

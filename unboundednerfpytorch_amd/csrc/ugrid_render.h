@@ -1,0 +1,567 @@
+// ugrid_render.h -- device code of the fused FourierGrid render path for gfx950 (MI355X), shared by
+// ugrid_march.hip (compiled with -fno-slp-vectorize: packed v_pk_*_f32 math is a measured LOSS for the
+// VALU-bound march kernel, 8.4 -> 7.0 ms) and ugrid_shade.hip (default flags: SLP helps there, 12.5 -> 11.7 ms).
+//
+// Replaces, for inference, the torch-op chain of the reference's FourierGridModel.forward
+// (FourierGrid/FourierGrid_model.py:509-672) and FourierGrid.forward (FourierGrid_grid.py:60-78):
+//
+//   k_march : 1 lane = 1 ray, 1 wave = 64 consecutive rays.  Per sample: contraction, Fourier
+//             level coordinates, ONE 32-byte brick load per level (the 2x2x2 neighbourhood of the
+//             trilinear cell, see DESIGN.md "brick layout"), mean over levels, raw2alpha, the two
+//             thresholds and the front-to-back transmittance recurrence -- which is a plain serial
+//             multiply in the lane's registers because a lane owns a ray.  A wave leaves the sample
+//             loop as soon as all of its 64 rays have terminated (T < 1e-3) -- wave-level early
+//             termination by ballot.  Surviving samples are compacted per wave (ballot + mbcnt
+//             prefix) into that wave's private slice of the work list: no atomics, deterministic.
+//   k_shade : 1 wave walks one tile's survivor list 32 at a time.  Lanes l and l+32 form a pair
+//             that owns survivor (l&31): each gathers half of the k0 channels from the 2x2x2 k0
+//             bricks and half of the view-direction embedding, which makes their registers exactly
+//             the B operand of v_mfma_f32_32x32x2_f32 (B[k=l>>5][j=l&31]).  The rgbnet runs
+//             "transposed" (H^T = W . X^T) so every layer's accumulator registers are directly the
+//             next layer's B operands -- activations never leave the register file; packed weights
+//             (A operands) are read from LDS.  fp32-input MFMA is bit-wise an fmaf chain, so the
+//             MLP stays inside the 1e-4 parity budget (no bf16 anywhere).
+//
+// Compiled with -ffp-contract=off: every a*b+c below that must match torch's separate
+// multiply/add is written as such; fmaf is explicit where torch's CPU kernels use FMA.
+#pragma once
+#include "ugrid_common.h"
+#include "ugrid_math.h"
+#include <string.h>
+
+#define UG_MAX_F 5  // fourier_freq_num <= 5  (P <= 11 levels)
+
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ----------------------------------------------------------------------------------------------
+// shared per-sample math
+// ----------------------------------------------------------------------------------------------
+struct ug_vec3 { float x, y, z; };
+
+// torch.linalg.vector_norm over 3 components (CPU kernel = fma chain, verified in tests)
+__device__ __forceinline__ float ug_norm3_torch(float x, float y, float z) {
+  return sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
+}
+
+// FourierGrid_model.py:534-548: p/|p| * ((1+bg) - bg/|p|) outside the unit cube (inf) / ball (l2)
+template <bool L2>
+__device__ __forceinline__ ug_vec3 ug_contract(ug_vec3 p, float B, float A) {
+  const float nrm = L2 ? ug_norm3_torch(p.x, p.y, p.z) : fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z)));
+  if (!(nrm <= 1.0f)) {
+    const float sc = B - A / nrm;
+    p.x = p.x / nrm * sc;
+    p.y = p.y / nrm * sc;
+    p.z = p.z / nrm * sc;
+  }
+  return p;
+}
+
+// grid_sample(align_corners=True) cell + fractional position along one axis of size n (n >= 2).
+// Returns the cell index clamped to [0, n-2]; lo/hi are the two linear weights (x1 - ix), (ix - x0)
+// exactly as torch forms them.  Points outside [-1,1] get zero weight on out-of-range corners
+// (zero padding) -- `ok_lo/ok_hi` report whether each corner is inside the grid.
+struct ug_axis { int cell; float wlo, whi; };
+
+__device__ __forceinline__ ug_axis ug_axis_setup(float c, int n) {
+  const float ix = ((c + 1.f) / 2.f) * (float)(n - 1);
+  const float f0 = floorf(ix);
+  ug_axis a;
+  float wlo = (f0 + 1.f) - ix;  // weight of corner x0
+  float whi = ix - f0;          // weight of corner x0+1
+  // zero padding: a corner outside [0, n-1] contributes nothing
+  int i0 = (int)fminf(fmaxf(f0, -2.f), (float)n);  // also tames NaN/inf
+  if (i0 < 0 || i0 > n - 1) wlo = 0.f;
+  if (i0 + 1 < 0 || i0 + 1 > n - 1) whi = 0.f;
+  // re-express on a cell inside [0, n-2] so that one brick covers both corners
+  if (i0 < 0) {            // only corner x0+1 (== 0) can be live: it is the LOW corner of cell 0
+    a.cell = 0; a.wlo = (i0 == -1) ? whi : 0.f; a.whi = 0.f;
+  } else if (i0 > n - 2) { // only corner x0 (== n-1) can be live: it is the HIGH corner of cell n-2
+    a.cell = n - 2; a.whi = (i0 == n - 1) ? wlo : 0.f; a.wlo = 0.f;
+  } else {
+    a.cell = i0; a.wlo = wlo; a.whi = whi;
+  }
+  return a;
+}
+
+// the 8 trilinear weights in grid_sample's accumulation order: corner c = di*4 + dj*2 + dk, with
+// i (world x, grid dim X) slowest.  torch forms each as (wx * wy) * wz with x = the W axis = world z.
+struct ug_cellw { int64_t rec; float w[8]; };
+
+__device__ __forceinline__ ug_cellw ug_cell_setup(float ux, float uy, float uz, int X, int Y, int Z,
+                                                 int64_t level_base) {
+  const ug_axis ax = ug_axis_setup(ux, X), ay = ug_axis_setup(uy, Y), az = ug_axis_setup(uz, Z);
+  ug_cellw r;
+  r.rec = level_base + ((int64_t)ax.cell * (Y - 1) + ay.cell) * (Z - 1) + az.cell;
+  // torch: tnw = (ix_bse-ix)*(iy_bse-iy)*(iz_bse-iz) with its x = world z, y = world y, z = world x
+  r.w[0] = az.wlo * ay.wlo * ax.wlo;
+  r.w[1] = az.whi * ay.wlo * ax.wlo;
+  r.w[2] = az.wlo * ay.whi * ax.wlo;
+  r.w[3] = az.whi * ay.whi * ax.wlo;
+  r.w[4] = az.wlo * ay.wlo * ax.whi;
+  r.w[5] = az.whi * ay.wlo * ax.whi;
+  r.w[6] = az.wlo * ay.whi * ax.whi;
+  r.w[7] = az.whi * ay.whi * ax.whi;
+  return r;
+}
+
+// level coordinate ℓ of the Fourier embedding of u: ℓ=0: u; ℓ=2k+1: sin(2^k u); ℓ=2k+2: cos(2^k u)
+template <int F>
+struct ug_levels { float cx[2 * F + 1], cy[2 * F + 1], cz[2 * F + 1]; };
+
+template <int F>
+__device__ __forceinline__ ug_levels<F> ug_pe(float ux, float uy, float uz) {
+  ug_levels<F> L;
+  L.cx[0] = ux; L.cy[0] = uy; L.cz[0] = uz;
+#pragma unroll
+  for (int k = 0; k < F; ++k) {
+    const float f = (float)(1 << k);
+    float s, c;
+    sincosf(f * ux, &s, &c); L.cx[2 * k + 1] = s; L.cx[2 * k + 2] = c;
+    sincosf(f * uy, &s, &c); L.cy[2 * k + 1] = s; L.cy[2 * k + 2] = c;
+    sincosf(f * uz, &s, &c); L.cz[2 * k + 1] = s; L.cz[2 * k + 2] = c;
+  }
+  return L;
+}
+
+// world position -> normalised grid coordinate per axis: ((p - min) / (max - min)) * 2 - 1
+__device__ __forceinline__ float ug_unorm(float p, float lo, float hi) {
+  return ((p - lo) / (hi - lo)) * 2.f - 1.f;
+}
+
+// ----------------------------------------------------------------------------------------------
+// work list shared by march and shade
+// ----------------------------------------------------------------------------------------------
+struct ug_ws_view {
+  int32_t *count;   // [n_tiles]
+  float4 *ent;      // [n_tiles][64*S]  (px, py, pz, weight)
+  uint8_t *slot;    // [n_tiles][64*S]  ray slot (0..63) inside the tile
+  int64_t n_tiles, cap;
+};
+
+__host__ __device__ static inline int64_t ug_align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+static inline ug_ws_view ug_ws_make(void *ws, int64_t n_rays, int32_t S) {
+  ug_ws_view v;
+  v.n_tiles = (n_rays + UG_WAVE - 1) / UG_WAVE;
+  v.cap = (int64_t)UG_WAVE * S;
+  char *b = (char *)ws + 256;  // first 256 B: dynamic tile counter of the shade kernel
+  v.count = (int32_t *)b;
+  b += ug_align256(v.n_tiles * (int64_t)sizeof(int32_t));
+  v.ent = (float4 *)b;
+  b += ug_align256(v.n_tiles * v.cap * (int64_t)sizeof(float4));
+  v.slot = (uint8_t *)b;
+  return v;
+}
+
+// blockIdx -> tile-group mapping: the dispatcher places block b on XCD (b % 8); give every XCD one
+// contiguous eighth of the ray range so neighbouring image rows share that XCD's L2.
+__device__ __forceinline__ int64_t ug_xcd_remap(int64_t b, int64_t nblocks) {
+  const int64_t per = (nblocks + 7) / 8;
+  return (b % 8) * per + b / 8;  // may be >= nblocks: caller skips
+}
+
+struct ug_march_args {
+  int64_t n_rays;
+  int32_t S, X, Y, Z;
+  float cx, cy, cz, rx, ry, rz;        // scene centre / radius
+  float lox, loy, loz, hix, hiy, hiz;  // contracted bounds
+  float ex, ey, ez, irx, iry, irz;     // extent hi-lo and RN(1/extent) per axis (host computed)
+  float B, A;                          // 1+bg_len, bg_len (as fp32)
+  float shift, interval, thres;
+};
+
+// one density level: in-range cell set-up + one 32-byte brick + trilinear in grid_sample's order.
+// `lvl` is the (wave-uniform) base of this level's bricks; the per-lane offset stays 32-bit.
+__device__ __forceinline__ float ug_density_level(const char *__restrict__ lvl, float cx, float cy, float cz,
+                                                  int X, int Y, int Z) {
+  const ug_axis_fast ax = ug_axis_inrange(cx, X), ay = ug_axis_inrange(cy, Y), az = ug_axis_inrange(cz, Z);
+  const unsigned rec = ((unsigned)ax.cell * (unsigned)(Y - 1) + (unsigned)ay.cell) * (unsigned)(Z - 1) + (unsigned)az.cell;
+  const float4 *b = (const float4 *)(lvl + (size_t)(rec * 32u));
+  const float4 v0 = b[0], v1 = b[1];
+  const float w00 = az.wlo * ay.wlo, w01 = az.whi * ay.wlo, w10 = az.wlo * ay.whi, w11 = az.whi * ay.whi;
+  float acc = v0.x * (w00 * ax.wlo);
+  acc += v0.y * (w01 * ax.wlo);
+  acc += v0.z * (w10 * ax.wlo);
+  acc += v0.w * (w11 * ax.wlo);
+  acc += v1.x * (w00 * ax.whi);
+  acc += v1.y * (w01 * ax.whi);
+  acc += v1.z * (w10 * ax.whi);
+  acc += v1.w * (w11 * ax.whi);
+  return acc;
+}
+
+// March one 64-ray tile (lane = ray): writes alphainv_last / depth for the tile's rays, appends the
+// survivors to ent/slot (this wave's private list) and returns their count (wave-uniform).
+template <int F, bool L2>
+__device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float *__restrict__ rays_o,
+                                             const float *__restrict__ rays_d, const float *__restrict__ t_table,
+                                             const float *__restrict__ s_table, const float *__restrict__ bricks,
+                                             float *__restrict__ alphainv_last, float *__restrict__ depth,
+                                             int64_t tile, float4 *__restrict__ ent, uint8_t *__restrict__ slot) {
+  constexpr int P = 2 * F + 1;
+  const int lane = ug_lane();
+  const int64_t ray = tile * UG_WAVE + lane;
+  const bool valid = ray < a.n_rays;
+
+  float ox = 0.f, oy = 0.f, oz = 0.f, dx = 0.f, dy = 0.f, dz = 1.f;
+  if (valid) {
+    const float rox = rays_o[3 * ray], roy = rays_o[3 * ray + 1], roz = rays_o[3 * ray + 2];
+    const float rdx = rays_d[3 * ray], rdy = rays_d[3 * ray + 1], rdz = rays_d[3 * ray + 2];
+    ox = (rox - a.cx) / a.rx; oy = (roy - a.cy) / a.ry; oz = (roz - a.cz) / a.rz;
+    const float dn = ug_norm3_torch(rdx, rdy, rdz);
+    dx = rdx / dn; dy = rdy / dn; dz = rdz / dn;
+  }
+
+  const size_t lvl_bytes = (size_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1) * 32;  // < 4 GiB per level (G <= 512)
+  const char *__restrict__ bkb = (const char *)bricks;
+
+  float T = 1.f, dsum = 0.f;
+  bool done = !valid;
+  int nsurv = 0;  // wave-uniform
+
+  for (int j = 0; j < a.S; ++j) {
+    if (__ballot(!done) == 0ull) break;  // every ray of this wave has terminated
+    bool surv = false;
+    float w = 0.f;
+    float px = 0.f, py = 0.f, pz = 0.f;
+    if (!done) {
+      const float t = t_table[j];
+      px = ox + dx * t; py = oy + dy * t; pz = oz + dz * t;
+      // contraction p/|p| * (B - A/|p|) outside the unit cube / ball (FourierGrid_model.py:534-548)
+      const float nrm = L2 ? ug_norm3_torch(px, py, pz) : fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz)));
+      if (!(nrm <= 1.0f)) {
+        const float rn = ug_rcp_refined(nrm);
+        const float sc = a.B - ug_div_r(a.A, nrm, rn);
+        px = ug_div_r(px, nrm, rn) * sc;
+        py = ug_div_r(py, nrm, rn) * sc;
+        pz = ug_div_r(pz, nrm, rn) * sc;
+      }
+      // ((p - lo) / (hi - lo)) * 2 - 1
+      const float ux = ug_div_r(px - a.lox, a.ex, a.irx) * 2.f - 1.f;
+      const float uy = ug_div_r(py - a.loy, a.ey, a.iry) * 2.f - 1.f;
+      const float uz = ug_div_r(pz - a.loz, a.ez, a.irz) * 2.f - 1.f;
+      float dens = ug_density_level(bkb, ux, uy, uz, a.X, a.Y, a.Z);
+#pragma unroll
+      for (int k = 0; k < F; ++k) {
+        const float f = (float)(1 << k);
+        float sx, cx_, sy, cy_, sz, cz_;
+        ug_sincos(f * ux, &sx, &cx_);
+        ug_sincos(f * uy, &sy, &cy_);
+        ug_sincos(f * uz, &sz, &cz_);
+        dens += ug_density_level(bkb + (size_t)(2 * k + 1) * lvl_bytes, sx, sy, sz, a.X, a.Y, a.Z);
+        dens += ug_density_level(bkb + (size_t)(2 * k + 2) * lvl_bytes, cx_, cy_, cz_, a.X, a.Y, a.Z);
+      }
+      dens = dens / (float)P;
+      const float xs = dens + a.shift;
+      const float alpha = ug_alpha(xs, a.interval);
+      if (alpha > a.thres) {
+        w = T * alpha;
+        T = (float)((double)T * (1. - (double)alpha));
+        if (w > a.thres) {
+          surv = true;
+          dsum += w * s_table[j];
+        }
+        if ((double)T < 1e-3) done = true;
+      }
+    }
+    const unsigned long long m = __ballot(surv);
+    if (m != 0ull) {
+      if (surv) {
+        const int idx = nsurv + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32),
+                                                          __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        ent[idx] = make_float4(px, py, pz, w);
+        slot[idx] = (uint8_t)lane;
+      }
+      nsurv += __popcll(m);
+    }
+  }
+  if (valid) {
+    alphainv_last[ray] = T;
+    depth[ray] = dsum;
+  }
+  return nsurv;
+}
+
+// ----------------------------------------------------------------------------------------------
+// rgbnet packing for the transposed MFMA chain
+// packed (floats): A1 [KL][64][4] | A2 [64][64][4] | bias1 [2][64] | bias2 [2][64] | W3 [2][64][4] | b3 [4]
+// ----------------------------------------------------------------------------------------------
+__host__ __device__ static inline int ug_feat_of(int o, int r, int h) { return 32 * o + (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+struct ug_mlp_layout { int KL, offA1, offA2, offB1, offB2, offW3, offb3, total; };
+__host__ __device__ static inline ug_mlp_layout ug_mlp_lay(int C, int n_emb) {
+  const int CH = (C + 1) / 2;
+  ug_mlp_layout L;
+  L.KL = (2 * CH + n_emb + 1) / 2;
+  L.offA1 = 0;
+  L.offA2 = L.offA1 + L.KL * 256;
+  L.offB1 = L.offA2 + 64 * 256;
+  L.offB2 = L.offB1 + 128;
+  L.offW3 = L.offB2 + 128;
+  L.offb3 = L.offW3 + 512;
+  L.total = L.offb3 + 4;
+  return L;
+}
+
+// original rgbnet input column of (step s, half h); -1 = zero padding
+__host__ __device__ static inline int ug_in_col(int s, int h, int C, int n_emb, int KL) {
+  const int CH = (C + 1) / 2;
+  if (s < CH) {
+    const int ch = h * CH + s;
+    return ch < C ? ch : -1;
+  }
+  const int e = h * (KL - CH) + (s - CH);
+  return e < n_emb ? C + e : -1;
+}
+
+// ----------------------------------------------------------------------------------------------
+// shade
+// ----------------------------------------------------------------------------------------------
+struct ug_shade_args {
+  int64_t n_rays;
+  int32_t X, Y, Z;
+  float lox, loy, loz, hix, hiy, hiz;
+  float ex, ey, ez, irx, iry, irz;  // extent hi-lo and RN(1/extent)
+};
+
+// one k0 level for one survivor half: in-range cell set-up + one contiguous (8*CH)-float half-brick,
+// trilinear per channel in grid_sample's corner order; adds into feat[] (first = level 0 initialises).
+template <int CH>
+__device__ __forceinline__ void ug_k0_level(const float *__restrict__ k0b, int h, int64_t level_base, float cx,
+                                            float cy, float cz, int X, int Y, int Z, bool first, float (&feat)[CH]) {
+  const ug_axis_fast ax = ug_axis_inrange(cx, X), ay = ug_axis_inrange(cy, Y), az = ug_axis_inrange(cz, Z);
+  const int64_t rec = level_base + ((int64_t)ax.cell * (Y - 1) + ay.cell) * (Z - 1) + az.cell;
+  const float *rec_p = k0b + (rec * 2 + h) * (8 * CH);
+  float v[8 * CH];
+  if constexpr ((8 * CH) % 4 == 0) {
+    const float4 *r4 = (const float4 *)rec_p;
+#pragma unroll
+    for (int q = 0; q < 2 * CH; ++q) {
+      const float4 t = r4[q];
+      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 8 * CH; ++q) v[q] = rec_p[q];
+  }
+  const float w00 = az.wlo * ay.wlo, w01 = az.whi * ay.wlo, w10 = az.wlo * ay.whi, w11 = az.whi * ay.whi;
+  const float w[8] = {w00 * ax.wlo, w01 * ax.wlo, w10 * ax.wlo, w11 * ax.wlo,
+                      w00 * ax.whi, w01 * ax.whi, w10 * ax.whi, w11 * ax.whi};
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) {
+    float acc = v[ch] * w[0];
+#pragma unroll
+    for (int c = 1; c < 8; ++c) acc += v[c * CH + ch] * w[c];
+    feat[ch] = first ? acc : feat[ch] + acc;
+  }
+}
+
+// k0 half-brick gather for one survivor: CH channels of half h, mean over P = 1+2F levels
+// (level order u, sin u, cos u, sin 2u, cos 2u, ... -- FourierGrid_grid.py:70)
+template <int F, int CH>
+__device__ __forceinline__ void ug_k0_gather(const float *__restrict__ k0b, int h, float px, float py, float pz,
+                                             const ug_shade_args &a, float (&feat)[CH]) {
+  constexpr int P = 2 * F + 1;
+  const float ux = ug_div_r(px - a.lox, a.ex, a.irx) * 2.f - 1.f;
+  const float uy = ug_div_r(py - a.loy, a.ey, a.iry) * 2.f - 1.f;
+  const float uz = ug_div_r(pz - a.loz, a.ez, a.irz) * 2.f - 1.f;
+  const int64_t cells = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1);
+  ug_k0_level<CH>(k0b, h, 0, ux, uy, uz, a.X, a.Y, a.Z, true, feat);
+#pragma unroll 1
+  for (int k = 0; k < F; ++k) {
+    const float f = (float)(1 << k);
+    float sx, cx_, sy, cy_, sz, cz_;
+    ug_sincos(f * ux, &sx, &cx_);
+    ug_sincos(f * uy, &sy, &cy_);
+    ug_sincos(f * uz, &sz, &cz_);
+    ug_k0_level<CH>(k0b, h, (int64_t)(2 * k + 1) * cells, sx, sy, sz, a.X, a.Y, a.Z, false, feat);
+    ug_k0_level<CH>(k0b, h, (int64_t)(2 * k + 2) * cells, cx_, cy_, cz_, a.X, a.Y, a.Z, false, feat);
+  }
+#pragma unroll
+  for (int ch = 0; ch < CH; ++ch) feat[ch] = feat[ch] / (float)P;
+}
+
+__device__ __forceinline__ float ug_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+
+// LDS-resident packed rgbnet (A operands of the transposed MFMA chain)
+struct ug_mlp_lds { const float4 *A1, *A2, *W3; const float *B1, *B2, *b3; };
+
+template <int C, int PE>
+__device__ __forceinline__ ug_mlp_lds ug_mlp_stage(float *lds, const float *__restrict__ mlp) {
+  const ug_mlp_layout ML = ug_mlp_lay(C, 3 + 6 * PE);
+  for (int i = threadIdx.x; i < ML.total; i += blockDim.x) lds[i] = mlp[i];
+  __syncthreads();
+  ug_mlp_lds m;
+  m.A1 = (const float4 *)(lds + ML.offA1);
+  m.A2 = (const float4 *)(lds + ML.offA2);
+  m.B1 = lds + ML.offB1;
+  m.B2 = lds + ML.offB2;
+  m.W3 = (const float4 *)(lds + ML.offW3);
+  m.b3 = lds + ML.offb3;
+  return m;
+}
+
+// Shade one tile's survivor list (32 survivors per pass, lanes l / l+32 pair up) and write the tile's
+// rgb_marched.  C = 2*CH or 2*CH-1 k0 channels, PE view-direction frequencies; rgbnet 128 wide, 3 layers.
+template <int F, int C, int PE>
+__device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const float *__restrict__ viewdirs,
+                                              const float *__restrict__ k0b, const ug_mlp_lds &M, int64_t tile,
+                                              int count, const float4 *__restrict__ ent,
+                                              const uint8_t *__restrict__ slot, float *__restrict__ rgb_marched) {
+  constexpr int CH = (C + 1) / 2;
+  constexpr int NEMB = 3 + 6 * PE;
+  constexpr int KL = (2 * CH + NEMB + 1) / 2;
+  const int lane = ug_lane();
+  const int h = lane >> 5, sv = lane & 31;
+  float accr = 0.f, accg = 0.f, accb = 0.f;  // lane = ray slot of this tile
+
+  for (int base = 0; base < count; base += 32) {
+    const int e = base + sv;
+    const bool ok = e < count;
+    float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
+    int sl = 0;
+    if (ok) { en = ent[e]; sl = slot[e]; }
+    // ---- layer-1 inputs of this lane: half of k0 + half of the view-direction embedding
+    float x[KL];
+    {
+      float feat[CH];
+      ug_k0_gather<F, CH>(k0b, h, en.x, en.y, en.z, a, feat);
+#pragma unroll
+      for (int s = 0; s < CH; ++s) x[s] = (h * CH + s < C) ? feat[s] : 0.f;
+      int64_t ray = tile * UG_WAVE + sl;
+      if (ray >= a.n_rays) ray = a.n_rays - 1;
+      const float vx = viewdirs[3 * ray], vy = viewdirs[3 * ray + 1], vz = viewdirs[3 * ray + 2];
+      float emb[NEMB];
+      emb[0] = vx; emb[1] = vy; emb[2] = vz;
+#pragma unroll
+      for (int ax = 0; ax < 3; ++ax) {
+        const float v = ax == 0 ? vx : (ax == 1 ? vy : vz);
+#pragma unroll
+        for (int k = 0; k < PE; ++k) {
+          float s_, c_;
+          ug_sincos(v * (float)(1 << k), &s_, &c_);
+          emb[3 + ax * PE + k] = s_;
+          emb[3 + 3 * PE + ax * PE + k] = c_;
+        }
+      }
+#pragma unroll
+      for (int s = CH; s < KL; ++s) {
+        const int e0 = s - CH, e1 = (KL - CH) + (s - CH);
+        const float lo = emb[e0];
+        const float hi = (e1 < NEMB) ? emb[e1 < NEMB ? e1 : 0] : 0.f;
+        x[s] = h ? hi : lo;
+      }
+    }
+    // ---- layer 1: acc1[o] = W0 . x  (A from LDS, B = x registers)
+    f32x16 acc1[4], acc2[4];
+    int bo = h * 64;
+    asm volatile("" : "+v"(bo));  // keeps the 128 bias reads inside the pass (LICM would hoist + spill them)
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc1[o][r] = M.B1[bo + o * 16 + r];
+#pragma unroll
+    for (int s = 0; s < KL; ++s) {
+      const float4 wa = M.A1[s * 64 + lane];
+      acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, x[s], acc1[0], 0, 0, 0);
+      acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, x[s], acc1[1], 0, 0, 0);
+      acc1[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, x[s], acc1[2], 0, 0, 0);
+      acc1[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, x[s], acc1[3], 0, 0, 0);
+      if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the A-operand prefetch depth
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc1[o][r] = fmaxf(acc1[o][r], 0.f);
+        acc2[o][r] = M.B2[bo + o * 16 + r];
+      }
+    // ---- layer 2: the accumulators of layer 1 ARE the B operands (k = lane>>5 picks feature +0/+4)
+#pragma unroll
+    for (int st = 0; st < 64; ++st) {
+      const float4 wa = M.A2[st * 64 + lane];
+      const float xb = acc1[st >> 4][st & 15];
+      acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, xb, acc2[0], 0, 0, 0);
+      acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, xb, acc2[1], 0, 0, 0);
+      acc2[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, xb, acc2[2], 0, 0, 0);
+      acc2[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, xb, acc2[3], 0, 0, 0);
+      if ((st & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- layer 3 (3 outputs) on the VALU: each lane of the pair reduces its 64 features
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+#pragma unroll
+    for (int st = 0; st < 64; ++st) {
+      const float hv = fmaxf(acc2[st >> 4][st & 15], 0.f);
+      const float4 w3 = M.W3[bo + st];
+      l0 = fmaf(w3.x, hv, l0);
+      l1 = fmaf(w3.y, hv, l1);
+      l2 = fmaf(w3.z, hv, l2);
+    }
+    l0 = (l0 + __shfl_xor(l0, 32)) + M.b3[0];
+    l1 = (l1 + __shfl_xor(l1, 32)) + M.b3[1];
+    l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
+    // weights.unsqueeze(-1) * rgb, then a per-ray sum in sample order (segment_coo semantics)
+    const float pr = en.w * ug_sigmoid(l0), pg = en.w * ug_sigmoid(l1), pb = en.w * ug_sigmoid(l2);
+    const int cnt = (count - base) < 32 ? (count - base) : 32;
+    for (int k = 0; k < cnt; ++k) {
+      const int sk = __builtin_amdgcn_readlane(sl, k);
+      const float r_ = ug_readlane_f(pr, k), g_ = ug_readlane_f(pg, k), b_ = ug_readlane_f(pb, k);
+      if (lane == sk) { accr += r_; accg += g_; accb += b_; }
+    }
+  }
+  const int64_t ray = tile * UG_WAVE + lane;
+  if (ray < a.n_rays) {
+    rgb_marched[3 * ray] = accr;
+    rgb_marched[3 * ray + 1] = accg;
+    rgb_marched[3 * ray + 2] = accb;
+  }
+}
+
+// dynamic tile scheduling with XCD affinity: the tile range is cut into 8 contiguous eighths, one atomic
+// counter each; a workgroup (XCD = blockIdx % 8) drains its own eighth first, then steals from the others.
+// Placement only affects speed, never results.  Returns -1 when every eighth is exhausted.
+__device__ __forceinline__ int64_t ug_next_tile(int32_t *__restrict__ tile_counter, int64_t n_tiles, int home,
+                                                int &victim) {
+  const int64_t per = (n_tiles + 7) / 8;
+  const int lane = ug_lane();
+  while (victim < 8) {
+    const int q = (home + victim) & 7;
+    int t = 0;
+    if (lane == 0) t = atomicAdd(tile_counter + q, 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    const int64_t cand = (int64_t)q * per + t;
+    if (t < per && cand < n_tiles) return cand;
+    ++victim;
+  }
+  return -1;
+}
+
+
+#define ST(s) ((hipStream_t)(s))
+
+static inline int ug_fill_march_args(const ugrid_render_params *p, ug_march_args &a) {
+  if (p->n_samples <= 0 || p->grid_x < 2 || p->grid_y < 2 || p->grid_z < 2) return (int)hipErrorInvalidValue;
+  if ((int64_t)(p->grid_x - 1) * (p->grid_y - 1) * (p->grid_z - 1) * 32 >= ((int64_t)1 << 32)) return (int)hipErrorInvalidValue;
+  a.n_rays = p->n_rays; a.S = p->n_samples; a.X = p->grid_x; a.Y = p->grid_y; a.Z = p->grid_z;
+  a.cx = p->scene_center[0]; a.cy = p->scene_center[1]; a.cz = p->scene_center[2];
+  a.rx = p->scene_radius[0]; a.ry = p->scene_radius[1]; a.rz = p->scene_radius[2];
+  a.lox = p->xyz_min[0]; a.loy = p->xyz_min[1]; a.loz = p->xyz_min[2];
+  a.hix = p->xyz_max[0]; a.hiy = p->xyz_max[1]; a.hiz = p->xyz_max[2];
+  a.ex = a.hix - a.lox; a.ey = a.hiy - a.loy; a.ez = a.hiz - a.loz;   // fp32, like (xyz_max - xyz_min)
+  a.irx = 1.0f / a.ex; a.iry = 1.0f / a.ey; a.irz = 1.0f / a.ez;       // IEEE RN(1/extent)
+  // python: B = 1 + bg_len, A = B*1 - 1 (doubles) then cast to fp32 when they meet the tensor
+  const double Bd = 1.0 + (double)p->bg_len;
+  a.B = (float)Bd; a.A = (float)(Bd * 1.0 - 1.0);
+  a.shift = p->act_shift; a.interval = p->interval; a.thres = p->thres;
+  return 0;
+}
+
+static inline void ug_fill_shade_args(const ugrid_render_params *p, ug_shade_args &a) {
+  a.n_rays = p->n_rays; a.X = p->grid_x; a.Y = p->grid_y; a.Z = p->grid_z;
+  a.lox = p->xyz_min[0]; a.loy = p->xyz_min[1]; a.loz = p->xyz_min[2];
+  a.hix = p->xyz_max[0]; a.hiy = p->xyz_max[1]; a.hiz = p->xyz_max[2];
+  a.ex = a.hix - a.lox; a.ey = a.hiy - a.loy; a.ez = a.hiz - a.loz;
+  a.irx = 1.0f / a.ex; a.iry = 1.0f / a.ey; a.irz = 1.0f / a.ez;
+}
+

@@ -1,0 +1,320 @@
+// libugrid_hip.so -- shade half of the fused render path (rgbnet on fp32 MFMA), the single-launch
+// variant and the rgbnet packing kernel.  Default optimisation flags.
+#include "ugrid_render.h"
+
+extern "C" int ug_set_march_waves(int w);  // ugrid_march.hip
+
+__global__ void k_pack_mlp(const float *__restrict__ w0, const float *__restrict__ b0,
+                           const float *__restrict__ w1, const float *__restrict__ b1,
+                           const float *__restrict__ w2, const float *__restrict__ b2, int C, int n_emb,
+                           float *__restrict__ out) {
+  const ug_mlp_layout L = ug_mlp_lay(C, n_emb);
+  const int mlp_in = C + n_emb;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L.total; i += gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (i < L.offA2) {                       // A1[s][lane][o] = W0[32o + (lane&31)][col(s, lane>>5)]
+      const int o = i & 3, lane = (i >> 2) & 63, s = i >> 8;
+      const int col = ug_in_col(s, lane >> 5, C, n_emb, L.KL);
+      if (col >= 0) v = w0[(32 * o + (lane & 31)) * mlp_in + col];
+    } else if (i < L.offB1) {                // A2[(o',r)][lane][o] = W1[32o + (lane&31)][feat(o',r,lane>>5)]
+      const int q = i - L.offA2;
+      const int o = q & 3, lane = (q >> 2) & 63, st = q >> 8;
+      v = w1[(32 * o + (lane & 31)) * 128 + ug_feat_of(st >> 4, st & 15, lane >> 5)];
+    } else if (i < L.offB2) {                // bias1[h][o*16+r]
+      const int q = i - L.offB1;
+      v = b0[ug_feat_of((q & 63) >> 4, q & 15, q >> 6)];
+    } else if (i < L.offW3) {
+      const int q = i - L.offB2;
+      v = b1[ug_feat_of((q & 63) >> 4, q & 15, q >> 6)];
+    } else if (i < L.offb3) {                // W3[h][o*16+r][c]
+      const int q = i - L.offW3;
+      const int c = q & 3, st = (q >> 2) & 63, h = q >> 8;
+      if (c < 3) v = w2[c * 128 + ug_feat_of(st >> 4, st & 15, h)];
+    } else {
+      const int c = i - L.offb3;
+      if (c < 3) v = b2[c];
+    }
+    out[i] = v;
+  }
+}
+
+// persistent shade kernel over a work list written by k_march (two-kernel path)
+template <int F, int C, int PE, int NW>
+__global__ void __launch_bounds__(NW * 64, NW / 4)
+k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
+            const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
+            int32_t *__restrict__ tile_counter) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const ug_mlp_lds M = ug_mlp_stage<C, PE>(lds, mlp);
+  int victim = 0;
+  for (;;) {
+    const int64_t tile = ug_next_tile(tile_counter, ws.n_tiles, blockIdx.x & 7, victim);
+    if (tile < 0) break;
+    ug_shade_tile<F, C, PE>(a, viewdirs, k0b, M, tile, ws.count[tile], ws.ent + tile * ws.cap,
+                            ws.slot + tile * ws.cap, rgb_marched);
+  }
+}
+
+// Single-launch render: every persistent wave marches a 64-ray tile and immediately shades the survivors
+// it found (its list lives in that wave's private scratch slot and is still L2-resident).  Waves of one CU
+// sit in different phases, so the VALU-bound march of some overlaps the MFMA-bound rgbnet of others.
+template <int F, bool L2, int C, int PE, int NW>
+__global__ void __launch_bounds__(NW * 64, NW / 4)
+k_render_fused(ug_march_args am, ug_shade_args as, const float *__restrict__ rays_o,
+               const float *__restrict__ rays_d, const float *__restrict__ viewdirs,
+               const float *__restrict__ t_table, const float *__restrict__ s_table,
+               const float *__restrict__ dens_bricks, const float *__restrict__ k0b,
+               const float *__restrict__ mlp, float *__restrict__ alphainv_last, float *__restrict__ depth,
+               float *__restrict__ rgb_marched, float4 *__restrict__ scratch_ent,
+               uint8_t *__restrict__ scratch_slot, unsigned long long *__restrict__ survivors_total,
+               int32_t *__restrict__ tile_counter, int64_t n_tiles) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const ug_mlp_lds M = ug_mlp_stage<C, PE>(lds, mlp);
+  const int64_t cap = (int64_t)UG_WAVE * am.S;
+  const int64_t wslot = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+  float4 *__restrict__ ent = scratch_ent + wslot * cap;
+  uint8_t *__restrict__ slot = scratch_slot + wslot * cap;
+  int victim = 0;
+  long long total = 0;
+  for (;;) {
+    const int64_t tile = ug_next_tile(tile_counter, n_tiles, blockIdx.x & 7, victim);
+    if (tile < 0) break;
+    const int count = ug_march_tile<F, L2>(am, rays_o, rays_d, t_table, s_table, dens_bricks, alphainv_last,
+                                           depth, tile, ent, slot);
+    // the list was written by this wave: make the stores visible to its own loads
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    ug_shade_tile<F, C, PE>(as, viewdirs, k0b, M, tile, count, ent, slot, rgb_marched);
+    total += count;
+  }
+  if (ug_lane() == 0 && total) atomicAdd(survivors_total, (unsigned long long)total);
+}
+
+// rgbnet == None: rgb = sigmoid(k0), k0 is a single-level 3-channel grid (bricks [8][4], ch 3 = 0)
+__global__ void __launch_bounds__(256)
+k_shade_direct(ug_shade_args a, const float *__restrict__ k0b, ug_ws_view ws,
+               float *__restrict__ rgb_marched) {
+  const int lane = ug_lane();
+  const int64_t tile = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (tile >= ws.n_tiles) return;
+  const int count = ws.count[tile];
+  const float4 *__restrict__ ent = ws.ent + tile * ws.cap;
+  const uint8_t *__restrict__ slot = ws.slot + tile * ws.cap;
+  float accr = 0.f, accg = 0.f, accb = 0.f;
+  for (int base = 0; base < count; base += UG_WAVE) {
+    const int e = base + lane;
+    const bool ok = e < count;
+    float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
+    int sl = 0;
+    if (ok) { en = ent[e]; sl = slot[e]; }
+    const float ux = ug_div_r(en.x - a.lox, a.ex, a.irx) * 2.f - 1.f;
+    const float uy = ug_div_r(en.y - a.loy, a.ey, a.iry) * 2.f - 1.f;
+    const float uz = ug_div_r(en.z - a.loz, a.ez, a.irz) * 2.f - 1.f;
+    const ug_cellw cw = ug_cell_setup(ux, uy, uz, a.X, a.Y, a.Z, 0);
+    const float4 *rec = (const float4 *)(k0b + cw.rec * 32);
+    float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      const float4 v = rec[c];
+      if (c == 0) { f0 = v.x * cw.w[0]; f1 = v.y * cw.w[0]; f2 = v.z * cw.w[0]; }
+      else { f0 += v.x * cw.w[c]; f1 += v.y * cw.w[c]; f2 += v.z * cw.w[c]; }
+    }
+    const float pr = en.w * ug_sigmoid(f0), pg = en.w * ug_sigmoid(f1), pb = en.w * ug_sigmoid(f2);
+    const int cnt = (count - base) < UG_WAVE ? (count - base) : UG_WAVE;
+    for (int k = 0; k < cnt; ++k) {
+      const int sk = __builtin_amdgcn_readlane(sl, k);
+      const float r_ = ug_readlane_f(pr, k), g_ = ug_readlane_f(pg, k), b_ = ug_readlane_f(pb, k);
+      if (lane == sk) { accr += r_; accg += g_; accb += b_; }
+    }
+  }
+  const int64_t ray = tile * UG_WAVE + lane;
+  if (ray < a.n_rays) {
+    rgb_marched[3 * ray] = accr;
+    rgb_marched[3 * ray + 1] = accg;
+    rgb_marched[3 * ray + 2] = accb;
+  }
+}
+
+__global__ void k_ws_stats(const int32_t *__restrict__ count, int64_t n_tiles, int64_t *__restrict__ out) {
+  int64_t s = 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_tiles; i += (int64_t)gridDim.x * blockDim.x)
+    s += count[i];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if (ug_lane() == 0 && s) atomicAdd((unsigned long long *)out, (unsigned long long)s);
+}
+
+
+// ----------------------------------------------------------------------------------------------
+// C ABI
+// ----------------------------------------------------------------------------------------------
+extern "C" int64_t ugrid_mlp_packed_bytes(int32_t k0_channels, int32_t viewbase_pe) {
+  return (int64_t)sizeof(float) * ug_mlp_lay(k0_channels, 3 + 6 * viewbase_pe).total;
+}
+
+extern "C" int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1, const float *b1,
+                              const float *w2, const float *b2, int32_t k0_channels, int32_t viewbase_pe,
+                              int32_t width, float *packed, ugrid_stream_t s) {
+  if (width != 128) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_pack_mlp, dim3(64), dim3(256), 0, ST(s), w0, b0, w1, b1, w2, b2, (int)k0_channels,
+                     3 + 6 * (int)viewbase_pe, packed);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- single-launch fused render -----------------------------------------------------------------
+#define UG_FUSED_NW 12  // slots are sized for the largest variant
+static int g_fused_waves = 12;
+#define UG_FUSED_MAX_WGS 256
+
+extern "C" int64_t ugrid_render_fused_ws_bytes(int32_t n_samples) {
+  const int64_t slots = (int64_t)UG_FUSED_MAX_WGS * UG_FUSED_NW, cap = (int64_t)UG_WAVE * n_samples;
+  return 256 + ug_align256(slots * cap * 16) + ug_align256(slots * cap);
+}
+
+template <int F, bool L2, int C, int PE, int NW>
+static int ug_fused_launch_nw(const ug_march_args &am, const ug_shade_args &as, const float *rays_o,
+                           const float *rays_d, const float *viewdirs, const float *t_table,
+                           const float *s_table, const float *dens_bricks, const float *k0b, const float *mlp,
+                           float *alphainv_last, float *depth, float *rgb, void *ws_mem, hipStream_t st) {
+  const int lds_bytes = (int)sizeof(float) * ug_mlp_lay(C, 3 + 6 * PE).total;
+  static bool attr_set = false;
+  if (!attr_set) {
+    UG_HIP(hipFuncSetAttribute((const void *)k_render_fused<F, L2, C, PE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_set = true;
+  }
+  const int64_t n_tiles = (am.n_rays + UG_WAVE - 1) / UG_WAVE;
+  const int64_t slots = (int64_t)UG_FUSED_MAX_WGS * NW, cap = (int64_t)UG_WAVE * am.S;
+  char *base = (char *)ws_mem;
+  UG_HIP(hipMemsetAsync(base, 0, 256, st));  // 8 tile counters @0, survivor total @64
+  float4 *ent = (float4 *)(base + 256);
+  uint8_t *slot = (uint8_t *)(base + 256 + ug_align256(slots * cap * 16));
+  int64_t wgs = (n_tiles + NW - 1) / NW;
+  if (wgs > UG_FUSED_MAX_WGS) wgs = UG_FUSED_MAX_WGS;
+  wgs = (wgs + 7) / 8 * 8;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_render_fused<F, L2, C, PE, NW>), dim3((unsigned)wgs), dim3(NW * 64), lds_bytes,
+                     st, am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks, k0b, mlp, alphainv_last,
+                     depth, rgb, ent, slot, (unsigned long long *)(base + 64), (int32_t *)base, n_tiles);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int F, bool L2, int C, int PE>
+static int ug_fused_launch(const ug_march_args &am, const ug_shade_args &as, const float *rays_o,
+                           const float *rays_d, const float *viewdirs, const float *t_table,
+                           const float *s_table, const float *dens_bricks, const float *k0b, const float *mlp,
+                           float *alphainv_last, float *depth, float *rgb, void *ws_mem, hipStream_t st) {
+  if (g_fused_waves == 8)
+    return ug_fused_launch_nw<F, L2, C, PE, 8>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks, k0b,
+                                               mlp, alphainv_last, depth, rgb, ws_mem, st);
+  return ug_fused_launch_nw<F, L2, C, PE, 12>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks, k0b,
+                                              mlp, alphainv_last, depth, rgb, ws_mem, st);
+}
+
+extern "C" int ugrid_render_fused(const ugrid_render_params *p, const float *rays_o, const float *rays_d,
+                                  const float *viewdirs, const float *t_table, const float *s_table,
+                                  const float *density_bricks, const float *k0_bricks, const float *mlp_packed,
+                                  float *alphainv_last, float *depth, float *rgb_marched, void *ws_mem,
+                                  ugrid_stream_t s) {
+  if (p->n_rays <= 0) return 0;
+  if (p->mlp_in == 0 || p->mlp_width != 128 || p->mlp_in != p->k0_channels + 3 + 6 * p->viewbase_pe)
+    return (int)hipErrorNotSupported;  // rgbnet-less models use the two-kernel path
+  ug_march_args am;
+  const int rc = ug_fill_march_args(p, am);
+  if (rc) return rc;
+  ug_shade_args as;
+  ug_fill_shade_args(p, as);
+#define UG_FUSED_CASE(F_, C_, PE_)                                                                        \
+  if (p->freq_num == F_ && p->k0_channels == C_ && p->viewbase_pe == PE_) {                               \
+    if (p->norm_l2)                                                                                       \
+      return ug_fused_launch<F_, true, C_, PE_>(am, as, rays_o, rays_d, viewdirs, t_table, s_table,       \
+                                                density_bricks, k0_bricks, mlp_packed, alphainv_last,     \
+                                                depth, rgb_marched, ws_mem, ST(s));                       \
+    return ug_fused_launch<F_, false, C_, PE_>(am, as, rays_o, rays_d, viewdirs, t_table, s_table,        \
+                                               density_bricks, k0_bricks, mlp_packed, alphainv_last,      \
+                                               depth, rgb_marched, ws_mem, ST(s));                        \
+  }
+  UG_FUSED_CASE(3, 12, 4)
+  UG_FUSED_CASE(4, 12, 4)
+  UG_FUSED_CASE(2, 3, 2)
+  UG_FUSED_CASE(3, 3, 2)
+  UG_FUSED_CASE(1, 12, 4)
+#undef UG_FUSED_CASE
+  return (int)hipErrorNotSupported;
+}
+
+extern "C" int ugrid_render_fused_stats(const void *ws_mem, int64_t *d_stats, ugrid_stream_t s) {
+  return (int)hipMemcpyAsync(d_stats, (const char *)ws_mem + 64, sizeof(int64_t), hipMemcpyDeviceToDevice, ST(s));
+}
+
+static int g_shade_waves = 12;  // waves per shade workgroup: 8 (2/SIMD, no spills) or 12 (3/SIMD)
+
+extern "C" int ugrid_tune(const char *key, int value) {
+  if (!key) return (int)hipErrorInvalidValue;
+  if (!strcmp(key, "shade_waves") && (value == 8 || value == 12)) { g_shade_waves = value; return 0; }
+  if (!strcmp(key, "march_waves")) return ug_set_march_waves(value) ? (int)hipErrorInvalidValue : 0;
+  if (!strcmp(key, "fused_waves") && (value == 8 || value == 12)) { g_fused_waves = value; return 0; }
+  return (int)hipErrorInvalidValue;
+}
+
+template <int F, int C, int PE, int NW>
+static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
+                              ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
+  const int lds_bytes = (int)sizeof(float) * ug_mlp_lay(C, 3 + 6 * PE).total;
+  static bool attr_set = false;
+  if (!attr_set) {
+    UG_HIP(hipFuncSetAttribute((const void *)k_shade_mlp<F, C, PE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_set = true;
+  }
+  UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
+  // persistent: one workgroup per CU (LDS holds the 89 KB packed rgbnet)
+  int64_t wgs = (ws.n_tiles + NW - 1) / NW;
+  if (wgs > 256) wgs = 256;
+  wgs = (wgs + 7) / 8 * 8;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_mlp<F, C, PE, NW>), dim3((unsigned)wgs), dim3(NW * 64), lds_bytes, st, a,
+                     viewdirs, k0b, mlp, ws, rgb, counter);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int F, int C, int PE>
+static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
+                           ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
+  if (g_shade_waves == 8) return ug_shade_launch_nw<F, C, PE, 8>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  return ug_shade_launch_nw<F, C, PE, 12>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+}
+
+extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *viewdirs, const float *k0_bricks,
+                                  const float *mlp_packed, void *ws_mem, float *rgb_marched, ugrid_stream_t s) {
+  if (p->n_rays <= 0) return 0;
+  ug_ws_view ws = ug_ws_make(ws_mem, p->n_rays, p->n_samples);
+  ug_shade_args a;
+  ug_fill_shade_args(p, a);
+  if (p->mlp_in == 0) {
+    if (p->k0_channels != 3) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_shade_direct, dim3(ug_blocks(ws.n_tiles * UG_WAVE, 256)), dim3(256), 0, ST(s), a,
+                       k0_bricks, ws, rgb_marched);
+    UG_LAUNCH_CHECK();
+    return 0;
+  }
+  if (p->mlp_width != 128 || p->mlp_in != p->k0_channels + 3 + 6 * p->viewbase_pe) return (int)hipErrorInvalidValue;
+  int32_t *counter = (int32_t *)ws_mem;  // first 256 B of the work list
+#define UG_SHADE_CASE(F_, C_, PE_)                                                          \
+  if (p->freq_num == F_ && p->k0_channels == C_ && p->viewbase_pe == PE_)                   \
+    return ug_shade_launch<F_, C_, PE_>(a, viewdirs, k0_bricks, mlp_packed, ws, rgb_marched, counter, ST(s));
+  UG_SHADE_CASE(3, 12, 4)  // Mip-NeRF-360 *_single.py  (configs/default.py:104-124)
+  UG_SHADE_CASE(4, 12, 4)  // tankstemple_unbounded/truck_single.py:105
+  UG_SHADE_CASE(2, 3, 2)   // waymo-style rgbnet_dim=3, viewbase_pe=2 (configs/waymo/waymo_no_block.py:144-149)
+  UG_SHADE_CASE(3, 3, 2)
+  UG_SHADE_CASE(1, 12, 4)
+#undef UG_SHADE_CASE
+  return (int)hipErrorNotSupported;
+}
+
+extern "C" int ugrid_render_stats(void *ws_mem, int64_t n_rays, int32_t S, int64_t *d_stats, ugrid_stream_t s) {
+  ug_ws_view ws = ug_ws_make(ws_mem, n_rays, S);
+  UG_HIP(hipMemsetAsync(d_stats, 0, sizeof(int64_t), ST(s)));
+  hipLaunchKernelGGL(k_ws_stats, dim3(64), dim3(256), 0, ST(s), ws.count, ws.n_tiles, d_stats);
+  UG_LAUNCH_CHECK();
+  return 0;
+}

@@ -51,12 +51,15 @@ class FourierGridRenderer:
       contracted_norm ('inf' | 'l2'), world_len.
     """
 
-    def __init__(self, state, device, max_ws_bytes=16 << 30):
+    def __init__(self, state, device, max_ws_bytes=16 << 30, fused=False):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("FourierGridRenderer needs a HIP device (no CPU path)")
         self.device = dev
         self.max_ws_bytes = int(max_ws_bytes)
+        # fused=True: single persistent launch (march+shade per wave, 0.9 GB scratch); False (default, measured
+        # faster on MI355X: 18.8 vs 23.5 ms per S1 frame): march kernel -> work list -> shade kernel
+        self.use_fused = bool(fused)
         dg = state["density_grid"].to(dev, torch.float32).contiguous()
         kg = state["k0_grid"].to(dev, torch.float32).contiguous()
         self.F = int(state["fourier_freq_num"])
@@ -109,7 +112,7 @@ class FourierGridRenderer:
             torch.cuda.current_stream(dev).synchronize()  # dg/kg temporaries may now be freed
         self._tables = {}
         self._ws = None
-        self.last_timing = None
+        self._last = None
 
     # -- helpers ---------------------------------------------------------------------------------
     def tables(self, stepsize):
@@ -165,28 +168,47 @@ class FourierGridRenderer:
         rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
         depth = torch.empty(R, dtype=torch.float32, device=dev)
         last = torch.empty(R, dtype=torch.float32, device=dev)
-        chunk = self.rays_per_chunk(S)
-        timing = render_kwargs.get("timing")  # optional list collecting (march_ev0, march_ev1, shade_ev1)
+        timing = render_kwargs.get("timing")  # optional list collecting ([ev0, ev1, ev2], n_rays) per launch group
+        fused = self.use_fused and self.has_mlp
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
-            ws = self._workspace(min(R, chunk), S)
-            for b in range(0, R, chunk):
-                e = min(R, b + chunk)
-                n = e - b
-                p = self._params(n, S, stepsize)
-                o_, d_, v_ = rays_o[b:e], rays_d[b:e], viewdirs[b:e]
+            if fused:
+                need = _L.ugrid_render_fused_ws_bytes(S)
+                if self._ws is None or self._ws.numel() < need:
+                    self._ws = None
+                    self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                p = self._params(R, S, stepsize)
                 if timing is not None:
-                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
                     ev[0].record()
-                _lib.check(_L.ugrid_render_march(p, _p(o_), _p(d_), _p(t_tab), _p(s_tab), _p(self.density_bricks),
-                                                 _p(last[b:e]), _p(depth[b:e]), _p(ws), st), "render_march")
+                _lib.check(_L.ugrid_render_fused(p, _p(rays_o), _p(rays_d), _p(viewdirs), _p(t_tab), _p(s_tab),
+                                                 _p(self.density_bricks), _p(self.k0_bricks), _p(self.mlp_packed),
+                                                 _p(last), _p(depth), _p(rgb), _p(self._ws), st), "render_fused")
                 if timing is not None:
                     ev[1].record()
-                _lib.check(_L.ugrid_render_shade(p, _p(v_), _p(self.k0_bricks), _p(self.mlp_packed), _p(ws),
-                                                 _p(rgb[b:e]), st), "render_shade")
-                if timing is not None:
-                    ev[2].record()
-                    timing.append((ev, n))
+                    timing.append((ev, R))
+                self._last = ("fused", R, S)
+            else:
+                chunk = self.rays_per_chunk(S)
+                ws = self._workspace(min(R, chunk), S)
+                for b in range(0, R, chunk):
+                    e = min(R, b + chunk)
+                    n = e - b
+                    p = self._params(n, S, stepsize)
+                    o_, d_, v_ = rays_o[b:e], rays_d[b:e], viewdirs[b:e]
+                    if timing is not None:
+                        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                        ev[0].record()
+                    _lib.check(_L.ugrid_render_march(p, _p(o_), _p(d_), _p(t_tab), _p(s_tab), _p(self.density_bricks),
+                                                     _p(last[b:e]), _p(depth[b:e]), _p(ws), st), "render_march")
+                    if timing is not None:
+                        ev[1].record()
+                    _lib.check(_L.ugrid_render_shade(p, _p(v_), _p(self.k0_bricks), _p(self.mlp_packed), _p(ws),
+                                                     _p(rgb[b:e]), st), "render_shade")
+                    if timing is not None:
+                        ev[2].record()
+                        timing.append((ev, n))
+                    self._last = ("split", n, S)
         out = {"alphainv_last": last, "rgb_marched": rgb, "n_max": S}
         if render_kwargs.get("render_depth", False):
             out["depth"] = depth
@@ -195,12 +217,17 @@ class FourierGridRenderer:
     __call__ = forward
 
     @torch.no_grad()
-    def survivors_of_last_chunk(self, n_rays, S):
-        """Number of surviving samples M in the work list of the most recent march (host sync)."""
+    def survivors_of_last_chunk(self, n_rays=None, S=None):
+        """Number of surviving samples M counted by the most recent launch (whole call for the fused path, last
+        chunk for the two-kernel path).  Host sync."""
+        kind, n, S_ = self._last
         out = torch.zeros(1, dtype=torch.int64, device=self.device)
         with torch.cuda.device(self.device):
-            _lib.check(_L.ugrid_render_stats(_p(self._ws), n_rays, S, _p(out),
-                                             torch.cuda.current_stream(self.device).cuda_stream), "render_stats")
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            if kind == "fused":
+                _lib.check(_L.ugrid_render_fused_stats(_p(self._ws), _p(out), st), "render_fused_stats")
+            else:
+                _lib.check(_L.ugrid_render_stats(_p(self._ws), n, S_, _p(out), st), "render_stats")
         return int(out.item())
 
     # -- constructors ------------------------------------------------------------------------------
