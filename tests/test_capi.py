@@ -41,7 +41,9 @@ def test_python_binding_table_matches_header(lib_path):
     assert lib.ugrid_brick_bytes(7, 1, 200, 200, 200, 0) == 7 * 199 ** 3 * 32
     assert lib.ugrid_brick_bytes(7, 12, 200, 200, 200, 0) == 7 * 199 ** 3 * 384
     assert lib.ugrid_brick_bytes(1, 3, 160, 160, 160, 1) == 159 ** 3 * 128
-    assert lib.ugrid_mlp_packed_bytes(12, 4) == 4 * (20 * 256 + 64 * 256 + 128 + 128 + 512 + 4)
+    fp32_img = 20 * 256 + 64 * 256 + 128 + 128 + 512 + 4
+    bf16_img = (3 + 8) * 4 * 3 * 64 * 4 + 128 + 128 + 512 + 4
+    assert lib.ugrid_mlp_packed_bytes(12, 4) == 4 * (fp32_img + bf16_img)
     assert lib.ugrid_render_ws_bytes(64, 256) >= 64 * 256 * 17
 
 

@@ -92,15 +92,38 @@ def test_fused_render_vs_oracle(fr, G, F, C, pe, norm, R, stepsize, dm, ds):
     assert abs(M - ref["weights"].numel()) <= max(3, int(2e-4 * M))
 
 
+@pytest.mark.parametrize("bf16x3", [0, 1])
+def test_rgbnet_mfma_modes(fr, bf16x3):
+    """The rgbnet runs on the matrix cores either as exact fp32 MFMA (v_mfma_f32_32x32x2_f32) or as six bf16
+    MFMAs per product on a three-way bf16 split of both operands (fp32-accurate, error ~2^-24 per product).
+    Both must meet the 1e-4 bound against the oracle; they differ from each other only at the 1e-6 level."""
+    G, F, C, R = 36, 3, 12, 6000
+    state = make_state(4242, G, F, C, 4, "inf", 1e-4, 6.0, 12.0)
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(4243, R)]
+    ref = model_oracle.fouriergrid_render(state, o, d, v, 0.5, render_depth=True, return_margin=True)
+    try:
+        fr.tune("mlp_bf16x3", bf16x3)
+        rend = fr.FourierGridRenderer(state, "cuda:0")
+        out = rend(o.cuda(), d.cuda(), v.cuda(), stepsize=0.5, render_depth=True)
+        worst = check_render(out, ref, R)
+        print("mlp_bf16x3=%d worst=%s" % (bf16x3, worst))
+        assert worst["rgb_marched"] < 2e-5
+    finally:
+        fr.tune("mlp_bf16x3", 1)
+
+
 def test_fused_render_deterministic_chunk_and_order_invariant(fr):
     """Size-independent properties: bitwise run-to-run determinism, independence of the work-list chunking,
     and per-ray results that do not depend on which other rays share the 64-ray tile."""
-    G, F, C, R = 32, 3, 12, 20_000
+    G, F, C, R = 32, 3, 12, 60_000
     state = make_state(99, G, F, C, 4, "inf", 1e-4, 6.0, 12.0)
     o, d, v = [torch.from_numpy(a).cuda() for a in synth.rays(5, R)]
     rend = fr.FourierGridRenderer(state, "cuda:0")
     a = rend(o, d, v, stepsize=0.5, render_depth=True)
     b = rend(o, d, v, stepsize=0.5, render_depth=True)
+    for _ in range(3):  # a race shows up as a lost / duplicated survivor in a few of many thousand rays
+        b2 = rend(o, d, v, stepsize=0.5, render_depth=True)
+        assert torch.equal(a["rgb_marched"], b2["rgb_marched"])
     # two-kernel path (march -> work list -> shade) with a tiny work list, i.e. many chunks
     small = fr.FourierGridRenderer(state, "cuda:0", max_ws_bytes=4 << 20, fused=False)
     assert small.rays_per_chunk(a["n_max"]) < R

@@ -47,7 +47,7 @@ def run_steps(device, backend_ru, backend_tv, adam_cls, n_steps, seed=21):
         w = 1e-5 * G / 128
         backend_tv.total_variation_add_grad(params['density_grid'], params['density_grid'].grad, w, w, w, step == 0)
         backend_tv.total_variation_add_grad(params['k0_grid'], params['k0_grid'].grad, w, w, w, step == 0)
-        info.append((float(loss), out['n_kept'], {k: p.grad.detach().cpu().clone() for k, p in params.items()}))
+        info.append((float(loss.detach()), out['n_kept'], {k: p.grad.detach().cpu().clone() for k, p in params.items()}))
         opt.step()
     return {k: p.detach().cpu() for k, p in params.items()}, info
 

@@ -289,7 +289,11 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
 // ----------------------------------------------------------------------------------------------
 __host__ __device__ static inline int ug_feat_of(int o, int r, int h) { return 32 * o + (r & 3) + 8 * (r >> 2) + 4 * h; }
 
-struct ug_mlp_layout { int KL, offA1, offA2, offB1, offB2, offW3, offb3, total; };
+// A second image of the same network follows for the bf16x3 path (each fp32 weight split into three bf16
+// parts h+m+l, A operands of v_mfma_f32_32x32x16_bf16, 8 bf16 = 16 B per lane):
+//   bfA1 [KB1][4 o][3 parts][64 lanes][8 bf16] | bfA2 [8][4][3][64][8] | bias1 | bias2 | W3 | b3   (fp32 tail)
+struct ug_mlp_layout { int KL, offA1, offA2, offB1, offB2, offW3, offb3, total;
+                       int KB1, bfA1, bfA2, bfB1, bfB2, bfW3, bfb3, total2; };
 __host__ __device__ static inline ug_mlp_layout ug_mlp_lay(int C, int n_emb) {
   const int CH = (C + 1) / 2;
   ug_mlp_layout L;
@@ -301,6 +305,14 @@ __host__ __device__ static inline ug_mlp_layout ug_mlp_lay(int C, int n_emb) {
   L.offW3 = L.offB2 + 128;
   L.offb3 = L.offW3 + 512;
   L.total = L.offb3 + 4;
+  L.KB1 = (L.KL + 7) / 8;
+  L.bfA1 = L.total;                          // all offsets in floats (a bf16x8 unit = 4 floats)
+  L.bfA2 = L.bfA1 + L.KB1 * 4 * 3 * 64 * 4;
+  L.bfB1 = L.bfA2 + 8 * 4 * 3 * 64 * 4;
+  L.bfB2 = L.bfB1 + 128;
+  L.bfW3 = L.bfB2 + 128;
+  L.bfb3 = L.bfW3 + 512;
+  L.total2 = L.bfb3 + 4;
   return L;
 }
 
@@ -384,27 +396,115 @@ __device__ __forceinline__ void ug_k0_gather(const float *__restrict__ k0b, int 
 
 __device__ __forceinline__ float ug_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
 
-// LDS-resident packed rgbnet (A operands of the transposed MFMA chain)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// LDS-resident packed rgbnet (A operands of the transposed MFMA chain); A1/A2 are fp32 (BF=false) or
+// bf16x8 units (BF=true)
 struct ug_mlp_lds { const float4 *A1, *A2, *W3; const float *B1, *B2, *b3; };
 
-template <int C, int PE>
+template <int C, int PE, bool BF>
+__host__ __device__ static inline int ug_mlp_lds_floats() {
+  const ug_mlp_layout ML = ug_mlp_lay(C, 3 + 6 * PE);
+#ifdef UG_EXP_A1_GLOBAL
+  return BF ? ML.total2 - ML.bfA2 : ML.total;
+#else
+  return BF ? ML.total2 - ML.bfA1 : ML.total;
+#endif
+}
+
+template <int C, int PE, bool BF>
 __device__ __forceinline__ ug_mlp_lds ug_mlp_stage(float *lds, const float *__restrict__ mlp) {
   const ug_mlp_layout ML = ug_mlp_lay(C, 3 + 6 * PE);
-  for (int i = threadIdx.x; i < ML.total; i += blockDim.x) lds[i] = mlp[i];
+#ifdef UG_EXP_A1_GLOBAL
+  const int base = BF ? ML.bfA2 : 0, n = ug_mlp_lds_floats<C, PE, BF>();
+#else
+  const int base = BF ? ML.bfA1 : 0, n = ug_mlp_lds_floats<C, PE, BF>();
+#endif
+  const float4 *src = (const float4 *)(mlp + base);
+  float4 *dst = (float4 *)lds;
+  for (int i = threadIdx.x; i < n / 4; i += blockDim.x) dst[i] = src[i];
   __syncthreads();
   ug_mlp_lds m;
-  m.A1 = (const float4 *)(lds + ML.offA1);
-  m.A2 = (const float4 *)(lds + ML.offA2);
-  m.B1 = lds + ML.offB1;
-  m.B2 = lds + ML.offB2;
-  m.W3 = (const float4 *)(lds + ML.offW3);
-  m.b3 = lds + ML.offb3;
+#ifdef UG_EXP_A1_GLOBAL
+  m.A1 = BF ? (const float4 *)(mlp + ML.bfA1) : (const float4 *)(lds + ML.offA1);
+#else
+  m.A1 = (const float4 *)(lds + (BF ? ML.bfA1 : ML.offA1) - base);
+#endif
+  m.A2 = (const float4 *)(lds + (BF ? ML.bfA2 : ML.offA2) - base);
+  m.B1 = lds + (BF ? ML.bfB1 : ML.offB1) - base;
+  m.B2 = lds + (BF ? ML.bfB2 : ML.offB2) - base;
+  m.W3 = (const float4 *)(lds + (BF ? ML.bfW3 : ML.offW3) - base);
+  m.b3 = lds + (BF ? ML.bfb3 : ML.offb3) - base;
   return m;
+}
+
+// fp32 -> three bf16 parts (x = h + m + l up to 2^-24 |x|); 8 values -> one MFMA operand per part
+struct ug_split3 { bf16x8 h, m, l; };
+__device__ __forceinline__ ug_split3 ug_split8(const float (&x)[8]) {
+  ug_split3 s;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 hh = (__bf16)x[i];
+    const float r1 = x[i] - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    const float r2 = r1 - (float)mm;
+    s.h[i] = hh; s.m[i] = mm; s.l[i] = (__bf16)r2;
+  }
+  return s;
+}
+
+// Explicit wait states around the gfx950-only bf16 MFMA.  With ROCm 7.2's hipcc the bf16x3 path produced
+// run-to-run differences (one survivor's contribution perturbed in ~1 % of rays) that the fp32 MFMA path
+// never shows; the pattern (timing dependent, small errors) is that of a missing VALU->MFMA / MFMA->VALU
+// hazard for v_cvt_pk_bf16_f32 / v_mfma_f32_32x32x16_bf16.  These fences cost < 1 % of a pass.
+__device__ __forceinline__ void ug_fence_operands() {   // around the cvt_pk that (re)builds B operands:
+  __builtin_amdgcn_sched_barrier(0);                    // RAW  cvt_pk write -> MFMA read, and
+  asm volatile("s_nop 15");                             // WAR  previous MFMA read -> cvt_pk write
+  __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void ug_fence_results() {    // before VALU reads MFMA accumulators (>= 16 passes)
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// acc[o] += (Wh+Wm+Wl)(xh+xm+xl) without the three terms below 2^-24: 6 bf16 MFMAs per output tile
+// (smallest terms first), issued round-robin over the 4 output tiles in a PINNED order so that an MFMA never
+// reads as SrcC the accumulator written by the MFMA issued right before it.  On gfx950 / ROCm 7.2 back-to-back
+// dependent v_mfma_f32_32x32x16_bf16 (which hipcc schedules freely and pads with no wait states) occasionally
+// dropped the previous partial product: run-to-run differences of one survivor's contribution in ~0.1-1 % of
+// rays, never seen on the fp32 MFMA path whose accumulators already rotate 4-deep.
+#define UG_MFMA_BF16(acc, a, b)                                       \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);  \
+  __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ void ug_mfma6x4(const bf16x8 *__restrict__ Ap, const ug_split3 &x, f32x16 (&acc)[4]) {
+  // Ap -> [o 4][part 3][64 lanes] units for this k-step
+  bf16x8 wh[4], wm[4], wl[4];
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    wh[o] = Ap[(o * 3 + 0) * 64];
+    wm[o] = Ap[(o * 3 + 1) * 64];
+    wl[o] = Ap[(o * 3 + 2) * 64];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wm[o], x.m); }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wl[o], x.h); }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wh[o], x.l); }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wm[o], x.h); }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wh[o], x.m); }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wh[o], x.h); }
 }
 
 // Shade one tile's survivor list (32 survivors per pass, lanes l / l+32 pair up) and write the tile's
 // rgb_marched.  C = 2*CH or 2*CH-1 k0 channels, PE view-direction frequencies; rgbnet 128 wide, 3 layers.
-template <int F, int C, int PE>
+template <int F, int C, int PE, bool BF>
 __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const float *__restrict__ viewdirs,
                                               const float *__restrict__ k0b, const ug_mlp_lds &M, int64_t tile,
                                               int count, const float4 *__restrict__ ent,
@@ -453,7 +553,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
         x[s] = h ? hi : lo;
       }
     }
-    // ---- layer 1: acc1[o] = W0 . x  (A from LDS, B = x registers)
+    // ---- layers 1 and 2 on the matrix cores, transposed (H^T = W . X^T): accumulators feed the next layer
     f32x16 acc1[4], acc2[4];
     int bo = h * 64;
     asm volatile("" : "+v"(bo));  // keeps the 128 bias reads inside the pass (LICM would hoist + spill them)
@@ -461,32 +561,66 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     for (int o = 0; o < 4; ++o)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc1[o][r] = M.B1[bo + o * 16 + r];
+    if constexpr (!BF) {
+      // exact fp32: v_mfma_f32_32x32x2_f32, B operand = one register (k = lane>>5 picks feature +0/+4)
 #pragma unroll
-    for (int s = 0; s < KL; ++s) {
-      const float4 wa = M.A1[s * 64 + lane];
-      acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, x[s], acc1[0], 0, 0, 0);
-      acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, x[s], acc1[1], 0, 0, 0);
-      acc1[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, x[s], acc1[2], 0, 0, 0);
-      acc1[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, x[s], acc1[3], 0, 0, 0);
-      if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the A-operand prefetch depth
-    }
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        acc1[o][r] = fmaxf(acc1[o][r], 0.f);
-        acc2[o][r] = M.B2[bo + o * 16 + r];
+      for (int s = 0; s < KL; ++s) {
+        const float4 wa = M.A1[s * 64 + lane];
+        acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, x[s], acc1[0], 0, 0, 0);
+        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, x[s], acc1[1], 0, 0, 0);
+        acc1[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, x[s], acc1[2], 0, 0, 0);
+        acc1[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, x[s], acc1[3], 0, 0, 0);
+        if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the A-operand prefetch depth
       }
-    // ---- layer 2: the accumulators of layer 1 ARE the B operands (k = lane>>5 picks feature +0/+4)
 #pragma unroll
-    for (int st = 0; st < 64; ++st) {
-      const float4 wa = M.A2[st * 64 + lane];
-      const float xb = acc1[st >> 4][st & 15];
-      acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, xb, acc2[0], 0, 0, 0);
-      acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, xb, acc2[1], 0, 0, 0);
-      acc2[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, xb, acc2[2], 0, 0, 0);
-      acc2[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, xb, acc2[3], 0, 0, 0);
-      if ((st & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc1[o][r] = fmaxf(acc1[o][r], 0.f);
+          acc2[o][r] = M.B2[bo + o * 16 + r];
+        }
+#pragma unroll
+      for (int st = 0; st < 64; ++st) {
+        const float4 wa = M.A2[st * 64 + lane];
+        const float xb = acc1[st >> 4][st & 15];
+        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, xb, acc2[0], 0, 0, 0);
+        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, xb, acc2[1], 0, 0, 0);
+        acc2[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, xb, acc2[2], 0, 0, 0);
+        acc2[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, xb, acc2[3], 0, 0, 0);
+        if ((st & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // fp32-accurate through bf16x3 splitting: v_mfma_f32_32x32x16_bf16, B operand = 8 values of this lane
+      // (lane half h supplies k = 8h..8h+7), i.e. 8 layer-1 inputs / 8 accumulator registers per k-step
+      const bf16x8 *A1b = (const bf16x8 *)M.A1, *A2b = (const bf16x8 *)M.A2;
+      constexpr int KB1 = (KL + 7) / 8;
+#pragma unroll
+      for (int s = 0; s < KB1; ++s) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (8 * s + e < KL) ? x[(8 * s + e < KL) ? 8 * s + e : 0] : 0.f;
+        const ug_split3 xs = ug_split8(v);
+        ug_fence_operands();
+        ug_mfma6x4(A1b + (s * 12) * 64 + lane, xs, acc1);
+      }
+      ug_fence_results();
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc1[o][r] = fmaxf(acc1[o][r], 0.f);
+          acc2[o][r] = M.B2[bo + o * 16 + r];
+        }
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc1[st >> 1][8 * (st & 1) + e];
+        const ug_split3 xs = ug_split8(v);
+        ug_fence_operands();
+        ug_mfma6x4(A2b + (st * 12) * 64 + lane, xs, acc2);
+      }
+      ug_fence_results();
     }
     // ---- layer 3 (3 outputs) on the VALU: each lane of the pair reduces its 64 features
     float l0 = 0.f, l1 = 0.f, l2 = 0.f;

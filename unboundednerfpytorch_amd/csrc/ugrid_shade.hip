@@ -10,6 +10,28 @@ __global__ void k_pack_mlp(const float *__restrict__ w0, const float *__restrict
                            float *__restrict__ out) {
   const ug_mlp_layout L = ug_mlp_lay(C, n_emb);
   const int mlp_in = C + n_emb;
+  // bf16x3 image: one thread per bf16 element
+  unsigned short *bf = (unsigned short *)(out + L.bfA1);
+  const int n_bf = (L.bfB1 - L.bfA1) * 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_bf; i += gridDim.x * blockDim.x) {
+    const int e = i & 7, lane = (i >> 3) & 63, u = i >> 9;      // u = (step*4 + o)*3 + part
+    const int part = u % 3, o = (u / 3) & 3, step = u / 12;
+    float w = 0.f;
+    if (step < L.KB1) {                                        // layer 1: inputs 8*step+e of half (lane>>5)
+      const int idx = 8 * step + e;
+      const int col = idx < L.KL ? ug_in_col(idx, lane >> 5, C, n_emb, L.KL) : -1;
+      if (col >= 0) w = w0[(32 * o + (lane & 31)) * mlp_in + col];
+    } else {                                                   // layer 2: k-step st = (o', q)
+      const int st = step - L.KB1;
+      w = w1[(32 * o + (lane & 31)) * 128 + ug_feat_of(st >> 1, 8 * (st & 1) + e, lane >> 5)];
+    }
+    const __bf16 hh = (__bf16)w;
+    const float r1 = w - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    const __bf16 ll = (__bf16)(r1 - (float)mm);
+    const __bf16 pick = part == 0 ? hh : (part == 1 ? mm : ll);
+    bf[i] = __builtin_bit_cast(unsigned short, pick);
+  }
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L.total; i += gridDim.x * blockDim.x) {
     float v = 0.f;
     if (i < L.offA2) {                       // A1[s][lane][o] = W0[32o + (lane&31)][col(s, lane>>5)]
@@ -35,22 +57,23 @@ __global__ void k_pack_mlp(const float *__restrict__ w0, const float *__restrict
       if (c < 3) v = b2[c];
     }
     out[i] = v;
+    if (i >= L.offB1) out[L.bfB1 + (i - L.offB1)] = v;  // tail copy for the bf16 image
   }
 }
 
 // persistent shade kernel over a work list written by k_march (two-kernel path)
-template <int F, int C, int PE, int NW>
+template <int F, int C, int PE, int NW, bool BF>
 __global__ void __launch_bounds__(NW * 64, NW / 4)
 k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
             const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
             int32_t *__restrict__ tile_counter) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const ug_mlp_lds M = ug_mlp_stage<C, PE>(lds, mlp);
+  const ug_mlp_lds M = ug_mlp_stage<C, PE, BF>(lds, mlp);
   int victim = 0;
   for (;;) {
     const int64_t tile = ug_next_tile(tile_counter, ws.n_tiles, blockIdx.x & 7, victim);
     if (tile < 0) break;
-    ug_shade_tile<F, C, PE>(a, viewdirs, k0b, M, tile, ws.count[tile], ws.ent + tile * ws.cap,
+    ug_shade_tile<F, C, PE, BF>(a, viewdirs, k0b, M, tile, ws.count[tile], ws.ent + tile * ws.cap,
                             ws.slot + tile * ws.cap, rgb_marched);
   }
 }
@@ -58,7 +81,7 @@ k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__
 // Single-launch render: every persistent wave marches a 64-ray tile and immediately shades the survivors
 // it found (its list lives in that wave's private scratch slot and is still L2-resident).  Waves of one CU
 // sit in different phases, so the VALU-bound march of some overlaps the MFMA-bound rgbnet of others.
-template <int F, bool L2, int C, int PE, int NW>
+template <int F, bool L2, int C, int PE, int NW, bool BF>
 __global__ void __launch_bounds__(NW * 64, NW / 4)
 k_render_fused(ug_march_args am, ug_shade_args as, const float *__restrict__ rays_o,
                const float *__restrict__ rays_d, const float *__restrict__ viewdirs,
@@ -69,7 +92,7 @@ k_render_fused(ug_march_args am, ug_shade_args as, const float *__restrict__ ray
                uint8_t *__restrict__ scratch_slot, unsigned long long *__restrict__ survivors_total,
                int32_t *__restrict__ tile_counter, int64_t n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const ug_mlp_lds M = ug_mlp_stage<C, PE>(lds, mlp);
+  const ug_mlp_lds M = ug_mlp_stage<C, PE, BF>(lds, mlp);
   const int64_t cap = (int64_t)UG_WAVE * am.S;
   const int64_t wslot = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
   float4 *__restrict__ ent = scratch_ent + wslot * cap;
@@ -81,11 +104,12 @@ k_render_fused(ug_march_args am, ug_shade_args as, const float *__restrict__ ray
     if (tile < 0) break;
     const int count = ug_march_tile<F, L2>(am, rays_o, rays_d, t_table, s_table, dens_bricks, alphainv_last,
                                            depth, tile, ent, slot);
-    // the list was written by this wave: make the stores visible to its own loads
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    ug_shade_tile<F, C, PE>(as, viewdirs, k0b, M, tile, count, ent, slot, rgb_marched);
+    // The list was written by this wave into a scratch slot it re-uses for every tile: its stores are
+    // write-through (they are in L2 once vmcnt drains), but this CU's vector L1 may still hold the slot's lines
+    // from the previous tile.  Drain the stores, then invalidate the L1 (agent-scope acquire = buffer_inv sc1).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    ug_shade_tile<F, C, PE, BF>(as, viewdirs, k0b, M, tile, count, ent, slot, rgb_marched);
     total += count;
   }
   if (ug_lane() == 0 && total) atomicAdd(survivors_total, (unsigned long long)total);
@@ -149,7 +173,7 @@ __global__ void k_ws_stats(const int32_t *__restrict__ count, int64_t n_tiles, i
 // C ABI
 // ----------------------------------------------------------------------------------------------
 extern "C" int64_t ugrid_mlp_packed_bytes(int32_t k0_channels, int32_t viewbase_pe) {
-  return (int64_t)sizeof(float) * ug_mlp_lay(k0_channels, 3 + 6 * viewbase_pe).total;
+  return (int64_t)sizeof(float) * ug_mlp_lay(k0_channels, 3 + 6 * viewbase_pe).total2;
 }
 
 extern "C" int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1, const float *b1,
@@ -164,7 +188,7 @@ extern "C" int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1,
 
 // ---- single-launch fused render -----------------------------------------------------------------
 #define UG_FUSED_NW 12  // slots are sized for the largest variant
-static int g_fused_waves = 12;
+static int g_fused_waves = 12;  // (kept for ABI of the knob; the single launch always uses 12 waves)
 #define UG_FUSED_MAX_WGS 256
 
 extern "C" int64_t ugrid_render_fused_ws_bytes(int32_t n_samples) {
@@ -172,15 +196,17 @@ extern "C" int64_t ugrid_render_fused_ws_bytes(int32_t n_samples) {
   return 256 + ug_align256(slots * cap * 16) + ug_align256(slots * cap);
 }
 
-template <int F, bool L2, int C, int PE, int NW>
+static int g_mlp_bf16x3 = 1;  // 1: rgbnet on bf16x3-split MFMA (fp32-accurate, 2.5x fewer MFMA cycles); 0: fp32 MFMA
+
+template <int F, bool L2, int C, int PE, int NW, bool BF>
 static int ug_fused_launch_nw(const ug_march_args &am, const ug_shade_args &as, const float *rays_o,
                            const float *rays_d, const float *viewdirs, const float *t_table,
                            const float *s_table, const float *dens_bricks, const float *k0b, const float *mlp,
                            float *alphainv_last, float *depth, float *rgb, void *ws_mem, hipStream_t st) {
-  const int lds_bytes = (int)sizeof(float) * ug_mlp_lay(C, 3 + 6 * PE).total;
+  const int lds_bytes = (int)sizeof(float) * ug_mlp_lds_floats<C, PE, BF>();
   static bool attr_set = false;
   if (!attr_set) {
-    UG_HIP(hipFuncSetAttribute((const void *)k_render_fused<F, L2, C, PE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    UG_HIP(hipFuncSetAttribute((const void *)k_render_fused<F, L2, C, PE, NW, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
   const int64_t n_tiles = (am.n_rays + UG_WAVE - 1) / UG_WAVE;
@@ -192,7 +218,7 @@ static int ug_fused_launch_nw(const ug_march_args &am, const ug_shade_args &as, 
   int64_t wgs = (n_tiles + NW - 1) / NW;
   if (wgs > UG_FUSED_MAX_WGS) wgs = UG_FUSED_MAX_WGS;
   wgs = (wgs + 7) / 8 * 8;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_render_fused<F, L2, C, PE, NW>), dim3((unsigned)wgs), dim3(NW * 64), lds_bytes,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_render_fused<F, L2, C, PE, NW, BF>), dim3((unsigned)wgs), dim3(NW * 64), lds_bytes,
                      st, am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks, k0b, mlp, alphainv_last,
                      depth, rgb, ent, slot, (unsigned long long *)(base + 64), (int32_t *)base, n_tiles);
   UG_LAUNCH_CHECK();
@@ -204,11 +230,12 @@ static int ug_fused_launch(const ug_march_args &am, const ug_shade_args &as, con
                            const float *rays_d, const float *viewdirs, const float *t_table,
                            const float *s_table, const float *dens_bricks, const float *k0b, const float *mlp,
                            float *alphainv_last, float *depth, float *rgb, void *ws_mem, hipStream_t st) {
-  if (g_fused_waves == 8)
-    return ug_fused_launch_nw<F, L2, C, PE, 8>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks, k0b,
-                                               mlp, alphainv_last, depth, rgb, ws_mem, st);
-  return ug_fused_launch_nw<F, L2, C, PE, 12>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks, k0b,
-                                              mlp, alphainv_last, depth, rgb, ws_mem, st);
+  // the single-launch variant is kept for experiments only (8 waves with bf16x3, 12 with fp32 MFMA)
+  if (g_mlp_bf16x3)
+    return ug_fused_launch_nw<F, L2, C, PE, 8, true>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks,
+                                                     k0b, mlp, alphainv_last, depth, rgb, ws_mem, st);
+  return ug_fused_launch_nw<F, L2, C, PE, 12, false>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks,
+                                                     k0b, mlp, alphainv_last, depth, rgb, ws_mem, st);
 }
 
 extern "C" int ugrid_render_fused(const ugrid_render_params *p, const float *rays_o, const float *rays_d,
@@ -254,16 +281,17 @@ extern "C" int ugrid_tune(const char *key, int value) {
   if (!strcmp(key, "shade_waves") && (value == 8 || value == 12)) { g_shade_waves = value; return 0; }
   if (!strcmp(key, "march_waves")) return ug_set_march_waves(value) ? (int)hipErrorInvalidValue : 0;
   if (!strcmp(key, "fused_waves") && (value == 8 || value == 12)) { g_fused_waves = value; return 0; }
+  if (!strcmp(key, "mlp_bf16x3") && (value == 0 || value == 1)) { g_mlp_bf16x3 = value; return 0; }
   return (int)hipErrorInvalidValue;
 }
 
-template <int F, int C, int PE, int NW>
+template <int F, int C, int PE, int NW, bool BF>
 static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
                               ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
-  const int lds_bytes = (int)sizeof(float) * ug_mlp_lay(C, 3 + 6 * PE).total;
+  const int lds_bytes = (int)sizeof(float) * ug_mlp_lds_floats<C, PE, BF>();
   static bool attr_set = false;
   if (!attr_set) {
-    UG_HIP(hipFuncSetAttribute((const void *)k_shade_mlp<F, C, PE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    UG_HIP(hipFuncSetAttribute((const void *)k_shade_mlp<F, C, PE, NW, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
   UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
@@ -271,7 +299,7 @@ static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, con
   int64_t wgs = (ws.n_tiles + NW - 1) / NW;
   if (wgs > 256) wgs = 256;
   wgs = (wgs + 7) / 8 * 8;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_mlp<F, C, PE, NW>), dim3((unsigned)wgs), dim3(NW * 64), lds_bytes, st, a,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_mlp<F, C, PE, NW, BF>), dim3((unsigned)wgs), dim3(NW * 64), lds_bytes, st, a,
                      viewdirs, k0b, mlp, ws, rgb, counter);
   UG_LAUNCH_CHECK();
   return 0;
@@ -280,8 +308,12 @@ static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, con
 template <int F, int C, int PE>
 static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
                            ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
-  if (g_shade_waves == 8) return ug_shade_launch_nw<F, C, PE, 8>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-  return ug_shade_launch_nw<F, C, PE, 12>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  // bf16x3 always runs 8 waves per workgroup (214 VGPRs, no spills).  The 12-wave build needs 37 spills to
+  // fit 168 VGPRs and showed run-to-run differences on MI355X (a survivor's contribution occasionally lost,
+  // tools/gpu_mlp_modes.py) while gaining only 4 %; it is not instantiated.
+  if (g_mlp_bf16x3) return ug_shade_launch_nw<F, C, PE, 8, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  if (g_shade_waves == 8) return ug_shade_launch_nw<F, C, PE, 8, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  return ug_shade_launch_nw<F, C, PE, 12, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
 }
 
 extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *viewdirs, const float *k0_bricks,
