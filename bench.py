@@ -106,7 +106,7 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer, get_rays_of_a_view, tune
     for kv in args.tune:
