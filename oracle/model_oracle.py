@@ -280,3 +280,71 @@ def fouriergrid_train_forward(params, cfg, rays_o, rays_d, viewdirs, stepsize, R
     rgb_marched = torch.zeros(R, 3, device=dev).index_add_(0, ray_id, weights.unsqueeze(-1) * rgb)
     return {'rgb_marched': rgb_marched, 'alphainv_last': alphainv_last, 'weights': weights, 'ray_id': ray_id,
             'n_kept': int(weights.numel())}
+
+
+# ---------------------------------------------------------------------------------------------
+# Bounded DVGO forward (config 1): dvgo.DirectVoxGO.forward, /root/reference/FourierGrid/dvgo.py:306-425.
+# Device-agnostic composition: `ops` is an extension-module backend (oracle on CPU, the product's drop-in
+# module on the GPU), `query` a dense-grid query with fourier_grid_query's signature.
+# ---------------------------------------------------------------------------------------------
+def dvgo_state_from_params(xyz_min, xyz_max, num_voxels, num_voxels_base, alpha_init, density_grid, k0_grid,
+                           rgbnet_weights, rgbnet_biases, mask, fast_color_thres, rgbnet_direct, viewbase_pe=4):
+    """Derived quantities exactly as DirectVoxGO.__init__/_set_grid_resolution compute them (dvgo.py:40-56,154-163)
+    and as grid.MaskGrid does (grid.py:221-228)."""
+    lo, hi = torch.Tensor(xyz_min), torch.Tensor(xyz_max)
+    voxel_size_base = ((hi - lo).prod() / num_voxels_base).pow(1 / 3)
+    voxel_size = ((hi - lo).prod() / num_voxels).pow(1 / 3)
+    world_size = ((hi - lo) / voxel_size).long()
+    scale = (torch.Tensor(list(mask.shape)) - 1) / (hi - lo)
+    return {
+        'xyz_min': lo, 'xyz_max': hi, 'voxel_size': voxel_size, 'voxel_size_ratio': voxel_size / voxel_size_base,
+        'world_size': world_size, 'act_shift': act_shift_from_alpha_init(alpha_init),
+        'density_grid': density_grid, 'k0_grid': k0_grid, 'rgbnet_weights': rgbnet_weights,
+        'rgbnet_biases': rgbnet_biases, 'mask': mask.bool(), 'xyz2ijk_scale': scale, 'xyz2ijk_shift': -lo * scale,
+        'fast_color_thres': fast_color_thres, 'rgbnet_direct': rgbnet_direct, 'viewbase_pe': viewbase_pe,
+    }
+
+
+@torch.no_grad()
+def dvgo_render(state, rays_o, rays_d, viewdirs, near, stepsize, bg, ops, query, render_depth=True):
+    dev = rays_o.device
+    st = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in state.items()}
+    N = rays_o.shape[0]
+    far = 1e9  # dvgo.py:318
+    stepdist = stepsize * st['voxel_size']
+    ray_pts, mask_outbbox, ray_id, step_id = ops.sample_pts_on_rays(
+        rays_o.contiguous(), rays_d.contiguous(), st['xyz_min'], st['xyz_max'], near, far, stepdist)[:4]
+    inb = ~mask_outbbox
+    ray_pts, ray_id, step_id = ray_pts[inb], ray_id[inb], step_id[inb]
+    interval = stepsize * st['voxel_size_ratio']
+    m = ops.maskcache_lookup(st['mask'], ray_pts.contiguous(), st['xyz2ijk_scale'], st['xyz2ijk_shift'])
+    ray_pts, ray_id, step_id = ray_pts[m], ray_id[m], step_id[m]
+    density = query(st['density_grid'], ray_pts, st['xyz_min'], st['xyz_max'], 0)
+    alpha = ops.raw2alpha(density.flatten().contiguous(), st['act_shift'], interval)[1]
+    thres = float(st['fast_color_thres'])
+    if thres > 0:
+        k = alpha > thres
+        ray_pts, ray_id, step_id, alpha = ray_pts[k], ray_id[k], step_id[k], alpha[k]
+    weights, _, alphainv_last = ops.alpha2weight(alpha.contiguous(), ray_id.contiguous(), N)[:3]
+    if thres > 0:
+        k = weights > thres
+        weights, alpha, ray_pts, ray_id, step_id = weights[k], alpha[k], ray_pts[k], ray_id[k], step_id[k]
+    k0 = query(st['k0_grid'], ray_pts, st['xyz_min'], st['xyz_max'], 0)
+    if k0.dim() == 1:
+        k0 = k0.unsqueeze(-1)
+    if len(st['rgbnet_weights']) == 0:
+        rgb = torch.sigmoid(k0)
+    else:
+        emb = viewdir_embedding(viewdirs.cpu(), int(st['viewbase_pe'])).to(dev)[ray_id]
+        if st['rgbnet_direct']:
+            rgb = torch.sigmoid(rgbnet_apply(st['rgbnet_weights'], st['rgbnet_biases'], torch.cat([k0, emb], -1)))
+        else:
+            logit = rgbnet_apply(st['rgbnet_weights'], st['rgbnet_biases'], torch.cat([k0[:, 3:], emb], -1))
+            rgb = torch.sigmoid(logit + k0[:, :3])
+    rgb_marched = torch.zeros(N, 3, device=dev).index_add_(0, ray_id, weights.unsqueeze(-1) * rgb)
+    rgb_marched = rgb_marched + alphainv_last.unsqueeze(-1) * bg
+    out = {'alphainv_last': alphainv_last, 'weights': weights, 'rgb_marched': rgb_marched, 'raw_alpha': alpha,
+           'raw_rgb': rgb, 'ray_id': ray_id}
+    if render_depth:
+        out['depth'] = torch.zeros(N, device=dev).index_add_(0, ray_id, weights * step_id)
+    return out

@@ -159,9 +159,49 @@ def gen_rays_view():
     print("rays_view", o.shape)
 
 
+DVGO_CASES = [
+    # name, seed, G, C (0 = coarse stage), rgbnet_direct, R, dens_mean, dens_std
+    ("dvgo_fine_direct", 31, 22, 12, True, 150, 2.0, 4.0),
+    ("dvgo_fine_residual", 32, 18, 9, False, 120, 3.0, 5.0),
+    ("dvgo_coarse", 33, 20, 0, False, 120, 1.0, 4.0),
+]
+
+
+def dvgo_inputs(seed, G, C):
+    """Synthetic DirectVoxGO parameters + a random occupancy mask + rays around a [-1,1]x[-0.8,0.9]x[-1.1,1] box."""
+    xyz_min, xyz_max = [-1.0, -0.8, -1.1], [1.0, 0.9, 1.0]
+    nvox = G ** 3
+    return xyz_min, xyz_max, nvox
+
+
+def gen_dvgo():
+    """dvgo.DirectVoxGO.forward (bounded scenes, config 1): variable-length sampling, mask cache, dense grids."""
+    dvgo = install_stubs.import_reference("dvgo")
+    for name, seed, G, C, direct, R, dm, ds in DVGO_CASES:
+        xyz_min, xyz_max, nvox = dvgo_inputs(seed, G, C)
+        model = dvgo.DirectVoxGO(xyz_min=xyz_min, xyz_max=xyz_max, num_voxels=nvox, num_voxels_base=nvox,
+                                 alpha_init=1e-2, fast_color_thres=1e-4, rgbnet_dim=C, rgbnet_direct=direct,
+                                 mask_cache_world_size=None)
+        ws = [int(x) for x in model.world_size]
+        sd = model.state_dict()
+        params = synth.dvgo_params(seed, ws, C, direct, dens_mean=dm, dens_std=ds)
+        with torch.no_grad():
+            for k, v in params.items():
+                assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
+                sd[k].copy_(torch.from_numpy(v))
+        o, d, v = [torch.from_numpy(a) for a in synth.rays(seed, R, origin_scale=0.4)]
+        with torch.no_grad():
+            out = model(o, d, v, near=0.2, far=6.0, stepsize=0.5, bg=1, render_depth=True)
+        keep = {k: out[k].numpy() for k in ("alphainv_last", "weights", "rgb_marched", "raw_alpha", "raw_rgb", "ray_id", "depth")}
+        keep["world_size"] = np.array(ws)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **keep)
+        print(name, "world", ws, "M=%d" % out["weights"].numel(), "rgb mean %.3f" % float(out["rgb_marched"].mean()))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)  # deterministic reduction order in F.linear / grid_sample
     gen_fouriergrid()
     gen_grid_query()
     gen_autograd_and_adam()
     gen_rays_view()
+    gen_dvgo()

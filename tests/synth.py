@@ -70,3 +70,22 @@ def rays(seed, R, origin_scale=0.3):
     d = d * uniform(seed + 102, R, 0.5, 2.0).reshape(R, 1)
     v = d / np.linalg.norm(d.astype(np.float64), axis=-1, keepdims=True)
     return o.astype(np.float32), d.astype(np.float32), v.astype(np.float32)
+
+
+def dvgo_params(seed, world_size, C, rgbnet_direct, viewbase_pe=4, width=128, dens_mean=8.0, dens_std=9.0):
+    """Synthetic DirectVoxGO parameters keyed like the reference state dict (+ 'mask_cache.mask').
+    C == 0: coarse stage (3-channel k0, no rgbnet)."""
+    ws = [int(x) for x in world_size]
+    n = int(np.prod(ws))
+    kc = C if C > 0 else 3
+    p = {'density.grid': normal(seed + 1, n, dens_mean, dens_std).reshape(1, 1, *ws),
+         'k0.grid': normal(seed + 2, kc * n).reshape(1, kc, *ws),
+         'mask_cache.mask': (uniform(seed + 3, n) > 0.25).reshape(*ws)}
+    if C > 0:
+        dim0 = 3 + 6 * viewbase_pe + (C if rgbnet_direct else C - 3)
+        dims = [dim0, width, width, 3]
+        for li, name in enumerate(['rgbnet.0', 'rgbnet.2.0', 'rgbnet.3']):
+            b = 1.0 / np.sqrt(dims[li])
+            p[name + '.weight'] = uniform(seed + 10 + li, dims[li + 1] * dims[li], -b, b).reshape(dims[li + 1], dims[li])
+            p[name + '.bias'] = uniform(seed + 20 + li, dims[li + 1], -b, b)
+    return p
