@@ -10,8 +10,15 @@ __global__ void k_pack_bricks(const float *__restrict__ grid, int P, int C, int 
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total;
        o += (int64_t)gridDim.x * blockDim.x) {
     int64_t q = o;
-    const int ch = (int)(q % CH); q /= CH;
-    const int c = (int)(q % 8); q /= 8;
+    int ch, c;
+    if (H == 2) {   // feature half-bricks: [pair CH/2][corner 8][2 channels]  (see ug_k0_gather_coop)
+      const int qi = (int)(q % (8 * CH)); q /= (8 * CH);
+      c = (qi >> 1) & 7;
+      ch = (qi >> 4) * 2 + (qi & 1);
+    } else {        // density / rgbnet-less colour bricks: [corner 8][CH]
+      ch = (int)(q % CH); q /= CH;
+      c = (int)(q % 8); q /= 8;
+    }
     const int h = (int)(q % H); q /= H;
     const int k = (int)(q % (Z - 1)); q /= (Z - 1);
     const int j = (int)(q % (Y - 1)); q /= (Y - 1);
@@ -101,7 +108,8 @@ k_march(ug_march_args a, const float *__restrict__ rays_o, const float *__restri
 // ----------------------------------------------------------------------------------------------
 extern "C" int64_t ugrid_render_ws_bytes(int64_t n_rays, int32_t S) {
   const int64_t n_tiles = (n_rays + UG_WAVE - 1) / UG_WAVE, cap = (int64_t)UG_WAVE * S;
-  return 256 + ug_align256(n_tiles * 4) + ug_align256(n_tiles * cap * 16) + ug_align256(n_tiles * cap);
+  return 256 + ug_align256(n_tiles * 4) + ug_align256(n_tiles * cap * 16) + ug_align256(n_tiles * cap) +
+         ug_align256(n_tiles * cap * UG_FEAT_STRIDE * 4);
 }
 
 extern "C" int ugrid_grid_query(const float *grid, int P, int C, int X, int Y, int Z, const float *xyz,
@@ -120,7 +128,7 @@ static inline int ug_brick_ch(int C, int *H) {
   // feature grids: 2 halves x ceil(C/2)
   if (C == 1) { *H = 1; return 1; }
   *H = 2;
-  return (C + 1) / 2;
+  return UG_CH(C);
 }
 
 extern "C" int64_t ugrid_brick_bytes(int P, int C, int X, int Y, int Z, int direct) {

@@ -29,6 +29,7 @@
 #include "ugrid_math.h"
 #include <string.h>
 
+#define UG_CH(C) (2 * (((C) + 3) / 4))  // channels per half-brick (even: stored as channel pairs)
 #define UG_MAX_F 5  // fourier_freq_num <= 5  (P <= 11 levels)
 
 
@@ -136,8 +137,10 @@ struct ug_ws_view {
   int32_t *count;   // [n_tiles]
   float4 *ent;      // [n_tiles][64*S]  (px, py, pz, weight)
   uint8_t *slot;    // [n_tiles][64*S]  ray slot (0..63) inside the tile
+  float *feat;      // [n_tiles][64*S][UG_FEAT_STRIDE] k0 features of the survivors (written by k_shade_gather)
   int64_t n_tiles, cap;
 };
+#define UG_FEAT_STRIDE 12
 
 __host__ __device__ static inline int64_t ug_align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 
@@ -151,6 +154,8 @@ static inline ug_ws_view ug_ws_make(void *ws, int64_t n_rays, int32_t S) {
   v.ent = (float4 *)b;
   b += ug_align256(v.n_tiles * v.cap * (int64_t)sizeof(float4));
   v.slot = (uint8_t *)b;
+  b += ug_align256(v.n_tiles * v.cap);
+  v.feat = (float *)b;
   return v;
 }
 
@@ -295,7 +300,7 @@ __host__ __device__ static inline int ug_feat_of(int o, int r, int h) { return 3
 struct ug_mlp_layout { int KL, offA1, offA2, offB1, offB2, offW3, offb3, total;
                        int KB1, bfA1, bfA2, bfB1, bfB2, bfW3, bfb3, total2; };
 __host__ __device__ static inline ug_mlp_layout ug_mlp_lay(int C, int n_emb) {
-  const int CH = (C + 1) / 2;
+  const int CH = UG_CH(C);
   ug_mlp_layout L;
   L.KL = (2 * CH + n_emb + 1) / 2;
   L.offA1 = 0;
@@ -318,7 +323,7 @@ __host__ __device__ static inline ug_mlp_layout ug_mlp_lay(int C, int n_emb) {
 
 // original rgbnet input column of (step s, half h); -1 = zero padding
 __host__ __device__ static inline int ug_in_col(int s, int h, int C, int n_emb, int KL) {
-  const int CH = (C + 1) / 2;
+  const int CH = UG_CH(C);
   if (s < CH) {
     const int ch = h * CH + s;
     return ch < C ? ch : -1;
@@ -362,9 +367,10 @@ __device__ __forceinline__ void ug_k0_level(const float *__restrict__ k0b, int h
                       w00 * ax.whi, w01 * ax.whi, w10 * ax.whi, w11 * ax.whi};
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch) {
-    float acc = v[ch] * w[0];
+    // half-brick layout [pair][corner][2 channels]: value of (corner c, channel ch) at (ch/2)*16 + c*2 + ch%2
+    float acc = v[(ch >> 1) * 16 + (ch & 1)] * w[0];
 #pragma unroll
-    for (int c = 1; c < 8; ++c) acc += v[c * CH + ch] * w[c];
+    for (int c = 1; c < 8; ++c) acc += v[(ch >> 1) * 16 + c * 2 + (ch & 1)] * w[c];
     feat[ch] = first ? acc : feat[ch] + acc;
   }
 }
@@ -380,8 +386,9 @@ __device__ __forceinline__ void ug_k0_gather(const float *__restrict__ k0b, int 
   const float uz = ug_div_r(pz - a.loz, a.ez, a.irz) * 2.f - 1.f;
   const int64_t cells = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1);
   ug_k0_level<CH>(k0b, h, 0, ux, uy, uz, a.X, a.Y, a.Z, true, feat);
+  constexpr int K0 = 0;
 #pragma unroll 1
-  for (int k = 0; k < F; ++k) {
+  for (int k = K0; k < F; ++k) {
     const float f = (float)(1 << k);
     float sx, cx_, sy, cy_, sz, cz_;
     ug_sincos(f * ux, &sx, &cx_);
@@ -392,6 +399,99 @@ __device__ __forceinline__ void ug_k0_gather(const float *__restrict__ k0b, int 
   }
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch) feat[ch] = feat[ch] / (float)P;
+}
+
+// ---- cooperative (coalesced) k0 gather ------------------------------------------------------------
+// A pass owns 32 survivors x 2 halves = 64 half-bricks of NI = 2*CH float4 each per level.  With "one lane
+// reads its own half-brick" every 16-byte load instruction touches 64 different cache lines and the CU's
+// texture-addresser serialises them (measured: ~51 cycles per load instruction, the whole shade kernel was
+// TA-bound).  Here the 64*NI float4 of a level are spread over the lanes in ADDRESS order instead: item
+// g = t*64 + lane reads float4 (g % NI) of half-brick (g / NI), so one instruction covers 64/NI contiguous
+// half-bricks = 8-11 cache lines.  The record layout [pair][corner][2 channels] makes every float4 hold two
+// corners x two channels: the loader multiplies by the two corner weights (published by the owning lanes
+// through a wave-private LDS table), accumulates over levels, and the four lanes of a quad (the four corner
+// pairs) are summed with two DPP-able shuffles once per pass.
+struct ug_coop_map { int j[12], i4[12]; };   // per-lane constants: survivor slot and float4 index of item t
+
+#define UG_COOP_SCRATCH_FLOATS (32 * 12 + 64 * 6)   // table T [32][12] + results [64][CH<=6]
+
+__device__ __forceinline__ void ug_wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int CH>
+__device__ __forceinline__ void ug_coop_level(const float *__restrict__ k0b, int64_t level_base, float cx, float cy,
+                                              float cz, const ug_shade_args &a, int lane, float *__restrict__ T,
+                                              float (&acc)[2 * CH][2]) {
+  constexpr int NI = 2 * CH;
+  const ug_axis_fast ax = ug_axis_inrange(cx, a.X), ay = ug_axis_inrange(cy, a.Y), az = ug_axis_inrange(cz, a.Z);
+  const int rec = (ax.cell * (a.Y - 1) + ay.cell) * (a.Z - 1) + az.cell;
+  const float w00 = az.wlo * ay.wlo, w01 = az.whi * ay.wlo, w10 = az.wlo * ay.whi, w11 = az.whi * ay.whi;
+  if (lane < 32) {  // owners publish cell + 8 trilinear weights (grid_sample corner order)
+    float *t = T + lane * 12;
+    t[0] = __int_as_float(rec);
+    *(float4 *)(t + 4) = make_float4(w00 * ax.wlo, w01 * ax.wlo, w10 * ax.wlo, w11 * ax.wlo);
+    *(float4 *)(t + 8) = make_float4(w00 * ax.whi, w01 * ax.whi, w10 * ax.whi, w11 * ax.whi);
+  }
+  ug_wave_lds_sync();
+#pragma unroll
+  for (int t = 0; t < NI; ++t) {
+    const int g = t * 64 + lane;
+    const int hb = g / NI, i = g - hb * NI;          // half-brick (hh*32 + j) and float4 index inside it
+    const int j = hb & 31, hh = hb >> 5, cp = i & 3;
+    const float *tj = T + j * 12;
+    const int rj = __float_as_int(tj[0]);
+    const float2 w2 = *(const float2 *)(tj + 4 + 2 * cp);
+    const float4 v = *(const float4 *)(k0b + ((level_base + rj) * 2 + hh) * (int64_t)(8 * CH) + i * 4);
+    acc[t][0] += v.x * w2.x;
+    acc[t][0] += v.z * w2.y;
+    acc[t][1] += v.y * w2.x;
+    acc[t][1] += v.w * w2.y;
+  }
+  ug_wave_lds_sync();
+}
+
+template <int F, int CH>
+__device__ __forceinline__ void ug_k0_gather_coop(const float *__restrict__ k0b, int lane, float px, float py, float pz,
+                                                  const ug_shade_args &a, float *__restrict__ scr, float (&feat)[CH]) {
+  constexpr int P = 2 * F + 1, NI = 2 * CH;
+  float *T = scr, *Rr = scr + 32 * 12;
+  const float ux = ug_div_r(px - a.lox, a.ex, a.irx) * 2.f - 1.f;
+  const float uy = ug_div_r(py - a.loy, a.ey, a.iry) * 2.f - 1.f;
+  const float uz = ug_div_r(pz - a.loz, a.ez, a.irz) * 2.f - 1.f;
+  const int64_t cells = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1);
+  float acc[NI][2];
+#pragma unroll
+  for (int t = 0; t < NI; ++t) acc[t][0] = acc[t][1] = 0.f;
+  ug_coop_level<CH>(k0b, 0, ux, uy, uz, a, lane, T, acc);
+#pragma unroll 1
+  for (int k = 0; k < F; ++k) {
+    const float f = (float)(1 << k);
+    float sx, cx_, sy, cy_, sz, cz_;
+    ug_sincos(f * ux, &sx, &cx_);
+    ug_sincos(f * uy, &sy, &cy_);
+    ug_sincos(f * uz, &sz, &cz_);
+    ug_coop_level<CH>(k0b, (int64_t)(2 * k + 1) * cells, sx, sy, sz, a, lane, T, acc);
+    ug_coop_level<CH>(k0b, (int64_t)(2 * k + 2) * cells, cx_, cy_, cz_, a, lane, T, acc);
+  }
+  // quad reduction over the four corner pairs, then hand the CH channel sums to the owning lanes
+#pragma unroll
+  for (int t = 0; t < NI; ++t) {
+    const int g = t * 64 + lane;
+    const int hb = g / NI, i = g - hb * NI;
+#pragma unroll
+    for (int c2 = 0; c2 < 2; ++c2) {
+      float x = acc[t][c2];
+      x += __shfl_xor(x, 1);
+      x += __shfl_xor(x, 2);
+      if ((lane & 3) == 0) Rr[hb * CH + (i >> 2) * 2 + c2] = x;
+    }
+  }
+  ug_wave_lds_sync();
+#pragma unroll
+  for (int s = 0; s < CH; ++s) feat[s] = Rr[lane * CH + s] / (float)P;   // lane = hh*32 + j = its own half-brick id
+  ug_wave_lds_sync();
 }
 
 __device__ __forceinline__ float ug_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
@@ -410,6 +510,11 @@ __host__ __device__ static inline int ug_mlp_lds_floats() {
 #else
   return BF ? ML.total2 - ML.bfA1 : ML.total;
 #endif
+}
+// dynamic LDS of a shade workgroup: packed rgbnet image + one cooperative-gather scratch per wave
+template <int C, int PE, bool BF, int NW>
+__host__ __device__ static inline int ug_shade_lds_bytes() {
+  return (int)sizeof(float) * (ug_mlp_lds_floats<C, PE, BF>() + NW * UG_COOP_SCRATCH_FLOATS);
 }
 
 template <int C, int PE, bool BF>
@@ -478,38 +583,57 @@ __device__ __forceinline__ void ug_fence_results() {    // before VALU reads MFM
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);  \
   __builtin_amdgcn_sched_barrier(0)
 
-__device__ __forceinline__ void ug_mfma6x4(const bf16x8 *__restrict__ Ap, const ug_split3 &x, f32x16 (&acc)[4]) {
-  // Ap -> [o 4][part 3][64 lanes] units for this k-step
-  bf16x8 wh[4], wm[4], wl[4];
+// One k-step for the 4 output tiles.  Part-major order (Wm: xm,xh | Wl: xh | Wh: xl,xm,xh) keeps only one
+// weight part (4 x bf16x8 = 16 VGPRs) live plus the prefetch of the next one: the LDS reads of the next part are
+// issued before the current part's MFMAs and land while those run.  `nxt` points at the next k-step's Wm part so
+// the prefetch chain continues across steps (pass nullptr-equivalent = same pointer on the last step).
+struct ug_wpart { bf16x8 w[4]; };
+
+__device__ __forceinline__ ug_wpart ug_load_part(const bf16x8 *__restrict__ Ap, int part) {
+  ug_wpart p;
 #pragma unroll
-  for (int o = 0; o < 4; ++o) {
-    wh[o] = Ap[(o * 3 + 0) * 64];
-    wm[o] = Ap[(o * 3 + 1) * 64];
-    wl[o] = Ap[(o * 3 + 2) * 64];
-  }
+  for (int o = 0; o < 4; ++o) p.w[o] = Ap[(o * 3 + part) * 64];
+  return p;
+}
+
+__device__ __forceinline__ void ug_mfma6x4(const bf16x8 *__restrict__ Ap, const bf16x8 *__restrict__ Ap_next,
+                                           const ug_split3 &x, const float (&v_next)[8], ug_split3 &x_next,
+                                           f32x16 (&acc)[4], ug_wpart &wm) {
+  // wm for this step was prefetched by the caller / the previous step
+  const ug_wpart wl = ug_load_part(Ap, 2);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wm[o], x.m); }
+  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wm.w[o], x.m); }
+  // the matrix pipe is now busy for 4 x 32 cycles: build the NEXT k-step's bf16 operands on the VALU meanwhile
+  x_next = ug_split8(v_next);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wl[o], x.h); }
+  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wm.w[o], x.h); }
+  const ug_wpart wh = ug_load_part(Ap, 0);
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wh[o], x.l); }
+  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wl.w[o], x.h); }
+  wm = ug_load_part(Ap_next, 1);   // next step's Wm (harmless re-read on the last step)
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wm[o], x.h); }
+  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wh.w[o], x.l); }
 #pragma unroll
-  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wh[o], x.m); }
+  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wh.w[o], x.m); }
 #pragma unroll
-  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wh[o], x.h); }
+  for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wh.w[o], x.h); }
 }
 
 // Shade one tile's survivor list (32 survivors per pass, lanes l / l+32 pair up) and write the tile's
 // rgb_marched.  C = 2*CH or 2*CH-1 k0 channels, PE view-direction frequencies; rgbnet 128 wide, 3 layers.
-template <int F, int C, int PE, bool BF>
+// PRE: the k0 features were gathered by k_shade_gather into `feat` ([entries][UG_FEAT_STRIDE]); otherwise they
+// are gathered here from the k0 bricks.
+template <int F, int C, int PE, bool BF, bool PRE, bool COOP>
 __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const float *__restrict__ viewdirs,
                                               const float *__restrict__ k0b, const ug_mlp_lds &M, int64_t tile,
                                               int count, const float4 *__restrict__ ent,
-                                              const uint8_t *__restrict__ slot, float *__restrict__ rgb_marched) {
-  constexpr int CH = (C + 1) / 2;
+                                              const uint8_t *__restrict__ slot, const float *__restrict__ feat_in,
+                                              float *__restrict__ scr, float *__restrict__ rgb_marched) {
+  constexpr int CH = UG_CH(C);
   constexpr int NEMB = 3 + 6 * PE;
   constexpr int KL = (2 * CH + NEMB + 1) / 2;
   const int lane = ug_lane();
@@ -526,7 +650,14 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     float x[KL];
     {
       float feat[CH];
-      ug_k0_gather<F, CH>(k0b, h, en.x, en.y, en.z, a, feat);
+      if constexpr (PRE) {
+#pragma unroll
+        for (int s = 0; s < CH; ++s) feat[s] = ok ? feat_in[(int64_t)e * UG_FEAT_STRIDE + h * CH + s] : 0.f;
+      } else if constexpr (COOP) {
+        ug_k0_gather_coop<F, CH>(k0b, lane, en.x, en.y, en.z, a, scr, feat);
+      } else {
+        ug_k0_gather<F, CH>(k0b, h, en.x, en.y, en.z, a, feat);
+      }
 #pragma unroll
       for (int s = 0; s < CH; ++s) x[s] = (h * CH + s < C) ? feat[s] : 0.f;
       int64_t ray = tile * UG_WAVE + sl;
@@ -594,14 +725,22 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
       // (lane half h supplies k = 8h..8h+7), i.e. 8 layer-1 inputs / 8 accumulator registers per k-step
       const bf16x8 *A1b = (const bf16x8 *)M.A1, *A2b = (const bf16x8 *)M.A2;
       constexpr int KB1 = (KL + 7) / 8;
-#pragma unroll
-      for (int s = 0; s < KB1; ++s) {
+      ug_wpart wm = ug_load_part(A1b + lane, 1);
+      ug_split3 xs, xn;
+      {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (8 * s + e < KL) ? x[(8 * s + e < KL) ? 8 * s + e : 0] : 0.f;
-        const ug_split3 xs = ug_split8(v);
-        ug_fence_operands();
-        ug_mfma6x4(A1b + (s * 12) * 64 + lane, xs, acc1);
+        for (int e = 0; e < 8; ++e) v[e] = (e < KL) ? x[e < KL ? e : 0] : 0.f;
+        xs = ug_split8(v);
+      }
+      ug_fence_operands();
+#pragma unroll
+      for (int s = 0; s < KB1; ++s) {
+        float vn[8];   // inputs of the next layer-1 step (dummy zeros after the last one)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vn[e] = (8 * (s + 1) + e < KL) ? x[(8 * (s + 1) + e < KL) ? 8 * (s + 1) + e : 0] : 0.f;
+        ug_mfma6x4(A1b + (s * 12) * 64 + lane, (s + 1 < KB1 ? A1b + ((s + 1) * 12) * 64 : A2b) + lane, xs, vn, xn, acc1, wm);
+        xs = xn;
       }
       ug_fence_results();
 #pragma unroll
@@ -611,14 +750,21 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
           acc1[o][r] = fmaxf(acc1[o][r], 0.f);
           acc2[o][r] = M.B2[bo + o * 16 + r];
         }
-#pragma unroll
-      for (int st = 0; st < 8; ++st) {
+      {
         float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc1[st >> 1][8 * (st & 1) + e];
-        const ug_split3 xs = ug_split8(v);
-        ug_fence_operands();
-        ug_mfma6x4(A2b + (st * 12) * 64 + lane, xs, acc2);
+        for (int e = 0; e < 8; ++e) v[e] = acc1[0][e];
+        xs = ug_split8(v);
+      }
+      ug_fence_operands();
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        float vn[8];   // accumulator registers feeding the next k-step (re-reads the last one at the end)
+        constexpr int dummy = 0; (void)dummy;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vn[e] = acc1[(st + 1 < 8 ? st + 1 : st) >> 1][8 * ((st + 1 < 8 ? st + 1 : st) & 1) + e];
+        ug_mfma6x4(A2b + (st * 12) * 64 + lane, A2b + ((st + 1 < 8 ? st + 1 : st) * 12) * 64 + lane, xs, vn, xn, acc2, wm);
+        xs = xn;
       }
       ug_fence_results();
     }

@@ -62,19 +62,49 @@ __global__ void k_pack_mlp(const float *__restrict__ w0, const float *__restrict
 }
 
 // persistent shade kernel over a work list written by k_march (two-kernel path)
-template <int F, int C, int PE, int NW, bool BF>
+// k0 feature gather for every survivor of the work list, decoupled from the rgbnet so it can run at high
+// occupancy (latency-bound scattered 192-byte reads): lanes l / l+32 own survivor l&31 and one channel half each.
+template <int F, int C>
+__global__ void __launch_bounds__(256, 4)
+k_shade_gather(ug_shade_args a, const float *__restrict__ k0b, ug_ws_view ws, int64_t nblocks) {
+  constexpr int CH = UG_CH(C);
+  const int64_t blk = ug_xcd_remap(blockIdx.x, nblocks);
+  if (blk >= nblocks) return;
+  const int64_t tile = blk * 4 + (threadIdx.x >> 6);
+  if (tile >= ws.n_tiles) return;
+  const int lane = ug_lane(), h = lane >> 5, sv = lane & 31;
+  const int count = ws.count[tile];
+  const float4 *__restrict__ ent = ws.ent + tile * ws.cap;
+  float *__restrict__ fo = ws.feat + tile * ws.cap * UG_FEAT_STRIDE;
+  for (int base = 0; base < count; base += 32) {
+    const int e = base + sv;
+    const bool ok = e < count;
+    float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) en = ent[e];
+    float feat[CH];
+    ug_k0_gather<F, CH>(k0b, h, en.x, en.y, en.z, a, feat);
+    if (ok) {
+#pragma unroll
+      for (int s = 0; s < CH; ++s) fo[(int64_t)e * UG_FEAT_STRIDE + h * CH + s] = feat[s];
+    }
+  }
+}
+
+template <int F, int C, int PE, int NW, bool BF, bool PRE, bool COOP>
 __global__ void __launch_bounds__(NW * 64, NW / 4)
 k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
             const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
             int32_t *__restrict__ tile_counter) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const ug_mlp_lds M = ug_mlp_stage<C, PE, BF>(lds, mlp);
+  float *scr = lds + ug_mlp_lds_floats<C, PE, BF>() + (threadIdx.x >> 6) * UG_COOP_SCRATCH_FLOATS;
   int victim = 0;
   for (;;) {
     const int64_t tile = ug_next_tile(tile_counter, ws.n_tiles, blockIdx.x & 7, victim);
     if (tile < 0) break;
-    ug_shade_tile<F, C, PE, BF>(a, viewdirs, k0b, M, tile, ws.count[tile], ws.ent + tile * ws.cap,
-                            ws.slot + tile * ws.cap, rgb_marched);
+    ug_shade_tile<F, C, PE, BF, PRE, COOP>(a, viewdirs, k0b, M, tile, ws.count[tile], ws.ent + tile * ws.cap,
+                                     ws.slot + tile * ws.cap, ws.feat + tile * ws.cap * UG_FEAT_STRIDE, scr,
+                                     rgb_marched);
   }
 }
 
@@ -93,6 +123,7 @@ k_render_fused(ug_march_args am, ug_shade_args as, const float *__restrict__ ray
                int32_t *__restrict__ tile_counter, int64_t n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const ug_mlp_lds M = ug_mlp_stage<C, PE, BF>(lds, mlp);
+  float *scr = lds + ug_mlp_lds_floats<C, PE, BF>() + (threadIdx.x >> 6) * UG_COOP_SCRATCH_FLOATS;
   const int64_t cap = (int64_t)UG_WAVE * am.S;
   const int64_t wslot = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
   float4 *__restrict__ ent = scratch_ent + wslot * cap;
@@ -109,7 +140,7 @@ k_render_fused(ug_march_args am, ug_shade_args as, const float *__restrict__ ray
     // from the previous tile.  Drain the stores, then invalidate the L1 (agent-scope acquire = buffer_inv sc1).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    ug_shade_tile<F, C, PE, BF>(as, viewdirs, k0b, M, tile, count, ent, slot, rgb_marched);
+    ug_shade_tile<F, C, PE, BF, false, false>(as, viewdirs, k0b, M, tile, count, ent, slot, nullptr, scr, rgb_marched);
     total += count;
   }
   if (ug_lane() == 0 && total) atomicAdd(survivors_total, (unsigned long long)total);
@@ -196,6 +227,8 @@ extern "C" int64_t ugrid_render_fused_ws_bytes(int32_t n_samples) {
   return 256 + ug_align256(slots * cap * 16) + ug_align256(slots * cap);
 }
 
+static int g_shade_split_gather = 0;  // 1: k_shade_gather + rgbnet-only kernel (measured slower: 12.8 vs 8.5 ms); 0: gather inside the rgbnet kernel
+static int g_coop_gather = 0;         // 1: cooperative coalesced k0 gather (experimental, measured slower: 10.3 vs 8.5 ms)
 static int g_mlp_bf16x3 = 1;  // 1: rgbnet on bf16x3-split MFMA (fp32-accurate, 2.5x fewer MFMA cycles); 0: fp32 MFMA
 
 template <int F, bool L2, int C, int PE, int NW, bool BF>
@@ -203,7 +236,7 @@ static int ug_fused_launch_nw(const ug_march_args &am, const ug_shade_args &as, 
                            const float *rays_d, const float *viewdirs, const float *t_table,
                            const float *s_table, const float *dens_bricks, const float *k0b, const float *mlp,
                            float *alphainv_last, float *depth, float *rgb, void *ws_mem, hipStream_t st) {
-  const int lds_bytes = (int)sizeof(float) * ug_mlp_lds_floats<C, PE, BF>();
+  const int lds_bytes = ug_shade_lds_bytes<C, PE, BF, NW>();
   static bool attr_set = false;
   if (!attr_set) {
     UG_HIP(hipFuncSetAttribute((const void *)k_render_fused<F, L2, C, PE, NW, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
@@ -234,8 +267,8 @@ static int ug_fused_launch(const ug_march_args &am, const ug_shade_args &as, con
   if (g_mlp_bf16x3)
     return ug_fused_launch_nw<F, L2, C, PE, 8, true>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks,
                                                      k0b, mlp, alphainv_last, depth, rgb, ws_mem, st);
-  return ug_fused_launch_nw<F, L2, C, PE, 12, false>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks,
-                                                     k0b, mlp, alphainv_last, depth, rgb, ws_mem, st);
+  return ug_fused_launch_nw<F, L2, C, PE, 8, false>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks,
+                                                    k0b, mlp, alphainv_last, depth, rgb, ws_mem, st);
 }
 
 extern "C" int ugrid_render_fused(const ugrid_render_params *p, const float *rays_o, const float *rays_d,
@@ -274,7 +307,7 @@ extern "C" int ugrid_render_fused_stats(const void *ws_mem, int64_t *d_stats, ug
   return (int)hipMemcpyAsync(d_stats, (const char *)ws_mem + 64, sizeof(int64_t), hipMemcpyDeviceToDevice, ST(s));
 }
 
-static int g_shade_waves = 12;  // waves per shade workgroup: 8 (2/SIMD, no spills) or 12 (3/SIMD)
+static int g_shade_waves = 8;   // (knob kept for ABI; every shade variant now runs 8 waves = 2 per SIMD per workgroup)
 
 extern "C" int ugrid_tune(const char *key, int value) {
   if (!key) return (int)hipErrorInvalidValue;
@@ -282,16 +315,18 @@ extern "C" int ugrid_tune(const char *key, int value) {
   if (!strcmp(key, "march_waves")) return ug_set_march_waves(value) ? (int)hipErrorInvalidValue : 0;
   if (!strcmp(key, "fused_waves") && (value == 8 || value == 12)) { g_fused_waves = value; return 0; }
   if (!strcmp(key, "mlp_bf16x3") && (value == 0 || value == 1)) { g_mlp_bf16x3 = value; return 0; }
+  if (!strcmp(key, "split_gather") && (value == 0 || value == 1)) { g_shade_split_gather = value; return 0; }
+  if (!strcmp(key, "coop_gather") && (value == 0 || value == 1)) { g_coop_gather = value; return 0; }
   return (int)hipErrorInvalidValue;
 }
 
-template <int F, int C, int PE, int NW, bool BF>
+template <int F, int C, int PE, int NW, bool BF, bool PRE, bool COOP>
 static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
                               ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
-  const int lds_bytes = (int)sizeof(float) * ug_mlp_lds_floats<C, PE, BF>();
+  const int lds_bytes = ug_shade_lds_bytes<C, PE, BF, NW>();
   static bool attr_set = false;
   if (!attr_set) {
-    UG_HIP(hipFuncSetAttribute((const void *)k_shade_mlp<F, C, PE, NW, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    UG_HIP(hipFuncSetAttribute((const void *)k_shade_mlp<F, C, PE, NW, BF, PRE, COOP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
   UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
@@ -299,7 +334,12 @@ static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, con
   int64_t wgs = (ws.n_tiles + NW - 1) / NW;
   if (wgs > 256) wgs = 256;
   wgs = (wgs + 7) / 8 * 8;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_mlp<F, C, PE, NW, BF>), dim3((unsigned)wgs), dim3(NW * 64), lds_bytes, st, a,
+  if (PRE) {
+    const int64_t nblocks = (ws.n_tiles + 3) / 4;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_gather<F, C>), dim3((unsigned)(((nblocks + 7) / 8) * 8)), dim3(256), 0, st,
+                       a, k0b, ws, nblocks);
+  }
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_mlp<F, C, PE, NW, BF, PRE, COOP>), dim3((unsigned)wgs), dim3(NW * 64), lds_bytes, st, a,
                      viewdirs, k0b, mlp, ws, rgb, counter);
   UG_LAUNCH_CHECK();
   return 0;
@@ -311,9 +351,12 @@ static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const 
   // bf16x3 always runs 8 waves per workgroup (214 VGPRs, no spills).  The 12-wave build needs 37 spills to
   // fit 168 VGPRs and showed run-to-run differences on MI355X (a survivor's contribution occasionally lost,
   // tools/gpu_mlp_modes.py) while gaining only 4 %; it is not instantiated.
-  if (g_mlp_bf16x3) return ug_shade_launch_nw<F, C, PE, 8, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-  if (g_shade_waves == 8) return ug_shade_launch_nw<F, C, PE, 8, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-  return ug_shade_launch_nw<F, C, PE, 12, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  if (g_mlp_bf16x3) {
+    if (g_shade_split_gather) return ug_shade_launch_nw<F, C, PE, 8, true, true, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+    if (g_coop_gather) return ug_shade_launch_nw<F, C, PE, 8, true, false, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+    return ug_shade_launch_nw<F, C, PE, 8, true, false, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  }
+  return ug_shade_launch_nw<F, C, PE, 8, false, false, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
 }
 
 extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *viewdirs, const float *k0_bricks,

@@ -51,7 +51,7 @@ class FourierGridRenderer:
       contracted_norm ('inf' | 'l2'), world_len.
     """
 
-    def __init__(self, state, device, max_ws_bytes=16 << 30, fused=False):
+    def __init__(self, state, device, max_ws_bytes=48 << 30, fused=False):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("FourierGridRenderer needs a HIP device (no CPU path)")
@@ -140,7 +140,7 @@ class FourierGridRenderer:
         return p
 
     def rays_per_chunk(self, S):
-        per_ray = 17 * S + 8
+        per_ray = (17 + 48) * S + 8   # {p, w} 16 B + slot 1 B + 12 k0 features 48 B per sample, worst case
         n = max(64, (self.max_ws_bytes // per_ray) // 64 * 64)
         return n
 
