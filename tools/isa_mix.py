@@ -1,12 +1,12 @@
 """Static instruction mix of the fused kernels (device-only assembly)."""
 import collections, re, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "unboundednerfpytorch_amd", "csrc", "ugrid_fused.hip")
+src = os.path.join(ROOT, "unboundednerfpytorch_amd", "csrc", "ugrid_march.hip")
 out = "/tmp/ugrid_fused.s"
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"),
+subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fno-slp-vectorize", "-I" + os.path.join(ROOT, "include"),
                        "-S", "--cuda-device-only", "-o", out, src], stderr=subprocess.DEVNULL)
 txt = open(out).read()
-pat = sys.argv[1:] or ["k_marchILi3ELb0", "k_shade_mlpILi3ELi12"]
+pat = sys.argv[1:] or ["k_marchILi3ELb0ELi5"]
 for f in re.split(r'\n(?=_Z\w+:)', txt):
     name = f.split(':', 1)[0]
     if any(p in name for p in pat):

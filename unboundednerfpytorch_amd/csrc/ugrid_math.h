@@ -78,15 +78,18 @@ __device__ __forceinline__ float ug_alpha(float dens_plus_shift, float interval)
 struct ug_axis_fast { int cell; float wlo, whi; };
 
 __device__ __forceinline__ ug_axis_fast ug_axis_inrange(float c, int n) {
-  const float ix = ((c + 1.0f) * 0.5f) * (float)(n - 1);
+  // ((c+1)/2)*(n-1): fma(c, .5, .5) == RN(c+1)*.5 exactly (scaling by 2 commutes with rounding)
+  const float ix = fmaf(c, 0.5f, 0.5f) * (float)(n - 1);
   // cell = floor(ix) clamped to [0, n-2].  For ix < n-1 this is torch's floor and the weights below are
-  // torch's (x1 - ix), (ix - x0) bit for bit; at ix == n-1 exactly (c == 1) the clamp moves to cell n-2 and the
-  // same two expressions give (0, 1): the live corner n-1 with weight 1, as torch computes it from cell n-1.
+  // torch's (ix - x0) and (x1 - ix) bit for bit: ix - cf is exact (Sterbenz), and (cf+1) - ix is exact for
+  // cf >= 1, so it equals RN(1 - (ix - cf)); for cf == 0 the two expressions are literally the same.  At
+  // ix == n-1 exactly (c == 1) the clamp moves to cell n-2 and the weights become (0, 1): the live corner n-1
+  // with weight 1, as torch computes it from cell n-1.
   // NaN -> med3 returns 0 -> cell 0 (never an out-of-bounds address), weights NaN (sample is dropped).
   const float cf = __builtin_amdgcn_fmed3f(floorf(ix), 0.0f, (float)(n - 2));
   ug_axis_fast a;
   a.cell = (int)cf;
-  a.wlo = (cf + 1.0f) - ix;
   a.whi = ix - cf;
+  a.wlo = 1.0f - a.whi;
   return a;
 }
