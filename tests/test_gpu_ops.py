@@ -203,10 +203,11 @@ def test_alpha2weight_properties_large(mods):
     assert torch.all(w[after] == 0) and torch.all(T[after] == 1)
 
 
+@pytest.mark.parametrize("shape", [(3, 2, 9, 6, 11), (2, 3, 5, 7, 12), (1, 1, 4, 4, 4), (7, 1, 20, 20, 20)])
 @pytest.mark.parametrize("dense", [True, False])
-def test_total_variation_bit_exact(mods, dense):
+def test_total_variation_bit_exact(mods, dense, shape):
+    """(.., 11): scalar kernel; sz_k % 4 == 0: the float4 kernel -- both bit-identical to the oracle."""
     tv = mods[1]
-    shape = (3, 2, 9, 6, 11)
     n = int(np.prod(shape))
     prm = torch.from_numpy(synth.normal(60, n, 0.0, 2.0).reshape(shape))
     g = synth.normal(61, n).reshape(shape)

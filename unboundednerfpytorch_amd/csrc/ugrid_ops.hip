@@ -411,6 +411,51 @@ __global__ void k_tv(const float *__restrict__ param, float *__restrict__ grad, 
   grad[idx] = g0 + g;
 }
 
+// 4 voxels (one float4 along the fastest axis) per lane, 32-bit index arithmetic: used when sz_k % 4 == 0,
+// N < 2^31 and both arrays are 16-byte aligned.  The per-voxel expression (six sequential float adds) is the
+// scalar kernel's, so results are bit-identical; neighbours along k come from the same float4 plus two scalar
+// loads, neighbours along j / i are four more float4 loads.
+template <bool DENSE>
+__global__ void __launch_bounds__(256)
+k_tv_vec4(const float *__restrict__ param, float *__restrict__ grad, float wy, float wz, int sz_i, int sz_j,
+          int sz_k, unsigned n4) {
+  const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n4) return;
+  const unsigned idx = q * 4u;
+  float4 g0 = *(const float4 *)(grad + idx);
+  if (!DENSE && g0.x == 0.f && g0.y == 0.f && g0.z == 0.f && g0.w == 0.f) return;
+  const unsigned k4 = (unsigned)sz_k >> 2;
+  const unsigned kq = q % k4, row = q / k4;      // row = (plane * sz_i + i) * sz_j + j
+  const unsigned j = row % (unsigned)sz_j, i = (row / (unsigned)sz_j) % (unsigned)sz_i;
+  const unsigned sj = (unsigned)sz_k, si = (unsigned)sz_k * (unsigned)sz_j;
+  const float4 p = *(const float4 *)(param + idx);
+  const bool k_first = kq == 0, k_last = kq == k4 - 1;
+  const float pm = k_first ? 0.f : param[idx - 1];
+  const float pp = k_last ? 0.f : param[idx + 4];
+  float4 nj0 = p, nj1 = p, ni0 = p, ni1 = p;
+  if (j != 0) nj0 = *(const float4 *)(param + idx - sj);
+  if (j != (unsigned)sz_j - 1) nj1 = *(const float4 *)(param + idx + sj);
+  if (i != 0) ni0 = *(const float4 *)(param + idx - si);
+  if (i != (unsigned)sz_i - 1) ni1 = *(const float4 *)(param + idx + si);
+  const float pv[4] = {p.x, p.y, p.z, p.w}, gv[4] = {g0.x, g0.y, g0.z, g0.w};
+  const float km[4] = {pm, p.x, p.y, p.z}, kp[4] = {p.y, p.z, p.w, pp};
+  const float a0[4] = {nj0.x, nj0.y, nj0.z, nj0.w}, a1[4] = {nj1.x, nj1.y, nj1.z, nj1.w};
+  const float b0[4] = {ni0.x, ni0.y, ni0.z, ni0.w}, b1[4] = {ni1.x, ni1.y, ni1.z, ni1.w};
+  float out[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float g = 0;
+    g += ((k_first && e == 0) ? 0.f : wz * ug_clamp1(pv[e] - km[e]));
+    g += ((k_last && e == 3) ? 0.f : wz * ug_clamp1(pv[e] - kp[e]));
+    g += (j == 0 ? 0.f : wy * ug_clamp1(pv[e] - a0[e]));
+    g += (j == (unsigned)sz_j - 1 ? 0.f : wy * ug_clamp1(pv[e] - a1[e]));
+    g += (i == 0 ? 0.f : wz * ug_clamp1(pv[e] - b0[e]));
+    g += (i == (unsigned)sz_i - 1 ? 0.f : wz * ug_clamp1(pv[e] - b1[e]));
+    out[e] = (DENSE || gv[e] != 0.f) ? gv[e] + g : gv[e];
+  }
+  *(float4 *)(grad + idx) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
 // ----------------------------------------------------------------------------------------------
 // cumdist_thres: one wave per ray, 64 distances per coalesced load, serial float chain as above
 // ----------------------------------------------------------------------------------------------
@@ -658,7 +703,17 @@ extern "C" int ugrid_total_variation_add_grad(const float *param, float *grad, f
   (void)wx;  // ignored by the reference as well (total_variation_kernel.cu:31-32)
   wy /= 6;
   wz /= 6;
-  if (dense_mode)
+  const bool vec = (sz_k % 4 == 0) && N < ((int64_t)1 << 31) && sz_i * sz_j * sz_k > 0 &&
+                   ((((uintptr_t)param) | ((uintptr_t)grad)) & 15) == 0;
+  if (vec) {
+    const unsigned n4 = (unsigned)(N / 4);
+    if (dense_mode)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_vec4<true>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, grad,
+                         wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, n4);
+    else
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_vec4<false>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, grad,
+                         wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, n4);
+  } else if (dense_mode)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv<true>), dim3(ug_blocks(N, 256)), dim3(256), 0, ST(s), param,
                        grad, wy, wz, sz_i, sz_j, sz_k, N);
   else
