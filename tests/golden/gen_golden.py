@@ -198,6 +198,35 @@ def gen_dvgo():
         print(name, "world", ws, "M=%d" % out["weights"].numel(), "rgb mean %.3f" % float(out["rgb_marched"].mean()))
 
 
+def gen_checkpoint():
+    """A reference-format checkpoint (FourierGrid_ckpt_manager.py:44-51: model_kwargs + model_state_dict) of a tiny
+    FourierGridModel with NON-trivial geometry (scene box != [-1,1]^3, num_voxels != num_voxels_base so that
+    voxel_size_ratio != 1) plus the reference's render of a few rays: exercises
+    FourierGridRenderer.from_reference_checkpoint."""
+    mod = install_stubs.import_reference("FourierGrid_model")
+    G, Gb, F, C = 9, 12, 2, 12
+    model = mod.FourierGridModel(xyz_min=[-2.0, -1.0, -3.0], xyz_max=[2.0, 3.0, 1.0],
+                                 num_voxels_density=G ** 3, num_voxels_base_density=Gb ** 3,
+                                 num_voxels_rgb=G ** 3, num_voxels_base_rgb=Gb ** 3, num_voxels_viewdir=-1,
+                                 alpha_init=1e-3, fast_color_thres=1e-4, fourier_freq_num=F, rgbnet_dim=C)
+    Gd = int(model.world_len_density)
+    params = synth.fouriergrid_params(41, Gd, F, C, dens_mean=4.0, dens_std=10.0)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in params.items():
+            sd[k].copy_(torch.from_numpy(v))
+    ckpt = {'global_step': 123, 'model_kwargs': model.get_kwargs(), 'model_state_dict': model.state_dict()}
+    torch.save(ckpt, os.path.join(HERE, "fg_ckpt_small.tar"))
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(41, 64, origin_scale=0.6)]
+    o = o + torch.tensor([0.0, 1.0, -1.0])   # around the scene centre
+    with torch.no_grad():
+        out = model(o, d, v, stepsize=0.5, render_depth=True)
+    np.savez_compressed(os.path.join(HERE, "fg_ckpt_small_render.npz"),
+                        **{k: out[k].numpy() for k in ("rgb_marched", "depth", "alphainv_last")},
+                        world_len=np.int64(Gd), interval=np.float32(float(0.5 * model.voxel_size_ratio_density)))
+    print("checkpoint world_len", Gd, "ratio", float(model.voxel_size_ratio_density), "M", out["weights"].numel())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)  # deterministic reduction order in F.linear / grid_sample
     gen_fouriergrid()
@@ -205,3 +234,4 @@ if __name__ == "__main__":
     gen_autograd_and_adam()
     gen_rays_view()
     gen_dvgo()
+    gen_checkpoint()

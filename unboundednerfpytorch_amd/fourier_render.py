@@ -231,41 +231,62 @@ class FourierGridRenderer:
         return int(out.item())
 
     # -- constructors ------------------------------------------------------------------------------
+    # -- frame-level entry point --------------------------------------------
+    @torch.no_grad()
+    def render_view(self, H, W, K, c2w, stepsize, inverse_y=False, flip_x=False, flip_y=False, group=None):
+        """One whole view, like the body of the reference's render_viewpoints loop (run_render.py:41-70) but
+        without its 8192-ray chunking: rays are generated on the device, rendered in one fused pass and, when a
+        process group is initialised, sharded over its ranks with one all-gather of the [R,5] tiles (dist.py).
+        Returns rgb [H,W,3], depth [H,W], bgmap [H,W] (= alphainv_last) on the device."""
+        from .dist import render_sharded
+        c2w = torch.as_tensor(c2w, dtype=torch.float32).to(self.device)
+        ro, rd, vd = get_rays_of_a_view(H, W, K, c2w, inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y)
+        ro, rd, vd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous(), vd.reshape(-1, 3).contiguous()
+        out = render_sharded(self.forward, ro, rd, vd, group=group, stepsize=stepsize)
+        return (out["rgb_marched"].reshape(H, W, 3), out["depth"].reshape(H, W), out["alphainv_last"].reshape(H, W))
+
     @classmethod
     def from_reference_checkpoint(cls, ckpt, device, **kw):
         """ckpt: the dict the reference saves (`model_kwargs`, `model_state_dict`;
-        FourierGrid_ckpt_manager.py:44-51).  Derived quantities are recomputed with the reference's own
-        formulas (FourierGrid_model.py:100-122,173,335-349)."""
-        mk, sd = ckpt["model_kwargs"], ckpt["model_state_dict"]
-        bg_len = float(mk.get("bg_len", 0.2))
-        lo = torch.Tensor([-1, -1, -1]) - bg_len
-        hi = torch.Tensor([1, 1, 1]) + bg_len
-        vol = (hi - lo).prod()
-        vs = (vol / mk["num_voxels_density"]).pow(1 / 3)
-        vs_base = (vol / mk["num_voxels_base_density"]).pow(1 / 3)
-        world = ((hi - lo) / vs).long()
-        ws_, bs_ = [], []
-        if any(k.startswith("rgbnet.") for k in sd):
-            names = sorted({k.rsplit(".", 1)[0] for k in sd if k.startswith("rgbnet.")},
-                           key=lambda n: [int(x) for x in n.split(".")[1:]])
-            ws_ = [sd[n + ".weight"] for n in names]
-            bs_ = [sd[n + ".bias"] for n in names]
-        state = {
-            "density_grid": sd["density.grid"], "k0_grid": sd["k0.grid"],
-            "rgbnet_weights": ws_, "rgbnet_biases": bs_,
-            "scene_center": sd["scene_center"], "scene_radius": sd["scene_radius"],
-            "xyz_min": sd.get("xyz_min", lo), "xyz_max": sd.get("xyz_max", hi),
-            "bg_len": bg_len, "fourier_freq_num": int(mk.get("fourier_freq_num", 5)),
-            "viewbase_pe": int(mk.get("viewbase_pe", 4)),
-            "act_shift": float(sd["act_shift"]) if "act_shift" in sd else math.log(1 / (1 - mk["alpha_init"]) - 1),
-            "voxel_size_ratio": float(vs / vs_base),
-            "fast_color_thres": mk.get("fast_color_thres", 0),
-            "contracted_norm": mk.get("contracted_norm", "inf"),
-            "world_len": int(world[0]),
-        }
-        if isinstance(state["fast_color_thres"], dict):
-            state["fast_color_thres"] = state["fast_color_thres"][max(state["fast_color_thres"])]
-        return cls(state, device, **kw)
+        FourierGrid_ckpt_manager.py:44-51), e.g. torch.load('fine_last.tar', weights_only=False)."""
+        return cls(state_from_reference_checkpoint(ckpt), device, **kw)
+
+
+def state_from_reference_checkpoint(ckpt):
+    """Reference checkpoint -> the plain `state` dict of FourierGridRenderer.  Derived quantities are recomputed
+    with the reference's own formulas (FourierGrid_model.py:100-122,173,335-349); note that the checkpoint's
+    model_kwargs['xyz_min'/'xyz_max'] are the CONTRACTED bounds (-1-bg_len .. 1+bg_len, get_kwargs :352-353) while
+    the scene box survives only as the scene_center / scene_radius buffers of the state dict."""
+    mk, sd = ckpt["model_kwargs"], ckpt["model_state_dict"]
+    bg_len = float(mk.get("bg_len", 0.2))
+    lo = torch.Tensor([-1, -1, -1]) - bg_len
+    hi = torch.Tensor([1, 1, 1]) + bg_len
+    vol = (hi - lo).prod()
+    vs = (vol / mk["num_voxels_density"]).pow(1 / 3)
+    vs_base = (vol / mk["num_voxels_base_density"]).pow(1 / 3)
+    world = ((hi - lo) / vs).long()
+    ws_, bs_ = [], []
+    if any(k.startswith("rgbnet.") for k in sd):
+        names = sorted({k.rsplit(".", 1)[0] for k in sd if k.startswith("rgbnet.")},
+                       key=lambda n: [int(x) for x in n.split(".")[1:]])
+        ws_ = [sd[n + ".weight"] for n in names]
+        bs_ = [sd[n + ".bias"] for n in names]
+    thres = mk.get("fast_color_thres", 0)
+    if isinstance(thres, dict):
+        thres = thres[max(thres)]
+    return {
+        "density_grid": sd["density.grid"], "k0_grid": sd["k0.grid"],
+        "rgbnet_weights": ws_, "rgbnet_biases": bs_,
+        "scene_center": sd["scene_center"], "scene_radius": sd["scene_radius"],
+        "xyz_min": sd.get("xyz_min", lo), "xyz_max": sd.get("xyz_max", hi),
+        "bg_len": bg_len, "fourier_freq_num": int(mk.get("fourier_freq_num", 5)),
+        "viewbase_pe": int(mk.get("viewbase_pe", 4)),
+        "act_shift": float(sd["act_shift"]) if "act_shift" in sd else math.log(1 / (1 - mk["alpha_init"]) - 1),
+        "voxel_size_ratio": float(vs / vs_base),
+        "fast_color_thres": thres,
+        "contracted_norm": mk.get("contracted_norm", "inf"),
+        "world_len": int(world[0]),
+    }
 
 
 def get_rays_of_a_view(H, W, K, c2w, inverse_y=False, flip_x=False, flip_y=False, mode="center"):
