@@ -640,12 +640,21 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
   const int h = lane >> 5, sv = lane & 31;
   float accr = 0.f, accg = 0.f, accb = 0.f;  // lane = ray slot of this tile
 
+  // the work-list entry of the NEXT pass is fetched while this pass's rgbnet runs (software prefetch)
+  float4 en_n = make_float4(0.f, 0.f, 0.f, 0.f);
+  int sl_n = 0;
+  if (sv < count) { en_n = ent[sv]; sl_n = slot[sv]; }
   for (int base = 0; base < count; base += 32) {
     const int e = base + sv;
     const bool ok = e < count;
-    float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
-    int sl = 0;
-    if (ok) { en = ent[e]; sl = slot[e]; }
+    const float4 en = en_n;
+    const int sl = sl_n;
+    {
+      const int e2 = e + 32;
+      en_n = make_float4(0.f, 0.f, 0.f, 0.f);
+      sl_n = 0;
+      if (e2 < count) { en_n = ent[e2]; sl_n = slot[e2]; }
+    }
     // ---- layer-1 inputs of this lane: half of k0 + half of the view-direction embedding
     float x[KL];
     {

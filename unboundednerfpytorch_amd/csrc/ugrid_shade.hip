@@ -296,9 +296,6 @@ extern "C" int ugrid_render_fused(const ugrid_render_params *p, const float *ray
   }
   UG_FUSED_CASE(3, 12, 4)
   UG_FUSED_CASE(4, 12, 4)
-  UG_FUSED_CASE(2, 3, 2)
-  UG_FUSED_CASE(3, 3, 2)
-  UG_FUSED_CASE(1, 12, 4)
 #undef UG_FUSED_CASE
   return (int)hipErrorNotSupported;
 }
@@ -379,9 +376,11 @@ extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *vie
     return ug_shade_launch<F_, C_, PE_>(a, viewdirs, k0_bricks, mlp_packed, ws, rgb_marched, counter, ST(s));
   UG_SHADE_CASE(3, 12, 4)  // Mip-NeRF-360 *_single.py  (configs/default.py:104-124)
   UG_SHADE_CASE(4, 12, 4)  // tankstemple_unbounded/truck_single.py:105
+  UG_SHADE_CASE(5, 12, 4)  // FourierGridModel's constructor default fourier_freq_num=5 (FourierGrid_model.py:137)
+  UG_SHADE_CASE(2, 12, 4)
+  UG_SHADE_CASE(1, 12, 4)
   UG_SHADE_CASE(2, 3, 2)   // waymo-style rgbnet_dim=3, viewbase_pe=2 (configs/waymo/waymo_no_block.py:144-149)
   UG_SHADE_CASE(3, 3, 2)
-  UG_SHADE_CASE(1, 12, 4)
 #undef UG_SHADE_CASE
   return (int)hipErrorNotSupported;
 }

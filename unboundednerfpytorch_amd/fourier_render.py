@@ -169,7 +169,7 @@ class FourierGridRenderer:
         depth = torch.empty(R, dtype=torch.float32, device=dev)
         last = torch.empty(R, dtype=torch.float32, device=dev)
         timing = render_kwargs.get("timing")  # optional list collecting ([ev0, ev1, ev2], n_rays) per launch group
-        fused = self.use_fused and self.has_mlp
+        fused = self.use_fused and self.has_mlp and (self.F, self.C, self.pe) in ((3, 12, 4), (4, 12, 4))
         with torch.cuda.device(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             if fused:
