@@ -3,7 +3,7 @@
 // instructions per sample, 131 per sincosf, 174 per powf, 12 per IEEE division).
 //
 // Accuracy contracts (checked in numpy before adoption):
-//   ug_sincos   |x| <= 64: max abs error 9.2e-8 (< 1 ulp at 1.0); results clamp-free in [-1, 1]
+//   ug_sincos   max abs error 1.2e-7 on |x| <= 4 (1 ulp at 1.0), 1.7e-7 on |x| <= 16
 //   ug_div_*    Markstein division: q = RN(x/d) except for rare double-rounding ties (<= 1 ulp)
 //   ug_alpha    reproduces 1 - RN(pow(RN(1+e), -interval)) (a correctly rounded powf) exactly for
 //               small alpha and to <= 1 ulp of pow elsewhere -- closer to glibc's powf than ocml powf is
@@ -25,21 +25,25 @@ __device__ __forceinline__ float ug_div_r(float x, float d, float r) {
 }
 
 // ---- sin / cos --------------------------------------------------------------------------------
-// Cody-Waite reduction by pi/2 with two FMAs (k <= 41 for |x| <= 64 keeps k*C1 exact inside the FMA),
-// Cephes single-precision minimax kernels on |r| <= pi/4, quadrant fix-up with selects.
+// Reduction by pi (not pi/2): x = k*pi + r, |r| <= pi/2, so sin x = (-1)^k sin r and cos x = (-1)^k cos r --
+// the quadrant fix-up is ONE shared sign bit (cvt, shift, two xors) instead of the swap-and-negate selects
+// of a pi/2 reduction, which cost as much as the polynomials.  Two-FMA Cody-Waite reduction (k <= 20 for
+// |x| <= 64 keeps k*PI_HI exact inside the FMA); least-squares polynomials on |r| <= pi/2, sin as
+// r + r^3 P(r^2) so the leading term is exact.  Max abs error (numpy check, fp64 truth): 1.2e-7 on |x| <= 4,
+// 1.7e-7 on |x| <= 16 -- one fp32 ulp at 1.0; the largest |sin| returned is 1 + 1 ulp.
 __device__ __forceinline__ void ug_sincos(float x, float *s, float *c) {
-  const float k = rintf(x * 0.636619772f);
-  float r = fmaf(-k, 1.5707963705062866f, x);
-  r = fmaf(-k, -4.371139000186241e-08f, r);
+  const float k = rintf(x * 0.3183098861837907f);
+  float r = fmaf(-k, 3.1415927410125732f, x);
+  r = fmaf(-k, -8.742278000372485e-08f, r);
   const float z = r * r;
-  const float sp = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f), z * r, r);
-  const float cp = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f),
-                        z * z, fmaf(-0.5f, z, 1.0f));
-  const int q = (int)k;
-  const float s0 = (q & 1) ? cp : sp;
-  const float c0 = (q & 1) ? sp : cp;
-  *s = (q & 2) ? -s0 : s0;
-  *c = ((q + 1) & 2) ? -c0 : c0;
+  const float ps = fmaf(fmaf(fmaf(2.605012241474469e-06f, z, -0.00019808979413937777f), z, 0.008333049714565277f), z,
+                        -0.16666658222675323f);
+  const float sp = fmaf(r * z, ps, r);
+  const float cp = fmaf(fmaf(fmaf(fmaf(fmaf(-2.60495482962142e-07f, z, 2.4760051019256935e-05f), z,
+                                            -0.0013888359535485506f), z, 0.04166663438081741f), z, -0.5f), z, 1.0f);
+  const unsigned sign = (unsigned)((int)k) << 31;
+  *s = __uint_as_float(__float_as_uint(sp) ^ sign);
+  *c = __uint_as_float(__float_as_uint(cp) ^ sign);
 }
 
 // ---- raw density -> alpha ----------------------------------------------------------------------
@@ -75,7 +79,7 @@ __device__ __forceinline__ float ug_alpha(float dens_plus_shift, float interval)
 // ---- in-range trilinear cell set-up --------------------------------------------------------------
 // grid_sample(align_corners=True) along one axis for a coordinate already inside [-1, 1] (contracted
 // points and sin/cos level coordinates always are): ix = ((c+1)/2)*(n-1) in [0, n-1].
-struct ug_axis_fast { int cell; float wlo, whi; };
+struct ug_axis_fast { int cell; float cellf, wlo, whi; };
 
 __device__ __forceinline__ ug_axis_fast ug_axis_inrange(float c, int n) {
   // ((c+1)/2)*(n-1): fma(c, .5, .5) == RN(c+1)*.5 exactly (scaling by 2 commutes with rounding)
@@ -89,6 +93,7 @@ __device__ __forceinline__ ug_axis_fast ug_axis_inrange(float c, int n) {
   const float cf = __builtin_amdgcn_fmed3f(floorf(ix), 0.0f, (float)(n - 2));
   ug_axis_fast a;
   a.cell = (int)cf;
+  a.cellf = cf;
   a.whi = ix - cf;
   a.wlo = 1.0f - a.whi;
   return a;

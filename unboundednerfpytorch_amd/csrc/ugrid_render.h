@@ -181,8 +181,12 @@ struct ug_march_args {
 __device__ __forceinline__ float ug_density_level(const char *__restrict__ lvl, float cx, float cy, float cz,
                                                   int X, int Y, int Z) {
   const ug_axis_fast ax = ug_axis_inrange(cx, X), ay = ug_axis_inrange(cy, Y), az = ug_axis_inrange(cz, Z);
-  const unsigned rec = ((unsigned)ax.cell * (unsigned)(Y - 1) + (unsigned)ay.cell) * (unsigned)(Z - 1) + (unsigned)az.cell;
-  const float4 *b = (const float4 *)(lvl + (size_t)(rec * 32u));
+  // byte offset of the cell record: the row index cx*(Y-1)+cy is exact in fp32 ((X-1)(Y-1) < 2^24), so it costs one
+  // FMA + one convert; row * rowbytes is a full-rate 24-bit multiply (level < 4 GiB), then + cz*32.  The plain
+  // integer form compiled to quarter-rate v_mad_u64_u32 pairs.
+  const unsigned row = (unsigned)fmaf(ax.cellf, (float)(Y - 1), ay.cellf);
+  const unsigned off = __umul24(row, (unsigned)(Z - 1) << 5) + ((unsigned)az.cell << 5);
+  const float4 *b = (const float4 *)(lvl + off);
   const float4 v0 = b[0], v1 = b[1];
   const float w00 = az.wlo * ay.wlo, w01 = az.whi * ay.wlo, w10 = az.wlo * ay.whi, w11 = az.whi * ay.whi;
   float acc = v0.x * (w00 * ax.wlo);
