@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--grid", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-launch", action="store_true", help="single persistent launch instead of march + shade")
+    ap.add_argument("--pipeline", type=int, default=0, help="ray chunks software-pipelined over two streams (0 = off)")
     ap.add_argument("--tune", action="append", default=[], help="key=value speed knob (ugrid_tune), repeatable")
     ap.add_argument("--cpu-chunks", type=int, default=4, help="8192-ray chunks timed for the CPU baseline")
     return ap.parse_args()
@@ -116,7 +117,7 @@ def main():
     H, W, G = args.height, args.width, args.grid
     stepsize = 1.31 * G / 200.0 if G != 200 else 1.31
     state = make_state(G, device, seed=0)  # same model on every rank (replicated read-only grids)
-    rend = FourierGridRenderer(state, device, fused=args.single_launch)
+    rend = FourierGridRenderer(state, device, fused=args.single_launch, pipeline=args.pipeline)
     cpu_state = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_state = {k: ([x.cpu() for x in v] if isinstance(v, list) else (v.cpu() if torch.is_tensor(v) else v))
@@ -164,13 +165,16 @@ def main():
     # per-kernel durations from HIP events recorded on the launch stream inside the timed region
     n_chunks = len(timing) // max(1, args.steps)
     if not args.single_launch:
+        # (pipelined frames carry 4 events per chunk: march start/end on the march stream, shade start/end on the
+        # shade stream; the kernels of neighbouring chunks overlap, so the per-kernel sums exceed the frame time)
         march_ms = sum(ev[0].elapsed_time(ev[1]) for ev, _ in timing) / args.steps
-        shade_ms = sum(ev[1].elapsed_time(ev[2]) for ev, _ in timing) / args.steps
+        shade_ms = sum(ev[-2].elapsed_time(ev[-1]) for ev, _ in timing) / args.steps
     else:
         fused_ms = sum(ev[0].elapsed_time(ev[1]) for ev, _ in timing) / args.steps
     # survivors of the frame (one extra, untimed frame)
     if not args.single_launch:
         M = 0
+        rend.pipeline = 0
         chunk = rend.rays_per_chunk(S)
         for b in range(0, R, chunk):
             e = min(R, b + chunk)

@@ -131,6 +131,13 @@ def test_fused_render_deterministic_chunk_and_order_invariant(fr):
     single = fr.FourierGridRenderer(state, "cuda:0", fused=True)   # single persistent launch
     c2 = single(o, d, v, stepsize=0.5, render_depth=True)
     assert rend.survivors_of_last_chunk() == single.survivors_of_last_chunk()
+    # software-pipelined chunks on two streams (march of chunk k+1 overlaps shade of chunk k), used twice so
+    # the rotating work lists are re-used while the side streams still hold work
+    piped = fr.FourierGridRenderer(state, "cuda:0", pipeline=5)
+    for _ in range(2):
+        c3 = piped(o, d, v, stepsize=0.5, render_depth=True)
+        for k in ("rgb_marched", "depth", "alphainv_last"):
+            assert torch.equal(a[k], c3[k]), k
     perm = torch.from_numpy(np.random.RandomState(0).permutation(R)).cuda()
     e = rend(o[perm].contiguous(), d[perm].contiguous(), v[perm].contiguous(), stepsize=0.5, render_depth=True)
     for k in ("rgb_marched", "depth", "alphainv_last"):

@@ -189,14 +189,16 @@ __device__ __forceinline__ float ug_density_level(const char *__restrict__ lvl, 
   const float4 *b = (const float4 *)(lvl + off);
   const float4 v0 = b[0], v1 = b[1];
   const float w00 = az.wlo * ay.wlo, w01 = az.whi * ay.wlo, w10 = az.wlo * ay.whi, w11 = az.whi * ay.whi;
+  // corner order of grid_sample; fused multiply-adds (one rounding per corner instead of two: closer to the exact
+  // trilinear value than torch's own mul+add chain, and half the VALU instructions)
   float acc = v0.x * (w00 * ax.wlo);
-  acc += v0.y * (w01 * ax.wlo);
-  acc += v0.z * (w10 * ax.wlo);
-  acc += v0.w * (w11 * ax.wlo);
-  acc += v1.x * (w00 * ax.whi);
-  acc += v1.y * (w01 * ax.whi);
-  acc += v1.z * (w10 * ax.whi);
-  acc += v1.w * (w11 * ax.whi);
+  acc = fmaf(v0.y, w01 * ax.wlo, acc);
+  acc = fmaf(v0.z, w10 * ax.wlo, acc);
+  acc = fmaf(v0.w, w11 * ax.wlo, acc);
+  acc = fmaf(v1.x, w00 * ax.whi, acc);
+  acc = fmaf(v1.y, w01 * ax.whi, acc);
+  acc = fmaf(v1.z, w10 * ax.whi, acc);
+  acc = fmaf(v1.w, w11 * ax.whi, acc);
   return acc;
 }
 
@@ -352,7 +354,11 @@ template <int CH>
 __device__ __forceinline__ void ug_k0_level(const float *__restrict__ k0b, int h, int64_t level_base, float cx,
                                             float cy, float cz, int X, int Y, int Z, bool first, float (&feat)[CH]) {
   const ug_axis_fast ax = ug_axis_inrange(cx, X), ay = ug_axis_inrange(cy, Y), az = ug_axis_inrange(cz, Z);
+#ifdef UG_EXP_BCAST   // experiment only: every lane reads lane 0's record (1 cache line per load instruction)
+  const int64_t rec = level_base + __builtin_amdgcn_readfirstlane((ax.cell * (Y - 1) + ay.cell) * (Z - 1) + az.cell);
+#else
   const int64_t rec = level_base + ((int64_t)ax.cell * (Y - 1) + ay.cell) * (Z - 1) + az.cell;
+#endif
   const float *rec_p = k0b + (rec * 2 + h) * (8 * CH);
   float v[8 * CH];
   if constexpr ((8 * CH) % 4 == 0) {
@@ -374,7 +380,7 @@ __device__ __forceinline__ void ug_k0_level(const float *__restrict__ k0b, int h
     // half-brick layout [pair][corner][2 channels]: value of (corner c, channel ch) at (ch/2)*16 + c*2 + ch%2
     float acc = v[(ch >> 1) * 16 + (ch & 1)] * w[0];
 #pragma unroll
-    for (int c = 1; c < 8; ++c) acc += v[(ch >> 1) * 16 + c * 2 + (ch & 1)] * w[c];
+    for (int c = 1; c < 8; ++c) acc = fmaf(v[(ch >> 1) * 16 + c * 2 + (ch & 1)], w[c], acc);
     feat[ch] = first ? acc : feat[ch] + acc;
   }
 }

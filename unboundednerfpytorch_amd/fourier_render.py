@@ -51,7 +51,7 @@ class FourierGridRenderer:
       contracted_norm ('inf' | 'l2'), world_len.
     """
 
-    def __init__(self, state, device, max_ws_bytes=48 << 30, fused=False):
+    def __init__(self, state, device, max_ws_bytes=48 << 30, fused=False, pipeline=0):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("FourierGridRenderer needs a HIP device (no CPU path)")
@@ -60,6 +60,7 @@ class FourierGridRenderer:
         # fused=True: single persistent launch (march+shade per wave, 0.9 GB scratch); False (default, measured
         # faster on MI355X: 18.8 vs 23.5 ms per S1 frame): march kernel -> work list -> shade kernel
         self.use_fused = bool(fused)
+        self.pipeline = int(pipeline)
         dg = state["density_grid"].to(dev, torch.float32).contiguous()
         kg = state["k0_grid"].to(dev, torch.float32).contiguous()
         self.F = int(state["fourier_freq_num"])
@@ -112,6 +113,8 @@ class FourierGridRenderer:
             torch.cuda.current_stream(dev).synchronize()  # dg/kg temporaries may now be freed
         self._tables = {}
         self._ws = None
+        self._ws_ring = None
+        self._streams = None
         self._last = None
 
     # -- helpers ---------------------------------------------------------------------------------
@@ -188,6 +191,8 @@ class FourierGridRenderer:
                     ev[1].record()
                     timing.append((ev, R))
                 self._last = ("fused", R, S)
+            elif self.pipeline > 1 and R >= 64 * 64 * self.pipeline:
+                self._forward_pipelined(rays_o, rays_d, viewdirs, t_tab, s_tab, S, stepsize, last, depth, rgb, timing)
             else:
                 chunk = self.rays_per_chunk(S)
                 ws = self._workspace(min(R, chunk), S)
@@ -215,6 +220,56 @@ class FourierGridRenderer:
         return out
 
     __call__ = forward
+
+    def _forward_pipelined(self, rays_o, rays_d, viewdirs, t_tab, s_tab, S, stepsize, last, depth, rgb, timing):
+        """Software pipeline over ray chunks on two HIP streams: k_march of chunk k+1 runs while k_shade of chunk k
+        does.  The two kernels stress different units (march: VALU; shade: vector-memory latency + MFMA), so they
+        co-reside on the CUs instead of running back to back.  Three work lists rotate so that a march never
+        waits for the shade two chunks back.  Results are independent of the chunking (tested)."""
+        dev = self.device
+        R = rays_o.shape[0]
+        nck = self.pipeline
+        per = ((R + nck - 1) // nck + 63) // 64 * 64
+        bounds = [(b, min(R, b + per)) for b in range(0, R, per)]
+        need = _L.ugrid_render_ws_bytes(per, S)
+        n_ws = min(3, len(bounds))
+        if self._ws_ring is None or len(self._ws_ring) < n_ws or self._ws_ring[0].numel() < need:
+            self._ws_ring = None
+            self._ws_ring = [torch.empty(need, dtype=torch.uint8, device=dev) for _ in range(n_ws)]
+        if self._streams is None:
+            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev, priority=-1))
+        sm, ss = self._streams
+        cur = torch.cuda.current_stream(dev)
+        start = cur.record_event()
+        sm.wait_event(start)
+        ss.wait_event(start)
+        shade_done = []
+        for k, (b, e) in enumerate(bounds):
+            n = e - b
+            p = self._params(n, S, stepsize)
+            ws = self._ws_ring[k % n_ws]
+            o_, d_, v_ = rays_o[b:e], rays_d[b:e], viewdirs[b:e]
+            ev = [torch.cuda.Event(enable_timing=timing is not None) for _ in range(4)]
+            if k >= n_ws:
+                sm.wait_event(shade_done[k - n_ws])
+            if timing is not None:
+                ev[0].record(sm)
+            _lib.check(_L.ugrid_render_march(p, _p(o_), _p(d_), _p(t_tab), _p(s_tab), _p(self.density_bricks),
+                                             _p(last[b:e]), _p(depth[b:e]), _p(ws), sm.cuda_stream), "render_march")
+            ev[1].record(sm)
+            ss.wait_event(ev[1])
+            if timing is not None:
+                ev[2].record(ss)
+            _lib.check(_L.ugrid_render_shade(p, _p(v_), _p(self.k0_bricks), _p(self.mlp_packed), _p(ws),
+                                             _p(rgb[b:e]), ss.cuda_stream), "render_shade")
+            ev[3].record(ss)
+            shade_done.append(ev[3])
+            if timing is not None:
+                timing.append((ev, n))
+        cur.wait_event(shade_done[-1])   # the shade stream is in order: the last shade implies all of them
+        cur.wait_event(ev[1])
+        self._ws = self._ws_ring[(len(bounds) - 1) % n_ws]
+        self._last = ("split", bounds[-1][1] - bounds[-1][0], S)
 
     @torch.no_grad()
     def survivors_of_last_chunk(self, n_rays=None, S=None):
