@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--grid", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-launch", action="store_true", help="single persistent launch instead of march + shade")
+    ap.add_argument("--mlp-mode", type=int, default=None, help="rgbnet arithmetic: 0 fp32 MFMA, 1 bf16x3, 2 fp16x2 (default: what ugrid_pack_mlp reports usable)")
     ap.add_argument("--pipeline", type=int, default=0, help="ray chunks software-pipelined over two streams (0 = off)")
     ap.add_argument("--tune", action="append", default=[], help="key=value speed knob (ugrid_tune), repeatable")
     ap.add_argument("--cpu-chunks", type=int, default=4, help="8192-ray chunks timed for the CPU baseline")
@@ -117,7 +118,7 @@ def main():
     H, W, G = args.height, args.width, args.grid
     stepsize = 1.31 * G / 200.0 if G != 200 else 1.31
     state = make_state(G, device, seed=0)  # same model on every rank (replicated read-only grids)
-    rend = FourierGridRenderer(state, device, fused=args.single_launch, pipeline=args.pipeline)
+    rend = FourierGridRenderer(state, device, fused=args.single_launch, pipeline=args.pipeline, mlp_mode=args.mlp_mode)
     cpu_state = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_state = {k: ([x.cpu() for x in v] if isinstance(v, list) else (v.cpu() if torch.is_tensor(v) else v))

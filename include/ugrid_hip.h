@@ -170,7 +170,13 @@ typedef struct ugrid_render_params {
   float xyz_min[3], xyz_max[3];   /* contracted bounds (-1-bg .. 1+bg) as the fp32 buffers hold them */
   double bg_len;                  /* python float, e.g. 0.2 */
   float act_shift, interval, thres;
+  int32_t mlp_mode;               /* rgbnet arithmetic of the shade kernel: UGRID_MLP_FP32 | _BF16X3 | _FP16X2
+                                     (all fp32-accurate; FP16X2 only if ugrid_pack_mlp reported it usable) */
 } ugrid_render_params;
+
+#define UGRID_MLP_FP32 0    /* v_mfma_f32_32x32x2_f32: plain fp32 products */
+#define UGRID_MLP_BF16X3 1  /* weights and activations split into 3 bf16 parts, 6 MFMA products (~2^-24) */
+#define UGRID_MLP_FP16X2 2  /* power-of-two scaled operands split into 2 fp16 parts, 3 MFMA products (~2^-22) */
 
 /* Bytes of the survivor work list (worst case: every sample survives) for n_rays x n_samples. */
 int64_t ugrid_render_ws_bytes(int64_t n_rays, int32_t n_samples);
@@ -183,7 +189,7 @@ int ugrid_render_march(const ugrid_render_params *h_params, const float *rays_o,
                        const float *t_table, const float *s_table, const float *density_bricks,
                        float *alphainv_last, float *depth, void *ws, ugrid_stream_t stream);
 
-/* Fused shade: survivors -> P-level k0 bricks -> [k0, viewdir emb] -> rgbnet (fp32 MFMA) -> sigmoid
+/* Fused shade: survivors -> P-level k0 bricks -> [k0, viewdir emb] -> rgbnet (MFMA, h_params->mlp_mode) -> sigmoid
  * -> weighted per-ray sum in sample order; writes rgb_marched [R,3].  mlp_packed: ugrid_pack_mlp(). */
 int ugrid_render_shade(const ugrid_render_params *h_params, const float *viewdirs,
                        const float *k0_bricks, const float *mlp_packed, void *ws,
@@ -204,13 +210,20 @@ int ugrid_render_fused(const ugrid_render_params *h_params, const float *rays_o,
 int ugrid_render_fused_stats(const void *ws, int64_t *d_stats, ugrid_stream_t stream);
 
 /* rgbnet packing for the MFMA shade kernel: w0 [128, C+3+6pe], b0 [128], w1 [128,128], b1 [128],
- * w2 [3,128], b2 [3] (nn.Linear layout, FourierGrid_model.py:233-241) -> packed device array. */
+ * w2 [3,128], b2 [3] (nn.Linear layout, FourierGrid_model.py:233-241) -> packed device array holding one
+ * image per arithmetic mode.  k0_absmax: an upper bound on |k0 feature| (max |k0 grid value|: the feature is
+ * a convex combination of grid values averaged over levels); it sizes the power-of-two activation scales of
+ * the fp16x2 image (view directions are assumed unit length like the reference's, dvgo.py:517).  Pass <= 0
+ * if unknown.  *best_mode (HOST int, may be NULL) receives the fastest usable mode: UGRID_MLP_FP16X2 when
+ * the weights and the propagated activation bounds fit fp16's range after scaling, else UGRID_MLP_BF16X3.
+ * Synchronises the stream once (the weights are read back to derive the scales). */
 int64_t ugrid_mlp_packed_bytes(int32_t k0_channels, int32_t viewbase_pe);
 int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1, const float *b1,
                    const float *w2, const float *b2, int32_t k0_channels, int32_t viewbase_pe,
-                   int32_t width, float *packed, ugrid_stream_t stream);
+                   int32_t width, float k0_absmax, float *packed, int32_t *best_mode,
+                   ugrid_stream_t stream);
 
-/* Tuning knobs (speed only, never results).  "shade_waves": 8 | 12 waves per shade workgroup. */
+/* Tuning knobs (speed only, never results): "march_waves" 4..6, "split_gather" 0|1, "coop_gather" 0|1. */
 int ugrid_tune(const char *key, int value);
 
 /* Total survivors of the last march on this ws -> *d_stats (device int64). */

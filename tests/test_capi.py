@@ -43,7 +43,8 @@ def test_python_binding_table_matches_header(lib_path):
     assert lib.ugrid_brick_bytes(1, 3, 160, 160, 160, 1) == 159 ** 3 * 128
     fp32_img = 20 * 256 + 64 * 256 + 128 + 128 + 512 + 4
     bf16_img = (3 + 8) * 4 * 3 * 64 * 4 + 128 + 128 + 512 + 4
-    assert lib.ugrid_mlp_packed_bytes(12, 4) == 4 * (fp32_img + bf16_img)
+    fp16_img = (3 + 8) * 4 * 2 * 64 * 4 + 128 + 128 + 512 + 4 + 4
+    assert lib.ugrid_mlp_packed_bytes(12, 4) == 4 * (fp32_img + bf16_img + fp16_img)
     assert lib.ugrid_render_ws_bytes(64, 256) >= 64 * 256 * 17
 
 

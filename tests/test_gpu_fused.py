@@ -92,24 +92,45 @@ def test_fused_render_vs_oracle(fr, G, F, C, pe, norm, R, stepsize, dm, ds):
     assert abs(M - ref["weights"].numel()) <= max(3, int(2e-4 * M))
 
 
-@pytest.mark.parametrize("bf16x3", [0, 1])
-def test_rgbnet_mfma_modes(fr, bf16x3):
-    """The rgbnet runs on the matrix cores either as exact fp32 MFMA (v_mfma_f32_32x32x2_f32) or as six bf16
-    MFMAs per product on a three-way bf16 split of both operands (fp32-accurate, error ~2^-24 per product).
-    Both must meet the 1e-4 bound against the oracle; they differ from each other only at the 1e-6 level."""
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_rgbnet_mfma_modes(fr, mode):
+    """The rgbnet runs on the matrix cores as exact fp32 MFMA (v_mfma_f32_32x32x2_f32, mode 0), as six bf16
+    MFMAs per product on a three-way bf16 split of both operands (mode 1, ~2^-24 per product) or as three fp16
+    MFMAs on a two-way fp16 split of power-of-two-scaled operands (mode 2, ~2^-22 per product; the default when
+    ugrid_pack_mlp finds the operand ranges fit).  All must meet the 1e-4 bound against the oracle with a wide
+    margin; they differ from each other only at the 1e-6 level."""
     G, F, C, R = 36, 3, 12, 6000
     state = make_state(4242, G, F, C, 4, "inf", 1e-4, 6.0, 12.0)
     o, d, v = [torch.from_numpy(a) for a in synth.rays(4243, R)]
     ref = model_oracle.fouriergrid_render(state, o, d, v, 0.5, render_depth=True, return_margin=True)
-    try:
-        fr.tune("mlp_bf16x3", bf16x3)
-        rend = fr.FourierGridRenderer(state, "cuda:0")
-        out = rend(o.cuda(), d.cuda(), v.cuda(), stepsize=0.5, render_depth=True)
-        worst = check_render(out, ref, R)
-        print("mlp_bf16x3=%d worst=%s" % (bf16x3, worst))
-        assert worst["rgb_marched"] < 2e-5
-    finally:
-        fr.tune("mlp_bf16x3", 1)
+    rend = fr.FourierGridRenderer(state, "cuda:0", mlp_mode=mode)
+    assert rend.mlp_mode == mode
+    assert fr.FourierGridRenderer(state, "cuda:0").mlp_mode == 2   # synthetic weights fit fp16x2's range
+    out = rend(o.cuda(), d.cuda(), v.cuda(), stepsize=0.5, render_depth=True)
+    worst = check_render(out, ref, R)
+    print("mlp_mode=%d worst=%s" % (mode, worst))
+    assert worst["rgb_marched"] < 2e-5
+
+
+def test_rgbnet_fp16x2_range_guard(fr):
+    """fp16x2 needs the scaled operands inside fp16's range: huge weights / features make ugrid_pack_mlp fall back
+    to bf16x3, and large-but-representable ones (1e3 x the usual magnitudes) still render within tolerance."""
+    G, F, C, R = 24, 3, 12, 3000
+    state = make_state(777, G, F, C, 4, "inf", 1e-4, 6.0, 12.0)
+    big = dict(state)
+    big["k0_grid"] = state["k0_grid"] * 1e3                      # features ~ +-4000
+    big["rgbnet_weights"] = [state["rgbnet_weights"][0] * 1e-3] + list(state["rgbnet_weights"][1:])  # same net output
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(778, R)]
+    ref = model_oracle.fouriergrid_render(big, o, d, v, 0.5, render_depth=True, return_margin=True)
+    rend = fr.FourierGridRenderer(big, "cuda:0")
+    assert rend.mlp_mode == 2
+    worst = check_render(rend(o.cuda(), d.cuda(), v.cuda(), stepsize=0.5, render_depth=True), ref, R)
+    assert worst["rgb_marched"] < 5e-5
+    huge = dict(state)
+    huge["k0_grid"] = state["k0_grid"] * 1e30
+    assert fr.FourierGridRenderer(huge, "cuda:0").mlp_mode == 1
+    with pytest.raises(RuntimeError):
+        fr.FourierGridRenderer(huge, "cuda:0", mlp_mode=2)
 
 
 def test_fused_render_deterministic_chunk_and_order_invariant(fr):
@@ -128,8 +149,11 @@ def test_fused_render_deterministic_chunk_and_order_invariant(fr):
     small = fr.FourierGridRenderer(state, "cuda:0", max_ws_bytes=4 << 20, fused=False)
     assert small.rays_per_chunk(a["n_max"]) < R
     c = small(o, d, v, stepsize=0.5, render_depth=True)
-    single = fr.FourierGridRenderer(state, "cuda:0", fused=True)   # single persistent launch
+    # single persistent launch (instantiated for bf16x3 / fp32 rgbnet arithmetic only)
+    single = fr.FourierGridRenderer(state, "cuda:0", fused=True)
+    assert single.mlp_mode == 1
     c2 = single(o, d, v, stepsize=0.5, render_depth=True)
+    a1 = fr.FourierGridRenderer(state, "cuda:0", mlp_mode=1)(o, d, v, stepsize=0.5, render_depth=True)
     assert rend.survivors_of_last_chunk() == single.survivors_of_last_chunk()
     # software-pipelined chunks on two streams (march of chunk k+1 overlaps shade of chunk k), used twice so
     # the rotating work lists are re-used while the side streams still hold work
@@ -143,7 +167,7 @@ def test_fused_render_deterministic_chunk_and_order_invariant(fr):
     for k in ("rgb_marched", "depth", "alphainv_last"):
         assert torch.equal(a[k], b[k]), k
         assert torch.equal(a[k], c[k]), k      # any chunking of the work list; single launch == two kernels
-        assert torch.equal(a[k], c2[k]), k
+        assert torch.equal(a1[k], c2[k]), k
         assert torch.equal(a[k][perm], e[k]), k
     assert float(a["rgb_marched"].min()) >= 0 and float(a["rgb_marched"].max()) <= 1 + 1e-5
     assert float(a["alphainv_last"].min()) >= 0 and float(a["alphainv_last"].max()) <= 1

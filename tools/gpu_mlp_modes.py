@@ -10,9 +10,8 @@ state = make_state(4242, G, F, C, 4, "inf", 1e-4, 6.0, 12.0)
 o, d, v = [torch.from_numpy(a) for a in synth.rays(4243, R)]
 og, dg, vg = o.cuda(), d.cuda(), v.cuda()
 base = None
-for mode in (0, 1):
-    fr.tune("mlp_bf16x3", mode)
-    rend = fr.FourierGridRenderer(state, "cuda:0")
+for mode in (0, 1, 2):
+    rend = fr.FourierGridRenderer(state, "cuda:0", mlp_mode=mode)
     outs = []
     for rep in range(12):
         out = rend(og, dg, vg, stepsize=0.5, render_depth=True)

@@ -8,9 +8,8 @@ G, F, C, R = 32, 3, 12, 60000
 state = make_state(99, G, F, C, 4, "inf", 1e-4, 6.0, 12.0)
 o, d, v = [torch.from_numpy(a).cuda() for a in synth.rays(5, R)]
 for mode in (0, 1):
-    fr.tune("mlp_bf16x3", mode)
-    split = fr.FourierGridRenderer(state, "cuda:0", fused=False)
-    single = fr.FourierGridRenderer(state, "cuda:0", fused=True)
+    split = fr.FourierGridRenderer(state, "cuda:0", fused=False, mlp_mode=mode)
+    single = fr.FourierGridRenderer(state, "cuda:0", fused=True, mlp_mode=mode)
     a = split(o, d, v, stepsize=0.5, render_depth=True)
     for rep in range(3):
         b = single(o, d, v, stepsize=0.5, render_depth=True)

@@ -24,6 +24,9 @@ _I = _c.c_int
 _L = _c.c_int64
 
 
+MLP_FP32, MLP_BF16X3, MLP_FP16X2 = 0, 1, 2   # ugrid_render_params.mlp_mode (include/ugrid_hip.h)
+
+
 class RenderParams(_c.Structure):
     """Mirror of `ugrid_render_params` (include/ugrid_hip.h)."""
     _fields_ = [
@@ -36,6 +39,7 @@ class RenderParams(_c.Structure):
         ("xyz_min", _c.c_float * 3), ("xyz_max", _c.c_float * 3),
         ("bg_len", _c.c_double),
         ("act_shift", _c.c_float), ("interval", _c.c_float), ("thres", _c.c_float),
+        ("mlp_mode", _c.c_int32),
     ]
 
 
@@ -69,7 +73,8 @@ _SIGNATURES = {
     "ugrid_render_fused": (_I, [_c.POINTER(RenderParams)] + [_P] * 13),
     "ugrid_render_fused_stats": (_I, [_P, _P, _P]),
     "ugrid_mlp_packed_bytes": (_L, [_c.c_int32, _c.c_int32]),
-    "ugrid_pack_mlp": (_I, [_P, _P, _P, _P, _P, _P, _c.c_int32, _c.c_int32, _c.c_int32, _P, _P]),
+    "ugrid_pack_mlp": (_I, [_P, _P, _P, _P, _P, _P, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_float, _P,
+                            _c.POINTER(_c.c_int32), _P]),
     "ugrid_tune": (_I, [_c.c_char_p, _I]),
     "ugrid_render_stats": (_I, [_P, _L, _c.c_int32, _P, _P]),
 }

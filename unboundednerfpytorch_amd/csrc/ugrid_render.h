@@ -303,8 +303,19 @@ __host__ __device__ static inline int ug_feat_of(int o, int r, int h) { return 3
 // A second image of the same network follows for the bf16x3 path (each fp32 weight split into three bf16
 // parts h+m+l, A operands of v_mfma_f32_32x32x16_bf16, 8 bf16 = 16 B per lane):
 //   bfA1 [KB1][4 o][3 parts][64 lanes][8 bf16] | bfA2 [8][4][3][64][8] | bias1 | bias2 | W3 | b3   (fp32 tail)
+//
+// A third image serves the fp16x2 path (mode 2): every weight is scaled by a power of two sW (so that the
+// largest |w| sits just below 2^15) and split into two fp16 parts h+l; activations are scaled by sX and split
+// the same way in the kernel; three MFMA products (h.h, h.l, l.h) then carry ~2^-22 relative accuracy, i.e.
+// fp32 quality at half the matrix work of bf16x3.  The tail holds the biases / W3 pre-scaled to match:
+//   hxA1 [KB1][4 o][2 parts][64 lanes][8 f16] | hxA2 [8][4][2][64][8] | bias1*sW1*sX1 | bias2*sW2*sX2 |
+//   W3/(sW2*sX2) | b3 | {sX1, sX2/(sW1*sX1), 0, 0}
 struct ug_mlp_layout { int KL, offA1, offA2, offB1, offB2, offW3, offb3, total;
-                       int KB1, bfA1, bfA2, bfB1, bfB2, bfW3, bfb3, total2; };
+                       int KB1, bfA1, bfA2, bfB1, bfB2, bfW3, bfb3, total2;
+                       int hxA1, hxA2, hxB1, hxB2, hxW3, hxb3, hxS, total3; };
+// power-of-two scales of the fp16x2 image (ugrid_pack_mlp computes them on the host from the weights and the
+// caller's bound on |k0|)
+struct ug_mlp_scales { float sX1, sW1, sX2, sW2; };
 __host__ __device__ static inline ug_mlp_layout ug_mlp_lay(int C, int n_emb) {
   const int CH = UG_CH(C);
   ug_mlp_layout L;
@@ -324,6 +335,14 @@ __host__ __device__ static inline ug_mlp_layout ug_mlp_lay(int C, int n_emb) {
   L.bfW3 = L.bfB2 + 128;
   L.bfb3 = L.bfW3 + 512;
   L.total2 = L.bfb3 + 4;
+  L.hxA1 = L.total2;
+  L.hxA2 = L.hxA1 + L.KB1 * 4 * 2 * 64 * 4;
+  L.hxB1 = L.hxA2 + 8 * 4 * 2 * 64 * 4;
+  L.hxB2 = L.hxB1 + 128;
+  L.hxW3 = L.hxB2 + 128;
+  L.hxb3 = L.hxW3 + 512;
+  L.hxS = L.hxb3 + 4;
+  L.total3 = L.hxS + 4;
   return L;
 }
 
@@ -508,48 +527,40 @@ __device__ __forceinline__ float ug_sigmoid(float x) { return 1.f / (1.f + expf(
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-// LDS-resident packed rgbnet (A operands of the transposed MFMA chain); A1/A2 are fp32 (BF=false) or
-// bf16x8 units (BF=true)
-struct ug_mlp_lds { const float4 *A1, *A2, *W3; const float *B1, *B2, *b3; };
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-template <int C, int PE, bool BF>
+// LDS-resident packed rgbnet (A operands of the transposed MFMA chain); A1/A2 are fp32 (BF=0), bf16x8 units
+// (BF=1: bf16x3) or f16x8 units (BF=2: fp16x2, with the activation scales sx1 / c12)
+struct ug_mlp_lds { const float4 *A1, *A2, *W3; const float *B1, *B2, *b3; float sx1, c12; };
+
+template <int C, int PE, int BF>
 __host__ __device__ static inline int ug_mlp_lds_floats() {
   const ug_mlp_layout ML = ug_mlp_lay(C, 3 + 6 * PE);
-#ifdef UG_EXP_A1_GLOBAL
-  return BF ? ML.total2 - ML.bfA2 : ML.total;
-#else
-  return BF ? ML.total2 - ML.bfA1 : ML.total;
-#endif
+  return BF == 2 ? ML.hxS - ML.hxA1 : (BF == 1 ? ML.total2 - ML.bfA1 : ML.total);
 }
 // dynamic LDS of a shade workgroup: packed rgbnet image + one cooperative-gather scratch per wave
-template <int C, int PE, bool BF, int NW>
+template <int C, int PE, int BF, int NW>
 __host__ __device__ static inline int ug_shade_lds_bytes() {
   return (int)sizeof(float) * (ug_mlp_lds_floats<C, PE, BF>() + NW * UG_COOP_SCRATCH_FLOATS);
 }
 
-template <int C, int PE, bool BF>
+template <int C, int PE, int BF>
 __device__ __forceinline__ ug_mlp_lds ug_mlp_stage(float *lds, const float *__restrict__ mlp) {
   const ug_mlp_layout ML = ug_mlp_lay(C, 3 + 6 * PE);
-#ifdef UG_EXP_A1_GLOBAL
-  const int base = BF ? ML.bfA2 : 0, n = ug_mlp_lds_floats<C, PE, BF>();
-#else
-  const int base = BF ? ML.bfA1 : 0, n = ug_mlp_lds_floats<C, PE, BF>();
-#endif
+  const int base = BF == 2 ? ML.hxA1 : (BF == 1 ? ML.bfA1 : 0), n = ug_mlp_lds_floats<C, PE, BF>();
   const float4 *src = (const float4 *)(mlp + base);
   float4 *dst = (float4 *)lds;
   for (int i = threadIdx.x; i < n / 4; i += blockDim.x) dst[i] = src[i];
   __syncthreads();
   ug_mlp_lds m;
-#ifdef UG_EXP_A1_GLOBAL
-  m.A1 = BF ? (const float4 *)(mlp + ML.bfA1) : (const float4 *)(lds + ML.offA1);
-#else
-  m.A1 = (const float4 *)(lds + (BF ? ML.bfA1 : ML.offA1) - base);
-#endif
-  m.A2 = (const float4 *)(lds + (BF ? ML.bfA2 : ML.offA2) - base);
-  m.B1 = lds + (BF ? ML.bfB1 : ML.offB1) - base;
-  m.B2 = lds + (BF ? ML.bfB2 : ML.offB2) - base;
-  m.W3 = (const float4 *)(lds + (BF ? ML.bfW3 : ML.offW3) - base);
-  m.b3 = lds + (BF ? ML.bfb3 : ML.offb3) - base;
+  m.A1 = (const float4 *)(lds + (BF == 2 ? ML.hxA1 : (BF == 1 ? ML.bfA1 : ML.offA1)) - base);
+  m.A2 = (const float4 *)(lds + (BF == 2 ? ML.hxA2 : (BF == 1 ? ML.bfA2 : ML.offA2)) - base);
+  m.B1 = lds + (BF == 2 ? ML.hxB1 : (BF == 1 ? ML.bfB1 : ML.offB1)) - base;
+  m.B2 = lds + (BF == 2 ? ML.hxB2 : (BF == 1 ? ML.bfB2 : ML.offB2)) - base;
+  m.W3 = (const float4 *)(lds + (BF == 2 ? ML.hxW3 : (BF == 1 ? ML.bfW3 : ML.offW3)) - base);
+  m.b3 = lds + (BF == 2 ? ML.hxb3 : (BF == 1 ? ML.bfb3 : ML.offb3)) - base;
+  m.sx1 = BF == 2 ? mlp[ML.hxS] : 1.f;
+  m.c12 = BF == 2 ? mlp[ML.hxS + 1] : 1.f;
   return m;
 }
 
@@ -633,11 +644,61 @@ __device__ __forceinline__ void ug_mfma6x4(const bf16x8 *__restrict__ Ap, const 
   for (int o = 0; o < 4; ++o) { UG_MFMA_BF16(acc[o], wh.w[o], x.h); }
 }
 
+// ---- fp16x2 (mode 2) -------------------------------------------------------------------------------
+// fp32 -> two fp16 parts of the scaled value: x*scale = h + l up to 2^-22 |x*scale| (scale is a power of two
+// chosen by the host so that |x*scale| <= 2^15, far from fp16 overflow; l only goes subnormal for
+// |x*scale| < 0.25, where its absolute contribution is below 2^-26 of the layer's full scale)
+struct ug_split2 { f16x8 h, l; };
+__device__ __forceinline__ ug_split2 ug_split8h(const float (&x)[8], float scale) {
+  ug_split2 s;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const float t = x[i] * scale;
+    const _Float16 hh = (_Float16)t;
+    s.h[i] = hh;
+    s.l[i] = (_Float16)(t - (float)hh);
+  }
+  return s;
+}
+
+#define UG_MFMA_F16(acc, a, b)                                       \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0);  \
+  __builtin_amdgcn_sched_barrier(0)
+
+struct ug_hpart { f16x8 w[4]; };
+__device__ __forceinline__ ug_hpart ug_load_hpart(const f16x8 *__restrict__ Ap, int part) {
+  ug_hpart p;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) p.w[o] = Ap[(o * 2 + part) * 64];
+  return p;
+}
+
+// One k-step for the 4 output tiles: acc[o] += Wl.xh + Wh.xl + Wh.xh (smallest terms first), round-robin over
+// the tiles in the same pinned order as ug_mfma6x4 (no MFMA reads the accumulator written right before it).
+// The low weight part of the step is prefetched by the previous step; the next step's activations are split on
+// the VALU while the first four MFMAs occupy the matrix pipe.
+__device__ __forceinline__ void ug_mfma3x4(const f16x8 *__restrict__ Ap, const f16x8 *__restrict__ Ap_next,
+                                           const ug_split2 &x, const float (&v_next)[8], float scale,
+                                           ug_split2 &x_next, f32x16 (&acc)[4], ug_hpart &wl) {
+  const ug_hpart wh = ug_load_hpart(Ap, 0);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) { UG_MFMA_F16(acc[o], wl.w[o], x.h); }
+  x_next = ug_split8h(v_next, scale);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) { UG_MFMA_F16(acc[o], wh.w[o], x.l); }
+  wl = ug_load_hpart(Ap_next, 1);   // next step's low part (harmless re-read on the last step)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) { UG_MFMA_F16(acc[o], wh.w[o], x.h); }
+}
+
 // Shade one tile's survivor list (32 survivors per pass, lanes l / l+32 pair up) and write the tile's
 // rgb_marched.  C = 2*CH or 2*CH-1 k0 channels, PE view-direction frequencies; rgbnet 128 wide, 3 layers.
 // PRE: the k0 features were gathered by k_shade_gather into `feat` ([entries][UG_FEAT_STRIDE]); otherwise they
 // are gathered here from the k0 bricks.
-template <int F, int C, int PE, bool BF, bool PRE, bool COOP>
+template <int F, int C, int PE, int BF, bool PRE, bool COOP>
 __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const float *__restrict__ viewdirs,
                                               const float *__restrict__ k0b, const ug_mlp_lds &M, int64_t tile,
                                               int count, const float4 *__restrict__ ent,
@@ -739,6 +800,52 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
         acc2[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, xb, acc2[3], 0, 0, 0);
         if ((st & 1) == 1) __builtin_amdgcn_sched_barrier(0);
       }
+    } else if constexpr (BF == 2) {
+      // fp32-accurate through fp16x2 splitting of power-of-two-scaled operands: v_mfma_f32_32x32x16_f16, three
+      // products per k-step; accumulators carry the factor sW*sX (biases / W3 are pre-scaled in the image)
+      const f16x8 *A1h = (const f16x8 *)M.A1, *A2h = (const f16x8 *)M.A2;
+      constexpr int KB1 = (KL + 7) / 8;
+      ug_hpart wl = ug_load_hpart(A1h + lane, 1);
+      ug_split2 xs, xn;
+      {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (e < KL) ? x[e < KL ? e : 0] : 0.f;
+        xs = ug_split8h(v, M.sx1);
+      }
+      ug_fence_operands();
+#pragma unroll
+      for (int s = 0; s < KB1; ++s) {
+        float vn[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vn[e] = (8 * (s + 1) + e < KL) ? x[(8 * (s + 1) + e < KL) ? 8 * (s + 1) + e : 0] : 0.f;
+        ug_mfma3x4(A1h + (s * 8) * 64 + lane, (s + 1 < KB1 ? A1h + ((s + 1) * 8) * 64 : A2h) + lane, xs, vn, M.sx1, xn, acc1, wl);
+        xs = xn;
+      }
+      ug_fence_results();
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          acc1[o][r] = fmaxf(acc1[o][r], 0.f);
+          acc2[o][r] = M.B2[bo + o * 16 + r];
+        }
+      {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc1[0][e];
+        xs = ug_split8h(v, M.c12);
+      }
+      ug_fence_operands();
+#pragma unroll
+      for (int st = 0; st < 8; ++st) {
+        float vn[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) vn[e] = acc1[(st + 1 < 8 ? st + 1 : st) >> 1][8 * ((st + 1 < 8 ? st + 1 : st) & 1) + e];
+        ug_mfma3x4(A2h + (st * 8) * 64 + lane, A2h + ((st + 1 < 8 ? st + 1 : st) * 8) * 64 + lane, xs, vn, M.c12, xn, acc2, wl);
+        xs = xn;
+      }
+      ug_fence_results();
     } else {
       // fp32-accurate through bf16x3 splitting: v_mfma_f32_32x32x16_bf16, B operand = 8 values of this lane
       // (lane half h supplies k = 8h..8h+7), i.e. 8 layer-1 inputs / 8 accumulator registers per k-step

@@ -7,9 +7,30 @@ extern "C" int ug_set_march_waves(int w);  // ugrid_march.hip
 __global__ void k_pack_mlp(const float *__restrict__ w0, const float *__restrict__ b0,
                            const float *__restrict__ w1, const float *__restrict__ b1,
                            const float *__restrict__ w2, const float *__restrict__ b2, int C, int n_emb,
-                           float *__restrict__ out) {
+                           ug_mlp_scales sc, float *__restrict__ out) {
   const ug_mlp_layout L = ug_mlp_lay(C, n_emb);
   const int mlp_in = C + n_emb;
+  // fp16x2 image: one thread per fp16 element, same (step, tile, lane, element) walk as the bf16 image
+  unsigned short *hx = (unsigned short *)(out + L.hxA1);
+  const int n_hx = (L.hxB1 - L.hxA1) * 2;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_hx; i += gridDim.x * blockDim.x) {
+    const int e = i & 7, lane = (i >> 3) & 63, u = i >> 9;      // u = (step*4 + o)*2 + part
+    const int part = u & 1, o = (u >> 1) & 3, step = u >> 3;
+    float w = 0.f;
+    if (step < L.KB1) {
+      const int idx = 8 * step + e;
+      const int col = idx < L.KL ? ug_in_col(idx, lane >> 5, C, n_emb, L.KL) : -1;
+      if (col >= 0) w = w0[(32 * o + (lane & 31)) * mlp_in + col] * sc.sW1;
+    } else {
+      const int st = step - L.KB1;
+      w = w1[(32 * o + (lane & 31)) * 128 + ug_feat_of(st >> 1, 8 * (st & 1) + e, lane >> 5)] * sc.sW2;
+    }
+    const _Float16 hh = (_Float16)w;
+    const _Float16 ll = (_Float16)(w - (float)hh);
+    hx[i] = __builtin_bit_cast(unsigned short, part == 0 ? hh : ll);
+  }
+  if (blockIdx.x == 0 && threadIdx.x < 4)
+    out[L.hxS + threadIdx.x] = threadIdx.x == 0 ? sc.sX1 : (threadIdx.x == 1 ? sc.sX2 / (sc.sW1 * sc.sX1) : 0.f);
   // bf16x3 image: one thread per bf16 element
   unsigned short *bf = (unsigned short *)(out + L.bfA1);
   const int n_bf = (L.bfB1 - L.bfA1) * 2;
@@ -57,7 +78,12 @@ __global__ void k_pack_mlp(const float *__restrict__ w0, const float *__restrict
       if (c < 3) v = b2[c];
     }
     out[i] = v;
-    if (i >= L.offB1) out[L.bfB1 + (i - L.offB1)] = v;  // tail copy for the bf16 image
+    if (i >= L.offB1) {
+      out[L.bfB1 + (i - L.offB1)] = v;  // tail copy for the bf16 image
+      // fp16x2 tail: biases carry the accumulator scale of their layer, W3 undoes layer 2's
+      const float f = i < L.offB2 ? sc.sW1 * sc.sX1 : (i < L.offW3 ? sc.sW2 * sc.sX2 : (i < L.offb3 ? 1.f / (sc.sW2 * sc.sX2) : 1.f));
+      out[L.hxB1 + (i - L.offB1)] = v * f;
+    }
   }
 }
 
@@ -90,7 +116,7 @@ k_shade_gather(ug_shade_args a, const float *__restrict__ k0b, ug_ws_view ws, in
   }
 }
 
-template <int F, int C, int PE, int NW, bool BF, bool PRE, bool COOP>
+template <int F, int C, int PE, int NW, int BF, bool PRE, bool COOP>
 __global__ void __launch_bounds__(NW * 64, NW / 4)
 k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
             const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
@@ -111,7 +137,7 @@ k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__
 // Single-launch render: every persistent wave marches a 64-ray tile and immediately shades the survivors
 // it found (its list lives in that wave's private scratch slot and is still L2-resident).  Waves of one CU
 // sit in different phases, so the VALU-bound march of some overlaps the MFMA-bound rgbnet of others.
-template <int F, bool L2, int C, int PE, int NW, bool BF>
+template <int F, bool L2, int C, int PE, int NW, int BF>
 __global__ void __launch_bounds__(NW * 64, NW / 4)
 k_render_fused(ug_march_args am, ug_shade_args as, const float *__restrict__ rays_o,
                const float *__restrict__ rays_d, const float *__restrict__ viewdirs,
@@ -204,16 +230,54 @@ __global__ void k_ws_stats(const int32_t *__restrict__ count, int64_t n_tiles, i
 // C ABI
 // ----------------------------------------------------------------------------------------------
 extern "C" int64_t ugrid_mlp_packed_bytes(int32_t k0_channels, int32_t viewbase_pe) {
-  return (int64_t)sizeof(float) * ug_mlp_lay(k0_channels, 3 + 6 * viewbase_pe).total2;
+  return (int64_t)sizeof(float) * ug_mlp_lay(k0_channels, 3 + 6 * viewbase_pe).total3;
 }
+
+// largest power of two <= v (v > 0, finite)
+static inline float ug_pow2_floor(double v) { return (float)std::ldexp(1.0, (int)std::floor(std::log2(v))); }
 
 extern "C" int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1, const float *b1,
                               const float *w2, const float *b2, int32_t k0_channels, int32_t viewbase_pe,
-                              int32_t width, float *packed, ugrid_stream_t s) {
+                              int32_t width, float k0_absmax, float *packed, int32_t *best_mode,
+                              ugrid_stream_t s) {
   if (width != 128) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_pack_mlp, dim3(64), dim3(256), 0, ST(s), w0, b0, w1, b1, w2, b2, (int)k0_channels,
-                     3 + 6 * (int)viewbase_pe, packed);
+  const int C = k0_channels, n_emb = 3 + 6 * (int)viewbase_pe, mlp_in = C + n_emb;
+  // scales of the fp16x2 image: interval bounds propagated through layer 1 (|k0| <= k0_absmax, |emb| <= 1)
+  std::vector<float> h0((size_t)128 * mlp_in), hb0(128), h1((size_t)128 * 128);
+  UG_HIP(hipMemcpyAsync(h0.data(), w0, h0.size() * sizeof(float), hipMemcpyDeviceToHost, ST(s)));
+  UG_HIP(hipMemcpyAsync(hb0.data(), b0, hb0.size() * sizeof(float), hipMemcpyDeviceToHost, ST(s)));
+  UG_HIP(hipMemcpyAsync(h1.data(), w1, h1.size() * sizeof(float), hipMemcpyDeviceToHost, ST(s)));
+  UG_HIP(hipStreamSynchronize(ST(s)));
+  double m1 = 0, m2 = 0, B1 = 0;
+  const double fb = k0_absmax > 0 ? (double)k0_absmax : 0.0;
+  for (int n = 0; n < 128; ++n) {
+    double acc = std::fabs((double)hb0[n]);
+    for (int k = 0; k < mlp_in; ++k) {
+      const double a = std::fabs((double)h0[(size_t)n * mlp_in + k]);
+      m1 = a > m1 ? a : m1;
+      acc += a * (k < C ? fb : 1.0);
+    }
+    B1 = acc > B1 ? acc : B1;
+  }
+  for (size_t i = 0; i < h1.size(); ++i) { const double a = std::fabs((double)h1[i]); m2 = a > m2 ? a : m2; }
+  const double B0 = fb > 1.0 ? fb : 1.0;
+  ug_mlp_scales sc = {1.f, 1.f, 1.f, 1.f};
+  bool ok = k0_absmax > 0 && std::isfinite(fb) && std::isfinite(B1) && std::isfinite(m1) && std::isfinite(m2) &&
+            m1 > 1e-30 && m2 > 1e-30 && B1 > 1e-30;
+  if (ok) {
+    sc.sX1 = ug_pow2_floor(32768.0 / B0);
+    sc.sW1 = ug_pow2_floor(32768.0 / m1);
+    sc.sX2 = ug_pow2_floor(32768.0 / B1);
+    sc.sW2 = ug_pow2_floor(32768.0 / m2);
+    // keep every scale (and the products that scale the biases) comfortably inside fp32's exponent range
+    const float lo = 1.0f / 1024.0f, hi = 1099511627776.0f;  // 2^-10 .. 2^40
+    ok = sc.sX1 >= lo && sc.sX2 >= lo && sc.sW1 >= lo && sc.sW2 >= lo && sc.sX1 <= hi && sc.sX2 <= hi &&
+         sc.sW1 <= hi && sc.sW2 <= hi;
+    if (!ok) sc = {1.f, 1.f, 1.f, 1.f};
+  }
+  hipLaunchKernelGGL(k_pack_mlp, dim3(64), dim3(256), 0, ST(s), w0, b0, w1, b1, w2, b2, C, n_emb, sc, packed);
   UG_LAUNCH_CHECK();
+  if (best_mode) *best_mode = ok ? UGRID_MLP_FP16X2 : UGRID_MLP_BF16X3;
   return 0;
 }
 
@@ -229,9 +293,8 @@ extern "C" int64_t ugrid_render_fused_ws_bytes(int32_t n_samples) {
 
 static int g_shade_split_gather = 0;  // 1: k_shade_gather + rgbnet-only kernel (measured slower: 12.8 vs 8.5 ms); 0: gather inside the rgbnet kernel
 static int g_coop_gather = 0;         // 1: cooperative coalesced k0 gather (experimental, measured slower: 10.3 vs 8.5 ms)
-static int g_mlp_bf16x3 = 1;  // 1: rgbnet on bf16x3-split MFMA (fp32-accurate, 2.5x fewer MFMA cycles); 0: fp32 MFMA
 
-template <int F, bool L2, int C, int PE, int NW, bool BF>
+template <int F, bool L2, int C, int PE, int NW, int BF>
 static int ug_fused_launch_nw(const ug_march_args &am, const ug_shade_args &as, const float *rays_o,
                            const float *rays_d, const float *viewdirs, const float *t_table,
                            const float *s_table, const float *dens_bricks, const float *k0b, const float *mlp,
@@ -262,12 +325,13 @@ template <int F, bool L2, int C, int PE>
 static int ug_fused_launch(const ug_march_args &am, const ug_shade_args &as, const float *rays_o,
                            const float *rays_d, const float *viewdirs, const float *t_table,
                            const float *s_table, const float *dens_bricks, const float *k0b, const float *mlp,
-                           float *alphainv_last, float *depth, float *rgb, void *ws_mem, hipStream_t st) {
-  // the single-launch variant is kept for experiments only (8 waves with bf16x3, 12 with fp32 MFMA)
-  if (g_mlp_bf16x3)
-    return ug_fused_launch_nw<F, L2, C, PE, 8, true>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks,
+                           float *alphainv_last, float *depth, float *rgb, void *ws_mem, int mlp_mode,
+                           hipStream_t st) {
+  // the single-launch variant is kept for experiments only (bf16x3 or fp32 MFMA; fp16x2 is not instantiated)
+  if (mlp_mode != UGRID_MLP_FP32)
+    return ug_fused_launch_nw<F, L2, C, PE, 8, 1>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks,
                                                      k0b, mlp, alphainv_last, depth, rgb, ws_mem, st);
-  return ug_fused_launch_nw<F, L2, C, PE, 8, false>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks,
+  return ug_fused_launch_nw<F, L2, C, PE, 8, 0>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks,
                                                     k0b, mlp, alphainv_last, depth, rgb, ws_mem, st);
 }
 
@@ -289,10 +353,10 @@ extern "C" int ugrid_render_fused(const ugrid_render_params *p, const float *ray
     if (p->norm_l2)                                                                                       \
       return ug_fused_launch<F_, true, C_, PE_>(am, as, rays_o, rays_d, viewdirs, t_table, s_table,       \
                                                 density_bricks, k0_bricks, mlp_packed, alphainv_last,     \
-                                                depth, rgb_marched, ws_mem, ST(s));                       \
+                                                depth, rgb_marched, ws_mem, p->mlp_mode, ST(s));          \
     return ug_fused_launch<F_, false, C_, PE_>(am, as, rays_o, rays_d, viewdirs, t_table, s_table,        \
                                                density_bricks, k0_bricks, mlp_packed, alphainv_last,      \
-                                               depth, rgb_marched, ws_mem, ST(s));                        \
+                                               depth, rgb_marched, ws_mem, p->mlp_mode, ST(s));           \
   }
   UG_FUSED_CASE(3, 12, 4)
   UG_FUSED_CASE(4, 12, 4)
@@ -311,13 +375,12 @@ extern "C" int ugrid_tune(const char *key, int value) {
   if (!strcmp(key, "shade_waves") && (value == 8 || value == 12)) { g_shade_waves = value; return 0; }
   if (!strcmp(key, "march_waves")) return ug_set_march_waves(value) ? (int)hipErrorInvalidValue : 0;
   if (!strcmp(key, "fused_waves") && (value == 8 || value == 12)) { g_fused_waves = value; return 0; }
-  if (!strcmp(key, "mlp_bf16x3") && (value == 0 || value == 1)) { g_mlp_bf16x3 = value; return 0; }
   if (!strcmp(key, "split_gather") && (value == 0 || value == 1)) { g_shade_split_gather = value; return 0; }
   if (!strcmp(key, "coop_gather") && (value == 0 || value == 1)) { g_coop_gather = value; return 0; }
   return (int)hipErrorInvalidValue;
 }
 
-template <int F, int C, int PE, int NW, bool BF, bool PRE, bool COOP>
+template <int F, int C, int PE, int NW, int BF, bool PRE, bool COOP>
 static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
                               ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
   const int lds_bytes = ug_shade_lds_bytes<C, PE, BF, NW>();
@@ -344,16 +407,17 @@ static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, con
 
 template <int F, int C, int PE>
 static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
-                           ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
-  // bf16x3 always runs 8 waves per workgroup (214 VGPRs, no spills).  The 12-wave build needs 37 spills to
-  // fit 168 VGPRs and showed run-to-run differences on MI355X (a survivor's contribution occasionally lost,
-  // tools/gpu_mlp_modes.py) while gaining only 4 %; it is not instantiated.
-  if (g_mlp_bf16x3) {
-    if (g_shade_split_gather) return ug_shade_launch_nw<F, C, PE, 8, true, true, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-    if (g_coop_gather) return ug_shade_launch_nw<F, C, PE, 8, true, false, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-    return ug_shade_launch_nw<F, C, PE, 8, true, false, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+                           ug_ws_view ws, float *rgb, int32_t *counter, int mlp_mode, hipStream_t st) {
+  // every variant runs 8 waves per workgroup (2 per SIMD, <= 256 registers each).  A 12-wave bf16x3 build needed
+  // spills and gained 4 %; it is not instantiated.
+  if (mlp_mode == UGRID_MLP_FP16X2)
+    return ug_shade_launch_nw<F, C, PE, 8, 2, false, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  if (mlp_mode == UGRID_MLP_BF16X3) {
+    if (g_shade_split_gather) return ug_shade_launch_nw<F, C, PE, 8, 1, true, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+    if (g_coop_gather) return ug_shade_launch_nw<F, C, PE, 8, 1, false, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+    return ug_shade_launch_nw<F, C, PE, 8, 1, false, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
   }
-  return ug_shade_launch_nw<F, C, PE, 8, false, false, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  return ug_shade_launch_nw<F, C, PE, 8, 0, false, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
 }
 
 extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *viewdirs, const float *k0_bricks,
@@ -370,10 +434,11 @@ extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *vie
     return 0;
   }
   if (p->mlp_width != 128 || p->mlp_in != p->k0_channels + 3 + 6 * p->viewbase_pe) return (int)hipErrorInvalidValue;
+  if (p->mlp_mode < UGRID_MLP_FP32 || p->mlp_mode > UGRID_MLP_FP16X2) return (int)hipErrorInvalidValue;
   int32_t *counter = (int32_t *)ws_mem;  // first 256 B of the work list
 #define UG_SHADE_CASE(F_, C_, PE_)                                                          \
   if (p->freq_num == F_ && p->k0_channels == C_ && p->viewbase_pe == PE_)                   \
-    return ug_shade_launch<F_, C_, PE_>(a, viewdirs, k0_bricks, mlp_packed, ws, rgb_marched, counter, ST(s));
+    return ug_shade_launch<F_, C_, PE_>(a, viewdirs, k0_bricks, mlp_packed, ws, rgb_marched, counter, p->mlp_mode, ST(s));
   UG_SHADE_CASE(3, 12, 4)  // Mip-NeRF-360 *_single.py  (configs/default.py:104-124)
   UG_SHADE_CASE(4, 12, 4)  // tankstemple_unbounded/truck_single.py:105
   UG_SHADE_CASE(5, 12, 4)  // FourierGridModel's constructor default fourier_freq_num=5 (FourierGrid_model.py:137)

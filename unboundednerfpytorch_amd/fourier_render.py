@@ -14,6 +14,7 @@ Device data owned by the renderer (all fp32):
   t / s tables    [S]
   work list       worst-case survivor list per 64-ray tile (ugrid_render_ws_bytes)
 """
+import ctypes
 import math
 
 import torch
@@ -51,7 +52,7 @@ class FourierGridRenderer:
       contracted_norm ('inf' | 'l2'), world_len.
     """
 
-    def __init__(self, state, device, max_ws_bytes=48 << 30, fused=False, pipeline=0):
+    def __init__(self, state, device, max_ws_bytes=48 << 30, fused=False, pipeline=0, mlp_mode=None):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("FourierGridRenderer needs a HIP device (no CPU path)")
@@ -60,6 +61,7 @@ class FourierGridRenderer:
         # fused=True: single persistent launch (march+shade per wave, 0.9 GB scratch); False (default, measured
         # faster on MI355X: 18.8 vs 23.5 ms per S1 frame): march kernel -> work list -> shade kernel
         self.use_fused = bool(fused)
+        self.mlp_mode = _lib.MLP_BF16X3   # rgbnet arithmetic; set from ugrid_pack_mlp's answer below
         self.pipeline = int(pipeline)
         dg = state["density_grid"].to(dev, torch.float32).contiguous()
         kg = state["k0_grid"].to(dev, torch.float32).contiguous()
@@ -102,7 +104,16 @@ class FourierGridRenderer:
                     raise RuntimeError("rgbnet input width must be C + 3 + 6*viewbase_pe")
                 t = [x.to(dev, torch.float32).contiguous() for x in (ws_[0], bs_[0], ws_[1], bs_[1], ws_[2], bs_[2])]
                 self.mlp_packed = torch.empty(_L.ugrid_mlp_packed_bytes(self.C, self.pe) // 4, dtype=torch.float32, device=dev)
-                _lib.check(_L.ugrid_pack_mlp(*[_p(x) for x in t], self.C, self.pe, 128, _p(self.mlp_packed), st), "pack mlp")
+                # |k0 feature| <= max |k0 grid value| (convex combinations, then a mean over levels): sizes the
+                # activation scales of the fp16x2 rgbnet image; the library reports whether that mode is usable
+                best = ctypes.c_int32(_lib.MLP_BF16X3)
+                _lib.check(_L.ugrid_pack_mlp(*[_p(x) for x in t], self.C, self.pe, 128, float(kg.abs().max()),
+                                             _p(self.mlp_packed), ctypes.byref(best), st), "pack mlp")
+                self.mlp_mode = int(best.value) if mlp_mode is None else int(mlp_mode)
+                if self.mlp_mode == _lib.MLP_FP16X2 and best.value != _lib.MLP_FP16X2:
+                    raise RuntimeError("fp16x2 rgbnet arithmetic is not usable for this network (operand range)")
+                if self.use_fused and mlp_mode is None:
+                    self.mlp_mode = min(self.mlp_mode, _lib.MLP_BF16X3)   # single-launch kernel: bf16x3 / fp32 only
             else:
                 if kg.shape[0] != 1 or self.C != 3:
                     raise RuntimeError("without an rgbnet k0 must be a single-level 3-channel grid")
@@ -140,6 +151,7 @@ class FourierGridRenderer:
                 getattr(p, k)[i] = self._vec[k][i]
         p.bg_len = self.bg_len
         p.act_shift, p.interval, p.thres = self.act_shift, self.interval(stepsize), self.thres
+        p.mlp_mode = self.mlp_mode
         return p
 
     def rays_per_chunk(self, S):
