@@ -10,6 +10,6 @@ hipcc $FLAGS -c ugrid_ops.hip -o $O/ugrid_ops.o "$@" &
 # packed fp32 VALU (v_pk_*_f32 from the SLP vectoriser) runs at half rate on gfx950 and needs extra moves:
 # the VALU-bound march kernel is 16 % faster without it (profiles/r01 notes in DESIGN.md)
 hipcc $FLAGS -fno-slp-vectorize -c ugrid_march.hip -o $O/ugrid_march.o "$@" &
-hipcc $FLAGS -c ugrid_shade.hip -o $O/ugrid_shade.o "$@" &
+hipcc $FLAGS ${UG_SHADE_FLAGS} -c ugrid_shade.hip -o $O/ugrid_shade.o "$@" &
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o ${UG_OUT:-../libugrid_hip.so} $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o

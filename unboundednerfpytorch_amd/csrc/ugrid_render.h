@@ -263,7 +263,7 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
         dens += ug_density_level(bkb + (size_t)(2 * k + 1) * lvl_bytes, sx, sy, sz, a.X, a.Y, a.Z);
         dens += ug_density_level(bkb + (size_t)(2 * k + 2) * lvl_bytes, cx_, cy_, cz_, a.X, a.Y, a.Z);
       }
-      dens = dens / (float)P;
+      dens = ug_div_r(dens, (float)P, 1.0f / (float)P);   // mean over levels: Markstein division, 3 VALU instead of 10
       const float xs = dens + a.shift;
       const float alpha = ug_alpha(xs, a.interval);
       if (alpha > a.thres) {
@@ -427,7 +427,7 @@ __device__ __forceinline__ void ug_k0_gather(const float *__restrict__ k0b, int 
     ug_k0_level<CH>(k0b, h, (int64_t)(2 * k + 2) * cells, cx_, cy_, cz_, a.X, a.Y, a.Z, false, feat);
   }
 #pragma unroll
-  for (int ch = 0; ch < CH; ++ch) feat[ch] = feat[ch] / (float)P;
+  for (int ch = 0; ch < CH; ++ch) feat[ch] = ug_div_r(feat[ch], (float)P, 1.0f / (float)P);
 }
 
 // ---- cooperative (coalesced) k0 gather ------------------------------------------------------------
@@ -523,7 +523,19 @@ __device__ __forceinline__ void ug_k0_gather_coop(const float *__restrict__ k0b,
   ug_wave_lds_sync();
 }
 
-__device__ __forceinline__ float ug_sigmoid(float x) { return 1.f / (1.f + expf(-x)); }
+// 1/(1+exp(-x)) with a refined reciprocal (<= 1 ulp from the IEEE division, 3 VALU instead of 10); the clamp keeps
+// exp finite (the Newton step would turn rcp(inf) = 0 into NaN) and changes nothing above fp32's denormal range
+__device__ __forceinline__ float ug_sigmoid(float x) {
+  return ug_rcp_refined(1.f + expf(-__builtin_amdgcn_fmed3f(x, -87.f, 87.f)));
+}
+
+// max(x, 0) as ONE v_max_f32: fmaxf() is preceded by a canonicalising v_max_f32 x, x, x under IEEE mode, which
+// doubled the cost of the 128 ReLUs per pass (NaN in -> NaN out here, like torch.relu)
+__device__ __forceinline__ float ug_relu(float x) {
+  float y;
+  asm("v_max_f32 %0, 0, %1" : "=v"(y) : "v"(x));
+  return y;
+}
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -787,7 +799,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
       for (int o = 0; o < 4; ++o)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          acc1[o][r] = fmaxf(acc1[o][r], 0.f);
+          acc1[o][r] = ug_relu(acc1[o][r]);
           acc2[o][r] = M.B2[bo + o * 16 + r];
         }
 #pragma unroll
@@ -827,7 +839,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
       for (int o = 0; o < 4; ++o)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          acc1[o][r] = fmaxf(acc1[o][r], 0.f);
+          acc1[o][r] = ug_relu(acc1[o][r]);
           acc2[o][r] = M.B2[bo + o * 16 + r];
         }
       {
@@ -873,7 +885,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
       for (int o = 0; o < 4; ++o)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          acc1[o][r] = fmaxf(acc1[o][r], 0.f);
+          acc1[o][r] = ug_relu(acc1[o][r]);
           acc2[o][r] = M.B2[bo + o * 16 + r];
         }
       {
@@ -898,7 +910,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     float l0 = 0.f, l1 = 0.f, l2 = 0.f;
 #pragma unroll
     for (int st = 0; st < 64; ++st) {
-      const float hv = fmaxf(acc2[st >> 4][st & 15], 0.f);
+      const float hv = ug_relu(acc2[st >> 4][st & 15]);
       const float4 w3 = M.W3[bo + st];
       l0 = fmaf(w3.x, hv, l0);
       l1 = fmaf(w3.y, hv, l1);
