@@ -550,10 +550,19 @@ __host__ __device__ static inline int ug_mlp_lds_floats() {
   const ug_mlp_layout ML = ug_mlp_lay(C, 3 + 6 * PE);
   return BF == 2 ? ML.hxS - ML.hxA1 : (BF == 1 ? ML.total2 - ML.bfA1 : ML.total);
 }
-// dynamic LDS of a shade workgroup: packed rgbnet image + one cooperative-gather scratch per wave
+// wave-private LDS scratch: [0,64) per-ray survivor bit masks + [64,192) 32 x {r,g,b,-} of the pass (ordered
+// per-ray accumulation), then either the cooperative-gather tables or -- fp16x2 mode, whose rgbnet image leaves
+// the room -- the tile's view-direction embedding table [64 rays][2 halves][EH]
+#define UG_ACC_SCRATCH_FLOATS 192
+template <int C, int PE, int BF>
+__host__ __device__ static inline int ug_wave_scratch_floats() {
+  constexpr int EH = (2 * UG_CH(C) + 3 + 6 * PE + 1) / 2 - UG_CH(C);
+  return BF == 2 ? UG_ACC_SCRATCH_FLOATS + 64 * 2 * EH : UG_COOP_SCRATCH_FLOATS;
+}
+// dynamic LDS of a shade workgroup: packed rgbnet image + one scratch per wave
 template <int C, int PE, int BF, int NW>
 __host__ __device__ static inline int ug_shade_lds_bytes() {
-  return (int)sizeof(float) * (ug_mlp_lds_floats<C, PE, BF>() + NW * UG_COOP_SCRATCH_FLOATS);
+  return (int)sizeof(float) * (ug_mlp_lds_floats<C, PE, BF>() + NW * ug_wave_scratch_floats<C, PE, BF>());
 }
 
 template <int C, int PE, int BF>
@@ -722,6 +731,38 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
   const int lane = ug_lane();
   const int h = lane >> 5, sv = lane & 31;
   float accr = 0.f, accg = 0.f, accb = 0.f;  // lane = ray slot of this tile
+  constexpr int EH = KL - CH;                // embedding values per lane half
+  constexpr bool EMB_LDS = (BF == 2) && !COOP;
+  constexpr bool ACC_LDS = !COOP;
+  unsigned *amask = (unsigned *)scr;         // [64] bit k set: entry k of the pass belongs to this ray slot
+  float4 *aval = (float4 *)(scr + 64);       // [32] weighted rgb of entry k
+  float *embt = scr + UG_ACC_SCRATCH_FLOATS; // [64][2][EH]
+  if constexpr (EMB_LDS) {
+    // the embedding depends on the ray only: build it once per tile (lane = ray slot) instead of once per
+    // survivor (a tile averages ~25 passes in S1), 12 sincos + 3 global loads per pass saved
+    int64_t ray = tile * UG_WAVE + lane;
+    if (ray >= a.n_rays) ray = a.n_rays - 1;
+    const float vx = viewdirs[3 * ray], vy = viewdirs[3 * ray + 1], vz = viewdirs[3 * ray + 2];
+    float emb[2 * EH];
+    emb[0] = vx; emb[1] = vy; emb[2] = vz;
+#pragma unroll
+    for (int ax = 0; ax < 3; ++ax) {
+      const float v = ax == 0 ? vx : (ax == 1 ? vy : vz);
+#pragma unroll
+      for (int k = 0; k < PE; ++k) {
+        float s_, c_;
+        ug_sincos(v * (float)(1 << k), &s_, &c_);
+        emb[3 + ax * PE + k] = s_;
+        emb[3 + 3 * PE + ax * PE + k] = c_;
+      }
+    }
+#pragma unroll
+    for (int e = NEMB; e < 2 * EH; ++e) emb[e] = 0.f;
+    __builtin_amdgcn_wave_barrier();   // the previous tile's last pass has read its table rows
+#pragma unroll
+    for (int e = 0; e < 2 * EH; ++e) embt[lane * (2 * EH) + e] = emb[e];
+    ug_wave_lds_sync();
+  }
 
   // the work-list entry of the NEXT pass is fetched while this pass's rgbnet runs (software prefetch)
   float4 en_n = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -752,28 +793,34 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
       }
 #pragma unroll
       for (int s = 0; s < CH; ++s) x[s] = (h * CH + s < C) ? feat[s] : 0.f;
-      int64_t ray = tile * UG_WAVE + sl;
-      if (ray >= a.n_rays) ray = a.n_rays - 1;
-      const float vx = viewdirs[3 * ray], vy = viewdirs[3 * ray + 1], vz = viewdirs[3 * ray + 2];
-      float emb[NEMB];
-      emb[0] = vx; emb[1] = vy; emb[2] = vz;
+      if constexpr (EMB_LDS) {
+        const float *er = embt + sl * (2 * EH) + h * EH;
 #pragma unroll
-      for (int ax = 0; ax < 3; ++ax) {
-        const float v = ax == 0 ? vx : (ax == 1 ? vy : vz);
+        for (int s = CH; s < KL; ++s) x[s] = er[s - CH];
+      } else {
+        int64_t ray = tile * UG_WAVE + sl;
+        if (ray >= a.n_rays) ray = a.n_rays - 1;
+        const float vx = viewdirs[3 * ray], vy = viewdirs[3 * ray + 1], vz = viewdirs[3 * ray + 2];
+        float emb[NEMB];
+        emb[0] = vx; emb[1] = vy; emb[2] = vz;
 #pragma unroll
-        for (int k = 0; k < PE; ++k) {
-          float s_, c_;
-          ug_sincos(v * (float)(1 << k), &s_, &c_);
-          emb[3 + ax * PE + k] = s_;
-          emb[3 + 3 * PE + ax * PE + k] = c_;
+        for (int ax = 0; ax < 3; ++ax) {
+          const float v = ax == 0 ? vx : (ax == 1 ? vy : vz);
+#pragma unroll
+          for (int k = 0; k < PE; ++k) {
+            float s_, c_;
+            ug_sincos(v * (float)(1 << k), &s_, &c_);
+            emb[3 + ax * PE + k] = s_;
+            emb[3 + 3 * PE + ax * PE + k] = c_;
+          }
         }
-      }
 #pragma unroll
-      for (int s = CH; s < KL; ++s) {
-        const int e0 = s - CH, e1 = (KL - CH) + (s - CH);
-        const float lo = emb[e0];
-        const float hi = (e1 < NEMB) ? emb[e1 < NEMB ? e1 : 0] : 0.f;
-        x[s] = h ? hi : lo;
+        for (int s = CH; s < KL; ++s) {
+          const int e0 = s - CH, e1 = (KL - CH) + (s - CH);
+          const float lo = emb[e0];
+          const float hi = (e1 < NEMB) ? emb[e1 < NEMB ? e1 : 0] : 0.f;
+          x[s] = h ? hi : lo;
+        }
       }
     }
     // ---- layers 1 and 2 on the matrix cores, transposed (H^T = W . X^T): accumulators feed the next layer
@@ -921,11 +968,34 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
     // weights.unsqueeze(-1) * rgb, then a per-ray sum in sample order (segment_coo semantics)
     const float pr = en.w * ug_sigmoid(l0), pg = en.w * ug_sigmoid(l1), pb = en.w * ug_sigmoid(l2);
-    const int cnt = (count - base) < 32 ? (count - base) : 32;
-    for (int k = 0; k < cnt; ++k) {
-      const int sk = __builtin_amdgcn_readlane(sl, k);
-      const float r_ = ug_readlane_f(pr, k), g_ = ug_readlane_f(pg, k), b_ = ug_readlane_f(pb, k);
-      if (lane == sk) { accr += r_; accg += g_; accb += b_; }
+    if constexpr (ACC_LDS) {
+      // per-ray sum in list (= sample) order through LDS: survivors publish their value and set their bit in the
+      // owning ray's mask (ds_or: commutative, so deterministic); each ray lane then walks its bits upwards.
+      // Each phase is closed with s_waitcnt lgkmcnt(0) + a wave barrier: with the scheduling barrier alone the fp32
+      // build lost contributions on MI355X (reset / OR / read of the masks not kept in order).  The walk takes as
+      // many rounds as the busiest ray has entries in the pass (1-3), against 32 readlane rounds before.
+      amask[lane] = 0u;
+      ug_wave_lds_sync();
+      if (ok && h == 0) {
+        aval[sv] = make_float4(pr, pg, pb, 0.f);
+        atomicOr(&amask[sl], 1u << sv);
+      }
+      ug_wave_lds_sync();
+      unsigned m = amask[lane];
+      while (m) {
+        const int k = __builtin_ctz(m);
+        const float4 t = aval[k];
+        accr += t.x; accg += t.y; accb += t.z;
+        m &= m - 1;
+      }
+      __builtin_amdgcn_wave_barrier();   // the next pass rewrites aval / amask
+    } else {
+      const int cnt = (count - base) < 32 ? (count - base) : 32;
+      for (int k = 0; k < cnt; ++k) {
+        const int sk = __builtin_amdgcn_readlane(sl, k);
+        const float r_ = ug_readlane_f(pr, k), g_ = ug_readlane_f(pg, k), b_ = ug_readlane_f(pb, k);
+        if (lane == sk) { accr += r_; accg += g_; accb += b_; }
+      }
     }
   }
   const int64_t ray = tile * UG_WAVE + lane;

@@ -123,7 +123,7 @@ k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__
             int32_t *__restrict__ tile_counter) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const ug_mlp_lds M = ug_mlp_stage<C, PE, BF>(lds, mlp);
-  float *scr = lds + ug_mlp_lds_floats<C, PE, BF>() + (threadIdx.x >> 6) * UG_COOP_SCRATCH_FLOATS;
+  float *scr = lds + ug_mlp_lds_floats<C, PE, BF>() + (threadIdx.x >> 6) * ug_wave_scratch_floats<C, PE, BF>();
   int victim = 0;
   for (;;) {
     const int64_t tile = ug_next_tile(tile_counter, ws.n_tiles, blockIdx.x & 7, victim);
@@ -149,7 +149,7 @@ k_render_fused(ug_march_args am, ug_shade_args as, const float *__restrict__ ray
                int32_t *__restrict__ tile_counter, int64_t n_tiles) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const ug_mlp_lds M = ug_mlp_stage<C, PE, BF>(lds, mlp);
-  float *scr = lds + ug_mlp_lds_floats<C, PE, BF>() + (threadIdx.x >> 6) * UG_COOP_SCRATCH_FLOATS;
+  float *scr = lds + ug_mlp_lds_floats<C, PE, BF>() + (threadIdx.x >> 6) * ug_wave_scratch_floats<C, PE, BF>();
   const int64_t cap = (int64_t)UG_WAVE * am.S;
   const int64_t wslot = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
   float4 *__restrict__ ent = scratch_ent + wslot * cap;
