@@ -146,10 +146,14 @@ int ugrid_grid_query(const float *grid, int P, int C, int X, int Y, int Z, const
                      float *out, ugrid_stream_t stream);
 
 /* Brick packing: canonical [P,C,X,Y,Z] -> cell-major 2x2x2 bricks, one contiguous record per
- * trilinear cell: [P*(X-1)(Y-1)(Z-1)][H halves][8 corners][CH channels] with
- *   C == 1 (density)        : H = 1, CH = 1            (32 B / cell)
- *   C  > 1 (rgbnet features): H = 2, CH = ceil(C/2)    (zero padded; 384 B / cell at C = 12)
- *   direct != 0 (no rgbnet, C == 3): H = 1, CH = 4     (128 B / cell)
+ * trilinear cell: [P*(X-1)(Y-1)(Z-1)][H halves][...] with
+ *   C == 1 (density)        : H = 1, [8 entries]                          (32 B / cell)
+ *   C  > 1 (rgbnet features): H = 2, [ceil(C/4) channel pairs][8 entries][2 channels]
+ *                                                    (zero padded; 384 B / cell at C = 12)
+ *   direct != 0 (no rgbnet, C == 3): H = 1, [8 corners][4 channels]       (128 B / cell)
+ * For the first two the 8 entries of a channel are the coefficients of the cell's trilinear polynomial
+ * sum c[4dx+2dy+dz] tx^dx ty^dy tz^dz in the fractional cell coordinates (computed in fp64 from the 8 corner
+ * values, rounded once), so a lookup is 7 FMAs per channel; direct bricks hold the corner values.
  * ugrid_brick_bytes returns the size of the packed array. */
 int64_t ugrid_brick_bytes(int P, int C, int X, int Y, int Z, int direct);
 int ugrid_pack_bricks(const float *grid, int P, int C, int X, int Y, int Z, int direct, float *bricks,
@@ -223,7 +227,7 @@ int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1, const floa
                    int32_t width, float k0_absmax, float *packed, int32_t *best_mode,
                    ugrid_stream_t stream);
 
-/* Tuning knobs (speed only, never results): "march_waves" 4..6, "split_gather" 0|1, "coop_gather" 0|1. */
+/* Tuning knobs (speed only, never results): "march_waves" 4..6, "split_gather" 0|1. */
 int ugrid_tune(const char *key, int value);
 
 /* Total survivors of the last march on this ws -> *d_stats (device int64). */

@@ -3,19 +3,23 @@
 #include "ugrid_render.h"
 
 // ----------------------------------------------------------------------------------------------
-// brick packing: canonical [P,C,X,Y,Z] -> [P*(X-1)(Y-1)(Z-1)] records of [H halves][8 corners][CH]
+// brick packing: canonical [P,C,X,Y,Z] -> [P*(X-1)(Y-1)(Z-1)] cell records of [H halves][8][CH]
+// coef=1 (density and feature bricks): the 8 entries of a cell are the coefficients of its trilinear
+// polynomial  f(tx,ty,tz) = sum_{dx,dy,dz} c[4dx+2dy+dz] tx^dx ty^dy tz^dz  (t = fractional cell coordinates),
+// computed in fp64 from the 8 corner values and rounded once: the kernels evaluate a cell with 7 FMAs per
+// channel and need no corner weights.  coef=0 (rgbnet-less colour bricks): the 8 corner values themselves.
 // ----------------------------------------------------------------------------------------------
 __global__ void k_pack_bricks(const float *__restrict__ grid, int P, int C, int X, int Y, int Z, int H,
-                              int CH, float *__restrict__ out, int64_t total) {
+                              int CH, int coef, float *__restrict__ out, int64_t total) {
   for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total;
        o += (int64_t)gridDim.x * blockDim.x) {
     int64_t q = o;
     int ch, c;
-    if (H == 2) {   // feature half-bricks: [pair CH/2][corner 8][2 channels]  (see ug_k0_gather_coop)
+    if (H == 2) {   // feature half-bricks: [pair CH/2][entry 8][2 channels]
       const int qi = (int)(q % (8 * CH)); q /= (8 * CH);
       c = (qi >> 1) & 7;
       ch = (qi >> 4) * 2 + (qi & 1);
-    } else {        // density / rgbnet-less colour bricks: [corner 8][CH]
+    } else {        // density / rgbnet-less colour bricks: [entry 8][CH]
       ch = (int)(q % CH); q /= CH;
       c = (int)(q % 8); q /= 8;
     }
@@ -27,8 +31,21 @@ __global__ void k_pack_bricks(const float *__restrict__ grid, int P, int C, int 
     const int chan = h * CH + ch;
     float v = 0.f;
     if (chan < C) {
-      const int ii = i + (c >> 2), jj = j + ((c >> 1) & 1), kk = k + (c & 1);
-      v = grid[((((int64_t)l * C + chan) * X + ii) * Y + jj) * Z + kk];
+      const float *g = grid + ((int64_t)l * C + chan) * X * Y * Z;
+      if (!coef) {
+        const int ii = i + (c >> 2), jj = j + ((c >> 1) & 1), kk = k + (c & 1);
+        v = g[((int64_t)ii * Y + jj) * Z + kk];
+      } else {
+        // inclusion-exclusion over the corners s that are sub-masks of c
+        double acc = 0.0;
+        for (int s = 0; s < 8; ++s) {
+          if (s & ~c) continue;
+          const int ii = i + (s >> 2), jj = j + ((s >> 1) & 1), kk = k + (s & 1);
+          const double t = (double)g[((int64_t)ii * Y + jj) * Z + kk];
+          acc += (__popc(c ^ s) & 1) ? -t : t;
+        }
+        v = (float)acc;
+      }
     }
     out[o] = v;
   }
@@ -146,12 +163,12 @@ extern "C" int ugrid_pack_bricks(const float *grid, int P, int C, int X, int Y, 
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 64) blocks = 256 * 64;
   hipLaunchKernelGGL(k_pack_bricks, dim3((unsigned)blocks), dim3(256), 0, ST(s), grid, P, C, X, Y, Z, H, CH,
-                     bricks, total);
+                     direct ? 0 : 1, bricks, total);
   UG_LAUNCH_CHECK();
   return 0;
 }
 
-static int g_march_waves = 5;
+static int g_march_waves = 6;
 extern "C" int ug_set_march_waves(int w) { if (w < 4 || w > 6) return 1; g_march_waves = w; return 0; }
   // min waves/SIMD the march kernel is compiled for (register cap 512/W)
 

@@ -188,18 +188,11 @@ __device__ __forceinline__ float ug_density_level(const char *__restrict__ lvl, 
   const unsigned off = __umul24(row, (unsigned)(Z - 1) << 5) + ((unsigned)az.cell << 5);
   const float4 *b = (const float4 *)(lvl + off);
   const float4 v0 = b[0], v1 = b[1];
-  const float w00 = az.wlo * ay.wlo, w01 = az.whi * ay.wlo, w10 = az.wlo * ay.whi, w11 = az.whi * ay.whi;
-  // corner order of grid_sample; fused multiply-adds (one rounding per corner instead of two: closer to the exact
-  // trilinear value than torch's own mul+add chain, and half the VALU instructions)
-  float acc = v0.x * (w00 * ax.wlo);
-  acc = fmaf(v0.y, w01 * ax.wlo, acc);
-  acc = fmaf(v0.z, w10 * ax.wlo, acc);
-  acc = fmaf(v0.w, w11 * ax.wlo, acc);
-  acc = fmaf(v1.x, w00 * ax.whi, acc);
-  acc = fmaf(v1.y, w01 * ax.whi, acc);
-  acc = fmaf(v1.z, w10 * ax.whi, acc);
-  acc = fmaf(v1.w, w11 * ax.whi, acc);
-  return acc;
+  // cell polynomial (k_pack_bricks): Horner in z, then y, then x -- 7 FMAs, no corner weights
+  const float tz = az.whi, ty = ay.whi, tx = ax.whi;
+  const float p00 = fmaf(v0.y, tz, v0.x), p01 = fmaf(v0.w, tz, v0.z);   // x^0: y^0, y^1
+  const float p10 = fmaf(v1.y, tz, v1.x), p11 = fmaf(v1.w, tz, v1.z);   // x^1
+  return fmaf(fmaf(p11, ty, p10), tx, fmaf(p01, ty, p00));
 }
 
 // March one 64-ray tile (lane = ray): writes alphainv_last / depth for the tile's rays, appends the
@@ -391,15 +384,15 @@ __device__ __forceinline__ void ug_k0_level(const float *__restrict__ k0b, int h
 #pragma unroll
     for (int q = 0; q < 8 * CH; ++q) v[q] = rec_p[q];
   }
-  const float w00 = az.wlo * ay.wlo, w01 = az.whi * ay.wlo, w10 = az.wlo * ay.whi, w11 = az.whi * ay.whi;
-  const float w[8] = {w00 * ax.wlo, w01 * ax.wlo, w10 * ax.wlo, w11 * ax.wlo,
-                      w00 * ax.whi, w01 * ax.whi, w10 * ax.whi, w11 * ax.whi};
+  const float tz = az.whi, ty = ay.whi, tx = ax.whi;
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch) {
-    // half-brick layout [pair][corner][2 channels]: value of (corner c, channel ch) at (ch/2)*16 + c*2 + ch%2
-    float acc = v[(ch >> 1) * 16 + (ch & 1)] * w[0];
-#pragma unroll
-    for (int c = 1; c < 8; ++c) acc = fmaf(v[(ch >> 1) * 16 + c * 2 + (ch & 1)], w[c], acc);
+    // half-brick layout [pair][entry][2 channels]: coefficient c of channel ch at (ch/2)*16 + c*2 + ch%2;
+    // cell polynomial by Horner in z, y, x (7 FMAs)
+    const float *q = v + (ch >> 1) * 16 + (ch & 1);
+    const float p00 = fmaf(q[2], tz, q[0]), p01 = fmaf(q[6], tz, q[4]);
+    const float p10 = fmaf(q[10], tz, q[8]), p11 = fmaf(q[14], tz, q[12]);
+    const float acc = fmaf(fmaf(p11, ty, p10), tx, fmaf(p01, ty, p00));
     feat[ch] = first ? acc : feat[ch] + acc;
   }
 }
@@ -430,97 +423,9 @@ __device__ __forceinline__ void ug_k0_gather(const float *__restrict__ k0b, int 
   for (int ch = 0; ch < CH; ++ch) feat[ch] = ug_div_r(feat[ch], (float)P, 1.0f / (float)P);
 }
 
-// ---- cooperative (coalesced) k0 gather ------------------------------------------------------------
-// A pass owns 32 survivors x 2 halves = 64 half-bricks of NI = 2*CH float4 each per level.  With "one lane
-// reads its own half-brick" every 16-byte load instruction touches 64 different cache lines and the CU's
-// texture-addresser serialises them (measured: ~51 cycles per load instruction, the whole shade kernel was
-// TA-bound).  Here the 64*NI float4 of a level are spread over the lanes in ADDRESS order instead: item
-// g = t*64 + lane reads float4 (g % NI) of half-brick (g / NI), so one instruction covers 64/NI contiguous
-// half-bricks = 8-11 cache lines.  The record layout [pair][corner][2 channels] makes every float4 hold two
-// corners x two channels: the loader multiplies by the two corner weights (published by the owning lanes
-// through a wave-private LDS table), accumulates over levels, and the four lanes of a quad (the four corner
-// pairs) are summed with two DPP-able shuffles once per pass.
-struct ug_coop_map { int j[12], i4[12]; };   // per-lane constants: survivor slot and float4 index of item t
-
-#define UG_COOP_SCRATCH_FLOATS (32 * 12 + 64 * 6)   // table T [32][12] + results [64][CH<=6]
-
 __device__ __forceinline__ void ug_wave_lds_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
-}
-
-template <int CH>
-__device__ __forceinline__ void ug_coop_level(const float *__restrict__ k0b, int64_t level_base, float cx, float cy,
-                                              float cz, const ug_shade_args &a, int lane, float *__restrict__ T,
-                                              float (&acc)[2 * CH][2]) {
-  constexpr int NI = 2 * CH;
-  const ug_axis_fast ax = ug_axis_inrange(cx, a.X), ay = ug_axis_inrange(cy, a.Y), az = ug_axis_inrange(cz, a.Z);
-  const int rec = (ax.cell * (a.Y - 1) + ay.cell) * (a.Z - 1) + az.cell;
-  const float w00 = az.wlo * ay.wlo, w01 = az.whi * ay.wlo, w10 = az.wlo * ay.whi, w11 = az.whi * ay.whi;
-  if (lane < 32) {  // owners publish cell + 8 trilinear weights (grid_sample corner order)
-    float *t = T + lane * 12;
-    t[0] = __int_as_float(rec);
-    *(float4 *)(t + 4) = make_float4(w00 * ax.wlo, w01 * ax.wlo, w10 * ax.wlo, w11 * ax.wlo);
-    *(float4 *)(t + 8) = make_float4(w00 * ax.whi, w01 * ax.whi, w10 * ax.whi, w11 * ax.whi);
-  }
-  ug_wave_lds_sync();
-#pragma unroll
-  for (int t = 0; t < NI; ++t) {
-    const int g = t * 64 + lane;
-    const int hb = g / NI, i = g - hb * NI;          // half-brick (hh*32 + j) and float4 index inside it
-    const int j = hb & 31, hh = hb >> 5, cp = i & 3;
-    const float *tj = T + j * 12;
-    const int rj = __float_as_int(tj[0]);
-    const float2 w2 = *(const float2 *)(tj + 4 + 2 * cp);
-    const float4 v = *(const float4 *)(k0b + ((level_base + rj) * 2 + hh) * (int64_t)(8 * CH) + i * 4);
-    acc[t][0] += v.x * w2.x;
-    acc[t][0] += v.z * w2.y;
-    acc[t][1] += v.y * w2.x;
-    acc[t][1] += v.w * w2.y;
-  }
-  ug_wave_lds_sync();
-}
-
-template <int F, int CH>
-__device__ __forceinline__ void ug_k0_gather_coop(const float *__restrict__ k0b, int lane, float px, float py, float pz,
-                                                  const ug_shade_args &a, float *__restrict__ scr, float (&feat)[CH]) {
-  constexpr int P = 2 * F + 1, NI = 2 * CH;
-  float *T = scr, *Rr = scr + 32 * 12;
-  const float ux = ug_div_r(px - a.lox, a.ex, a.irx) * 2.f - 1.f;
-  const float uy = ug_div_r(py - a.loy, a.ey, a.iry) * 2.f - 1.f;
-  const float uz = ug_div_r(pz - a.loz, a.ez, a.irz) * 2.f - 1.f;
-  const int64_t cells = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1);
-  float acc[NI][2];
-#pragma unroll
-  for (int t = 0; t < NI; ++t) acc[t][0] = acc[t][1] = 0.f;
-  ug_coop_level<CH>(k0b, 0, ux, uy, uz, a, lane, T, acc);
-#pragma unroll 1
-  for (int k = 0; k < F; ++k) {
-    const float f = (float)(1 << k);
-    float sx, cx_, sy, cy_, sz, cz_;
-    ug_sincos(f * ux, &sx, &cx_);
-    ug_sincos(f * uy, &sy, &cy_);
-    ug_sincos(f * uz, &sz, &cz_);
-    ug_coop_level<CH>(k0b, (int64_t)(2 * k + 1) * cells, sx, sy, sz, a, lane, T, acc);
-    ug_coop_level<CH>(k0b, (int64_t)(2 * k + 2) * cells, cx_, cy_, cz_, a, lane, T, acc);
-  }
-  // quad reduction over the four corner pairs, then hand the CH channel sums to the owning lanes
-#pragma unroll
-  for (int t = 0; t < NI; ++t) {
-    const int g = t * 64 + lane;
-    const int hb = g / NI, i = g - hb * NI;
-#pragma unroll
-    for (int c2 = 0; c2 < 2; ++c2) {
-      float x = acc[t][c2];
-      x += __shfl_xor(x, 1);
-      x += __shfl_xor(x, 2);
-      if ((lane & 3) == 0) Rr[hb * CH + (i >> 2) * 2 + c2] = x;
-    }
-  }
-  ug_wave_lds_sync();
-#pragma unroll
-  for (int s = 0; s < CH; ++s) feat[s] = Rr[lane * CH + s] / (float)P;   // lane = hh*32 + j = its own half-brick id
-  ug_wave_lds_sync();
 }
 
 // 1/(1+exp(-x)) with a refined reciprocal (<= 1 ulp from the IEEE division, 3 VALU instead of 10); the clamp keeps
@@ -551,13 +456,13 @@ __host__ __device__ static inline int ug_mlp_lds_floats() {
   return BF == 2 ? ML.hxS - ML.hxA1 : (BF == 1 ? ML.total2 - ML.bfA1 : ML.total);
 }
 // wave-private LDS scratch: [0,64) per-ray survivor bit masks + [64,192) 32 x {r,g,b,-} of the pass (ordered
-// per-ray accumulation), then either the cooperative-gather tables or -- fp16x2 mode, whose rgbnet image leaves
-// the room -- the tile's view-direction embedding table [64 rays][2 halves][EH]
+// per-ray accumulation), then -- fp16x2 mode only, whose rgbnet image leaves the room -- the tile's
+// view-direction embedding table [64 rays][2 halves][EH]
 #define UG_ACC_SCRATCH_FLOATS 192
 template <int C, int PE, int BF>
 __host__ __device__ static inline int ug_wave_scratch_floats() {
   constexpr int EH = (2 * UG_CH(C) + 3 + 6 * PE + 1) / 2 - UG_CH(C);
-  return BF == 2 ? UG_ACC_SCRATCH_FLOATS + 64 * 2 * EH : UG_COOP_SCRATCH_FLOATS;
+  return BF == 2 ? UG_ACC_SCRATCH_FLOATS + 64 * 2 * EH : UG_ACC_SCRATCH_FLOATS;
 }
 // dynamic LDS of a shade workgroup: packed rgbnet image + one scratch per wave
 template <int C, int PE, int BF, int NW>
@@ -719,7 +624,7 @@ __device__ __forceinline__ void ug_mfma3x4(const f16x8 *__restrict__ Ap, const f
 // rgb_marched.  C = 2*CH or 2*CH-1 k0 channels, PE view-direction frequencies; rgbnet 128 wide, 3 layers.
 // PRE: the k0 features were gathered by k_shade_gather into `feat` ([entries][UG_FEAT_STRIDE]); otherwise they
 // are gathered here from the k0 bricks.
-template <int F, int C, int PE, int BF, bool PRE, bool COOP>
+template <int F, int C, int PE, int BF, bool PRE>
 __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const float *__restrict__ viewdirs,
                                               const float *__restrict__ k0b, const ug_mlp_lds &M, int64_t tile,
                                               int count, const float4 *__restrict__ ent,
@@ -732,8 +637,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
   const int h = lane >> 5, sv = lane & 31;
   float accr = 0.f, accg = 0.f, accb = 0.f;  // lane = ray slot of this tile
   constexpr int EH = KL - CH;                // embedding values per lane half
-  constexpr bool EMB_LDS = (BF == 2) && !COOP;
-  constexpr bool ACC_LDS = !COOP;
+  constexpr bool EMB_LDS = (BF == 2);
   unsigned *amask = (unsigned *)scr;         // [64] bit k set: entry k of the pass belongs to this ray slot
   float4 *aval = (float4 *)(scr + 64);       // [32] weighted rgb of entry k
   float *embt = scr + UG_ACC_SCRATCH_FLOATS; // [64][2][EH]
@@ -786,8 +690,6 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
       if constexpr (PRE) {
 #pragma unroll
         for (int s = 0; s < CH; ++s) feat[s] = ok ? feat_in[(int64_t)e * UG_FEAT_STRIDE + h * CH + s] : 0.f;
-      } else if constexpr (COOP) {
-        ug_k0_gather_coop<F, CH>(k0b, lane, en.x, en.y, en.z, a, scr, feat);
       } else {
         ug_k0_gather<F, CH>(k0b, h, en.x, en.y, en.z, a, feat);
       }
@@ -968,7 +870,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
     // weights.unsqueeze(-1) * rgb, then a per-ray sum in sample order (segment_coo semantics)
     const float pr = en.w * ug_sigmoid(l0), pg = en.w * ug_sigmoid(l1), pb = en.w * ug_sigmoid(l2);
-    if constexpr (ACC_LDS) {
+    {
       // per-ray sum in list (= sample) order through LDS: survivors publish their value and set their bit in the
       // owning ray's mask (ds_or: commutative, so deterministic); each ray lane then walks its bits upwards.
       // Each phase is closed with s_waitcnt lgkmcnt(0) + a wave barrier: with the scheduling barrier alone the fp32
@@ -989,13 +891,6 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
         m &= m - 1;
       }
       __builtin_amdgcn_wave_barrier();   // the next pass rewrites aval / amask
-    } else {
-      const int cnt = (count - base) < 32 ? (count - base) : 32;
-      for (int k = 0; k < cnt; ++k) {
-        const int sk = __builtin_amdgcn_readlane(sl, k);
-        const float r_ = ug_readlane_f(pr, k), g_ = ug_readlane_f(pg, k), b_ = ug_readlane_f(pb, k);
-        if (lane == sk) { accr += r_; accg += g_; accb += b_; }
-      }
     }
   }
   const int64_t ray = tile * UG_WAVE + lane;

@@ -116,7 +116,7 @@ k_shade_gather(ug_shade_args a, const float *__restrict__ k0b, ug_ws_view ws, in
   }
 }
 
-template <int F, int C, int PE, int NW, int BF, bool PRE, bool COOP>
+template <int F, int C, int PE, int NW, int BF, bool PRE>
 __global__ void __launch_bounds__(NW * 64, NW / 4)
 k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
             const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
@@ -128,7 +128,7 @@ k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__
   for (;;) {
     const int64_t tile = ug_next_tile(tile_counter, ws.n_tiles, blockIdx.x & 7, victim);
     if (tile < 0) break;
-    ug_shade_tile<F, C, PE, BF, PRE, COOP>(a, viewdirs, k0b, M, tile, ws.count[tile], ws.ent + tile * ws.cap,
+    ug_shade_tile<F, C, PE, BF, PRE>(a, viewdirs, k0b, M, tile, ws.count[tile], ws.ent + tile * ws.cap,
                                      ws.slot + tile * ws.cap, ws.feat + tile * ws.cap * UG_FEAT_STRIDE, scr,
                                      rgb_marched);
   }
@@ -166,7 +166,7 @@ k_render_fused(ug_march_args am, ug_shade_args as, const float *__restrict__ ray
     // from the previous tile.  Drain the stores, then invalidate the L1 (agent-scope acquire = buffer_inv sc1).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    ug_shade_tile<F, C, PE, BF, false, false>(as, viewdirs, k0b, M, tile, count, ent, slot, nullptr, scr, rgb_marched);
+    ug_shade_tile<F, C, PE, BF, false>(as, viewdirs, k0b, M, tile, count, ent, slot, nullptr, scr, rgb_marched);
     total += count;
   }
   if (ug_lane() == 0 && total) atomicAdd(survivors_total, (unsigned long long)total);
@@ -292,7 +292,6 @@ extern "C" int64_t ugrid_render_fused_ws_bytes(int32_t n_samples) {
 }
 
 static int g_shade_split_gather = 0;  // 1: k_shade_gather + rgbnet-only kernel (measured slower: 12.8 vs 8.5 ms); 0: gather inside the rgbnet kernel
-static int g_coop_gather = 0;         // 1: cooperative coalesced k0 gather (experimental, measured slower: 10.3 vs 8.5 ms)
 
 template <int F, bool L2, int C, int PE, int NW, int BF>
 static int ug_fused_launch_nw(const ug_march_args &am, const ug_shade_args &as, const float *rays_o,
@@ -376,17 +375,16 @@ extern "C" int ugrid_tune(const char *key, int value) {
   if (!strcmp(key, "march_waves")) return ug_set_march_waves(value) ? (int)hipErrorInvalidValue : 0;
   if (!strcmp(key, "fused_waves") && (value == 8 || value == 12)) { g_fused_waves = value; return 0; }
   if (!strcmp(key, "split_gather") && (value == 0 || value == 1)) { g_shade_split_gather = value; return 0; }
-  if (!strcmp(key, "coop_gather") && (value == 0 || value == 1)) { g_coop_gather = value; return 0; }
   return (int)hipErrorInvalidValue;
 }
 
-template <int F, int C, int PE, int NW, int BF, bool PRE, bool COOP>
+template <int F, int C, int PE, int NW, int BF, bool PRE>
 static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
                               ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
   const int lds_bytes = ug_shade_lds_bytes<C, PE, BF, NW>();
   static bool attr_set = false;
   if (!attr_set) {
-    UG_HIP(hipFuncSetAttribute((const void *)k_shade_mlp<F, C, PE, NW, BF, PRE, COOP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    UG_HIP(hipFuncSetAttribute((const void *)k_shade_mlp<F, C, PE, NW, BF, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
   UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
@@ -399,7 +397,7 @@ static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, con
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_gather<F, C>), dim3((unsigned)(((nblocks + 7) / 8) * 8)), dim3(256), 0, st,
                        a, k0b, ws, nblocks);
   }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_mlp<F, C, PE, NW, BF, PRE, COOP>), dim3((unsigned)wgs), dim3(NW * 64), lds_bytes, st, a,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_mlp<F, C, PE, NW, BF, PRE>), dim3((unsigned)wgs), dim3(NW * 64), lds_bytes, st, a,
                      viewdirs, k0b, mlp, ws, rgb, counter);
   UG_LAUNCH_CHECK();
   return 0;
@@ -411,13 +409,12 @@ static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const 
   // every variant runs 8 waves per workgroup (2 per SIMD, <= 256 registers each).  A 12-wave bf16x3 build needed
   // spills and gained 4 %; it is not instantiated.
   if (mlp_mode == UGRID_MLP_FP16X2)
-    return ug_shade_launch_nw<F, C, PE, 8, 2, false, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+    return ug_shade_launch_nw<F, C, PE, 8, 2, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
   if (mlp_mode == UGRID_MLP_BF16X3) {
-    if (g_shade_split_gather) return ug_shade_launch_nw<F, C, PE, 8, 1, true, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-    if (g_coop_gather) return ug_shade_launch_nw<F, C, PE, 8, 1, false, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-    return ug_shade_launch_nw<F, C, PE, 8, 1, false, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+    if (g_shade_split_gather) return ug_shade_launch_nw<F, C, PE, 8, 1, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+    return ug_shade_launch_nw<F, C, PE, 8, 1, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
   }
-  return ug_shade_launch_nw<F, C, PE, 8, 0, false, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  return ug_shade_launch_nw<F, C, PE, 8, 0, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
 }
 
 extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *viewdirs, const float *k0_bricks,
