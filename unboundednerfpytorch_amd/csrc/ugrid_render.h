@@ -575,15 +575,27 @@ __device__ __forceinline__ void ug_mfma6x4(const bf16x8 *__restrict__ Ap, const 
 // chosen by the host so that |x*scale| <= 2^15, far from fp16 overflow; l only goes subnormal for
 // |x*scale| < 0.25, where its absolute contribution is below 2^-26 of the layer's full scale)
 struct ug_split2 { f16x8 h, l; };
+// Two values per pair of v_fma_mix instructions: h = RN16(x*scale) and l = RN16(x*scale - h), each ONE fused
+// operation (fp32 product, fp16 source for h, a single rounding to fp16) writing one half of the destination
+// register -- 2 VALU per value instead of mul, cvt, cvt back, sub, cvt, pack.
+__device__ __forceinline__ void ug_split_pair(float x0, float x1, float scale, unsigned &h, unsigned &l) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(scale));
+  asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(scale));
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(scale), "v"(h));
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(scale), "v"(h));
+}
 __device__ __forceinline__ ug_split2 ug_split8h(const float (&x)[8], float scale) {
-  ug_split2 s;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 hh, ll;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const float t = x[i] * scale;
-    const _Float16 hh = (_Float16)t;
-    s.h[i] = hh;
-    s.l[i] = (_Float16)(t - (float)hh);
+  for (int i = 0; i < 4; ++i) {
+    unsigned h, l;
+    ug_split_pair(x[2 * i], x[2 * i + 1], scale, h, l);
+    hh[i] = h; ll[i] = l;
   }
+  ug_split2 s;
+  s.h = __builtin_bit_cast(f16x8, hh);
+  s.l = __builtin_bit_cast(f16x8, ll);
   return s;
 }
 
