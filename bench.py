@@ -243,6 +243,7 @@ def cpu_baseline(cpu_state, ro, rd, vd, gpu_out, stepsize, S, n_chunks):
     starts = [int(i * (R - chunk) / max(1, n_chunks - 1)) // 64 * 64 for i in range(n_chunks)] if n_chunks > 1 else [0]
     worst = 0.0
     t_total, n_samples = 0.0, 0
+    errs, margins, sq = [], [], 0.0
     for i, b in enumerate([starts[0]] + starts):  # first pass = warm-up, not timed
         o, d, v = ro[b:b + chunk].cpu(), rd[b:b + chunk].cpu(), vd[b:b + chunk].cpu()
         t0 = time.perf_counter()
@@ -253,14 +254,38 @@ def cpu_baseline(cpu_state, ro, rd, vd, gpu_out, stepsize, S, n_chunks):
         t_total += t1 - t0
         n_samples += chunk * S
         safe = ref["margin"] > 1e-4
+        per_ray = torch.zeros(chunk)
         for k in ("rgb_marched", "depth", "alphainv_last"):
             err = (gpu_out[k][b:b + chunk].cpu() - ref[k]).abs()
             err = err.amax(dim=1) if err.dim() == 2 else err
             worst = max(worst, float(err[safe].max()))
+            per_ray = torch.maximum(per_ray, err)
+        errs.append(per_ray)
+        margins.append(ref["margin"])
+        sq += float(((gpu_out["rgb_marched"][b:b + chunk].cpu() - ref["rgb_marched"]).double() ** 2).sum())
     return {"value": n_samples / t_total / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
             "sample": "%d chunks x 8192 rays x %d samples of the same frame (oracle/model_oracle.py, torch CPU "
                       "grid_sample path), 1 warm-up chunk" % (n_chunks, S),
-            "rays_per_sec": n_chunks * chunk / t_total, "gpu_vs_oracle_linf_on_sample": worst}
+            "rays_per_sec": n_chunks * chunk / t_total, "gpu_vs_oracle_linf_on_sample": worst,
+            "gpu_vs_oracle": parity_stats(torch.cat(errs), torch.cat(margins), sq)}
+
+
+def parity_stats(err, margin, sq_rgb):
+    """Per-ray L-inf error of (rgb, depth, alphainv_last) against the oracle on the sampled rays, split by the
+    ray's threshold margin (smallest relative distance of any of its samples to one of the three hard thresholds
+    alpha > thres, weight > thres, T < 1e-3).  A sample that sits on a threshold flips with ANY change of rounding
+    and moves the ray by up to its weight (~thres = 1e-4), so rays with tiny margins measure the thresholds, not the
+    arithmetic; PSNR is over all sampled rays, flips included."""
+    import math
+    n = err.numel()
+    out = {"rays": n, "linf_all": float(err.max()), "mean_abs": float(err.mean()),
+           "frac_rays_above_1e-5": float((err > 1e-5).float().mean()),
+           "psnr_rgb_db": 10.0 * math.log10(1.0 / max(sq_rgb / (3 * n), 1e-30))}
+    for m in (1e-4, 1e-3, 1e-2):
+        sel = margin > m
+        out["linf_margin_gt_%g" % m] = float(err[sel].max()) if bool(sel.any()) else None
+        out["frac_rays_margin_gt_%g" % m] = float(sel.float().mean())
+    return out
 
 
 if __name__ == "__main__":

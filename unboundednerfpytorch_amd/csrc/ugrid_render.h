@@ -353,6 +353,10 @@ __host__ __device__ static inline int ug_in_col(int s, int h, int C, int n_emb, 
 // ----------------------------------------------------------------------------------------------
 // shade
 // ----------------------------------------------------------------------------------------------
+#ifndef UG_K0_BATCH
+#define UG_K0_BATCH 2   // k0 levels whose loads are in flight together (x 48 VGPRs at C = 12; 3 measured equal, 4 spills)
+#endif
+
 struct ug_shade_args {
   int64_t n_rays;
   int32_t X, Y, Z;
@@ -360,64 +364,77 @@ struct ug_shade_args {
   float ex, ey, ez, irx, iry, irz;  // extent hi-lo and RN(1/extent)
 };
 
-// one k0 level for one survivor half: in-range cell set-up + one contiguous (8*CH)-float half-brick,
-// trilinear per channel in grid_sample's corner order; adds into feat[] (first = level 0 initialises).
+// cell set-up of one k0 level for one survivor half: record pointer + fractional coordinates
+struct ug_k0_cell { const float4 *rec; float tx, ty, tz; };
 template <int CH>
-__device__ __forceinline__ void ug_k0_level(const float *__restrict__ k0b, int h, int64_t level_base, float cx,
-                                            float cy, float cz, int X, int Y, int Z, bool first, float (&feat)[CH]) {
+__device__ __forceinline__ ug_k0_cell ug_k0_cell_setup(const float *__restrict__ k0b, int h, int64_t level_base, float cx,
+                                                       float cy, float cz, int X, int Y, int Z) {
   const ug_axis_fast ax = ug_axis_inrange(cx, X), ay = ug_axis_inrange(cy, Y), az = ug_axis_inrange(cz, Z);
-#ifdef UG_EXP_BCAST   // experiment only: every lane reads lane 0's record (1 cache line per load instruction)
-  const int64_t rec = level_base + __builtin_amdgcn_readfirstlane((ax.cell * (Y - 1) + ay.cell) * (Z - 1) + az.cell);
-#else
-  const int64_t rec = level_base + ((int64_t)ax.cell * (Y - 1) + ay.cell) * (Z - 1) + az.cell;
-#endif
-  const float *rec_p = k0b + (rec * 2 + h) * (8 * CH);
-  float v[8 * CH];
-  if constexpr ((8 * CH) % 4 == 0) {
-    const float4 *r4 = (const float4 *)rec_p;
-#pragma unroll
-    for (int q = 0; q < 2 * CH; ++q) {
-      const float4 t = r4[q];
-      v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < 8 * CH; ++q) v[q] = rec_p[q];
-  }
-  const float tz = az.whi, ty = ay.whi, tx = ax.whi;
-#pragma unroll
-  for (int ch = 0; ch < CH; ++ch) {
-    // half-brick layout [pair][entry][2 channels]: coefficient c of channel ch at (ch/2)*16 + c*2 + ch%2;
-    // cell polynomial by Horner in z, y, x (7 FMAs)
-    const float *q = v + (ch >> 1) * 16 + (ch & 1);
-    const float p00 = fmaf(q[2], tz, q[0]), p01 = fmaf(q[6], tz, q[4]);
-    const float p10 = fmaf(q[10], tz, q[8]), p11 = fmaf(q[14], tz, q[12]);
-    const float acc = fmaf(fmaf(p11, ty, p10), tx, fmaf(p01, ty, p00));
-    feat[ch] = first ? acc : feat[ch] + acc;
-  }
+  // row index exact in fp32 ((X-1)(Y-1) < 2^24): one FMA + one convert, then 24-bit multiplies (cells < 2^32)
+  const unsigned row = (unsigned)fmaf(ax.cellf, (float)(Y - 1), ay.cellf);
+  const unsigned cell = __umul24(row, (unsigned)(Z - 1)) + (unsigned)az.cell;
+  ug_k0_cell c;
+  c.rec = (const float4 *)(k0b + ((level_base + cell) * 2 + h) * (8 * CH));
+  c.tx = ax.whi; c.ty = ay.whi; c.tz = az.whi;
+  return c;
 }
 
-// k0 half-brick gather for one survivor: CH channels of half h, mean over P = 1+2F levels
-// (level order u, sin u, cos u, sin 2u, cos 2u, ... -- FourierGrid_grid.py:70)
+// k0 features of one survivor half: mean over the P levels of the cell polynomials.  The loads of NB levels are
+// issued back to back before the first polynomial is evaluated (NB = 2 and 3 measured equal on MI355X: the
+// shade kernel is bound by VALU + MFMA issue, not by the gather's latency).
 template <int F, int CH>
 __device__ __forceinline__ void ug_k0_gather(const float *__restrict__ k0b, int h, float px, float py, float pz,
                                              const ug_shade_args &a, float (&feat)[CH]) {
   constexpr int P = 2 * F + 1;
+  constexpr int NB = UG_K0_BATCH;
+  static_assert((8 * CH) % 4 == 0, "half-brick must be a whole number of float4");
   const float ux = ug_div_r(px - a.lox, a.ex, a.irx) * 2.f - 1.f;
   const float uy = ug_div_r(py - a.loy, a.ey, a.iry) * 2.f - 1.f;
   const float uz = ug_div_r(pz - a.loz, a.ez, a.irz) * 2.f - 1.f;
   const int64_t cells = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1);
-  ug_k0_level<CH>(k0b, h, 0, ux, uy, uz, a.X, a.Y, a.Z, true, feat);
-  constexpr int K0 = 0;
-#pragma unroll 1
-  for (int k = K0; k < F; ++k) {
+  ug_k0_cell c[P];
+  c[0] = ug_k0_cell_setup<CH>(k0b, h, 0, ux, uy, uz, a.X, a.Y, a.Z);
+#pragma unroll
+  for (int k = 0; k < F; ++k) {
     const float f = (float)(1 << k);
     float sx, cx_, sy, cy_, sz, cz_;
     ug_sincos(f * ux, &sx, &cx_);
     ug_sincos(f * uy, &sy, &cy_);
     ug_sincos(f * uz, &sz, &cz_);
-    ug_k0_level<CH>(k0b, h, (int64_t)(2 * k + 1) * cells, sx, sy, sz, a.X, a.Y, a.Z, false, feat);
-    ug_k0_level<CH>(k0b, h, (int64_t)(2 * k + 2) * cells, cx_, cy_, cz_, a.X, a.Y, a.Z, false, feat);
+    c[2 * k + 1] = ug_k0_cell_setup<CH>(k0b, h, (int64_t)(2 * k + 1) * cells, sx, sy, sz, a.X, a.Y, a.Z);
+    c[2 * k + 2] = ug_k0_cell_setup<CH>(k0b, h, (int64_t)(2 * k + 2) * cells, cx_, cy_, cz_, a.X, a.Y, a.Z);
+  }
+#pragma unroll
+  for (int s = 0; s < CH; ++s) feat[s] = 0.f;
+#pragma unroll
+  for (int b0 = 0; b0 < P; b0 += NB) {
+    float4 v[NB][2 * CH];
+#pragma unroll
+    for (int l = 0; l < NB; ++l)
+      if (b0 + l < P) {
+#pragma unroll
+        for (int q = 0; q < 2 * CH; ++q) v[l][q] = c[b0 + l].rec[q];
+      }
+    __builtin_amdgcn_sched_barrier(0);   // keep every load of the batch ahead of the first use
+#pragma unroll
+    for (int l = 0; l < NB; ++l)
+      if (b0 + l < P) {
+        const float tz = c[b0 + l].tz, ty = c[b0 + l].ty, tx = c[b0 + l].tx;
+#pragma unroll
+        for (int pr = 0; pr < CH / 2; ++pr) {
+          // half-brick layout [pair][entry][2 channels]: float4 q of the pair = entries 2q, 2q+1 x 2 channels;
+          // cell polynomial by Horner in z, y, x (7 FMAs per channel)
+          const float4 q0 = v[l][4 * pr], q1 = v[l][4 * pr + 1], q2 = v[l][4 * pr + 2], q3 = v[l][4 * pr + 3];
+          const float a00 = fmaf(q0.z, tz, q0.x), a01 = fmaf(q1.z, tz, q1.x);
+          const float a10 = fmaf(q2.z, tz, q2.x), a11 = fmaf(q3.z, tz, q3.x);
+          const float b00 = fmaf(q0.w, tz, q0.y), b01 = fmaf(q1.w, tz, q1.y);
+          const float b10 = fmaf(q2.w, tz, q2.y), b11 = fmaf(q3.w, tz, q3.y);
+          const float fa = fmaf(fmaf(a11, ty, a10), tx, fmaf(a01, ty, a00));
+          const float fb = fmaf(fmaf(b11, ty, b10), tx, fmaf(b01, ty, b00));
+          feat[2 * pr] = (b0 + l == 0) ? fa : feat[2 * pr] + fa;
+          feat[2 * pr + 1] = (b0 + l == 0) ? fb : feat[2 * pr + 1] + fb;
+        }
+      }
   }
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch) feat[ch] = ug_div_r(feat[ch], (float)P, 1.0f / (float)P);

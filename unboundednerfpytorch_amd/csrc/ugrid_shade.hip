@@ -408,8 +408,10 @@ static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const 
                            ug_ws_view ws, float *rgb, int32_t *counter, int mlp_mode, hipStream_t st) {
   // every variant runs 8 waves per workgroup (2 per SIMD, <= 256 registers each).  A 12-wave bf16x3 build needed
   // spills and gained 4 %; it is not instantiated.
-  if (mlp_mode == UGRID_MLP_FP16X2)
+  if (mlp_mode == UGRID_MLP_FP16X2) {
+    if (g_shade_split_gather) return ug_shade_launch_nw<F, C, PE, 8, 2, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
     return ug_shade_launch_nw<F, C, PE, 8, 2, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  }
   if (mlp_mode == UGRID_MLP_BF16X3) {
     if (g_shade_split_gather) return ug_shade_launch_nw<F, C, PE, 8, 1, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
     return ug_shade_launch_nw<F, C, PE, 8, 1, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
