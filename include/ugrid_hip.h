@@ -145,6 +145,16 @@ int ugrid_grid_query(const float *grid, int P, int C, int X, int Y, int Z, const
                      const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
                      float *out, ugrid_stream_t stream);
 
+/* Gradient of ugrid_grid_query w.r.t. the grid (the autograd backward of FourierGrid.forward /
+ * DenseGrid.forward, i.e. F.grid_sample's grid gradient followed by the mean over levels,
+ * FourierGrid_grid.py:60-78): grad_grid [P,C,X,Y,Z] += scatter of grad_out [n,C] through the trilinear
+ * weights (zero padding: taps outside the grid receive nothing).  grad_grid must be initialised by the caller
+ * (zeros for a fresh gradient); hardware fp32 atomics, so sums agree with torch's to rounding.  Entries whose
+ * incoming gradient is exactly 0 add nothing (MaskedAdam's skip_zero_grad test keeps working). */
+int ugrid_grid_query_backward(const float *grad_out, int P, int C, int X, int Y, int Z, const float *xyz,
+                              const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
+                              float *grad_grid, ugrid_stream_t stream);
+
 /* Brick packing: canonical [P,C,X,Y,Z] -> cell-major 2x2x2 bricks, one contiguous record per
  * trilinear cell: [P*(X-1)(Y-1)(Z-1)][H halves][...] with
  *   C == 1 (density)        : H = 1, [8 entries]                          (32 B / cell)

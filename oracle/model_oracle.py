@@ -252,9 +252,12 @@ def make_autograd_ops(backend):
     return Raw2Alpha, Alphas2Weights
 
 
-def fouriergrid_train_forward(params, cfg, rays_o, rays_d, viewdirs, stepsize, Raw2Alpha, Alphas2Weights):
+def fouriergrid_train_forward(params, cfg, rays_o, rays_d, viewdirs, stepsize, Raw2Alpha, Alphas2Weights,
+                              grid_query=None):
     """FourierGridModel.forward in training mode (FourierGrid_model.py:554-672) on params' device.
-    params: dict of leaf tensors density_grid, k0_grid, w0,b0,w1,b1,w2,b2; cfg: the non-learned `state` fields."""
+    params: dict of leaf tensors density_grid, k0_grid, w0,b0,w1,b1,w2,b2; cfg: the non-learned `state` fields.
+    grid_query: differentiable lookup with fourier_grid_query's signature (default: the torch restatement)."""
+    fourier_grid_query_ = grid_query or fourier_grid_query
     dev = rays_o.device
     R = rays_o.shape[0]
     F_num, thres = int(cfg['fourier_freq_num']), float(cfg['fast_color_thres'])
@@ -265,7 +268,7 @@ def fouriergrid_train_forward(params, cfg, rays_o, rays_d, viewdirs, stepsize, R
     interval = float(torch.tensor(float(cfg['voxel_size_ratio']), dtype=torch.float32) * stepsize)
     ray_id = torch.arange(R, device=dev).view(-1, 1).expand(R, S).flatten()
     lo, hi = cfg['xyz_min'].to(dev), cfg['xyz_max'].to(dev)
-    density = fourier_grid_query(params['density_grid'], pts, lo, hi, F_num)
+    density = fourier_grid_query_(params['density_grid'], pts, lo, hi, F_num)
     alpha = Raw2Alpha.apply(density.flatten(), float(cfg['act_shift']), interval).reshape(density.shape)
     m1 = alpha > thres
     pts, alpha, tt = pts[m1], alpha[m1], t[None].repeat(R, 1)[m1]
@@ -273,7 +276,7 @@ def fouriergrid_train_forward(params, cfg, rays_o, rays_d, viewdirs, stepsize, R
     weights, alphainv_last = Alphas2Weights.apply(alpha, ray_id, R)
     m2 = weights > thres
     pts, weights, ray_id, tt = pts[m2], weights[m2], ray_id[m2], tt[m2]
-    k0 = fourier_grid_query(params['k0_grid'], pts, lo, hi, F_num)
+    k0 = fourier_grid_query_(params['k0_grid'], pts, lo, hi, F_num)
     emb = viewdir_embedding(viewdirs.cpu(), int(cfg['viewbase_pe'])).to(dev)[ray_id]
     rgb = torch.sigmoid(rgbnet_apply([params['w0'], params['w1'], params['w2']],
                                      [params['b0'], params['b1'], params['b2']], torch.cat([k0, emb], -1)))

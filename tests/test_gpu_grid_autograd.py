@@ -1,0 +1,76 @@
+"""SURVEY.md section 8 row f2 (first piece): the Fourier / dense grid lookup as an autograd op on the HIP kernels --
+forward = ugrid_grid_query, backward = ugrid_grid_query_backward (scatter of the output gradient through the
+trilinear weights, hardware fp32 atomics) -- against torch autograd through the oracle's F.grid_sample restatement
+of FourierGrid.forward (FourierGrid_grid.py:60-78).  Like torch's own grid_sample backward the device accumulation
+order is not fixed, so gradients agree to rounding (tolerance below), not bit for bit."""
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import model_oracle
+
+pytestmark = pytest.mark.gpu
+
+GRAD_RTOL = 2e-5   # of the largest |gradient entry| (fp32 sums of up to ~n/cells terms in arbitrary order)
+
+
+def _case(C, Fq, G, n, seed):
+    P = 1 + 2 * Fq if Fq > 0 else 1
+    grid = torch.from_numpy(synth.normal(seed, P * C * G[0] * G[1] * G[2]).reshape(P, C, *G))
+    pts = torch.from_numpy(synth.uniform(seed + 1, n * 3, -1.4, 1.4).reshape(n, 3))   # some fall outside the box
+    pts[:4] = torch.tensor([[-1.2, -1.2, -1.2], [1.2, 1.2, 1.2], [0.0, 0.0, 0.0], [1.3, 0.1, -0.2]])
+    gout = torch.from_numpy(synth.normal(seed + 2, n * C).reshape(n, C))
+    gout[5:9] = 0.0   # exact zeros must not touch the gradient
+    return grid, pts, gout
+
+
+@pytest.mark.parametrize("C,Fq,G,n", [(1, 3, (9, 7, 5), 4001), (12, 3, (8, 8, 8), 3000), (3, 2, (6, 9, 7), 2000),
+                                      (4, 0, (6, 8, 11), 2500), (1, 0, (5, 5, 5), 700)])
+def test_grid_query_backward_matches_torch_autograd(C, Fq, G, n):
+    from unboundednerfpytorch_amd.grid import GridQuery
+    grid, pts, gout = _case(C, Fq, G, n, 900 + C + 10 * Fq)
+    lo, hi = torch.full((3,), -1.2), torch.full((3,), 1.2)
+    # oracle: torch autograd on CPU
+    g_ref = grid.clone().requires_grad_(True)
+    out_ref = model_oracle.fourier_grid_query(g_ref, pts, lo, hi, Fq).reshape(n, C)
+    (out_ref * gout).sum().backward()
+    # product: HIP forward + HIP backward
+    g_dev = grid.cuda().requires_grad_(True)
+    out = GridQuery.apply(g_dev, pts.cuda(), lo.cuda(), hi.cuda(), Fq).reshape(n, C)
+    (out * gout.cuda()).sum().backward()
+    np.testing.assert_allclose(out.detach().cpu().numpy(), out_ref.detach().numpy(), rtol=0, atol=2e-5)
+    ref = g_ref.grad.numpy()
+    got = g_dev.grad.cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= GRAD_RTOL * max(1.0, np.abs(ref).max())
+    # voxels no sample touches keep an exact zero (MaskedAdam's skip_zero_grad depends on it)
+    assert np.array_equal(got == 0, ref == 0) or (np.abs(ref[(got == 0) != (ref == 0)]).max() < 1e-6)
+
+
+def test_fourier_grid_module_mirrors_the_reference_module():
+    from unboundednerfpytorch_amd.grid import FourierGrid, create_grid, grid_query
+    ws = torch.tensor([7, 6, 5])
+    m = create_grid('DenseGrid', channels=12, world_size=ws, xyz_min=[-1.2] * 3, xyz_max=[1.2] * 3,
+                    use_nerf_pos=True, fourier_freq_num=3, config=None).cuda()
+    assert isinstance(m, FourierGrid)
+    assert set(m.state_dict().keys()) == {"grid", "xyz_min", "xyz_max"}     # FourierGrid_grid.py:43-58
+    assert tuple(m.grid.shape) == (7, 12, 7, 6, 5)
+    with torch.no_grad():
+        m.grid.copy_(torch.from_numpy(synth.normal(5, m.grid.numel()).reshape(m.grid.shape)))
+    pts = torch.from_numpy(synth.uniform(6, 300 * 3, -1.2, 1.2).reshape(10, 30, 3)).cuda()
+    out = m(pts)
+    assert out.shape == (10, 30, 12)
+    assert torch.equal(out.detach(), grid_query(m.grid.detach(), pts, m.xyz_min, m.xyz_max, 3))
+    out.square().sum().backward()
+    assert m.grid.grad is not None and float(m.grid.grad.abs().sum()) > 0
+    before = m.grid.grad.clone()
+    m.total_variation_add_grad(1e-3, 1e-3, 1e-3, True)                     # in place on .grad, dense mode
+    assert not torch.equal(before, m.grid.grad)
+    m.scale_volume_grid([9, 8, 7])
+    assert tuple(m.grid.shape) == (7, 12, 9, 8, 7)
+    m -= 0.5
+    d = create_grid('DenseGrid', channels=1, world_size=ws, xyz_min=[-1.0] * 3, xyz_max=[1.0] * 3,
+                    use_nerf_pos=False, fourier_freq_num=5, config=None).cuda()
+    assert tuple(d.grid.shape) == (1, 1, 7, 6, 5) and d(pts).shape == (10, 30)
+    assert "channels=12" in repr(m)

@@ -18,7 +18,7 @@ from test_oracle_golden import make_state
 pytestmark = pytest.mark.gpu
 
 
-def run_steps(device, backend_ru, backend_tv, adam_cls, n_steps, seed=21):
+def run_steps(device, backend_ru, backend_tv, adam_cls, n_steps, seed=21, grid_query=None):
     G, F, C, R, stepsize = 20, 3, 12, 512, 0.5
     cfg = make_state(seed, G, F, C, 4, "inf", 1e-4, 4.0, 10.0)
     params = {
@@ -38,7 +38,8 @@ def run_steps(device, backend_ru, backend_tv, adam_cls, n_steps, seed=21):
     info = []
     for step in range(n_steps):
         opt.zero_grad(set_to_none=True)
-        out = model_oracle.fouriergrid_train_forward(params, cfg, o, d, v, stepsize, Raw2Alpha, Alphas2Weights)
+        out = model_oracle.fouriergrid_train_forward(params, cfg, o, d, v, stepsize, Raw2Alpha, Alphas2Weights,
+                                                     grid_query=grid_query)
         loss = torch.nn.functional.mse_loss(out['rgb_marched'], target)
         pout = out['alphainv_last'].clamp(1e-6, 1 - 1e-6)
         loss = loss + 0.01 * (-(pout * torch.log(pout) + (1 - pout) * torch.log(1 - pout))).mean()  # entropy_last
@@ -80,7 +81,11 @@ def test_train_step_gpu_matches_cpu_oracle():
     torch.set_num_threads(8)
     n_steps = 2
     p_cpu, info_cpu = run_steps("cpu", ref_ops, ref_ops, _OracleAdam, n_steps)
-    p_gpu, info_gpu = run_steps("cuda", render_utils_cuda, total_variation_cuda, MaskedAdam, n_steps)
+    # GPU side: every grid lookup (forward AND backward) on the HIP kernels too -- the whole step then runs on the
+    # product's ops except the three rgbnet Linear layers (plain rocBLAS GEMMs through torch)
+    from unboundednerfpytorch_amd.grid import GridQuery
+    p_gpu, info_gpu = run_steps("cuda", render_utils_cuda, total_variation_cuda, MaskedAdam, n_steps,
+                                grid_query=GridQuery.apply)
     for (l0, n0, g0), (l1, n1, g1) in zip(info_cpu, info_gpu):
         assert abs(l0 - l1) <= 1e-5 * max(1.0, abs(l0)), (l0, l1)
         assert abs(n0 - n1) <= 2

@@ -55,9 +55,10 @@ __global__ void k_pack_bricks(const float *__restrict__ grid, int P, int C, int 
 // stand-alone grid query on the canonical layout (FourierGrid.forward / DenseGrid.forward).
 // 1 lane per point; corner taps are z-pairs in the [.., Z] fastest dimension.
 // ----------------------------------------------------------------------------------------------
-__device__ __forceinline__ float ug_tap(const float *__restrict__ g, int X, int Y, int Z, float cx, float cy,
-                                        float cz) {
-  // generic zero-padded trilinear tap at normalised (cx->X axis, cy->Y, cz->Z)
+// generic zero-padded trilinear tap at normalised (cx->X axis, cy->Y, cz->Z): the 8 corner offsets inside one
+// [X,Y,Z] plane (-1 = outside the grid, zero padding) and their weights, in grid_sample's corner order
+struct ug_taps { int64_t off[8]; float w[8]; };
+__device__ __forceinline__ ug_taps ug_tap_setup(int X, int Y, int Z, float cx, float cy, float cz) {
   const float ix = ((cx + 1.f) / 2.f) * (float)(X - 1);
   const float iy = ((cy + 1.f) / 2.f) * (float)(Y - 1);
   const float iz = ((cz + 1.f) / 2.f) * (float)(Z - 1);
@@ -67,18 +68,29 @@ __device__ __forceinline__ float ug_tap(const float *__restrict__ g, int X, int 
   const float wz0 = (fz + 1.f) - iz, wz1 = iz - fz;
   const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)X), y0 = (int)fminf(fmaxf(fy, -2.f), (float)Y),
             z0 = (int)fminf(fmaxf(fz, -2.f), (float)Z);
-  float acc = 0.f;
+  ug_taps t;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     const int xi = x0 + (c >> 2), yi = y0 + ((c >> 1) & 1), zi = z0 + (c & 1);
-    if (xi >= 0 && xi < X && yi >= 0 && yi < Y && zi >= 0 && zi < Z) {
-      const float w = ((c & 1) ? wz1 : wz0) * (((c >> 1) & 1) ? wy1 : wy0) * ((c >> 2) ? wx1 : wx0);
-      acc += g[((int64_t)xi * Y + yi) * Z + zi] * w;
-    }
+    const bool in = xi >= 0 && xi < X && yi >= 0 && yi < Y && zi >= 0 && zi < Z;
+    t.off[c] = in ? ((int64_t)xi * Y + yi) * Z + zi : -1;
+    t.w[c] = ((c & 1) ? wz1 : wz0) * (((c >> 1) & 1) ? wy1 : wy0) * ((c >> 2) ? wx1 : wx0);
   }
-  return acc;
+  return t;
 }
 
+// level coordinates of the Fourier grid: l = 0 plain, odd l = sin(2^k u), even l = cos(2^k u), k = (l-1)/2
+__device__ __forceinline__ void ug_level_coords(int l, float ux, float uy, float uz, float &cx, float &cy, float &cz) {
+  cx = ux; cy = uy; cz = uz;
+  if (l > 0) {
+    const float f = (float)(1 << ((l - 1) >> 1));
+    if ((l - 1) & 1) { cx = cosf(f * ux); cy = cosf(f * uy); cz = cosf(f * uz); }
+    else { cx = sinf(f * ux); cy = sinf(f * uy); cz = sinf(f * uz); }
+  }
+}
+
+// forward: 1 lane per point; per level the taps are set up once and reused by every channel; the per-channel sums
+// over levels build up in the output row itself (level 0 first, like the reference's mean over the level axis)
 __global__ void k_grid_query(const float *__restrict__ grid, int P, int C, int X, int Y, int Z,
                              const float *__restrict__ xyz, const float *__restrict__ xyz_min,
                              const float *__restrict__ xyz_max, int F, int64_t n, float *__restrict__ out) {
@@ -88,19 +100,50 @@ __global__ void k_grid_query(const float *__restrict__ grid, int P, int C, int X
   const float uy = ug_unorm(xyz[3 * p + 1], xyz_min[1], xyz_max[1]);
   const float uz = ug_unorm(xyz[3 * p + 2], xyz_min[2], xyz_max[2]);
   const int64_t vol = (int64_t)X * Y * Z;
-  for (int ch = 0; ch < C; ++ch) {
-    float acc = 0.f;
-    for (int l = 0; l < P; ++l) {
-      float cx = ux, cy = uy, cz = uz;
-      if (l > 0) {
-        const float f = (float)(1 << ((l - 1) >> 1));
-        if ((l - 1) & 1) { cx = cosf(f * ux); cy = cosf(f * uy); cz = cosf(f * uz); }
-        else { cx = sinf(f * ux); cy = sinf(f * uy); cz = sinf(f * uz); }
-      }
-      const float v = ug_tap(grid + ((int64_t)l * C + ch) * vol, X, Y, Z, cx, cy, cz);
-      acc = (l == 0) ? v : acc + v;
+  float *__restrict__ row = out + p * C;
+  for (int l = 0; l < P; ++l) {
+    float cx, cy, cz;
+    ug_level_coords(l, ux, uy, uz, cx, cy, cz);
+    const ug_taps t = ug_tap_setup(X, Y, Z, cx, cy, cz);
+    for (int ch = 0; ch < C; ++ch) {
+      const float *__restrict__ g = grid + ((int64_t)l * C + ch) * vol;
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (t.off[c] >= 0) acc += g[t.off[c]] * t.w[c];
+      row[ch] = (l == 0) ? acc : row[ch] + acc;
     }
-    out[p * C + ch] = (F > 0) ? acc / (float)P : acc;
+  }
+  if (F > 0)
+    for (int ch = 0; ch < C; ++ch) row[ch] = row[ch] / (float)P;
+}
+
+// backward w.r.t. the grid: 1 lane per (point, level); grad_grid[l, ch, corner] += w * grad_out[p, ch] / P with
+// hardware fp32 atomics (global_atomic_add_f32).  Like torch's grid_sample backward the accumulation order is
+// not fixed, so sums agree to rounding, not bit for bit.
+__global__ void k_grid_query_backward(const float *__restrict__ grad_out, int P, int C, int X, int Y, int Z,
+                                      const float *__restrict__ xyz, const float *__restrict__ xyz_min,
+                                      const float *__restrict__ xyz_max, int F, int64_t n,
+                                      float *__restrict__ grad_grid) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n * P) return;
+  const int64_t p = q / P;
+  const int l = (int)(q - p * P);
+  const float ux = ug_unorm(xyz[3 * p], xyz_min[0], xyz_max[0]);
+  const float uy = ug_unorm(xyz[3 * p + 1], xyz_min[1], xyz_max[1]);
+  const float uz = ug_unorm(xyz[3 * p + 2], xyz_min[2], xyz_max[2]);
+  float cx, cy, cz;
+  ug_level_coords(l, ux, uy, uz, cx, cy, cz);
+  const ug_taps t = ug_tap_setup(X, Y, Z, cx, cy, cz);
+  const int64_t vol = (int64_t)X * Y * Z;
+  for (int ch = 0; ch < C; ++ch) {
+    float g = grad_out[p * C + ch];
+    if (F > 0) g = g / (float)P;
+    if (g == 0.f) continue;   // exact zeros stay exact zeros in the grid gradient (MaskedAdam keys on them)
+    float *__restrict__ gg = grad_grid + ((int64_t)l * C + ch) * vol;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (t.off[c] >= 0) unsafeAtomicAdd(gg + t.off[c], g * t.w[c]);
   }
 }
 
@@ -136,6 +179,17 @@ extern "C" int ugrid_grid_query(const float *grid, int P, int C, int X, int Y, i
   if (P != (freq_num > 0 ? 2 * freq_num + 1 : 1)) return (int)hipErrorInvalidValue;
   hipLaunchKernelGGL(k_grid_query, dim3(ug_blocks(n, 256)), dim3(256), 0, ST(s), grid, P, C, X, Y, Z, xyz,
                      xyz_min, xyz_max, freq_num, n, out);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ugrid_grid_query_backward(const float *grad_out, int P, int C, int X, int Y, int Z, const float *xyz,
+                                         const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
+                                         float *grad_grid, ugrid_stream_t s) {
+  if (n <= 0) return 0;
+  if (P != (freq_num > 0 ? 2 * freq_num + 1 : 1)) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_grid_query_backward, dim3(ug_blocks(n * P, 256)), dim3(256), 0, ST(s), grad_out, P, C, X, Y,
+                     Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid);
   UG_LAUNCH_CHECK();
   return 0;
 }

@@ -1,8 +1,12 @@
-"""Inference-time voxel-grid queries on the canonical [P,C,X,Y,Z] layout:
-  grid_query     <- FourierGrid.forward (FourierGrid_grid.py:60-78) / DenseGrid.forward (grid.py:50-61)
-  MaskGrid       <- MaskGrid.forward (grid.py:230-239, FourierGrid_grid.py:159-168)
-No autograd: training keeps using the reference's F.grid_sample modules."""
+"""Voxel-grid queries on the canonical [P,C,X,Y,Z] layout:
+  grid_query     <- FourierGrid.forward (FourierGrid_grid.py:60-78) / DenseGrid.forward (grid.py:50-61), no autograd
+  GridQuery      the same lookup as an autograd.Function: HIP forward + HIP scatter backward into the grid
+                 (replaces F.grid_sample and its atomics-bound backward in training)
+  FourierGrid    drop-in for the reference's nn.Module of that name (FourierGrid_grid.py:43-103): same constructor,
+                 parameter / buffer names (state_dict compatible) and methods
+  MaskGrid       <- MaskGrid.forward (grid.py:230-239, FourierGrid_grid.py:159-168)"""
 import torch
+import torch.nn.functional as F
 
 from . import _lib, render_utils_cuda
 
@@ -27,6 +31,88 @@ def grid_query(grid, xyz, xyz_min, xyz_max, freq_num):
                                        _lib.stream_of(grid)), "grid_query")
     out = out.reshape(*lead, C)
     return out.squeeze(-1) if C == 1 else out
+
+
+class GridQuery(torch.autograd.Function):
+    """out[..., C] = mean over the Fourier levels of trilinear(grid[l], level coordinates of xyz).  Differentiable in
+    the grid only (the reference never differentiates the sample positions: rays carry no gradient)."""
+
+    @staticmethod
+    def forward(ctx, grid, xyz, xyz_min, xyz_max, freq_num):
+        out = grid_query(grid, xyz, xyz_min, xyz_max, freq_num)
+        if grid.requires_grad:
+            ctx.save_for_backward(xyz.reshape(-1, 3).contiguous(), xyz_min, xyz_max)
+            ctx.shape = tuple(grid.shape)
+            ctx.freq_num = max(int(freq_num), 0)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_out):
+        pts, xyz_min, xyz_max = ctx.saved_tensors
+        P, C, X, Y, Z = ctx.shape
+        g = grad_out.reshape(-1, C).to(torch.float32).contiguous()
+        grad_grid = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        with torch.cuda.device(g.device):
+            _lib.check(_L.ugrid_grid_query_backward(_lib.ptr(g), P, C, X, Y, Z, _lib.ptr(pts), _lib.ptr(xyz_min),
+                                                    _lib.ptr(xyz_max), ctx.freq_num, pts.shape[0],
+                                                    _lib.ptr(grad_grid), _lib.stream_of(g)), "grid_query_backward")
+        return grad_grid, None, None, None, None
+
+
+def create_grid(type, **kwargs):
+    if type == 'DenseGrid':
+        return FourierGrid(**kwargs)
+    raise NotImplementedError
+
+
+class FourierGrid(torch.nn.Module):
+    """Dense voxel grid with optional Fourier levels; mirrors FourierGrid_grid.FourierGrid (same ctor arguments,
+    `grid` parameter [P,C,X,Y,Z], `xyz_min` / `xyz_max` buffers, methods), with the lookup, its backward and the
+    total-variation gradient on the HIP kernels."""
+
+    def __init__(self, channels, world_size, xyz_min, xyz_max, use_nerf_pos, fourier_freq_num, config=None):
+        super().__init__()
+        self.channels = channels
+        self.world_size = world_size
+        self.register_buffer('xyz_min', torch.Tensor(xyz_min))
+        self.register_buffer('xyz_max', torch.Tensor(xyz_max))
+        if use_nerf_pos:
+            self.nerf_pos_num_freq = fourier_freq_num
+            self.pos_embed_output_dim = 1 + self.nerf_pos_num_freq * 2
+            self.grid = torch.nn.Parameter(torch.zeros([self.pos_embed_output_dim, channels, *world_size]))
+        else:
+            self.nerf_pos_num_freq = -1
+            self.pos_embed_output_dim = -1
+            self.grid = torch.nn.Parameter(torch.zeros([1, channels, *world_size]))
+
+    def forward(self, xyz):
+        """xyz [..., 3] world coordinates -> [..., C] (squeezed when C == 1)"""
+        return GridQuery.apply(self.grid, xyz, self.xyz_min, self.xyz_max, self.nerf_pos_num_freq)
+
+    def scale_volume_grid(self, new_world_size):
+        if self.channels == 0:
+            self.grid = torch.nn.Parameter(torch.zeros([1, self.channels, *new_world_size]))
+        else:
+            self.grid = torch.nn.Parameter(
+                F.interpolate(self.grid.data, size=tuple(new_world_size), mode='trilinear', align_corners=True))
+
+    def total_variation_add_grad(self, wx, wy, wz, dense_mode):
+        """Add the total-variation gradient in place (total_variation_kernel.cu:14-67)."""
+        from . import total_variation_cuda
+        total_variation_cuda.total_variation_add_grad(self.grid, self.grid.grad, wx, wy, wz, dense_mode)
+
+    def get_dense_grid(self):
+        return self.grid
+
+    @torch.no_grad()
+    def __isub__(self, val):
+        self.grid.data -= val
+        return self
+
+    def extra_repr(self):
+        ws = self.world_size.tolist() if torch.is_tensor(self.world_size) else list(self.world_size)
+        return f'channels={self.channels}, world_size={ws}'
 
 
 class MaskGrid(torch.nn.Module):
