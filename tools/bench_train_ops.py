@@ -38,3 +38,31 @@ t = timed(lambda: total_variation_cuda.total_variation_add_grad(p, gsp, 1e-3, 1e
 res["TV masked (5%)"] = (t, 4 * N + 32 * touched)
 for k, (ms, b) in res.items():
     print("%-26s %8.3f ms  %8.1f GB/s algorithmic  (%.2f of 8 TB/s)" % (k, ms, b / ms / 1e6, b / ms / 1e6 / 8000))
+
+# grid lookup forward / backward at the config-3 training shape: 4096 rays x 668 samples through the density grid
+# (all samples), ~5 % of them through the 12-channel k0 grid; HIP op against torch's grid_sample autograd
+del p, m, v, g, gs, gg, gsp
+torch.cuda.empty_cache()
+import torch.nn.functional as Fn
+from unboundednerfpytorch_amd.grid import GridQuery
+Fq, G = 3, 200
+lo, hi = torch.full((3,), -1.2, device=dev), torch.full((3,), 1.2, device=dev)
+def torch_query(grid, pts):
+    u = ((pts - lo) / (hi - lo)).flip((-1,)) * 2 - 1
+    lv = [u]
+    for k in range(Fq):
+        lv += [torch.sin(u * 2 ** k), torch.cos(u * 2 ** k)]
+    taps = Fn.grid_sample(grid, torch.stack(lv, 0)[:, None, None], mode='bilinear', align_corners=True)
+    return taps.mean(0).reshape(grid.shape[1], -1).T
+for name, C, n in (("density grid (C=1), 2.74 M points", 1, 4096 * 668), ("k0 grid (C=12), 137 k points", 12, 4096 * 668 // 20)):
+    grid = torch.randn(7, C, G, G, G, device=dev, requires_grad=True)
+    pts = torch.rand(n, 3, device=dev) * 2.4 - 1.2
+    gout = torch.randn(n, C, device=dev)
+    def fb(fn):
+        grid.grad = None
+        out = fn().reshape(n, C)
+        out.backward(gout)
+    t_hip = timed(lambda: fb(lambda: GridQuery.apply(grid, pts, lo, hi, Fq)))
+    t_ref = timed(lambda: fb(lambda: torch_query(grid, pts)))
+    t_f = timed(lambda: GridQuery.apply(grid.detach(), pts, lo, hi, Fq))
+    print("%-36s fwd+bwd HIP %7.3f ms (fwd %6.3f)   torch grid_sample fwd+bwd %7.3f ms   x%.1f" % (name, t_hip, t_f, t_ref, t_ref / t_hip))
