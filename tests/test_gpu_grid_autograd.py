@@ -74,3 +74,28 @@ def test_fourier_grid_module_mirrors_the_reference_module():
                     use_nerf_pos=False, fourier_freq_num=5, config=None).cuda()
     assert tuple(d.grid.shape) == (1, 1, 7, 6, 5) and d(pts).shape == (10, 30)
     assert "channels=12" in repr(m)
+
+
+def test_mask_grid_constructor_variants(tmp_path):
+    """MaskGrid(path=..., mask_cache_thres=...) / MaskGrid(path=None, mask=..., xyz_min=..., xyz_max=...) as the
+    reference models call it (FourierGrid_model.py:259,437; dvgo.py:88-96)."""
+    import torch.nn.functional as Fn
+    from unboundednerfpytorch_amd.grid import MaskGrid
+    from unboundednerfpytorch_amd import render_utils_cuda
+    G = (9, 8, 7)
+    dens = torch.from_numpy(synth.normal(77, G[0] * G[1] * G[2]).reshape(1, 1, *G)) * 4
+    ck = {"model_kwargs": {"xyz_min": [-1.0, -1.0, -1.0], "xyz_max": [1.0, 1.5, 1.0], "voxel_size_ratio": 0.5},
+          "model_state_dict": {"density.grid": dens, "act_shift": torch.tensor([-2.0])}}
+    path = str(tmp_path / "coarse_last.tar")
+    torch.save(ck, path)
+    m = MaskGrid(path=path, mask_cache_thres=1e-3).cuda()
+    pooled = Fn.max_pool3d(dens, kernel_size=3, padding=1, stride=1)
+    want = (1 - torch.exp(-Fn.softplus(pooled - 2.0) * 0.5) >= 1e-3)[0, 0]
+    assert torch.equal(m.mask.cpu(), want) and 0 < int(want.sum()) < want.numel()
+    m2 = MaskGrid(path=None, mask=want, xyz_min=[-1.0, -1.0, -1.0], xyz_max=[1.0, 1.5, 1.0]).cuda()
+    pts = torch.from_numpy(synth.uniform(78, 500 * 3, -1.2, 1.6).reshape(5, 100, 3)).cuda()
+    a, b = m(pts), m2(pts)
+    assert a.shape == (5, 100) and a.dtype == torch.bool and torch.equal(a, b)
+    direct = render_utils_cuda.maskcache_lookup(m.mask, pts.reshape(-1, 3).contiguous(), m.xyz2ijk_scale, m.xyz2ijk_shift)
+    assert torch.equal(a.flatten(), direct)
+    assert "mask.shape=[9, 8, 7]" in repr(m)

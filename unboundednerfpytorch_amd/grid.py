@@ -116,18 +116,29 @@ class FourierGrid(torch.nn.Module):
 
 
 class MaskGrid(torch.nn.Module):
-    """Occupancy lookup (known free space).  Built from an explicit mask (the `path=` constructor of the
-    reference belongs to the checkpoint row)."""
+    """Occupancy lookup (known free space); same constructor as the reference's MaskGrid (FourierGrid_grid.py:139-158,
+    grid.py:205-228): either an explicit boolean `mask` with its bounds, or `path` to a checkpoint whose density grid
+    is max-pooled (3x3x3), turned into alpha and thresholded at `mask_cache_thres`."""
 
-    def __init__(self, mask, xyz_min, xyz_max):
+    def __init__(self, path=None, mask_cache_thres=None, mask=None, xyz_min=None, xyz_max=None):
         super().__init__()
-        mask = mask.bool()
-        xyz_min = torch.as_tensor(xyz_min, dtype=torch.float32)
-        xyz_max = torch.as_tensor(xyz_max, dtype=torch.float32)
+        if path is not None:
+            st = torch.load(path, map_location='cpu', weights_only=False)
+            self.mask_cache_thres = mask_cache_thres
+            sd, kw = st['model_state_dict'], st['model_kwargs']
+            density = F.max_pool3d(sd['density.grid'], kernel_size=3, padding=1, stride=1)
+            alpha = 1 - torch.exp(-F.softplus(density + sd['act_shift']) * kw['voxel_size_ratio'])
+            mask = (alpha >= self.mask_cache_thres).squeeze(0).squeeze(0)
+            xyz_min, xyz_max = torch.Tensor(kw['xyz_min']), torch.Tensor(kw['xyz_max'])
+        else:
+            mask = mask.bool()
+            xyz_min = torch.as_tensor(xyz_min, dtype=torch.float32).cpu()
+            xyz_max = torch.as_tensor(xyz_max, dtype=torch.float32).cpu()
         self.register_buffer('mask', mask)
         xyz_len = xyz_max - xyz_min
-        self.register_buffer('xyz2ijk_scale', (torch.Tensor(list(mask.shape)) - 1) / xyz_len)
-        self.register_buffer('xyz2ijk_shift', -xyz_min * self.xyz2ijk_scale)
+        scale = (torch.Tensor(list(mask.shape)) - 1) / xyz_len
+        self.register_buffer('xyz2ijk_scale', scale)
+        self.register_buffer('xyz2ijk_shift', -xyz_min * scale)
 
     @torch.no_grad()
     def forward(self, xyz):
@@ -135,3 +146,6 @@ class MaskGrid(torch.nn.Module):
         out = render_utils_cuda.maskcache_lookup(self.mask, xyz.reshape(-1, 3).contiguous(), self.xyz2ijk_scale,
                                                  self.xyz2ijk_shift)
         return out.reshape(shape)
+
+    def extra_repr(self):
+        return f'mask.shape={list(self.mask.shape)}'
