@@ -88,9 +88,9 @@ def test_mask_grid_constructor_variants(tmp_path):
           "model_state_dict": {"density.grid": dens, "act_shift": torch.tensor([-2.0])}}
     path = str(tmp_path / "coarse_last.tar")
     torch.save(ck, path)
-    m = MaskGrid(path=path, mask_cache_thres=1e-3).cuda()
+    m = MaskGrid(path=path, mask_cache_thres=0.9).cuda()
     pooled = Fn.max_pool3d(dens, kernel_size=3, padding=1, stride=1)
-    want = (1 - torch.exp(-Fn.softplus(pooled - 2.0) * 0.5) >= 1e-3)[0, 0]
+    want = (1 - torch.exp(-Fn.softplus(pooled - 2.0) * 0.5) >= 0.9)[0, 0]
     assert torch.equal(m.mask.cpu(), want) and 0 < int(want.sum()) < want.numel()
     m2 = MaskGrid(path=None, mask=want, xyz_min=[-1.0, -1.0, -1.0], xyz_max=[1.0, 1.5, 1.0]).cuda()
     pts = torch.from_numpy(synth.uniform(78, 500 * 3, -1.2, 1.6).reshape(5, 100, 3)).cuda()
