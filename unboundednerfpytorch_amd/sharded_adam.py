@@ -1,0 +1,151 @@
+"""Data-parallel MaskedAdam with the per-voxel optimizer state sharded across the ranks (SURVEY.md section 8e,
+training: "rays -- and per-voxel Adam state -- shard embarrassingly across the GPUs of one node").
+
+The reference trains on one GPU (run_train.py:185-296).  With N ranks each rendering N_rand/N of the ray batch,
+every rank produces a full-size, mostly-zero gradient for the voxel grids.  Instead of all-reducing 2.7 GB and
+running Adam N times on replicated state, each parameter is cut into N contiguous flat ranges:
+
+    reduce_scatter(grad)  ->  rank r holds the summed gradient of range r          (RCCL, (N-1)/N x bytes out)
+    MaskedAdam kernels on range r only (exp_avg / exp_avg_sq exist only for it: 1/N of the state memory)
+    all_gather(param range) -> every rank has the updated parameter again          ((N-1)/N x bytes out)
+
+Small parameters (the rgbnet, 88 KB) are all-reduced and updated redundantly.  The update kernels are the same
+three as MaskedAdam's (adam_upd / masked_adam_upd / adam_upd_with_perlr); exact zeros stay exact through the sum,
+so the skip_zero_grad semantics are unchanged, and with `average=True` (default, DDP convention: every rank's loss
+is a mean over its own rays) the result equals the single-process optimizer stepping on the rank-averaged
+gradient bit for bit when N is a power of two.
+"""
+import torch
+import torch.distributed as dist
+
+
+class ShardedMaskedAdam(torch.optim.Optimizer):
+    """Same constructor and param-group keys as MaskedAdam (`skip_zero_grad` per group, masked_adam.py:21-41) plus
+    the process group.  `ops`: module providing the three update kernels (default: the HIP drop-in
+    adam_upd_cuda)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, group=None, average=True,
+                 min_shard_numel=1 << 16, ops=None):
+        if not 0.0 <= lr:
+            raise ValueError("Invalid learning rate: {}".format(lr))
+        if not 0.0 <= eps:
+            raise ValueError("Invalid epsilon value: {}".format(eps))
+        if not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
+            raise ValueError("Invalid beta parameters: {}".format(betas))
+        if ops is None:
+            from . import adam_upd_cuda as ops
+        self.ops = ops
+        self.group = group
+        self.average = bool(average)
+        self.min_shard_numel = int(min_shard_numel)
+        self.per_lr = None
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+
+    # -- topology ------------------------------------------------------------------------------------
+    def _world(self):
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_world_size(self.group), dist.get_rank(self.group)
+        return 1, 0
+
+    @staticmethod
+    def shard_len(numel, world, align=4):
+        """Flat elements per rank: ceil(numel / world) rounded up to the update kernels' 4-voxel vectors."""
+        per = -(-numel // world)
+        return -(-per // align) * align
+
+    def set_pervoxel_lr(self, count):
+        assert self.param_groups[0]['params'][0].shape == count.shape
+        self.per_lr = count.float() / count.max()
+
+    # -- one parameter ---------------------------------------------------------------------------------
+    def _update(self, group, p, g, m, v, step, per_lr):
+        beta1, beta2 = group['betas']
+        args = (step, beta1, beta2, group['lr'], group['eps'])
+        if per_lr is not None:
+            self.ops.adam_upd_with_perlr(p, g, m, v, per_lr, *args)
+        elif group['skip_zero_grad']:
+            self.ops.masked_adam_upd(p, g, m, v, *args)
+        else:
+            self.ops.adam_upd(p, g, m, v, *args)
+
+    @torch.no_grad()
+    def step(self):
+        world, rank = self._world()
+        scale = (1.0 / world) if (self.average and world > 1) else None
+        for group in self.param_groups:
+            for param in group['params']:
+                if param.grad is None:
+                    continue
+                state = self.state[param]
+                n = param.numel()
+                use_perlr = self.per_lr is not None and param.shape == self.per_lr.shape
+                sharded = world > 1 and n >= self.min_shard_numel
+                if not sharded:
+                    # replicated: every rank applies the same (summed) gradient to its own full state
+                    g = param.grad
+                    if world > 1:
+                        dist.all_reduce(g, group=self.group)
+                        if scale is not None:
+                            g.mul_(scale)
+                    if len(state) == 0:
+                        state['step'] = 0
+                        state['exp_avg'] = torch.zeros_like(param, memory_format=torch.preserve_format)
+                        state['exp_avg_sq'] = torch.zeros_like(param, memory_format=torch.preserve_format)
+                    state['step'] += 1
+                    self._update(group, param, g, state['exp_avg'], state['exp_avg_sq'], state['step'],
+                                 self.per_lr if use_perlr else None)
+                    continue
+                per = self.shard_len(n, world)
+                total = per * world
+                b = min(n, rank * per)
+                e = min(n, b + per)
+                if len(state) == 0:
+                    state['step'] = 0
+                    state['exp_avg'] = torch.zeros(per, dtype=param.dtype, device=param.device)      # this rank's
+                    state['exp_avg_sq'] = torch.zeros(per, dtype=param.dtype, device=param.device)   # range only
+                    state['shard'] = (b, e, per)
+                state['step'] += 1
+                flat_p = param.data.view(-1)
+                flat_g = param.grad.contiguous().view(-1)
+                exact = (total == n)       # no padding: collectives run on the parameter / gradient storage itself
+                if not exact:
+                    pad_g = torch.zeros(total, dtype=flat_g.dtype, device=flat_g.device)
+                    pad_g[:n] = flat_g
+                    flat_g = pad_g
+                g_shard = torch.empty(per, dtype=flat_g.dtype, device=flat_g.device)
+                dist.reduce_scatter_tensor(g_shard, flat_g, group=self.group)
+                if scale is not None:
+                    g_shard.mul_(scale)
+                if exact:
+                    p_shard = flat_p[b:b + per]                  # a view: updated in place
+                else:
+                    p_shard = torch.zeros(per, dtype=flat_p.dtype, device=flat_p.device)
+                    p_shard[: e - b] = flat_p[b:e]
+                lr_shard = None
+                if use_perlr:
+                    lr_shard = torch.zeros(per, dtype=torch.float32, device=param.device)
+                    lr_shard[: e - b] = self.per_lr.reshape(-1)[b:e]
+                self._update(group, p_shard, g_shard, state['exp_avg'], state['exp_avg_sq'], state['step'], lr_shard)
+                if exact:
+                    dist.all_gather_into_tensor(flat_p, p_shard.clone(), group=self.group)
+                else:
+                    full = torch.empty(total, dtype=flat_p.dtype, device=flat_p.device)
+                    dist.all_gather_into_tensor(full, p_shard, group=self.group)
+                    flat_p.copy_(full[:n])
+
+    # -- checkpointing ---------------------------------------------------------------------------------
+    @torch.no_grad()
+    def gather_full_state(self, param):
+        """exp_avg / exp_avg_sq of `param` assembled on every rank in the parameter's shape (what the reference's
+        optimizer_state_dict would hold, utils.py:70-74); for saving a checkpoint."""
+        world, _ = self._world()
+        st = self.state[param]
+        if 'shard' not in st:
+            return st['exp_avg'], st['exp_avg_sq']
+        n = param.numel()
+        out = []
+        for k in ('exp_avg', 'exp_avg_sq'):
+            full = torch.empty(st['shard'][2] * world, dtype=st[k].dtype, device=st[k].device)
+            dist.all_gather_into_tensor(full, st[k], group=self.group)
+            out.append(full[:n].reshape(param.shape))
+        return tuple(out)
