@@ -334,3 +334,23 @@ def test_autograd_and_masked_adam_match_reference_golden(mods, golden_dir):
     np.testing.assert_array_equal(p_dense.detach().cpu().numpy(), gold["adam_dense"])
     np.testing.assert_array_equal(opt.state[p_grid]['exp_avg'].cpu().numpy(), gold["adam_grid_m"])
     np.testing.assert_array_equal(opt.state[p_grid]['exp_avg_sq'].cpu().numpy(), gold["adam_grid_v"])
+
+
+def test_sharded_masked_adam_degenerates_to_masked_adam_on_one_gpu():
+    """Without a process group ShardedMaskedAdam must step exactly like MaskedAdam on the HIP kernels (the sharded
+    path itself is covered by the 2-rank gloo test in test_host_logic.py)."""
+    from unboundednerfpytorch_amd.masked_adam import MaskedAdam
+    from unboundednerfpytorch_amd.sharded_adam import ShardedMaskedAdam
+    shape = (7, 3, 9, 8, 8)
+    n = int(np.prod(shape))
+    base = torch.from_numpy(synth.normal(61, n).reshape(shape)).cuda()
+    a, b = torch.nn.Parameter(base.clone()), torch.nn.Parameter(base.clone())
+    oa = MaskedAdam([{'params': [a], 'lr': 0.1, 'skip_zero_grad': True}])
+    ob = ShardedMaskedAdam([{'params': [b], 'lr': 0.1, 'skip_zero_grad': True}])
+    for step in range(3):
+        g = torch.from_numpy(synth.normal(62 + step, n).reshape(shape))
+        g = torch.where(torch.from_numpy(synth.uniform(70 + step, n).reshape(shape)) < 0.3, g, torch.zeros_like(g)).cuda()
+        a.grad, b.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    assert torch.equal(a.data, b.data)
+    assert torch.equal(oa.state[a]['exp_avg_sq'], ob.state[b]['exp_avg_sq'])
