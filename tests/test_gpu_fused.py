@@ -92,6 +92,21 @@ def test_fused_render_vs_oracle(fr, G, F, C, pe, norm, R, stepsize, dm, ds):
     assert abs(M - ref["weights"].numel()) <= max(3, int(2e-4 * M))
 
 
+def test_fused_render_non_cubic_grid(fr):
+    """X != Y != Z: the cell addressing of the packed bricks (fp32 row index, 24-bit multiplies, z-fastest records)
+    must use the right extent per axis in the pack, march and shade kernels."""
+    G, F, C, R = 48, 3, 12, 3000
+    state = make_state(4321, G, F, C, 4, "inf", 1e-4, 6.0, 12.0)
+    state["density_grid"] = state["density_grid"][:, :, :37, :29, :45].contiguous()
+    state["k0_grid"] = state["k0_grid"][:, :, :37, :29, :45].contiguous()
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(4322, R)]
+    ref = model_oracle.fouriergrid_render(state, o, d, v, 0.5, render_depth=True, return_margin=True)
+    rend = fr.FourierGridRenderer(state, "cuda:0")
+    assert rend.G == (37, 29, 45)
+    worst = check_render(rend(o.cuda(), d.cuda(), v.cuda(), stepsize=0.5, render_depth=True), ref, R)
+    assert ref["weights"].numel() > R and worst["rgb_marched"] < 5e-5
+
+
 @pytest.mark.parametrize("mode", [0, 1, 2])
 def test_rgbnet_mfma_modes(fr, mode):
     """The rgbnet runs on the matrix cores as exact fp32 MFMA (v_mfma_f32_32x32x2_f32, mode 0), as six bf16
