@@ -237,6 +237,12 @@ int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1, const floa
                    int32_t width, float k0_absmax, float *packed, int32_t *best_mode,
                    ugrid_stream_t stream);
 
+/* The host arithmetic behind ugrid_pack_mlp's answer, on HOST copies of w0 [128, C+3+6pe], b0 [128], w1 [128,128]:
+ * scales4 = {sX1, sW1, sX2, sW2}, the power-of-two activation / weight scales of layers 1 and 2 of the fp16x2
+ * image.  Returns 1 if the mode is usable (finite, non-degenerate ranges), else 0 (scales4 = 1).  No GPU needed. */
+int ugrid_mlp_fp16x2_scales(const float *h_w0, const float *h_b0, const float *h_w1, int32_t k0_channels,
+                            int32_t viewbase_pe, float k0_absmax, float *scales4);
+
 /* Tuning knobs (speed only, never results): "march_waves" 4..6, "split_gather" 0|1. */
 int ugrid_tune(const char *key, int value);
 

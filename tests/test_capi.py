@@ -85,3 +85,37 @@ def test_reference_module_names_and_signatures():
     import torch
     with pytest.raises(RuntimeError, match="must be a CUDA tensor"):
         render_utils_cuda.raw2alpha(torch.zeros(3), 0.0, 0.5)
+
+
+def test_fp16x2_scale_derivation_is_host_arithmetic(lib_path):
+    """ugrid_mlp_fp16x2_scales (the decision behind ugrid_pack_mlp's best_mode) runs on host buffers: powers of two
+    that put the largest weight / the propagated activation bound just below 2^15, and a refusal for degenerate or
+    out-of-range networks."""
+    import numpy as np
+    from unboundednerfpytorch_amd import _lib
+    lib = _lib.load()
+    C, pe = 12, 4
+    mlp_in = C + 3 + 6 * pe
+    rs = np.random.RandomState(0)
+    w0 = rs.uniform(-0.16, 0.16, (128, mlp_in)).astype(np.float32)
+    b0 = rs.uniform(-0.16, 0.16, 128).astype(np.float32)
+    w1 = rs.uniform(-0.088, 0.088, (128, 128)).astype(np.float32)
+    sc = (ctypes.c_float * 4)()
+
+    def call(w0_, b0_, w1_, k0max):
+        return lib.ugrid_mlp_fp16x2_scales(w0_.ctypes.data, b0_.ctypes.data, w1_.ctypes.data, C, pe,
+                                           ctypes.c_float(k0max), ctypes.cast(sc, ctypes.c_void_p))
+
+    assert call(w0, b0, w1, 5.5) == 1
+    sX1, sW1, sX2, sW2 = list(sc)
+    for v in (sX1, sW1, sX2, sW2):
+        assert v > 0 and np.log2(v) == np.round(np.log2(v))          # exact powers of two
+    bound = np.array([5.5] * C + [1.0] * (mlp_in - C))
+    B1 = (np.abs(w0.astype(np.float64)) @ bound + np.abs(b0)).max()
+    for scale, mag in ((sX1, 5.5), (sW1, np.abs(w0).max()), (sX2, B1), (sW2, np.abs(w1).max())):
+        assert 16384.0 < scale * mag <= 32768.0                       # largest scaled operand in (2^14, 2^15]
+    assert call(w0, b0, w1, 0.0) == 0 and list(sc) == [1.0] * 4       # unknown feature bound
+    assert call(w0, b0, w1, 1e30) == 0                                # bound far outside fp16's reach
+    assert call(w0, b0, np.zeros_like(w1), 5.5) == 0                  # degenerate layer
+    w_nan = w0.copy(); w_nan[3, 4] = np.nan
+    assert call(w_nan, b0, w1, 5.5) == 0

@@ -236,33 +236,34 @@ extern "C" int64_t ugrid_mlp_packed_bytes(int32_t k0_channels, int32_t viewbase_
 // largest power of two <= v (v > 0, finite)
 static inline float ug_pow2_floor(double v) { return (float)std::ldexp(1.0, (int)std::floor(std::log2(v))); }
 
-extern "C" int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1, const float *b1,
-                              const float *w2, const float *b2, int32_t k0_channels, int32_t viewbase_pe,
-                              int32_t width, float k0_absmax, float *packed, int32_t *best_mode,
-                              ugrid_stream_t s) {
-  if (width != 128) return (int)hipErrorInvalidValue;
+// fp16x2 scales from HOST copies of the first two layers (pure host arithmetic: unit-testable without a GPU).
+// Interval bounds are propagated through layer 1 (|k0| <= k0_absmax, |view embedding| <= 1); every scale is the
+// largest power of two that keeps the largest scaled operand <= 2^15.  Returns 1 when the mode is usable.
+extern "C" int ugrid_mlp_fp16x2_scales(const float *h_w0, const float *h_b0, const float *h_w1, int32_t k0_channels,
+                                       int32_t viewbase_pe, float k0_absmax, float *scales4) {
   const int C = k0_channels, n_emb = 3 + 6 * (int)viewbase_pe, mlp_in = C + n_emb;
-  // scales of the fp16x2 image: interval bounds propagated through layer 1 (|k0| <= k0_absmax, |emb| <= 1)
-  std::vector<float> h0((size_t)128 * mlp_in), hb0(128), h1((size_t)128 * 128);
-  UG_HIP(hipMemcpyAsync(h0.data(), w0, h0.size() * sizeof(float), hipMemcpyDeviceToHost, ST(s)));
-  UG_HIP(hipMemcpyAsync(hb0.data(), b0, hb0.size() * sizeof(float), hipMemcpyDeviceToHost, ST(s)));
-  UG_HIP(hipMemcpyAsync(h1.data(), w1, h1.size() * sizeof(float), hipMemcpyDeviceToHost, ST(s)));
-  UG_HIP(hipStreamSynchronize(ST(s)));
   double m1 = 0, m2 = 0, B1 = 0;
+  bool finite = true;   // NaN / inf weights: comparisons would silently skip them
   const double fb = k0_absmax > 0 ? (double)k0_absmax : 0.0;
   for (int n = 0; n < 128; ++n) {
-    double acc = std::fabs((double)hb0[n]);
+    double acc = std::fabs((double)h_b0[n]);
     for (int k = 0; k < mlp_in; ++k) {
-      const double a = std::fabs((double)h0[(size_t)n * mlp_in + k]);
+      const double a = std::fabs((double)h_w0[(size_t)n * mlp_in + k]);
+      finite = finite && std::isfinite(a);
       m1 = a > m1 ? a : m1;
       acc += a * (k < C ? fb : 1.0);
     }
+    finite = finite && std::isfinite(acc);
     B1 = acc > B1 ? acc : B1;
   }
-  for (size_t i = 0; i < h1.size(); ++i) { const double a = std::fabs((double)h1[i]); m2 = a > m2 ? a : m2; }
+  for (size_t i = 0; i < (size_t)128 * 128; ++i) {
+    const double a = std::fabs((double)h_w1[i]);
+    finite = finite && std::isfinite(a);
+    m2 = a > m2 ? a : m2;
+  }
   const double B0 = fb > 1.0 ? fb : 1.0;
   ug_mlp_scales sc = {1.f, 1.f, 1.f, 1.f};
-  bool ok = k0_absmax > 0 && std::isfinite(fb) && std::isfinite(B1) && std::isfinite(m1) && std::isfinite(m2) &&
+  bool ok = finite && k0_absmax > 0 && std::isfinite(fb) && std::isfinite(B1) && std::isfinite(m1) && std::isfinite(m2) &&
             m1 > 1e-30 && m2 > 1e-30 && B1 > 1e-30;
   if (ok) {
     sc.sX1 = ug_pow2_floor(32768.0 / B0);
@@ -275,6 +276,24 @@ extern "C" int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1,
          sc.sW1 <= hi && sc.sW2 <= hi;
     if (!ok) sc = {1.f, 1.f, 1.f, 1.f};
   }
+  scales4[0] = sc.sX1; scales4[1] = sc.sW1; scales4[2] = sc.sX2; scales4[3] = sc.sW2;
+  return ok ? 1 : 0;
+}
+
+extern "C" int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1, const float *b1,
+                              const float *w2, const float *b2, int32_t k0_channels, int32_t viewbase_pe,
+                              int32_t width, float k0_absmax, float *packed, int32_t *best_mode,
+                              ugrid_stream_t s) {
+  if (width != 128) return (int)hipErrorInvalidValue;
+  const int C = k0_channels, n_emb = 3 + 6 * (int)viewbase_pe, mlp_in = C + n_emb;
+  std::vector<float> h0((size_t)128 * mlp_in), hb0(128), h1((size_t)128 * 128);
+  UG_HIP(hipMemcpyAsync(h0.data(), w0, h0.size() * sizeof(float), hipMemcpyDeviceToHost, ST(s)));
+  UG_HIP(hipMemcpyAsync(hb0.data(), b0, hb0.size() * sizeof(float), hipMemcpyDeviceToHost, ST(s)));
+  UG_HIP(hipMemcpyAsync(h1.data(), w1, h1.size() * sizeof(float), hipMemcpyDeviceToHost, ST(s)));
+  UG_HIP(hipStreamSynchronize(ST(s)));
+  float sc4[4];
+  const int ok = ugrid_mlp_fp16x2_scales(h0.data(), hb0.data(), h1.data(), k0_channels, viewbase_pe, k0_absmax, sc4);
+  const ug_mlp_scales sc = {sc4[0], sc4[1], sc4[2], sc4[3]};
   hipLaunchKernelGGL(k_pack_mlp, dim3(64), dim3(256), 0, ST(s), w0, b0, w1, b1, w2, b2, C, n_emb, sc, packed);
   UG_LAUNCH_CHECK();
   if (best_mode) *best_mode = ok ? UGRID_MLP_FP16X2 : UGRID_MLP_BF16X3;
