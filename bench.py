@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--mlp-mode", type=int, default=None, help="rgbnet arithmetic: 0 fp32 MFMA, 1 bf16x3, 2 fp16x2 (default: what ugrid_pack_mlp reports usable)")
     ap.add_argument("--pipeline", type=int, default=0, help="ray chunks software-pipelined over two streams (0 = off)")
     ap.add_argument("--tune", action="append", default=[], help="key=value speed knob (ugrid_tune), repeatable")
-    ap.add_argument("--cpu-chunks", type=int, default=4, help="8192-ray chunks timed for the CPU baseline")
+    ap.add_argument("--cpu-chunks", type=int, default=12, help="8192-ray chunks timed for the CPU baseline (~1 s each)")
     return ap.parse_args()
 
 
