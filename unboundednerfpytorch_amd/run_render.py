@@ -1,0 +1,72 @@
+"""Frame loop of the render driver: the MI355X counterpart of
+run_render.render_viewpoints (/root/reference/FourierGrid/run_render.py:14-114).
+
+The reference generates rays on the host, renders 8192-ray chunks through a dict-per-chunk loop, concatenates, and
+calls `.cpu().numpy()` three times per frame (a blocking device sync each).  Here a frame is: rays generated on the
+device, ONE fused march + shade pass over all H*W rays (sharded over the process group when one is initialised,
+dist.render_sharded), and ONE asynchronous device-to-host copy of the packed [H,W,5] result into pinned memory on
+a side stream, overlapped with the next frame's render.  Same return values as the reference: numpy arrays
+rgbs [N,H,W,3], depths [N,H,W,1], bgmaps [N,H,W,1] (+ PSNRs when ground truth is given)."""
+import numpy as np
+import torch
+
+
+@torch.no_grad()
+def render_viewpoints(model, render_poses, HW, Ks, render_kwargs, gt_imgs=None, render_factor=0,
+                      flip_x=False, flip_y=False, group=None, verbose=False):
+    """model: FourierGridRenderer; render_poses [N,3or4,4] camera-to-world; HW [N,2]; Ks [N,3,3];
+    render_kwargs: needs 'stepsize', may carry 'inverse_y' (the keys run_render.py passes; others are ignored).
+    Returns (rgbs, depths, bgmaps) or (rgbs, depths, bgmaps, psnrs) when gt_imgs is given."""
+    assert len(render_poses) == len(HW) and len(HW) == len(Ks)
+    HW = np.asarray(HW).copy()
+    Ks = np.asarray(Ks, dtype=np.float64).copy()
+    if render_factor != 0:                                    # run_render.py:22-26
+        HW = (HW / render_factor).astype(int)
+        Ks[:, :2, :3] /= render_factor
+    dev = model.device
+    copy_stream = torch.cuda.Stream(dev)
+    n = len(render_poses)
+    host = [None, None]           # pinned double buffer, re-allocated when the frame size changes
+    done = [None, None]
+    frames = []
+
+    def drain(slot, H, W):
+        done[slot].synchronize()
+        a = host[slot][: H * W * 5].numpy().reshape(H, W, 5).copy()
+        frames.append(a)
+
+    pending = []                  # (slot, H, W) of copies in flight, oldest first
+    for i in range(n):
+        H, W = int(HW[i][0]), int(HW[i][1])
+        rgb, depth, bg = model.render_view(H, W, Ks[i], render_poses[i], render_kwargs["stepsize"],
+                                           inverse_y=bool(render_kwargs.get("inverse_y", False)),
+                                           flip_x=flip_x, flip_y=flip_y, group=group)
+        packed = torch.cat([rgb.reshape(-1, 3), depth.reshape(-1, 1), bg.reshape(-1, 1)], dim=1).reshape(-1)
+        slot = i & 1
+        if len(pending) == 2:     # the buffer about to be re-used must have been read out
+            drain(*pending.pop(0))
+        if host[slot] is None or host[slot].numel() < packed.numel():
+            host[slot] = torch.empty(packed.numel(), dtype=torch.float32, pin_memory=True)
+        ready = torch.cuda.current_stream(dev).record_event()
+        with torch.cuda.stream(copy_stream):
+            copy_stream.wait_event(ready)
+            host[slot][: packed.numel()].copy_(packed, non_blocking=True)
+            packed.record_stream(copy_stream)
+            done[slot] = copy_stream.record_event()
+        pending.append((slot, H, W))
+        if verbose:
+            print("render_viewpoints: frame %d/%d queued (%dx%d)" % (i + 1, n, W, H))
+    while pending:
+        drain(*pending.pop(0))
+    rgbs = np.array([f[..., 0:3] for f in frames])
+    depths = np.array([f[..., 3:4] for f in frames])
+    bgmaps = np.array([f[..., 4:5] for f in frames])
+    if gt_imgs is None:
+        return rgbs, depths, bgmaps
+    psnrs = []
+    for i in range(n):
+        gt = np.asarray(gt_imgs[i])
+        if render_factor != 0:
+            raise ValueError("ground-truth comparison needs render_factor == 0 (run_render.py:74 compares full frames)")
+        psnrs.append(-10.0 * np.log10(np.mean(np.square(rgbs[i] - gt))))          # run_render.py:75
+    return rgbs, depths, bgmaps, psnrs
