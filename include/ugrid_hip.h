@@ -123,6 +123,14 @@ int ugrid_total_variation_add_grad(const float *param, float *grad, float wx, fl
 int ugrid_cumdist_thres(const float *dist, float thres, int64_t n_rays, int64_t n_pts,
                         uint8_t *mask, ugrid_stream_t stream);
 
+/* segment_cumsum(w, s, ray_id) -> (w_prefix, w_total, ws_prefix, ws_total): the op the reference's DistortionLoss
+ * calls (FourierGrid_model.py:689; also dcvgo.py:392) but its ub360_utils.cpp:21 never exports.  Exclusive fp32
+ * running sums of w and w*s inside each segment of the sorted ray_id [n], in sample order, and per-ray totals
+ * [n_rays] (0 for rays without samples).  seg_scratch: 2*n_rays int64 of device scratch. */
+int ugrid_segment_cumsum(const float *w, const float *s, const int64_t *ray_id, int64_t n, int64_t n_rays,
+                         float *w_prefix, float *w_total, float *ws_prefix, float *ws_total,
+                         int64_t *seg_scratch, ugrid_stream_t stream);
+
 /* ------------------------------------------------------------------ adam_upd_cuda */
 
 /* replaces adam_upd / masked_adam_upd / adam_upd_with_perlr (adam_upd.cpp:79-86 ->

@@ -288,6 +288,30 @@ ORC_API void orc_total_variation_add_grad(const float *param, float *grad, float
   }
 }
 
+/* segment_cumsum: the op FourierGrid_model.py:684-708 (DistortionLoss) and dcvgo.py:392 call as
+ * ub360_utils_cuda.segment_cumsum(w, s, ray_id) -> (w_prefix, w_total, ws_prefix, ws_total) but which the reference's
+ * ub360_utils.cpp:21 never exports (dead code there).  Semantics fixed by its use in DistortionLoss.backward
+ * (w_suffix = w_total[ray] - (w_prefix + w)): EXCLUSIVE running sums of w and of w*s inside each ray segment of the
+ * sorted ray_id, and the per-ray totals; fp32, accumulated in sample order.  Rays without samples keep total 0. */
+ORC_API void orc_segment_cumsum(const float *w, const float *s, const int64_t *ray_id, int64_t n, int64_t n_rays,
+                                float *w_prefix, float *w_total, float *ws_prefix, float *ws_total) {
+  for (int64_t r = 0; r < n_rays; ++r) { w_total[r] = 0.f; ws_total[r] = 0.f; }
+  int64_t i = 0;
+  while (i < n) {
+    const int64_t r = ray_id[i];
+    float cw = 0.f, cws = 0.f;
+    while (i < n && ray_id[i] == r) {
+      w_prefix[i] = cw;
+      ws_prefix[i] = cws;
+      cw = cw + w[i];
+      cws = cws + w[i] * s[i];
+      ++i;
+    }
+    w_total[r] = cw;
+    ws_total[r] = cws;
+  }
+}
+
 /* ub360_utils_kernel.cu:13-33  cumdist_thres */
 ORC_API void orc_cumdist_thres(const float *dist, float thres, int64_t n_rays, int64_t n_pts, uint8_t *mask) {
   for (int64_t r = 0; r < n_rays; ++r) {

@@ -213,6 +213,21 @@ def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
 
 
 # ------------------------------------------------------------------ ub360_utils_cuda
+def segment_cumsum(w, s, ray_id, n_rays=None):
+    """(w_prefix, w_total, ws_prefix, ws_total): see orc_segment_cumsum (the reference calls this op but does not
+    ship it; FourierGrid_model.py:684-708)."""
+    _chk32(w, s)
+    assert ray_id.dtype == torch.int64 and w.shape == s.shape == ray_id.shape and w.dim() == 1
+    n = w.shape[0]
+    if n_rays is None:
+        n_rays = int(ray_id.max()) + 1 if n > 0 else 0
+    w_prefix, ws_prefix = torch.empty_like(w), torch.empty_like(w)
+    w_total, ws_total = torch.zeros(n_rays, dtype=torch.float32), torch.zeros(n_rays, dtype=torch.float32)
+    lib().orc_segment_cumsum(_p(w), _p(s), _p(ray_id), _i64(n), _i64(n_rays), _p(w_prefix), _p(w_total),
+                             _p(ws_prefix), _p(ws_total))
+    return w_prefix, w_total, ws_prefix, ws_total
+
+
 def cumdist_thres(dist, thres):
     _chk32(dist)
     mask = torch.zeros(dist.shape[0], dist.shape[1], dtype=torch.bool)
@@ -258,5 +273,5 @@ render_utils_cuda = _mod("render_utils_cuda", [
     sample_bg_pts_on_rays, maskcache_lookup, raw2alpha, raw2alpha_nonuni, raw2alpha_backward,
     raw2alpha_nonuni_backward, alpha2weight, alpha2weight_backward])
 total_variation_cuda = _mod("total_variation_cuda", [total_variation_add_grad])
-ub360_utils_cuda = _mod("ub360_utils_cuda", [cumdist_thres])
+ub360_utils_cuda = _mod("ub360_utils_cuda", [cumdist_thres, segment_cumsum])
 adam_upd_cuda = _mod("adam_upd_cuda", [adam_upd, masked_adam_upd, adam_upd_with_perlr])

@@ -142,6 +142,22 @@ def gen_autograd_and_adam():
     print("autograd_adam", {k: v.shape for k, v in res.items()})
 
 
+def gen_distortion():
+    """The reference's own DistortionLoss class (FourierGrid_model.py:684-708) on CPU; its segment_cumsum call is
+    served by the oracle op (the reference extension never exported one)."""
+    fgm = install_stubs.import_reference("FourierGrid_model")
+    w, s, ray_id, n_max = synth.distortion_inputs()
+    wt = torch.from_numpy(w).requires_grad_(True)
+    loss = fgm.distortion_loss(wt, torch.from_numpy(s), n_max, torch.from_numpy(ray_id))
+    loss.backward()
+    from oracle import ref_ops
+    pre = ref_ops.segment_cumsum(torch.from_numpy(w), torch.from_numpy(s), torch.from_numpy(ray_id))
+    res = dict(loss=loss.detach().numpy(), grad=wt.grad.numpy(), w_prefix=pre[0].numpy(), w_total=pre[1].numpy(),
+               ws_prefix=pre[2].numpy(), ws_total=pre[3].numpy())
+    np.savez_compressed(os.path.join(HERE, "distortion.npz"), **res)
+    print("distortion", float(loss), wt.grad.shape)
+
+
 def gen_rays_view():
     """dvgo.get_rays_of_a_view (dvgo.py:493-521,554-559) for a small view and three flag combinations."""
     dvgo = install_stubs.import_reference("dvgo")
@@ -235,3 +251,4 @@ if __name__ == "__main__":
     gen_rays_view()
     gen_dvgo()
     gen_checkpoint()
+    gen_distortion()

@@ -89,3 +89,13 @@ def dvgo_params(seed, world_size, C, rgbnet_direct, viewbase_pe=4, width=128, de
             p[name + '.weight'] = uniform(seed + 10 + li, dims[li + 1] * dims[li], -b, b).reshape(dims[li + 1], dims[li])
             p[name + '.bias'] = uniform(seed + 20 + li, dims[li + 1], -b, b)
     return p
+
+
+def distortion_inputs():
+    """Flattened survivor list of 9 rays (two of them empty): weights, s ascending inside each ray, sorted ray ids."""
+    counts = [5, 0, 17, 1, 64, 0, 70, 3, 130]
+    ray_id = np.concatenate([np.full(c, r, dtype=np.int64) for r, c in enumerate(counts)])
+    n = ray_id.shape[0]
+    w = uniform(301, n, 0.0, 0.08).astype(np.float32)
+    s = np.concatenate([np.sort(uniform(310 + r, c, 0.0, 1.0)) for r, c in enumerate(counts) if c > 0]).astype(np.float32)
+    return w, s, ray_id, 256

@@ -354,3 +354,33 @@ def test_sharded_masked_adam_degenerates_to_masked_adam_on_one_gpu():
         oa.step(); ob.step()
     assert torch.equal(a.data, b.data)
     assert torch.equal(oa.state[a]['exp_avg_sq'], ob.state[b]['exp_avg_sq'])
+
+
+def test_segment_cumsum_and_distortion_loss(mods, golden_dir):
+    """segment_cumsum (HIP, wave per ray, serial fp32 chains) is bit-exact against the oracle op; DistortionLoss on
+    top of it reproduces the loss and gradient of the reference's own class (tests/golden/distortion.npz)."""
+    from unboundednerfpytorch_amd import ub360_utils_cuda as ub
+    from unboundednerfpytorch_amd.ops import DistortionLoss, distortion_loss
+    gold = np.load(os.path.join(golden_dir, "distortion.npz"))
+    w, s, ray_id, n_max = synth.distortion_inputs()
+    wd, sd, rd = torch.from_numpy(w).cuda(), torch.from_numpy(s).cuda(), torch.from_numpy(ray_id).cuda()
+    got = ub.segment_cumsum(wd, sd, rd)
+    for g, key in zip(got, ("w_prefix", "w_total", "ws_prefix", "ws_total")):
+        assert np.array_equal(g.cpu().numpy(), gold[key]), key
+    # a long random case against the oracle op, incl. empty rays at both ends and an explicit n_rays
+    n_rays = 300
+    counts = np.floor(synth.uniform(41, n_rays, 0.0, 150.0)).astype(np.int64)
+    counts[[0, 7, n_rays - 1]] = 0
+    rid = np.concatenate([np.full(c, r, dtype=np.int64) for r, c in enumerate(counts)])
+    ww = synth.uniform(42, rid.shape[0], 0.0, 1.0)
+    ss = synth.uniform(43, rid.shape[0], 0.0, 1.0)
+    ref = ref_ops.segment_cumsum(torch.from_numpy(ww), torch.from_numpy(ss), torch.from_numpy(rid), n_rays)
+    dev = ub.segment_cumsum(torch.from_numpy(ww).cuda(), torch.from_numpy(ss).cuda(), torch.from_numpy(rid).cuda(), n_rays)
+    for a, b in zip(ref, dev):
+        assert torch.equal(a, b.cpu())
+    wt = wd.clone().requires_grad_(True)
+    loss = distortion_loss(wt, sd, n_max, rd)
+    loss.backward()
+    np.testing.assert_allclose(float(loss), float(gold["loss"]), rtol=2e-6)
+    np.testing.assert_allclose(wt.grad.cpu().numpy(), gold["grad"], rtol=2e-6, atol=1e-7)
+    assert DistortionLoss.apply is not None

@@ -119,3 +119,41 @@ def test_oracle_ops_invariants():
     # cumdist: running sum resets only when it exceeds the threshold
     mask = ref_ops.cumdist_thres(torch.tensor([[0.4, 0.4, 0.4, 0.4, 0.4]]), 1.0)
     assert mask.tolist() == [[False, False, True, False, False]]
+
+
+def test_distortion_loss_pinned_on_the_reference_class(golden_dir):
+    """DistortionLoss (FourierGrid_model.py:684-708): tests/golden/distortion.npz was produced by the reference's own
+    class (its segment_cumsum call served by the oracle op, which the reference extension never shipped).  Here the
+    oracle op is checked against an independent fp64 evaluation and the golden loss / gradient against the
+    definition  (1/R) [ sum_{i != j in a ray} w_i w_j |s_i - s_j| + (1/(3 n_max)) sum w_i^2 ]  differentiated by
+    torch autograd in fp64."""
+    gold = np.load(os.path.join(golden_dir, "distortion.npz"))
+    w, s, ray_id, n_max = synth.distortion_inputs()
+    pre = ref_ops.segment_cumsum(torch.from_numpy(w), torch.from_numpy(s), torch.from_numpy(ray_id))
+    for got, key in zip(pre, ("w_prefix", "w_total", "ws_prefix", "ws_total")):
+        assert np.array_equal(got.numpy(), gold[key]), key
+    R = int(ray_id.max()) + 1
+    w64, s64 = w.astype(np.float64), s.astype(np.float64)
+    for r in range(R):
+        m = ray_id == r
+        cw = np.concatenate([[0.0], np.cumsum(w64[m])])
+        cws = np.concatenate([[0.0], np.cumsum(w64[m] * s64[m])])
+        np.testing.assert_allclose(gold["w_prefix"][m], cw[:-1], rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(gold["ws_prefix"][m], cws[:-1], rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(gold["w_total"][r], cw[-1], rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(gold["ws_total"][r], cws[-1], rtol=2e-6, atol=1e-7)
+    wt = torch.from_numpy(w64).requires_grad_(True)
+    st = torch.from_numpy(s64)
+    total = 0.0
+    for r in range(R):
+        m = torch.from_numpy(ray_id == r)
+        if int(m.sum()) == 0:
+            continue
+        wr, sr = wt[m], st[m]
+        total = total + (wr[:, None] * wr[None, :] * (sr[:, None] - sr[None, :]).abs()).sum() + (wr ** 2).sum() / (3 * n_max)
+    loss = total / R
+    loss.backward()
+    np.testing.assert_allclose(float(gold["loss"]), float(loss), rtol=5e-6)
+    # reference quirk, kept: the forward divides by n_rays but DistortionLoss.backward (FourierGrid_model.py:699-708)
+    # does not, so the class returns n_rays x the true gradient of the loss it reports
+    np.testing.assert_allclose(gold["grad"], R * wt.grad.numpy(), rtol=2e-5, atol=2e-6)

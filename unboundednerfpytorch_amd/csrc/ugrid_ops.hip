@@ -482,6 +482,37 @@ k_cumdist(const float *__restrict__ dist, float thres, int64_t n_rays, int64_t n
 }
 
 // ----------------------------------------------------------------------------------------------
+// segment_cumsum (called by the reference's DistortionLoss, FourierGrid_model.py:684-708, never shipped by its
+// ub360_utils.cpp): exclusive running sums of w and w*s inside each ray segment + per-ray totals.  One wave per
+// ray, 64 samples per coalesced load, the two fp32 chains run in sample order on wave-uniform values.
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_segment_cumsum(const float *__restrict__ w, const float *__restrict__ s, int64_t n_rays,
+                 const int64_t *__restrict__ i_start, const int64_t *__restrict__ i_end,
+                 float *__restrict__ w_prefix, float *__restrict__ w_total, float *__restrict__ ws_prefix,
+                 float *__restrict__ ws_total) {
+  const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= n_rays) return;
+  const int lane = ug_lane();
+  const int64_t i_s = i_start[r], i_e = i_end[r];
+  float cw = 0.f, cws = 0.f;
+  for (int64_t base = i_s; base < i_e; base += UG_WAVE) {
+    const int64_t i = base + lane;
+    const float wi = (i < i_e) ? w[i] : 0.f;
+    const float wsi = (i < i_e) ? wi * s[i] : 0.f;
+    const int cnt = (int)((i_e - base) < UG_WAVE ? (i_e - base) : UG_WAVE);
+    float my_w = 0.f, my_ws = 0.f;
+    for (int k = 0; k < cnt; ++k) {
+      if (lane == k) { my_w = cw; my_ws = cws; }
+      cw = cw + ug_readlane_f(wi, k);
+      cws = cws + ug_readlane_f(wsi, k);
+    }
+    if (i < i_e) { w_prefix[i] = my_w; ws_prefix[i] = my_ws; }
+  }
+  if (lane == 0) { w_total[r] = cw; ws_total[r] = cws; }
+}
+
+// ----------------------------------------------------------------------------------------------
 // Adam family.  MODE 0 dense, 1 masked (skip grad==0), 2 per-voxel lr.  4 voxels per lane with
 // 16-byte loads; in masked mode a lane touches m/v/param only when one of its 4 grads is non-zero,
 // so an almost-empty gradient costs ~4 B/voxel of HBM reads.
@@ -728,6 +759,20 @@ extern "C" int ugrid_cumdist_thres(const float *dist, float thres, int64_t n_ray
   if (n_rays <= 0 || n_pts <= 0) return 0;
   hipLaunchKernelGGL(k_cumdist, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), dist, thres,
                      n_rays, n_pts, mask);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ugrid_segment_cumsum(const float *w, const float *s_, const int64_t *ray_id, int64_t n, int64_t n_rays,
+                                    float *w_prefix, float *w_total, float *ws_prefix, float *ws_total,
+                                    int64_t *seg_scratch, ugrid_stream_t s) {
+  if (n_rays <= 0) return 0;
+  int64_t *i_start = seg_scratch, *i_end = seg_scratch + n_rays;   // zero = "ray without samples"
+  UG_HIP(hipMemsetAsync(seg_scratch, 0, sizeof(int64_t) * 2 * n_rays, ST(s)));
+  if (n > 0)
+    hipLaunchKernelGGL(k_segments, dim3(ug_blocks(n, 256)), dim3(256), 0, ST(s), ray_id, n, i_start, i_end);
+  hipLaunchKernelGGL(k_segment_cumsum, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), w, s_, n_rays,
+                     i_start, i_end, w_prefix, w_total, ws_prefix, ws_total);
   UG_LAUNCH_CHECK();
   return 0;
 }

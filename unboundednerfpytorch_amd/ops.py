@@ -1,9 +1,11 @@
 """Autograd boundary of the hot path, same class names / argument order / return arity as the
 reference (/root/reference/FourierGrid/dvgo.py:430-488): Raw2Alpha, Raw2Alpha_nonuni, Alphas2Weights.
-All three are once_differentiable and save tensors only when the input requires grad."""
+All three are once_differentiable and save tensors only when the input requires grad.
+DistortionLoss mirrors FourierGrid_model.py:684-708 (the mip-NeRF-360 distortion regulariser over the flattened
+survivor list; run_train.py:270-275 obtains the same quantity from the third-party flatten_eff_distloss)."""
 import torch
 
-from . import render_utils_cuda
+from . import render_utils_cuda, ub360_utils_cuda
 
 
 class Raw2Alpha(torch.autograd.Function):
@@ -61,3 +63,35 @@ class Alphas2Weights(torch.autograd.Function):
             alpha, weights, T, alphainv_last, i_start, i_end, ctx.n_rays,
             grad_weights.contiguous(), grad_last.contiguous())
         return grad, None, None
+
+
+class DistortionLoss(torch.autograd.Function):
+    """loss = (1/n_rays) * sum over samples of [ 2 w_i (s_i W_<i - WS_<i)  +  w_i^2 / (3 n_max) ], with W_<i / WS_<i
+    the exclusive per-ray running sums of w and w*s (HIP segment_cumsum).  For s ascending inside a ray this is
+    sum_{i != j} w_i w_j |s_i - s_j| plus the intra-interval term of width 1/n_max.  Gradient w.r.t. w only.
+    Reference quirk kept: the forward divides by n_rays, the backward does not (FourierGrid_model.py:699-708)."""
+
+    @staticmethod
+    def forward(ctx, w, s, n_max, ray_id):
+        n_rays = ray_id.max() + 1
+        width = 1 / n_max
+        w_pre, w_tot, ws_pre, ws_tot = ub360_utils_cuda.segment_cumsum(w, s, ray_id, int(n_rays))
+        pair = 2 * w * (s * w_pre - ws_pre)
+        self_term = (1 / 3) * width * w.pow(2)      # same operation order as the reference's loss_uni
+        ctx.save_for_backward(w, s, w_pre, w_tot, ws_pre, ws_tot, ray_id)
+        ctx.width = width
+        return (pair.sum() + self_term.sum()) / n_rays
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_back):
+        w, s, w_pre, w_tot, ws_pre, ws_tot, ray_id = ctx.saved_tensors
+        # sums over the samples AFTER i in the same ray: total - (prefix + own)
+        w_after = w_tot[ray_id] - (w_pre + w)
+        ws_after = ws_tot[ray_id] - (ws_pre + w * s)
+        d_pair = 2 * (s * (w_pre - w_after) + (ws_after - ws_pre))
+        d_self = (1 / 3) * ctx.width * 2 * w
+        return grad_back * (d_pair + d_self), None, None, None
+
+
+distortion_loss = DistortionLoss.apply
