@@ -9,7 +9,7 @@ O=../../build/obj
 hipcc $FLAGS -c ugrid_ops.hip -o $O/ugrid_ops.o "$@" &
 # packed fp32 VALU (v_pk_*_f32 from the SLP vectoriser) issues at half rate on gfx950 and needs extra moves to form
 # register pairs: the VALU-bound march kernel is 16 % faster without it, the shade kernel 1.3 %
-hipcc $FLAGS -fno-slp-vectorize -c ugrid_march.hip -o $O/ugrid_march.o "$@" &
+hipcc $FLAGS -fno-slp-vectorize ${UG_MARCH_FLAGS} -c ugrid_march.hip -o $O/ugrid_march.o "$@" &
 hipcc $FLAGS -fno-slp-vectorize ${UG_SHADE_FLAGS} -c ugrid_shade.hip -o $O/ugrid_shade.o "$@" &
 wait
 hipcc --offload-arch=gfx950 -shared -fPIC -o ${UG_OUT:-../libugrid_hip.so} $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o
