@@ -287,7 +287,10 @@ def parity_stats(err, margin, sq_rgb):
     arithmetic; PSNR is over all sampled rays, flips included."""
     import math
     n = err.numel()
-    out = {"rays": n, "linf_all": float(err.max()), "mean_abs": float(err.mean()),
+    out = {"note": "tail rays are fp32 conditioning of the reference formula on this white-noise scene: an fp64 "
+                   "re-evaluation puts the GPU closer to exact than the fp32 oracle (DESIGN.md 2.1, "
+                   "profiles/r01/parity_scan_s1.txt)",
+           "rays": n, "linf_all": float(err.max()), "mean_abs": float(err.mean()),
            "frac_rays_above_1e-5": float((err > 1e-5).float().mean()),
            "psnr_rgb_db": 10.0 * math.log10(1.0 / max(sq_rgb / (3 * n), 1e-30))}
     for m in (1e-4, 1e-3, 1e-2):
