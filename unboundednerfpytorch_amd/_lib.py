@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede the CDLL below, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("UGRID_LIB") or os.path.join(_HERE, "libugrid_hip.so")  # UGRID_LIB: A/B builds only
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c = ctypes
 _P = _c.c_void_p

@@ -10,7 +10,7 @@
 // file:line citations are in include/ugrid_hip.h.
 #include "ugrid_common.h"
 
-extern "C" int ugrid_abi_version(void) { return 1; }
+extern "C" int ugrid_abi_version(void) { return 2; }  // 2: ugrid_render_params.mlp_mode, ugrid_pack_mlp(k0_absmax, best_mode)
 extern "C" const char *ugrid_target_arch(void) { return "gfx950"; }
 
 // ----------------------------------------------------------------------------------------------
