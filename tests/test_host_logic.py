@@ -159,3 +159,67 @@ def test_sharded_masked_adam_single_process_equals_plain_loop():
         ref_ops.masked_adam_upd(r, grads[step][0]["dens"], m, v, step + 1, 0.9, 0.99, 0.1, 1e-8)
     assert torch.equal(p.data, r)
     assert ShardedMaskedAdam.shard_len(1050, 2) == 528 and ShardedMaskedAdam.shard_len(6048, 8) == 756
+
+
+# ---------------------------------------------------------------------------------------------------------
+# interleaved tile dealing and block compositing (dist.py), 2 ranks over gloo
+# ---------------------------------------------------------------------------------------------------------
+def _block_forward(block):
+    def fwd(o, d, v, **kw):
+        rgb = torch.sigmoid(torch.stack([o[:, 0] + block, d[:, 1] * (block + 1), v[:, 2]], dim=1))
+        last = torch.sigmoid(o.sum(-1) * (3.0 if block == 0 else 0.5) + (4.0 if block == 1 else -1.0))
+        return {"rgb_marched": rgb, "depth": d.abs().sum(-1) + block, "alphainv_last": last}
+    return fwd
+
+
+def _dist2_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from unboundednerfpytorch_amd.dist import composite_blocks, render_sharded, tile_assignment
+    ok = True
+    for R in (1000, 64, 7, 200, 129):
+        g = torch.Generator().manual_seed(R)
+        o, d, v = [torch.randn(R, 3, generator=g) for _ in range(3)]
+        out = render_sharded(_fake_forward, o, d, v, interleave=True, stepsize=0.5)
+        ref = _fake_forward(o, d, v)
+        ok = ok and all(torch.equal(out[k], ref[k]) for k in ref)
+        mine = tile_assignment(R, world, rank)
+        other = tile_assignment(R, world, 1 - rank)
+        ok = ok and sorted(torch.cat([mine, other]).tolist()) == list(range(R))
+    # blocks: rank b holds block b; block 1 is (nearly) transparent for this view -> dropped by the opacity rule
+    g = torch.Generator().manual_seed(5)
+    R = 300
+    o, d, v = [torch.randn(R, 3, generator=g) for _ in range(3)]
+    cam = torch.tensor([0.5, -0.2, 0.1])
+    cents = [torch.tensor([1.0, 0.0, 0.0]), torch.tensor([-2.0, 1.0, 0.5])]
+    for min_op in (0.05, 0.0):
+        got = composite_blocks(_block_forward(rank), o, d, v, cam, cents[rank], p=4.0, min_opacity=min_op)
+        outs = [_block_forward(b)(o, d, v) for b in range(2)]
+        ws_ = []
+        for b in range(2):
+            op = float((1 - outs[b]["alphainv_last"]).mean())
+            ws_.append(float((cam.double() - cents[b].double()).norm() ** -4.0) if op > min_op else 0.0)
+        tot = sum(ws_)
+        for k in ("rgb_marched", "depth", "alphainv_last"):
+            want = sum(outs[b][k] * ws_[b] for b in range(2)) / tot
+            ok = ok and torch.allclose(got[k], want, rtol=1e-5, atol=1e-6)
+        ok = ok and abs(got["block_weight"] - ws_[rank]) <= 1e-12 * max(1.0, ws_[rank])
+        if min_op == 0.05:
+            ok = ok and ws_[1] == 0.0 and ws_[0] > 0.0      # the case really exercises the visibility rule
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+def test_interleaved_sharding_and_block_compositing_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dist2_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]

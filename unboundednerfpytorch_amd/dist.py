@@ -4,6 +4,13 @@ Rays are independent and the grids + rgbnet are read-only at render time (SURVEY
 data path is: every rank holds a full replica of the bricks, renders its contiguous ray shard with the
 fused kernels, and ONE all-gather exchanges the rendered tiles [rgb(3), depth, alphainv_last] = 20 B/ray.
 There is no collective inside the march/shade kernels.
+
+`render_sharded(..., interleave=True)` deals 64-ray tiles round-robin instead of in contiguous ranges: on real
+scenes sky and dense regions cluster in the image, and the fused kernels' time per tile follows the survivor
+count, so contiguous row bands can be badly unbalanced.
+
+`composite_blocks` is the one-model-per-GPU layout of BASELINE.json configs[4] (Waymo-style blocks): every rank
+renders ITS block for ALL rays and one all-reduce(sum) of [R,6] merges them.
 """
 import torch
 import torch.distributed as dist
@@ -19,28 +26,88 @@ def shard_bounds(n, world_size, rank, align=64):
     return b, e
 
 
-def render_sharded(renderer_forward, rays_o, rays_d, viewdirs, group=None, **render_kwargs):
+def tile_assignment(n, world_size, rank, tile=64):
+    """Indices of the rays of `rank` when 64-ray tiles are dealt round-robin (tile k -> rank k % world_size)."""
+    n_tiles = -(-n // tile)
+    mine = torch.arange(rank, n_tiles, world_size)
+    idx = (mine[:, None] * tile + torch.arange(tile)[None, :]).reshape(-1)
+    return idx[idx < n]
+
+
+def render_sharded(renderer_forward, rays_o, rays_d, viewdirs, group=None, interleave=False, **render_kwargs):
     """Render rays [R,3] split across the process group; every rank returns the full
     {'rgb_marched','depth','alphainv_last'}.  `renderer_forward(o,d,v,**kw)` is FourierGridRenderer.forward
     (or any callable with the reference forward's signature and return keys)."""
     ws = dist.get_world_size(group) if dist.is_initialized() else 1
     rk = dist.get_rank(group) if dist.is_initialized() else 0
     R = rays_o.shape[0]
-    b, e = shard_bounds(R, ws, rk)
     kw = dict(render_kwargs)
     kw["render_depth"] = True
-    out = renderer_forward(rays_o[b:e].contiguous(), rays_d[b:e].contiguous(), viewdirs[b:e].contiguous(), **kw)
-    per = shard_bounds(R, ws, 0)[1]
+    if interleave and ws > 1:
+        idx = tile_assignment(R, ws, rk).to(rays_o.device)
+        n_mine = idx.numel()
+        per = tile_assignment(R, ws, 0).numel()      # rank 0 always holds the largest share
+        o_, d_, v_ = rays_o[idx].contiguous(), rays_d[idx].contiguous(), viewdirs[idx].contiguous()
+    else:
+        b, e = shard_bounds(R, ws, rk)
+        n_mine = e - b
+        per = shard_bounds(R, ws, 0)[1]
+        o_, d_, v_ = rays_o[b:e].contiguous(), rays_d[b:e].contiguous(), viewdirs[b:e].contiguous()
     tile = torch.zeros(per, 5, dtype=torch.float32, device=rays_o.device)
-    if e > b:
-        tile[: e - b, 0:3] = out["rgb_marched"]
-        tile[: e - b, 3] = out["depth"]
-        tile[: e - b, 4] = out["alphainv_last"]
+    if n_mine > 0:
+        out = renderer_forward(o_, d_, v_, **kw)
+        tile[:n_mine, 0:3] = out["rgb_marched"]
+        tile[:n_mine, 3] = out["depth"]
+        tile[:n_mine, 4] = out["alphainv_last"]
     if ws > 1:
         full = torch.empty(ws * per, 5, dtype=torch.float32, device=rays_o.device)
         dist.all_gather_into_tensor(full, tile, group=group)
+        if interleave:
+            # undo the deal: rank r's rows are its tiles r, r+ws, ... in order
+            res = torch.empty(R, 5, dtype=torch.float32, device=rays_o.device)
+            for r in range(ws):
+                ir = tile_assignment(R, ws, r).to(rays_o.device)
+                res[ir] = full[r * per: r * per + ir.numel()]
+            full = res
     else:
         full = tile
     full = full[:R]
     return {"rgb_marched": full[:, 0:3].contiguous(), "depth": full[:, 3].contiguous(),
             "alphainv_last": full[:, 4].contiguous()}
+
+
+def composite_blocks(renderer_forward, rays_o, rays_d, viewdirs, cam_origin, block_centroid, p=4.0, min_opacity=0.05,
+                     group=None, **render_kwargs):
+    """One block model per rank, the same rays on every rank, one all-reduce(sum).
+
+    The reference's FourierGrid path never composites blocks (it renders each block's own image subset,
+    run_render.py:146-207); the only merging rule in the repository is the legacy Block-NeRF evaluation
+    (eval_block_nerf.py:95-133,215-225): keep a block if its mean visibility exceeds 0.05, weight it by the inverse
+    camera-to-centroid distance to the power p (IDW_Power = 4), normalise the weights, blend the images.  This
+    function applies that rule to the fused renderer's float outputs: visibility of a block := its mean
+    accumulated opacity 1 - alphainv_last over the rays (the FourierGrid model has no visibility network), weight
+    w_b = |cam_origin - block_centroid|^-p if visible else 0, result = sum_b w_b * [rgb, depth, alphainv_last] /
+    sum_b w_b (rays no visible block covers get the unweighted mean).  Traffic: [R,6] fp32 per rank."""
+    ws = dist.get_world_size(group) if dist.is_initialized() else 1
+    kw = dict(render_kwargs)
+    kw["render_depth"] = True
+    out = renderer_forward(rays_o, rays_d, viewdirs, **kw)
+    R = rays_o.shape[0]
+    opacity = float((1.0 - out["alphainv_last"]).mean()) if R > 0 else 0.0
+    dvec = torch.as_tensor(cam_origin, dtype=torch.float64).reshape(3) - torch.as_tensor(block_centroid, dtype=torch.float64).reshape(3)
+    w = float(dvec.norm() ** (-float(p))) if opacity > min_opacity else 0.0
+    acc = torch.empty(R, 7, dtype=torch.float32, device=rays_o.device)
+    acc[:, 0:3] = out["rgb_marched"] * w
+    acc[:, 3] = out["depth"] * w
+    acc[:, 4] = out["alphainv_last"] * w
+    acc[:, 5] = w
+    # fallback numerators for views no block claims: plain mean over the blocks
+    plain = torch.cat([out["rgb_marched"], out["depth"][:, None], out["alphainv_last"][:, None]], dim=1)
+    acc[:, 6] = 1.0
+    if ws > 1:
+        dist.all_reduce(acc, group=group)
+        dist.all_reduce(plain, group=group)
+    wsum = acc[:, 5:6]
+    blended = torch.where(wsum > 0, acc[:, 0:5] / wsum.clamp_min(1e-30), plain / acc[:, 6:7])
+    return {"rgb_marched": blended[:, 0:3].contiguous(), "depth": blended[:, 3].contiguous(),
+            "alphainv_last": blended[:, 4].contiguous(), "block_weight": w}

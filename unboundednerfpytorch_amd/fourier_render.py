@@ -300,16 +300,18 @@ class FourierGridRenderer:
     # -- constructors ------------------------------------------------------------------------------
     # -- frame-level entry point --------------------------------------------
     @torch.no_grad()
-    def render_view(self, H, W, K, c2w, stepsize, inverse_y=False, flip_x=False, flip_y=False, group=None):
+    def render_view(self, H, W, K, c2w, stepsize, inverse_y=False, flip_x=False, flip_y=False, group=None,
+                    interleave=False):
         """One whole view, like the body of the reference's render_viewpoints loop (run_render.py:41-70) but
         without its 8192-ray chunking: rays are generated on the device, rendered in one fused pass and, when a
-        process group is initialised, sharded over its ranks with one all-gather of the [R,5] tiles (dist.py).
+        process group is initialised, sharded over its ranks (contiguous 64-aligned ranges, or 64-ray tiles dealt
+        round-robin with interleave=True) with one all-gather of the [R,5] tiles (dist.py).
         Returns rgb [H,W,3], depth [H,W], bgmap [H,W] (= alphainv_last) on the device."""
         from .dist import render_sharded
         c2w = torch.as_tensor(c2w, dtype=torch.float32).to(self.device)
         ro, rd, vd = get_rays_of_a_view(H, W, K, c2w, inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y)
         ro, rd, vd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous(), vd.reshape(-1, 3).contiguous()
-        out = render_sharded(self.forward, ro, rd, vd, group=group, stepsize=stepsize)
+        out = render_sharded(self.forward, ro, rd, vd, group=group, interleave=interleave, stepsize=stepsize)
         return (out["rgb_marched"].reshape(H, W, 3), out["depth"].reshape(H, W), out["alphainv_last"].reshape(H, W))
 
     @classmethod
