@@ -302,7 +302,6 @@ extern "C" int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1,
 
 // ---- single-launch fused render -----------------------------------------------------------------
 #define UG_FUSED_NW 12  // slots are sized for the largest variant
-static int g_fused_waves = 12;  // (kept for ABI of the knob; the single launch always uses 12 waves)
 #define UG_FUSED_MAX_WGS 256
 
 extern "C" int64_t ugrid_render_fused_ws_bytes(int32_t n_samples) {
@@ -386,13 +385,10 @@ extern "C" int ugrid_render_fused_stats(const void *ws_mem, int64_t *d_stats, ug
   return (int)hipMemcpyAsync(d_stats, (const char *)ws_mem + 64, sizeof(int64_t), hipMemcpyDeviceToDevice, ST(s));
 }
 
-static int g_shade_waves = 8;   // (knob kept for ABI; every shade variant now runs 8 waves = 2 per SIMD per workgroup)
 
 extern "C" int ugrid_tune(const char *key, int value) {
   if (!key) return (int)hipErrorInvalidValue;
-  if (!strcmp(key, "shade_waves") && (value == 8 || value == 12)) { g_shade_waves = value; return 0; }
   if (!strcmp(key, "march_waves")) return ug_set_march_waves(value) ? (int)hipErrorInvalidValue : 0;
-  if (!strcmp(key, "fused_waves") && (value == 8 || value == 12)) { g_fused_waves = value; return 0; }
   if (!strcmp(key, "split_gather") && (value == 0 || value == 1)) { g_shade_split_gather = value; return 0; }
   return (int)hipErrorInvalidValue;
 }

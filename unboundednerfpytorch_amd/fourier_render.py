@@ -7,10 +7,10 @@ render program consumes -- `rgb_marched [R,3]`, `depth [R]`, `alphainv_last [R]`
 (run_render.py:46).  The training-only per-sample keys (`weights`, `raw_rgb`, `ray_id`, ...) are not
 materialised by the fused path; training goes through the drop-in ops (ops.py) instead.
 
-Device data owned by the renderer (all fp32):
-  density bricks  [P*(G-1)^3][8]            32 B per trilinear cell
-  k0 bricks       [P*(G-1)^3][2][8][C/2]    384 B per cell at C = 12
-  packed rgbnet   A1 | A2 | biases | W3     (MFMA A-operand order, 89 KB)
+Device data owned by the renderer:
+  density bricks  [P*(G-1)^3][8]                  32 B per trilinear cell: its 8 trilinear-polynomial coefficients
+  k0 bricks       [P*(G-1)^3][2][C/4][8][2]       384 B per cell at C = 12, same coefficient form per channel
+  packed rgbnet   fp32 | bf16x3 | fp16x2 images   (MFMA A-operand order, 321 KB; one of them is staged in LDS)
   t / s tables    [S]
   work list       worst-case survivor list per 64-ray tile (ugrid_render_ws_bytes)
 """
@@ -26,7 +26,7 @@ _p = _lib.ptr
 
 
 def tune(key, value):
-    """Speed-only tuning knobs of the fused kernels (ugrid_tune): 'shade_waves' in (8, 12)."""
+    """Speed-only tuning knobs of the fused kernels (ugrid_tune): 'march_waves' 4..6, 'split_gather' 0|1."""
     _lib.check(_L.ugrid_tune(key.encode(), int(value)), "ugrid_tune(%s)" % key)
 
 
@@ -58,8 +58,10 @@ class FourierGridRenderer:
             raise RuntimeError("FourierGridRenderer needs a HIP device (no CPU path)")
         self.device = dev
         self.max_ws_bytes = int(max_ws_bytes)
-        # fused=True: single persistent launch (march+shade per wave, 0.9 GB scratch); False (default, measured
-        # faster on MI355X: 18.8 vs 23.5 ms per S1 frame): march kernel -> work list -> shade kernel
+        # fused=True: single persistent launch (march+shade per wave, 0.9 GB scratch), kept for experiments; False
+        # (default, measured faster on MI355X): march kernel -> work list -> shade kernel.
+        # pipeline=N>1: N ray chunks software-pipelined over two streams (measured slower: both kernels are
+        # issue-bound on the same SIMDs), also experimental.
         self.use_fused = bool(fused)
         self.mlp_mode = _lib.MLP_BF16X3   # rgbnet arithmetic; set from ugrid_pack_mlp's answer below
         self.pipeline = int(pipeline)
