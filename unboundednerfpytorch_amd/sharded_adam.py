@@ -25,7 +25,7 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
     adam_upd_cuda)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, group=None, average=True,
-                 min_shard_numel=1 << 16, ops=None):
+                 min_shard_numel=1 << 16, ops=None, local_only=False):
         if not 0.0 <= lr:
             raise ValueError("Invalid learning rate: {}".format(lr))
         if not 0.0 <= eps:
@@ -38,12 +38,13 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         self.group = group
         self.average = bool(average)
         self.min_shard_numel = int(min_shard_numel)
+        self.local_only = bool(local_only)     # MaskedAdam: the reference's single-process optimizer, no collectives
         self.per_lr = None
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
     # -- topology ------------------------------------------------------------------------------------
     def _world(self):
-        if dist.is_available() and dist.is_initialized():
+        if not self.local_only and dist.is_available() and dist.is_initialized():
             return dist.get_world_size(self.group), dist.get_rank(self.group)
         return 1, 0
 
