@@ -158,6 +158,30 @@ def gen_distortion():
     print("distortion", float(loss), wt.grad.shape)
 
 
+def gen_train_step():
+    """One training forward + backward of the reference FourierGridModel itself (forward(..., global_step=1,
+    is_train=True), loss = mse + 0.01 * entropy_last as run_train.py:254-261 forms it): the gradients of every
+    parameter, to pin oracle/model_oracle.fouriergrid_train_forward (the CPU side of tests/test_gpu_train_step.py)."""
+    mod = install_stubs.import_reference("FourierGrid_model")
+    c = synth.TRAIN_CASE
+    params = synth.fouriergrid_params(c["seed"], c["G"], c["F"], c["C"], viewbase_pe=c["pe"], dens_mean=c["dm"], dens_std=c["ds"])
+    model = build_reference_model(mod, c["G"], c["F"], c["C"], c["pe"], c["norm"], c["thres"], params)
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(c["seed"], c["R"])]
+    target = torch.from_numpy(synth.uniform(c["seed"] + 5, c["R"] * 3).reshape(c["R"], 3))
+    out = model(o, d, v, global_step=1, is_train=True, stepsize=c["stepsize"], render_depth=True)
+    loss = torch.nn.functional.mse_loss(out["rgb_marched"], target)
+    pout = out["alphainv_last"].clamp(1e-6, 1 - 1e-6)
+    loss = loss + 0.01 * (-(pout * torch.log(pout) + (1 - pout) * torch.log(1 - pout))).mean()
+    loss.backward()
+    res = {"loss": loss.detach().numpy(), "n_kept": np.int64(out["weights"].numel()),
+           "rgb_marched": out["rgb_marched"].detach().numpy(), "alphainv_last": out["alphainv_last"].detach().numpy()}
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            res["grad." + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(HERE, "train_step.npz"), **res)
+    print("train_step loss %.6f kept %d grads %s" % (float(loss), int(res["n_kept"]), sorted(k for k in res if k.startswith("grad."))))
+
+
 def gen_rays_view():
     """dvgo.get_rays_of_a_view (dvgo.py:493-521,554-559) for a small view and three flag combinations."""
     dvgo = install_stubs.import_reference("dvgo")
@@ -252,3 +276,4 @@ if __name__ == "__main__":
     gen_dvgo()
     gen_checkpoint()
     gen_distortion()
+    gen_train_step()

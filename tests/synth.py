@@ -99,3 +99,7 @@ def distortion_inputs():
     w = uniform(301, n, 0.0, 0.08).astype(np.float32)
     s = np.concatenate([np.sort(uniform(310 + r, c, 0.0, 1.0)) for r, c in enumerate(counts) if c > 0]).astype(np.float32)
     return w, s, ray_id, 256
+
+
+# the training-step golden (tests/golden/train_step.npz): model and batch
+TRAIN_CASE = dict(seed=21, G=12, F=3, C=12, pe=4, norm="inf", thres=1e-4, dm=4.0, ds=10.0, R=96, stepsize=0.5)

@@ -157,3 +157,40 @@ def test_distortion_loss_pinned_on_the_reference_class(golden_dir):
     # reference quirk, kept: the forward divides by n_rays but DistortionLoss.backward (FourierGrid_model.py:699-708)
     # does not, so the class returns n_rays x the true gradient of the loss it reports
     np.testing.assert_allclose(gold["grad"], R * wt.grad.numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_train_forward_backward_pinned_on_the_reference_model(golden_dir):
+    """tests/golden/train_step.npz holds loss, outputs and the gradient of EVERY parameter from one training forward
+    + backward of the reference's own FourierGridModel (forward(global_step=1, is_train=True), run_train.py loss).
+    The oracle's restatement of that training forward -- the CPU side of tests/test_gpu_train_step.py -- must
+    reproduce them (same torch ops, same oracle extension ops: bit-exact in the generating container, 2e-6
+    relative elsewhere)."""
+    c = synth.TRAIN_CASE
+    gold = np.load(os.path.join(golden_dir, "train_step.npz"))
+    torch.set_num_threads(1)
+    cfg = make_state(c["seed"], c["G"], c["F"], c["C"], c["pe"], c["norm"], c["thres"], c["dm"], c["ds"])
+    params = {'density_grid': cfg['density_grid'].clone(), 'k0_grid': cfg['k0_grid'].clone(),
+              'w0': cfg['rgbnet_weights'][0].clone(), 'b0': cfg['rgbnet_biases'][0].clone(),
+              'w1': cfg['rgbnet_weights'][1].clone(), 'b1': cfg['rgbnet_biases'][1].clone(),
+              'w2': cfg['rgbnet_weights'][2].clone(), 'b2': cfg['rgbnet_biases'][2].clone()}
+    params = {k: v.requires_grad_(True) for k, v in params.items()}
+    Raw2Alpha, Alphas2Weights = model_oracle.make_autograd_ops(ref_ops)
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(c["seed"], c["R"])]
+    target = torch.from_numpy(synth.uniform(c["seed"] + 5, c["R"] * 3).reshape(c["R"], 3))
+    out = model_oracle.fouriergrid_train_forward(params, cfg, o, d, v, c["stepsize"], Raw2Alpha, Alphas2Weights)
+    loss = torch.nn.functional.mse_loss(out['rgb_marched'], target)
+    pout = out['alphainv_last'].clamp(1e-6, 1 - 1e-6)
+    loss = loss + 0.01 * (-(pout * torch.log(pout) + (1 - pout) * torch.log(1 - pout))).mean()
+    loss.backward()
+    assert out['n_kept'] == int(gold['n_kept'])
+    np.testing.assert_allclose(float(loss), float(gold['loss']), rtol=2e-6)
+    np.testing.assert_allclose(out['rgb_marched'].detach().numpy(), gold['rgb_marched'], rtol=2e-6, atol=1e-7)
+    names = {'density_grid': 'density.grid', 'k0_grid': 'k0.grid', 'w0': 'rgbnet.0.weight', 'b0': 'rgbnet.0.bias',
+             'w1': 'rgbnet.2.0.weight', 'b1': 'rgbnet.2.0.bias', 'w2': 'rgbnet.3.weight', 'b2': 'rgbnet.3.bias'}
+    for k, ref_name in names.items():
+        g = gold['grad.' + ref_name]
+        got = params[k].grad.numpy()
+        assert got.shape == g.shape, k
+        scale = np.abs(g).max()
+        assert np.abs(got - g).max() <= 2e-6 * scale + 1e-12, (k, float(np.abs(got - g).max()), float(scale))
+        assert np.array_equal(got == 0, g == 0), k      # the touched-voxel mask MaskedAdam keys on
