@@ -238,6 +238,34 @@ def gen_dvgo():
         print(name, "world", ws, "M=%d" % out["weights"].numel(), "rgb mean %.3f" % float(out["rgb_marched"].mean()))
 
 
+def gen_dcvgo():
+    """dcvgo.DirectContractedVoxGO.forward (contracted unbounded DVGOv2: cumdist_thres, mask cache, dense grids);
+    num_voxels != num_voxels_base so that voxel_size_ratio != 1, a non-trivial mask, a scene cube off the origin."""
+    dcvgo = install_stubs.import_reference("dcvgo")
+    for name, seed, G, Gb, C, norm, R, dm, ds in synth.DCVGO_CASES:
+        model = dcvgo.DirectContractedVoxGO(xyz_min=synth.DCVGO_BOX[0], xyz_max=synth.DCVGO_BOX[1], num_voxels=G ** 3,
+                                            num_voxels_base=Gb ** 3, alpha_init=1e-2, fast_color_thres=1e-4,
+                                            contracted_norm=norm, rgbnet_dim=C)
+        ws = [int(x) for x in model.world_size]
+        sd = model.state_dict()
+        params = synth.dvgo_params(seed, ws, C, True, dens_mean=dm, dens_std=ds)
+        with torch.no_grad():
+            for k, v in params.items():
+                assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
+                sd[k].copy_(torch.from_numpy(v))
+        o, d, v = [torch.from_numpy(a) for a in synth.rays(seed, R, origin_scale=0.5)]
+        o = o + torch.tensor(synth.DCVGO_BOX[0]) * 0.5 + torch.tensor(synth.DCVGO_BOX[1]) * 0.5
+        with torch.no_grad():
+            out = model(o, d, v, stepsize=0.5, bg=1, render_depth=True)
+        keep = {k: out[k].numpy() for k in ("alphainv_last", "weights", "wsum_mid", "rgb_marched", "raw_density", "raw_alpha",
+                                            "raw_rgb", "ray_id", "step_id", "t", "s", "depth")}
+        keep["n_max"] = np.int64(out["n_max"])
+        keep["world_size"] = np.array(ws)
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **keep)
+        print(name, "world", ws, "M=%d of %d" % (out["weights"].numel(), R * out["n_max"]),
+              "terminated %d/%d" % (int((out["alphainv_last"] < 1e-3).sum()), R), "wsum_mid mean %.3f" % float(out["wsum_mid"].mean()))
+
+
 def gen_checkpoint():
     """A reference-format checkpoint (FourierGrid_ckpt_manager.py:44-51: model_kwargs + model_state_dict) of a tiny
     FourierGridModel with NON-trivial geometry (scene box != [-1,1]^3, num_voxels != num_voxels_base so that
@@ -277,3 +305,4 @@ if __name__ == "__main__":
     gen_checkpoint()
     gen_distortion()
     gen_train_step()
+    gen_dcvgo()

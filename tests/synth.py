@@ -103,3 +103,13 @@ def distortion_inputs():
 
 # the training-step golden (tests/golden/train_step.npz): model and batch
 TRAIN_CASE = dict(seed=21, G=12, F=3, C=12, pe=4, norm="inf", thres=1e-4, dm=4.0, ds=10.0, R=96, stepsize=0.5)
+
+
+# dcvgo.DirectContractedVoxGO goldens: name, seed, G (num_voxels = G^3), Gb (num_voxels_base), C (0 = coarse, 3-channel
+# k0 without rgbnet), contracted_norm, rays, density mean / std
+DCVGO_CASES = [
+    ("dcvgo_fine_inf", 51, 14, 16, 12, "inf", 90, 1.0, 5.0),
+    ("dcvgo_coarse_l2", 52, 12, 12, 0, "l2", 80, 0.0, 4.0),
+]
+DCVGO_BOX = ([-0.9, -1.1, -1.0], [1.1, 0.9, 1.0])     # the fg/bg separating cube (must be a cube), off the origin
+

@@ -1,0 +1,148 @@
+"""DirectContractedVoxGORenderer: inference forward of the reference's contracted-unbounded DVGOv2 model
+dcvgo.DirectContractedVoxGO (/root/reference/FourierGrid/dcvgo.py:228-384, the "dcvgo contracted bg grid" of
+BASELINE.json configs[1]) composed from the drop-in kernels, like DirectVoxGORenderer is for the bounded model:
+
+  mid-point sample table (t_boundary = 2) -> contraction -> cumdist_thres (drops oversampled contracted points)
+  -> maskcache_lookup -> dense grid query -> raw2alpha -> alpha2weight -> k0 query -> rgbnet -> per-ray sums
+  (+ alphainv_last * bg, wsum_mid over the un-contracted samples, depth = sum w * s)
+
+Same call signature and return keys as the reference forward.  Boolean compactions and the tiny rgbnet use torch on
+the device, exactly like the reference; every kernel the reference has natively is the HIP one.  `ops` / `query`
+exist for tests: they let the same composition run against another implementation of the four extension modules
+(the CPU oracle); the default is the HIP library, which needs a GPU -- there is no CPU fallback.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def dcvgo_state_from_params(xyz_min, xyz_max, num_voxels, num_voxels_base, alpha_init, density_grid, k0_grid,
+                            rgbnet_weights, rgbnet_biases, mask, fast_color_thres, bg_len=0.2, contracted_norm='inf',
+                            viewbase_pe=4):
+    """The derived quantities of DirectContractedVoxGO.__init__ / _set_grid_resolution (dcvgo.py:42-60,128-136) and of
+    its MaskGrid (grid.py:221-228), from the constructor arguments and the learned tensors."""
+    import math
+    lo_s, hi_s = torch.Tensor(xyz_min), torch.Tensor(xyz_max)            # fg / bg separating cube (scene space)
+    lo = torch.Tensor([-1, -1, -1]) - bg_len                              # contracted bounds
+    hi = torch.Tensor([1, 1, 1]) + bg_len
+    voxel_size_base = ((hi - lo).prod() / num_voxels_base).pow(1 / 3)
+    voxel_size = ((hi - lo).prod() / num_voxels).pow(1 / 3)
+    world_size = ((hi - lo) / voxel_size).long()
+    scale = (torch.Tensor(list(mask.shape)) - 1) / (hi - lo)
+    return {
+        'scene_center': (lo_s + hi_s) * 0.5, 'scene_radius': (hi_s - lo_s) * 0.5, 'xyz_min': lo, 'xyz_max': hi,
+        'bg_len': bg_len, 'contracted_norm': contracted_norm, 'world_size': world_size,
+        'world_len': int(world_size[0]), 'voxel_size_ratio': voxel_size / voxel_size_base,
+        'act_shift': torch.FloatTensor([math.log(1 / (1 - alpha_init) - 1)]),
+        'density_grid': density_grid, 'k0_grid': k0_grid, 'rgbnet_weights': rgbnet_weights,
+        'rgbnet_biases': rgbnet_biases, 'mask': mask.bool(), 'xyz2ijk_scale': scale, 'xyz2ijk_shift': -lo * scale,
+        'fast_color_thres': fast_color_thres, 'viewbase_pe': viewbase_pe,
+    }
+
+
+class _HipOps:
+    """The product's extension modules + grid query, resolved lazily (importing them loads libugrid_hip.so)."""
+
+    def __init__(self):
+        from . import render_utils_cuda, ub360_utils_cuda
+        from .grid import grid_query
+        self.ru, self.ub, self.query = render_utils_cuda, ub360_utils_cuda, grid_query
+
+
+class DirectContractedVoxGORenderer:
+    def __init__(self, state, device, ops=None, query=None):
+        dev = torch.device(device)
+        if ops is None:
+            if dev.type != "cuda":
+                raise RuntimeError("DirectContractedVoxGORenderer needs a HIP device (no CPU path)")
+            hip = _HipOps()
+            self.ru, self.ub, self.query = hip.ru, hip.ub, hip.query
+        else:                                   # tests: another implementation of the extension modules
+            self.ru, self.ub, self.query = ops.render_utils_cuda, ops.ub360_utils_cuda, query
+        self.device = dev
+        self.s = {k: (v.to(dev).contiguous() if torch.is_tensor(v) else
+                      ([x.to(dev).contiguous() for x in v] if isinstance(v, list) else v)) for k, v in state.items()}
+        self.viewfreq = torch.tensor([float(2 ** i) for i in range(int(state["viewbase_pe"]))], device=dev)
+        self._tables = {}
+
+    def _t_table(self, stepsize):
+        key = float(stepsize)
+        if key not in self._tables:
+            from .fourier_render import sample_table
+            t, _ = sample_table(self.s['world_len'], key, self.s['bg_len'], t_boundary=2)     # dcvgo.py:243-250
+            self._tables[key] = t.to(self.device)
+        return self._tables[key]
+
+    @torch.no_grad()
+    def forward(self, rays_o, rays_d, viewdirs, global_step=None, **render_kwargs):
+        s = self.s
+        assert rays_o.dim() == 2 and rays_o.shape[-1] == 3, 'Only support point queries in [N, 3] format'
+        N = rays_o.shape[0]
+        stepsize = render_kwargs['stepsize']
+        bg_len = s['bg_len']
+        t = self._t_table(stepsize)
+        S = t.numel()
+        # samples in the normalised scene, contracted outside the unit cube / ball (dcvgo.py:240-262)
+        o = (rays_o - s['scene_center']) / s['scene_radius']
+        d = rays_d / rays_d.norm(dim=-1, keepdim=True)
+        pts = o[:, None, :] + d[:, None, :] * t[None, :, None]
+        if s['contracted_norm'] == 'inf':
+            nrm = pts.abs().amax(dim=-1, keepdim=True)
+        elif s['contracted_norm'] == 'l2':
+            nrm = pts.norm(dim=-1, keepdim=True)
+        else:
+            raise NotImplementedError(s['contracted_norm'])
+        inner = nrm <= 1
+        pts = torch.where(inner, pts, pts / nrm * ((1 + bg_len) - bg_len / nrm))
+        inner = inner.squeeze(-1)
+        interval = stepsize * s['voxel_size_ratio']
+        # keep every un-contracted sample; of the contracted ones only those that moved on by ~one step (:283-289)
+        keep = inner.clone()
+        dist_thres = (2 + 2 * bg_len) / s['world_len'] * stepsize * 0.95
+        dist = (pts[:, 1:] - pts[:, :-1]).norm(dim=-1)
+        keep[:, 1:] |= self.ub.cumdist_thres(dist.contiguous(), dist_thres)
+        ray_id = torch.arange(N, device=pts.device).view(-1, 1).expand(N, S)[keep]
+        step_id = torch.arange(S, device=pts.device).view(1, -1).expand(N, S)[keep]
+        tt = t[None].expand(N, S)[keep]
+        pts, inner = pts[keep], inner[keep]
+        # known free space
+        m = self.ru.maskcache_lookup(s['mask'], pts.contiguous(), s['xyz2ijk_scale'], s['xyz2ijk_shift'])
+        pts, inner, tt, ray_id, step_id = pts[m], inner[m], tt[m], ray_id[m], step_id[m]
+        density = self.query(s['density_grid'], pts, s['xyz_min'], s['xyz_max'], 0)
+        alpha = self.ru.raw2alpha(density.flatten().contiguous(), s['act_shift'], interval)[1]
+        thres = float(s['fast_color_thres'])
+        if thres > 0:
+            k = alpha > thres
+            pts, inner, tt, ray_id, step_id, density, alpha = pts[k], inner[k], tt[k], ray_id[k], step_id[k], density[k], alpha[k]
+        weights, _, alphainv_last = self.ru.alpha2weight(alpha.contiguous(), ray_id.contiguous(), N)[:3]
+        if thres > 0:
+            k = weights > thres
+            pts, inner, tt, ray_id, step_id = pts[k], inner[k], tt[k], ray_id[k], step_id[k]
+            density, alpha, weights = density[k], alpha[k], weights[k]
+        k0 = self.query(s['k0_grid'], pts, s['xyz_min'], s['xyz_max'], 0)
+        if k0.dim() == 1:
+            k0 = k0.unsqueeze(-1)
+        if len(s['rgbnet_weights']) == 0:
+            rgb = torch.sigmoid(k0)
+        else:
+            e = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
+            emb = torch.cat([viewdirs, e.sin(), e.cos()], -1)[ray_id]
+            h = torch.cat([k0, emb], -1)
+            n = len(s['rgbnet_weights'])
+            for i in range(n):
+                h = F.linear(h, s['rgbnet_weights'][i], s['rgbnet_biases'][i])
+                if i + 1 < n:
+                    h = torch.relu(h)
+            rgb = torch.sigmoid(h)
+        dev = pts.device
+        rgb_marched = torch.zeros(N, 3, device=dev).index_add_(0, ray_id, weights.unsqueeze(-1) * rgb)
+        rgb_marched += alphainv_last.unsqueeze(-1) * render_kwargs['bg']
+        wsum_mid = torch.zeros(N, device=dev).index_add_(0, ray_id[inner], weights[inner])
+        sdist = 1 - 1 / (1 + tt)
+        out = {'alphainv_last': alphainv_last, 'weights': weights, 'wsum_mid': wsum_mid, 'rgb_marched': rgb_marched,
+               'raw_density': density, 'raw_alpha': alpha, 'raw_rgb': rgb, 'ray_id': ray_id, 'step_id': step_id,
+               'n_max': S, 't': tt, 's': sdist}
+        if render_kwargs.get('render_depth', False):
+            out['depth'] = torch.zeros(N, device=dev).index_add_(0, ray_id, weights * sdist)
+        return out
+
+    __call__ = forward
