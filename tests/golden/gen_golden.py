@@ -238,6 +238,43 @@ def gen_dvgo():
         print(name, "world", ws, "M=%d" % out["weights"].numel(), "rgb mean %.3f" % float(out["rgb_marched"].mean()))
 
 
+def gen_dvgo_utils():
+    """Training-ray preparation of the bounded model, from the reference's own methods: DirectVoxGO.hit_coarse_geo
+    (dvgo.py:292-304), DirectVoxGO.voxel_count_views (:247-277) and get_training_rays_in_maskcache_sampling (:619-657)
+    on three tiny views of the dvgo_fine_direct model."""
+    dvgo = install_stubs.import_reference("dvgo")
+    name, seed, G, C, direct, R, dm, ds = DVGO_CASES[0]
+    xyz_min, xyz_max, nvox = dvgo_inputs(seed, G, C)
+    model = dvgo.DirectVoxGO(xyz_min=xyz_min, xyz_max=xyz_max, num_voxels=nvox, num_voxels_base=nvox, alpha_init=1e-2,
+                             fast_color_thres=1e-4, rgbnet_dim=C, rgbnet_direct=direct, mask_cache_world_size=None)
+    ws = [int(x) for x in model.world_size]
+    sd = model.state_dict()
+    params = synth.dvgo_params(seed, ws, C, direct, dens_mean=dm, dens_std=ds)
+    with torch.no_grad():
+        for k, v in params.items():
+            sd[k].copy_(torch.from_numpy(v))
+    H, W, K, poses = synth.dvgo_views()
+    imgs = [torch.from_numpy(synth.uniform(900 + i, H * W * 3).reshape(H, W, 3)) for i in range(len(poses))]
+    rk = dict(near=0.2, far=6.0, stepsize=0.5)
+    ro, rd = [], []
+    hits = []
+    for c2w in poses:
+        o, d, _ = dvgo.get_rays_of_a_view(H=H, W=W, K=K, c2w=torch.from_numpy(c2w), ndc=False, inverse_y=False,
+                                          flip_x=False, flip_y=False)
+        ro.append(o); rd.append(d)
+        hits.append(model.hit_coarse_geo(rays_o=o, rays_d=d, **rk).numpy())
+    count = model.voxel_count_views(rays_o_tr=torch.stack(ro), rays_d_tr=torch.stack(rd), imsz=1, near=0.2, far=6.0,
+                                    stepsize=0.5, downrate=1, irregular_shape=False)
+    rgb_tr, o_tr, d_tr, v_tr, imsz = dvgo.get_training_rays_in_maskcache_sampling(
+        rgb_tr_ori=imgs, train_poses=[torch.from_numpy(p) for p in poses], HW=[(H, W)] * len(poses), Ks=[K] * len(poses),
+        ndc=False, inverse_y=False, flip_x=False, flip_y=False, model=model, render_kwargs=rk)
+    res = dict(hit=np.stack(hits), count=count.detach().numpy(), rgb_tr=rgb_tr.numpy(), rays_o_tr=o_tr.numpy(),
+               rays_d_tr=d_tr.numpy(), viewdirs_tr=v_tr.numpy(), imsz=np.array([int(x) for x in imsz]))
+    np.savez_compressed(os.path.join(HERE, "dvgo_utils.npz"), **res)
+    print("dvgo_utils hit frac %.2f, seen voxels %d of %d, kept rays %s" % (res["hit"].mean(), int((res["count"] > 0).sum()),
+                                                                         res["count"].size, res["imsz"].tolist()))
+
+
 def gen_dcvgo():
     """dcvgo.DirectContractedVoxGO.forward (contracted unbounded DVGOv2: cumdist_thres, mask cache, dense grids);
     num_voxels != num_voxels_base so that voxel_size_ratio != 1, a non-trivial mask, a scene cube off the origin."""
@@ -306,3 +343,4 @@ if __name__ == "__main__":
     gen_distortion()
     gen_train_step()
     gen_dcvgo()
+    gen_dvgo_utils()

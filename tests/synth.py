@@ -113,3 +113,17 @@ DCVGO_CASES = [
 ]
 DCVGO_BOX = ([-0.9, -1.1, -1.0], [1.1, 0.9, 1.0])     # the fg/bg separating cube (must be a cube), off the origin
 
+
+def dvgo_views():
+    """Three small pinhole views around the dvgo test box: H, W, K [3,3], poses [3][3,4] (camera-to-world)."""
+    H, W = 12, 16
+    K = np.array([[14.0, 0, W / 2], [0, 14.0, H / 2], [0, 0, 1]], dtype=np.float32)
+    poses = []
+    for a, h in ((0.3, 0.2), (2.2, -0.3), (4.0, 0.5)):
+        eye = np.array([2.6 * np.cos(a), 2.6 * np.sin(a), h], dtype=np.float64)
+        fwd = -eye / np.linalg.norm(eye)
+        right = np.cross(fwd, [0.0, 0.0, 1.0]); right /= np.linalg.norm(right)
+        up = np.cross(right, fwd)
+        poses.append(np.stack([right, up, -fwd, eye], axis=1).astype(np.float32))    # OpenGL: x right, y up, looks along -z
+    return H, W, K, poses
+

@@ -93,3 +93,58 @@ def test_dvgo_lego_shaped_view_vs_oracle():
     psnr_between = -10.0 * np.log10(max(mse, 1e-20))
     assert psnr_between > 80.0   # PSNR of HIP vs oracle image: far inside the +-0.01 dB parity band
     np.testing.assert_allclose(out["alphainv_last"].cpu().numpy(), ref["alphainv_last"].numpy(), atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# training-ray preparation: hit_coarse_geo, voxel_count_views,
+# get_training_rays_in_maskcache_sampling -- goldens from the reference's own methods (gen_dvgo_utils)
+# ---------------------------------------------------------------------------------------------------------
+def _utils_check(rend, get_rays, dev, gold):
+    from unboundednerfpytorch_amd.dvgo_render import get_training_rays_in_maskcache_sampling
+    H, W, K, poses = synth.dvgo_views()
+    rk = dict(near=0.2, far=6.0, stepsize=0.5)
+    ro, rd = [], []
+    for i, c2w in enumerate(poses):
+        o, d, _ = get_rays(H, W, K, torch.from_numpy(c2w).to(dev))
+        ro.append(o); rd.append(d)
+        hit = rend.hit_coarse_geo(rays_o=o, rays_d=d, **rk)
+        assert hit.shape == (H, W) and hit.dtype == torch.bool
+        assert np.array_equal(hit.cpu().numpy(), gold["hit"][i]), i
+    count = rend.voxel_count_views(rays_o_tr=torch.stack(ro), rays_d_tr=torch.stack(rd), imsz=1, near=0.2, far=6.0,
+                                   stepsize=0.5, downrate=1, irregular_shape=False)
+    assert count.shape == gold["count"].shape
+    # a voxel is "seen" when its accumulated trilinear weight exceeds 1: a different summation order can only flip
+    # voxels whose sum sits within rounding of exactly 1
+    assert float((count.cpu().numpy() != gold["count"]).mean()) < 2e-3
+    imgs = [torch.from_numpy(synth.uniform(900 + i, H * W * 3).reshape(H, W, 3)).to(dev) for i in range(len(poses))]
+    rgb_tr, o_tr, d_tr, v_tr, imsz = get_training_rays_in_maskcache_sampling(
+        imgs, [torch.from_numpy(p) for p in poses], [(H, W)] * len(poses), [K] * len(poses), False, False, False, False,
+        rend, rk, get_rays=get_rays)
+    assert [int(x) for x in imsz] == gold["imsz"].tolist()
+    assert np.array_equal(rgb_tr.cpu().numpy(), gold["rgb_tr"])
+    for got, key in ((o_tr, "rays_o_tr"), (d_tr, "rays_d_tr"), (v_tr, "viewdirs_tr")):
+        np.testing.assert_allclose(got.cpu().numpy(), gold[key], rtol=2e-6, atol=1e-7, err_msg=key)
+
+
+def test_dvgo_training_ray_utils_cpu(golden_dir):
+    """the product composition with the oracle's extension modules injected (host logic), vs the reference's methods"""
+    from unboundednerfpytorch_amd.dvgo_render import DirectVoxGORenderer
+    from unboundednerfpytorch_amd.fourier_render import get_rays_of_a_view
+    gold = np.load(os.path.join(golden_dir, "dvgo_utils.npz"))
+    name, seed, G, C, direct, R, dm, ds = DVGO_CASES[0]
+    torch.set_num_threads(1)
+    state, _ = dvgo_state(seed, G, C, direct, dm, ds)
+    rend = DirectVoxGORenderer(state, "cpu", ops=ref_ops, query=model_oracle.fourier_grid_query)
+    _utils_check(rend, get_rays_of_a_view, "cpu", gold)
+    with pytest.raises(RuntimeError):
+        DirectVoxGORenderer(state, "cpu")
+
+
+@pytest.mark.gpu
+def test_dvgo_training_ray_utils_hip(golden_dir):
+    from unboundednerfpytorch_amd.dvgo_render import DirectVoxGORenderer
+    from unboundednerfpytorch_amd.fourier_render import get_rays_of_a_view
+    gold = np.load(os.path.join(golden_dir, "dvgo_utils.npz"))
+    name, seed, G, C, direct, R, dm, ds = DVGO_CASES[0]
+    state, _ = dvgo_state(seed, G, C, direct, dm, ds)
+    _utils_check(DirectVoxGORenderer(state, "cuda:0"), get_rays_of_a_view, "cuda", gold)

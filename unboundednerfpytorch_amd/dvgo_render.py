@@ -6,12 +6,15 @@ reference forward (`rgb_marched`, `depth`, `alphainv_last`, `weights`, `raw_alph
 
 The compaction steps (boolean masks) and the tiny rgbnet use torch on the device, exactly like the
 reference does; every kernel the reference has natively is the HIP one.
+
+Also the training-ray preparation that leans on the same kernels: `hit_coarse_geo`
+(dvgo.py:292-304), `voxel_count_views` (dvgo.py:247-277) and `get_training_rays_in_maskcache_sampling`
+(dvgo.py:619-657).  `ops` / `query` / `grad_query` exist for tests: they let the same composition run against another
+implementation of the extension modules (the CPU oracle); the default is the HIP library, which needs a GPU.
 """
+import numpy as np
 import torch
 import torch.nn.functional as F
-
-from . import render_utils_cuda
-from .grid import grid_query
 
 
 class DirectVoxGORenderer:
@@ -19,10 +22,16 @@ class DirectVoxGORenderer:
     mask [mx,my,mz] bool, xyz2ijk_scale/shift [3], act_shift, voxel_size, voxel_size_ratio (0-d tensors or floats),
     fast_color_thres, rgbnet_direct, viewbase_pe."""
 
-    def __init__(self, state, device):
+    def __init__(self, state, device, ops=None, query=None, grad_query=None):
         dev = torch.device(device)
-        if dev.type != "cuda":
-            raise RuntimeError("DirectVoxGORenderer needs a HIP device (no CPU path)")
+        if ops is None:
+            if dev.type != "cuda":
+                raise RuntimeError("DirectVoxGORenderer needs a HIP device (no CPU path)")
+            from . import render_utils_cuda
+            from .grid import GridQuery, grid_query
+            self.ru, self.query, self.grad_query = render_utils_cuda, grid_query, GridQuery.apply
+        else:                                   # tests: another implementation of the extension modules
+            self.ru, self.query, self.grad_query = ops.render_utils_cuda, query, grad_query or query
         self.device = dev
         self.s = {k: (v.to(dev).contiguous() if torch.is_tensor(v) else
                       ([x.to(dev).contiguous() for x in v] if isinstance(v, list) else v)) for k, v in state.items()}
@@ -36,24 +45,24 @@ class DirectVoxGORenderer:
         stepsize = render_kwargs['stepsize']
         far = 1e9  # the given far can be too small while rays stop when hitting scene bbox (dvgo.py:318)
         stepdist = stepsize * s['voxel_size']
-        ray_pts, mask_outbbox, ray_id, step_id = render_utils_cuda.sample_pts_on_rays(
+        ray_pts, mask_outbbox, ray_id, step_id = self.ru.sample_pts_on_rays(
             rays_o.contiguous(), rays_d.contiguous(), s['xyz_min'], s['xyz_max'], render_kwargs['near'], far, stepdist)[:4]
         inb = ~mask_outbbox
         ray_pts, ray_id, step_id = ray_pts[inb], ray_id[inb], step_id[inb]
         interval = stepsize * s['voxel_size_ratio']
-        m = render_utils_cuda.maskcache_lookup(s['mask'], ray_pts.contiguous(), s['xyz2ijk_scale'], s['xyz2ijk_shift'])
+        m = self.ru.maskcache_lookup(s['mask'], ray_pts.contiguous(), s['xyz2ijk_scale'], s['xyz2ijk_shift'])
         ray_pts, ray_id, step_id = ray_pts[m], ray_id[m], step_id[m]
-        density = grid_query(s['density_grid'], ray_pts, s['xyz_min'], s['xyz_max'], 0)
-        alpha = render_utils_cuda.raw2alpha(density.flatten().contiguous(), s['act_shift'], interval)[1]
+        density = self.query(s['density_grid'], ray_pts, s['xyz_min'], s['xyz_max'], 0)
+        alpha = self.ru.raw2alpha(density.flatten().contiguous(), s['act_shift'], interval)[1]
         thres = float(s['fast_color_thres'])
         if thres > 0:
             k = alpha > thres
             ray_pts, ray_id, step_id, alpha = ray_pts[k], ray_id[k], step_id[k], alpha[k]
-        weights, _, alphainv_last = render_utils_cuda.alpha2weight(alpha.contiguous(), ray_id.contiguous(), N)[:3]
+        weights, _, alphainv_last = self.ru.alpha2weight(alpha.contiguous(), ray_id.contiguous(), N)[:3]
         if thres > 0:
             k = weights > thres
             weights, alpha, ray_pts, ray_id, step_id = weights[k], alpha[k], ray_pts[k], ray_id[k], step_id[k]
-        k0 = grid_query(s['k0_grid'], ray_pts, s['xyz_min'], s['xyz_max'], 0)
+        k0 = self.query(s['k0_grid'], ray_pts, s['xyz_min'], s['xyz_max'], 0)
         if k0.dim() == 1:
             k0 = k0.unsqueeze(-1)
         if len(s['rgbnet_weights']) == 0:
@@ -69,12 +78,91 @@ class DirectVoxGORenderer:
                 if i + 1 < n:
                     h = torch.relu(h)
             rgb = torch.sigmoid(h if s['rgbnet_direct'] else h + k0[:, :3])
-        rgb_marched = torch.zeros(N, 3, device=self.device).index_add_(0, ray_id, weights.unsqueeze(-1) * rgb)
+        rgb_marched = torch.zeros(N, 3, device=rays_o.device).index_add_(0, ray_id, weights.unsqueeze(-1) * rgb)
         rgb_marched += alphainv_last.unsqueeze(-1) * render_kwargs['bg']
         out = {'alphainv_last': alphainv_last, 'weights': weights, 'rgb_marched': rgb_marched, 'raw_alpha': alpha,
                'raw_rgb': rgb, 'ray_id': ray_id}
         if render_kwargs.get('render_depth', False):
-            out['depth'] = torch.zeros(N, device=self.device).index_add_(0, ray_id, weights * step_id)
+            out['depth'] = torch.zeros(N, device=rays_o.device).index_add_(0, ray_id, weights * step_id)
         return out
 
     __call__ = forward
+
+    # -- training-ray preparation ---------------------------------------------------------------------------
+    @torch.no_grad()
+    def hit_coarse_geo(self, rays_o, rays_d, near, far, stepsize, **render_kwargs):
+        """bool [...]: does the ray pass through a cell the mask cache marks as possibly occupied? (dvgo.py:292-304)"""
+        s = self.s
+        far = 1e9
+        shape = rays_o.shape[:-1]
+        o = rays_o.reshape(-1, 3).contiguous()
+        d = rays_d.reshape(-1, 3).contiguous()
+        ray_pts, mask_outbbox, ray_id = self.ru.sample_pts_on_rays(o, d, s['xyz_min'], s['xyz_max'], near, far,
+                                                                  stepsize * s['voxel_size'])[:3]
+        inb = ~mask_outbbox
+        pts_in, rid_in = ray_pts[inb], ray_id[inb]
+        occ = self.ru.maskcache_lookup(s['mask'], pts_in.contiguous(), s['xyz2ijk_scale'], s['xyz2ijk_shift'])
+        hit = torch.zeros(o.shape[0], dtype=torch.bool, device=o.device)
+        hit[rid_in[occ]] = True
+        return hit.reshape(shape)
+
+    def voxel_count_views(self, rays_o_tr, rays_d_tr, imsz, near, far, stepsize, downrate=1, irregular_shape=False):
+        """Per-voxel count of the training views that see it (dvgo.py:247-277): for every image the trilinear
+        footprint of its rays' samples is scattered into a zero grid -- here by the lookup's scatter backward -- and a
+        voxel counts as seen when its accumulated weight exceeds 1."""
+        s = self.s
+        far = 1e9
+        ws = s['world_size']
+        dev = s['density_grid'].device
+        n_samples = int(np.linalg.norm(ws.cpu().numpy().astype(np.float64) + 1) / stepsize) + 1
+        rng = torch.arange(n_samples, device=dev)[None].float()
+        count = torch.zeros_like(s['density_grid'])
+        for o_img, d_img in zip(rays_o_tr.split(imsz), rays_d_tr.split(imsz)):
+            ones = torch.zeros_like(s['density_grid']).requires_grad_(True)
+            if irregular_shape:
+                o_chunks, d_chunks = o_img.split(10000), d_img.split(10000)
+            else:
+                o_chunks = o_img[::downrate, ::downrate].to(dev).flatten(0, -2).split(10000)
+                d_chunks = d_img[::downrate, ::downrate].to(dev).flatten(0, -2).split(10000)
+            for o, d in zip(o_chunks, d_chunks):
+                vec = torch.where(d == 0, torch.full_like(d, 1e-6), d)
+                rate_a = (s['xyz_max'] - o) / vec
+                rate_b = (s['xyz_min'] - o) / vec
+                t_min = torch.minimum(rate_a, rate_b).amax(-1).clamp(min=near, max=far)
+                step = stepsize * s['voxel_size'] * rng
+                interpx = t_min[..., None] + step / d.norm(dim=-1, keepdim=True)
+                pts = o[..., None, :] + d[..., None, :] * interpx[..., None]
+                self.grad_query(ones, pts, s['xyz_min'], s['xyz_max'], 0).sum().backward()
+            with torch.no_grad():
+                count += (ones.grad > 1)
+        return count
+
+
+@torch.no_grad()
+def get_training_rays_in_maskcache_sampling(rgb_tr_ori, train_poses, HW, Ks, ndc, inverse_y, flip_x, flip_y, model,
+                                            render_kwargs, get_rays=None):
+    """Keep only the pixels whose rays hit the coarse geometry (dvgo.py:619-657); returns the flattened
+    (rgb, rays_o, rays_d, viewdirs, imsz).  model: DirectVoxGORenderer (anything with hit_coarse_geo)."""
+    assert len(rgb_tr_ori) == len(train_poses) and len(rgb_tr_ori) == len(Ks) and len(rgb_tr_ori) == len(HW)
+    if ndc:
+        raise NotImplementedError("NDC rays belong to the DirectMPIGO path (out of scope, SURVEY.md section 2)")
+    if get_rays is None:
+        from .fourier_render import get_rays_of_a_view as get_rays
+    dev = rgb_tr_ori[0].device
+    total = sum(im.shape[0] * im.shape[1] for im in rgb_tr_ori)
+    rgb_tr = torch.zeros(total, 3, device=dev)
+    rays_o_tr, rays_d_tr, viewdirs_tr = torch.zeros_like(rgb_tr), torch.zeros_like(rgb_tr), torch.zeros_like(rgb_tr)
+    imsz, top = [], 0
+    for c2w, img, (H, W), K in zip(train_poses, rgb_tr_ori, HW, Ks):
+        assert img.shape[:2] == (H, W)
+        rays_o, rays_d, viewdirs = get_rays(H, W, K, torch.as_tensor(c2w, dtype=torch.float32).to(dev),
+                                            inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y)
+        mask = model.hit_coarse_geo(rays_o=rays_o, rays_d=rays_d, **render_kwargs).to(dev)   # whole image at once
+        n = int(mask.sum())
+        rgb_tr[top:top + n] = img[mask]
+        rays_o_tr[top:top + n] = rays_o[mask]
+        rays_d_tr[top:top + n] = rays_d[mask]
+        viewdirs_tr[top:top + n] = viewdirs[mask]
+        imsz.append(n)
+        top += n
+    return rgb_tr[:top], rays_o_tr[:top], rays_d_tr[:top], viewdirs_tr[:top], imsz
