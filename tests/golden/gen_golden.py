@@ -275,6 +275,41 @@ def gen_dvgo_utils():
                                                                          res["count"].size, res["imsz"].tolist()))
 
 
+def gen_model_utils():
+    """Model-level training utilities of the reference FourierGridModel on the MODEL_UTILS_CASE model: parameter / buffer
+    names and shapes, update_occupancy_cache, the TV wrappers, scale_volume_grid (coarse-to-fine resampling + mask
+    cache rebuild) and get_kwargs -- to pin unboundednerfpytorch_amd.fourier_model.FourierGridModel."""
+    mod = install_stubs.import_reference("FourierGrid_model")
+    c = synth.MODEL_UTILS_CASE
+    params = synth.fouriergrid_params(c["seed"], c["G"], c["F"], c["C"], viewbase_pe=c["pe"], dens_mean=c["dm"], dens_std=c["ds"])
+    model = build_reference_model(mod, c["G"], c["F"], c["C"], c["pe"], c["norm"], c["thres"], params)
+    res = {}
+    sd = model.state_dict()
+    res["sd_keys"] = np.array(sorted(sd.keys()))
+    res["sd_shapes"] = np.array([str(tuple(sd[k].shape)) for k in sorted(sd.keys())])
+    model.update_occupancy_cache()
+    res["occ_mask"] = model.mask_cache.mask.numpy().copy()
+    model.density.grid.grad = torch.from_numpy(synth.normal(700, model.density.grid.numel()).reshape(model.density.grid.shape))
+    gk = synth.normal(701, model.k0.grid.numel()).reshape(model.k0.grid.shape)
+    gk[np.abs(gk) < 1.0] = 0.0
+    model.k0.grid.grad = torch.from_numpy(gk)
+    model.density_total_variation_add_grad(1e-3, True)
+    model.k0_total_variation_add_grad(2e-3, False)
+    res["tv_density_grad"] = model.density.grid.grad.numpy().copy()
+    res["tv_k0_grad"] = model.k0.grid.grad.numpy().copy()
+    model.scale_volume_grid(c["G2"] ** 3, c["G2"] ** 3)
+    res["scaled_density"] = model.density.grid.detach().numpy().copy()
+    res["scaled_k0"] = model.k0.grid.detach().numpy().copy()
+    res["scaled_mask"] = model.mask_cache.mask.numpy().copy()
+    res["scaled_world_size"] = model.world_size_density.numpy().copy()
+    res["scaled_ratio"] = np.float32(float(model.voxel_size_ratio_density))
+    kw = model.get_kwargs()
+    res["kwargs_keys"] = np.array(sorted(kw.keys()))
+    np.savez_compressed(os.path.join(HERE, "fg_model_utils.npz"), **res)
+    print("model_utils: occupancy %.3f -> scaled world %s mask %.3f ratio %.4f" % (
+        res["occ_mask"].mean(), res["scaled_world_size"].tolist(), res["scaled_mask"].mean(), float(res["scaled_ratio"])))
+
+
 def gen_dcvgo():
     """dcvgo.DirectContractedVoxGO.forward (contracted unbounded DVGOv2: cumdist_thres, mask cache, dense grids);
     num_voxels != num_voxels_base so that voxel_size_ratio != 1, a non-trivial mask, a scene cube off the origin."""
@@ -344,3 +379,4 @@ if __name__ == "__main__":
     gen_train_step()
     gen_dcvgo()
     gen_dvgo_utils()
+    gen_model_utils()

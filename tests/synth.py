@@ -127,3 +127,8 @@ def dvgo_views():
         poses.append(np.stack([right, up, -fwd, eye], axis=1).astype(np.float32))    # OpenGL: x right, y up, looks along -z
     return H, W, K, poses
 
+
+# model-level training utilities golden (tests/golden/fg_model_utils.npz): a sparse scene so that the occupancy
+# cache really changes; scale_volume_grid goes from G^3 to G2^3 voxels
+MODEL_UTILS_CASE = dict(seed=61, G=8, G2=10, F=2, C=4, pe=2, norm="inf", thres=1e-4, dm=-1.8, ds=3.0)
+

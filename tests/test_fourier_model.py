@@ -1,0 +1,140 @@
+"""unboundednerfpytorch_amd.fourier_model.FourierGridModel (the training-side mirror of the reference's nn.Module,
+SURVEY.md section 8 row f2) against golden vectors produced by the reference's own model class:
+  * train_step.npz      loss + gradient of every parameter of one training forward/backward,
+  * fg_model_utils.npz  state_dict names/shapes, update_occupancy_cache, the TV wrappers, scale_volume_grid, get_kwargs.
+The module is device-agnostic Python over the extension-module boundary; here it runs on the CPU with the oracle's
+implementation of that boundary injected (`backend=`), which checks all of its host logic; the HIP implementation of
+each op behind the boundary is checked op by op in the GPU tests."""
+import os
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from oracle import model_oracle, ref_ops
+
+
+def oracle_backend():
+    Raw2Alpha, Alphas2Weights = model_oracle.make_autograd_ops(ref_ops)
+    return SimpleNamespace(Raw2Alpha=Raw2Alpha, Alphas2Weights=Alphas2Weights, grid_query=model_oracle.fourier_grid_query,
+                           total_variation_cuda=ref_ops.total_variation_cuda, render_utils_cuda=ref_ops.render_utils_cuda)
+
+
+def build(c, G=None):
+    from unboundednerfpytorch_amd.fourier_model import FourierGridModel
+    G = G or c["G"]
+    m = FourierGridModel(xyz_min=[-1, -1, -1], xyz_max=[1, 1, 1], num_voxels_density=G ** 3, num_voxels_base_density=G ** 3,
+                         num_voxels_rgb=G ** 3, num_voxels_base_rgb=G ** 3, num_voxels_viewdir=-1, alpha_init=1e-4,
+                         fast_color_thres=c["thres"], contracted_norm=c["norm"], fourier_freq_num=c["F"],
+                         rgbnet_dim=c["C"], viewbase_pe=c["pe"], backend=oracle_backend())
+    params = synth.fouriergrid_params(c["seed"], G, c["F"], c["C"], viewbase_pe=c["pe"], dens_mean=c["dm"], dens_std=c["ds"])
+    sd = m.state_dict()
+    with torch.no_grad():
+        for k, v in params.items():
+            assert tuple(sd[k].shape) == tuple(v.shape), k
+            sd[k].copy_(torch.from_numpy(v))
+    return m
+
+
+def test_training_forward_backward_matches_the_reference_model(golden_dir):
+    c = synth.TRAIN_CASE
+    gold = np.load(os.path.join(golden_dir, "train_step.npz"))
+    torch.set_num_threads(1)
+    m = build(c)
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(c["seed"], c["R"])]
+    target = torch.from_numpy(synth.uniform(c["seed"] + 5, c["R"] * 3).reshape(c["R"], 3))
+    out = m(o, d, v, global_step=1, is_train=True, stepsize=c["stepsize"], render_depth=True)
+    assert set(out) == {"alphainv_last", "weights", "rgb_marched", "raw_density", "raw_alpha", "raw_rgb", "ray_id",
+                        "step_id", "n_max", "t", "s", "depth"}                     # FourierGrid_model.py:650-672
+    loss = torch.nn.functional.mse_loss(out["rgb_marched"], target)
+    pout = out["alphainv_last"].clamp(1e-6, 1 - 1e-6)
+    loss = loss + 0.01 * (-(pout * torch.log(pout) + (1 - pout) * torch.log(1 - pout))).mean()
+    loss.backward()
+    assert out["weights"].numel() == int(gold["n_kept"])
+    np.testing.assert_allclose(float(loss), float(gold["loss"]), rtol=2e-6)
+    for name, p in m.named_parameters():
+        g = gold["grad." + name]
+        scale = np.abs(g).max()
+        assert np.abs(p.grad.numpy() - g).max() <= 2e-6 * scale + 1e-12, name
+        assert np.array_equal(p.grad.numpy() == 0, g == 0), name
+
+
+def test_model_utilities_match_the_reference_model(golden_dir):
+    c = synth.MODEL_UTILS_CASE
+    gold = np.load(os.path.join(golden_dir, "fg_model_utils.npz"))
+    torch.set_num_threads(1)
+    m = build(c)
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == gold["sd_keys"].tolist()                             # checkpoints interchange
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd.keys())] == gold["sd_shapes"].tolist()
+    m.update_occupancy_cache()
+    assert np.array_equal(m.mask_cache.mask.numpy(), gold["occ_mask"])
+    assert 0.05 < gold["occ_mask"].mean() < 0.95                                     # the case changes the cache
+    m.density.grid.grad = torch.from_numpy(synth.normal(700, m.density.grid.numel()).reshape(m.density.grid.shape))
+    gk = synth.normal(701, m.k0.grid.numel()).reshape(m.k0.grid.shape)
+    gk[np.abs(gk) < 1.0] = 0.0
+    m.k0.grid.grad = torch.from_numpy(gk)
+    m.density_total_variation_add_grad(1e-3, True)
+    m.k0_total_variation_add_grad(2e-3, False)
+    assert np.array_equal(m.density.grid.grad.numpy(), gold["tv_density_grad"])
+    assert np.array_equal(m.k0.grid.grad.numpy(), gold["tv_k0_grad"])
+    m.scale_volume_grid(c["G2"] ** 3, c["G2"] ** 3)
+    assert m.world_size_density.tolist() == gold["scaled_world_size"].tolist()
+    np.testing.assert_allclose(m.density.grid.detach().numpy(), gold["scaled_density"], rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(m.k0.grid.detach().numpy(), gold["scaled_k0"], rtol=1e-6, atol=1e-6)
+    assert np.array_equal(m.mask_cache.mask.numpy(), gold["scaled_mask"])
+    assert abs(float(m.voxel_size_ratio_density) - float(gold["scaled_ratio"])) < 1e-7
+    assert sorted(m.get_kwargs().keys()) == gold["kwargs_keys"].tolist()
+    # the rescaled model still runs and its new grids receive gradients
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(3, 32)]
+    out = m(o, d, v, global_step=2, is_train=True, stepsize=0.5)
+    out["rgb_marched"].sum().backward()
+    assert m.density.grid.grad is not None and tuple(m.density.grid.shape[2:]) == (10, 10, 10)
+
+
+def test_unsupported_options_fail_loudly():
+    from unboundednerfpytorch_amd.fourier_model import FourierGridModel
+    kw = dict(xyz_min=[-1, -1, -1], xyz_max=[1, 1, 1], num_voxels_density=512, num_voxels_base_density=512, num_voxels_rgb=512,
+              num_voxels_base_rgb=512, alpha_init=1e-4, rgbnet_dim=4, fourier_freq_num=2, backend=oracle_backend())
+    with pytest.raises(NotImplementedError):
+        FourierGridModel(num_voxels_viewdir=64, **kw)
+    with pytest.raises(NotImplementedError):
+        FourierGridModel(img_emb_dim=8, sample_num=10, **kw)
+
+
+@pytest.mark.gpu
+def test_training_model_on_hip_matches_the_oracle_backend():
+    """The same module with its default back-end (libugrid_hip.so) on the GPU against the CPU run above: loss,
+    gradients, occupancy cache and rescaled grids."""
+    from unboundednerfpytorch_amd.fourier_model import FourierGridModel
+    c = synth.MODEL_UTILS_CASE
+    torch.set_num_threads(4)
+    ref = build(c)
+    dev = FourierGridModel(xyz_min=[-1, -1, -1], xyz_max=[1, 1, 1], num_voxels_density=c["G"] ** 3,
+                           num_voxels_base_density=c["G"] ** 3, num_voxels_rgb=c["G"] ** 3, num_voxels_base_rgb=c["G"] ** 3,
+                           num_voxels_viewdir=-1, alpha_init=1e-4, fast_color_thres=c["thres"], contracted_norm=c["norm"],
+                           fourier_freq_num=c["F"], rgbnet_dim=c["C"], viewbase_pe=c["pe"])
+    dev.load_state_dict(ref.state_dict())
+    dev = dev.cuda()
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(9, 200)]
+    target = torch.from_numpy(synth.uniform(10, 600).reshape(200, 3))
+    losses = []
+    for m, to in ((ref, lambda x: x), (dev, lambda x: x.cuda())):
+        out = m(to(o), to(d), to(v), global_step=1, is_train=True, stepsize=0.5, render_depth=True)
+        loss = torch.nn.functional.mse_loss(out["rgb_marched"], to(target))
+        loss.backward()
+        m.density_total_variation_add_grad(1e-3, True)
+        losses.append(float(loss.detach()))
+    assert abs(losses[0] - losses[1]) <= 1e-5 * max(1.0, abs(losses[0]))
+    for (n0, p0), (n1, p1) in zip(ref.named_parameters(), dev.named_parameters()):
+        assert n0 == n1
+        scale = float(p0.grad.abs().max()) + 1e-12
+        assert float((p0.grad - p1.grad.cpu()).abs().max()) <= 5e-4 * scale, n0
+    ref.update_occupancy_cache(); dev.update_occupancy_cache()
+    assert float((ref.mask_cache.mask != dev.mask_cache.mask.cpu()).float().mean()) < 5e-3
+    ref.scale_volume_grid(c["G2"] ** 3, c["G2"] ** 3); dev.scale_volume_grid(c["G2"] ** 3, c["G2"] ** 3)
+    np.testing.assert_allclose(dev.k0.grid.detach().cpu().numpy(), ref.k0.grid.detach().numpy(), rtol=1e-5, atol=1e-5)
+    assert float((ref.mask_cache.mask != dev.mask_cache.mask.cpu()).float().mean()) < 5e-3
+    assert dev.mask_cache.mask.is_cuda and dev.mask_cache.xyz2ijk_scale.is_cuda

@@ -1,0 +1,225 @@
+"""FourierGridModel for TRAINING on the HIP ops: the counterpart of the reference's
+nn.Module of that name (/root/reference/FourierGrid/FourierGrid_model.py:136-672) with the same constructor
+arguments, the same parameter / buffer names (`density.grid`, `k0.grid`, `rgbnet.*`, `mask_cache.*`, `act_shift`,
+`scene_center`, ... -- state_dicts and `get_kwargs()` checkpoints interchange) and the same methods the training
+program calls: `forward` (returns the per-sample dict run_train.py consumes), `scale_volume_grid`,
+`update_occupancy_cache`, `density_total_variation_add_grad`, `k0_total_variation_add_grad`, `activate_density`.
+
+Every grid lookup (forward and backward), raw2alpha, alpha2weight, the TV gradient and the mask-cache lookup run on
+libugrid_hip.so; the compaction masks, the three rgbnet Linear layers and the two resampling ops of the coarse-to-fine
+schedule (F.interpolate, F.max_pool3d) are torch, as in the reference.  Inference should use
+fourier_render.FourierGridRenderer (fused kernels); this class exists so that training needs nothing but this
+package.  `backend` is a test hook (another implementation of the extension modules, e.g. the CPU oracle)."""
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import grid as _grid
+
+
+def _hip_backend():
+    from . import ops, render_utils_cuda, total_variation_cuda
+    return SimpleNamespace(Raw2Alpha=ops.Raw2Alpha, Alphas2Weights=ops.Alphas2Weights, grid_query=None,
+                           total_variation_cuda=None, render_utils_cuda=None)
+
+
+class FourierGridModel(nn.Module):
+    def __init__(self, xyz_min, xyz_max, num_voxels_density=0, num_voxels_base_density=0, num_voxels_rgb=0,
+                 num_voxels_base_rgb=0, num_voxels_viewdir=-1, alpha_init=None, mask_cache_world_size=None,
+                 fast_color_thres=0, bg_len=0.2, contracted_norm='inf', density_type='DenseGrid', k0_type='DenseGrid',
+                 density_config={}, k0_config={}, rgbnet_dim=0, rgbnet_depth=3, rgbnet_width=128, fourier_freq_num=5,
+                 viewbase_pe=4, img_emb_dim=-1, verbose=False, backend=None, **kwargs):
+        super().__init__()
+        if num_voxels_viewdir is not None and num_voxels_viewdir > 0:
+            raise NotImplementedError("view-direction colour grid (num_voxels_viewdir > 0) is not on the hot path")
+        if img_emb_dim > 0 and kwargs.get('sample_num', -1) > 0:
+            raise NotImplementedError("per-image appearance embeddings are not on the hot path")
+        self._be = backend if backend is not None else _hip_backend()
+        lo_s, hi_s = torch.Tensor(xyz_min), torch.Tensor(xyz_max)
+        self.register_buffer('scene_center', (lo_s + hi_s) * 0.5)
+        self.register_buffer('scene_radius', (hi_s - lo_s) * 0.5)
+        self.register_buffer('xyz_min', torch.Tensor([-1, -1, -1]) - bg_len)      # contracted bounds
+        self.register_buffer('xyz_max', torch.Tensor([1, 1, 1]) + bg_len)
+        self._fast_color_thres = fast_color_thres if isinstance(fast_color_thres, dict) else None
+        self.fast_color_thres = fast_color_thres[0] if isinstance(fast_color_thres, dict) else fast_color_thres
+        self.bg_len, self.contracted_norm, self.verbose = bg_len, contracted_norm, verbose
+        self.fourier_freq_num = fourier_freq_num
+        self.num_voxels_viewdir = num_voxels_viewdir
+        self.num_voxels_base_density, self.num_voxels_base_rgb = num_voxels_base_density, num_voxels_base_rgb
+        vol = (self.xyz_max - self.xyz_min).prod()
+        self.voxel_size_base_density = (vol / num_voxels_base_density).pow(1 / 3)
+        self.voxel_size_base_rgb = (vol / num_voxels_base_rgb).pow(1 / 3)
+        self._set_grid_resolution(num_voxels_density, num_voxels_rgb)
+        self.alpha_init = alpha_init
+        self.register_buffer('act_shift', torch.FloatTensor([np.log(1 / (1 - alpha_init) - 1)]))
+        self.density_type, self.k0_type = density_type, k0_type
+        self.density_config, self.k0_config = density_config, k0_config
+        self.world_size = self.world_size_density
+        self.density = self._make_grid(1, self.world_size_density, True)
+        self.rgbnet_kwargs = {'rgbnet_dim': rgbnet_dim, 'rgbnet_depth': rgbnet_depth, 'rgbnet_width': rgbnet_width,
+                              'viewbase_pe': viewbase_pe}
+        self.sample_num = kwargs.get('sample_num', -1)
+        self.vd = None
+        if rgbnet_dim <= 0:                       # coarse stage: a plain 3-channel colour grid
+            self.k0_dim = 3
+            self.k0 = self._make_grid(3, self.world_size_rgb, False)
+            self.rgbnet = None
+        else:                                     # feature grid + shallow MLP on [k0, view-direction embedding]
+            self.k0_dim = rgbnet_dim
+            self.k0 = self._make_grid(rgbnet_dim, self.world_size_rgb, True)
+            self.register_buffer('viewfreq', torch.FloatTensor([(2 ** i) for i in range(viewbase_pe)]))
+            layers = [nn.Linear(3 + 6 * viewbase_pe + rgbnet_dim, rgbnet_width), nn.ReLU(inplace=True)]
+            layers += [nn.Sequential(nn.Linear(rgbnet_width, rgbnet_width), nn.ReLU(inplace=True))
+                       for _ in range(rgbnet_depth - 2)]
+            layers += [nn.Linear(rgbnet_width, 3)]
+            self.rgbnet = nn.Sequential(*layers)
+            nn.init.constant_(self.rgbnet[-1].bias, 0)
+        if mask_cache_world_size is None:
+            mask_cache_world_size = self.world_size_density
+        self.mask_cache = self._make_mask(torch.ones(list(mask_cache_world_size), dtype=torch.bool))
+
+    # -- construction helpers ------------------------------------------------------------------------------
+    def _make_grid(self, channels, world_size, fourier):
+        g = _grid.FourierGrid(channels=channels, world_size=world_size, xyz_min=self.xyz_min, xyz_max=self.xyz_max,
+                              use_nerf_pos=fourier, fourier_freq_num=self.fourier_freq_num, config=None)
+        g.query_fn, g.tv_module = self._be.grid_query, self._be.total_variation_cuda
+        return g
+
+    def _make_mask(self, mask):
+        m = _grid.MaskGrid(path=None, mask=mask, xyz_min=self.xyz_min, xyz_max=self.xyz_max)
+        m.lookup_module = self._be.render_utils_cuda
+        return m
+
+    def _set_grid_resolution(self, num_voxels_density, num_voxels_rgb):
+        self.num_voxels_density, self.num_voxels_rgb = num_voxels_density, num_voxels_rgb
+        ext = self.xyz_max - self.xyz_min
+        self.voxel_size_density = (ext.prod() / num_voxels_density).pow(1 / 3)
+        self.voxel_size_rgb = (ext.prod() / num_voxels_rgb).pow(1 / 3)
+        self.world_size_density = (ext / self.voxel_size_density).long()
+        self.world_size_rgb = (ext / self.voxel_size_rgb).long()
+        self.world_len_density = self.world_size_density[0].item()
+        self.world_len_rgb = self.world_size_rgb[0].item()
+        self.voxel_size_ratio_density = self.voxel_size_density / self.voxel_size_base_density
+        self.voxel_size_ratio_rgb = self.voxel_size_rgb / self.voxel_size_base_rgb
+
+    def get_kwargs(self):
+        """What the reference stores as `model_kwargs` in its checkpoints (FourierGrid_model.py:350-373)."""
+        return {
+            'xyz_min': self.xyz_min.cpu().numpy(), 'xyz_max': self.xyz_max.cpu().numpy(),
+            'num_voxels_density': self.num_voxels_density, 'num_voxels_rgb': self.num_voxels_rgb,
+            'num_voxels_viewdir': self.num_voxels_viewdir, 'fourier_freq_num': self.fourier_freq_num,
+            'num_voxels_base_density': self.num_voxels_base_density, 'num_voxels_base_rgb': self.num_voxels_base_rgb,
+            'alpha_init': self.alpha_init, 'voxel_size_ratio_density': self.voxel_size_ratio_density,
+            'voxel_size_ratio_rgb': self.voxel_size_ratio_rgb,
+            'mask_cache_world_size': list(self.mask_cache.mask.shape), 'fast_color_thres': self.fast_color_thres,
+            'contracted_norm': self.contracted_norm, 'density_type': self.density_type, 'k0_type': self.k0_type,
+            'density_config': self.density_config, 'k0_config': self.k0_config, 'sample_num': self.sample_num,
+            **self.rgbnet_kwargs,
+        }
+
+    # -- the pieces run_train.py calls -----------------------------------------------------------------------
+    def activate_density(self, density, interval=None):
+        interval = interval if interval is not None else self.voxel_size_ratio_density
+        return self._be.Raw2Alpha.apply(density.flatten(), self.act_shift, interval).reshape(density.shape)
+
+    def density_total_variation_add_grad(self, weight, dense_mode):
+        w = weight * self.world_size_density.max() / 128
+        self.density.total_variation_add_grad(w, w, w, dense_mode)
+
+    def k0_total_variation_add_grad(self, weight, dense_mode):
+        w = weight * self.world_size_rgb.max() / 128
+        self.k0.total_variation_add_grad(w, w, w, dense_mode)
+
+    def _cell_centres(self, shape):
+        axes = [torch.linspace(float(self.xyz_min[a]), float(self.xyz_max[a]), int(shape[a])) for a in range(3)]
+        return torch.stack(torch.meshgrid(*axes, indexing='ij'), -1).to(self.xyz_min.device)
+
+    @torch.no_grad()
+    def scale_volume_grid(self, num_voxels_density, num_voxels_rgb):
+        """Coarse-to-fine step (FourierGrid_model.py:421-437): resample both grids trilinearly to the new resolution and
+        rebuild the mask cache at that resolution from the old cache and the max-pooled alpha of level 0."""
+        self._set_grid_resolution(num_voxels_density, num_voxels_rgb)
+        self.density.scale_volume_grid(self.world_size_density)
+        self.k0.scale_volume_grid(self.world_size_rgb)
+        self.world_size = self.world_size_density
+        if np.prod(self.world_size_density.tolist()) <= 256 ** 3:
+            xyz = self._cell_centres(self.world_size_density.tolist())
+            alpha = F.max_pool3d(self.activate_density(self.density.get_dense_grid()), kernel_size=3, padding=1, stride=1)[0, 0]
+            self.mask_cache = self._make_mask(self.mask_cache(xyz) & (alpha > self.fast_color_thres)).to(xyz.device)
+
+    @torch.no_grad()
+    def update_occupancy_cache(self):
+        """AND the mask cache with (3x3x3 max-pooled alpha at the cache's own vertices > fast_color_thres)
+        (FourierGrid_model.py:440-453)."""
+        xyz = self._cell_centres(self.mask_cache.mask.shape)
+        alpha = self.activate_density(self.density(xyz)[None, None])
+        alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1)[0, 0]
+        self.mask_cache.mask &= (alpha > self.fast_color_thres)
+
+    # -- forward ---------------------------------------------------------------------------------------------
+    def sample_ray(self, ori_rays_o, ori_rays_d, stepsize, **unused):
+        """Mid-point samples shared by all rays, contracted outside the unit cube / ball (:509-552)."""
+        o = (ori_rays_o - self.scene_center) / self.scene_radius
+        d = ori_rays_d / ori_rays_d.norm(dim=-1, keepdim=True)
+        n_inner = int(2 / (2 + 2 * self.bg_len) * self.world_len_density / stepsize) + 1
+        edge_in = torch.linspace(0, 1.5, n_inner + 1)
+        edge_out = 1.5 / torch.linspace(1, 1 / 128, n_inner + 1)
+        t = torch.cat([(edge_in[1:] + edge_in[:-1]) * 0.5, (edge_out[1:] + edge_out[:-1]) * 0.5]).to(o.device)
+        pts = o[:, None, :] + d[:, None, :] * t[None, :, None]
+        if self.contracted_norm == 'inf':
+            nrm = pts.abs().amax(dim=-1, keepdim=True)
+        elif self.contracted_norm == 'l2':
+            nrm = pts.norm(dim=-1, keepdim=True)
+        else:
+            raise NotImplementedError
+        B = 1 + self.bg_len
+        A = B * 1.0 - 1.0
+        inner = nrm <= 1.0
+        pts = torch.where(inner, pts, pts / nrm * (B - A / nrm))
+        return pts, inner.squeeze(-1), t
+
+    def forward(self, rays_o, rays_d, viewdirs, global_step=None, is_train=False, **render_kwargs):
+        assert rays_o.dim() == 2 and rays_o.shape[-1] == 3, 'Only support point queries in [N, 3] format'
+        if self._fast_color_thres is not None and global_step in self._fast_color_thres:
+            self.fast_color_thres = self._fast_color_thres[global_step]
+        R = rays_o.shape[0]
+        pts, inner, t = self.sample_ray(rays_o, rays_d, **render_kwargs)
+        S = t.numel()
+        dev = pts.device
+        interval = render_kwargs['stepsize'] * self.voxel_size_ratio_density
+        ray_id = torch.arange(R, device=dev).view(-1, 1).expand(R, S).flatten()
+        step_id = torch.arange(S, device=dev).view(1, -1).expand(R, S).flatten()
+        tt = t[None].repeat(R, 1)
+        density = self.density(pts)
+        alpha = self.activate_density(density, interval)
+        if self.fast_color_thres > 0:
+            keep = alpha > self.fast_color_thres
+            pts, inner, tt, density, alpha = pts[keep], inner[keep], tt[keep], density[keep], alpha[keep]
+            ray_id, step_id = ray_id[keep.flatten()], step_id[keep.flatten()]
+        weights, alphainv_last = self._be.Alphas2Weights.apply(alpha, ray_id, R)
+        if self.fast_color_thres > 0:
+            keep = weights > self.fast_color_thres
+            pts, inner, tt, density, alpha, weights = pts[keep], inner[keep], tt[keep], density[keep], alpha[keep], weights[keep]
+            ray_id, step_id = ray_id[keep], step_id[keep]
+        else:
+            pts, weights, inner = pts.reshape(-1, 3), weights.reshape(-1), inner.reshape(-1)
+        k0 = self.k0(pts)
+        if self.rgbnet is None:
+            rgb = torch.sigmoid(k0)
+        else:
+            e = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
+            emb = torch.cat([viewdirs, e.sin(), e.cos()], -1).flatten(0, -2)[ray_id]
+            rgb = torch.sigmoid(self.rgbnet(torch.cat([k0, emb], -1)))
+        rgb_marched = torch.zeros(R, 3, device=dev).index_add_(0, ray_id, weights.unsqueeze(-1) * rgb)
+        if render_kwargs.get('rand_bkgd', False):
+            rgb_marched = rgb_marched + alphainv_last.unsqueeze(-1) * torch.rand_like(rgb_marched)
+        s = 1 - 1 / (1 + tt)
+        out = {'alphainv_last': alphainv_last, 'weights': weights, 'rgb_marched': rgb_marched, 'raw_density': density,
+               'raw_alpha': alpha, 'raw_rgb': rgb, 'ray_id': ray_id, 'step_id': step_id, 'n_max': S, 't': tt, 's': s}
+        if render_kwargs.get('render_depth', False):
+            with torch.no_grad():
+                out['depth'] = torch.zeros(R, device=dev).index_add_(0, ray_id, weights * s)
+        return out

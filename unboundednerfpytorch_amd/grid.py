@@ -86,9 +86,15 @@ class FourierGrid(torch.nn.Module):
             self.pos_embed_output_dim = -1
             self.grid = torch.nn.Parameter(torch.zeros([1, channels, *world_size]))
 
+    # test hooks: another implementation of the lookup (differentiable, fourier_grid_query's signature) and of the
+    # total_variation_cuda module; None = the HIP kernels
+    query_fn = None
+    tv_module = None
+
     def forward(self, xyz):
         """xyz [..., 3] world coordinates -> [..., C] (squeezed when C == 1)"""
-        return GridQuery.apply(self.grid, xyz, self.xyz_min, self.xyz_max, self.nerf_pos_num_freq)
+        q = self.query_fn or GridQuery.apply
+        return q(self.grid, xyz, self.xyz_min, self.xyz_max, self.nerf_pos_num_freq)
 
     def scale_volume_grid(self, new_world_size):
         if self.channels == 0:
@@ -99,8 +105,10 @@ class FourierGrid(torch.nn.Module):
 
     def total_variation_add_grad(self, wx, wy, wz, dense_mode):
         """Add the total-variation gradient in place (total_variation_kernel.cu:14-67)."""
-        from . import total_variation_cuda
-        total_variation_cuda.total_variation_add_grad(self.grid, self.grid.grad, wx, wy, wz, dense_mode)
+        tv = self.tv_module
+        if tv is None:
+            from . import total_variation_cuda as tv
+        tv.total_variation_add_grad(self.grid, self.grid.grad, wx, wy, wz, dense_mode)
 
     def get_dense_grid(self):
         return self.grid
@@ -140,11 +148,13 @@ class MaskGrid(torch.nn.Module):
         self.register_buffer('xyz2ijk_scale', scale)
         self.register_buffer('xyz2ijk_shift', -xyz_min * scale)
 
+    lookup_module = None    # test hook: another implementation of render_utils_cuda; None = the HIP kernels
+
     @torch.no_grad()
     def forward(self, xyz):
         shape = xyz.shape[:-1]
-        out = render_utils_cuda.maskcache_lookup(self.mask, xyz.reshape(-1, 3).contiguous(), self.xyz2ijk_scale,
-                                                 self.xyz2ijk_shift)
+        ru = self.lookup_module or render_utils_cuda
+        out = ru.maskcache_lookup(self.mask, xyz.reshape(-1, 3).contiguous(), self.xyz2ijk_scale, self.xyz2ijk_shift)
         return out.reshape(shape)
 
     def extra_repr(self):
