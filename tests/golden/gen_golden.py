@@ -310,6 +310,71 @@ def gen_model_utils():
         res["occ_mask"].mean(), res["scaled_world_size"].tolist(), res["scaled_mask"].mean(), float(res["scaled_ratio"])))
 
 
+class _Cfg(dict):
+    """dict with attribute access, like the mmengine Config the reference passes around"""
+    __getattr__ = dict.__getitem__
+
+
+TRAIN_CFG = dict(lrate_density=1e-1, lrate_k0=1e-1, lrate_rgbnet=1e-3, lrate_viewfreq=0.5, lrate_nosuchfield=1.0,
+                 lrate_decay=20, skip_zero_grad_fields=['density', 'k0'])
+
+
+def gen_train_utils():
+    """utils.create_optimizer_or_freeze_model (utils.py:26-56) on the reference model: the param groups it builds (lr,
+    skip flag, parameter shapes) at two global steps and with a frozen field.  Also the reverse direction of the
+    checkpoint interchange: a checkpoint written by THIS package's save_checkpoint from its own FourierGridModel is
+    loaded by the reference's load_model and must render identically (checked here, recorded as a flag)."""
+    mod = install_stubs.import_reference("FourierGrid_model")
+    utils = install_stubs.import_reference("utils")
+    c = synth.MODEL_UTILS_CASE
+    params = synth.fouriergrid_params(c["seed"], c["G"], c["F"], c["C"], viewbase_pe=c["pe"], dens_mean=c["dm"], dens_std=c["ds"])
+    res = {}
+    for tag, step, over in (("a", 0, {}), ("b", 5000, {}), ("c", 300, {"lrate_rgbnet": 0.0})):
+        model = build_reference_model(mod, c["G"], c["F"], c["C"], c["pe"], c["norm"], c["thres"], params)
+        opt = utils.create_optimizer_or_freeze_model(model, _Cfg({**TRAIN_CFG, **over}), global_step=step)
+        res[tag + "_lr"] = np.array([g["lr"] for g in opt.param_groups], dtype=np.float64)
+        res[tag + "_skip"] = np.array([bool(g["skip_zero_grad"]) for g in opt.param_groups])
+        res[tag + "_shapes"] = np.array([";".join(str(tuple(p.shape)) for p in g["params"]) for g in opt.param_groups])
+        res[tag + "_frozen"] = np.array(sorted(n for n, p in model.named_parameters() if not p.requires_grad))
+    # reverse checkpoint direction
+    import tempfile
+    from types import SimpleNamespace
+    from oracle import model_oracle, ref_ops
+    from unboundednerfpytorch_amd.fourier_model import FourierGridModel as Mine
+    from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model, save_checkpoint
+    R2A, A2W = model_oracle.make_autograd_ops(ref_ops)
+    be = SimpleNamespace(Raw2Alpha=R2A, Alphas2Weights=A2W, grid_query=model_oracle.fourier_grid_query,
+                         total_variation_cuda=ref_ops.total_variation_cuda, render_utils_cuda=ref_ops.render_utils_cuda)
+    mine = Mine(xyz_min=[-2.0, -1.0, -3.0], xyz_max=[2.0, 3.0, 1.0], num_voxels_density=9 ** 3, num_voxels_base_density=12 ** 3,
+                num_voxels_rgb=9 ** 3, num_voxels_base_rgb=12 ** 3, num_voxels_viewdir=-1, alpha_init=1e-3,
+                fast_color_thres=1e-4, fourier_freq_num=2, rgbnet_dim=12, backend=be)
+    p2 = synth.fouriergrid_params(41, int(mine.world_len_density), 2, 12, dens_mean=4.0, dens_std=10.0)
+    sd = mine.state_dict()
+    with torch.no_grad():
+        for k, v in p2.items():
+            sd[k].copy_(torch.from_numpy(v))
+    opt = create_optimizer_or_freeze_model(mine, TRAIN_CFG, 0, ops=ref_ops)
+    path = os.path.join(tempfile.mkdtemp(), "mine_last.tar")
+    save_checkpoint(path, mine, opt, 77)
+    import functools
+    orig_load = torch.load        # the reference calls torch.load(path) (torch 1.13 semantics: full unpickling)
+    torch.load = functools.partial(orig_load, weights_only=False)
+    try:
+        theirs = utils.load_model(mod.FourierGridModel, path)
+    finally:
+        torch.load = orig_load
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(41, 64, origin_scale=0.6)]
+    o = o + torch.tensor([0.0, 1.0, -1.0])
+    with torch.no_grad():
+        a = mine(o, d, v, stepsize=0.5, render_depth=True)
+        b = theirs(o, d, v, stepsize=0.5, render_depth=True)
+    same = all(torch.equal(a[k], b[k]) for k in ("rgb_marched", "depth", "alphainv_last", "weights", "ray_id"))
+    assert same, "reference model loaded from this package's checkpoint renders differently"
+    res["reverse_checkpoint_ok"] = np.int64(1)
+    np.savez_compressed(os.path.join(HERE, "train_utils.npz"), **res)
+    print("train_utils", {k: v.tolist() for k, v in res.items() if k.endswith("_lr")}, "reverse ckpt ok")
+
+
 def gen_dcvgo():
     """dcvgo.DirectContractedVoxGO.forward (contracted unbounded DVGOv2: cumdist_thres, mask cache, dense grids);
     num_voxels != num_voxels_base so that voxel_size_ratio != 1, a non-trivial mask, a scene cube off the origin."""
@@ -380,3 +445,4 @@ if __name__ == "__main__":
     gen_dcvgo()
     gen_dvgo_utils()
     gen_model_utils()
+    gen_train_utils()
