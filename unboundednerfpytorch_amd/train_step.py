@@ -1,0 +1,85 @@
+"""One iteration of the reference's training loop (run_train.py:185-296) on this package's model and optimizers:
+progressive grid scaling at the `pg_scale` steps, forward, the loss terms the train config switches on, backward, the
+total-variation gradient inside its step window, the (masked) Adam step and the continuous learning-rate decay.
+Data loading, ray-batch sampling, logging and checkpoint scheduling stay with the caller (the reference's
+`scene_rep_reconstruction` does them inline around these lines)."""
+import torch
+import torch.nn.functional as F
+
+from .train_utils import create_optimizer_or_freeze_model
+
+
+def _get(cfg, key, default=None):
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default)
+
+
+def fourier_mse_loss(pred, gt):
+    """MSE between the real parts of the FFTs over the colour axis (FourierMSELoss, FourierGrid_model.py:115-133)."""
+    return F.mse_loss(torch.fft.fft(pred, dim=-1).real, torch.fft.fft(gt, dim=-1).real)
+
+
+def maybe_scale_grids(model, optimizer, cfg_train, cfg_model, global_step, **optimizer_kw):
+    """run_train.py:186-201: at a `pg_scale` step the grids grow to num_voxels / 2^(scales still to come), the
+    optimizer is rebuilt (its state refers to the old grids) and the density bias is lowered by `decay_after_scale`."""
+    pg = list(_get(cfg_train, 'pg_scale', []))
+    if global_step not in pg:
+        return optimizer
+    rest = len(pg) - pg.index(global_step) - 1
+    model.scale_volume_grid(int(_get(cfg_model, 'num_voxels_density') / (2 ** rest)),
+                            int(_get(cfg_model, 'num_voxels_rgb') / (2 ** rest)))
+    optimizer = create_optimizer_or_freeze_model(model, cfg_train, global_step=0, **optimizer_kw)
+    model.act_shift -= _get(cfg_train, 'decay_after_scale', 0.0)
+    return optimizer
+
+
+def training_loss(render_result, target, cfg_train, n_rays, near_thres=None, distortion_fn=None):
+    """The loss of run_train.py:254-279 from the model's return dict.  near_thres = near_clip / scene_radius[0] when
+    weight_nearclip is used; distortion_fn(w, s, n_max, ray_id) defaults to ops.distortion_loss."""
+    mse = F.mse_loss(render_result['rgb_marched'], target)
+    loss = _get(cfg_train, 'weight_main', 1.0) * mse
+    w_freq = _get(cfg_train, 'weight_freq', 0.0)
+    if w_freq:
+        loss = loss + w_freq * fourier_mse_loss(render_result['rgb_marched'], target)
+    if _get(cfg_train, 'weight_entropy_last', 0.0) > 0:
+        p = render_result['alphainv_last'].clamp(1e-6, 1 - 1e-6)
+        loss = loss + _get(cfg_train, 'weight_entropy_last') * (-(p * torch.log(p) + (1 - p) * torch.log(1 - p))).mean()
+    if _get(cfg_train, 'weight_nearclip', 0.0) > 0:
+        d = render_result['raw_density'][render_result['t'] < near_thres]
+        if len(d):
+            loss = loss + _get(cfg_train, 'weight_nearclip') * (d - d.detach()).sum()
+    if _get(cfg_train, 'weight_distortion', 0.0) > 0 and render_result['weights'].numel() > 0:
+        if distortion_fn is None:
+            from .ops import distortion_loss as distortion_fn
+        loss = loss + _get(cfg_train, 'weight_distortion') * distortion_fn(
+            render_result['weights'], render_result['s'], render_result['n_max'], render_result['ray_id'])
+    if _get(cfg_train, 'weight_rgbper', 0.0) > 0:
+        per = (render_result['raw_rgb'] - target[render_result['ray_id']]).pow(2).sum(-1)
+        loss = loss + _get(cfg_train, 'weight_rgbper') * (per * render_result['weights'].detach()).sum() / n_rays
+    return loss, mse
+
+
+def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_train, global_step, render_kwargs,
+                    near_thres=None, distortion_fn=None, decay_lr=True):
+    """Forward ... optimizer.step() of one global_step (call maybe_scale_grids first).  Returns (loss, psnr)."""
+    out = model(rays_o, rays_d, viewdirs, global_step=global_step, is_train=True, **render_kwargs)
+    optimizer.zero_grad(set_to_none=True)
+    n_rays = len(rays_o)
+    loss, mse = training_loss(out, target, cfg_train, n_rays, near_thres, distortion_fn)
+    loss.backward()
+    tv_on = (global_step < _get(cfg_train, 'tv_before', 0) and global_step > _get(cfg_train, 'tv_after', 0)
+             and global_step % _get(cfg_train, 'tv_every', 1) == 0)
+    if tv_on:
+        dense = global_step < _get(cfg_train, 'tv_dense_before', 0)
+        if _get(cfg_train, 'weight_tv_density', 0.0) > 0:
+            model.density_total_variation_add_grad(_get(cfg_train, 'weight_tv_density') / n_rays, dense)
+        if _get(cfg_train, 'weight_tv_k0', 0.0) > 0:
+            model.k0_total_variation_add_grad(_get(cfg_train, 'weight_tv_k0') / n_rays, dense)
+    optimizer.step()
+    if decay_lr:                      # run_train.py:290-295 (the reference skips this for FourierGrid on tankstemple)
+        factor = 0.1 ** (1 / (_get(cfg_train, 'lrate_decay') * 1000))
+        for g in optimizer.param_groups:
+            g['lr'] = g['lr'] * factor
+    psnr = -10.0 * torch.log10(mse.detach())
+    return float(loss.detach()), float(psnr)
