@@ -239,3 +239,73 @@ def test_bench_parity_stats_fields():
     st2 = bench.parity_stats(err[:3], margin[:3], sq_rgb=1.0)
     assert abs(st2["linf_margin_gt_0.01"] - 1e-6) < 1e-10
     assert "note" in st
+
+
+# ---------------------------------------------------------------------------------------------------------
+# data-parallel training: 2 ranks (gloo), each with half of the ray batch and ShardedMaskedAdam, against the
+# single-process step on the whole batch (model = fourier_model.FourierGridModel with the oracle back-end)
+# ---------------------------------------------------------------------------------------------------------
+def _dp_setup():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import synth
+    import test_fourier_model as T
+    c = dict(synth.MODEL_UTILS_CASE, dm=0.5, ds=2.0)
+    cfg = dict(T.TRAIN_CFG, weight_main=1.0, weight_entropy_last=0.001, weight_tv_density=1e-4, weight_tv_k0=1e-5, tv_after=0,
+               tv_before=10, tv_every=1, tv_dense_before=10)   # dense TV: see train_iteration on masked TV under DP
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(77, 128)]
+    target = torch.sigmoid(torch.from_numpy(synth.normal(78, 128 * 3).reshape(128, 3)))
+    return T, c, cfg, (o, d, v, target)
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from oracle import ref_ops
+    from unboundednerfpytorch_amd import train_step as ts
+    from unboundednerfpytorch_amd.sharded_adam import ShardedMaskedAdam
+    from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
+    T, c, cfg, (o, d, v, target) = _dp_setup()
+    m = T.build(c)
+    opt = create_optimizer_or_freeze_model(m, cfg, 0, sharded=True, ops=ref_ops)
+    opt.min_shard_numel = 256
+    assert isinstance(opt, ShardedMaskedAdam)
+    sl = slice(rank * 64, (rank + 1) * 64)
+    for step in (1, 2):
+        ts.train_iteration(m, opt, o[sl], d[sl], v[sl], target[sl], cfg, step, dict(stepsize=0.5), world_size=world)
+    q.put((rank, {k: p.detach().numpy().copy() for k, p in m.named_parameters()},     # numpy: pickled by value
+           opt.state[m.k0.grid]['exp_avg'].numel()))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_matches_single_process_gloo():
+    from oracle import ref_ops
+    from unboundednerfpytorch_amd import train_step as ts
+    from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    # single process, whole batch
+    torch.set_num_threads(1)
+    T, c, cfg, (o, d, v, target) = _dp_setup()
+    m = T.build(c)
+    opt = create_optimizer_or_freeze_model(m, cfg, 0, ops=ref_ops)
+    for step in (1, 2):
+        ts.train_iteration(m, opt, o, d, v, target, cfg, step, dict(stepsize=0.5))
+    ref = {k: p.detach() for k, p in m.named_parameters()}
+    for k in ref:
+        assert np.array_equal(res[0][1][k], res[1][1][k]), k                   # the ranks stay in lock-step
+        diff = (torch.from_numpy(res[0][1][k]) - ref[k]).abs()
+        lr = 0.1 if 'grid' in k else 1e-3
+        # the mean-of-halves gradient equals the whole-batch gradient up to summation order; Adam's first steps move
+        # an entry by ~lr whatever its gradient's size, so compare against a fraction of one step
+        assert float((diff > 0.05 * lr).float().mean()) < 5e-3, (k, float(diff.max()))
+    assert res[0][2] == m.k0.grid.numel() // 2                                 # k0's Adam state is split over the ranks

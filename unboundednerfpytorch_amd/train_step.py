@@ -61,8 +61,15 @@ def training_loss(render_result, target, cfg_train, n_rays, near_thres=None, dis
 
 
 def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_train, global_step, render_kwargs,
-                    near_thres=None, distortion_fn=None, decay_lr=True):
-    """Forward ... optimizer.step() of one global_step (call maybe_scale_grids first).  Returns (loss, psnr)."""
+                    near_thres=None, distortion_fn=None, decay_lr=True, world_size=1):
+    """Forward ... optimizer.step() of one global_step (call maybe_scale_grids first).  Returns (loss, psnr).
+    Data-parallel use (ShardedMaskedAdam averages the ranks' gradients): pass world_size so that the total-variation
+    term, which the reference scales by 1 / len(rays_o), is scaled by the GLOBAL batch size -- the ray-mean losses
+    need no change (mean over the local rays, then mean over ranks).  With that the data-parallel step equals the
+    single-process step on the whole batch while the TV pass is dense (tests/test_host_logic.py).  In the masked TV
+    phase (global_step >= tv_dense_before) a difference remains: each rank applies TV where ITS rays left a non-zero
+    gradient, before the reduction, so a voxel touched by k of N ranks receives k/N of the TV term; exact
+    equivalence needs the TV pass on the reduced gradient shard (a ranged TV kernel: next round)."""
     out = model(rays_o, rays_d, viewdirs, global_step=global_step, is_train=True, **render_kwargs)
     optimizer.zero_grad(set_to_none=True)
     n_rays = len(rays_o)
@@ -73,9 +80,9 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
     if tv_on:
         dense = global_step < _get(cfg_train, 'tv_dense_before', 0)
         if _get(cfg_train, 'weight_tv_density', 0.0) > 0:
-            model.density_total_variation_add_grad(_get(cfg_train, 'weight_tv_density') / n_rays, dense)
+            model.density_total_variation_add_grad(_get(cfg_train, 'weight_tv_density') / (n_rays * world_size), dense)
         if _get(cfg_train, 'weight_tv_k0', 0.0) > 0:
-            model.k0_total_variation_add_grad(_get(cfg_train, 'weight_tv_k0') / n_rays, dense)
+            model.k0_total_variation_add_grad(_get(cfg_train, 'weight_tv_k0') / (n_rays * world_size), dense)
     optimizer.step()
     if decay_lr:                      # run_train.py:290-295 (the reference skips this for FourierGrid on tankstemple)
         factor = 0.1 ** (1 / (_get(cfg_train, 'lrate_decay') * 1000))
