@@ -227,8 +227,13 @@ def test_train_iteration_schedule_and_losses():
     assert abs(float(loss) - float(want)) <= 1e-6 * max(1.0, abs(float(want)))
     # schedule
     calls, cur = [], {"step": 0}
-    orig = m.density.total_variation_add_grad
-    m.density.total_variation_add_grad = lambda *a: (calls.append((cur["step"], a[3])), orig(*a))[1]
+
+    class _RecordingTV:      # the TV term reaches the density grid through its tv_module (train_step's grad_hook)
+        @staticmethod
+        def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
+            calls.append((cur["step"], dense_mode))
+            return ref_ops.total_variation_cuda.total_variation_add_grad(param, grad, wx, wy, wz, dense_mode)
+    m.density.tv_module = _RecordingTV
     shifts, sizes, psnrs = [], [], []
     for step in range(1, 9):
         cur["step"] = step

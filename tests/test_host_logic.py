@@ -251,7 +251,7 @@ def _dp_setup():
     import test_fourier_model as T
     c = dict(synth.MODEL_UTILS_CASE, dm=0.5, ds=2.0)
     cfg = dict(T.TRAIN_CFG, weight_main=1.0, weight_entropy_last=0.001, weight_tv_density=1e-4, weight_tv_k0=1e-5, tv_after=0,
-               tv_before=10, tv_every=1, tv_dense_before=10)   # dense TV: see train_iteration on masked TV under DP
+               tv_before=10, tv_every=1, tv_dense_before=2)     # step 1 dense TV, step 2 masked TV
     o, d, v = [torch.from_numpy(a) for a in synth.rays(77, 128)]
     target = torch.sigmoid(torch.from_numpy(synth.normal(78, 128 * 3).reshape(128, 3)))
     return T, c, cfg, (o, d, v, target)

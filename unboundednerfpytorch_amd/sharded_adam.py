@@ -70,7 +70,10 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
             self.ops.adam_upd(p, g, m, v, *args)
 
     @torch.no_grad()
-    def step(self):
+    def step(self, grad_hook=None):
+        """grad_hook(param, grad): optional in-place edit of the REDUCED gradient before the update (the training
+        iteration uses it for the total-variation term, which must see the gradient summed over all ranks).  For a
+        sharded parameter the hook receives a full-shape gradient that is zero outside this rank's range."""
         world, rank = self._world()
         scale = (1.0 / world) if (self.average and world > 1) else None
         for group in self.param_groups:
@@ -88,6 +91,8 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                         dist.all_reduce(g, group=self.group)
                         if scale is not None:
                             g.mul_(scale)
+                    if grad_hook is not None:
+                        grad_hook(param, g)
                     if len(state) == 0:
                         state['step'] = 0
                         state['exp_avg'] = torch.zeros_like(param, memory_format=torch.preserve_format)
@@ -117,6 +122,12 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                 dist.reduce_scatter_tensor(g_shard, flat_g, group=self.group)
                 if scale is not None:
                     g_shard.mul_(scale)
+                if grad_hook is not None:
+                    full_g = torch.zeros(n, dtype=g_shard.dtype, device=g_shard.device)
+                    full_g[b:e] = g_shard[: e - b]
+                    grad_hook(param, full_g.view_as(param))
+                    g_shard[: e - b] = full_g[b:e]
+                    del full_g
                 if exact:
                     p_shard = flat_p[b:b + per]                  # a view: updated in place
                 else:

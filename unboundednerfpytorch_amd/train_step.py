@@ -65,11 +65,9 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
     """Forward ... optimizer.step() of one global_step (call maybe_scale_grids first).  Returns (loss, psnr).
     Data-parallel use (ShardedMaskedAdam averages the ranks' gradients): pass world_size so that the total-variation
     term, which the reference scales by 1 / len(rays_o), is scaled by the GLOBAL batch size -- the ray-mean losses
-    need no change (mean over the local rays, then mean over ranks).  With that the data-parallel step equals the
-    single-process step on the whole batch while the TV pass is dense (tests/test_host_logic.py).  In the masked TV
-    phase (global_step >= tv_dense_before) a difference remains: each rank applies TV where ITS rays left a non-zero
-    gradient, before the reduction, so a voxel touched by k of N ranks receives k/N of the TV term; exact
-    equivalence needs the TV pass on the reduced gradient shard (a ranged TV kernel: next round)."""
+    need no change (mean over the local rays, then mean over ranks).  TV itself runs inside optimizer.step on the
+    REDUCED gradient (grad_hook), so its masked mode sees the voxels any rank touched: the data-parallel step equals
+    the single-process step on the whole batch in both TV phases (tests/test_host_logic.py)."""
     out = model(rays_o, rays_d, viewdirs, global_step=global_step, is_train=True, **render_kwargs)
     optimizer.zero_grad(set_to_none=True)
     n_rays = len(rays_o)
@@ -77,13 +75,30 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
     loss.backward()
     tv_on = (global_step < _get(cfg_train, 'tv_before', 0) and global_step > _get(cfg_train, 'tv_after', 0)
              and global_step % _get(cfg_train, 'tv_every', 1) == 0)
+    hook = None
     if tv_on:
+        # run_train.py:281-287.  The TV term is applied to the gradient the optimizer is about to use -- through the
+        # optimizer's grad_hook, i.e. AFTER the cross-rank reduction in data-parallel runs (in a single process that is
+        # exactly "TV, then step").  weight / batch size, then the models' own scaling by world_size.max() / 128.
         dense = global_step < _get(cfg_train, 'tv_dense_before', 0)
+        n_global = n_rays * world_size
+        terms = []
         if _get(cfg_train, 'weight_tv_density', 0.0) > 0:
-            model.density_total_variation_add_grad(_get(cfg_train, 'weight_tv_density') / (n_rays * world_size), dense)
+            terms.append((model.density, _get(cfg_train, 'weight_tv_density') / n_global * model.world_size_density.max() / 128))
         if _get(cfg_train, 'weight_tv_k0', 0.0) > 0:
-            model.k0_total_variation_add_grad(_get(cfg_train, 'weight_tv_k0') / (n_rays * world_size), dense)
-    optimizer.step()
+            terms.append((model.k0, _get(cfg_train, 'weight_tv_k0') / n_global * model.world_size_rgb.max() / 128))
+
+        def hook(param, grad):
+            for grid_module, w in terms:
+                if param is grid_module.grid:
+                    tv = grid_module.tv_module
+                    if tv is None:
+                        from . import total_variation_cuda as tv
+                    tv.total_variation_add_grad(param, grad, w, w, w, dense)
+    if hook is not None:
+        optimizer.step(grad_hook=hook)
+    else:
+        optimizer.step()
     if decay_lr:                      # run_train.py:290-295 (the reference skips this for FourierGrid on tankstemple)
         factor = 0.1 ** (1 / (_get(cfg_train, 'lrate_decay') * 1000))
         for g in optimizer.param_groups:
