@@ -305,6 +305,18 @@ def gen_model_utils():
     res["scaled_ratio"] = np.float32(float(model.voxel_size_ratio_density))
     kw = model.get_kwargs()
     res["kwargs_keys"] = np.array(sorted(kw.keys()))
+    # voxel_count_views on the rescaled model: three tiny views placed inside the unit cube
+    dvgo = install_stubs.import_reference("dvgo")
+    H, W, K, poses = synth.dvgo_views()
+    ro, rd = [], []
+    for c2w in poses:
+        c2w = c2w.copy(); c2w[:, 3] *= 0.25
+        o, d, _ = dvgo.get_rays_of_a_view(H=H, W=W, K=K, c2w=torch.from_numpy(c2w), ndc=False, inverse_y=False,
+                                          flip_x=False, flip_y=False)
+        ro.append(o); rd.append(d)
+    cnt = model.voxel_count_views(rays_o_tr=torch.stack(ro), rays_d_tr=torch.stack(rd), imsz=1, near=0.05, far=6.0,
+                                  stepsize=0.5, downrate=1, irregular_shape=False)
+    res["view_count"] = cnt.detach().numpy().copy()
     np.savez_compressed(os.path.join(HERE, "fg_model_utils.npz"), **res)
     print("model_utils: occupancy %.3f -> scaled world %s mask %.3f ratio %.4f" % (
         res["occ_mask"].mean(), res["scaled_world_size"].tolist(), res["scaled_mask"].mean(), float(res["scaled_ratio"])))

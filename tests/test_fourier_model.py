@@ -87,6 +87,18 @@ def test_model_utilities_match_the_reference_model(golden_dir):
     assert np.array_equal(m.mask_cache.mask.numpy(), gold["scaled_mask"])
     assert abs(float(m.voxel_size_ratio_density) - float(gold["scaled_ratio"])) < 1e-7
     assert sorted(m.get_kwargs().keys()) == gold["kwargs_keys"].tolist()
+    # voxel_count_views on the rescaled model (three tiny views inside the unit cube)
+    from unboundednerfpytorch_amd.fourier_render import get_rays_of_a_view
+    H, W, K, poses = synth.dvgo_views()
+    ro, rd = [], []
+    for c2w in poses:
+        c2w = c2w.copy(); c2w[:, 3] *= 0.25
+        o_, d_, _ = get_rays_of_a_view(H, W, K, torch.from_numpy(c2w))
+        ro.append(o_); rd.append(d_)
+    cnt = m.voxel_count_views(rays_o_tr=torch.stack(ro), rays_d_tr=torch.stack(rd), imsz=1, near=0.05, far=6.0,
+                              stepsize=0.5, downrate=1, irregular_shape=False)
+    assert cnt.shape == gold["view_count"].shape and float(gold["view_count"].max()) == 3.0
+    assert float((cnt.numpy() != gold["view_count"]).mean()) < 2e-3
     # the rescaled model still runs and its new grids receive gradients
     o, d, v = [torch.from_numpy(a) for a in synth.rays(3, 32)]
     out = m(o, d, v, global_step=2, is_train=True, stepsize=0.5)

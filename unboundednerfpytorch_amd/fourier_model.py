@@ -159,6 +159,36 @@ class FourierGridModel(nn.Module):
         alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1)[0, 0]
         self.mask_cache.mask &= (alpha > self.fast_color_thres)
 
+    def voxel_count_views(self, rays_o_tr, rays_d_tr, imsz, near, far, stepsize, downrate=1, irregular_shape=False):
+        """How many training views see each voxel of a plain grid of the density resolution (FourierGrid_model.py:
+        392-418): per image the trilinear footprint of its rays' samples is scattered into a zero grid (the lookup's
+        backward), a voxel counts as seen when it gathered more than 1."""
+        far = 1e9
+        dev = self.xyz_min.device
+        n_samples = int(np.linalg.norm(self.world_size_density.cpu().numpy().astype(np.float64) + 1) / stepsize) + 1
+        rng = torch.arange(n_samples, device=dev)[None].float()
+        shape = [1, 1] + self.world_size_density.tolist()
+        count = torch.zeros(self.density.get_dense_grid().shape, device=dev)
+        query = self._be.grid_query
+        if query is None:
+            query = _grid.GridQuery.apply
+        for o_img, d_img in zip(rays_o_tr.split(imsz), rays_d_tr.split(imsz)):
+            ones = torch.zeros(shape, device=dev).requires_grad_(True)
+            if irregular_shape:
+                o_chunks, d_chunks = o_img.split(10000), d_img.split(10000)
+            else:
+                o_chunks = o_img[::downrate, ::downrate].to(dev).flatten(0, -2).split(10000)
+                d_chunks = d_img[::downrate, ::downrate].to(dev).flatten(0, -2).split(10000)
+            for o, d in zip(o_chunks, d_chunks):
+                vec = torch.where(d == 0, torch.full_like(d, 1e-6), d)
+                t_min = torch.minimum((self.xyz_max - o) / vec, (self.xyz_min - o) / vec).amax(-1).clamp(min=near, max=far)
+                step = stepsize * self.voxel_size_density * rng
+                pts = o[..., None, :] + d[..., None, :] * (t_min[..., None] + step / d.norm(dim=-1, keepdim=True))[..., None]
+                query(ones, pts, self.xyz_min, self.xyz_max, 0).sum().backward()
+            with torch.no_grad():
+                count += (ones.grad > 1)
+        return count
+
     # -- forward ---------------------------------------------------------------------------------------------
     def sample_ray(self, ori_rays_o, ori_rays_d, stepsize, **unused):
         """Mid-point samples shared by all rays, contracted outside the unit cube / ball (:509-552)."""
