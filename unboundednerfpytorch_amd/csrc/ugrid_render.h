@@ -1,29 +1,30 @@
 // ugrid_render.h -- device code of the fused FourierGrid render path for gfx950 (MI355X), shared by
-// ugrid_march.hip (compiled with -fno-slp-vectorize: packed v_pk_*_f32 math is a measured LOSS for the
-// VALU-bound march kernel, 8.4 -> 7.0 ms) and ugrid_shade.hip (default flags: SLP helps there, 12.5 -> 11.7 ms).
+// ugrid_march.hip and ugrid_shade.hip (both compiled with -fno-slp-vectorize: packed v_pk_*_f32 math issues at
+// half rate on gfx950 and costs extra moves -- a 16 % loss for the VALU-bound march kernel, 1.3 % for shade).
 //
 // Replaces, for inference, the torch-op chain of the reference's FourierGridModel.forward
 // (FourierGrid/FourierGrid_model.py:509-672) and FourierGrid.forward (FourierGrid_grid.py:60-78):
 //
 //   k_march : 1 lane = 1 ray, 1 wave = 64 consecutive rays.  Per sample: contraction, Fourier
-//             level coordinates, ONE 32-byte brick load per level (the 2x2x2 neighbourhood of the
-//             trilinear cell, see DESIGN.md "brick layout"), mean over levels, raw2alpha, the two
+//             level coordinates, ONE 32-byte brick load per level (the 8 coefficients of the cell's
+//             trilinear polynomial), 7 FMAs, mean over levels, raw2alpha, the two
 //             thresholds and the front-to-back transmittance recurrence -- which is a plain serial
 //             multiply in the lane's registers because a lane owns a ray.  A wave leaves the sample
 //             loop as soon as all of its 64 rays have terminated (T < 1e-3) -- wave-level early
 //             termination by ballot.  Surviving samples are compacted per wave (ballot + mbcnt
 //             prefix) into that wave's private slice of the work list: no atomics, deterministic.
 //   k_shade : 1 wave walks one tile's survivor list 32 at a time.  Lanes l and l+32 form a pair
-//             that owns survivor (l&31): each gathers half of the k0 channels from the 2x2x2 k0
-//             bricks and half of the view-direction embedding, which makes their registers exactly
-//             the B operand of v_mfma_f32_32x32x2_f32 (B[k=l>>5][j=l&31]).  The rgbnet runs
-//             "transposed" (H^T = W . X^T) so every layer's accumulator registers are directly the
-//             next layer's B operands -- activations never leave the register file; packed weights
-//             (A operands) are read from LDS.  fp32-input MFMA is bit-wise an fmaf chain, so the
-//             MLP stays inside the 1e-4 parity budget (no bf16 anywhere).
+//             that owns survivor (l&31): each gathers half of the k0 channels from the k0 bricks and
+//             half of the view-direction embedding, which makes their registers exactly the B operand
+//             of the MFMA (B[k-half = l>>5][j = l&31]).  The rgbnet runs "transposed" (H^T = W . X^T) so
+//             every layer's accumulator registers are directly the next layer's B operands --
+//             activations never leave the register file; packed weights (A operands) are read from
+//             LDS.  Three fp32-accurate arithmetic modes: fp32 MFMA (bit-wise an fmaf chain), bf16x3
+//             (three-way bf16 split, 6 products) and fp16x2 (power-of-two scaled two-way fp16 split,
+//             3 products; the default when ugrid_pack_mlp finds the value ranges fit).
 //
 // Compiled with -ffp-contract=off: every a*b+c below that must match torch's separate
-// multiply/add is written as such; fmaf is explicit where torch's CPU kernels use FMA.
+// multiply/add is written as such; fmaf is explicit where a fused operation is intended.
 #pragma once
 #include "ugrid_common.h"
 #include "ugrid_math.h"

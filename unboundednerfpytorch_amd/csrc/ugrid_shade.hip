@@ -1,5 +1,5 @@
-// libugrid_hip.so -- shade half of the fused render path (rgbnet on fp32 MFMA), the single-launch
-// variant and the rgbnet packing kernel.  Default optimisation flags.
+// libugrid_hip.so -- shade half of the fused render path (rgbnet on MFMA: fp16x2 / bf16x3 / fp32), the
+// single-launch variant and the rgbnet packing kernel.
 #include "ugrid_render.h"
 
 extern "C" int ug_set_march_waves(int w);  // ugrid_march.hip
@@ -403,7 +403,7 @@ static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, con
     attr_set = true;
   }
   UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
-  // persistent: one workgroup per CU (LDS holds the 89 KB packed rgbnet)
+  // persistent: one workgroup per CU (LDS holds the packed rgbnet image of the mode: 89 / 138 / 93 KB)
   int64_t wgs = (ws.n_tiles + NW - 1) / NW;
   if (wgs > 256) wgs = 256;
   wgs = (wgs + 7) / 8 * 8;
