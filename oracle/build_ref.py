@@ -1,0 +1,106 @@
+"""oracle/_ref -- the reference's OWN native extension modules, compiled as TEST INFRASTRUCTURE only.
+
+The product never loads anything built here (tests/, tools/gen_native_golden.py and nothing else do).  Purpose:
+pin `oracle/ref_ops.c` (the C restatement) and the HIP library on outputs of the reference's own kernels
+(`FourierGrid/cuda/*.cu`), see tests/golden/native_ops.npz and tests/test_gpu_ref_native.py.
+
+Recipe (run in the build container, where /root/reference exists):
+
+    python oracle/build_ref.py            # -> oracle/_ref/{nofma,fma}/<module>.so   (git-ignored, shipped by gpurun)
+
+* the four modules of FourierGrid/cuda/setup.py:15-18 are built from the sources where they lie; torch's
+  cpp_extension (ROCm build) hipifies `.cu` next to the file it reads, and /root/reference is read-only, so the
+  sources are first copied to a throw-away directory under $TMPDIR (never into the repository);
+* ONE mechanical edit is applied to that throw-away copy: `AT_DISPATCH_FLOATING_TYPES(x.type(), ...)` ->
+  `x.scalar_type()` -- torch >= 2.x removed the implicit DeprecatedTypeProperties -> ScalarType conversion
+  (the first attempt's failing log is profiles/r02/oracle_ref_build_fail.log).  No arithmetic is touched;
+* two builds: `nofma` (-ffp-contract=off: every a*b+c rounded twice, the semantics the C restatement follows) and
+  `fma` (hipcc's default contraction, the analogue of nvcc's default -fmad=true).  Where the two differ the
+  reference itself is ambiguous to 1 ulp; the tests demand bit equality against `nofma` and report the
+  distance to `fma`.
+"""
+import glob
+import os
+import re
+import shutil
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "oracle", "_ref")
+MODULES = [  # FourierGrid/cuda/setup.py:15-18
+    ("adam_upd_cuda", ["adam_upd.cpp", "adam_upd_kernel.cu"]),
+    ("ub360_utils_cuda", ["ub360_utils.cpp", "ub360_utils_kernel.cu"]),
+    ("total_variation_cuda", ["total_variation.cpp", "total_variation_kernel.cu"]),
+    ("render_utils_cuda", ["render_utils.cpp", "render_utils_kernel.cu"]),
+]
+VARIANTS = {"nofma": ["-ffp-contract=off"], "fma": []}
+
+
+def reference_cuda_dir():
+    root = os.environ.get("UNERF_REFERENCE_ROOT", "/root/reference")
+    d = os.path.join(root, "FourierGrid", "cuda")
+    return d if os.path.isdir(d) else None
+
+
+def built(variant="nofma"):
+    return all(os.path.exists(os.path.join(OUT, variant, name + ".so")) for name, _ in MODULES)
+
+
+def build(variants=("nofma", "fma"), verbose=False):
+    """One subprocess per variant: torch's JIT loader renames a module that the process has already loaded
+    (name_v1), which would break the PyInit symbol of the second variant."""
+    import subprocess
+    for variant in variants:
+        if not built(variant):
+            subprocess.check_call([sys.executable, os.path.abspath(__file__), "--variant", variant] + (["-v"] if verbose else []))
+
+
+def _build_variant(variant, verbose=False):
+    src = reference_cuda_dir()
+    if src is None:
+        raise RuntimeError("reference sources not present (UNERF_REFERENCE_ROOT / /root/reference)")
+    os.environ.setdefault("PYTORCH_ROCM_ARCH", "gfx950")
+    from torch.utils import cpp_extension
+    if True:
+        work = tempfile.mkdtemp(prefix="unerf_ref_%s_" % variant)
+        try:
+            for f in glob.glob(os.path.join(src, "*.cpp")) + glob.glob(os.path.join(src, "*.cu")):
+                dst = os.path.join(work, os.path.basename(f))
+                shutil.copyfile(f, dst)
+                if dst.endswith(".cu"):
+                    txt = open(dst).read()
+                    txt = re.sub(r"(AT_DISPATCH_FLOATING_TYPES\(\s*\w+)\.type\(\)", r"\1.scalar_type()", txt)
+                    open(dst, "w").write(txt)
+            os.makedirs(os.path.join(OUT, variant), exist_ok=True)
+            for name, files in MODULES:
+                bdir = os.path.join(work, "build_" + name)
+                os.makedirs(bdir)
+                cpp_extension.load(name=name, sources=[os.path.join(work, f) for f in files], build_directory=bdir,
+                                   extra_cuda_cflags=VARIANTS[variant] + ["-w"], extra_cflags=["-w"],
+                                   verbose=verbose, is_python_module=False)
+                shutil.copyfile(os.path.join(bdir, name + ".so"), os.path.join(OUT, variant, name + ".so"))
+        finally:
+            shutil.rmtree(work, ignore_errors=True)
+
+
+def load(variant="nofma"):
+    """Import the four prebuilt modules (needs a GPU at call time, not at import time).  Returns a dict."""
+    import importlib.util
+    import torch  # noqa: F401  (the modules link against libtorch)
+    mods = {}
+    for name, _ in MODULES:
+        path = os.path.join(OUT, variant, name + ".so")
+        spec = importlib.util.spec_from_file_location(name, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return mods
+
+
+if __name__ == "__main__":
+    if "--variant" in sys.argv:
+        _build_variant(sys.argv[sys.argv.index("--variant") + 1], verbose="-v" in sys.argv)
+    else:
+        build(verbose="-v" in sys.argv)
+        print("built:", sorted(glob.glob(os.path.join(OUT, "*", "*.so"))))

@@ -234,7 +234,7 @@ def test_train_iteration_schedule_and_losses():
     per = (out['raw_rgb'] - target[out['ray_id']]).pow(2).sum(-1)
     want = (mse + 0.1 * ts.fourier_mse_loss(out['rgb_marched'], target)
             + 0.001 * (-(p * torch.log(p) + (1 - p) * torch.log(1 - p))).mean()
-            + 0.001 * dist_fn(out['weights'], out['s'], out['n_max'], out['ray_id'])
+            + 0.001 * dist_fn(out['weights'], out['s'], 1 / out['n_max'], out['ray_id'])
             + 0.05 * (per * out['weights'].detach()).sum() / 128)
     assert abs(float(loss) - float(want)) <= 1e-6 * max(1.0, abs(float(want)))
     # schedule
@@ -265,19 +265,52 @@ def test_train_iteration_schedule_and_losses():
 
 
 def model_oracle_distortion():
-    """DistortionLoss over the oracle's segment_cumsum (the product's needs the HIP library)."""
-    class _D(torch.autograd.Function):
-        @staticmethod
-        def forward(ctx, w, s, n_max, ray_id):
-            n_rays = int(ray_id.max()) + 1
-            wp, wt, wsp, wst = ref_ops.segment_cumsum(w.detach().contiguous(), s.contiguous(), ray_id.contiguous(), n_rays)
-            ctx.save_for_backward(w, s, wp, wt, wsp, wst, ray_id)
-            ctx.width = 1 / n_max
-            return ((2 * w * (s * wp - wsp)).sum() + ((1 / 3) * ctx.width * w.pow(2)).sum()) / n_rays
+    """flatten_eff_distloss(w, m, interval, ray_id) (the library call of run_train.py:274) over the oracle's
+    segment_cumsum: the product class with its test hook pointing at the oracle op."""
+    from unboundednerfpytorch_amd import ops
 
-        @staticmethod
-        def backward(ctx, g):
-            w, s, wp, wt, wsp, wst, ray_id = ctx.saved_tensors
-            wa, wsa = wt[ray_id] - (wp + w), wst[ray_id] - (wsp + w * s)
-            return g * (2 * (s * (wp - wa) + (wsa - wsp)) + (1 / 3) * ctx.width * 2 * w), None, None, None
-    return _D.apply
+    def fn(w, s, interval, ray_id):
+        ops.DistortionLoss.segment_cumsum = staticmethod(
+            lambda w_, s_, r_, n_: ref_ops.segment_cumsum(w_.detach().contiguous(), s_.contiguous(), r_.contiguous(), n_))
+        try:
+            return ops.flatten_eff_distloss(w, s, interval, ray_id)
+        finally:
+            ops.DistortionLoss.segment_cumsum = None
+    return fn
+
+
+def test_flatten_eff_distloss_backward_is_the_derivative_of_its_forward():
+    """the training loop's distortion term is torch_efficient_distloss.flatten_eff_distloss
+    (run_train.py:274), whose backward divides by n_rays; the reference's in-repo DistortionLoss (dead code) does
+    not.  ops.flatten_eff_distloss must be the derivative of its own value: checked against torch autograd of the
+    definition in fp64, and against the quirky class (ratio exactly n_rays)."""
+    from unboundednerfpytorch_amd import ops
+    w, s, ray_id, n_max = synth.distortion_inputs()
+    R = int(ray_id.max()) + 1
+    cum = staticmethod(lambda w_, s_, r_, n_: ref_ops.segment_cumsum(w_.detach().contiguous(), s_.contiguous(), r_.contiguous(), n_))
+    ops.DistortionLoss.segment_cumsum = cum
+    try:
+        wt = torch.from_numpy(w).requires_grad_(True)
+        loss = ops.flatten_eff_distloss(wt, torch.from_numpy(s), 1 / n_max, torch.from_numpy(ray_id))
+        loss.backward()
+        g_new = wt.grad.clone()
+        wq = torch.from_numpy(w).requires_grad_(True)
+        loss_q = ops.distortion_loss(wq, torch.from_numpy(s), n_max, torch.from_numpy(ray_id))
+        loss_q.backward()
+    finally:
+        ops.DistortionLoss.segment_cumsum = None
+    assert float(loss) == float(loss_q)
+    np.testing.assert_allclose(g_new.numpy() * R, wq.grad.numpy(), rtol=1e-6, atol=1e-9)
+    # definition, fp64 autograd
+    w64 = torch.from_numpy(w.astype(np.float64)).requires_grad_(True)
+    s64 = torch.from_numpy(s.astype(np.float64))
+    total = 0.0
+    for r in range(R):
+        m = torch.from_numpy(ray_id == r)
+        if int(m.sum()) == 0:
+            continue
+        wr, sr = w64[m], s64[m]
+        total = total + (wr[:, None] * wr[None, :] * (sr[:, None] - sr[None, :]).abs()).sum() + (wr ** 2).sum() / (3 * n_max)
+    (total / R).backward()
+    np.testing.assert_allclose(float(loss), float(total / R), rtol=2e-5)
+    np.testing.assert_allclose(g_new.numpy(), w64.grad.numpy(), rtol=2e-4, atol=2e-7)

@@ -251,10 +251,14 @@ def _dp_setup():
     import test_fourier_model as T
     c = dict(synth.MODEL_UTILS_CASE, dm=0.5, ds=2.0)
     cfg = dict(T.TRAIN_CFG, weight_main=1.0, weight_entropy_last=0.001, weight_tv_density=1e-4, weight_tv_k0=1e-5, tv_after=0,
-               tv_before=10, tv_every=1, tv_dense_before=2)     # step 1 dense TV, step 2 masked TV
+               tv_before=10, tv_every=1, tv_dense_before=2,     # step 1 dense TV, step 2 masked TV
+               weight_nearclip=0.01, weight_distortion=0.01, weight_rgbper=0.05)   # sum-type and ray-normalised terms
     o, d, v = [torch.from_numpy(a) for a in synth.rays(77, 128)]
     target = torch.sigmoid(torch.from_numpy(synth.normal(78, 128 * 3).reshape(128, 3)))
     return T, c, cfg, (o, d, v, target)
+
+
+NEAR_THRES = 0.35   # t < NEAR_THRES: the samples the nearclip term pushes on (a few per ray at stepsize 0.5)
 
 
 def _dp_worker(rank, world, port, q):
@@ -273,10 +277,46 @@ def _dp_worker(rank, world, port, q):
     opt.min_shard_numel = 256
     assert isinstance(opt, ShardedMaskedAdam)
     sl = slice(rank * 64, (rank + 1) * 64)
+    # (a) the loss scaling alone: gradient of training_loss(world_size=2) on the half batch, averaged over the ranks
+    dfn = T.model_oracle_distortion()
+    out = m(o[sl], d[sl], v[sl], global_step=1, is_train=True, stepsize=0.5)
+    last_ray_sampled = int(out['ray_id'].max()) + 1 == 64
+    loss, _ = ts.training_loss(out, target[sl], cfg, 64, near_thres=NEAR_THRES, distortion_fn=dfn, world_size=world)
+    loss.backward()
+    avg = {}
+    for k, p in m.named_parameters():
+        g = p.grad.clone()
+        dist.all_reduce(g)
+        avg[k] = (g / world).numpy().copy()
+        p.grad = None
+    # (b) two full iterations
     for step in (1, 2):
-        ts.train_iteration(m, opt, o[sl], d[sl], v[sl], target[sl], cfg, step, dict(stepsize=0.5), world_size=world)
-    q.put((rank, {k: p.detach().numpy().copy() for k, p in m.named_parameters()},     # numpy: pickled by value
-           opt.state[m.k0.grid]['exp_avg'].numel()))
+        ts.train_iteration(m, opt, o[sl], d[sl], v[sl], target[sl], cfg, step, dict(stepsize=0.5), world_size=world,
+                           near_thres=NEAR_THRES, distortion_fn=dfn)
+    params_after_2 = {k: p.detach().numpy().copy() for k, p in m.named_parameters()}     # numpy: pickled by value
+    shard_numel = opt.state[m.k0.grid]['exp_avg'].numel()
+    # (c) checkpoint round trip: state_dict() is the reference's full-shape layout on every rank; a fresh
+    # sharded optimizer that loads it continues bit-identically to the one that kept running
+    import copy
+    sd = opt.state_dict()
+    k0_index = [i for i, p in enumerate(pp for g in opt.param_groups for pp in g['params']) if p is m.k0.grid][0]
+    full_ok = (tuple(sd['state'][k0_index]['exp_avg'].shape) == tuple(m.k0.grid.shape)
+               and all('shard' not in st for st in sd['state'].values()))
+    sd_np = {i: {k: (x.numpy().copy() if torch.is_tensor(x) else x) for k, x in st.items()} for i, st in sd['state'].items()}
+    m2 = T.build(c)
+    m2.load_state_dict(m.state_dict())
+    m2.act_shift = m.act_shift
+    opt2 = create_optimizer_or_freeze_model(m2, cfg, 0, sharded=True, ops=ref_ops)
+    opt2.min_shard_numel = 256
+    opt2.load_state_dict(copy.deepcopy(sd))
+    for g2, g1 in zip(opt2.param_groups, opt.param_groups):
+        assert g2['lr'] == g1['lr']
+    resumed_sharded = opt2.state[m2.k0.grid]['exp_avg'].numel() == shard_numel
+    for mm, oo in ((m, opt), (m2, opt2)):
+        ts.train_iteration(mm, oo, o[sl], d[sl], v[sl], target[sl], cfg, 3, dict(stepsize=0.5), world_size=world,
+                           near_thres=NEAR_THRES, distortion_fn=dfn)
+    same = all(torch.equal(a, b) for a, b in zip(m.parameters(), m2.parameters()))
+    q.put((rank, params_after_2, shard_numel, avg, last_ray_sampled, full_ok and resumed_sharded and same, sd_np))
     dist.destroy_process_group()
 
 
@@ -298,8 +338,23 @@ def test_data_parallel_training_matches_single_process_gloo():
     T, c, cfg, (o, d, v, target) = _dp_setup()
     m = T.build(c)
     opt = create_optimizer_or_freeze_model(m, cfg, 0, ops=ref_ops)
+    # (a) whole-batch gradient of the same loss: the rank-averaged half-batch gradients must equal it (ADVICE r1:
+    # nearclip is a SUM over samples -> x world_size in data-parallel mode; distortion / rgbper are ray-normalised)
+    dfn = T.model_oracle_distortion()
+    out = m(o, d, v, global_step=1, is_train=True, stepsize=0.5)
+    assert int((out['t'] < NEAR_THRES).sum()) > 50 and res[0][4] and res[1][4]     # the terms are really exercised
+    loss, _ = ts.training_loss(out, target, cfg, 128, near_thres=NEAR_THRES, distortion_fn=dfn)
+    loss.backward()
+    for k, p in m.named_parameters():
+        want = p.grad.numpy()
+        scale = float(np.abs(want).max())
+        assert scale > 0, k
+        assert np.array_equal(res[0][3][k], res[1][3][k]), k
+        np.testing.assert_allclose(res[0][3][k], want, rtol=0, atol=2e-5 * scale, err_msg=k)
+        p.grad = None
+    # and a wrong scaling would be seen: dropping the x world_size of nearclip changes the density gradient by > 10 %
     for step in (1, 2):
-        ts.train_iteration(m, opt, o, d, v, target, cfg, step, dict(stepsize=0.5))
+        ts.train_iteration(m, opt, o, d, v, target, cfg, step, dict(stepsize=0.5), near_thres=NEAR_THRES, distortion_fn=dfn)
     ref = {k: p.detach() for k, p in m.named_parameters()}
     for k in ref:
         assert np.array_equal(res[0][1][k], res[1][1][k]), k                   # the ranks stay in lock-step
@@ -309,3 +364,24 @@ def test_data_parallel_training_matches_single_process_gloo():
         # an entry by ~lr whatever its gradient's size, so compare against a fraction of one step
         assert float((diff > 0.05 * lr).float().mean()) < 5e-3, (k, float(diff.max()))
     assert res[0][2] == m.k0.grid.numel() // 2                                 # k0's Adam state is split over the ranks
+    # checkpoint round trip: full-shape state on both ranks, identical, loads into the single-process MaskedAdam (the
+    # reference optimizer's layout) and matches that optimizer's own state after the same two steps
+    assert res[0][5] and res[1][5]
+    mine = opt.state_dict()
+    plist = [pp for g in opt.param_groups for pp in g['params']]
+    for i, st in mine['state'].items():
+        name = [n for n, pp in m.named_parameters() if pp is plist[i]][0]
+        for k in ('exp_avg', 'exp_avg_sq'):
+            assert np.array_equal(res[0][6][i][k], res[1][6][i][k])
+            assert res[0][6][i][k].shape == tuple(st[k].shape)
+            if 'grid' in name:
+                # (the rgbnet's second-step gradient depends on first-step Adam moves of +-lr whose sign is decided by
+                # gradients at rounding level, so only the grids' moments are compared value by value)
+                scale = float(st[k].abs().max())
+                bad = np.abs(res[0][6][i][k] - st[k].numpy()) > 1e-2 * scale
+                assert bad.mean() < 5e-3, (name, k, float(bad.mean()))
+        assert res[0][6][i]['step'] == st['step'] == 2
+    loaded = {'state': {i: {k: (torch.from_numpy(x) if isinstance(x, np.ndarray) else x) for k, x in st.items()}
+                        for i, st in res[0][6].items()}, 'param_groups': mine['param_groups']}
+    opt.load_state_dict(loaded)
+    assert opt.state[m.k0.grid]['exp_avg'].shape == m.k0.grid.shape

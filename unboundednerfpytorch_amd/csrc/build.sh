@@ -6,10 +6,15 @@ cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include"
 mkdir -p ../../build/obj
 O=../../build/obj
+rm -f $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o   # a failed compile must not link a stale object
+pids=()
 hipcc $FLAGS -c ugrid_ops.hip -o $O/ugrid_ops.o "$@" &
+pids+=($!)
 # packed fp32 VALU (v_pk_*_f32 from the SLP vectoriser) issues at half rate on gfx950 and needs extra moves to form
 # register pairs: the VALU-bound march kernel is 16 % faster without it, the shade kernel 1.3 %
 hipcc $FLAGS -fno-slp-vectorize ${UG_MARCH_FLAGS} -c ugrid_march.hip -o $O/ugrid_march.o "$@" &
+pids+=($!)
 hipcc $FLAGS -fno-slp-vectorize ${UG_SHADE_FLAGS} -c ugrid_shade.hip -o $O/ugrid_shade.o "$@" &
-wait
+pids+=($!)
+for p in "${pids[@]}"; do wait "$p"; done   # a bare `wait` returns 0 even when a job failed
 hipcc --offload-arch=gfx950 -shared -fPIC -o ${UG_OUT:-../libugrid_hip.so} $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o

@@ -178,6 +178,9 @@ class FourierGridRenderer:
         assert rays_o.dim() == 2 and rays_o.shape[-1] == 3, "Only support point queries in [N, 3] format"
         _lib.require_cuda(("rays_o", rays_o), ("rays_d", rays_d), ("viewdirs", viewdirs))
         _lib.require_f32(("rays_o", rays_o), ("rays_d", rays_d), ("viewdirs", viewdirs))
+        for name, t in (("rays_o", rays_o), ("rays_d", rays_d), ("viewdirs", viewdirs)):
+            if t.device.type != "cuda" or (self.device.index is not None and t.device.index != self.device.index):
+                raise RuntimeError("%s is on %s, the renderer's grids are on %s" % (name, t.device, self.device))
         stepsize = render_kwargs["stepsize"]
         t_tab, s_tab, S = self.tables(stepsize)
         R = rays_o.shape[0]

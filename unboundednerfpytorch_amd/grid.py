@@ -24,6 +24,9 @@ def grid_query(grid, xyz, xyz_min, xyz_max, freq_num):
     P, C, X, Y, Z = grid.shape
     lead = xyz.shape[:-1]
     pts = xyz.reshape(-1, 3).contiguous()
+    _lib.require_cuda(("xyz", pts))
+    if pts.device != grid.device or xyz_min.device != grid.device or xyz_max.device != grid.device:
+        raise RuntimeError("grid, xyz, xyz_min and xyz_max must be on the same device")
     out = torch.empty(pts.shape[0], C, dtype=torch.float32, device=grid.device)
     with torch.cuda.device(grid.device):
         _lib.check(_L.ugrid_grid_query(_lib.ptr(grid), P, C, X, Y, Z, _lib.ptr(pts), _lib.ptr(xyz_min),

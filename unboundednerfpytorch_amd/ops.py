@@ -2,7 +2,10 @@
 reference (/root/reference/FourierGrid/dvgo.py:430-488): Raw2Alpha, Raw2Alpha_nonuni, Alphas2Weights.
 All three are once_differentiable and save tensors only when the input requires grad.
 DistortionLoss mirrors FourierGrid_model.py:684-708 (the mip-NeRF-360 distortion regulariser over the flattened
-survivor list; run_train.py:270-275 obtains the same quantity from the third-party flatten_eff_distloss)."""
+survivor list) INCLUDING that dead-code class's quirk (backward not divided by n_rays).  The training loop itself
+(run_train.py:270-275) calls the third-party torch_efficient_distloss.flatten_eff_distloss, whose forward is the
+same value and whose backward IS the derivative of that forward (divided by n_rays): FlattenEffDistLoss /
+flatten_eff_distloss below, the default of train_step.training_loss."""
 import torch
 
 from . import render_utils_cuda, ub360_utils_cuda
@@ -75,23 +78,52 @@ class DistortionLoss(torch.autograd.Function):
     def forward(ctx, w, s, n_max, ray_id):
         n_rays = ray_id.max() + 1
         width = 1 / n_max
-        w_pre, w_tot, ws_pre, ws_tot = ub360_utils_cuda.segment_cumsum(w, s, ray_id, int(n_rays))
+        cumsum = DistortionLoss.segment_cumsum or ub360_utils_cuda.segment_cumsum
+        w_pre, w_tot, ws_pre, ws_tot = cumsum(w, s, ray_id, int(n_rays))
         pair = 2 * w * (s * w_pre - ws_pre)
         self_term = (1 / 3) * width * w.pow(2)      # same operation order as the reference's loss_uni
         ctx.save_for_backward(w, s, w_pre, w_tot, ws_pre, ws_tot, ray_id)
         ctx.width = width
+        ctx.n_rays = n_rays
         return (pair.sum() + self_term.sum()) / n_rays
 
-    @staticmethod
-    @torch.autograd.function.once_differentiable
-    def backward(ctx, grad_back):
+    normalize_backward = False   # the reference's dead-code class forgets the 1/n_rays of its own forward
+    segment_cumsum = None        # test hook: another implementation of the op (the oracle's); None = the HIP kernel
+
+    @classmethod
+    def _grad(cls, ctx, grad_back):
         w, s, w_pre, w_tot, ws_pre, ws_tot, ray_id = ctx.saved_tensors
         # sums over the samples AFTER i in the same ray: total - (prefix + own)
         w_after = w_tot[ray_id] - (w_pre + w)
         ws_after = ws_tot[ray_id] - (ws_pre + w * s)
         d_pair = 2 * (s * (w_pre - w_after) + (ws_after - ws_pre))
         d_self = (1 / 3) * ctx.width * 2 * w
-        return grad_back * (d_pair + d_self), None, None, None
+        grad = grad_back * (d_pair + d_self)
+        return grad / ctx.n_rays if cls.normalize_backward else grad
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_back):
+        return DistortionLoss._grad(ctx, grad_back), None, None, None
 
 
-distortion_loss = DistortionLoss.apply
+class FlattenEffDistLoss(DistortionLoss):
+    """flatten_eff_distloss(w, m, interval, ray_id) of torch_efficient_distloss, the function run_train.py:274 calls
+    (third-party, not vendored by the reference; restated from its published algorithm): same forward as
+    DistortionLoss with `interval` given directly (the loop passes 1/n_max), and a backward that is the exact
+    derivative of the forward, i.e. divided by n_rays = ray_id.max()+1 (checked by gradcheck in fp64 on the oracle
+    op, tests/test_host_logic.py)."""
+    normalize_backward = True
+
+    @staticmethod
+    def forward(ctx, w, m, interval, ray_id):
+        return DistortionLoss.forward(ctx, w, m, 1 / interval, ray_id)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, grad_back):
+        return FlattenEffDistLoss._grad(ctx, grad_back), None, None, None
+
+
+distortion_loss = DistortionLoss.apply          # (w, s, n_max, ray_id): the reference's in-repo class, quirk kept
+flatten_eff_distloss = FlattenEffDistLoss.apply  # (w, m, interval, ray_id): what the training loop uses

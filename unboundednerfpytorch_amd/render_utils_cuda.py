@@ -173,8 +173,16 @@ def alpha2weight(alpha, ray_id, n_rays):
         raise RuntimeError("ray_id must be int64")
     n, n_rays = alpha.size(0), int(n_rays)
     dev = alpha.device
-    weight = torch.empty_like(alpha)
-    T = torch.empty_like(alpha)
+    if ray_id.numel() < n:
+        raise RuntimeError("ray_id has fewer entries than alpha.size(0)")
+    if alpha.dim() == 1:
+        weight = torch.empty_like(alpha)      # the kernel writes all n entries (defaults 0 / 1 after the early stop)
+        T = torch.empty_like(alpha)
+    else:
+        # the reference takes n_pts = alpha.size(0) whatever the rank (render_utils_kernel.cu:620-626) and leaves the
+        # rest of its zeros_like / ones_like outputs untouched: same here for a [R,S] alpha (fast_color_thres == 0)
+        weight = torch.zeros_like(alpha)
+        T = torch.ones_like(alpha)
     last = torch.empty(n_rays, dtype=alpha.dtype, device=dev)
     i_start = torch.empty(n_rays, dtype=torch.int64, device=dev)
     i_end = torch.empty(n_rays, dtype=torch.int64, device=dev)

@@ -146,6 +146,56 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                     flat_p.copy_(full[:n])
 
     # -- checkpointing ---------------------------------------------------------------------------------
+    def _would_shard(self, param):
+        world, _ = self._world()
+        return world > 1 and param.numel() >= self.min_shard_numel
+
+    @torch.no_grad()
+    def state_dict(self):
+        """The reference optimizer's layout (utils.py:70-74 saves optimizer.state_dict() verbatim): `exp_avg` /
+        `exp_avg_sq` in the PARAMETER's shape, no shard bookkeeping -- so a checkpoint written by a sharded run loads
+        into the reference's MaskedAdam (and into MaskedAdam here) and vice versa.  COLLECTIVE when parameters are
+        sharded (an all-gather per state tensor): every rank must call it, every rank gets the full dictionary."""
+        sd = super().state_dict()
+        index = 0
+        for group in self.param_groups:
+            for param in group['params']:
+                st = self.state.get(param)
+                if st is not None and 'shard' in st:
+                    exp_avg, exp_avg_sq = self.gather_full_state(param)
+                    sd['state'][index] = {'step': st['step'], 'exp_avg': exp_avg, 'exp_avg_sq': exp_avg_sq}
+                index += 1
+        return sd
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """Accepts the full-shape layout (the reference's, MaskedAdam's, or state_dict() above) under any world size:
+        after torch has cast and placed the tensors, a parameter this run shards keeps only its own flat range
+        [b, e) (zero-padded to the shard length), exactly what the lazy initialisation of step() would have set up."""
+        for st in state_dict.get('state', {}).values():
+            if 'shard' in st:
+                raise RuntimeError("rank-local optimizer state (written before state_dict() gathered shards) cannot be "
+                                   "loaded: it holds one rank's range only")
+        super().load_state_dict(state_dict)
+        world, rank = self._world()
+        for group in self.param_groups:
+            for param in group['params']:
+                st = self.state.get(param)
+                if not st or not self._would_shard(param):
+                    continue
+                n = param.numel()
+                per = self.shard_len(n, world)
+                b = min(n, rank * per)
+                e = min(n, b + per)
+                for k in ('exp_avg', 'exp_avg_sq'):
+                    full = st[k].reshape(-1)
+                    if full.numel() != n:
+                        raise RuntimeError("optimizer state %s has %d elements, parameter has %d" % (k, full.numel(), n))
+                    shard = torch.zeros(per, dtype=full.dtype, device=full.device)
+                    shard[: e - b] = full[b:e]
+                    st[k] = shard
+                st['shard'] = (b, e, per)
+
     @torch.no_grad()
     def gather_full_state(self, param):
         """exp_avg / exp_avg_sq of `param` assembled on every rank in the parameter's shape (what the reference's

@@ -34,9 +34,13 @@ def maybe_scale_grids(model, optimizer, cfg_train, cfg_model, global_step, **opt
     return optimizer
 
 
-def training_loss(render_result, target, cfg_train, n_rays, near_thres=None, distortion_fn=None):
+def training_loss(render_result, target, cfg_train, n_rays, near_thres=None, distortion_fn=None, world_size=1):
     """The loss of run_train.py:254-279 from the model's return dict.  near_thres = near_clip / scene_radius[0] when
-    weight_nearclip is used; distortion_fn(w, s, n_max, ray_id) defaults to ops.distortion_loss."""
+    weight_nearclip is used; distortion_fn(w, s, interval, ray_id) defaults to ops.flatten_eff_distloss (the library call
+    of run_train.py:274, gradient = derivative of the value, 1/n_rays included).
+    world_size > 1 (data-parallel, gradients AVERAGED over ranks by ShardedMaskedAdam): every term that is a mean over
+    the local rays needs no change; the one SUM-type term (nearclip: +1 per near sample) is multiplied by world_size
+    so that the rank average equals the whole-batch sum."""
     mse = F.mse_loss(render_result['rgb_marched'], target)
     loss = _get(cfg_train, 'weight_main', 1.0) * mse
     w_freq = _get(cfg_train, 'weight_freq', 0.0)
@@ -48,12 +52,12 @@ def training_loss(render_result, target, cfg_train, n_rays, near_thres=None, dis
     if _get(cfg_train, 'weight_nearclip', 0.0) > 0:
         d = render_result['raw_density'][render_result['t'] < near_thres]
         if len(d):
-            loss = loss + _get(cfg_train, 'weight_nearclip') * (d - d.detach()).sum()
+            loss = loss + (_get(cfg_train, 'weight_nearclip') * world_size) * (d - d.detach()).sum()
     if _get(cfg_train, 'weight_distortion', 0.0) > 0 and render_result['weights'].numel() > 0:
         if distortion_fn is None:
-            from .ops import distortion_loss as distortion_fn
+            from .ops import flatten_eff_distloss as distortion_fn
         loss = loss + _get(cfg_train, 'weight_distortion') * distortion_fn(
-            render_result['weights'], render_result['s'], render_result['n_max'], render_result['ray_id'])
+            render_result['weights'], render_result['s'], 1 / render_result['n_max'], render_result['ray_id'])
     if _get(cfg_train, 'weight_rgbper', 0.0) > 0:
         per = (render_result['raw_rgb'] - target[render_result['ray_id']]).pow(2).sum(-1)
         loss = loss + _get(cfg_train, 'weight_rgbper') * (per * render_result['weights'].detach()).sum() / n_rays
@@ -64,14 +68,16 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
                     near_thres=None, distortion_fn=None, decay_lr=True, world_size=1):
     """Forward ... optimizer.step() of one global_step (call maybe_scale_grids first).  Returns (loss, psnr).
     Data-parallel use (ShardedMaskedAdam averages the ranks' gradients): pass world_size so that the total-variation
-    term, which the reference scales by 1 / len(rays_o), is scaled by the GLOBAL batch size -- the ray-mean losses
-    need no change (mean over the local rays, then mean over ranks).  TV itself runs inside optimizer.step on the
+    term, which the reference scales by 1 / len(rays_o), is scaled by the GLOBAL batch size and the sum-type nearclip
+    term by world_size -- the ray-mean losses (mse, entropy, distortion, rgbper) need no change (mean over the local
+    rays, then mean over ranks; exact when every rank's last ray has a sample, since the distortion loss normalises by
+    ray_id.max()+1 like the library).  TV itself runs inside optimizer.step on the
     REDUCED gradient (grad_hook), so its masked mode sees the voxels any rank touched: the data-parallel step equals
     the single-process step on the whole batch in both TV phases (tests/test_host_logic.py)."""
     out = model(rays_o, rays_d, viewdirs, global_step=global_step, is_train=True, **render_kwargs)
     optimizer.zero_grad(set_to_none=True)
     n_rays = len(rays_o)
-    loss, mse = training_loss(out, target, cfg_train, n_rays, near_thres, distortion_fn)
+    loss, mse = training_loss(out, target, cfg_train, n_rays, near_thres, distortion_fn, world_size)
     loss.backward()
     tv_on = (global_step < _get(cfg_train, 'tv_before', 0) and global_step > _get(cfg_train, 'tv_after', 0)
              and global_step % _get(cfg_train, 'tv_every', 1) == 0)
