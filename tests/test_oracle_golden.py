@@ -194,3 +194,37 @@ def test_train_forward_backward_pinned_on_the_reference_model(golden_dir):
         scale = np.abs(g).max()
         assert np.abs(got - g).max() <= 2e-6 * scale + 1e-12, (k, float(np.abs(got - g).max()), float(scale))
         assert np.array_equal(got == 0, g == 0), k      # the touched-voxel mask MaskedAdam keys on
+
+
+def test_c_oracle_pinned_on_reference_kernels(golden_dir):
+    """oracle/ref_ops.c against outputs of the REFERENCE'S OWN native kernels (FourierGrid/cuda/*.cu compiled by
+    oracle/build_ref.py, run on an MI355X by tests/golden/gen_native_golden.py): all 18 exported functions on the
+    seeded cases of tests/native_cases.py.  Bit-exact for everything that is integer / IEEE add-mul-div-sqrt work;
+    the raw2alpha family goes through expf / powf (glibc here, device libm there): exp <= 2 ulp, alpha <= 1.2e-7
+    absolute (the subtraction from 1 amplifies pow's ulp for small alpha), gradients <= 4 ulp."""
+    import native_cases as nc
+    gold, z = nc.load_golden(os.path.join(golden_dir, "native_ops.npz"))
+    assert sum(nc.EXPORTED.values()) == 18 and len({(c[1], c[2]) for c in nc.CASES}) == 18   # every m.def covered
+    orc = {nc.RU: ref_ops.render_utils_cuda, nc.TV: ref_ops.total_variation_cuda, nc.UB: ref_ops.ub360_utils_cuda,
+           nc.AD: ref_ops.adam_upd_cuda}
+    got = nc.run_all(orc, scale=1, chain_from=gold)
+    for name in gold:
+        assert len(got[name]) == len(gold[name]) > 0, name
+        for k, (a, b) in enumerate(zip(gold[name], got[name])):
+            key = "%s[%d]" % (name, k)
+            assert a.shape == b.shape and a.dtype == b.dtype, key
+            if name not in nc.TRANSCENDENTAL:
+                assert np.array_equal(a.numpy(), b.numpy(), equal_nan=True), key
+                continue
+            an, bn = a.numpy(), b.numpy()
+            assert np.array_equal(np.isfinite(an), np.isfinite(bn)), key
+            fin = np.isfinite(an)
+            assert np.array_equal(an[~fin], bn[~fin]), key                     # +inf where the exponent overflows
+            if name in ("raw2alpha", "raw2alpha_nonuni") and k == 1:             # alpha = 1 - pow(1 + e, -interval)
+                np.testing.assert_allclose(bn[fin], an[fin], rtol=0, atol=1.2e-7, err_msg=key)
+            else:                                                                # exp, gradients
+                assert nc.ulp_diff(an[fin], bn[fin]).max() <= 4, key
+    # the reference itself is unambiguous on these cases: its fma-contracted build produced the same bits
+    import json
+    fma = json.loads(bytes(z["report_json"]).decode())
+    assert fma and all(v == 0 for v in fma.values())

@@ -246,9 +246,14 @@ __global__ void k_maskcache(const uint8_t *__restrict__ world, const float *__re
                             uint8_t *__restrict__ out) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n) return;
-  const float fi = roundf(xyz[3 * p] * scale[0] + shift[0]);
-  const float fj = roundf(xyz[3 * p + 1] * scale[1] + shift[1]);
-  const float fk = roundf(xyz[3 * p + 2] * scale[2] + shift[2]);
+  float fi = roundf(xyz[3 * p] * scale[0] + shift[0]);
+  float fj = roundf(xyz[3 * p + 1] * scale[1] + shift[1]);
+  float fk = roundf(xyz[3 * p + 2] * scale[2] + shift[2]);
+  // the reference converts the rounded value with `const int i = round(...)` (render_utils_kernel.cu:385-387): the
+  // hardware float->int conversion saturates and maps NaN to 0 (v_cvt_i32_f32, and cvt.rzi.s32.f32 on the
+  // reference's own target), so a NaN coordinate indexes plane 0 of that axis -- pinned on the reference kernels
+  // themselves (tests/golden/native_ops.npz); +-inf / huge values saturate out of range
+  fi = (fi != fi) ? 0.f : fi; fj = (fj != fj) ? 0.f : fj; fk = (fk != fk) ? 0.f : fk;
   uint8_t v = 0;
   if (fi >= 0.f && fi < (float)sz_i && fj >= 0.f && fj < (float)sz_j && fk >= 0.f && fk < (float)sz_k)
     v = world[(int64_t)fi * sz_j * sz_k + (int64_t)fj * sz_k + (int64_t)fk];
