@@ -251,7 +251,7 @@ int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1, const floa
 int ugrid_mlp_fp16x2_scales(const float *h_w0, const float *h_b0, const float *h_w1, int32_t k0_channels,
                             int32_t viewbase_pe, float k0_absmax, float *scales4);
 
-/* Tuning knobs (speed only, never results): "march_waves" 4..6, "split_gather" 0|1. */
+/* Tuning knobs (speed only, never results): "march_waves" 4..6. */
 int ugrid_tune(const char *key, int value);
 
 /* Total survivors of the last march on this ws -> *d_stats (device int64). */

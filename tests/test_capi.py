@@ -44,7 +44,8 @@ def test_python_binding_table_matches_header(lib_path):
     fp32_img = 20 * 256 + 64 * 256 + 128 + 128 + 512 + 4
     bf16_img = (3 + 8) * 4 * 3 * 64 * 4 + 128 + 128 + 512 + 4
     fp16_img = (3 + 8) * 4 * 2 * 64 * 4 + 128 + 128 + 512 + 4 + 4
-    assert lib.ugrid_mlp_packed_bytes(12, 4) == 4 * (fp32_img + bf16_img + fp16_img)
+    q16_img = (2 + 4) * 8 * 2 * 64 * 4 + 128 + 512 + 4 + 4          # 16x16x32 chain: A1 | A2 | bias2 | W3 | b3 | scales
+    assert lib.ugrid_mlp_packed_bytes(12, 4) == 4 * (fp32_img + bf16_img + fp16_img + q16_img)
     assert lib.ugrid_render_ws_bytes(64, 256) >= 64 * 256 * 17
 
 
@@ -112,7 +113,8 @@ def test_fp16x2_scale_derivation_is_host_arithmetic(lib_path):
         assert v > 0 and np.log2(v) == np.round(np.log2(v))          # exact powers of two
     bound = np.array([5.5] * C + [1.0] * (mlp_in - C))
     B1 = (np.abs(w0.astype(np.float64)) @ bound + np.abs(b0)).max()
-    for scale, mag in ((sX1, 5.5), (sW1, np.abs(w0).max()), (sX2, B1), (sW2, np.abs(w1).max())):
+    # (the layer-1 bias is stored as one more weight column of the 16x16x32 image, so it shares sW1's range)
+    for scale, mag in ((sX1, 5.5), (sW1, max(np.abs(w0).max(), np.abs(b0).max())), (sX2, B1), (sW2, np.abs(w1).max())):
         assert 16384.0 < scale * mag <= 32768.0                       # largest scaled operand in (2^14, 2^15]
     assert call(w0, b0, w1, 0.0) == 0 and list(sc) == [1.0] * 4       # unknown feature bound
     assert call(w0, b0, w1, 1e30) == 0                                # bound far outside fp16's reach

@@ -49,9 +49,11 @@ def main():
     L.ugx_pack.restype = ctypes.c_int
     L.ugx_pack.argtypes = [ctypes.c_void_p] + [ctypes.c_int] * 6 + [ctypes.c_void_p, ctypes.c_void_p]
     L.ugx_gather.restype = ctypes.c_int
-    L.ugx_gather.argtypes = [ctypes.POINTER(_lib.RenderParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.ugx_gather.argtypes = [ctypes.POINTER(_lib.RenderParams), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     L.ugx_feat_checksum.restype = ctypes.c_int
-    L.ugx_feat_checksum.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    L.ugx_feat_checksum.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p]
+    L.ugx_feat_bytes.restype = ctypes.c_int64
+    L.ugx_feat_bytes.argtypes = [ctypes.c_int64, ctypes.c_int32]
 
     G, H, W = args.grid, args.height, args.width
     stepsize = 1.31 * G / 200.0 if G != 200 else 1.31
@@ -70,8 +72,9 @@ def main():
     p = rend._params(R, S, stepsize)
     st = torch.cuda.current_stream(dev).cuda_stream
     P, C = 7, 12
-    bricks = {0: rend.k0_bricks}
-    for layout in (1, 2):
+    featbuf = torch.empty(L.ugx_feat_bytes(R, S) // 4, dtype=torch.float32, device=dev)   # [tile][64*S][12], sparse use
+    bricks = {1: rend.k0_bricks}       # the product layout (C == 12) is the quad layout
+    for layout in (0, 2):
         n = L.ugx_pack_bytes(P, C, G, G, G, layout) // 4
         bricks[layout] = torch.empty(n, dtype=torch.float32, device=dev)
         _lib.check(L.ugx_pack(kg.data_ptr(), P, C, G, G, G, layout, bricks[layout].data_ptr(), st), "ugx_pack")
@@ -87,7 +90,7 @@ def main():
         for _ in range(args.reps + 1):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            err = L.ugx_gather(ctypes.byref(p), bricks[layout].data_ptr(), rend._ws.data_ptr(), vid, st)
+            err = L.ugx_gather(ctypes.byref(p), bricks[layout].data_ptr(), rend._ws.data_ptr(), featbuf.data_ptr(), vid, st)
             e1.record()
             torch.cuda.synchronize()
             times.append(e0.elapsed_time(e1))
@@ -95,7 +98,7 @@ def main():
             print("%3d  ERROR %d   %s" % (vid, err, desc))
             continue
         times = times[1:]
-        _lib.check(L.ugx_feat_checksum(rend._ws.data_ptr(), R, S, chk.data_ptr(), st), "checksum")
+        _lib.check(L.ugx_feat_checksum(rend._ws.data_ptr(), featbuf.data_ptr(), R, S, chk.data_ptr(), st), "checksum")
         torch.cuda.synchronize()
         bits = int(chk[0].item())
         sums = chk[1:].view(torch.float64).cpu().tolist()

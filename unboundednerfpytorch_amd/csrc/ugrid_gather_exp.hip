@@ -11,31 +11,8 @@
 
 // ---- packing --------------------------------------------------------------------------------------------------
 __global__ void k_pack_quad(const float *__restrict__ grid, int P, int C, int X, int Y, int Z, float *__restrict__ out,
-                            int64_t total) {
-  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
-    const int e = (int)(o & 3), g = (int)((o >> 2) & 3);
-    int64_t r = o >> 4;
-    const int q = (int)(r % 6); r /= 6;
-    const int k = (int)(r % (Z - 1)); r /= (Z - 1);
-    const int j = (int)(r % (Y - 1)); r /= (Y - 1);
-    const int i = (int)(r % (X - 1)); r /= (X - 1);
-    const int l = (int)r;
-    const int chan = 3 * g + (q >> 1), c = 4 * (q & 1) + e;
-    float v = 0.f;
-    if (chan < C) {
-      const float *gp = grid + ((int64_t)l * C + chan) * X * Y * Z;
-      double acc = 0.0;   // inclusion-exclusion over the corners s that are sub-masks of c (as k_pack_bricks)
-      for (int s = 0; s < 8; ++s) {
-        if (s & ~c) continue;
-        const int ii = i + (s >> 2), jj = j + ((s >> 1) & 1), kk = k + (s & 1);
-        const double t = (double)gp[((int64_t)ii * Y + jj) * Z + kk];
-        acc += (__popc(c ^ s) & 1) ? -t : t;
-      }
-      v = (float)acc;
-    }
-    out[o] = v;
-  }
-}
+                            int64_t total);   // ugrid_march.hip
+extern "C" int ug_pack_bricks_pair(const float *grid, int P, int C, int X, int Y, int Z, float *bricks, ugrid_stream_t s);
 
 __global__ void k_pack_vertex(const float *__restrict__ grid, int P, int C, int X, int Y, int Z, float *__restrict__ out,
                               int64_t total) {
@@ -49,13 +26,14 @@ __global__ void k_pack_vertex(const float *__restrict__ grid, int P, int C, int 
 }
 
 extern "C" int64_t ugx_pack_bytes(int P, int C, int X, int Y, int Z, int layout) {
-  if (layout == 1) return (int64_t)P * (X - 1) * (Y - 1) * (Z - 1) * 96 * 4;
+  if (layout <= 1) return (int64_t)P * (X - 1) * (Y - 1) * (Z - 1) * 96 * 4;
   return (int64_t)P * X * Y * Z * C * 4;
 }
 
 extern "C" int ugx_pack(const float *grid, int P, int C, int X, int Y, int Z, int layout, float *out, ugrid_stream_t s) {
   if (C != 12) return (int)hipErrorInvalidValue;
   const int64_t total = ugx_pack_bytes(P, C, X, Y, Z, layout) / 4;
+  if (layout == 0) return ug_pack_bricks_pair(grid, P, C, X, Y, Z, out, s);
   if (layout == 1)
     hipLaunchKernelGGL(k_pack_quad, dim3(256 * 64), dim3(256), 0, (hipStream_t)s, grid, P, C, X, Y, Z, out, total);
   else
@@ -64,20 +42,8 @@ extern "C" int ugx_pack(const float *grid, int P, int C, int X, int Y, int Z, in
   return 0;
 }
 
-// ---- explicit loads -------------------------------------------------------------------------------------------------
-// hipcc sinks plain C++ loads down to their first use (one load in flight, s_waitcnt vmcnt(0) after each) whatever
-// sched_barrier says, so the gathers issue their loads as volatile asm (program order is kept among volatile asms)
-// and wait with explicit s_waitcnt whose "+v" operands make every use of the loaded registers depend on the wait.
-// The compiler's own vmcnt bookkeeping stays safe: memory operations return in order, and loads it does not know
-// about can only make its waits conservative.
-typedef float ug_f4 __attribute__((ext_vector_type(4)));
+// dwordx3 flavour of the explicit loads (ugrid_render.h) for the vertex layout
 typedef float ug_f3v __attribute__((ext_vector_type(3)));
-template <int IMM>
-__device__ __forceinline__ ug_f4 ug_gload4(unsigned voff, const float *sbase) {
-  ug_f4 r;
-  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
-  return r;
-}
 template <int IMM>
 __device__ __forceinline__ ug_f3v ug_gload3(unsigned voff, const float *sbase) {
   ug_f3v r;
@@ -85,20 +51,11 @@ __device__ __forceinline__ ug_f3v ug_gload3(unsigned voff, const float *sbase) {
   return r;
 }
 template <int N>
-__device__ __forceinline__ void ug_vmwait6(ug_f4 (&v)[6]) {
-  asm volatile("s_waitcnt vmcnt(%6)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]) : "n"(N));
-}
-template <int N>
 __device__ __forceinline__ void ug_vmwait8(ug_f3v (&v)[8]) {
   asm volatile("s_waitcnt vmcnt(%8)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) : "n"(N));
 }
 
 // ---- quad helpers ------------------------------------------------------------------------------------------------
-template <int K>
-__device__ __forceinline__ float ug_quad_bcast(float x) {   // value of lane (lane & ~3) + K, one DPP move
-  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), K * 0x55, 0xf, 0xf, true));
-}
-
 struct ug_qcell { unsigned cell; float tx, ty, tz; };
 
 // every lane computes the whole cell set-up of one level (4x redundant inside a quad)
@@ -121,23 +78,11 @@ __device__ __forceinline__ ug_qcell ug_qcell_shared(const ug_axis_fast &mine, in
   return c;
 }
 
-// 3 channels of one level from the lane's 6 float4 (coefficients 0..3 | 4..7 per channel): Horner z, y, x
-__device__ __forceinline__ void ug_quad_poly(const ug_f4 (&v)[6], float tx, float ty, float tz, bool first, float (&feat)[3]) {
-#pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    const ug_f4 lo = v[2 * c], hi = v[2 * c + 1];
-    const float p00 = fmaf(lo.y, tz, lo.x), p01 = fmaf(lo.w, tz, lo.z);
-    const float p10 = fmaf(hi.y, tz, hi.x), p11 = fmaf(hi.w, tz, hi.z);
-    const float f = fmaf(fmaf(p11, ty, p10), tx, fmaf(p01, ty, p00));
-    feat[c] = first ? f : feat[c] + f;
-  }
-}
-
 // MODE 0: redundant set-up; 1: set-up shared across the quad; 2: as 1 but every quad reads the cell of quad 0
 // (diagnostic: removes the address divergence between quads, keeps the instruction stream)
 template <int F, int NBL, int WPS, int MODE>
 __global__ void __launch_bounds__(256, WPS)
-k_gather_quad(ug_shade_args a, const float *__restrict__ qb, ug_ws_view ws, int64_t nblocks) {
+k_gather_quad(ug_shade_args a, const float *__restrict__ qb, ug_ws_view ws, float *__restrict__ featbuf, int64_t nblocks) {
   constexpr int P = 2 * F + 1;
   const int64_t blk = ug_xcd_remap(blockIdx.x, nblocks);
   if (blk >= nblocks) return;
@@ -146,7 +91,7 @@ k_gather_quad(ug_shade_args a, const float *__restrict__ qb, ug_ws_view ws, int6
   const int lane = ug_lane(), s = lane >> 2, g = lane & 3;
   const int count = ws.count[tile];
   const float4 *__restrict__ ent = ws.ent + tile * ws.cap;
-  float *__restrict__ fo = ws.feat + tile * ws.cap * UG_FEAT_STRIDE;
+  float *__restrict__ fo = featbuf + tile * ws.cap * UG_FEAT_STRIDE;
   const int64_t cells = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1);
   // per-lane axis constants (shared set-up): lane g works on axis min(g, 2)
   const float lo_g = g == 0 ? a.lox : (g == 1 ? a.loy : a.loz);
@@ -238,7 +183,7 @@ k_gather_quad(ug_shade_args a, const float *__restrict__ qb, ug_ws_view ws, int6
 struct ug_f3 { float x, y, z; };
 template <int F, int NBL, int WPS>
 __global__ void __launch_bounds__(256, WPS)
-k_gather_vertex(ug_shade_args a, const float *__restrict__ vb, ug_ws_view ws, int64_t nblocks) {
+k_gather_vertex(ug_shade_args a, const float *__restrict__ vb, ug_ws_view ws, float *__restrict__ featbuf, int64_t nblocks) {
   constexpr int P = 2 * F + 1;
   const int64_t blk = ug_xcd_remap(blockIdx.x, nblocks);
   if (blk >= nblocks) return;
@@ -247,7 +192,7 @@ k_gather_vertex(ug_shade_args a, const float *__restrict__ vb, ug_ws_view ws, in
   const int lane = ug_lane(), s = lane >> 2, g = lane & 3;
   const int count = ws.count[tile];
   const float4 *__restrict__ ent = ws.ent + tile * ws.cap;
-  float *__restrict__ fo = ws.feat + tile * ws.cap * UG_FEAT_STRIDE;
+  float *__restrict__ fo = featbuf + tile * ws.cap * UG_FEAT_STRIDE;
   const int64_t vol = (int64_t)a.X * a.Y * a.Z;
   const float lo_g = g == 0 ? a.lox : (g == 1 ? a.loy : a.loz);
   const float ex_g = g == 0 ? a.ex : (g == 1 ? a.ey : a.ez);
@@ -329,7 +274,7 @@ k_gather_vertex(ug_shade_args a, const float *__restrict__ vb, ug_ws_view ws, in
 // the round-1 pair layout, optionally with every lane reading lane 0's cell (diagnostic)
 template <int F, int C, bool SAMECELL>
 __global__ void __launch_bounds__(256, 4)
-k_gather_pair(ug_shade_args a, const float *__restrict__ k0b, ug_ws_view ws, int64_t nblocks) {
+k_gather_pair(ug_shade_args a, const float *__restrict__ k0b, ug_ws_view ws, float *__restrict__ featbuf, int64_t nblocks) {
   constexpr int CH = UG_CH(C);
   const int64_t blk = ug_xcd_remap(blockIdx.x, nblocks);
   if (blk >= nblocks) return;
@@ -338,7 +283,7 @@ k_gather_pair(ug_shade_args a, const float *__restrict__ k0b, ug_ws_view ws, int
   const int lane = ug_lane(), h = lane >> 5, sv = lane & 31;
   const int count = ws.count[tile];
   const float4 *__restrict__ ent = ws.ent + tile * ws.cap;
-  float *__restrict__ fo = ws.feat + tile * ws.cap * UG_FEAT_STRIDE;
+  float *__restrict__ fo = featbuf + tile * ws.cap * UG_FEAT_STRIDE;
   for (int base = 0; base < count; base += 32) {
     const int e = base + sv;
     const bool ok = e < count;
@@ -357,12 +302,12 @@ k_gather_pair(ug_shade_args a, const float *__restrict__ k0b, ug_ws_view ws, int
 }
 
 // order-independent exact checksum of the valid feature entries (sum of the fp32 bit patterns) + double sum / sum of squares
-__global__ void k_feat_checksum(ug_ws_view ws, unsigned long long *__restrict__ out_bits, double *__restrict__ out_sum) {
+__global__ void k_feat_checksum(ug_ws_view ws, const float *__restrict__ featbuf, unsigned long long *__restrict__ out_bits, double *__restrict__ out_sum) {
   unsigned long long bits = 0;
   double s1 = 0.0, s2 = 0.0;
   for (int64_t tile = blockIdx.x; tile < ws.n_tiles; tile += gridDim.x) {
     const int64_t n = (int64_t)ws.count[tile] * UG_FEAT_STRIDE;
-    const float *f = ws.feat + tile * ws.cap * UG_FEAT_STRIDE;
+    const float *f = featbuf + tile * ws.cap * UG_FEAT_STRIDE;
     for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
       const float v = f[i];
       bits += (unsigned long long)__float_as_uint(v);
@@ -374,17 +319,22 @@ __global__ void k_feat_checksum(ug_ws_view ws, unsigned long long *__restrict__ 
   atomicAdd(out_sum + 1, s2);
 }
 
-extern "C" int ugx_feat_checksum(void *ws_mem, int64_t n_rays, int32_t S, void *out3, ugrid_stream_t s) {
+extern "C" int64_t ugx_feat_bytes(int64_t n_rays, int32_t S) {
+  return ((n_rays + UG_WAVE - 1) / UG_WAVE) * (int64_t)UG_WAVE * S * UG_FEAT_STRIDE * 4;
+}
+
+extern "C" int ugx_feat_checksum(void *ws_mem, const float *featbuf, int64_t n_rays, int32_t S, void *out3, ugrid_stream_t s) {
   ug_ws_view ws = ug_ws_make(ws_mem, n_rays, S);
   UG_HIP(hipMemsetAsync(out3, 0, 24, (hipStream_t)s));
-  hipLaunchKernelGGL(k_feat_checksum, dim3(2048), dim3(256), 0, (hipStream_t)s, ws, (unsigned long long *)out3,
+  hipLaunchKernelGGL(k_feat_checksum, dim3(2048), dim3(256), 0, (hipStream_t)s, ws, featbuf, (unsigned long long *)out3,
                      (double *)((char *)out3 + 8));
   UG_LAUNCH_CHECK();
   return 0;
 }
 
 // variant ids: see tools/gpu_gather_variants.py
-extern "C" int ugx_gather(const ugrid_render_params *p, const float *bricks, void *ws_mem, int variant, ugrid_stream_t s) {
+extern "C" int ugx_gather(const ugrid_render_params *p, const float *bricks, void *ws_mem, float *featbuf, int variant,
+                          ugrid_stream_t s) {
   if (p->freq_num != 3 || p->k0_channels != 12) return (int)hipErrorNotSupported;
   ug_ws_view ws = ug_ws_make(ws_mem, p->n_rays, p->n_samples);
   ug_shade_args a;
@@ -392,11 +342,11 @@ extern "C" int ugx_gather(const ugrid_render_params *p, const float *bricks, voi
   const int64_t nblocks = (ws.n_tiles + 3) / 4;
   const dim3 grid((unsigned)(((nblocks + 7) / 8) * 8)), block(256);
   hipStream_t st = (hipStream_t)s;
-#define UGX_Q(NBL, WPS, MODE) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_quad<3, NBL, WPS, MODE>), grid, block, 0, st, a, bricks, ws, nblocks)
-#define UGX_V(NBL, WPS) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_vertex<3, NBL, WPS>), grid, block, 0, st, a, bricks, ws, nblocks)
+#define UGX_Q(NBL, WPS, MODE) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_quad<3, NBL, WPS, MODE>), grid, block, 0, st, a, bricks, ws, featbuf, nblocks)
+#define UGX_V(NBL, WPS) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_vertex<3, NBL, WPS>), grid, block, 0, st, a, bricks, ws, featbuf, nblocks)
   switch (variant) {
-    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_pair<3, 12, false>), grid, block, 0, st, a, bricks, ws, nblocks); break;
-    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_pair<3, 12, true>), grid, block, 0, st, a, bricks, ws, nblocks); break;
+    case 0: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_pair<3, 12, false>), grid, block, 0, st, a, bricks, ws, featbuf, nblocks); break;
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(k_gather_pair<3, 12, true>), grid, block, 0, st, a, bricks, ws, featbuf, nblocks); break;
     case 10: UGX_Q(2, 4, 0); break;
     case 11: UGX_Q(2, 4, 1); break;
     case 12: UGX_Q(2, 4, 2); break;

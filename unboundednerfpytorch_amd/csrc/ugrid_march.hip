@@ -51,6 +51,31 @@ __global__ void k_pack_bricks(const float *__restrict__ grid, int P, int C, int 
   }
 }
 
+// quad layout of the C == 12 feature bricks (ugrid_render.h "quad k0 gather"): [cell][q 0..5][g 0..3][4 floats]; lane g
+// of a quad owns channels 3g..3g+2, float4 q holds coefficients 4(q&1)..4(q&1)+3 of channel 3g + (q>>1)
+__global__ void k_pack_quad(const float *__restrict__ grid, int P, int C, int X, int Y, int Z, float *__restrict__ out,
+                            int64_t total) {
+  for (int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+    const int e = (int)(o & 3), g = (int)((o >> 2) & 3);
+    int64_t r = o >> 4;
+    const int q = (int)(r % 6); r /= 6;
+    const int k = (int)(r % (Z - 1)); r /= (Z - 1);
+    const int j = (int)(r % (Y - 1)); r /= (Y - 1);
+    const int i = (int)(r % (X - 1)); r /= (X - 1);
+    const int l = (int)r;
+    const int chan = 3 * g + (q >> 1), c = 4 * (q & 1) + e;
+    const float *gp = grid + ((int64_t)l * C + chan) * X * Y * Z;
+    double acc = 0.0;   // inclusion-exclusion over the corners s that are sub-masks of c (as k_pack_bricks)
+    for (int s = 0; s < 8; ++s) {
+      if (s & ~c) continue;
+      const int ii = i + (s >> 2), jj = j + ((s >> 1) & 1), kk = k + (s & 1);
+      const double t = (double)gp[((int64_t)ii * Y + jj) * Z + kk];
+      acc += (__popc(c ^ s) & 1) ? -t : t;
+    }
+    out[o] = (float)acc;
+  }
+}
+
 // ----------------------------------------------------------------------------------------------
 // stand-alone grid query on the canonical layout (FourierGrid.forward / DenseGrid.forward).
 // 1 lane per point; corner taps are z-pairs in the [.., Z] fastest dimension.
@@ -174,8 +199,7 @@ k_march(ug_march_args a, const float *__restrict__ rays_o, const float *__restri
 // ----------------------------------------------------------------------------------------------
 extern "C" int64_t ugrid_render_ws_bytes(int64_t n_rays, int32_t S) {
   const int64_t n_tiles = (n_rays + UG_WAVE - 1) / UG_WAVE, cap = (int64_t)UG_WAVE * S;
-  return 256 + ug_align256(n_tiles * 4) + ug_align256(n_tiles * cap * 16) + ug_align256(n_tiles * cap) +
-         ug_align256(n_tiles * cap * UG_FEAT_STRIDE * 4);
+  return 256 + ug_align256(n_tiles * 4) + ug_align256(n_tiles * cap * 16) + ug_align256(n_tiles * cap);
 }
 
 extern "C" int ugrid_grid_query(const float *grid, int P, int C, int X, int Y, int Z, const float *xyz,
@@ -214,6 +238,15 @@ extern "C" int64_t ugrid_brick_bytes(int P, int C, int X, int Y, int Z, int dire
   return (int64_t)P * (X - 1) * (Y - 1) * (Z - 1) * H * 8 * CH * (int64_t)sizeof(float);
 }
 
+// the round-1 pair layout for any C (the C == 12 product path packs quads; kept for tools/gpu_gather_variants.py)
+extern "C" int ug_pack_bricks_pair(const float *grid, int P, int C, int X, int Y, int Z, float *bricks, ugrid_stream_t s) {
+  int H, CH = ug_brick_ch(C, &H);
+  const int64_t total = (int64_t)P * (X - 1) * (Y - 1) * (Z - 1) * H * 8 * CH;
+  hipLaunchKernelGGL(k_pack_bricks, dim3(256 * 64), dim3(256), 0, ST(s), grid, P, C, X, Y, Z, H, CH, 1, bricks, total);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ugrid_pack_bricks(const float *grid, int P, int C, int X, int Y, int Z, int direct,
                                  float *bricks, ugrid_stream_t s) {
   if (X < 2 || Y < 2 || Z < 2 || P < 1 || C < 1) return (int)hipErrorInvalidValue;
@@ -222,6 +255,12 @@ extern "C" int ugrid_pack_bricks(const float *grid, int P, int C, int X, int Y, 
   const int64_t total = (int64_t)P * (X - 1) * (Y - 1) * (Z - 1) * H * 8 * CH;
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 64) blocks = 256 * 64;
+  if (C == 12 && !direct) {   // 384 B per cell in the quad layout (same size as two 192-byte halves)
+    if ((int64_t)(X - 1) * (Y - 1) * (Z - 1) * 384 >= ((int64_t)1 << 32)) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_pack_quad, dim3((unsigned)blocks), dim3(256), 0, ST(s), grid, P, C, X, Y, Z, bricks, total);
+    UG_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_pack_bricks, dim3((unsigned)blocks), dim3(256), 0, ST(s), grid, P, C, X, Y, Z, H, CH,
                      direct ? 0 : 1, bricks, total);
   UG_LAUNCH_CHECK();

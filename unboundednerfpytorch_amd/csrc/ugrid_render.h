@@ -138,7 +138,6 @@ struct ug_ws_view {
   int32_t *count;   // [n_tiles]
   float4 *ent;      // [n_tiles][64*S]  (px, py, pz, weight)
   uint8_t *slot;    // [n_tiles][64*S]  ray slot (0..63) inside the tile
-  float *feat;      // [n_tiles][64*S][UG_FEAT_STRIDE] k0 features of the survivors (written by k_shade_gather)
   int64_t n_tiles, cap;
 };
 #define UG_FEAT_STRIDE 12
@@ -155,8 +154,6 @@ static inline ug_ws_view ug_ws_make(void *ws, int64_t n_rays, int32_t S) {
   v.ent = (float4 *)b;
   b += ug_align256(v.n_tiles * v.cap * (int64_t)sizeof(float4));
   v.slot = (uint8_t *)b;
-  b += ug_align256(v.n_tiles * v.cap);
-  v.feat = (float *)b;
   return v;
 }
 
@@ -306,7 +303,8 @@ __host__ __device__ static inline int ug_feat_of(int o, int r, int h) { return 3
 //   W3/(sW2*sX2) | b3 | {sX1, sX2/(sW1*sX1), 0, 0}
 struct ug_mlp_layout { int KL, offA1, offA2, offB1, offB2, offW3, offb3, total;
                        int KB1, bfA1, bfA2, bfB1, bfB2, bfW3, bfb3, total2;
-                       int hxA1, hxA2, hxB1, hxB2, hxW3, hxb3, hxS, total3; };
+                       int hxA1, hxA2, hxB1, hxB2, hxW3, hxb3, hxS, total3;
+                       int qA1, qA2, qB2, qW3, qb3, qS, total4; };
 // power-of-two scales of the fp16x2 image (ugrid_pack_mlp computes them on the host from the weights and the
 // caller's bound on |k0|)
 struct ug_mlp_scales { float sX1, sW1, sX2, sW2; };
@@ -337,8 +335,37 @@ __host__ __device__ static inline ug_mlp_layout ug_mlp_lay(int C, int n_emb) {
   L.hxb3 = L.hxW3 + 512;
   L.hxS = L.hxb3 + 4;
   L.total3 = L.hxS + 4;
+  // fourth image: fp16x2 operands for the 16x16x32 MFMA chain of k_shade_mlp16 (C = 12, PE = 4 only; see ug_shade_tile16):
+  //   qA1 [2 k-steps][8 tiles][2 parts][64 lanes][8 f16] | qA2 [4][8][2][64][8] | bias2 [4 groups][32] (x sW2 sX2) |
+  //   W3 [4 groups][32][4] (/ (sW2 sX2)) | b3 [4] | {sX1, sX2/(sW1 sX1), 0, 0}       (layer-1 bias rides in a K slot)
+  L.qA1 = L.total3;
+  L.qA2 = L.qA1 + 2 * 8 * 2 * 64 * 4;
+  L.qB2 = L.qA2 + 4 * 8 * 2 * 64 * 4;
+  L.qW3 = L.qB2 + 128;
+  L.qb3 = L.qW3 + 512;
+  L.qS = L.qb3 + 4;
+  L.total4 = L.qS + 4;
   return L;
 }
+
+// ---- K-slot maps of the 16x16x32 chain (C = 12, PE = 4): lane group jg = lane >> 4 supplies 16 layer-1 input slots
+//   0..2  k0 channels 3jg..3jg+2 (exactly what lane g = jg of a gather quad produces)
+//   3..8  (sin, cos) of the view-embedding pairs p = 3jg + (slot-3)/2, pair p = (axis p/4, frequency 2^(p%4))
+//   9     viewdir component jg (jg < 3) or the constant 1 whose weight column is the layer-1 bias (jg = 3)
+//   10..15 zero
+// returns the rgbnet input column, -1 for zero padding, -2 for the bias slot
+__host__ __device__ static inline int ug_q16_col(int slot, int jg) {
+  if (slot < 3) return 3 * jg + slot;
+  if (slot < 9) {
+    const int p = 3 * jg + ((slot - 3) >> 1), is_cos = (slot - 3) & 1;
+    return 12 + 3 + (is_cos ? 12 : 0) + p;      // sins: columns 15..26 ordered (axis, frequency) = p; cosines 27..38
+  }
+  if (slot == 9) return jg < 3 ? 12 + jg : -2;
+  return -1;
+}
+// layer-2 K slot (k-step ks, group jg, element e) = hidden feature 16 (2 ks + e/4) + 4 jg + e%4: the accumulator
+// registers [e%4] of tiles 2ks, 2ks+1 of the lane itself (C/D layout: rows 4 jg + r of a 16-row tile)
+__host__ __device__ static inline int ug_q16_feat(int ks, int jg, int e) { return 16 * (2 * ks + (e >> 2)) + 4 * jg + (e & 3); }
 
 // original rgbnet input column of (step s, half h); -1 = zero padding
 __host__ __device__ static inline int ug_in_col(int s, int h, int C, int n_emb, int KL) {
@@ -439,6 +466,118 @@ __device__ __forceinline__ void ug_k0_gather(const float *__restrict__ k0b, int 
   }
 #pragma unroll
   for (int ch = 0; ch < CH; ++ch) feat[ch] = ug_div_r(feat[ch], (float)P, 1.0f / (float)P);
+}
+
+// ---- explicit loads ------------------------------------------------------------------------------------------
+// hipcc sinks plain C++ loads down to their first use (one load in flight, s_waitcnt vmcnt(0) after each) or hoists
+// all of them (spills), whatever sched_barrier says, so the k0 gather issues its loads as volatile asm (program order
+// is kept among volatile asms) and waits with explicit s_waitcnt whose "+v" operands make every use of the loaded
+// registers depend on the wait.  The compiler's own vmcnt bookkeeping stays safe: memory operations return in order,
+// so loads it does not know about can only make its waits conservative.
+typedef float ug_f4 __attribute__((ext_vector_type(4)));
+template <int IMM>
+__device__ __forceinline__ ug_f4 ug_gload4(unsigned voff, const float *sbase) {
+  ug_f4 r;
+  asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
+  return r;
+}
+template <int N>
+__device__ __forceinline__ void ug_vmwait6(ug_f4 (&v)[6]) {
+  asm volatile("s_waitcnt vmcnt(%6)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]) : "n"(N));
+}
+
+// ---- quad k0 gather (C == 12) ----------------------------------------------------------------------------------
+// Four ADJACENT lanes own a survivor.  Brick = [cell][q 0..5][g 0..3][4 floats] (k_pack_quad): load q of the quad reads 64
+// contiguous, 64-byte aligned bytes, and lane g ends up with all 8 polynomial coefficients of channels 3g..3g+2
+// (float4 2c = coefficients 0..3, 2c+1 = 4..7 of channel 3g+c).  The texture addresser works through a dwordx4 load
+// four lanes (64 B) per cycle, and measured on the S1 work list (profiles/r02/gather_variants.txt) the round-1 layout
+// -- lanes l / l+32 per survivor, 64 different 16-byte pieces per instruction -- ran the stand-alone gather in 5.3 ms
+// against 3.4 ms for this one (same bytes, same arithmetic, bit-identical features).
+template <int K>
+__device__ __forceinline__ float ug_quad_bcast(float x) {   // value of lane (lane & ~3) + K: one DPP move
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(x), K * 0x55, 0xf, 0xf, true));
+}
+
+// 3 channels of one level from the lane's 6 float4: Horner in z, y, x (7 FMAs per channel, as ug_density_level)
+__device__ __forceinline__ void ug_quad_poly(const ug_f4 (&v)[6], float tx, float ty, float tz, bool first, float (&feat)[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const ug_f4 lo = v[2 * c], hi = v[2 * c + 1];
+    const float p00 = fmaf(lo.y, tz, lo.x), p01 = fmaf(lo.w, tz, lo.z);
+    const float p10 = fmaf(hi.y, tz, hi.x), p11 = fmaf(hi.w, tz, hi.z);
+    const float f = fmaf(fmaf(p11, ty, p10), tx, fmaf(p01, ty, p00));
+    feat[c] = first ? f : feat[c] + f;
+  }
+}
+
+// per-lane axis constants of the shared set-up: lane g of a quad works on axis min(g, 2) and the quad combines the
+// three axes through DPP broadcasts (the set-up -- 3 sincos, 7 cell / fraction pairs -- costs a third per survivor)
+struct ug_quad_axis { float lo, ex, ir, nm1, nm2; unsigned goff; };
+__device__ __forceinline__ ug_quad_axis ug_quad_axis_of(const ug_shade_args &a, int g) {
+  ug_quad_axis q;
+  q.lo = g == 0 ? a.lox : (g == 1 ? a.loy : a.loz);
+  q.ex = g == 0 ? a.ex : (g == 1 ? a.ey : a.ez);
+  q.ir = g == 0 ? a.irx : (g == 1 ? a.iry : a.irz);
+  const int n = g == 0 ? a.X : (g == 1 ? a.Y : a.Z);
+  q.nm1 = (float)(n - 1); q.nm2 = (float)(n - 2);
+  q.goff = (unsigned)g * 16u;
+  return q;
+}
+
+// k0 features (mean over the P levels) of the quad's survivor at p: this lane's 3 channels.  NBL levels (x 6 loads) are
+// in flight; level l+NBL is issued right after level l's polynomial.
+template <int F, int NBL>
+__device__ __forceinline__ void ug_k0_gather_quad(const float *__restrict__ k0b, const ug_shade_args &a,
+                                                  const ug_quad_axis &qa, float p_g, float (&feat)[3]) {
+  constexpr int P = 2 * F + 1;
+  const float u = ug_div_r(p_g - qa.lo, qa.ex, qa.ir) * 2.f - 1.f;
+  float lc[P];
+  lc[0] = u;
+#pragma unroll
+  for (int k = 0; k < F; ++k) ug_sincos((float)(1 << k) * u, &lc[2 * k + 1], &lc[2 * k + 2]);
+  unsigned off[P];
+  float tx[P], ty[P], tz[P];
+#pragma unroll
+  for (int l = 0; l < P; ++l) {
+    // ug_axis_inrange with the lane's own axis length
+    const float ix = fmaf(lc[l], 0.5f, 0.5f) * qa.nm1;
+    const float cf = __builtin_amdgcn_fmed3f(floorf(ix), 0.0f, qa.nm2);
+    const float wh = ix - cf;
+    const float cxf = ug_quad_bcast<0>(cf), cyf = ug_quad_bcast<1>(cf), czf = ug_quad_bcast<2>(cf);
+    tx[l] = ug_quad_bcast<0>(wh); ty[l] = ug_quad_bcast<1>(wh); tz[l] = ug_quad_bcast<2>(wh);
+    const unsigned row = (unsigned)fmaf(cxf, (float)(a.Y - 1), cyf);     // exact in fp32: (X-1)(Y-1) < 2^24
+    const unsigned cell = __umul24(row, (unsigned)(a.Z - 1)) + (unsigned)czf;
+    off[l] = __umul24(cell, 384u) + qa.goff;                              // bytes inside the level (< 4 GiB)
+  }
+  const int64_t lvl_floats = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1) * 96;
+  ug_f4 v[NBL][6];
+#define UG_ISSUE_LEVEL(l_)                                                                             \
+  {                                                                                                    \
+    const float *lb = k0b + (int64_t)(l_) * lvl_floats;                                                \
+    v[(l_) % NBL][0] = ug_gload4<0>(off[l_], lb);   v[(l_) % NBL][1] = ug_gload4<64>(off[l_], lb);    \
+    v[(l_) % NBL][2] = ug_gload4<128>(off[l_], lb); v[(l_) % NBL][3] = ug_gload4<192>(off[l_], lb);   \
+    v[(l_) % NBL][4] = ug_gload4<256>(off[l_], lb); v[(l_) % NBL][5] = ug_gload4<320>(off[l_], lb);   \
+  }
+#pragma unroll
+  for (int l = 0; l < NBL && l < P; ++l) UG_ISSUE_LEVEL(l)
+#pragma unroll
+  for (int l = 0; l < P; ++l) {
+    const int after = (P - 1 - l) < (NBL - 1) ? (P - 1 - l) : (NBL - 1);   // levels issued after level l
+    if (after == 0) ug_vmwait6<0>(v[l % NBL]);
+    else if (after == 1) ug_vmwait6<6>(v[l % NBL]);
+    else if (after == 2) ug_vmwait6<12>(v[l % NBL]);
+    else if (after == 3) ug_vmwait6<18>(v[l % NBL]);
+    else if (after == 4) ug_vmwait6<24>(v[l % NBL]);
+    else ug_vmwait6<30>(v[l % NBL]);
+    ug_quad_poly(v[l % NBL], tx[l], ty[l], tz[l], l == 0, feat);
+    // keep the level's math here: without the pin the scheduler hoists every later load above it (spills)
+    asm volatile("" :: "v"(feat[0]), "v"(feat[1]), "v"(feat[2]));
+    __builtin_amdgcn_sched_barrier(0);
+    if (l + NBL < P) UG_ISSUE_LEVEL(l + NBL)
+  }
+#undef UG_ISSUE_LEVEL
+#pragma unroll
+  for (int c = 0; c < 3; ++c) feat[c] = ug_div_r(feat[c], (float)P, 1.0f / (float)P);
 }
 
 __device__ __forceinline__ void ug_wave_lds_sync() {
@@ -650,16 +789,27 @@ __device__ __forceinline__ void ug_mfma3x4(const f16x8 *__restrict__ Ap, const f
   for (int o = 0; o < 4; ++o) { UG_MFMA_F16(acc[o], wh.w[o], x.h); }
 }
 
+// Optional phase profile (-DUG_SHADE_PROF, tools/gpu_shade_phases.sh): shader-clock ticks per phase of ug_shade_tile,
+// summed over all waves into g_shade_prof; phases: 0 tile set-up, 1 gather round 0, 2 gather round 1, 3 layer 1,
+// 4 layer 2, 5 layer 3 + sigmoid, 6 per-ray accumulation, 7 tile scheduling (outside this function)
+#ifdef UG_SHADE_PROF
+struct ug_prof { unsigned long long t, acc[8]; };
+#define UG_PROF_MARK(pr, i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (pr).acc[i] += now_ - (pr).t; (pr).t = now_; }
+#else
+struct ug_prof { };
+#define UG_PROF_MARK(pr, i)
+#endif
+
 // Shade one tile's survivor list (32 survivors per pass, lanes l / l+32 pair up) and write the tile's
 // rgb_marched.  C = 2*CH or 2*CH-1 k0 channels, PE view-direction frequencies; rgbnet 128 wide, 3 layers.
-// PRE: the k0 features were gathered by k_shade_gather into `feat` ([entries][UG_FEAT_STRIDE]); otherwise they
-// are gathered here from the k0 bricks.
-template <int F, int C, int PE, int BF, bool PRE>
+// C == 12: k0 bricks in the quad layout, gathered 16 survivors at a time by lane quads and transposed into the MFMA
+// operand layout through 768 B of the wave's LDS scratch; other C: pair half-bricks gathered directly in that layout.
+template <int F, int C, int PE, int BF>
 __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const float *__restrict__ viewdirs,
                                               const float *__restrict__ k0b, const ug_mlp_lds &M, int64_t tile,
                                               int count, const float4 *__restrict__ ent,
-                                              const uint8_t *__restrict__ slot, const float *__restrict__ feat_in,
-                                              float *__restrict__ scr, float *__restrict__ rgb_marched) {
+                                              const uint8_t *__restrict__ slot,
+                                              float *__restrict__ scr, float *__restrict__ rgb_marched, ug_prof &prof) {
   constexpr int CH = UG_CH(C);
   constexpr int NEMB = 3 + 6 * PE;
   constexpr int KL = (2 * CH + NEMB + 1) / 2;
@@ -698,28 +848,62 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     ug_wave_lds_sync();
   }
 
-  // the work-list entry of the NEXT pass is fetched while this pass's rgbnet runs (software prefetch)
+  UG_PROF_MARK(prof, 7)
+  constexpr bool QUAD = (C == 12);
+  const int qs = lane >> 2, qg = lane & 3;
+  const ug_quad_axis qa = ug_quad_axis_of(a, qg);
+  // the work-list entries of the NEXT pass are fetched while this pass's rgbnet runs (software prefetch): the lane's own
+  // survivor (weight, ray slot) and, in the quad layout, the positions of the two survivors its quad gathers
+  float w_n = 0.f, pg0_n = 0.f, pg1_n = 0.f;
   float4 en_n = make_float4(0.f, 0.f, 0.f, 0.f);
   int sl_n = 0;
-  if (sv < count) { en_n = ent[sv]; sl_n = slot[sv]; }
+  if (sv < count) { sl_n = slot[sv]; if constexpr (QUAD) w_n = ent[sv].w; else en_n = ent[sv]; }
+  if constexpr (QUAD) {
+    const float *ef = (const float *)ent;
+    if (qs < count) pg0_n = ef[4 * qs + (qg < 2 ? qg : 2)];
+    if (16 + qs < count) pg1_n = ef[4 * (16 + qs) + (qg < 2 ? qg : 2)];
+  }
+  UG_PROF_MARK(prof, 0)
   for (int base = 0; base < count; base += 32) {
     const int e = base + sv;
     const bool ok = e < count;
-    const float4 en = en_n;
+    const float4 en = QUAD ? make_float4(0.f, 0.f, 0.f, w_n) : en_n;
     const int sl = sl_n;
+    const float pg0 = pg0_n, pg1 = pg1_n;
     {
       const int e2 = e + 32;
       en_n = make_float4(0.f, 0.f, 0.f, 0.f);
-      sl_n = 0;
-      if (e2 < count) { en_n = ent[e2]; sl_n = slot[e2]; }
+      sl_n = 0; w_n = 0.f; pg0_n = 0.f; pg1_n = 0.f;
+      if (e2 < count) { sl_n = slot[e2]; if constexpr (QUAD) w_n = ent[e2].w; else en_n = ent[e2]; }
+      if constexpr (QUAD) {
+        const float *ef = (const float *)ent;
+        const int q0 = base + 32 + qs, q1 = base + 48 + qs;
+        if (q0 < count) pg0_n = ef[4 * q0 + (qg < 2 ? qg : 2)];
+        if (q1 < count) pg1_n = ef[4 * q1 + (qg < 2 ? qg : 2)];
+      }
     }
     // ---- layer-1 inputs of this lane: half of k0 + half of the view-direction embedding
     float x[KL];
     {
       float feat[CH];
-      if constexpr (PRE) {
+      if constexpr (QUAD) {
+        // two rounds of 16 survivors (one per quad); lane (qs, qg) computes channels 3qg..3qg+2, the round's 16 x 12
+        // features go through the scratch ([survivor][12], conflict-free both ways) and lane (h, sv) of that round
+        // picks its 6 channels.  LDS operations of a wave execute in order: write -> read -> next round's write.
+        float *xp = scr;
 #pragma unroll
-        for (int s = 0; s < CH; ++s) feat[s] = ok ? feat_in[(int64_t)e * UG_FEAT_STRIDE + h * CH + s] : 0.f;
+        for (int it = 0; it < 2; ++it) {
+          float f3[3];
+          ug_k0_gather_quad<F, 4>(k0b, a, qa, it ? pg1 : pg0, f3);
+          xp[qs * 12 + 3 * qg + 0] = f3[0]; xp[qs * 12 + 3 * qg + 1] = f3[1]; xp[qs * 12 + 3 * qg + 2] = f3[2];
+          ug_wave_lds_sync();
+          const float *rp = xp + (sv & 15) * 12 + h * 6;
+          const bool mine = ((sv >> 4) == it);
+#pragma unroll
+          for (int k = 0; k < 6; ++k) { const float t = rp[k]; feat[k] = (it == 0 || mine) ? t : feat[k]; }
+          ug_wave_lds_sync();
+          UG_PROF_MARK(prof, 1 + it)
+        }
       } else {
         ug_k0_gather<F, CH>(k0b, h, en.x, en.y, en.z, a, feat);
       }
@@ -756,6 +940,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
       }
     }
     // ---- layers 1 and 2 on the matrix cores, transposed (H^T = W . X^T): accumulators feed the next layer
+    UG_PROF_MARK(prof, 2)
     f32x16 acc1[4], acc2[4];
     int bo = h * 64;
     asm volatile("" : "+v"(bo));  // keeps the 128 bias reads inside the pass (LICM would hoist + spill them)
@@ -814,6 +999,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
         xs = xn;
       }
       ug_fence_results();
+      UG_PROF_MARK(prof, 3)
 #pragma unroll
       for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -886,6 +1072,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
       ug_fence_results();
     }
     // ---- layer 3 (3 outputs) on the VALU: each lane of the pair reduces its 64 features
+    UG_PROF_MARK(prof, 4)
     float l0 = 0.f, l1 = 0.f, l2 = 0.f;
 #pragma unroll
     for (int st = 0; st < 64; ++st) {
@@ -900,6 +1087,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
     // weights.unsqueeze(-1) * rgb, then a per-ray sum in sample order (segment_coo semantics)
     const float pr = en.w * ug_sigmoid(l0), pg = en.w * ug_sigmoid(l1), pb = en.w * ug_sigmoid(l2);
+    UG_PROF_MARK(prof, 5)
     {
       // per-ray sum in list (= sample) order through LDS: survivors publish their value and set their bit in the
       // owning ray's mask (ds_or: commutative, so deterministic); each ray lane then walks its bits upwards.
@@ -922,6 +1110,241 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
       }
       __builtin_amdgcn_wave_barrier();   // the next pass rewrites aval / amask
     }
+    UG_PROF_MARK(prof, 6)
+  }
+  const int64_t ray = tile * UG_WAVE + lane;
+  if (ray < a.n_rays) {
+    rgb_marched[3 * ray] = accr;
+    rgb_marched[3 * ray + 1] = accg;
+    rgb_marched[3 * ray + 2] = accb;
+  }
+}
+
+
+// ================================================================================================================
+// 16x16x32 variant of the shade tile (C = 12, PE = 4, fp16x2 arithmetic): 16 survivors per pass, half the accumulator
+// registers of the 32x32 chain, so the kernel fits 128 VGPRs and runs 16 waves per CU (4 per SIMD) instead of 8.
+// Why: the phase profile of the 8-wave kernel (profiles/r02/shade_phases_8wave.txt) shows a wave spending ~23 k ticks
+// per 32 survivors in strictly serial phases (gather 10 k, layers 1+2 8.7 k, layer 3 3.3 k, accumulation 1 k) with
+// every pipe under 40 % busy: latency-bound at 2 waves per SIMD, not bound by any unit.
+//   * gather: one round of ug_k0_gather_quad (lane = 4 s + g), then 3 ds_bpermute move channels 3g..3g+2 of survivor s to
+//     lane (n = s, jg = g) = s + 16 g, the lane group that owns those K slots of the MFMA B operand
+//   * view embedding: no per-tile table (LDS is taken by 16 waves' worth of weights); lane group jg evaluates the three
+//     (axis, frequency) pairs of its K slots -- 3 sincos per pass
+//   * layer 1: K = 40 inputs (12 + 27 + the bias slot) in 2 k-steps of 32; layer 2: 4 k-steps; 8 output tiles of 16 rows;
+//     three fp16 products per k-step (Wl.xh, Wh.xl, Wh.xh); MFMAs round-robin over >= 4 tiles so that none reads the
+//     accumulator written right before it; A operands stream from LDS four tiles at a time, one group ahead
+//   * layer 3: each lane reduces its 32 hidden features, two cross-group shuffles finish the dot products
+// ================================================================================================================
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+struct ug_mlp16_lds { const f16x8 *A1, *A2; const float *B2, *b3; const float4 *W3; float sx1, c12; };
+
+__host__ __device__ static inline int ug_mlp16_lds_floats() {
+  const ug_mlp_layout ML = ug_mlp_lay(12, 27);
+  return ML.qS - ML.qA1;
+}
+#define UG_ACC16_SCRATCH_FLOATS 128   // per wave: [0,64) per-ray survivor bit masks + [64,128) 16 x {r,g,b,-}
+
+__device__ __forceinline__ ug_mlp16_lds ug_mlp16_stage(float *lds, const float *__restrict__ mlp) {
+  const ug_mlp_layout ML = ug_mlp_lay(12, 27);
+  const int n = ug_mlp16_lds_floats();
+  const float4 *src = (const float4 *)(mlp + ML.qA1);
+  float4 *dst = (float4 *)lds;
+  for (int i = threadIdx.x; i < n / 4; i += blockDim.x) dst[i] = src[i];
+  __syncthreads();
+  ug_mlp16_lds m;
+  m.A1 = (const f16x8 *)lds;
+  m.A2 = (const f16x8 *)(lds + (ML.qA2 - ML.qA1));
+  m.B2 = lds + (ML.qB2 - ML.qA1);
+  m.W3 = (const float4 *)(lds + (ML.qW3 - ML.qA1));
+  m.b3 = lds + (ML.qb3 - ML.qA1);
+  m.sx1 = mlp[ML.qS];
+  m.c12 = mlp[ML.qS + 1];
+  return m;
+}
+
+#define UG_MFMA16(acc, a, b)                                          \
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);   \
+  __builtin_amdgcn_sched_barrier(0)
+
+struct ug_a4 { f16x8 w[4]; };
+// A operands of tiles t0..t0+3 for (k-step block `ks_base` already folded into Ap, part): unit = 64 lanes x 16 B
+__device__ __forceinline__ ug_a4 ug_load_a4(const f16x8 *__restrict__ Ap, int t0, int part) {
+  ug_a4 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.w[i] = Ap[((t0 + i) * 2 + part) * 64];
+  return r;
+}
+
+// one k-step over the 8 output tiles: acc[t] += Wl.xh + Wh.xl + Wh.xh.  `cur` holds Wl of tiles 0..3 on entry (loaded by
+// the previous step); on exit it holds the next step's (Ap_next).
+__device__ __forceinline__ void ug_kstep16(const f16x8 *__restrict__ Ap, const f16x8 *__restrict__ Ap_next,
+                                           const ug_split2 &x, f32x4 (&acc)[8], ug_a4 &cur) {
+  ug_a4 nxt = ug_load_a4(Ap, 4, 1);          // Wl tiles 4..7
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { UG_MFMA16(acc[i], cur.w[i], x.h); }
+  cur = ug_load_a4(Ap, 0, 0);                // Wh tiles 0..3
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { UG_MFMA16(acc[4 + i], nxt.w[i], x.h); }
+  nxt = ug_load_a4(Ap, 4, 0);                // Wh tiles 4..7
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { UG_MFMA16(acc[i], cur.w[i], x.l); }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { UG_MFMA16(acc[i], cur.w[i], x.h); }
+  cur = ug_load_a4(Ap_next, 0, 1);           // next step's Wl tiles 0..3 (harmless re-read after the last step)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { UG_MFMA16(acc[4 + i], nxt.w[i], x.l); }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { UG_MFMA16(acc[4 + i], nxt.w[i], x.h); }
+}
+
+template <int F>
+__device__ __forceinline__ void ug_shade_tile16(const ug_shade_args &a, const float *__restrict__ viewdirs,
+                                                const float *__restrict__ k0b, const ug_mlp16_lds &M, int64_t tile,
+                                                int count, const float4 *__restrict__ ent,
+                                                const uint8_t *__restrict__ slot, float *__restrict__ scr,
+                                                float *__restrict__ rgb_marched, ug_prof &prof, int dbg) {
+  // dbg (experiments only, ugrid_tune("shade_dbg")): bit 0 = no k0 loads (features := position), bit 1 = no rgbnet
+  const int lane = ug_lane();
+  const int n = lane & 15, jg = lane >> 4;     // MFMA roles: survivor of the pass, K-slot group
+  const int qs = lane >> 2, qg = lane & 3;     // gather roles: survivor of the pass, channel group
+  const ug_quad_axis qa = ug_quad_axis_of(a, qg);
+  unsigned *amask = (unsigned *)scr;           // [64]
+  float4 *aval = (float4 *)(scr + 64);         // [16]
+  float accr = 0.f, accg = 0.f, accb = 0.f;    // lane = ray slot of this tile
+  // this lane's three embedding pairs p = 3 jg + i: axis p >> 2, frequency 2^(p & 3)
+  int ax_i[3];
+  float fr_i[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { const int p = 3 * jg + i; ax_i[i] = p >> 2; fr_i[i] = (float)(1 << (p & 3)); }
+  const float *ef = (const float *)ent;
+  const int comp = qg < 2 ? qg : 2;
+  UG_PROF_MARK(prof, 7)
+  float w_n = 0.f, pg_n = 0.f;
+  int sl_n = 0;
+  if (n < count) { sl_n = slot[n]; w_n = ef[4 * n + 3]; }
+  if (qs < count) pg_n = ef[4 * qs + comp];
+  UG_PROF_MARK(prof, 0)
+  for (int base = 0; base < count; base += 16) {
+    const bool ok = base + n < count;
+    const float w = w_n, pg = pg_n;
+    const int sl = sl_n;
+    {
+      const int e2 = base + 16 + n, q2 = base + 16 + qs;
+      w_n = 0.f; pg_n = 0.f; sl_n = 0;
+      if (e2 < count) { sl_n = slot[e2]; w_n = ef[4 * e2 + 3]; }
+      if (q2 < count) pg_n = ef[4 * q2 + comp];
+    }
+    // view direction of the survivor's ray (L1-resident: 64 rays per tile)
+    int64_t ray = tile * UG_WAVE + sl;
+    if (ray >= a.n_rays) ray = a.n_rays - 1;
+    const float vx = viewdirs[3 * ray], vy = viewdirs[3 * ray + 1], vz = viewdirs[3 * ray + 2];
+    // ---- k0 features: quad gather, then to the MFMA lane of (survivor, channel group)
+    float x[16];
+    {
+      float f3[3];
+      if (dbg & 1) { f3[0] = pg; f3[1] = pg * 0.5f; f3[2] = pg * 0.25f; }
+      else ug_k0_gather_quad<F, 2>(k0b, a, qa, pg, f3);
+      const int src = (4 * n + jg) << 2;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) x[c] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(f3[c])));
+    }
+    UG_PROF_MARK(prof, 1)
+    if (dbg & 2) {
+      if (ok && jg == 0) { accr += x[0] * w; accg += x[1] * w; accb += x[2] * w; }
+      continue;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const float v = ax_i[i] == 0 ? vx : (ax_i[i] == 1 ? vy : vz);
+      ug_sincos(v * fr_i[i], &x[3 + 2 * i], &x[4 + 2 * i]);
+    }
+    x[9] = jg == 0 ? vx : (jg == 1 ? vy : (jg == 2 ? vz : 1.0f));
+    ug_split2 xs0, xs1;
+    {
+      float v8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v8[e] = x[e];
+      xs0 = ug_split8h(v8, M.sx1);
+      v8[0] = x[8]; v8[1] = x[9];
+#pragma unroll
+      for (int e = 2; e < 8; ++e) v8[e] = 0.f;
+      xs1 = ug_split8h(v8, M.sx1);
+    }
+    UG_PROF_MARK(prof, 2)
+    // ---- layer 1: 2 k-steps
+    f32x4 acc1[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ug_a4 cur = ug_load_a4(M.A1 + lane, 0, 1);
+    ug_fence_operands();
+    ug_kstep16(M.A1 + lane, M.A1 + 16 * 64 + lane, xs0, acc1, cur);
+    ug_kstep16(M.A1 + 16 * 64 + lane, M.A2 + lane, xs1, acc1, cur);
+    ug_fence_results();
+    UG_PROF_MARK(prof, 3)
+    // ---- layer 2: relu, rescale + split (K slot e of k-step ks = register e%4 of tile 2ks + e/4), 4 k-steps
+    ug_split2 hs[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      float v8[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v8[e] = ug_relu(acc1[2 * ks + (e >> 2)][e & 3]);
+      hs[ks] = ug_split8h(v8, M.c12);
+    }
+    f32x4 acc2[8];
+    {
+      const float4 *b2p = (const float4 *)(M.B2 + jg * 32);
+#pragma unroll
+      for (int t = 0; t < 8; ++t) { const float4 b = b2p[t]; acc2[t] = (f32x4){b.x, b.y, b.z, b.w}; }
+    }
+    ug_fence_operands();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      ug_kstep16(M.A2 + ks * 16 * 64 + lane, M.A2 + (ks + 1 < 4 ? ks + 1 : ks) * 16 * 64 + lane, hs[ks], acc2, cur);
+    ug_fence_results();
+    UG_PROF_MARK(prof, 4)
+    // ---- layer 3: this lane's 32 hidden features, then the other three lane groups of the survivor
+    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+    {
+      const float4 *w3p = M.W3 + jg * 32;
+#pragma unroll
+      for (int tr = 0; tr < 32; ++tr) {
+        const float hv = ug_relu(acc2[tr >> 2][tr & 3]);
+        const float4 w3 = w3p[tr];
+        l0 = fmaf(w3.x, hv, l0);
+        l1 = fmaf(w3.y, hv, l1);
+        l2 = fmaf(w3.z, hv, l2);
+      }
+    }
+    l0 = l0 + __shfl_xor(l0, 16); l1 = l1 + __shfl_xor(l1, 16); l2 = l2 + __shfl_xor(l2, 16);
+    l0 = (l0 + __shfl_xor(l0, 32)) + M.b3[0];
+    l1 = (l1 + __shfl_xor(l1, 32)) + M.b3[1];
+    l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
+    const float pr = w * ug_sigmoid(l0), pgc = w * ug_sigmoid(l1), pb = w * ug_sigmoid(l2);
+    UG_PROF_MARK(prof, 5)
+    {
+      // ordered per-ray sum through LDS (see ug_shade_tile): 16 entries per pass, published by lane group 0
+      amask[lane] = 0u;
+      ug_wave_lds_sync();
+      if (ok && jg == 0) {
+        aval[n] = make_float4(pr, pgc, pb, 0.f);
+        atomicOr(&amask[sl], 1u << n);
+      }
+      ug_wave_lds_sync();
+      unsigned m = amask[lane];
+      while (m) {
+        const int k = __builtin_ctz(m);
+        const float4 t = aval[k];
+        accr += t.x; accg += t.y; accb += t.z;
+        m &= m - 1;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    UG_PROF_MARK(prof, 6)
   }
   const int64_t ray = tile * UG_WAVE + lane;
   if (ray < a.n_rays) {

@@ -3,6 +3,8 @@
 #include "ugrid_render.h"
 
 extern "C" int ug_set_march_waves(int w);  // ugrid_march.hip
+static int g_shade_dbg = 0;  // experiments: ugrid_tune("shade_dbg", bits) -- WRONG RESULTS by design (see ug_shade_tile16)
+static int g_shade16 = 0;   // ugrid_tune("shade16", 0|1): 16x16x32 / 16-wave kernel where it applies (A/B switch)
 
 __global__ void k_pack_mlp(const float *__restrict__ w0, const float *__restrict__ b0,
                            const float *__restrict__ w1, const float *__restrict__ b1,
@@ -31,6 +33,45 @@ __global__ void k_pack_mlp(const float *__restrict__ w0, const float *__restrict
   }
   if (blockIdx.x == 0 && threadIdx.x < 4)
     out[L.hxS + threadIdx.x] = threadIdx.x == 0 ? sc.sX1 : (threadIdx.x == 1 ? sc.sX2 / (sc.sW1 * sc.sX1) : 0.f);
+  // 16x16x32 fp16x2 image (k_shade_mlp16; C = 12, PE = 4): A operands lane (m = lane & 15, jg = lane >> 4) holds
+  // W[16 t + m][input of K slot (jg, 8 ks + e)]
+  if (C == 12 && n_emb == 27) {
+    unsigned short *qx = (unsigned short *)(out + L.qA1);
+    const int n_q = (L.qB2 - L.qA1) * 2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_q; i += gridDim.x * blockDim.x) {
+      const int e = i & 7, lane = (i >> 3) & 63, u = i >> 9;      // u = (ks * 8 + t) * 2 + part, layer 2 after layer 1
+      const int part = u & 1, t = (u >> 1) & 7, ksg = u >> 4;
+      const int m = lane & 15, jg = lane >> 4, f = 16 * t + m;
+      float w = 0.f;
+      if (ksg < 2) {
+        const int slot = 8 * ksg + e;
+        const int col = ug_q16_col(slot, jg);
+        if (col >= 0) w = w0[f * mlp_in + col] * sc.sW1;
+        else if (col == -2) w = b0[f] * sc.sW1;                 // the constant-one slot carries the layer-1 bias
+      } else {
+        const int ks = ksg - 2;
+        w = w1[f * 128 + ug_q16_feat(ks, jg, e)] * sc.sW2;
+      }
+      const _Float16 hh = (_Float16)w;
+      const _Float16 ll = (_Float16)(w - (float)hh);
+      qx[i] = __builtin_bit_cast(unsigned short, part == 0 ? hh : ll);
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 128 + 512 + 8; i += gridDim.x * blockDim.x) {
+      float v = 0.f;
+      if (i < 128) {                     // bias2 [jg][4 t + r] at the accumulator scale of layer 2
+        const int jg = i >> 5, t = (i >> 2) & 7, r = i & 3;
+        v = b1[16 * t + 4 * jg + r] * (sc.sW2 * sc.sX2);
+      } else if (i < 640) {              // W3 [jg][4 t + r][c]
+        const int q = i - 128, c = q & 3, tr = (q >> 2) & 31, jg = q >> 7;
+        if (c < 3) v = w2[c * 128 + 16 * (tr >> 2) + 4 * jg + (tr & 3)] / (sc.sW2 * sc.sX2);
+      } else if (i < 644) {
+        if (i - 640 < 3) v = b2[i - 640];
+      } else {
+        v = (i == 644) ? sc.sX1 : (i == 645 ? sc.sX2 / (sc.sW1 * sc.sX1) : 0.f);
+      }
+      out[L.qB2 + i] = v;
+    }
+  }
   // bf16x3 image: one thread per bf16 element
   unsigned short *bf = (unsigned short *)(out + L.bfA1);
   const int n_bf = (L.bfB1 - L.bfA1) * 2;
@@ -87,36 +128,23 @@ __global__ void k_pack_mlp(const float *__restrict__ w0, const float *__restrict
   }
 }
 
-// persistent shade kernel over a work list written by k_march (two-kernel path)
-// k0 feature gather for every survivor of the work list, decoupled from the rgbnet so it can run at high
-// occupancy (latency-bound scattered 192-byte reads): lanes l / l+32 own survivor l&31 and one channel half each.
-template <int F, int C>
-__global__ void __launch_bounds__(256, 4)
-k_shade_gather(ug_shade_args a, const float *__restrict__ k0b, ug_ws_view ws, int64_t nblocks) {
-  constexpr int CH = UG_CH(C);
-  const int64_t blk = ug_xcd_remap(blockIdx.x, nblocks);
-  if (blk >= nblocks) return;
-  const int64_t tile = blk * 4 + (threadIdx.x >> 6);
-  if (tile >= ws.n_tiles) return;
-  const int lane = ug_lane(), h = lane >> 5, sv = lane & 31;
-  const int count = ws.count[tile];
-  const float4 *__restrict__ ent = ws.ent + tile * ws.cap;
-  float *__restrict__ fo = ws.feat + tile * ws.cap * UG_FEAT_STRIDE;
-  for (int base = 0; base < count; base += 32) {
-    const int e = base + sv;
-    const bool ok = e < count;
-    float4 en = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (ok) en = ent[e];
-    float feat[CH];
-    ug_k0_gather<F, CH>(k0b, h, en.x, en.y, en.z, a, feat);
-    if (ok) {
-#pragma unroll
-      for (int s = 0; s < CH; ++s) fo[(int64_t)e * UG_FEAT_STRIDE + h * CH + s] = feat[s];
-    }
-  }
+#ifdef UG_SHADE_PROF
+__device__ unsigned long long g_shade_prof[8];
+extern "C" int ugx_shade_prof_read(unsigned long long *host8) {
+  UG_HIP(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_shade_prof), 64));
+  unsigned long long z[8] = {0};
+  UG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_shade_prof), z, 64));
+  return 0;
 }
+#define UG_PROF_INIT(pr) ug_prof pr; pr.t = __builtin_amdgcn_s_memtime(); for (int i_ = 0; i_ < 8; ++i_) pr.acc[i_] = 0;
+#define UG_PROF_FLUSH(pr) if (ug_lane() == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_shade_prof[i_], pr.acc[i_]);
+#else
+#define UG_PROF_INIT(pr) ug_prof pr;
+#define UG_PROF_FLUSH(pr)
+#endif
 
-template <int F, int C, int PE, int NW, int BF, bool PRE>
+// persistent shade kernel over a work list written by k_march (two-kernel path)
+template <int F, int C, int PE, int NW, int BF>
 __global__ void __launch_bounds__(NW * 64, NW / 4)
 k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
             const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
@@ -125,13 +153,34 @@ k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__
   const ug_mlp_lds M = ug_mlp_stage<C, PE, BF>(lds, mlp);
   float *scr = lds + ug_mlp_lds_floats<C, PE, BF>() + (threadIdx.x >> 6) * ug_wave_scratch_floats<C, PE, BF>();
   int victim = 0;
+  UG_PROF_INIT(prof)
   for (;;) {
     const int64_t tile = ug_next_tile(tile_counter, ws.n_tiles, blockIdx.x & 7, victim);
     if (tile < 0) break;
-    ug_shade_tile<F, C, PE, BF, PRE>(a, viewdirs, k0b, M, tile, ws.count[tile], ws.ent + tile * ws.cap,
-                                     ws.slot + tile * ws.cap, ws.feat + tile * ws.cap * UG_FEAT_STRIDE, scr,
-                                     rgb_marched);
+    ug_shade_tile<F, C, PE, BF>(a, viewdirs, k0b, M, tile, ws.count[tile], ws.ent + tile * ws.cap,
+                                ws.slot + tile * ws.cap, scr, rgb_marched, prof);
   }
+  UG_PROF_FLUSH(prof)
+}
+
+// 16-wave variant on 16x16x32 MFMA tiles (ug_shade_tile16): C = 12, PE = 4, fp16x2 arithmetic
+template <int F>
+__global__ void __launch_bounds__(1024, 1)
+k_shade_mlp16(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
+              const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
+              int32_t *__restrict__ tile_counter, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const ug_mlp16_lds M = ug_mlp16_stage(lds, mlp);
+  float *scr = lds + ug_mlp16_lds_floats() + (threadIdx.x >> 6) * UG_ACC16_SCRATCH_FLOATS;
+  int victim = 0;
+  UG_PROF_INIT(prof)
+  for (;;) {
+    const int64_t tile = ug_next_tile(tile_counter, ws.n_tiles, blockIdx.x & 7, victim);
+    if (tile < 0) break;
+    ug_shade_tile16<F>(a, viewdirs, k0b, M, tile, ws.count[tile], ws.ent + tile * ws.cap, ws.slot + tile * ws.cap, scr,
+                       rgb_marched, prof, dbg);
+  }
+  UG_PROF_FLUSH(prof)
 }
 
 // Single-launch render: every persistent wave marches a 64-ray tile and immediately shades the survivors
@@ -166,7 +215,8 @@ k_render_fused(ug_march_args am, ug_shade_args as, const float *__restrict__ ray
     // from the previous tile.  Drain the stores, then invalidate the L1 (agent-scope acquire = buffer_inv sc1).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    ug_shade_tile<F, C, PE, BF, false>(as, viewdirs, k0b, M, tile, count, ent, slot, nullptr, scr, rgb_marched);
+    ug_prof prof_unused;
+    ug_shade_tile<F, C, PE, BF>(as, viewdirs, k0b, M, tile, count, ent, slot, scr, rgb_marched, prof_unused);
     total += count;
   }
   if (ug_lane() == 0 && total) atomicAdd(survivors_total, (unsigned long long)total);
@@ -230,7 +280,7 @@ __global__ void k_ws_stats(const int32_t *__restrict__ count, int64_t n_tiles, i
 // C ABI
 // ----------------------------------------------------------------------------------------------
 extern "C" int64_t ugrid_mlp_packed_bytes(int32_t k0_channels, int32_t viewbase_pe) {
-  return (int64_t)sizeof(float) * ug_mlp_lay(k0_channels, 3 + 6 * viewbase_pe).total3;
+  return (int64_t)sizeof(float) * ug_mlp_lay(k0_channels, 3 + 6 * viewbase_pe).total4;
 }
 
 // largest power of two <= v (v > 0, finite)
@@ -247,6 +297,7 @@ extern "C" int ugrid_mlp_fp16x2_scales(const float *h_w0, const float *h_b0, con
   const double fb = k0_absmax > 0 ? (double)k0_absmax : 0.0;
   for (int n = 0; n < 128; ++n) {
     double acc = std::fabs((double)h_b0[n]);
+    m1 = acc > m1 ? acc : m1;   // the 16x16x32 image stores the layer-1 bias as one more weight column (x = 1)
     for (int k = 0; k < mlp_in; ++k) {
       const double a = std::fabs((double)h_w0[(size_t)n * mlp_in + k]);
       finite = finite && std::isfinite(a);
@@ -309,7 +360,6 @@ extern "C" int64_t ugrid_render_fused_ws_bytes(int32_t n_samples) {
   return 256 + ug_align256(slots * cap * 16) + ug_align256(slots * cap);
 }
 
-static int g_shade_split_gather = 0;  // 1: k_shade_gather + rgbnet-only kernel (measured slower: 12.8 vs 8.5 ms); 0: gather inside the rgbnet kernel
 
 template <int F, bool L2, int C, int PE, int NW, int BF>
 static int ug_fused_launch_nw(const ug_march_args &am, const ug_shade_args &as, const float *rays_o,
@@ -389,17 +439,18 @@ extern "C" int ugrid_render_fused_stats(const void *ws_mem, int64_t *d_stats, ug
 extern "C" int ugrid_tune(const char *key, int value) {
   if (!key) return (int)hipErrorInvalidValue;
   if (!strcmp(key, "march_waves")) return ug_set_march_waves(value) ? (int)hipErrorInvalidValue : 0;
-  if (!strcmp(key, "split_gather") && (value == 0 || value == 1)) { g_shade_split_gather = value; return 0; }
+  if (!strcmp(key, "shade16") && (value == 0 || value == 1)) { g_shade16 = value; return 0; }
+  if (!strcmp(key, "shade_dbg") && value >= 0 && value < 4) { g_shade_dbg = value; return 0; }
   return (int)hipErrorInvalidValue;
 }
 
-template <int F, int C, int PE, int NW, int BF, bool PRE>
+template <int F, int C, int PE, int NW, int BF>
 static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
                               ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
   const int lds_bytes = ug_shade_lds_bytes<C, PE, BF, NW>();
   static bool attr_set = false;
   if (!attr_set) {
-    UG_HIP(hipFuncSetAttribute((const void *)k_shade_mlp<F, C, PE, NW, BF, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    UG_HIP(hipFuncSetAttribute((const void *)k_shade_mlp<F, C, PE, NW, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
   UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
@@ -407,13 +458,28 @@ static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, con
   int64_t wgs = (ws.n_tiles + NW - 1) / NW;
   if (wgs > 256) wgs = 256;
   wgs = (wgs + 7) / 8 * 8;
-  if (PRE) {
-    const int64_t nblocks = (ws.n_tiles + 3) / 4;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_gather<F, C>), dim3((unsigned)(((nblocks + 7) / 8) * 8)), dim3(256), 0, st,
-                       a, k0b, ws, nblocks);
-  }
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_mlp<F, C, PE, NW, BF, PRE>), dim3((unsigned)wgs), dim3(NW * 64), lds_bytes, st, a,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_mlp<F, C, PE, NW, BF>), dim3((unsigned)wgs), dim3(NW * 64), lds_bytes, st, a,
                      viewdirs, k0b, mlp, ws, rgb, counter);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+
+template <int F>
+static int ug_shade16_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
+                             ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
+  const int lds_bytes = (int)sizeof(float) * (ug_mlp16_lds_floats() + 16 * UG_ACC16_SCRATCH_FLOATS);
+  static bool attr_set = false;
+  if (!attr_set) {
+    UG_HIP(hipFuncSetAttribute((const void *)k_shade_mlp16<F>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    attr_set = true;
+  }
+  UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
+  int64_t wgs = (ws.n_tiles + 15) / 16;
+  if (wgs > 256) wgs = 256;
+  wgs = (wgs + 7) / 8 * 8;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_mlp16<F>), dim3((unsigned)wgs), dim3(1024), lds_bytes, st, a, viewdirs, k0b,
+                     mlp, ws, rgb, counter, g_shade_dbg);
   UG_LAUNCH_CHECK();
   return 0;
 }
@@ -421,17 +487,14 @@ static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, con
 template <int F, int C, int PE>
 static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
                            ug_ws_view ws, float *rgb, int32_t *counter, int mlp_mode, hipStream_t st) {
+  if constexpr (C == 12 && PE == 4) {
+    if (mlp_mode == UGRID_MLP_FP16X2 && g_shade16) return ug_shade16_launch<F>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  }
   // every variant runs 8 waves per workgroup (2 per SIMD, <= 256 registers each).  A 12-wave bf16x3 build needed
   // spills and gained 4 %; it is not instantiated.
-  if (mlp_mode == UGRID_MLP_FP16X2) {
-    if (g_shade_split_gather) return ug_shade_launch_nw<F, C, PE, 8, 2, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-    return ug_shade_launch_nw<F, C, PE, 8, 2, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-  }
-  if (mlp_mode == UGRID_MLP_BF16X3) {
-    if (g_shade_split_gather) return ug_shade_launch_nw<F, C, PE, 8, 1, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-    return ug_shade_launch_nw<F, C, PE, 8, 1, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-  }
-  return ug_shade_launch_nw<F, C, PE, 8, 0, false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  if (mlp_mode == UGRID_MLP_FP16X2) return ug_shade_launch_nw<F, C, PE, 8, 2>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  if (mlp_mode == UGRID_MLP_BF16X3) return ug_shade_launch_nw<F, C, PE, 8, 1>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  return ug_shade_launch_nw<F, C, PE, 8, 0>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
 }
 
 extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *viewdirs, const float *k0_bricks,

@@ -26,7 +26,7 @@ _p = _lib.ptr
 
 
 def tune(key, value):
-    """Speed-only tuning knobs of the fused kernels (ugrid_tune): 'march_waves' 4..6, 'split_gather' 0|1."""
+    """Speed-only tuning knobs of the fused kernels (ugrid_tune): 'march_waves' 4..6."""
     _lib.check(_L.ugrid_tune(key.encode(), int(value)), "ugrid_tune(%s)" % key)
 
 
