@@ -4,16 +4,21 @@
 Workload (SURVEY.md section 8d "S1", BASELINE.json configs[1]): one synthetic Mip-NeRF-360-'garden'-shaped
 frame -- 1920x1080 rays x 256 samples/ray through a FourierGridModel with G=200^3 voxels, F=3 (P=7 Fourier
 levels), C=12 feature channels, rgbnet 39->128->128->3, contracted unbounded scene, stepsize 1.31,
-fast_color_thres 1e-4.  A "step" = one full frame: ray march (density query + alpha + compositing scan)
-+ shade (k0 query + rgbnet + weighted sum), inputs (rays, grids) already resident in HBM.
+fast_color_thres 1e-4.  A "step" = one full frame: ray generation + ray march (density query + alpha + compositing
+scan) + shade (k0 query + rgbnet + weighted sum); grids and camera are resident in HBM.
 
   python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
 
-Prints ONE JSON line on rank 0.  value = Msamples/s = N * R * S / t_step (all generated samples, before
-thresholding); scaling is weak: every rank renders its own frame (own camera) and the rendered tiles
-[R,5] are exchanged with one RCCL all-gather inside the timed step.
+Prints ONE JSON line on rank 0.  value = Msamples/s = R * S / t_step (all generated samples, before thresholding).
+Multi-GPU is STRONG-scaled: the N ranks render ONE frame -- rank r takes the 64-ray tiles r, r+N, ... (or a contiguous
+band with --contiguous) and the rendered tiles [R/N,5] are exchanged with one RCCL all-gather inside the timed step
+(issued asynchronously: frame k's exchange overlaps frame k+1's render; the last one is waited for before the closing
+barrier).  A short weak-scaled loop (every rank its own full frame) is reported beside it as `weak_scaling`.
+A second scene (`secondary`, S1b: smooth density with surfaces, ~half of the rays terminate early) shows what wave-level
+early termination buys and carries its own parity numbers.
 """
 import argparse
+import hashlib
 import json
 import math
 import os
@@ -26,10 +31,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md (6.3 TB/s achievable)
+# peaks used by the roofline block (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0               # HBM3E spec peak (~6.3 TB/s achievable)
+N_CU, N_SIMD, CLK_HZ = 256, 1024, 2.4e9
+L1_PEAK_GBS = N_CU * 64 * CLK_HZ / 1e9          # vector L1 / texture path: 64 B per clock per CU = 39.3 TB/s
+MFMA_F16_PEAK_TFLOPS = 2500.0       # dense f16/bf16 MFMA peak
+VALU_PEAK_GINST = N_SIMD * CLK_HZ / 2 / 1e9     # one wave64 VALU instruction per 2 cycles per SIMD
 
 # S1 scene statistics (white-noise grids; calibrated with the CPU oracle so that ~5% of samples survive both
-# thresholds, see DESIGN.md "synthetic scene")
+# thresholds, tools/calibrate_s1.py)
 DENS_MEAN, DENS_STD = -8.5, 24.0
 
 
@@ -41,7 +51,10 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--grid", type=int, default=200)
+    ap.add_argument("--scene", default="s1", choices=["s1", "s1b"], help="headline scene (s1b is also run as `secondary`)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the S1b secondary scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--contiguous", action="store_true", help="N>1: contiguous ray bands instead of interleaved 64-ray tiles")
     ap.add_argument("--single-launch", action="store_true", help="single persistent launch instead of march + shade")
     ap.add_argument("--mlp-mode", type=int, default=None, help="rgbnet arithmetic: 0 fp32 MFMA, 1 bf16x3, 2 fp16x2 (default: what ugrid_pack_mlp reports usable)")
     ap.add_argument("--pipeline", type=int, default=0, help="ray chunks software-pipelined over two streams (0 = off)")
@@ -50,15 +63,7 @@ def parse():
     return ap.parse_args()
 
 
-def make_state(G, device, seed):
-    """Synthetic FourierGridModel parameters generated ON the device (no dataset / checkpoint in the image):
-    density.grid ~ N(mu, sigma^2), k0.grid ~ N(0,1), rgbnet with nn.Linear's default init."""
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    F, C, pe = 3, 12, 4
-    P = 1 + 2 * F
-    dens = torch.empty(P, 1, G, G, G, device=device).normal_(DENS_MEAN, DENS_STD, generator=g)
-    k0 = torch.empty(P, C, G, G, G, device=device).normal_(0.0, 1.0, generator=g)
+def _rgbnet(g, device, C, pe):
     dims = [C + 3 + 6 * pe, 128, 128, 3]
     ws, bs = [], []
     for i in range(3):
@@ -66,6 +71,10 @@ def make_state(G, device, seed):
         ws.append(torch.empty(dims[i + 1], dims[i], device=device).uniform_(-b, b, generator=g))
         bs.append(torch.empty(dims[i + 1], device=device).uniform_(-b, b, generator=g))
     bs[2].zero_()  # nn.init.constant_(rgbnet[-1].bias, 0)  (FourierGrid_model.py:241)
+    return ws, bs
+
+
+def _state(dens, k0, ws, bs, G, F, pe):
     return {
         "density_grid": dens, "k0_grid": k0, "rgbnet_weights": ws, "rgbnet_biases": bs,
         "scene_center": torch.zeros(3), "scene_radius": torch.ones(3),
@@ -76,8 +85,68 @@ def make_state(G, device, seed):
     }
 
 
+def make_state(G, device, seed):
+    """S1: synthetic FourierGridModel parameters generated ON the device (no dataset / checkpoint in the image):
+    density.grid ~ N(mu, sigma^2), k0.grid ~ N(0,1), rgbnet with nn.Linear's default init."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    F, C, pe = 3, 12, 4
+    P = 1 + 2 * F
+    dens = torch.empty(P, 1, G, G, G, device=device).normal_(DENS_MEAN, DENS_STD, generator=g)
+    k0 = torch.empty(P, C, G, G, G, device=device).normal_(0.0, 1.0, generator=g)
+    ws, bs = _rgbnet(g, device, C, pe)
+    return _state(dens, k0, ws, bs, G, F, pe)
+
+
+def make_state_surfaces(G, device, seed):
+    """S1b: the same model shape with TRAINED-LIKE statistics -- smooth fields, opaque surfaces, empty space below the
+    alpha threshold.  Level 0 of the density grid carries 7x a smooth occupancy field (soft spheres, a ground slab and
+    the lower half of the contracted far shell; 1.5-voxel transitions between raw density -6 and +16, so empty space
+    has alpha ~3e-7 < thres and solids saturate in 1-2 samples); the six sin/cos levels and all k0 levels are low-pass
+    noise.  Rays that look down end on a surface (T < 1e-3), rays that look up leave through empty sky."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed + 1000)
+    F, C, pe = 3, 12, 4
+    P = 1 + 2 * F
+    lin = torch.linspace(-1.2, 1.2, G, device=device)
+    X, Y, Z = torch.meshgrid(lin, lin, lin, indexing="ij")
+    w = 1.5 * 2.4 / (G - 1)                                     # transition half-width: 1.5 voxels
+    occ = torch.sigmoid((-0.45 - Z) / w)                        # ground slab z < -0.45
+    cheb = torch.maximum(torch.maximum(X.abs(), Y.abs()), Z.abs())
+    occ = torch.maximum(occ, torch.sigmoid((cheb - 1.12) / w) * (Z < 0.1).float())    # lower far shell
+    cg = torch.Generator()
+    cg.manual_seed(seed + 7)
+    eye = camera(0, "cpu")[:, 3]
+    placed = 0
+    while placed < 14:                                          # soft spheres around the scene centre, clear of the camera
+        ct = torch.rand(3, generator=cg) * 1.4 - 0.7
+        r = float(torch.rand(1, generator=cg) * 0.2 + 0.08)
+        if float((ct - eye).norm()) < r + 0.12:
+            continue
+        placed += 1
+        c = ct.tolist()
+        dist_c = ((X - c[0]) ** 2 + (Y - c[1]) ** 2 + (Z - c[2]) ** 2).sqrt()
+        occ = torch.maximum(occ, torch.sigmoid((r - dist_c) / w))
+    del X, Y, Z, cheb
+    target = -6.0 + 22.0 * occ                                  # raw density the mean over levels should produce
+
+    def smooth_noise(n_ch, amp):
+        x = torch.empty(n_ch, 1, G, G, G, device=device).normal_(0.0, 1.0, generator=g)
+        for _ in range(2):                                      # two 5^3 box filters ~ a smooth field
+            x = torch.nn.functional.avg_pool3d(x, 5, stride=1, padding=2, count_include_pad=False)
+        return x / x.std() * amp
+
+    dens = smooth_noise(P, 2.0).reshape(P, 1, G, G, G)
+    dens[0, 0] = P * target                                     # the mean over the 7 levels restores `target` (+- noise)
+    k0 = torch.empty(P, C, G, G, G, device=device)
+    for l in range(P):
+        k0[l] = smooth_noise(C, 1.0)[:, 0]
+    ws, bs = _rgbnet(g, device, C, pe)
+    return _state(dens.contiguous(), k0, ws, bs, G, F, pe)
+
+
 def camera(rank, device):
-    """Look-at-origin pinhole camera; each rank gets its own azimuth so weak-scaled frames differ."""
+    """Look-at-origin pinhole camera; `rank` picks an azimuth (weak-scaled frames differ per rank)."""
     ang = 0.35 * rank
     eye = torch.tensor([0.3 * math.cos(ang) - 0.2 * math.sin(ang), 0.3 * math.sin(ang) + 0.2 * math.cos(ang), 0.4])
     fwd = -eye / eye.norm()
@@ -87,6 +156,187 @@ def camera(rank, device):
     up2 = torch.linalg.cross(right, fwd)
     c2w = torch.stack([right, up2, -fwd, eye], dim=1)  # OpenGL-style: camera looks along -z
     return c2w.to(device)
+
+
+def lib_sha16():
+    from unboundednerfpytorch_amd import _lib
+    return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
+
+
+class FrameBench:
+    """One scene on this rank: renderer + camera + the timed step (ray generation, shard, render, tile exchange)."""
+
+    def __init__(self, args, state, device, world, rank, dist):
+        from unboundednerfpytorch_amd.dist import shard_bounds, tile_assignment
+        from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer, get_rays_of_a_view
+        self.get_rays = get_rays_of_a_view
+        self.args, self.device, self.world, self.rank, self.dist = args, device, world, rank, dist
+        H, W, G = args.height, args.width, args.grid
+        self.H, self.W = H, W
+        self.stepsize = 1.31 * G / 200.0 if G != 200 else 1.31
+        self.rend = FourierGridRenderer(state, device, fused=args.single_launch, pipeline=args.pipeline, mlp_mode=args.mlp_mode)
+        self.K = [[1600.0 * W / 1920.0, 0, W / 2.0], [0, 1600.0 * W / 1920.0, H / 2.0], [0, 0, 1]]
+        self.R = H * W
+        self.S = self.rend.tables(self.stepsize)[2]
+        self.c2w = camera(0, device)
+        self.use_dist = dist is not None
+        if world > 1 and not args.contiguous:
+            self.idx = tile_assignment(self.R, world, rank).to(device)
+            self.per = tile_assignment(self.R, world, 0).numel()
+            self.bounds = None
+        else:
+            self.idx = None
+            self.bounds = shard_bounds(self.R, world, rank)
+            self.per = shard_bounds(self.R, world, 0)[1]
+        self.gathered = [torch.empty(world * self.per, 5, device=device) for _ in range(2)] if self.use_dist else None
+        self.inflight = {"work": None, "n": 0, "tile": None}
+        self.last_out = None
+
+    def rays(self, c2w=None):
+        ro, rd, vd = self.get_rays(self.H, self.W, self.K, self.c2w if c2w is None else c2w)
+        return ro.reshape(-1, 3), rd.reshape(-1, 3), vd.reshape(-1, 3)
+
+    def my_shard(self, ro, rd, vd):
+        if self.idx is not None:
+            return ro[self.idx].contiguous(), rd[self.idx].contiguous(), vd[self.idx].contiguous()
+        b, e = self.bounds
+        return ro[b:e].contiguous(), rd[b:e].contiguous(), vd[b:e].contiguous()
+
+    def step(self, timing=None, weak=False):
+        """strong (default): this rank's shard of THE frame; weak: a whole frame of its own camera."""
+        ro, rd, vd = self.rays(camera(self.rank, self.device) if weak else None)      # ray generation is inside the step
+        if not weak and self.world > 1:
+            ro, rd, vd = self.my_shard(ro, rd, vd)
+        else:
+            ro, rd, vd = ro.contiguous(), rd.contiguous(), vd.contiguous()
+        out = self.rend(ro, rd, vd, stepsize=self.stepsize, render_depth=True, timing=timing)
+        self.last_out = out
+        if self.use_dist and not weak:
+            # the one exchange step of the path: rendered tiles [R/N,5] = rgb(3), depth, alphainv_last -> every rank
+            n = out["depth"].shape[0]
+            tile = torch.zeros(self.per, 5, device=self.device) if n < self.per else torch.empty(self.per, 5, device=self.device)
+            tile[:n, 0:3] = out["rgb_marched"]
+            tile[:n, 3] = out["depth"]
+            tile[:n, 4] = out["alphainv_last"]
+            fl = self.inflight
+            if fl["work"] is not None:
+                fl["work"].wait()                # stream-level wait for the previous frame's exchange
+            fl["work"] = self.dist.all_gather_into_tensor(self.gathered[fl["n"] & 1], tile, async_op=True)
+            fl["tile"] = tile                    # keep the send buffer alive until the collective has run
+            fl["n"] += 1
+        return out
+
+    def barrier(self):
+        if self.use_dist:
+            if self.inflight["work"] is not None:
+                self.inflight["work"].wait()     # the last exchange is inside the timed region
+                self.inflight["work"] = None
+            self.dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, weak=False):
+        for _ in range(warmup):
+            self.step(weak=weak)
+        self.barrier()
+        timing = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(timing, weak=weak)
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.use_dist:
+            t = torch.tensor([dt], device=self.device, dtype=torch.float64)
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, timing
+
+    def check_exchange(self):
+        """this rank's tile must sit at its slot of the gathered frame"""
+        if not self.use_dist:
+            return
+        out = self.last_out
+        n = out["depth"].shape[0]
+        mine = self.gathered[(self.inflight["n"] - 1) & 1][self.rank * self.per: self.rank * self.per + n]
+        assert torch.equal(mine[:, 0:3], out["rgb_marched"]) and torch.equal(mine[:, 4], out["alphainv_last"])
+
+    def full_frame(self):
+        """The whole frame rendered on this rank (for survivor statistics and parity): untimed."""
+        ro, rd, vd = [x.contiguous() for x in self.rays()]
+        self.rend.pipeline = 0
+        M = 0
+        outs = []
+        chunk = self.rend.rays_per_chunk(self.S)
+        for b in range(0, self.R, chunk):
+            e = min(self.R, b + chunk)
+            outs.append(self.rend(ro[b:e], rd[b:e], vd[b:e], stepsize=self.stepsize, render_depth=True))
+            M += self.rend.survivors_of_last_chunk()
+        out = {k: torch.cat([o[k] for o in outs]) for k in ("rgb_marched", "depth", "alphainv_last")}
+        return (ro, rd, vd), out, M
+
+
+def kernel_ms(timing, steps, single_launch):
+    if single_launch:
+        return {"render_fused": sum(ev[0].elapsed_time(ev[1]) for ev, _ in timing) / steps}
+    # (pipelined frames carry 4 events per chunk; the kernels of neighbouring chunks overlap then)
+    return {"render_march": sum(ev[0].elapsed_time(ev[1]) for ev, _ in timing) / steps,
+            "render_shade": sum(ev[-2].elapsed_time(ev[-1]) for ev, _ in timing) / steps}
+
+
+def roofline_block(kern, M, R, S, shade_passes):
+    """Per-kernel utilisation of the four candidate limits -- no single 'HBM fraction' describes these kernels: the
+    algorithmic gather bytes of SURVEY 8d are served by L1/L2 (fraction of HBM peak > 1), so they are priced against the
+    vector-L1 path they actually go through, HBM against the PMC-measured traffic, VALU against instruction counts, the
+    matrix pipe against executed MFMA flops.  Static per-launch counters come from profiles/r02/pmc_summary.json (same
+    scene, same binary: `lib_sha16`); times are live HIP events."""
+    pmc = {}
+    ppath = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
+    if os.path.exists(ppath):
+        try:
+            pmc = json.load(open(ppath))
+        except Exception:
+            pmc = {}
+    alg = {"render_march": R * S * 224 + R * 32,     # 8 coefficients x 7 levels x 4 B per sample + rays in / (depth, alphainv) out
+           "render_shade": M * 2688 + R * 24}        # x 12 channels per survivor + viewdirs in / rgb out
+    # executed f16 MFMA flops of the fp16x2 rgbnet: 132 MFMAs (32x32x16) per 32-survivor pass
+    mfma_flops = {"render_march": 0.0, "render_shade": shade_passes * 132 * 32 * 32 * 16 * 2.0}
+    per = {}
+    for name, ms in kern.items():
+        if name not in alg:
+            continue
+        t = ms * 1e-3
+        c = pmc.get(name, {})
+        e = {"ms": ms, "algorithmic_bytes": alg[name], "algorithmic_GBps": alg[name] / t / 1e9,
+             "l1_frac": alg[name] / t / 1e9 / L1_PEAK_GBS,
+             "mfma_TFLOPs": mfma_flops[name] / t / 1e12, "mfma_frac": mfma_flops[name] / t / 1e12 / MFMA_F16_PEAK_TFLOPS}
+        if "hbm_bytes" in c:
+            e["hbm_bytes_pmc"] = c["hbm_bytes"]
+            e["hbm_GBps"] = c["hbm_bytes"] / t / 1e9
+            e["hbm_frac"] = e["hbm_GBps"] / HBM_PEAK_GBS
+        if "valu_insts" in c:
+            e["valu_Ginst_per_s"] = c["valu_insts"] / t / 1e9
+            e["valu_frac"] = e["valu_Ginst_per_s"] / VALU_PEAK_GINST
+        fr = {k[:-5]: v for k, v in e.items() if k.endswith("_frac")}
+        e["bound"] = max(fr, key=fr.get)
+        per[name] = e
+    if not per:
+        return None
+    dom = max(per, key=lambda k: per[k]["ms"])
+    d = per[dom]
+    units = {"hbm": ("GB/s", d.get("hbm_GBps"), HBM_PEAK_GBS), "l1": ("GB/s", d["algorithmic_GBps"], L1_PEAK_GBS),
+             "mfma": ("TFLOP/s", d["mfma_TFLOPs"], MFMA_F16_PEAK_TFLOPS),
+             "valu": ("Ginst/s", d.get("valu_Ginst_per_s"), VALU_PEAK_GINST)}
+    unit, ach, peak = units[d["bound"]]
+    frame_hbm = sum(p.get("hbm_bytes_pmc", 0) for p in per.values())
+    frame_ms = sum(p["ms"] for p in per.values())
+    return {"kernel": dom, "bound": d["bound"], "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
+            "traffic": d.get("hbm_bytes_pmc"),
+            "peaks": {"hbm_GBps": HBM_PEAK_GBS, "l1_GBps": L1_PEAK_GBS, "mfma_f16_TFLOPs": MFMA_F16_PEAK_TFLOPS,
+                      "valu_Ginst_per_s": VALU_PEAK_GINST, "clock_GHz_assumed": CLK_HZ / 1e9},
+            "frame": {"algorithmic_bytes_formula": "R*S*224 + M*2688 + R*56 = %d" % (sum(alg.values())),
+                      "hbm_bytes_pmc": frame_hbm or None,
+                      "hbm_frac": (frame_hbm / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if frame_hbm else None},
+            "pmc_source": "profiles/r02/pmc_summary.json" if pmc else None, "pmc_lib_sha16": pmc.get("lib_sha16"),
+            "per_kernel": per}
 
 
 def main():
@@ -110,149 +360,132 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
-    from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer, get_rays_of_a_view, tune
+    from unboundednerfpytorch_amd.fourier_render import tune
     for kv in args.tune:
         k, v = kv.split("=")
         tune(k, int(v))
 
-    H, W, G = args.height, args.width, args.grid
-    stepsize = 1.31 * G / 200.0 if G != 200 else 1.31
-    state = make_state(G, device, seed=0)  # same model on every rank (replicated read-only grids)
-    rend = FourierGridRenderer(state, device, fused=args.single_launch, pipeline=args.pipeline, mlp_mode=args.mlp_mode)
+    make = {"s1": make_state, "s1b": make_state_surfaces}
+    scene_desc = {"s1": "white-noise grids N(%g,%g^2)" % (DENS_MEAN, DENS_STD),
+                  "s1b": "smooth fields with opaque surfaces (make_state_surfaces)"}
+    G = args.grid
+    state = make[args.scene](G, device, seed=0)  # same model on every rank (replicated read-only grids)
+    fb = FrameBench(args, state, device, world, rank, dist)
+    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
     cpu_state = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if want_cpu:
         cpu_state = {k: ([x.cpu() for x in v] if isinstance(v, list) else (v.cpu() if torch.is_tensor(v) else v))
                      for k, v in state.items()}
     del state
     torch.cuda.empty_cache()
 
-    K = [[1600.0 * W / 1920.0, 0, W / 2.0], [0, 1600.0 * W / 1920.0, H / 2.0], [0, 0, 1]]
-    ro, rd, vd = get_rays_of_a_view(H, W, K, camera(rank, device))
-    ro, rd, vd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous(), vd.reshape(-1, 3).contiguous()
-    R = ro.shape[0]
-    S = rend.tables(stepsize)[2]
-    # two frame-set buffers: the all-gather of frame k runs on RCCL's stream while frame k+1 renders
-    gathered = [torch.empty(world * R, 5, device=device) for _ in range(2)] if use_dist else None
-    inflight = {"work": None, "n": 0, "tile": None}
-
-    def step(timing=None):
-        out = rend(ro, rd, vd, stepsize=stepsize, render_depth=True, timing=timing)
-        if use_dist:
-            # the one exchange step of the path: rendered tiles [R,5] = rgb(3), depth, alphainv_last -> every rank
-            tile = torch.cat([out["rgb_marched"], out["depth"][:, None], out["alphainv_last"][:, None]], dim=1)
-            if inflight["work"] is not None:
-                inflight["work"].wait()          # stream-level wait for the previous frame's exchange
-            inflight["work"] = dist.all_gather_into_tensor(gathered[inflight["n"] & 1], tile, async_op=True)
-            inflight["tile"] = tile              # keep the send buffer alive until the collective has run
-            inflight["n"] += 1
-        return out
-
-    def barrier():
-        if use_dist:
-            if inflight["work"] is not None:
-                inflight["work"].wait()          # the last exchange is inside the timed region
-                inflight["work"] = None
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    timing = []
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step(timing)
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-        # sanity of the exchange: this rank's tile must sit at its slot of the gathered frame set
-        mine = gathered[(inflight["n"] - 1) & 1][rank * R:(rank + 1) * R]
-        assert torch.equal(mine[:, 0:3], out["rgb_marched"]) and torch.equal(mine[:, 4], out["alphainv_last"])
-
-    # per-kernel durations from HIP events recorded on the launch stream inside the timed region
+    dt, timing = fb.timed(args.steps, args.warmup)
+    fb.check_exchange()
+    kern = kernel_ms(timing, args.steps, args.single_launch)
     n_chunks = len(timing) // max(1, args.steps)
-    if not args.single_launch:
-        # (pipelined frames carry 4 events per chunk: march start/end on the march stream, shade start/end on the
-        # shade stream; the kernels of neighbouring chunks overlap, so the per-kernel sums exceed the frame time)
-        march_ms = sum(ev[0].elapsed_time(ev[1]) for ev, _ in timing) / args.steps
-        shade_ms = sum(ev[-2].elapsed_time(ev[-1]) for ev, _ in timing) / args.steps
-    else:
-        fused_ms = sum(ev[0].elapsed_time(ev[1]) for ev, _ in timing) / args.steps
-    # survivors of the frame (one extra, untimed frame)
-    if not args.single_launch:
-        M = 0
-        rend.pipeline = 0
-        chunk = rend.rays_per_chunk(S)
-        for b in range(0, R, chunk):
-            e = min(R, b + chunk)
-            rend(ro[b:e], rd[b:e], vd[b:e], stepsize=stepsize)
-            M += rend.survivors_of_last_chunk()
-    else:
-        M = rend.survivors_of_last_chunk()
-    term_frac = float((out["alphainv_last"] < 1e-3).float().mean())
+    rays_this_rank = sum(n for _, n in timing) // max(1, args.steps)
+    # per-rank kernel times (load imbalance of the strong-scaled frame)
+    per_rank = None
+    if use_dist:
+        mine = torch.tensor([kern.get("render_march", kern.get("render_fused", 0.0)), kern.get("render_shade", 0.0),
+                             float(rays_this_rank)], device=device, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": i, "march_ms": float(a[0]), "shade_ms": float(a[1]), "rays": int(a[2])} for i, a in enumerate(allr)]
+    weak = None
+    if use_dist and world > 1:
+        wdt, _ = fb.timed(max(3, args.steps // 2), 1, weak=True)
+        wsteps = max(3, args.steps // 2)
+        weak = {"value": world * fb.R * fb.S / (wdt / wsteps) / 1e6, "unit": "Msamples/s", "ms_per_step": wdt / wsteps * 1e3,
+                "note": "every rank renders its own full frame (own camera); no exchange"}
+    # survivor statistics + parity inputs from one extra, untimed full frame on this rank
+    rays_full, out_full, M = fb.full_frame()
+    R, S = fb.R, fb.S
+    term_frac = float((out_full["alphainv_last"] < 1e-3).float().mean())
+    shade_passes = (M + 31) // 32 + R // 64 // 2      # ~ sum over tiles of ceil(count / 32)
 
+    res = None
     if rank == 0:
         ms_step = dt / args.steps * 1e3
-        samples = world * R * S
-        bytes_march = R * S * 224 + R * 32          # 8 corners x 7 levels x 4 B per sample + rays in / (depth, alphainv) out
-        bytes_shade = M * 2688 + R * 24             # x 12 channels per survivor + viewdirs in / rgb out
-        if not args.single_launch:
-            kern = {"render_march": {"ms": march_ms, "algorithmic_bytes": bytes_march},
-                    "render_shade": {"ms": shade_ms, "algorithmic_bytes": bytes_shade}}
-            dom = "render_march" if march_ms >= shade_ms else "render_shade"
-        else:
-            kern = {"render_fused": {"ms": fused_ms, "algorithmic_bytes": bytes_march + bytes_shade}}
-            dom = "render_fused"
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dom)
-            except Exception:
-                traffic = None
-        achieved = kern[dom]["algorithmic_bytes"] / (kern[dom]["ms"] * 1e-3) / 1e9
+        samples = R * S
         res = {
             "metric": "Msamples/sec (Mip-360 garden-shaped 1920x1080x256 frame, FourierGrid render)",
             "value": samples / (dt / args.steps) / 1e6, "unit": "Msamples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "rays_per_sec": world * R / (dt / args.steps),
-            "config": {"workload": "S1: FourierGridModel render, R=%dx%d rays x S=%d samples, G=%d^3, F=3 (P=7), C=12, "
-                                   "rgbnet 39-128-128-3, stepsize %.3g, thres 1e-4, white-noise grids N(%g,%g^2)"
-                                   % (W, H, S, G, stepsize, DENS_MEAN, DENS_STD),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "rays_per_sec": R / (dt / args.steps),
+            "config": {"workload": "%s: FourierGridModel render, R=%dx%d rays x S=%d samples, G=%d^3, F=3 (P=7), C=12, "
+                                   "rgbnet 39-128-128-3, stepsize %.3g, thres 1e-4, %s"
+                                   % (args.scene.upper(), fb.W, fb.H, S, G, fb.stepsize, scene_desc[args.scene]),
                        "rays": R, "samples_per_ray": S, "survivors_M": M, "survivor_frac": M / float(R * S),
                        "terminated_ray_frac": term_frac, "chunks_per_frame": n_chunks,
-                       "parallelism": "ray-sharded replicas x%d, 1 all-gather of [R,5] tiles per frame (overlapped with the next frame)" % world},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "frame_bytes_formula": "R*S*224 + M*2688 + R*56 = %d" % (bytes_march + bytes_shade),
-                         "frame_frac": (bytes_march + bytes_shade) / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS},
-            "kernels": kern,
+                       "step": "ray generation + march + shade%s" % (" + all-gather of the tiles" if use_dist else ""),
+                       "parallelism": ("one frame over %d ranks, %s, 1 all-gather of [R/N,5] tiles per frame (async, overlaps "
+                                       "the next frame)" % (world, "contiguous 64-aligned ray bands" if args.contiguous
+                                                            else "64-ray tiles dealt round-robin")) if world > 1 else "1 GPU"},
+            "lib_sha16": lib_sha16(),
+            "kernels": {k: {"ms": v} for k, v in kern.items()},
         }
+        if not args.single_launch and world == 1:
+            res["roofline"] = roofline_block(kern, M, R, S, shade_passes)
+        else:
+            res["roofline"] = None
+        if per_rank is not None:
+            res["per_rank"] = per_rank
+        if weak is not None:
+            res["weak_scaling"] = weak
         if cpu_state is not None:
-            res["cpu_baseline"] = cpu_baseline(cpu_state, ro, rd, vd, out, stepsize, S, args.cpu_chunks)
+            res["cpu_baseline"] = cpu_baseline(cpu_state, rays_full, out_full, fb.stepsize, S, args.cpu_chunks)
+    # secondary scene (single GPU only: it re-packs 23 GB of bricks)
+    if world == 1 and not args.no_secondary and args.scene == "s1":
+        del fb, out_full, rays_full
+        cpu_state = None
+        torch.cuda.empty_cache()
+        sec_args = argparse.Namespace(**vars(args))
+        state = make_state_surfaces(G, device, seed=0)
+        fb2 = FrameBench(sec_args, state, device, 1, 0, None)
+        cpu2 = None
+        if want_cpu:
+            cpu2 = {k: ([x.cpu() for x in v] if isinstance(v, list) else (v.cpu() if torch.is_tensor(v) else v))
+                    for k, v in state.items()}
+        del state
+        torch.cuda.empty_cache()
+        steps2 = max(3, args.steps // 2)
+        dt2, timing2 = fb2.timed(steps2, 1)
+        kern2 = kernel_ms(timing2, steps2, args.single_launch)
+        rays2, out2, M2 = fb2.full_frame()
+        sec = {"workload": "S1b: same model shape, smooth fields with opaque surfaces (make_state_surfaces)",
+               "value": fb2.R * fb2.S / (dt2 / steps2) / 1e6, "unit": "Msamples/s", "ms_per_step": dt2 / steps2 * 1e3, "steps": steps2,
+               "survivor_frac": M2 / float(fb2.R * fb2.S), "terminated_ray_frac": float((out2["alphainv_last"] < 1e-3).float().mean()),
+               "kernels": {k: {"ms": v} for k, v in kern2.items()}}
+        if cpu2 is not None:
+            cb = cpu_baseline(cpu2, rays2, out2, fb2.stepsize, fb2.S, max(4, args.cpu_chunks // 2))
+            sec["cpu_baseline_Msamples"] = cb["value"]
+            sec["gpu_vs_oracle"] = cb["gpu_vs_oracle"]
+        res["secondary"] = sec
+    if rank == 0:
         print(json.dumps(res))
     if use_dist:
         dist.destroy_process_group()
 
 
-def cpu_baseline(cpu_state, ro, rd, vd, gpu_out, stepsize, S, n_chunks):
+def cpu_baseline(cpu_state, rays, gpu_out, stepsize, S, n_chunks):
     """The oracle (CPU restatement of the reference's pure-PyTorch F.grid_sample forward, kind='port') timed on
-    this box's host cores on a bounded sample of the same frame: n_chunks x 8192 rays spread over the image."""
+    this box's host cores on a bounded sample of the same frame: n_chunks x 8192 rays spread over the image.
+    (BASELINE.md section 3 asks for the reference's own Python over stub modules; /root/reference does not exist on the
+    GPU box, so the restatement -- pinned bit for bit on that Python in the build container -- is what runs here.)"""
     from oracle import model_oracle
     # torch's intra-op threading stops scaling early on this op mix: on the 256-core GPU-box host 8 threads
     # gave 8.6 Msamples/s, 64 -> 5.4, 256 -> 0.13 (tools/cpu_threads_sweep.py); use the fastest setting.
     cores = min(8, os.cpu_count() or 1)
     torch.set_num_threads(cores)
+    ro, rd, vd = rays
     R = ro.shape[0]
     chunk = 8192
     starts = [int(i * (R - chunk) / max(1, n_chunks - 1)) // 64 * 64 for i in range(n_chunks)] if n_chunks > 1 else [0]
-    worst = 0.0
     t_total, n_samples = 0.0, 0
-    errs, margins, sq = [], [], 0.0
+    errs = {k: [] for k in ("rgb_marched", "depth", "alphainv_last")}
+    margins, sq = [], 0.0
     for i, b in enumerate([starts[0]] + starts):  # first pass = warm-up, not timed
         o, d, v = ro[b:b + chunk].cpu(), rd[b:b + chunk].cpu(), vd[b:b + chunk].cpu()
         t0 = time.perf_counter()
@@ -262,41 +495,47 @@ def cpu_baseline(cpu_state, ro, rd, vd, gpu_out, stepsize, S, n_chunks):
             continue
         t_total += t1 - t0
         n_samples += chunk * S
-        safe = ref["margin"] > 1e-4
-        per_ray = torch.zeros(chunk)
-        for k in ("rgb_marched", "depth", "alphainv_last"):
+        for k in errs:
             err = (gpu_out[k][b:b + chunk].cpu() - ref[k]).abs()
-            err = err.amax(dim=1) if err.dim() == 2 else err
-            worst = max(worst, float(err[safe].max()))
-            per_ray = torch.maximum(per_ray, err)
-        errs.append(per_ray)
+            errs[k].append(err.amax(dim=1) if err.dim() == 2 else err)
         margins.append(ref["margin"])
         sq += float(((gpu_out["rgb_marched"][b:b + chunk].cpu() - ref["rgb_marched"]).double() ** 2).sum())
-    return {"value": n_samples / t_total / 1e6, "unit": "Msamples/s", "cores": cores, "kind": "port",
+    errs = {k: torch.cat(v) for k, v in errs.items()}
+    stats = parity_stats(errs, torch.cat(margins), sq)
+    return {"value": n_samples / t_total / 1e6, "unit": "Msamples/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
             "sample": "%d chunks x 8192 rays x %d samples of the same frame (oracle/model_oracle.py, torch CPU "
-                      "grid_sample path), 1 warm-up chunk" % (n_chunks, S),
-            "rays_per_sec": n_chunks * chunk / t_total, "gpu_vs_oracle_linf_on_sample": worst,
-            "gpu_vs_oracle": parity_stats(torch.cat(errs), torch.cat(margins), sq)}
+                      "grid_sample path, %d threads: the fastest setting on this host), 1 warm-up chunk" % (n_chunks, S, cores),
+            "rays_per_sec": n_chunks * chunk / t_total,
+            "gpu_vs_oracle_linf_rgb": stats["rgb_marched"]["linf_all"], "gpu_vs_oracle_linf_depth": stats["depth"]["linf_all"],
+            "gpu_vs_oracle_linf_alphainv_last": stats["alphainv_last"]["linf_all"],
+            "gpu_vs_oracle": stats}
 
 
-def parity_stats(err, margin, sq_rgb):
-    """Per-ray L-inf error of (rgb, depth, alphainv_last) against the oracle on the sampled rays, split by the
-    ray's threshold margin (smallest relative distance of any of its samples to one of the three hard thresholds
-    alpha > thres, weight > thres, T < 1e-3).  A sample that sits on a threshold flips with ANY change of rounding
-    and moves the ray by up to its weight (~thres = 1e-4), so rays with tiny margins measure the thresholds, not the
-    arithmetic; PSNR is over all sampled rays, flips included."""
-    import math
-    n = err.numel()
-    out = {"note": "tail rays are fp32 conditioning of the reference formula on this white-noise scene: an fp64 "
-                   "re-evaluation puts the GPU closer to exact than the fp32 oracle (DESIGN.md 2.1, "
-                   "profiles/r01/parity_scan_s1.txt)",
-           "rays": n, "linf_all": float(err.max()), "mean_abs": float(err.mean()),
-           "frac_rays_above_1e-5": float((err > 1e-5).float().mean()),
-           "psnr_rgb_db": 10.0 * math.log10(1.0 / max(sq_rgb / (3 * n), 1e-30))}
-    for m in (1e-4, 1e-3, 1e-2):
-        sel = margin > m
-        out["linf_margin_gt_%g" % m] = float(err[sel].max()) if bool(sel.any()) else None
-        out["frac_rays_margin_gt_%g" % m] = float(sel.float().mean())
+def parity_stats(errs, margin, sq_rgb):
+    """Per-output L-inf error against the oracle on the sampled rays: over ALL rays, and over the rays whose threshold
+    margin exceeds m (smallest relative distance of any of the ray's samples to one of the three hard thresholds
+    alpha > thres, weight > thres, T < 1e-3: a sample that sits on a threshold flips with ANY change of rounding and
+    moves the ray by up to its weight).  `errs`: dict output -> per-ray error (a single tensor = already the max over
+    the outputs, kept for old callers).  PSNR is over all sampled rays, flips included."""
+    if torch.is_tensor(errs):
+        errs = {"all_outputs": errs}
+    n = margin.numel()
+    out = {"rays": n, "psnr_rgb_db": 10.0 * math.log10(1.0 / max(sq_rgb / (3 * n), 1e-30)),
+           "frac_rays_margin_gt_0.0001": float((margin > 1e-4).float().mean())}
+    for k, err in errs.items():
+        e = {"linf_all": float(err.max()), "mean_abs": float(err.mean()), "rays_above_1e-4": int((err > 1e-4).sum()),
+             "frac_rays_above_1e-5": float((err > 1e-5).float().mean())}
+        for m in (1e-4, 1e-3, 1e-2):
+            sel = margin > m
+            e["linf_margin_gt_%g" % m] = float(err[sel].max()) if bool(sel.any()) else None
+        out[k] = e
+    if "all_outputs" in out:         # flat layout of round 1 (tests/test_host_logic.py)
+        flat = out.pop("all_outputs")
+        out.update({"linf_all": flat["linf_all"], "mean_abs": flat["mean_abs"], "frac_rays_above_1e-5": flat["frac_rays_above_1e-5"]})
+        for m in (1e-4, 1e-3, 1e-2):
+            out["linf_margin_gt_%g" % m] = flat["linf_margin_gt_%g" % m]
+            out["frac_rays_margin_gt_%g" % m] = float((margin > m).float().mean())
+        out["note"] = "per-ray max over rgb, depth, alphainv_last"
     return out
 
 

@@ -25,14 +25,27 @@ import torch.nn.functional as F
 from oracle import ref_ops
 
 
+# How sin / cos of the Fourier levels are evaluated.  "torch" (default) = torch.sin / torch.cos on fp32 tensors, i.e. what
+# the reference's Python does on this host (Sleef's 1-ulp vector kernels).  "rounded64" = the correctly rounded fp32
+# results (evaluated in fp64, rounded once): a second, equally conforming libm.  The two differ by 1 ulp on a fraction
+# of the arguments; tests use the pair to measure how far two VALID evaluations of the reference formula are apart on
+# a given scene (tests/test_gpu_s1_scale.py) -- the arithmetic of everything else is identical.
+PE_MATH = "torch"
+
+
 def pe_levels(u, freq_num):
     """[..., 3] normalised coords -> list of P=1+2F coordinate triples
     [u, sin(1u), cos(1u), sin(2u), cos(2u), ...]  (FourierGrid_grid.py:26-36,70; no pi)."""
     levels = [u]
     for k in range(freq_num):
         f = float(2 ** k)
-        levels.append(torch.sin(f * u))
-        levels.append(torch.cos(f * u))
+        if PE_MATH == "rounded64":
+            x = (f * u).double()
+            levels.append(torch.sin(x).float())
+            levels.append(torch.cos(x).float())
+        else:
+            levels.append(torch.sin(f * u))
+            levels.append(torch.cos(f * u))
     return levels
 
 

@@ -1,0 +1,96 @@
+"""Parity of the fused render at the HEADLINE scale (BASELINE.json configs[1] / SURVEY 8d "S1": G = 200^3, F = 3, C = 12,
+1920x1080 rays x 256 samples) -- VERDICT r1 "What's weak" #1.  131 072 rays (16 chunks of 8192 spread over the frame)
+are compared with the CPU oracle, all rays, no margin carve-out.
+
+* S1b (smooth fields, opaque surfaces: trained-like statistics, every ray ends on a surface): rgb, depth and
+  alphainv_last within 1e-4 of the oracle on ALL rays -- in practice ~1e-7.
+* S1 (white-noise grids, sigma = 24 density units per voxel): RGB within 1e-4 on all rays.  depth / alphainv_last carry
+  a tail of a few rays in 10^5 just above 1e-4 that is NOT produced by any arithmetic shortcut of the kernels
+  (profiles/r02/parity_ab_s1.txt: IEEE divisions, libm sincos / pow and grid_sample's own corner sum change the worst
+  rays by < 2e-6): it is the conditioning of the reference formula on this scene.  The test measures that directly:
+  the oracle evaluated with a second conforming libm for the Fourier sin / cos (correctly rounded instead of 1-ulp
+  Sleef; everything else identical) moves the same outputs by a comparable amount, and the GPU must stay within that
+  ambiguity (1.5x + 2e-5) of the reference evaluation, the tail must be a handful of rays, the mean error ~1e-6.
+"""
+import os
+import sys
+
+import pytest
+import torch
+
+from oracle import model_oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+G, H, W, N_CHUNKS, CHUNK, STEPSIZE = 200, 1080, 1920, 16, 8192, 1.31
+KEYS = ("rgb_marched", "depth", "alphainv_last")
+
+
+def render_and_reference(make_state, two_libms):
+    import bench
+    from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer, get_rays_of_a_view
+    dev = torch.device("cuda", 0)
+    state = make_state(G, dev, seed=0)
+    rend = FourierGridRenderer(state, dev)
+    K = [[1600.0, 0, W / 2.0], [0, 1600.0, H / 2.0], [0, 0, 1]]
+    ro, rd, vd = [x.reshape(-1, 3).contiguous() for x in get_rays_of_a_view(H, W, K, bench.camera(0, dev))]
+    R = ro.shape[0]
+    out = rend(ro, rd, vd, stepsize=STEPSIZE, render_depth=True)
+    torch.cuda.synchronize()
+    M = rend.survivors_of_last_chunk()
+    cpu_state = {k: ([x.cpu() for x in v] if isinstance(v, list) else (v.cpu() if torch.is_tensor(v) else v)) for k, v in state.items()}
+    del state, rend
+    torch.cuda.empty_cache()
+    starts = [int(i * (R - CHUNK) / (N_CHUNKS - 1)) // 64 * 64 for i in range(N_CHUNKS)]
+    idx = torch.cat([torch.arange(b, b + CHUNK) for b in starts])
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    refs = []
+    for mode in (("torch", "rounded64") if two_libms else ("torch",)):
+        model_oracle.PE_MATH = mode
+        try:
+            parts = [model_oracle.fouriergrid_render(cpu_state, ro[b:b + CHUNK].cpu(), rd[b:b + CHUNK].cpu(), vd[b:b + CHUNK].cpu(),
+                                                     STEPSIZE, render_depth=True) for b in starts]
+        finally:
+            model_oracle.PE_MATH = "torch"
+        refs.append({k: torch.cat([p[k] for p in parts]) for k in KEYS})
+    got = {k: out[k].cpu()[idx] for k in KEYS}
+    return got, refs, M, R
+
+
+def per_ray_err(a, b):
+    e = (a - b).abs()
+    return e.amax(dim=1) if e.dim() == 2 else e
+
+
+def test_s1b_surfaces_all_outputs_within_1e_4_on_all_rays():
+    import bench
+    got, (ref,), M, R = render_and_reference(bench.make_state_surfaces, two_libms=False)
+    assert float((ref["alphainv_last"] < 1e-3).float().mean()) > 0.3          # a surface scene: rays terminate early
+    assert 0.01 < M / (R * 256.0) < 0.2
+    for k in KEYS:
+        err = per_ray_err(got[k], ref[k])
+        print("S1b %-14s linf %.3e mean %.3e" % (k, float(err.max()), float(err.mean())))
+        assert float(err.max()) <= 1e-4, (k, float(err.max()))
+
+
+def test_s1_headline_scene_rgb_depth_parity():
+    import bench
+    got, (ref, ref2), M, R = render_and_reference(bench.make_state, two_libms=True)
+    assert abs(M / (R * 256.0) - 0.049) < 0.003                              # the calibrated 4.9 % survivors
+    stats = {}
+    for k in KEYS:
+        err = per_ray_err(got[k], ref[k])
+        amb = per_ray_err(ref2[k], ref[k])                                   # two conforming libms, same formula
+        stats[k] = (float(err.max()), float(err.mean()), int((err > 1e-4).sum()), float(amb.max()), int((amb > 1e-4).sum()))
+        print("S1  %-14s gpu-vs-oracle linf %.3e mean %.3e rays>1e-4 %d | oracle libm ambiguity linf %.3e rays>1e-4 %d"
+              % ((k,) + stats[k]))
+    n = got["depth"].numel()
+    # the north-star quantity
+    assert stats["rgb_marched"][0] <= 1e-4, stats["rgb_marched"]
+    for k in KEYS:
+        linf, mean, n_above, amb, _ = stats[k]
+        assert mean <= 5e-6, (k, mean)
+        assert n_above <= max(8, n // 10000), (k, n_above)                   # a handful of rays in 10^5
+        assert linf <= max(1e-4, 1.5 * amb + 2e-5), (k, linf, amb)           # inside the reference's own ambiguity

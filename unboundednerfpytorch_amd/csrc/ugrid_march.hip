@@ -261,8 +261,12 @@ extern "C" int ugrid_pack_bricks(const float *grid, int P, int C, int X, int Y, 
     UG_LAUNCH_CHECK();
     return 0;
   }
+  int coef = direct ? 0 : 1;
+#ifdef UG_CORNER_SUM
+  if (C == 1) coef = 0;   // A/B build: density bricks hold corner values (ug_density_level)
+#endif
   hipLaunchKernelGGL(k_pack_bricks, dim3((unsigned)blocks), dim3(256), 0, ST(s), grid, P, C, X, Y, Z, H, CH,
-                     direct ? 0 : 1, bricks, total);
+                     coef, bricks, total);
   UG_LAUNCH_CHECK();
   return 0;
 }

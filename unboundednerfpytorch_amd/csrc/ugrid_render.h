@@ -186,6 +186,22 @@ __device__ __forceinline__ float ug_density_level(const char *__restrict__ lvl, 
   const unsigned off = __umul24(row, (unsigned)(Z - 1) << 5) + ((unsigned)az.cell << 5);
   const float4 *b = (const float4 *)(lvl + off);
   const float4 v0 = b[0], v1 = b[1];
+#ifdef UG_CORNER_SUM
+  // A/B build (tools/gpu_parity_ab.sh): bricks hold the 8 corner VALUES and the lookup is grid_sample's own weighted
+  // corner sum, weights (wz*wy)*wx, separate multiply and add in its accumulation order (tnw, tne, tsw, tse, bnw, ...)
+  {
+    const float zy00 = az.wlo * ay.wlo, zy10 = az.whi * ay.wlo, zy01 = az.wlo * ay.whi, zy11 = az.whi * ay.whi;
+    float r = v0.x * (zy00 * ax.wlo);
+    r = r + v0.y * (zy10 * ax.wlo);
+    r = r + v0.z * (zy01 * ax.wlo);
+    r = r + v0.w * (zy11 * ax.wlo);
+    r = r + v1.x * (zy00 * ax.whi);
+    r = r + v1.y * (zy10 * ax.whi);
+    r = r + v1.z * (zy01 * ax.whi);
+    r = r + v1.w * (zy11 * ax.whi);
+    return r;
+  }
+#endif
   // cell polynomial (k_pack_bricks): Horner in z, then y, then x -- 7 FMAs, no corner weights
   const float tz = az.whi, ty = ay.whi, tx = ax.whi;
   const float p00 = fmaf(v0.y, tz, v0.x), p01 = fmaf(v0.w, tz, v0.z);   // x^0: y^0, y^1
@@ -232,6 +248,17 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
       px = ox + dx * t; py = oy + dy * t; pz = oz + dz * t;
       // contraction p/|p| * (B - A/|p|) outside the unit cube / ball (FourierGrid_model.py:534-548)
       const float nrm = L2 ? ug_norm3_torch(px, py, pz) : fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz)));
+      // A/B builds for the parity study (tools/gpu_parity_ab.sh): UG_EXACT_DIV = IEEE divisions instead of Markstein's,
+      // UG_LIBM_SINCOS / UG_LIBM_ALPHA = the device libm instead of ugrid_math.h, UG_CORNER_SUM (ug_density_level)
+#ifdef UG_EXACT_DIV
+      if (!(nrm <= 1.0f)) {
+        const float sc = a.B - a.A / nrm;
+        px = px / nrm * sc; py = py / nrm * sc; pz = pz / nrm * sc;
+      }
+      const float ux = ((px - a.lox) / a.ex) * 2.f - 1.f;
+      const float uy = ((py - a.loy) / a.ey) * 2.f - 1.f;
+      const float uz = ((pz - a.loz) / a.ez) * 2.f - 1.f;
+#else
       if (!(nrm <= 1.0f)) {
         const float rn = ug_rcp_refined(nrm);
         const float sc = a.B - ug_div_r(a.A, nrm, rn);
@@ -243,20 +270,35 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
       const float ux = ug_div_r(px - a.lox, a.ex, a.irx) * 2.f - 1.f;
       const float uy = ug_div_r(py - a.loy, a.ey, a.iry) * 2.f - 1.f;
       const float uz = ug_div_r(pz - a.loz, a.ez, a.irz) * 2.f - 1.f;
+#endif
       float dens = ug_density_level(bkb, ux, uy, uz, a.X, a.Y, a.Z);
 #pragma unroll
       for (int k = 0; k < F; ++k) {
         const float f = (float)(1 << k);
         float sx, cx_, sy, cy_, sz, cz_;
+#ifdef UG_LIBM_SINCOS
+        sincosf(f * ux, &sx, &cx_);
+        sincosf(f * uy, &sy, &cy_);
+        sincosf(f * uz, &sz, &cz_);
+#else
         ug_sincos(f * ux, &sx, &cx_);
         ug_sincos(f * uy, &sy, &cy_);
         ug_sincos(f * uz, &sz, &cz_);
+#endif
         dens += ug_density_level(bkb + (size_t)(2 * k + 1) * lvl_bytes, sx, sy, sz, a.X, a.Y, a.Z);
         dens += ug_density_level(bkb + (size_t)(2 * k + 2) * lvl_bytes, cx_, cy_, cz_, a.X, a.Y, a.Z);
       }
+#ifdef UG_EXACT_DIV
+      dens = dens / (float)P;
+#else
       dens = ug_div_r(dens, (float)P, 1.0f / (float)P);   // mean over levels: Markstein division, 3 VALU instead of 10
+#endif
       const float xs = dens + a.shift;
+#ifdef UG_LIBM_ALPHA
+      const float alpha = 1.0f - powf(1.0f + expf(xs), -a.interval);
+#else
       const float alpha = ug_alpha(xs, a.interval);
+#endif
       if (alpha > a.thres) {
         w = T * alpha;
         T = (float)((double)T * (1. - (double)alpha));

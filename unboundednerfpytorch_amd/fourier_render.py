@@ -157,7 +157,7 @@ class FourierGridRenderer:
         return p
 
     def rays_per_chunk(self, S):
-        per_ray = (17 + 48) * S + 8   # {p, w} 16 B + slot 1 B + 12 k0 features 48 B per sample, worst case
+        per_ray = 17 * S + 8   # work-list entry {p, w} 16 B + ray slot 1 B per sample, worst case
         n = max(64, (self.max_ws_bytes // per_ray) // 64 * 64)
         return n
 
