@@ -315,6 +315,16 @@ def roofline_block(kern, M, R, S, shade_passes):
         if "valu_insts" in c:
             e["valu_Ginst_per_s"] = c["valu_insts"] / t / 1e9
             e["valu_frac"] = e["valu_Ginst_per_s"] / VALU_PEAK_GINST
+        if "gui_active_cycles" in c:
+            # the chip runs these kernels at its power-limited clock, well below the 2.4 GHz the peaks assume: the same
+            # counts against the cycles the kernel actually had (profiled launch) = how busy the units were
+            cyc = c["gui_active_cycles"]
+            e["effective_clock_GHz_profiled"] = cyc / (c.get("profiled_ms", ms) * 1e-3) / 1e9
+            if "valu_insts" in c:
+                e["valu_issue_busy"] = c["valu_insts"] * 2.0 / N_SIMD / cyc
+            if "mfma_busy_cycles" in c:
+                e["mfma_pipe_busy"] = c["mfma_busy_cycles"] / N_SIMD / cyc
+            e["l1_path_busy"] = alg[name] / (N_CU * 64.0) / cyc
         fr = {k[:-5]: v for k, v in e.items() if k.endswith("_frac")}
         e["bound"] = max(fr, key=fr.get)
         per[name] = e

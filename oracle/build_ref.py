@@ -84,6 +84,44 @@ def _build_variant(variant, verbose=False):
             shutil.rmtree(work, ignore_errors=True)
 
 
+REFERENCE_PY = ["__init__.py", "FourierGrid_model.py", "FourierGrid_grid.py", "grid.py", "dvgo.py", "dcvgo.py", "dmpigo.py",
+                "masked_adam.py", "utils.py"]
+
+
+def stage_reference_python():
+    """oracle/_ref/reference_py.tar: the reference's own model files (the callers of the four extension modules), so
+    that tests/test_gpu_reference_callers.py can run them UNCHANGED over the HIP modules on the GPU box, where
+    /root/reference does not exist.  Like the .so files beside it the archive is git-ignored (never part of the
+    repository's history) and shipped by gpurun; the test unpacks it into a temporary directory."""
+    import tarfile
+    root = os.environ.get("UNERF_REFERENCE_ROOT", "/root/reference")
+    src = os.path.join(root, "FourierGrid")
+    if not os.path.isdir(src):
+        raise RuntimeError("reference sources not present")
+    os.makedirs(OUT, exist_ok=True)
+    dst = os.path.join(OUT, "reference_py.tar")
+    with tarfile.open(dst, "w") as tf:
+        for f in REFERENCE_PY:
+            tf.add(os.path.join(src, f), arcname=os.path.join("FourierGrid", f))
+    return dst
+
+
+def reference_python_root():
+    """Directory to put on sys.path so that `import FourierGrid.<module>` finds the reference's files: the reference tree
+    itself when present, else the staged archive unpacked into a temporary directory, else None."""
+    root = os.environ.get("UNERF_REFERENCE_ROOT", "/root/reference")
+    if os.path.isdir(os.path.join(root, "FourierGrid")):
+        return root
+    tar = os.path.join(OUT, "reference_py.tar")
+    if not os.path.exists(tar):
+        return None
+    import tarfile
+    d = tempfile.mkdtemp(prefix="unerf_refpy_")
+    with tarfile.open(tar) as tf:
+        tf.extractall(d)
+    return d
+
+
 def load(variant="nofma"):
     """Import the four prebuilt modules (needs a GPU at call time, not at import time).  Returns a dict."""
     import importlib.util
@@ -103,4 +141,4 @@ if __name__ == "__main__":
         _build_variant(sys.argv[sys.argv.index("--variant") + 1], verbose="-v" in sys.argv)
     else:
         build(verbose="-v" in sys.argv)
-        print("built:", sorted(glob.glob(os.path.join(OUT, "*", "*.so"))))
+        print("built:", sorted(glob.glob(os.path.join(OUT, "*", "*.so"))), stage_reference_python())

@@ -21,6 +21,7 @@ import types
 import torch
 
 REFERENCE_ROOT = os.environ.get("UNERF_REFERENCE_ROOT", "/root/reference")
+OPS_BACKEND = None   # default back-end of install(): None = the CPU oracle (tests/test_gpu_reference_callers.py sets the HIP modules)
 
 
 def reference_available():
@@ -48,6 +49,8 @@ def install(ops_backend=None):
     """Register the stubs.  `ops_backend` may provide the four extension modules
     (an object with attributes render_utils_cuda, total_variation_cuda, ub360_utils_cuda,
     adam_upd_cuda); default is the CPU oracle."""
+    if ops_backend is None:
+        ops_backend = OPS_BACKEND
     if ops_backend is None:
         from oracle import ref_ops as ops_backend
     for name in ("render_utils_cuda", "total_variation_cuda", "ub360_utils_cuda", "adam_upd_cuda"):

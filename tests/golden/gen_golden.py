@@ -18,6 +18,10 @@ import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
+# tests/test_gpu_reference_callers.py re-runs these generators with the HIP modules installed as the reference's
+# extension modules, DEVICE = "cuda" and OUT = a scratch directory, and compares the files with the committed ones
+DEVICE = "cpu"
+OUT = HERE
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
@@ -49,7 +53,7 @@ def build_reference_model(mod, G, F, C, viewbase_pe, norm, thres, params):
             assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
             sd[k].copy_(torch.from_numpy(v))
     assert int(model.world_len_density) == G
-    return model
+    return model.to(DEVICE)
 
 
 def gen_fouriergrid():
@@ -65,7 +69,7 @@ def gen_fouriergrid():
         keep["n_max"] = np.int64(out["n_max"])
         keep["interval"] = np.float32(float(stepsize * model.voxel_size_ratio_density))
         keep["act_shift"] = model.act_shift.numpy()
-        np.savez_compressed(os.path.join(HERE, name + ".npz"), **keep)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **keep)
         print(name, "M=%d" % out["weights"].numel(), "rgb max %.4f" % float(out["rgb_marched"].max()),
               "terminated %d/%d" % (int((out["alphainv_last"] < 1e-3).sum()), R))
 
@@ -82,19 +86,19 @@ def gen_grid_query():
     for C, F in ((1, 3), (12, 3), (3, 2)):
         G = (9, 7, 5)
         m = fg.FourierGrid(channels=C, world_size=torch.tensor(G), xyz_min=[-1.2] * 3, xyz_max=[1.2] * 3,
-                           use_nerf_pos=True, fourier_freq_num=F, config={})
+                           use_nerf_pos=True, fourier_freq_num=F, config={}).to(DEVICE)
         g = synth.normal(40 + C, (1 + 2 * F) * C * G[0] * G[1] * G[2]).reshape(1 + 2 * F, C, *G)
         with torch.no_grad():
             m.grid.copy_(torch.from_numpy(g))
             res["fourier_c%d_f%d" % (C, F)] = m(pts).numpy()
     for C in (1, 4):
         G = (6, 8, 11)
-        m = dg.DenseGrid(channels=C, world_size=torch.tensor(G), xyz_min=[-1.0, -0.5, -2.0], xyz_max=[1.0, 1.5, 1.0])
+        m = dg.DenseGrid(channels=C, world_size=torch.tensor(G), xyz_min=[-1.0, -0.5, -2.0], xyz_max=[1.0, 1.5, 1.0]).to(DEVICE)
         g = synth.normal(50 + C, C * G[0] * G[1] * G[2]).reshape(1, C, *G)
         with torch.no_grad():
             m.grid.copy_(torch.from_numpy(g))
             res["dense_c%d" % C] = m(pts).numpy()
-    np.savez_compressed(os.path.join(HERE, "grid_query.npz"), **res)
+    np.savez_compressed(os.path.join(OUT, "grid_query.npz"), **res)
     print("grid_query", {k: v.shape for k, v in res.items()})
 
 
@@ -138,7 +142,7 @@ def gen_autograd_and_adam():
         opt.step()
     res.update(adam_grid=p_grid.detach().numpy(), adam_dense=p_dense.detach().numpy(),
                adam_grid_m=opt.state[p_grid]['exp_avg'].numpy(), adam_grid_v=opt.state[p_grid]['exp_avg_sq'].numpy())
-    np.savez_compressed(os.path.join(HERE, "autograd_adam.npz"), **res)
+    np.savez_compressed(os.path.join(OUT, "autograd_adam.npz"), **res)
     print("autograd_adam", {k: v.shape for k, v in res.items()})
 
 
@@ -154,7 +158,7 @@ def gen_distortion():
     pre = ref_ops.segment_cumsum(torch.from_numpy(w), torch.from_numpy(s), torch.from_numpy(ray_id))
     res = dict(loss=loss.detach().numpy(), grad=wt.grad.numpy(), w_prefix=pre[0].numpy(), w_total=pre[1].numpy(),
                ws_prefix=pre[2].numpy(), ws_total=pre[3].numpy())
-    np.savez_compressed(os.path.join(HERE, "distortion.npz"), **res)
+    np.savez_compressed(os.path.join(OUT, "distortion.npz"), **res)
     print("distortion", float(loss), wt.grad.shape)
 
 
@@ -178,7 +182,7 @@ def gen_train_step():
     for k, p in model.named_parameters():
         if p.grad is not None:
             res["grad." + k] = p.grad.numpy()
-    np.savez_compressed(os.path.join(HERE, "train_step.npz"), **res)
+    np.savez_compressed(os.path.join(OUT, "train_step.npz"), **res)
     print("train_step loss %.6f kept %d grads %s" % (float(loss), int(res["n_kept"]), sorted(k for k in res if k.startswith("grad."))))
 
 
@@ -195,7 +199,7 @@ def gen_rays_view():
                     ("c", dict(inverse_y=False, flip_x=False, flip_y=True))):
         o, d, v = dvgo.get_rays_of_a_view(H=5, W=7, K=K, c2w=torch.from_numpy(c2w), ndc=False, mode='center', **kw)
         res[tag + "_o"], res[tag + "_d"], res[tag + "_v"] = o.numpy(), d.numpy(), v.numpy()
-    np.savez_compressed(os.path.join(HERE, "rays_view.npz"), **res)
+    np.savez_compressed(os.path.join(OUT, "rays_view.npz"), **res)
     print("rays_view", o.shape)
 
 
@@ -229,12 +233,13 @@ def gen_dvgo():
             for k, v in params.items():
                 assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
                 sd[k].copy_(torch.from_numpy(v))
+        model = model.to(DEVICE)
         o, d, v = [torch.from_numpy(a) for a in synth.rays(seed, R, origin_scale=0.4)]
         with torch.no_grad():
             out = model(o, d, v, near=0.2, far=6.0, stepsize=0.5, bg=1, render_depth=True)
         keep = {k: out[k].numpy() for k in ("alphainv_last", "weights", "rgb_marched", "raw_alpha", "raw_rgb", "ray_id", "depth")}
         keep["world_size"] = np.array(ws)
-        np.savez_compressed(os.path.join(HERE, name + ".npz"), **keep)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **keep)
         print(name, "world", ws, "M=%d" % out["weights"].numel(), "rgb mean %.3f" % float(out["rgb_marched"].mean()))
 
 
@@ -270,7 +275,7 @@ def gen_dvgo_utils():
         ndc=False, inverse_y=False, flip_x=False, flip_y=False, model=model, render_kwargs=rk)
     res = dict(hit=np.stack(hits), count=count.detach().numpy(), rgb_tr=rgb_tr.numpy(), rays_o_tr=o_tr.numpy(),
                rays_d_tr=d_tr.numpy(), viewdirs_tr=v_tr.numpy(), imsz=np.array([int(x) for x in imsz]))
-    np.savez_compressed(os.path.join(HERE, "dvgo_utils.npz"), **res)
+    np.savez_compressed(os.path.join(OUT, "dvgo_utils.npz"), **res)
     print("dvgo_utils hit frac %.2f, seen voxels %d of %d, kept rays %s" % (res["hit"].mean(), int((res["count"] > 0).sum()),
                                                                          res["count"].size, res["imsz"].tolist()))
 
@@ -317,7 +322,7 @@ def gen_model_utils():
     cnt = model.voxel_count_views(rays_o_tr=torch.stack(ro), rays_d_tr=torch.stack(rd), imsz=1, near=0.05, far=6.0,
                                   stepsize=0.5, downrate=1, irregular_shape=False)
     res["view_count"] = cnt.detach().numpy().copy()
-    np.savez_compressed(os.path.join(HERE, "fg_model_utils.npz"), **res)
+    np.savez_compressed(os.path.join(OUT, "fg_model_utils.npz"), **res)
     print("model_utils: occupancy %.3f -> scaled world %s mask %.3f ratio %.4f" % (
         res["occ_mask"].mean(), res["scaled_world_size"].tolist(), res["scaled_mask"].mean(), float(res["scaled_ratio"])))
 
@@ -383,7 +388,7 @@ def gen_train_utils():
     same = all(torch.equal(a[k], b[k]) for k in ("rgb_marched", "depth", "alphainv_last", "weights", "ray_id"))
     assert same, "reference model loaded from this package's checkpoint renders differently"
     res["reverse_checkpoint_ok"] = np.int64(1)
-    np.savez_compressed(os.path.join(HERE, "train_utils.npz"), **res)
+    np.savez_compressed(os.path.join(OUT, "train_utils.npz"), **res)
     print("train_utils", {k: v.tolist() for k, v in res.items() if k.endswith("_lr")}, "reverse ckpt ok")
 
 
@@ -402,6 +407,7 @@ def gen_dcvgo():
             for k, v in params.items():
                 assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
                 sd[k].copy_(torch.from_numpy(v))
+        model = model.to(DEVICE)
         o, d, v = [torch.from_numpy(a) for a in synth.rays(seed, R, origin_scale=0.5)]
         o = o + torch.tensor(synth.DCVGO_BOX[0]) * 0.5 + torch.tensor(synth.DCVGO_BOX[1]) * 0.5
         with torch.no_grad():
@@ -410,7 +416,7 @@ def gen_dcvgo():
                                             "raw_rgb", "ray_id", "step_id", "t", "s", "depth")}
         keep["n_max"] = np.int64(out["n_max"])
         keep["world_size"] = np.array(ws)
-        np.savez_compressed(os.path.join(HERE, name + ".npz"), **keep)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **keep)
         print(name, "world", ws, "M=%d of %d" % (out["weights"].numel(), R * out["n_max"]),
               "terminated %d/%d" % (int((out["alphainv_last"] < 1e-3).sum()), R), "wsum_mid mean %.3f" % float(out["wsum_mid"].mean()))
 
@@ -433,12 +439,12 @@ def gen_checkpoint():
         for k, v in params.items():
             sd[k].copy_(torch.from_numpy(v))
     ckpt = {'global_step': 123, 'model_kwargs': model.get_kwargs(), 'model_state_dict': model.state_dict()}
-    torch.save(ckpt, os.path.join(HERE, "fg_ckpt_small.tar"))
+    torch.save(ckpt, os.path.join(OUT, "fg_ckpt_small.tar"))
     o, d, v = [torch.from_numpy(a) for a in synth.rays(41, 64, origin_scale=0.6)]
     o = o + torch.tensor([0.0, 1.0, -1.0])   # around the scene centre
     with torch.no_grad():
         out = model(o, d, v, stepsize=0.5, render_depth=True)
-    np.savez_compressed(os.path.join(HERE, "fg_ckpt_small_render.npz"),
+    np.savez_compressed(os.path.join(OUT, "fg_ckpt_small_render.npz"),
                         **{k: out[k].numpy() for k in ("rgb_marched", "depth", "alphainv_last")},
                         world_len=np.int64(Gd), interval=np.float32(float(0.5 * model.voxel_size_ratio_density)))
     print("checkpoint world_len", Gd, "ratio", float(model.voxel_size_ratio_density), "M", out["weights"].numel())

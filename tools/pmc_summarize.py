@@ -18,7 +18,8 @@ NAMES = {"k_march": "render_march", "k_shade_mlp": "render_shade"}
 def main():
     tag = sys.argv[1]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(tag, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
+    files = glob.glob(os.path.join(tag, "pmc_*", "**", "*counter_collection.csv"), recursive=True) + glob.glob(os.path.join(tag, "pmc_*.csv"))
+    for f in files:
         for r in csv.DictReader(open(f)):
             for k, name in NAMES.items():
                 if k in r["Kernel_Name"]:
@@ -38,6 +39,8 @@ def main():
             e["mfma_insts"] = m["SQ_INSTS_MFMA"]
         if "SQ_VALU_MFMA_BUSY_CYCLES" in m:
             e["mfma_busy_cycles"] = m["SQ_VALU_MFMA_BUSY_CYCLES"]
+        if "GRBM_GUI_ACTIVE" in m:
+            e["gui_active_cycles"] = m["GRBM_GUI_ACTIVE"] / 8.0     # the counter sums the 8 XCDs
         if "TCC_HIT_sum" in m and "TCC_REQ_sum" in m:
             e["l2_hit_rate"] = m["TCC_HIT_sum"] / max(1.0, m["TCC_REQ_sum"])
         out[name] = e
