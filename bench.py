@@ -166,15 +166,20 @@ def lib_sha16():
 class FrameBench:
     """One scene on this rank: renderer + camera + the timed step (ray generation, shard, render, tile exchange)."""
 
-    def __init__(self, args, state, device, world, rank, dist):
+    def __init__(self, args, state, device, world, rank, dist, renderer=None):
+        """renderer: test hook (tests/test_host_logic.py drives the sharding / exchange logic over gloo with a stand-in
+        that has the renderer's call signature); None = the HIP FourierGridRenderer."""
         from unboundednerfpytorch_amd.dist import shard_bounds, tile_assignment
-        from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer, get_rays_of_a_view
+        from unboundednerfpytorch_amd.fourier_render import get_rays_of_a_view
         self.get_rays = get_rays_of_a_view
         self.args, self.device, self.world, self.rank, self.dist = args, device, world, rank, dist
         H, W, G = args.height, args.width, args.grid
         self.H, self.W = H, W
         self.stepsize = 1.31 * G / 200.0 if G != 200 else 1.31
-        self.rend = FourierGridRenderer(state, device, fused=args.single_launch, pipeline=args.pipeline, mlp_mode=args.mlp_mode)
+        if renderer is None:
+            from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer
+            renderer = FourierGridRenderer(state, device, fused=args.single_launch, pipeline=args.pipeline, mlp_mode=args.mlp_mode)
+        self.rend = renderer
         self.K = [[1600.0 * W / 1920.0, 0, W / 2.0], [0, 1600.0 * W / 1920.0, H / 2.0], [0, 0, 1]]
         self.R = H * W
         self.S = self.rend.tables(self.stepsize)[2]
@@ -232,7 +237,20 @@ class FrameBench:
                 self.inflight["work"].wait()     # the last exchange is inside the timed region
                 self.inflight["work"] = None
             self.dist.barrier()
-        torch.cuda.synchronize()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize()
+
+    def assembled_frame(self):
+        """The last exchanged frame in ray order, [R,5] = rgb(3), depth, alphainv_last (every rank holds it)."""
+        from unboundednerfpytorch_amd.dist import shard_bounds, tile_assignment
+        full = self.gathered[(self.inflight["n"] - 1) & 1]
+        if self.idx is None:
+            return full[:self.R]
+        res = torch.empty(self.R, 5, dtype=full.dtype, device=full.device)
+        for r in range(self.world):
+            ir = tile_assignment(self.R, self.world, r).to(full.device)
+            res[ir] = full[r * self.per: r * self.per + ir.numel()]
+        return res
 
     def timed(self, steps, warmup, weak=False):
         for _ in range(warmup):

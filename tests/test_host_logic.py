@@ -385,3 +385,67 @@ def test_data_parallel_training_matches_single_process_gloo():
                         for i, st in res[0][6].items()}, 'param_groups': mine['param_groups']}
     opt.load_state_dict(loaded)
     assert opt.state[m.k0.grid]['exp_avg'].shape == m.k0.grid.shape
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bench.py's strong-scaled step (one frame over N ranks + the tile all-gather) over gloo, with a stand-in renderer
+# ---------------------------------------------------------------------------------------------------------
+class _FakeRenderer:
+    """Call signature of FourierGridRenderer; per-ray outputs are a deterministic function of the ray alone."""
+    pipeline = 0
+
+    def tables(self, stepsize):
+        return None, None, 16
+
+    def __call__(self, ro, rd, vd, stepsize=None, render_depth=True, timing=None):
+        if timing is not None:
+            timing.append(((_FakeEvent(), _FakeEvent(), _FakeEvent()), ro.shape[0]))
+        return {"rgb_marched": torch.sin(vd * 3.0), "depth": (rd * vd).sum(-1), "alphainv_last": torch.cos(vd[:, 0] * 5.0), "n_max": 16}
+
+
+class _FakeEvent:
+    def elapsed_time(self, other):
+        return 0.0
+
+
+def _bench_worker(rank, world, port, q, contiguous):
+    import argparse
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    import bench
+    args = argparse.Namespace(height=37, width=101, grid=200, contiguous=contiguous, single_launch=False, pipeline=0, mlp_mode=None)
+    fb = bench.FrameBench(args, None, torch.device("cpu"), world, rank, dist, renderer=_FakeRenderer())
+    dt, timing = fb.timed(3, 1)
+    fb.check_exchange()
+    frame = fb.assembled_frame()
+    rays = sum(n for _, n in timing) // 3
+    q.put((rank, frame.numpy().copy(), rays, dt > 0))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("contiguous", [False, True])
+def test_bench_strong_scaled_step_over_gloo(contiguous):
+    import argparse
+    import bench
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 37500 + os.getpid() % 2000 + (1 if contiguous else 0)
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q, contiguous)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    args = argparse.Namespace(height=37, width=101, grid=200, contiguous=contiguous, single_launch=False, pipeline=0, mlp_mode=None)
+    fb = bench.FrameBench(args, None, torch.device("cpu"), 1, 0, None, renderer=_FakeRenderer())
+    ro, rd, vd = fb.rays()
+    want = _FakeRenderer()(ro, rd, vd)
+    R = 37 * 101
+    for rank, frame, rays, ok in res:
+        assert ok and frame.shape == (R, 5)
+        np.testing.assert_array_equal(frame[:, 0:3], want["rgb_marched"].numpy())
+        np.testing.assert_array_equal(frame[:, 3], want["depth"].numpy())
+        np.testing.assert_array_equal(frame[:, 4], want["alphainv_last"].numpy())
+    assert res[0][2] + res[1][2] == R and abs(res[0][2] - res[1][2]) <= 128    # every ray rendered once, shards balanced to the 64-ray tile
