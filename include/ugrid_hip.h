@@ -136,6 +136,17 @@ int ugrid_segment_cumsum(const float *w, const float *s, const int64_t *ray_id, 
 /* replaces adam_upd / masked_adam_upd / adam_upd_with_perlr (adam_upd.cpp:79-86 ->
  * adam_upd_kernel.cu:9-132).  mode: 0 dense, 1 masked (skip grad==0), 2 per-voxel lr (perlr != NULL).
  * param, exp_avg, exp_avg_sq updated in place. */
+/* NEW (no reference counterpart): dense total_variation_add_grad + (masked_)adam_upd in ONE pass over a grid parameter --
+ * what run_train.py:281-288 does with two extension calls while global_step < tv_dense_before.  The TV term is added to
+ * the gradient in registers (grad is not modified), the updated parameter is written to param_out (a second buffer of
+ * the same shape: the stencil needs the neighbours' old values; the caller swaps the buffers), exp_avg / exp_avg_sq in
+ * place.  Results are bit-identical to ugrid_total_variation_add_grad(dense) followed by ugrid_adam_upd(mode =
+ * skip_zero_grad).  Returns hipErrorNotSupported (801) when the shape cannot take the vector path (sz_k % 4 != 0,
+ * N >= 2^31, unaligned or aliasing buffers); the caller then uses the two separate entry points. */
+int ugrid_tv_adam_dense(const float *param, float *param_out, const float *grad, float *exp_avg, float *exp_avg_sq,
+                        float wx, float wy, float wz, int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t N, int step,
+                        float beta1, float beta2, float lr, float eps, int skip_zero_grad, ugrid_stream_t stream);
+
 int ugrid_adam_upd(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                    const float *perlr, int64_t N, int step, float beta1, float beta2, float lr,
                    float eps, int mode, ugrid_stream_t stream);

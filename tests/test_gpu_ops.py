@@ -384,3 +384,41 @@ def test_segment_cumsum_and_distortion_loss(mods, golden_dir):
     np.testing.assert_allclose(float(loss), float(gold["loss"]), rtol=2e-6)
     np.testing.assert_allclose(wt.grad.cpu().numpy(), gold["grad"], rtol=2e-6, atol=1e-7)
     assert DistortionLoss.apply is not None
+
+
+@pytest.mark.parametrize("shape", [(3, 2, 9, 6, 12), (1, 1, 4, 4, 4), (7, 1, 20, 20, 20), (2, 3, 5, 7, 11)])
+@pytest.mark.parametrize("skip_zero", [True, False])
+def test_fused_dense_tv_adam_is_bit_identical_to_the_two_reference_calls(mods, shape, skip_zero):
+    """adam_upd_cuda.tv_adam_dense (one pass, out-of-place parameter) == total_variation_add_grad(dense) followed by
+    masked_adam_upd / adam_upd, bit for bit; shapes whose last dimension is not a multiple of 4 report 'not supported'
+    (the optimizer then uses the two calls).  Also through MaskedAdam.step(tv_terms=...), which swaps the buffers."""
+    from unboundednerfpytorch_amd.masked_adam import MaskedAdam
+    tv, ad = mods[1], mods[3]
+    n = int(np.prod(shape))
+    p = torch.from_numpy(synth.normal(60, n, 0.0, 2.0).reshape(shape)).cuda()
+    g = synth.normal(61, n).reshape(shape)
+    g[np.abs(g) < 0.7] = 0
+    g = torch.from_numpy(g).cuda()
+    m = torch.from_numpy(synth.normal(62, n, 0, 0.1).reshape(shape)).cuda()
+    v = torch.from_numpy(synth.uniform(63, n, 0, 0.01).reshape(shape)).cuda()
+    w, args = 0.37, (5, 0.9, 0.99, 0.1, 1e-8)
+    p_ref, g_ref, m_ref, v_ref = p.clone(), g.clone(), m.clone(), v.clone()
+    tv.total_variation_add_grad(p_ref, g_ref, w, w, w, True)
+    (ad.masked_adam_upd if skip_zero else ad.adam_upd)(p_ref, g_ref, m_ref, v_ref, *args)
+    out, m2, v2 = torch.empty_like(p), m.clone(), v.clone()
+    ok = ad.tv_adam_dense(p, out, g, m2, v2, w, w, w, *args, skip_zero)
+    assert ok == (shape[-1] % 4 == 0)
+    if ok:
+        assert torch.equal(out, p_ref) and torch.equal(m2, m_ref) and torch.equal(v2, v_ref)
+        assert torch.equal(g, torch.from_numpy(np.where(np.abs(synth.normal(61, n).reshape(shape)) < 0.7, 0, synth.normal(61, n).reshape(shape))).cuda())
+    # optimizer level: three steps with a TV term, fused vs the hook-free reference sequence
+    pa, pb = torch.nn.Parameter(p.clone()), torch.nn.Parameter(p.clone())
+    oa = MaskedAdam([{'params': [pa], 'lr': 0.1, 'skip_zero_grad': skip_zero}])
+    ob = MaskedAdam([{'params': [pb], 'lr': 0.1, 'skip_zero_grad': skip_zero}])
+    for step in range(3):
+        gs = torch.from_numpy(synth.normal(70 + step, n).reshape(shape)).cuda()
+        pa.grad, pb.grad = gs.clone(), gs.clone()
+        oa.step(tv_terms={pa: (w, True, None)})
+        tv.total_variation_add_grad(pb, pb.grad, w, w, w, True)
+        ob.step()
+    assert torch.equal(pa.data, pb.data) and torch.equal(oa.state[pa]['exp_avg_sq'], ob.state[pb]['exp_avg_sq'])

@@ -64,6 +64,7 @@ _SIGNATURES = {
     "ugrid_cumdist_thres": (_I, [_P, _F, _L, _L, _P, _P]),
     "ugrid_segment_cumsum": (_I, [_P, _P, _P, _L, _L, _P, _P, _P, _P, _P, _P]),
     "ugrid_adam_upd": (_I, [_P, _P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _I, _P]),
+    "ugrid_tv_adam_dense": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _L, _L, _L, _L, _I, _F, _F, _F, _F, _I, _P]),
     "ugrid_grid_query": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _L, _P, _P]),
     "ugrid_grid_query_backward": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _L, _P, _P]),
     "ugrid_brick_bytes": (_L, [_I, _I, _I, _I, _I, _I]),

@@ -29,3 +29,22 @@ def masked_adam_upd(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2, lr, ep
 
 def adam_upd_with_perlr(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps):
     _run(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps, 2, "adam_upd_with_perlr")
+
+
+def tv_adam_dense(param, param_out, grad, exp_avg, exp_avg_sq, wx, wy, wz, step, beta1, beta2, lr, eps, skip_zero_grad):
+    """NEW (not in the reference module): dense total_variation_add_grad + (masked_)adam_upd of one grid parameter
+    [.., X, Y, Z] in a single pass (include/ugrid_hip.h: ugrid_tv_adam_dense).  The updated parameter lands in
+    `param_out`; `grad` is left untouched.  Returns False when the shape cannot take the fused path (the caller then
+    runs the two reference calls), True otherwise."""
+    named = [("param", param), ("param_out", param_out), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)]
+    _lib.require_cuda(*named)
+    _lib.require_f32(*named)
+    sz_i, sz_j, sz_k = param.shape[-3:]
+    with torch.cuda.device(param.device):
+        rc = _L.ugrid_tv_adam_dense(_lib.ptr(param), _lib.ptr(param_out), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
+                                    float(wx), float(wy), float(wz), sz_i, sz_j, sz_k, param.numel(), int(step), float(beta1),
+                                    float(beta2), float(lr), float(eps), int(bool(skip_zero_grad)), _lib.stream_of(param))
+    if rc == 801:      # hipErrorNotSupported
+        return False
+    _lib.check(rc, "tv_adam_dense")
+    return True

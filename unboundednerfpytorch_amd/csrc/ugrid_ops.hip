@@ -591,6 +591,62 @@ static int ug_adam_launch(float *param, const float *grad, float *m, float *v, c
   return 0;
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Fused DENSE total-variation gradient + Adam (new entry point, no reference counterpart).
+// While `tv_dense_before` holds (run_train.py:281-287, 10 000 of truck_single's 30 000 iterations) the reference runs
+// total_variation_add_grad(dense) -- which makes EVERY gradient entry non-zero -- and then masked_adam_upd, i.e. two
+// full passes over param / grad and one over both moments: 13 arrays of traffic.  Fused: per 4 voxels the TV term is
+// formed exactly as k_tv_vec4<true> does (same six sequential adds), added to the gradient in registers and fed to
+// ug_adam_one: 7 arrays (param, grad, m, v read; param', m, v written), the gradient is never written back.  The
+// stencil needs the neighbours' OLD values, so the new parameters go to a second buffer that the caller swaps in.
+// Bit-identical to the two-kernel sequence.  MASKED = the skip_zero_grad rule applied to the TV-added gradient.
+// ----------------------------------------------------------------------------------------------
+template <bool MASKED>
+__global__ void __launch_bounds__(256)
+k_tv_adam_vec4(const float *__restrict__ param, float *__restrict__ param_out, const float *__restrict__ grad,
+               float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, float wy, float wz, int sz_i, int sz_j,
+               int sz_k, unsigned n4, float step_size, float beta1, float beta2, float eps) {
+  const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n4) return;
+  const unsigned idx = q * 4u;
+  const float4 g0 = *(const float4 *)(grad + idx);
+  const unsigned k4 = (unsigned)sz_k >> 2;
+  const unsigned kq = q % k4, row = q / k4;
+  const unsigned j = row % (unsigned)sz_j, i = (row / (unsigned)sz_j) % (unsigned)sz_i;
+  const unsigned sj = (unsigned)sz_k, si = (unsigned)sz_k * (unsigned)sz_j;
+  const float4 p = *(const float4 *)(param + idx);
+  const bool k_first = kq == 0, k_last = kq == k4 - 1;
+  const float pm = k_first ? 0.f : param[idx - 1];
+  const float pp = k_last ? 0.f : param[idx + 4];
+  float4 nj0 = p, nj1 = p, ni0 = p, ni1 = p;
+  if (j != 0) nj0 = *(const float4 *)(param + idx - sj);
+  if (j != (unsigned)sz_j - 1) nj1 = *(const float4 *)(param + idx + sj);
+  if (i != 0) ni0 = *(const float4 *)(param + idx - si);
+  if (i != (unsigned)sz_i - 1) ni1 = *(const float4 *)(param + idx + si);
+  const float4 m4 = *(const float4 *)(exp_avg + idx), v4 = *(const float4 *)(exp_avg_sq + idx);
+  float pv[4] = {p.x, p.y, p.z, p.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
+  const float pold[4] = {p.x, p.y, p.z, p.w}, gv[4] = {g0.x, g0.y, g0.z, g0.w};
+  const float km[4] = {pm, p.x, p.y, p.z}, kp[4] = {p.y, p.z, p.w, pp};
+  const float a0[4] = {nj0.x, nj0.y, nj0.z, nj0.w}, a1[4] = {nj1.x, nj1.y, nj1.z, nj1.w};
+  const float b0[4] = {ni0.x, ni0.y, ni0.z, ni0.w}, b1[4] = {ni1.x, ni1.y, ni1.z, ni1.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float g = 0;
+    g += ((k_first && e == 0) ? 0.f : wz * ug_clamp1(pold[e] - km[e]));
+    g += ((k_last && e == 3) ? 0.f : wz * ug_clamp1(pold[e] - kp[e]));
+    g += (j == 0 ? 0.f : wy * ug_clamp1(pold[e] - a0[e]));
+    g += (j == (unsigned)sz_j - 1 ? 0.f : wy * ug_clamp1(pold[e] - a1[e]));
+    g += (i == 0 ? 0.f : wz * ug_clamp1(pold[e] - b0[e]));
+    g += (i == (unsigned)sz_i - 1 ? 0.f : wz * ug_clamp1(pold[e] - b1[e]));
+    const float gt = gv[e] + g;
+    if (!MASKED || gt != 0.f) ug_adam_one<0>(pv[e], gt, mv[e], vv[e], 1.f, step_size, beta1, beta2, eps);
+  }
+  *(float4 *)(param_out + idx) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+  *(float4 *)(exp_avg + idx) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+  *(float4 *)(exp_avg_sq + idx) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+}
+
 // ----------------------------------------------------------------------------------------------
 // C ABI
 // ----------------------------------------------------------------------------------------------
@@ -778,6 +834,29 @@ extern "C" int ugrid_segment_cumsum(const float *w, const float *s_, const int64
     hipLaunchKernelGGL(k_segments, dim3(ug_blocks(n, 256)), dim3(256), 0, ST(s), ray_id, n, i_start, i_end);
   hipLaunchKernelGGL(k_segment_cumsum, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), w, s_, n_rays,
                      i_start, i_end, w_prefix, w_total, ws_prefix, ws_total);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ugrid_tv_adam_dense(const float *param, float *param_out, const float *grad, float *exp_avg,
+                                   float *exp_avg_sq, float wx, float wy, float wz, int64_t sz_i, int64_t sz_j,
+                                   int64_t sz_k, int64_t N, int step, float beta1, float beta2, float lr, float eps,
+                                   int skip_zero_grad, ugrid_stream_t s) {
+  if (N <= 0) return 0;
+  (void)wx;
+  const uintptr_t al = (uintptr_t)param | (uintptr_t)param_out | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq;
+  if (sz_k % 4 != 0 || N >= ((int64_t)1 << 31) || sz_i * sz_j * sz_k <= 0 || (al & 15) != 0 || param == param_out)
+    return (int)hipErrorNotSupported;   // caller falls back to total_variation_add_grad + adam_upd
+  wy /= 6;
+  wz /= 6;
+  const float step_size = lr * sqrtf(1 - powf(beta2, (float)step)) / (1 - powf(beta1, (float)step));
+  const unsigned n4 = (unsigned)(N / 4);
+  if (skip_zero_grad)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_adam_vec4<true>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, param_out,
+                       grad, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, n4, step_size, beta1, beta2, eps);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_adam_vec4<false>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, param_out,
+                       grad, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, n4, step_size, beta1, beta2, eps);
   UG_LAUNCH_CHECK();
   return 0;
 }

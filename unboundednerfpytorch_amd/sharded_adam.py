@@ -40,6 +40,7 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         self.min_shard_numel = int(min_shard_numel)
         self.local_only = bool(local_only)     # MaskedAdam: the reference's single-process optimizer, no collectives
         self.per_lr = None
+        self._alt = {}      # second parameter buffers of the fused TV + Adam pass (not optimizer state: never checkpointed)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
 
     # -- topology ------------------------------------------------------------------------------------
@@ -69,12 +70,39 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         else:
             self.ops.adam_upd(p, g, m, v, *args)
 
+    def _tv_then_update(self, group, param, g, state, tv, use_perlr):
+        """Total-variation term (w, dense_mode, tv_module) on the reduced gradient `g`, then the Adam update.  Dense mode
+        on the HIP ops: ONE fused pass (adam_upd_cuda.tv_adam_dense -- 7 instead of 13 array transfers, the gradient is
+        not written back, bit-identical results); the new parameter values land in a second buffer that is swapped in."""
+        w, dense, tv_module = tv
+        fused_fn = getattr(self.ops, 'tv_adam_dense', None)
+        if dense and fused_fn is not None and tv_module is None and not use_perlr and param.dim() >= 3 and g.is_contiguous():
+            alt = self._alt.get(param)
+            if alt is None or alt.shape != param.shape or alt.device != param.device:
+                alt = torch.empty_like(param.data, memory_format=torch.contiguous_format)
+            beta1, beta2 = group['betas']
+            if param.data.is_contiguous() and fused_fn(param.data, alt, g, state['exp_avg'], state['exp_avg_sq'], w, w, w,
+                                                       state['step'], beta1, beta2, group['lr'], group['eps'],
+                                                       group['skip_zero_grad']):
+                self._alt[param] = param.data
+                param.data = alt
+                return
+        if tv_module is None:
+            from . import total_variation_cuda as tv_module
+        tv_module.total_variation_add_grad(param, g, w, w, w, dense)
+        self._update(group, param, g, state['exp_avg'], state['exp_avg_sq'], state['step'],
+                     self.per_lr if use_perlr else None)
+
     @torch.no_grad()
-    def step(self, grad_hook=None):
-        """grad_hook(param, grad): optional in-place edit of the REDUCED gradient before the update (the training
-        iteration uses it for the total-variation term, which must see the gradient summed over all ranks).  For a
-        sharded parameter the hook receives a full-shape gradient that is zero outside this rank's range."""
+    def step(self, grad_hook=None, tv_terms=None):
+        """grad_hook(param, grad): optional in-place edit of the REDUCED gradient before the update.  For a sharded
+        parameter the hook receives a full-shape gradient that is zero outside this rank's range.
+        tv_terms: optional {param: (w, dense_mode, tv_module or None)} -- the total-variation term of the training
+        iteration (run_train.py:281-287), applied to the gradient summed over all ranks (a rank-local masked TV would
+        give a voxel touched by k of N ranks only k/N of the term); for a replicated parameter in dense mode it is
+        fused with the update (see _tv_then_update)."""
         world, rank = self._world()
+        tv_terms = tv_terms or {}
         scale = (1.0 / world) if (self.average and world > 1) else None
         for group in self.param_groups:
             for param in group['params']:
@@ -98,8 +126,11 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                         state['exp_avg'] = torch.zeros_like(param, memory_format=torch.preserve_format)
                         state['exp_avg_sq'] = torch.zeros_like(param, memory_format=torch.preserve_format)
                     state['step'] += 1
-                    self._update(group, param, g, state['exp_avg'], state['exp_avg_sq'], state['step'],
-                                 self.per_lr if use_perlr else None)
+                    if param in tv_terms:
+                        self._tv_then_update(group, param, g, state, tv_terms[param], use_perlr)
+                    else:
+                        self._update(group, param, g, state['exp_avg'], state['exp_avg_sq'], state['step'],
+                                     self.per_lr if use_perlr else None)
                     continue
                 per = self.shard_len(n, world)
                 total = per * world
@@ -122,10 +153,16 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                 dist.reduce_scatter_tensor(g_shard, flat_g, group=self.group)
                 if scale is not None:
                     g_shard.mul_(scale)
-                if grad_hook is not None:
+                if grad_hook is not None or param in tv_terms:
                     full_g = torch.zeros(n, dtype=g_shard.dtype, device=g_shard.device)
                     full_g[b:e] = g_shard[: e - b]
-                    grad_hook(param, full_g.view_as(param))
+                    if grad_hook is not None:
+                        grad_hook(param, full_g.view_as(param))
+                    if param in tv_terms:
+                        w, dense, tv_module = tv_terms[param]
+                        if tv_module is None:
+                            from . import total_variation_cuda as tv_module
+                        tv_module.total_variation_add_grad(param, full_g.view_as(param), w, w, w, dense)
                     g_shard[: e - b] = full_g[b:e]
                     del full_g
                 if exact:

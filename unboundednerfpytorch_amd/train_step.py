@@ -64,8 +64,16 @@ def training_loss(render_result, target, cfg_train, n_rays, near_thres=None, dis
     return loss, mse
 
 
+def _mark(timers, name):
+    """timers: optional dict name -> list of torch.cuda.Event pairs (tools/bench_train_step.py splits a step by phase)"""
+    if timers is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        timers.setdefault(name, []).append(ev)
+
+
 def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_train, global_step, render_kwargs,
-                    near_thres=None, distortion_fn=None, decay_lr=True, world_size=1):
+                    near_thres=None, distortion_fn=None, decay_lr=True, world_size=1, timers=None):
     """Forward ... optimizer.step() of one global_step (call maybe_scale_grids first).  Returns (loss, psnr).
     Data-parallel use (ShardedMaskedAdam averages the ranks' gradients): pass world_size so that the total-variation
     term, which the reference scales by 1 / len(rays_o), is scaled by the GLOBAL batch size and the sum-type nearclip
@@ -74,37 +82,37 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
     ray_id.max()+1 like the library).  TV itself runs inside optimizer.step on the
     REDUCED gradient (grad_hook), so its masked mode sees the voxels any rank touched: the data-parallel step equals
     the single-process step on the whole batch in both TV phases (tests/test_host_logic.py)."""
+    _mark(timers, "start")
     out = model(rays_o, rays_d, viewdirs, global_step=global_step, is_train=True, **render_kwargs)
+    _mark(timers, "forward")
     optimizer.zero_grad(set_to_none=True)
     n_rays = len(rays_o)
     loss, mse = training_loss(out, target, cfg_train, n_rays, near_thres, distortion_fn, world_size)
+    _mark(timers, "loss")
     loss.backward()
+    _mark(timers, "backward")
     tv_on = (global_step < _get(cfg_train, 'tv_before', 0) and global_step > _get(cfg_train, 'tv_after', 0)
              and global_step % _get(cfg_train, 'tv_every', 1) == 0)
-    hook = None
+    tv_terms = None
     if tv_on:
-        # run_train.py:281-287.  The TV term is applied to the gradient the optimizer is about to use -- through the
-        # optimizer's grad_hook, i.e. AFTER the cross-rank reduction in data-parallel runs (in a single process that is
-        # exactly "TV, then step").  weight / batch size, then the models' own scaling by world_size.max() / 128.
+        # run_train.py:281-287.  The TV term is applied to the gradient the optimizer is about to use -- inside
+        # optimizer.step, i.e. AFTER the cross-rank reduction in data-parallel runs (in a single process that is exactly
+        # "TV, then step", and in dense mode the HIP optimizer fuses the two passes).  weight / batch size, then the
+        # models' own scaling by world_size.max() / 128.
         dense = global_step < _get(cfg_train, 'tv_dense_before', 0)
         n_global = n_rays * world_size
-        terms = []
+        tv_terms = {}
         if _get(cfg_train, 'weight_tv_density', 0.0) > 0:
-            terms.append((model.density, _get(cfg_train, 'weight_tv_density') / n_global * model.world_size_density.max() / 128))
+            tv_terms[model.density.grid] = (float(_get(cfg_train, 'weight_tv_density') / n_global * model.world_size_density.max() / 128),
+                                            dense, model.density.tv_module)
         if _get(cfg_train, 'weight_tv_k0', 0.0) > 0:
-            terms.append((model.k0, _get(cfg_train, 'weight_tv_k0') / n_global * model.world_size_rgb.max() / 128))
-
-        def hook(param, grad):
-            for grid_module, w in terms:
-                if param is grid_module.grid:
-                    tv = grid_module.tv_module
-                    if tv is None:
-                        from . import total_variation_cuda as tv
-                    tv.total_variation_add_grad(param, grad, w, w, w, dense)
-    if hook is not None:
-        optimizer.step(grad_hook=hook)
+            tv_terms[model.k0.grid] = (float(_get(cfg_train, 'weight_tv_k0') / n_global * model.world_size_rgb.max() / 128),
+                                       dense, model.k0.tv_module)
+    if tv_terms:
+        optimizer.step(tv_terms=tv_terms)
     else:
         optimizer.step()
+    _mark(timers, "tv+adam")
     if decay_lr:                      # run_train.py:290-295 (the reference skips this for FourierGrid on tankstemple)
         factor = 0.1 ** (1 / (_get(cfg_train, 'lrate_decay') * 1000))
         for g in optimizer.param_groups:
