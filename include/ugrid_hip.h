@@ -262,6 +262,25 @@ int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1, const floa
 int ugrid_mlp_fp16x2_scales(const float *h_w0, const float *h_b0, const float *h_w1, int32_t k0_channels,
                             int32_t viewbase_pe, float k0_absmax, float *scales4);
 
+/* ------------------------------------------------------------------ fused training forward, stage 1 (new)
+ * Replaces the head of FourierGridModel.forward in training mode (FourierGrid_model.py:554-598): sample_ray, the
+ * density lookup on all R*S points, Raw2Alpha, the `alpha > fast_color_thres` mask and its boolean-index gathers.
+ * ugrid_train_march: one wave per ray; every sample's point / density / alpha is formed with the operation order of the
+ * composed path (torch elementwise chain of sample_ray, ugrid_grid_query, ugrid_raw2alpha) and the survivors of the
+ * threshold are compacted into the ray's slot [r*S, r*S+count[r]) of three scratch arrays ([R*S,3] f32, [R*S] f32,
+ * [R*S] i32).  host: offset_end = inclusive cumsum(count) (int64), M1 = offset_end[R-1].
+ * ugrid_train_compact: scratch -> ray-major compact outputs pts [M1,3], density [M1], ray_id / step_id [M1] i64, t [M1].
+ * scene_center3 / scene_radius3 are HOST pointers; density_grid is the canonical [P,1,X,Y,Z] parameter. */
+int ugrid_train_march(const float *density_grid, int P, int X, int Y, int Z, int freq_num, const float *rays_o,
+                      const float *rays_d, int64_t n_rays, const float *t_table, int32_t n_samples,
+                      const float *scene_center3, const float *scene_radius3, const float *xyz_min, const float *xyz_max,
+                      double bg_len, int norm_l2, float act_shift, float interval, float thres, float *scratch_pts,
+                      float *scratch_density, int32_t *scratch_step, int32_t *count, ugrid_stream_t stream);
+int ugrid_train_compact(int64_t n_rays, int32_t n_samples, const float *scratch_pts, const float *scratch_density,
+                        const int32_t *scratch_step, const int32_t *count, const int64_t *offset_end,
+                        const float *t_table, float *pts, float *density, int64_t *ray_id, int64_t *step_id, float *t,
+                        ugrid_stream_t stream);
+
 /* Tuning knobs (speed only, never results): "march_waves" 4..6. */
 int ugrid_tune(const char *key, int value);
 

@@ -178,6 +178,139 @@ __global__ void k_grid_query_backward(const float *__restrict__ grad_out, int P,
   }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Training forward, stage 1 (new entry points; replace the head of FourierGridModel.forward in training mode,
+// FourierGrid_model.py:554-598: sample_ray -> [R,S,3] points, density lookup on all R*S points, Raw2Alpha, the
+// `alpha > fast_color_thres` mask and seven boolean-index gathers with their host syncs).
+//   k_train_march   one wave per ray, lane = sample (S/64 rounds): point, contraction, P-level density on the CANONICAL
+//                   layout (the parameter being trained; same device functions and operation order as k_grid_query,
+//                   so the densities are bit-identical to the composed path), alpha exactly as k_raw2alpha forms it,
+//                   threshold, ballot + mbcnt compaction into the ray's private slot [r*S, r*S + count[r]) of a scratch
+//   k_train_compact after a cumsum of the counts: one wave per ray copies its slot to the ray-major compact outputs
+// The point arithmetic follows the torch elementwise chain of sample_ray (separate multiply / add, IEEE divisions).
+// ----------------------------------------------------------------------------------------------
+struct ug_train_args {
+  int64_t n_rays;
+  int32_t S, P, F, X, Y, Z, norm_l2;
+  float cx, cy, cz, rx, ry, rz;
+  float B, A;
+  float shift, interval, thres;
+};
+
+__global__ void __launch_bounds__(256)
+k_train_march(ug_train_args a, const float *__restrict__ grid, const float *__restrict__ rays_o,
+              const float *__restrict__ rays_d, const float *__restrict__ t_table, const float *__restrict__ xyz_min,
+              const float *__restrict__ xyz_max, float *__restrict__ s_pts, float *__restrict__ s_dens,
+              int32_t *__restrict__ s_step, int32_t *__restrict__ count) {
+  const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (ray >= a.n_rays) return;
+  const int lane = ug_lane();
+  const float ox = (rays_o[3 * ray] - a.cx) / a.rx, oy = (rays_o[3 * ray + 1] - a.cy) / a.ry, oz = (rays_o[3 * ray + 2] - a.cz) / a.rz;
+  const float rdx = rays_d[3 * ray], rdy = rays_d[3 * ray + 1], rdz = rays_d[3 * ray + 2];
+  const float dn = ug_norm3_torch(rdx, rdy, rdz);
+  const float dx = rdx / dn, dy = rdy / dn, dz = rdz / dn;
+  const float lox = xyz_min[0], loy = xyz_min[1], loz = xyz_min[2], hix = xyz_max[0], hiy = xyz_max[1], hiz = xyz_max[2];
+  const int64_t vol = (int64_t)a.X * a.Y * a.Z;
+  const int64_t slot = ray * a.S;
+  int kept = 0;   // wave-uniform
+  for (int j0 = 0; j0 < a.S; j0 += UG_WAVE) {
+    const int j = j0 + lane;
+    bool keep = false;
+    float px = 0.f, py = 0.f, pz = 0.f, dens = 0.f;
+    if (j < a.S) {
+      const float t = t_table[j];
+      px = ox + dx * t; py = oy + dy * t; pz = oz + dz * t;
+      const float nrm = a.norm_l2 ? ug_norm3_torch(px, py, pz) : fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz)));
+      if (!(nrm <= 1.0f)) {
+        const float sc = a.B - a.A / nrm;
+        px = px / nrm * sc; py = py / nrm * sc; pz = pz / nrm * sc;
+      }
+      const float ux = ug_unorm(px, lox, hix), uy = ug_unorm(py, loy, hiy), uz = ug_unorm(pz, loz, hiz);
+      for (int l = 0; l < a.P; ++l) {
+        float cx, cy, cz;
+        ug_level_coords(l, ux, uy, uz, cx, cy, cz);
+        const ug_taps tp = ug_tap_setup(a.X, a.Y, a.Z, cx, cy, cz);
+        const float *__restrict__ g = grid + (int64_t)l * vol;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (tp.off[c] >= 0) acc += g[tp.off[c]] * tp.w[c];
+        dens = (l == 0) ? acc : dens + acc;
+      }
+      if (a.F > 0) dens = dens / (float)a.P;
+      const float e = expf(dens + a.shift);
+      const float alpha = 1 - powf(1 + e, -a.interval);
+      keep = alpha > a.thres;
+    }
+    const unsigned long long m = __ballot(keep);
+    if (m != 0ull) {
+      if (keep) {
+        const int64_t idx = slot + kept + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        s_pts[3 * idx] = px; s_pts[3 * idx + 1] = py; s_pts[3 * idx + 2] = pz;
+        s_dens[idx] = dens;
+        s_step[idx] = j;
+      }
+      kept += __popcll(m);
+    }
+  }
+  if (lane == 0) count[ray] = kept;
+}
+
+__global__ void __launch_bounds__(256)
+k_train_compact(int64_t n_rays, int32_t S, const float *__restrict__ s_pts, const float *__restrict__ s_dens,
+                const int32_t *__restrict__ s_step, const int32_t *__restrict__ count, const int64_t *__restrict__ offset_end,
+                const float *__restrict__ t_table, float *__restrict__ pts, float *__restrict__ dens,
+                int64_t *__restrict__ ray_id, int64_t *__restrict__ step_id, float *__restrict__ tt) {
+  const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (ray >= n_rays) return;
+  const int lane = ug_lane();
+  const int n = count[ray];
+  const int64_t dst = offset_end[ray] - n, src = ray * (int64_t)S;
+  for (int i = lane; i < n; i += UG_WAVE) {
+    const int st = s_step[src + i];
+    pts[3 * (dst + i)] = s_pts[3 * (src + i)];
+    pts[3 * (dst + i) + 1] = s_pts[3 * (src + i) + 1];
+    pts[3 * (dst + i) + 2] = s_pts[3 * (src + i) + 2];
+    dens[dst + i] = s_dens[src + i];
+    ray_id[dst + i] = ray;
+    step_id[dst + i] = st;
+    tt[dst + i] = t_table[st];
+  }
+}
+
+extern "C" int ugrid_train_march(const float *density_grid, int P, int X, int Y, int Z, int freq_num, const float *rays_o,
+                                 const float *rays_d, int64_t n_rays, const float *t_table, int32_t n_samples,
+                                 const float *scene_center3, const float *scene_radius3, const float *xyz_min,
+                                 const float *xyz_max, double bg_len, int norm_l2, float act_shift, float interval,
+                                 float thres, float *scratch_pts, float *scratch_density, int32_t *scratch_step,
+                                 int32_t *count, ugrid_stream_t s) {
+  if (n_rays <= 0) return 0;
+  if (P != (freq_num > 0 ? 2 * freq_num + 1 : 1) || n_samples <= 0) return (int)hipErrorInvalidValue;
+  ug_train_args a;
+  a.n_rays = n_rays; a.S = n_samples; a.P = P; a.F = freq_num; a.X = X; a.Y = Y; a.Z = Z; a.norm_l2 = norm_l2;
+  a.cx = scene_center3[0]; a.cy = scene_center3[1]; a.cz = scene_center3[2];
+  a.rx = scene_radius3[0]; a.ry = scene_radius3[1]; a.rz = scene_radius3[2];
+  const double Bd = 1.0 + bg_len;
+  a.B = (float)Bd; a.A = (float)(Bd * 1.0 - 1.0);
+  a.shift = act_shift; a.interval = interval; a.thres = thres;
+  hipLaunchKernelGGL(k_train_march, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), a, density_grid, rays_o,
+                     rays_d, t_table, xyz_min, xyz_max, scratch_pts, scratch_density, scratch_step, count);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ugrid_train_compact(int64_t n_rays, int32_t n_samples, const float *scratch_pts, const float *scratch_density,
+                                   const int32_t *scratch_step, const int32_t *count, const int64_t *offset_end,
+                                   const float *t_table, float *pts, float *density, int64_t *ray_id, int64_t *step_id,
+                                   float *t, ugrid_stream_t s) {
+  if (n_rays <= 0) return 0;
+  hipLaunchKernelGGL(k_train_compact, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), n_rays, n_samples,
+                     scratch_pts, scratch_density, scratch_step, count, offset_end, t_table, pts, density, ray_id, step_id, t);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int F, bool L2, int W>
 __global__ void __launch_bounds__(256, W)
 k_march(ug_march_args a, const float *__restrict__ rays_o, const float *__restrict__ rays_d,

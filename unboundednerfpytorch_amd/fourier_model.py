@@ -38,6 +38,9 @@ class FourierGridModel(nn.Module):
         if img_emb_dim > 0 and kwargs.get('sample_num', -1) > 0:
             raise NotImplementedError("per-image appearance embeddings are not on the hot path")
         self._be = backend if backend is not None else _hip_backend()
+        # fused stage 1 of the training forward (grid.TrainMarch): on by default with the HIP ops; the composed torch-op
+        # chain below remains for injected back-ends, fast_color_thres == 0 and as the A/B reference of the tests
+        self.fused_forward = backend is None
         lo_s, hi_s = torch.Tensor(xyz_min), torch.Tensor(xyz_max)
         self.register_buffer('scene_center', (lo_s + hi_s) * 0.5)
         self.register_buffer('scene_radius', (hi_s - lo_s) * 0.5)
@@ -211,31 +214,69 @@ class FourierGridModel(nn.Module):
         pts = torch.where(inner, pts, pts / nrm * (B - A / nrm))
         return pts, inner.squeeze(-1), t
 
+    def _host_consts(self):
+        """host copies of scene_center / scene_radius / act_shift for the kernel arguments, refreshed only when the
+        buffers change (act_shift moves at the pg_scale steps): no device-to-host read per iteration"""
+        ver = (self.act_shift._version, self.scene_center._version, self.scene_radius._version, self.act_shift.data_ptr())
+        if getattr(self, '_hc_ver', None) != ver:
+            self._hc = (self.scene_center.tolist(), self.scene_radius.tolist(), float(self.act_shift))
+            self._hc_ver = ver
+        return self._hc
+
+    def sample_table(self, stepsize, device):
+        key = (float(stepsize), int(self.world_len_density), str(device))
+        cached = getattr(self, '_t_cache', None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        t = self._sample_table(stepsize).to(device)
+        self._t_cache = (key, t)
+        return t
+
+    def _sample_table(self, stepsize):
+        """the mid-point sample distances of sample_ray, [S] on `device`"""
+        n_inner = int(2 / (2 + 2 * self.bg_len) * self.world_len_density / stepsize) + 1
+        edge_in = torch.linspace(0, 1.5, n_inner + 1)
+        edge_out = 1.5 / torch.linspace(1, 1 / 128, n_inner + 1)
+        return torch.cat([(edge_in[1:] + edge_in[:-1]) * 0.5, (edge_out[1:] + edge_out[:-1]) * 0.5])
+
     def forward(self, rays_o, rays_d, viewdirs, global_step=None, is_train=False, **render_kwargs):
         assert rays_o.dim() == 2 and rays_o.shape[-1] == 3, 'Only support point queries in [N, 3] format'
         if self._fast_color_thres is not None and global_step in self._fast_color_thres:
             self.fast_color_thres = self._fast_color_thres[global_step]
         R = rays_o.shape[0]
-        pts, inner, t = self.sample_ray(rays_o, rays_d, **render_kwargs)
-        S = t.numel()
-        dev = pts.device
         interval = render_kwargs['stepsize'] * self.voxel_size_ratio_density
-        ray_id = torch.arange(R, device=dev).view(-1, 1).expand(R, S).flatten()
-        step_id = torch.arange(S, device=dev).view(1, -1).expand(R, S).flatten()
-        tt = t[None].repeat(R, 1)
-        density = self.density(pts)
-        alpha = self.activate_density(density, interval)
-        if self.fast_color_thres > 0:
-            keep = alpha > self.fast_color_thres
-            pts, inner, tt, density, alpha = pts[keep], inner[keep], tt[keep], density[keep], alpha[keep]
-            ray_id, step_id = ray_id[keep.flatten()], step_id[keep.flatten()]
+        if self.fused_forward and self.fast_color_thres > 0 and rays_o.is_cuda:
+            # stage 1 in two HIP kernels: no [R,S,3] point tensor, no [R,S] density / alpha, no boolean-index gathers
+            dev = rays_o.device
+            t = self.sample_table(render_kwargs['stepsize'], dev)
+            S = t.numel()
+            hc = self._host_consts()
+            pts, density, ray_id, step_id, tt = _grid.TrainMarch.apply(
+                self.density.grid, rays_o.contiguous(), rays_d.contiguous(), t, hc[0], hc[1], self.xyz_min, self.xyz_max,
+                self.bg_len, self.contracted_norm == 'l2', hc[2], float(interval), float(self.fast_color_thres),
+                self.fourier_freq_num)
+            alpha = self.activate_density(density, interval)
+            inner = None
+        else:
+            pts, inner, t = self.sample_ray(rays_o, rays_d, **render_kwargs)
+            S = t.numel()
+            dev = pts.device
+            ray_id = torch.arange(R, device=dev).view(-1, 1).expand(R, S).flatten()
+            step_id = torch.arange(S, device=dev).view(1, -1).expand(R, S).flatten()
+            tt = t[None].repeat(R, 1)
+            density = self.density(pts)
+            alpha = self.activate_density(density, interval)
+            if self.fast_color_thres > 0:
+                keep = alpha > self.fast_color_thres
+                pts, inner, tt, density, alpha = pts[keep], inner[keep], tt[keep], density[keep], alpha[keep]
+                ray_id, step_id = ray_id[keep.flatten()], step_id[keep.flatten()]
         weights, alphainv_last = self._be.Alphas2Weights.apply(alpha, ray_id, R)
         if self.fast_color_thres > 0:
             keep = weights > self.fast_color_thres
-            pts, inner, tt, density, alpha, weights = pts[keep], inner[keep], tt[keep], density[keep], alpha[keep], weights[keep]
+            pts, tt, density, alpha, weights = pts[keep], tt[keep], density[keep], alpha[keep], weights[keep]
             ray_id, step_id = ray_id[keep], step_id[keep]
         else:
-            pts, weights, inner = pts.reshape(-1, 3), weights.reshape(-1), inner.reshape(-1)
+            pts, weights = pts.reshape(-1, 3), weights.reshape(-1)
         k0 = self.k0(pts)
         if self.rgbnet is None:
             rgb = torch.sigmoid(k0)

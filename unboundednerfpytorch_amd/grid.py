@@ -63,6 +63,77 @@ class GridQuery(torch.autograd.Function):
         return grad_grid, None, None, None, None
 
 
+class TrainMarch(torch.autograd.Function):
+    """Fused stage 1 of the training forward (FourierGrid_model.py:554-598): rays -> the samples whose alpha exceeds
+    fast_color_thres, compacted ray-major, with their raw densities -- sample_ray, the density lookup of all R*S points,
+    Raw2Alpha, the mask and its boolean-index gathers in two kernels (ugrid_train_march / ugrid_train_compact) and ONE
+    host read (the survivor count).  Differentiable in the density grid only: the backward scatters the M1 incoming
+    density gradients with ugrid_grid_query_backward (the composed path runs that scatter over all R*S points).
+
+    forward(grid [P,1,X,Y,Z], rays_o [R,3], rays_d [R,3], t [S], scene_center, scene_radius, xyz_min, xyz_max, bg_len,
+            norm_l2, act_shift, interval, thres, freq_num) -> pts [M1,3], density [M1], ray_id [M1] i64, step_id [M1] i64,
+            t [M1]"""
+    _scratch = {}
+
+    @staticmethod
+    def forward(ctx, grid, rays_o, rays_d, t, scene_center, scene_radius, xyz_min, xyz_max, bg_len, norm_l2, act_shift,
+                interval, thres, freq_num):
+        import ctypes
+        _lib.require_cuda(("grid", grid), ("rays_o", rays_o), ("rays_d", rays_d), ("t", t), ("xyz_min", xyz_min), ("xyz_max", xyz_max))
+        _lib.require_f32(("grid", grid), ("rays_o", rays_o), ("rays_d", rays_d), ("t", t))
+        if grid.dim() != 5 or grid.shape[1] != 1:
+            raise RuntimeError("density grid must be [P,1,X,Y,Z]")
+        P, _, X, Y, Z = grid.shape
+        R, S = rays_o.shape[0], t.numel()
+        dev = grid.device
+        key = (dev, R * S)
+        sc = TrainMarch._scratch.get(key)
+        if sc is None:
+            TrainMarch._scratch.clear()          # one ray-batch shape at a time: 24 B per (ray, sample)
+            sc = (torch.empty(R * S, 3, device=dev), torch.empty(R * S, device=dev), torch.empty(R * S, dtype=torch.int32, device=dev))
+            TrainMarch._scratch[key] = sc
+        count = torch.empty(R, dtype=torch.int32, device=dev)
+        c3 = (ctypes.c_float * 3)(*[float(x) for x in scene_center])
+        r3 = (ctypes.c_float * 3)(*[float(x) for x in scene_radius])
+        F_ = max(int(freq_num), 0)
+        with torch.cuda.device(dev):
+            st = _lib.stream_of(grid)
+            _lib.check(_L.ugrid_train_march(_lib.ptr(grid), P, X, Y, Z, F_, _lib.ptr(rays_o), _lib.ptr(rays_d), R, _lib.ptr(t), S,
+                                            ctypes.cast(c3, ctypes.c_void_p), ctypes.cast(r3, ctypes.c_void_p), _lib.ptr(xyz_min),
+                                            _lib.ptr(xyz_max), float(bg_len), int(bool(norm_l2)), float(act_shift), float(interval),
+                                            float(thres), _lib.ptr(sc[0]), _lib.ptr(sc[1]), _lib.ptr(sc[2]), _lib.ptr(count), st),
+                       "train_march")
+            off = torch.cumsum(count, 0, dtype=torch.int64)
+            M1 = int(off[-1].item()) if R > 0 else 0
+            pts = torch.empty(M1, 3, device=dev)
+            dens = torch.empty(M1, device=dev)
+            ray_id = torch.empty(M1, dtype=torch.int64, device=dev)
+            step_id = torch.empty(M1, dtype=torch.int64, device=dev)
+            tt = torch.empty(M1, device=dev)
+            if M1 > 0:
+                _lib.check(_L.ugrid_train_compact(R, S, _lib.ptr(sc[0]), _lib.ptr(sc[1]), _lib.ptr(sc[2]), _lib.ptr(count),
+                                                  _lib.ptr(off), _lib.ptr(t), _lib.ptr(pts), _lib.ptr(dens), _lib.ptr(ray_id),
+                                                  _lib.ptr(step_id), _lib.ptr(tt), st), "train_compact")
+        ctx.save_for_backward(pts, xyz_min, xyz_max)
+        ctx.shape, ctx.freq_num = tuple(grid.shape), F_
+        ctx.mark_non_differentiable(pts, ray_id, step_id, tt)
+        return pts, dens, ray_id, step_id, tt
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_pts, g_dens, g_ray, g_step, g_t):
+        pts, xyz_min, xyz_max = ctx.saved_tensors
+        P, C, X, Y, Z = ctx.shape
+        grad_grid = torch.zeros(ctx.shape, dtype=torch.float32, device=pts.device)
+        if pts.shape[0] > 0:
+            g = g_dens.reshape(-1, 1).to(torch.float32).contiguous()
+            with torch.cuda.device(g.device):
+                _lib.check(_L.ugrid_grid_query_backward(_lib.ptr(g), P, C, X, Y, Z, _lib.ptr(pts), _lib.ptr(xyz_min), _lib.ptr(xyz_max),
+                                                        ctx.freq_num, pts.shape[0], _lib.ptr(grad_grid), _lib.stream_of(g)),
+                           "grid_query_backward")
+        return (grad_grid,) + (None,) * 13
+
+
 def create_grid(type, **kwargs):
     if type == 'DenseGrid':
         return FourierGrid(**kwargs)
