@@ -74,14 +74,14 @@ def _rgbnet(g, device, C, pe):
     return ws, bs
 
 
-def _state(dens, k0, ws, bs, G, F, pe):
+def _state(dens, k0, ws, bs, G, F, pe, norm="inf"):
     return {
         "density_grid": dens, "k0_grid": k0, "rgbnet_weights": ws, "rgbnet_biases": bs,
         "scene_center": torch.zeros(3), "scene_radius": torch.ones(3),
         "xyz_min": torch.Tensor([-1, -1, -1]) - 0.2, "xyz_max": torch.Tensor([1, 1, 1]) + 0.2,
         "bg_len": 0.2, "fourier_freq_num": F, "viewbase_pe": pe,
         "act_shift": float(torch.FloatTensor([math.log(1 / (1 - 1e-4) - 1)])), "voxel_size_ratio": 1.0,
-        "fast_color_thres": 1e-4, "contracted_norm": "inf", "world_len": G,
+        "fast_color_thres": 1e-4, "contracted_norm": norm, "world_len": G,
     }
 
 
@@ -98,15 +98,15 @@ def make_state(G, device, seed):
     return _state(dens, k0, ws, bs, G, F, pe)
 
 
-def make_state_surfaces(G, device, seed):
-    """S1b: the same model shape with TRAINED-LIKE statistics -- smooth fields, opaque surfaces, empty space below the
+def make_state_surfaces(G, device, seed, C=12, pe=4, norm="inf"):
+    """S1b (and, with C=3, pe=2, norm='l2', G=300, one S5 Waymo-style block): the model shape with TRAINED-LIKE statistics -- smooth fields, opaque surfaces, empty space below the
     alpha threshold.  Level 0 of the density grid carries 7x a smooth occupancy field (soft spheres, a ground slab and
     the lower half of the contracted far shell; 1.5-voxel transitions between raw density -6 and +16, so empty space
     has alpha ~3e-7 < thres and solids saturate in 1-2 samples); the six sin/cos levels and all k0 levels are low-pass
     noise.  Rays that look down end on a surface (T < 1e-3), rays that look up leave through empty sky."""
     g = torch.Generator(device=device)
     g.manual_seed(seed + 1000)
-    F, C, pe = 3, 12, 4
+    F = 3
     P = 1 + 2 * F
     lin = torch.linspace(-1.2, 1.2, G, device=device)
     X, Y, Z = torch.meshgrid(lin, lin, lin, indexing="ij")
@@ -142,7 +142,7 @@ def make_state_surfaces(G, device, seed):
     for l in range(P):
         k0[l] = smooth_noise(C, 1.0)[:, 0]
     ws, bs = _rgbnet(g, device, C, pe)
-    return _state(dens.contiguous(), k0, ws, bs, G, F, pe)
+    return _state(dens.contiguous(), k0, ws, bs, G, F, pe, norm)
 
 
 def camera(rank, device):
