@@ -566,60 +566,69 @@ __device__ __forceinline__ ug_quad_axis ug_quad_axis_of(const ug_shade_args &a, 
   return q;
 }
 
-// k0 features (mean over the P levels) of the quad's survivor at p: this lane's 3 channels.  NBL levels (x 6 loads) are
-// in flight; level l+NBL is issued right after level l's polynomial.
-template <int F, int NBL>
+// k0 features (mean over the P levels) of the quad's NR survivors (one per gather round) at p_g[r]: this lane's 3
+// channels of each.  The NR x P (round, level) cell loads form ONE software pipeline with NBL items (x 6 loads) in
+// flight -- item i+NBL is issued right after item i's polynomial -- so the rounds' memory latencies overlap instead of
+// adding up (the phase profile of the 8-wave kernel showed the two rounds back to back: 5.6 k + 4.4 k ticks).
+template <int F, int NBL, int NR>
 __device__ __forceinline__ void ug_k0_gather_quad(const float *__restrict__ k0b, const ug_shade_args &a,
-                                                  const ug_quad_axis &qa, float p_g, float (&feat)[3]) {
+                                                  const ug_quad_axis &qa, const float (&p_g)[NR], float (&feat)[NR][3]) {
   constexpr int P = 2 * F + 1;
-  const float u = ug_div_r(p_g - qa.lo, qa.ex, qa.ir) * 2.f - 1.f;
-  float lc[P];
-  lc[0] = u;
+  constexpr int NI = NR * P;           // pipeline items, level-major: item i = (level i / NR, round i % NR)
+  unsigned off[NI];
+  float tx[NI], ty[NI], tz[NI];
 #pragma unroll
-  for (int k = 0; k < F; ++k) ug_sincos((float)(1 << k) * u, &lc[2 * k + 1], &lc[2 * k + 2]);
-  unsigned off[P];
-  float tx[P], ty[P], tz[P];
+  for (int r = 0; r < NR; ++r) {
+    const float u = ug_div_r(p_g[r] - qa.lo, qa.ex, qa.ir) * 2.f - 1.f;
+    float lc[P];
+    lc[0] = u;
 #pragma unroll
-  for (int l = 0; l < P; ++l) {
-    // ug_axis_inrange with the lane's own axis length
-    const float ix = fmaf(lc[l], 0.5f, 0.5f) * qa.nm1;
-    const float cf = __builtin_amdgcn_fmed3f(floorf(ix), 0.0f, qa.nm2);
-    const float wh = ix - cf;
-    const float cxf = ug_quad_bcast<0>(cf), cyf = ug_quad_bcast<1>(cf), czf = ug_quad_bcast<2>(cf);
-    tx[l] = ug_quad_bcast<0>(wh); ty[l] = ug_quad_bcast<1>(wh); tz[l] = ug_quad_bcast<2>(wh);
-    const unsigned row = (unsigned)fmaf(cxf, (float)(a.Y - 1), cyf);     // exact in fp32: (X-1)(Y-1) < 2^24
-    const unsigned cell = __umul24(row, (unsigned)(a.Z - 1)) + (unsigned)czf;
-    off[l] = __umul24(cell, 384u) + qa.goff;                              // bytes inside the level (< 4 GiB)
+    for (int k = 0; k < F; ++k) ug_sincos((float)(1 << k) * u, &lc[2 * k + 1], &lc[2 * k + 2]);
+#pragma unroll
+    for (int l = 0; l < P; ++l) {
+      const int i = l * NR + r;
+      // ug_axis_inrange with the lane's own axis length
+      const float ix = fmaf(lc[l], 0.5f, 0.5f) * qa.nm1;
+      const float cf = __builtin_amdgcn_fmed3f(floorf(ix), 0.0f, qa.nm2);
+      const float wh = ix - cf;
+      const float cxf = ug_quad_bcast<0>(cf), cyf = ug_quad_bcast<1>(cf), czf = ug_quad_bcast<2>(cf);
+      tx[i] = ug_quad_bcast<0>(wh); ty[i] = ug_quad_bcast<1>(wh); tz[i] = ug_quad_bcast<2>(wh);
+      const unsigned row = (unsigned)fmaf(cxf, (float)(a.Y - 1), cyf);     // exact in fp32: (X-1)(Y-1) < 2^24
+      const unsigned cell = __umul24(row, (unsigned)(a.Z - 1)) + (unsigned)czf;
+      off[i] = __umul24(cell, 384u) + qa.goff;                              // bytes inside the level (< 4 GiB)
+    }
   }
   const int64_t lvl_floats = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1) * 96;
   ug_f4 v[NBL][6];
-#define UG_ISSUE_LEVEL(l_)                                                                             \
+#define UG_ISSUE_ITEM(i_)                                                                              \
   {                                                                                                    \
-    const float *lb = k0b + (int64_t)(l_) * lvl_floats;                                                \
-    v[(l_) % NBL][0] = ug_gload4<0>(off[l_], lb);   v[(l_) % NBL][1] = ug_gload4<64>(off[l_], lb);    \
-    v[(l_) % NBL][2] = ug_gload4<128>(off[l_], lb); v[(l_) % NBL][3] = ug_gload4<192>(off[l_], lb);   \
-    v[(l_) % NBL][4] = ug_gload4<256>(off[l_], lb); v[(l_) % NBL][5] = ug_gload4<320>(off[l_], lb);   \
+    const float *lb = k0b + (int64_t)((i_) / NR) * lvl_floats;                                         \
+    v[(i_) % NBL][0] = ug_gload4<0>(off[i_], lb);   v[(i_) % NBL][1] = ug_gload4<64>(off[i_], lb);    \
+    v[(i_) % NBL][2] = ug_gload4<128>(off[i_], lb); v[(i_) % NBL][3] = ug_gload4<192>(off[i_], lb);   \
+    v[(i_) % NBL][4] = ug_gload4<256>(off[i_], lb); v[(i_) % NBL][5] = ug_gload4<320>(off[i_], lb);   \
   }
 #pragma unroll
-  for (int l = 0; l < NBL && l < P; ++l) UG_ISSUE_LEVEL(l)
+  for (int i = 0; i < NBL && i < NI; ++i) UG_ISSUE_ITEM(i)
 #pragma unroll
-  for (int l = 0; l < P; ++l) {
-    const int after = (P - 1 - l) < (NBL - 1) ? (P - 1 - l) : (NBL - 1);   // levels issued after level l
-    if (after == 0) ug_vmwait6<0>(v[l % NBL]);
-    else if (after == 1) ug_vmwait6<6>(v[l % NBL]);
-    else if (after == 2) ug_vmwait6<12>(v[l % NBL]);
-    else if (after == 3) ug_vmwait6<18>(v[l % NBL]);
-    else if (after == 4) ug_vmwait6<24>(v[l % NBL]);
-    else ug_vmwait6<30>(v[l % NBL]);
-    ug_quad_poly(v[l % NBL], tx[l], ty[l], tz[l], l == 0, feat);
-    // keep the level's math here: without the pin the scheduler hoists every later load above it (spills)
-    asm volatile("" :: "v"(feat[0]), "v"(feat[1]), "v"(feat[2]));
+  for (int i = 0; i < NI; ++i) {
+    const int after = (NI - 1 - i) < (NBL - 1) ? (NI - 1 - i) : (NBL - 1);   // items issued after item i
+    if (after == 0) ug_vmwait6<0>(v[i % NBL]);
+    else if (after == 1) ug_vmwait6<6>(v[i % NBL]);
+    else if (after == 2) ug_vmwait6<12>(v[i % NBL]);
+    else if (after == 3) ug_vmwait6<18>(v[i % NBL]);
+    else if (after == 4) ug_vmwait6<24>(v[i % NBL]);
+    else ug_vmwait6<30>(v[i % NBL]);
+    ug_quad_poly(v[i % NBL], tx[i], ty[i], tz[i], i < NR, feat[i % NR]);
+    // keep the item's math here: without the pin the scheduler hoists every later load above it (spills)
+    asm volatile("" :: "v"(feat[i % NR][0]), "v"(feat[i % NR][1]), "v"(feat[i % NR][2]));
     __builtin_amdgcn_sched_barrier(0);
-    if (l + NBL < P) UG_ISSUE_LEVEL(l + NBL)
+    if (i + NBL < NI) UG_ISSUE_ITEM(i + NBL)
   }
-#undef UG_ISSUE_LEVEL
+#undef UG_ISSUE_ITEM
 #pragma unroll
-  for (int c = 0; c < 3; ++c) feat[c] = ug_div_r(feat[c], (float)P, 1.0f / (float)P);
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) feat[r][c] = ug_div_r(feat[r][c], (float)P, 1.0f / (float)P);
 }
 
 __device__ __forceinline__ void ug_wave_lds_sync() {
@@ -933,11 +942,14 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
         // features go through the scratch ([survivor][12], conflict-free both ways) and lane (h, sv) of that round
         // picks its 6 channels.  LDS operations of a wave execute in order: write -> read -> next round's write.
         float *xp = scr;
+        float f3[2][3];
+        {
+          const float pgs[2] = {pg0, pg1};
+          ug_k0_gather_quad<F, 4, 2>(k0b, a, qa, pgs, f3);
+        }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
-          float f3[3];
-          ug_k0_gather_quad<F, 4>(k0b, a, qa, it ? pg1 : pg0, f3);
-          xp[qs * 12 + 3 * qg + 0] = f3[0]; xp[qs * 12 + 3 * qg + 1] = f3[1]; xp[qs * 12 + 3 * qg + 2] = f3[2];
+          xp[qs * 12 + 3 * qg + 0] = f3[it][0]; xp[qs * 12 + 3 * qg + 1] = f3[it][1]; xp[qs * 12 + 3 * qg + 2] = f3[it][2];
           ug_wave_lds_sync();
           const float *rp = xp + (sv & 15) * 12 + h * 6;
           const bool mine = ((sv >> 4) == it);
@@ -986,10 +998,16 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     f32x16 acc1[4], acc2[4];
     int bo = h * 64;
     asm volatile("" : "+v"(bo));  // keeps the 128 bias reads inside the pass (LICM would hoist + spill them)
+    {
+      const float4 *b1p = (const float4 *)(M.B1 + bo);     // 16-byte aligned: 16 ds_read_b128 instead of 32 ds_read2_b32
 #pragma unroll
-    for (int o = 0; o < 4; ++o)
+      for (int o = 0; o < 4; ++o)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc1[o][r] = M.B1[bo + o * 16 + r];
+        for (int q = 0; q < 4; ++q) {
+          const float4 b = b1p[o * 4 + q];
+          acc1[o][4 * q] = b.x; acc1[o][4 * q + 1] = b.y; acc1[o][4 * q + 2] = b.z; acc1[o][4 * q + 3] = b.w;
+        }
+    }
     if constexpr (!BF) {
       // exact fp32: v_mfma_f32_32x32x2_f32, B operand = one register (k = lane>>5 picks feature +0/+4)
 #pragma unroll
@@ -1006,7 +1024,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           acc1[o][r] = ug_relu(acc1[o][r]);
-          acc2[o][r] = M.B2[bo + o * 16 + r];
+          acc2[o][r] = ((const float4 *)(M.B2 + bo))[o * 4 + (r >> 2)][r & 3];
         }
 #pragma unroll
       for (int st = 0; st < 64; ++st) {
@@ -1047,7 +1065,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           acc1[o][r] = ug_relu(acc1[o][r]);
-          acc2[o][r] = M.B2[bo + o * 16 + r];
+          acc2[o][r] = ((const float4 *)(M.B2 + bo))[o * 4 + (r >> 2)][r & 3];
         }
       {
         float v[8];
@@ -1093,7 +1111,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           acc1[o][r] = ug_relu(acc1[o][r]);
-          acc2[o][r] = M.B2[bo + o * 16 + r];
+          acc2[o][r] = ((const float4 *)(M.B2 + bo))[o * 4 + (r >> 2)][r & 3];
         }
       {
         float v[8];
@@ -1116,13 +1134,22 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     // ---- layer 3 (3 outputs) on the VALU: each lane of the pair reduces its 64 features
     UG_PROF_MARK(prof, 4)
     float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+    // W3 comes from LDS 16 rows at a time, all 16 reads issued before the first use: left to itself hipcc emits
+    // read -> s_waitcnt -> 3 FMAs 64 times, one exposed LDS latency per hidden feature (phase profile: 3.3 k ticks)
 #pragma unroll
-    for (int st = 0; st < 64; ++st) {
-      const float hv = ug_relu(acc2[st >> 4][st & 15]);
-      const float4 w3 = M.W3[bo + st];
-      l0 = fmaf(w3.x, hv, l0);
-      l1 = fmaf(w3.y, hv, l1);
-      l2 = fmaf(w3.z, hv, l2);
+    for (int sb = 0; sb < 64; sb += 16) {
+      float4 w3[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) w3[i] = M.W3[bo + sb + i];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float hv = ug_relu(acc2[(sb + i) >> 4][(sb + i) & 15]);
+        l0 = fmaf(w3[i].x, hv, l0);
+        l1 = fmaf(w3[i].y, hv, l1);
+        l2 = fmaf(w3[i].z, hv, l2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     l0 = (l0 + __shfl_xor(l0, 32)) + M.b3[0];
     l1 = (l1 + __shfl_xor(l1, 32)) + M.b3[1];
@@ -1288,12 +1315,15 @@ __device__ __forceinline__ void ug_shade_tile16(const ug_shade_args &a, const fl
     // ---- k0 features: quad gather, then to the MFMA lane of (survivor, channel group)
     float x[16];
     {
-      float f3[3];
-      if (dbg & 1) { f3[0] = pg; f3[1] = pg * 0.5f; f3[2] = pg * 0.25f; }
-      else ug_k0_gather_quad<F, 2>(k0b, a, qa, pg, f3);
+      float f3[1][3];
+      if (dbg & 1) { f3[0][0] = pg; f3[0][1] = pg * 0.5f; f3[0][2] = pg * 0.25f; }
+      else {
+        const float pgs[1] = {pg};
+        ug_k0_gather_quad<F, 2, 1>(k0b, a, qa, pgs, f3);
+      }
       const int src = (4 * n + jg) << 2;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) x[c] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(f3[c])));
+      for (int c = 0; c < 3; ++c) x[c] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(f3[0][c])));
     }
     UG_PROF_MARK(prof, 1)
     if (dbg & 2) {
@@ -1354,12 +1384,19 @@ __device__ __forceinline__ void ug_shade_tile16(const ug_shade_args &a, const fl
     {
       const float4 *w3p = M.W3 + jg * 32;
 #pragma unroll
-      for (int tr = 0; tr < 32; ++tr) {
-        const float hv = ug_relu(acc2[tr >> 2][tr & 3]);
-        const float4 w3 = w3p[tr];
-        l0 = fmaf(w3.x, hv, l0);
-        l1 = fmaf(w3.y, hv, l1);
-        l2 = fmaf(w3.z, hv, l2);
+      for (int sb = 0; sb < 32; sb += 16) {
+        float4 w3[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w3[i] = w3p[sb + i];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const float hv = ug_relu(acc2[(sb + i) >> 2][(sb + i) & 3]);
+          l0 = fmaf(w3[i].x, hv, l0);
+          l1 = fmaf(w3[i].y, hv, l1);
+          l2 = fmaf(w3[i].z, hv, l2);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     l0 = l0 + __shfl_xor(l0, 16); l1 = l1 + __shfl_xor(l1, 16); l2 = l2 + __shfl_xor(l2, 16);
