@@ -566,17 +566,28 @@ __device__ __forceinline__ ug_quad_axis ug_quad_axis_of(const ug_shade_args &a, 
   return q;
 }
 
-// k0 features (mean over the P levels) of the quad's NR survivors (one per gather round) at p_g[r]: this lane's 3
-// channels of each.  The NR x P (round, level) cell loads form ONE software pipeline with NBL items (x 6 loads) in
-// flight -- item i+NBL is issued right after item i's polynomial -- so the rounds' memory latencies overlap instead of
-// adding up (the phase profile of the 8-wave kernel showed the two rounds back to back: 5.6 k + 4.4 k ticks).
 template <int F, int NBL, int NR>
-__device__ __forceinline__ void ug_k0_gather_quad(const float *__restrict__ k0b, const ug_shade_args &a,
-                                                  const ug_quad_axis &qa, const float (&p_g)[NR], float (&feat)[NR][3]) {
-  constexpr int P = 2 * F + 1;
-  constexpr int NI = NR * P;           // pipeline items, level-major: item i = (level i / NR, round i % NR)
+struct ug_gather_state {
+  static constexpr int P = 2 * F + 1, NI = NR * P;   // pipeline items, level-major: item i = (level i / NR, round i % NR)
   unsigned off[NI];
   float tx[NI], ty[NI], tz[NI];
+  ug_f4 v[NBL][6];
+};
+
+#define UG_ISSUE_ITEM(st_, i_)                                                                                     \
+  {                                                                                                                \
+    const float *lb = k0b + (int64_t)((i_) / NR) * lvl_floats;                                                     \
+    st_.v[(i_) % NBL][0] = ug_gload4<0>(st_.off[i_], lb);   st_.v[(i_) % NBL][1] = ug_gload4<64>(st_.off[i_], lb);  \
+    st_.v[(i_) % NBL][2] = ug_gload4<128>(st_.off[i_], lb); st_.v[(i_) % NBL][3] = ug_gload4<192>(st_.off[i_], lb); \
+    st_.v[(i_) % NBL][4] = ug_gload4<256>(st_.off[i_], lb); st_.v[(i_) % NBL][5] = ug_gload4<320>(st_.off[i_], lb); \
+  }
+
+// first half: cell set-up of the NR survivors and the first NBL items' loads issued (nothing waited for)
+template <int F, int NBL, int NR>
+__device__ __forceinline__ void ug_k0_gather_begin(const float *__restrict__ k0b, const ug_shade_args &a,
+                                                   const ug_quad_axis &qa, const float (&p_g)[NR],
+                                                   ug_gather_state<F, NBL, NR> &st) {
+  constexpr int P = 2 * F + 1, NI = NR * P;
 #pragma unroll
   for (int r = 0; r < NR; ++r) {
     const float u = ug_div_r(p_g[r] - qa.lo, qa.ex, qa.ir) * 2.f - 1.f;
@@ -592,43 +603,56 @@ __device__ __forceinline__ void ug_k0_gather_quad(const float *__restrict__ k0b,
       const float cf = __builtin_amdgcn_fmed3f(floorf(ix), 0.0f, qa.nm2);
       const float wh = ix - cf;
       const float cxf = ug_quad_bcast<0>(cf), cyf = ug_quad_bcast<1>(cf), czf = ug_quad_bcast<2>(cf);
-      tx[i] = ug_quad_bcast<0>(wh); ty[i] = ug_quad_bcast<1>(wh); tz[i] = ug_quad_bcast<2>(wh);
+      st.tx[i] = ug_quad_bcast<0>(wh); st.ty[i] = ug_quad_bcast<1>(wh); st.tz[i] = ug_quad_bcast<2>(wh);
       const unsigned row = (unsigned)fmaf(cxf, (float)(a.Y - 1), cyf);     // exact in fp32: (X-1)(Y-1) < 2^24
       const unsigned cell = __umul24(row, (unsigned)(a.Z - 1)) + (unsigned)czf;
-      off[i] = __umul24(cell, 384u) + qa.goff;                              // bytes inside the level (< 4 GiB)
+      st.off[i] = __umul24(cell, 384u) + qa.goff;                           // bytes inside the level (< 4 GiB)
     }
   }
   const int64_t lvl_floats = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1) * 96;
-  ug_f4 v[NBL][6];
-#define UG_ISSUE_ITEM(i_)                                                                              \
-  {                                                                                                    \
-    const float *lb = k0b + (int64_t)((i_) / NR) * lvl_floats;                                         \
-    v[(i_) % NBL][0] = ug_gload4<0>(off[i_], lb);   v[(i_) % NBL][1] = ug_gload4<64>(off[i_], lb);    \
-    v[(i_) % NBL][2] = ug_gload4<128>(off[i_], lb); v[(i_) % NBL][3] = ug_gload4<192>(off[i_], lb);   \
-    v[(i_) % NBL][4] = ug_gload4<256>(off[i_], lb); v[(i_) % NBL][5] = ug_gload4<320>(off[i_], lb);   \
-  }
+  __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int i = 0; i < NBL && i < NI; ++i) UG_ISSUE_ITEM(i)
+  for (int i = 0; i < NBL && i < NI; ++i) UG_ISSUE_ITEM(st, i)
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// second half: the NR x P (round, level) records as ONE software pipeline with NBL items (x 6 loads) in flight -- item
+// i+NBL is issued right after item i's polynomial -- so the rounds' memory latencies overlap instead of adding up.
+// (Loads the compiler issues in between only make the vmcnt waits conservative: memory operations return in order.)
+template <int F, int NBL, int NR>
+__device__ __forceinline__ void ug_k0_gather_finish(const float *__restrict__ k0b, const ug_shade_args &a,
+                                                    ug_gather_state<F, NBL, NR> &st, float (&feat)[NR][3]) {
+  constexpr int P = 2 * F + 1, NI = NR * P;
+  const int64_t lvl_floats = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1) * 96;
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int after = (NI - 1 - i) < (NBL - 1) ? (NI - 1 - i) : (NBL - 1);   // items issued after item i
-    if (after == 0) ug_vmwait6<0>(v[i % NBL]);
-    else if (after == 1) ug_vmwait6<6>(v[i % NBL]);
-    else if (after == 2) ug_vmwait6<12>(v[i % NBL]);
-    else if (after == 3) ug_vmwait6<18>(v[i % NBL]);
-    else if (after == 4) ug_vmwait6<24>(v[i % NBL]);
-    else ug_vmwait6<30>(v[i % NBL]);
-    ug_quad_poly(v[i % NBL], tx[i], ty[i], tz[i], i < NR, feat[i % NR]);
+    if (after == 0) ug_vmwait6<0>(st.v[i % NBL]);
+    else if (after == 1) ug_vmwait6<6>(st.v[i % NBL]);
+    else if (after == 2) ug_vmwait6<12>(st.v[i % NBL]);
+    else if (after == 3) ug_vmwait6<18>(st.v[i % NBL]);
+    else if (after == 4) ug_vmwait6<24>(st.v[i % NBL]);
+    else ug_vmwait6<30>(st.v[i % NBL]);
+    ug_quad_poly(st.v[i % NBL], st.tx[i], st.ty[i], st.tz[i], i < NR, feat[i % NR]);
     // keep the item's math here: without the pin the scheduler hoists every later load above it (spills)
     asm volatile("" :: "v"(feat[i % NR][0]), "v"(feat[i % NR][1]), "v"(feat[i % NR][2]));
     __builtin_amdgcn_sched_barrier(0);
-    if (i + NBL < NI) UG_ISSUE_ITEM(i + NBL)
+    if (i + NBL < NI) UG_ISSUE_ITEM(st, i + NBL)
   }
-#undef UG_ISSUE_ITEM
 #pragma unroll
   for (int r = 0; r < NR; ++r)
 #pragma unroll
     for (int c = 0; c < 3; ++c) feat[r][c] = ug_div_r(feat[r][c], (float)P, 1.0f / (float)P);
+}
+
+// k0 features (mean over the P levels) of the quad's NR survivors (one per gather round) at p_g[r]: this lane's 3
+// channels of each.
+template <int F, int NBL, int NR>
+__device__ __forceinline__ void ug_k0_gather_quad(const float *__restrict__ k0b, const ug_shade_args &a,
+                                                  const ug_quad_axis &qa, const float (&p_g)[NR], float (&feat)[NR][3]) {
+  ug_gather_state<F, NBL, NR> st;
+  ug_k0_gather_begin<F, NBL, NR>(k0b, a, qa, p_g, st);
+  ug_k0_gather_finish<F, NBL, NR>(k0b, a, st, feat);
 }
 
 __device__ __forceinline__ void ug_wave_lds_sync() {
@@ -914,6 +938,21 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     if (qs < count) pg0_n = ef[4 * qs + (qg < 2 ? qg : 2)];
     if (16 + qs < count) pg1_n = ef[4 * (16 + qs) + (qg < 2 ? qg : 2)];
   }
+  // UG_SHADE_XPASS (experiment, default OFF): start the gather of pass i+1 (cell set-up, first 2 items = 12 loads in
+  // flight) at the end of pass i so that its first memory round trip runs under the per-ray accumulation.  Measured on
+  // MI355X: the 56 set-up values + 48 load registers carried over the loop edge do not fit beside the rgbnet's
+  // accumulators -- hipcc spills 47-120 VGPRs and the kernel runs 10.2 ms instead of 4.8 ms.
+#ifndef UG_SHADE_XPASS
+#define UG_SHADE_XPASS 0
+#endif
+  constexpr int GNBL = UG_SHADE_XPASS ? 2 : 4;
+  ug_gather_state<F, GNBL, 2> gst;
+  if constexpr (QUAD && UG_SHADE_XPASS) {
+    if (count > 0) {
+      const float pgs[2] = {pg0_n, pg1_n};
+      ug_k0_gather_begin<F, GNBL, 2>(k0b, a, qa, pgs, gst);
+    }
+  }
   UG_PROF_MARK(prof, 0)
   for (int base = 0; base < count; base += 32) {
     const int e = base + sv;
@@ -943,9 +982,12 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
         // picks its 6 channels.  LDS operations of a wave execute in order: write -> read -> next round's write.
         float *xp = scr;
         float f3[2][3];
-        {
+        if constexpr (UG_SHADE_XPASS) {
+          ug_k0_gather_finish<F, GNBL, 2>(k0b, a, gst, f3);
+        } else {
           const float pgs[2] = {pg0, pg1};
-          ug_k0_gather_quad<F, 4, 2>(k0b, a, qa, pgs, f3);
+          ug_k0_gather_begin<F, GNBL, 2>(k0b, a, qa, pgs, gst);
+          ug_k0_gather_finish<F, GNBL, 2>(k0b, a, gst, f3);
         }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
@@ -1136,14 +1178,15 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     float l0 = 0.f, l1 = 0.f, l2 = 0.f;
     // W3 comes from LDS 16 rows at a time, all 16 reads issued before the first use: left to itself hipcc emits
     // read -> s_waitcnt -> 3 FMAs 64 times, one exposed LDS latency per hidden feature (phase profile: 3.3 k ticks)
+    constexpr int W3B = UG_SHADE_XPASS ? 8 : 16;   // rows per batch (the started gather holds ~100 registers meanwhile)
 #pragma unroll
-    for (int sb = 0; sb < 64; sb += 16) {
-      float4 w3[16];
+    for (int sb = 0; sb < 64; sb += W3B) {
+      float4 w3[W3B];
 #pragma unroll
-      for (int i = 0; i < 16; ++i) w3[i] = M.W3[bo + sb + i];
+      for (int i = 0; i < W3B; ++i) w3[i] = M.W3[bo + sb + i];
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
+      for (int i = 0; i < W3B; ++i) {
         const float hv = ug_relu(acc2[(sb + i) >> 4][(sb + i) & 15]);
         l0 = fmaf(w3[i].x, hv, l0);
         l1 = fmaf(w3[i].y, hv, l1);
@@ -1156,6 +1199,12 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
     // weights.unsqueeze(-1) * rgb, then a per-ray sum in sample order (segment_coo semantics)
     const float pr = en.w * ug_sigmoid(l0), pg = en.w * ug_sigmoid(l1), pb = en.w * ug_sigmoid(l2);
+    if constexpr (QUAD && UG_SHADE_XPASS) {
+      if (base + 32 < count) {      // wave-uniform
+        const float pgs[2] = {pg0_n, pg1_n};
+        ug_k0_gather_begin<F, GNBL, 2>(k0b, a, qa, pgs, gst);
+      }
+    }
     UG_PROF_MARK(prof, 5)
     {
       // per-ray sum in list (= sample) order through LDS: survivors publish their value and set their bit in the

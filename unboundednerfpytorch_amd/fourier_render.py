@@ -363,6 +363,36 @@ def state_from_reference_checkpoint(ckpt):
     }
 
 
+def pixel_grid(H, W, device, flip_x=False, flip_y=False, mode="center"):
+    """Pixel-centre coordinates (ii = column, jj = row) of a view, [H,W] each -- the first half of get_rays_of_a_view,
+    split out so that a rank of a sharded render can keep the coordinates of ITS pixels and generate only those rays."""
+    jj, ii = torch.meshgrid(torch.linspace(0, H - 1, H, device=device), torch.linspace(0, W - 1, W, device=device),
+                            indexing="ij")
+    if mode == "center":
+        ii, jj = ii + 0.5, jj + 0.5
+    elif mode != "lefttop":
+        raise NotImplementedError(mode)
+    if flip_x:
+        ii = ii.flip((1,))
+    if flip_y:
+        jj = jj.flip((0,))
+    return ii, jj
+
+
+def get_rays_of_pixels(ii, jj, K, c2w, inverse_y=False):
+    """Rays of the given pixel coordinates (any shape [...]): same arithmetic as get_rays_of_a_view, so a sharded frame
+    is bit-identical to the whole frame."""
+    K = torch.as_tensor(K, dtype=torch.float32, device=c2w.device)
+    if inverse_y:
+        dirs = torch.stack([(ii - K[0][2]) / K[0][0], (jj - K[1][2]) / K[1][1], torch.ones_like(ii)], -1)
+    else:
+        dirs = torch.stack([(ii - K[0][2]) / K[0][0], -(jj - K[1][2]) / K[1][1], -torch.ones_like(ii)], -1)
+    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
+    rays_o = c2w[:3, 3].expand(rays_d.shape)
+    viewdirs = rays_d / rays_d.norm(dim=-1, keepdim=True)
+    return rays_o.contiguous(), rays_d.contiguous(), viewdirs.contiguous()
+
+
 def get_rays_of_a_view(H, W, K, c2w, inverse_y=False, flip_x=False, flip_y=False, mode="center"):
     """Pinhole rays of one view, pixel centres (+0.5): rays_o, rays_d, viewdirs, each [H,W,3], on c2w's
     device.  Same conventions as the reference (dvgo.py:493-521,554-559; no NDC)."""
