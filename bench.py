@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--mlp-mode", type=int, default=None, help="rgbnet arithmetic: 0 fp32 MFMA, 1 bf16x3, 2 fp16x2 (default: what ugrid_pack_mlp reports usable)")
     ap.add_argument("--pipeline", type=int, default=0, help="ray chunks software-pipelined over two streams (0 = off)")
     ap.add_argument("--tune", action="append", default=[], help="key=value speed knob (ugrid_tune), repeatable")
+    ap.add_argument("--shuffle-rays", action="store_true", help="render the frame's rays in a random order (incoherent 64-ray tiles, "
+                    "like a training batch): shows what the kernels owe to neighbouring pixels sharing cells")
     ap.add_argument("--cpu-chunks", type=int, default=12, help="8192-ray chunks timed for the CPU baseline (~1 s each)")
     return ap.parse_args()
 
@@ -207,7 +209,14 @@ class FrameBench:
 
     def rays(self, c2w=None):
         ro, rd, vd = self.get_rays(self.H, self.W, self.K, self.c2w if c2w is None else c2w)
-        return ro.reshape(-1, 3), rd.reshape(-1, 3), vd.reshape(-1, 3)
+        ro, rd, vd = ro.reshape(-1, 3), rd.reshape(-1, 3), vd.reshape(-1, 3)
+        if getattr(self.args, "shuffle_rays", False):
+            if not hasattr(self, "_perm"):
+                g = torch.Generator(device=self.device)
+                g.manual_seed(1234)
+                self._perm = torch.randperm(ro.shape[0], device=self.device, generator=g)
+            ro, rd, vd = ro[self._perm], rd[self._perm], vd[self._perm]
+        return ro, rd, vd
 
     def my_shard(self, ro, rd, vd):
         if self.idx is not None:
@@ -456,6 +465,7 @@ def main():
                        "rays": R, "samples_per_ray": S, "survivors_M": M, "survivor_frac": M / float(R * S),
                        "terminated_ray_frac": term_frac, "chunks_per_frame": n_chunks,
                        "step": "ray generation + march + shade%s" % (" + all-gather of the tiles" if use_dist else ""),
+                       "ray_order": "shuffled (incoherent tiles)" if args.shuffle_rays else "image order (64-pixel row segments per wave)",
                        "parallelism": ("one frame over %d ranks, %s, 1 all-gather of [R/N,5] tiles per frame (async, overlaps "
                                        "the next frame)" % (world, "contiguous 64-aligned ray bands" if args.contiguous
                                                             else "64-ray tiles dealt round-robin")) if world > 1 else "1 GPU"},

@@ -110,6 +110,28 @@ def load():
     return lib
 
 
+class _NoGuard:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_GUARD = _NoGuard()
+
+
+def guard(device):
+    """Device guard for a launch on `device` (a torch.device or something torch.device() accepts): the reference's
+    extensions have none (render_utils.cpp launches on whatever device is current); ours must select the tensors'
+    device for multi-GPU use, but switching contexts costs several microseconds per call, so it is a no-op when that
+    device is already current -- the common case, one process per GPU."""
+    dev = device if isinstance(device, torch.device) else torch.device(device)
+    if dev.index is None or dev.index == torch.cuda.current_device():
+        return _NO_GUARD
+    return torch.cuda.device(dev)
+
+
 def check(err, what):
     if err != 0:
         raise RuntimeError("%s failed: hipError_t %d" % (what, err))

@@ -13,7 +13,7 @@ def _run(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps, m
         named.append(("perlr", perlr))
     _lib.require_cuda(*named)
     _lib.require_f32(*named)
-    with torch.cuda.device(param.device):
+    with _lib.guard(param.device):
         _lib.check(_L.ugrid_adam_upd(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
                                      _lib.ptr(perlr), param.numel(), int(step), float(beta1), float(beta2),
                                      float(lr), float(eps), mode, _lib.stream_of(param)), what)
@@ -40,7 +40,7 @@ def tv_adam_dense(param, param_out, grad, exp_avg, exp_avg_sq, wx, wy, wz, step,
     _lib.require_cuda(*named)
     _lib.require_f32(*named)
     sz_i, sz_j, sz_k = param.shape[-3:]
-    with torch.cuda.device(param.device):
+    with _lib.guard(param.device):
         rc = _L.ugrid_tv_adam_dense(_lib.ptr(param), _lib.ptr(param_out), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
                                     float(wx), float(wy), float(wz), sz_i, sz_j, sz_k, param.numel(), int(step), float(beta1),
                                     float(beta2), float(lr), float(eps), int(bool(skip_zero_grad)), _lib.stream_of(param))

@@ -87,7 +87,7 @@ class FourierGridRenderer:
         if self.thres <= 0:
             raise RuntimeError("fast_color_thres must be > 0 (the reference forward is not usable at 0 either, "
                                "FourierGrid_model.py:600-614)")
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             X, Y, Z = self.G
             self.density_bricks = torch.empty(_L.ugrid_brick_bytes(P, 1, X, Y, Z, 0) // 4, dtype=torch.float32, device=dev)
@@ -190,7 +190,7 @@ class FourierGridRenderer:
         last = torch.empty(R, dtype=torch.float32, device=dev)
         timing = render_kwargs.get("timing")  # optional list collecting ([ev0, ev1, ev2], n_rays) per launch group
         fused = self.use_fused and self.has_mlp and (self.F, self.C, self.pe) in ((3, 12, 4), (4, 12, 4))
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             if fused:
                 need = _L.ugrid_render_fused_ws_bytes(S)
@@ -294,7 +294,7 @@ class FourierGridRenderer:
         chunk for the two-kernel path).  Host sync."""
         kind, n, S_ = self._last
         out = torch.zeros(1, dtype=torch.int64, device=self.device)
-        with torch.cuda.device(self.device):
+        with _lib.guard(self.device):
             st = torch.cuda.current_stream(self.device).cuda_stream
             if kind == "fused":
                 _lib.check(_L.ugrid_render_fused_stats(_p(self._ws), _p(out), st), "render_fused_stats")

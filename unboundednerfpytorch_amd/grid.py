@@ -28,7 +28,7 @@ def grid_query(grid, xyz, xyz_min, xyz_max, freq_num):
     if pts.device != grid.device or xyz_min.device != grid.device or xyz_max.device != grid.device:
         raise RuntimeError("grid, xyz, xyz_min and xyz_max must be on the same device")
     out = torch.empty(pts.shape[0], C, dtype=torch.float32, device=grid.device)
-    with torch.cuda.device(grid.device):
+    with _lib.guard(grid.device):
         _lib.check(_L.ugrid_grid_query(_lib.ptr(grid), P, C, X, Y, Z, _lib.ptr(pts), _lib.ptr(xyz_min),
                                        _lib.ptr(xyz_max), max(int(freq_num), 0), pts.shape[0], _lib.ptr(out),
                                        _lib.stream_of(grid)), "grid_query")
@@ -56,7 +56,7 @@ class GridQuery(torch.autograd.Function):
         P, C, X, Y, Z = ctx.shape
         g = grad_out.reshape(-1, C).to(torch.float32).contiguous()
         grad_grid = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
-        with torch.cuda.device(g.device):
+        with _lib.guard(g.device):
             _lib.check(_L.ugrid_grid_query_backward(_lib.ptr(g), P, C, X, Y, Z, _lib.ptr(pts), _lib.ptr(xyz_min),
                                                     _lib.ptr(xyz_max), ctx.freq_num, pts.shape[0],
                                                     _lib.ptr(grad_grid), _lib.stream_of(g)), "grid_query_backward")
@@ -96,7 +96,7 @@ class TrainMarch(torch.autograd.Function):
         c3 = (ctypes.c_float * 3)(*[float(x) for x in scene_center])
         r3 = (ctypes.c_float * 3)(*[float(x) for x in scene_radius])
         F_ = max(int(freq_num), 0)
-        with torch.cuda.device(dev):
+        with _lib.guard(dev):
             st = _lib.stream_of(grid)
             _lib.check(_L.ugrid_train_march(_lib.ptr(grid), P, X, Y, Z, F_, _lib.ptr(rays_o), _lib.ptr(rays_d), R, _lib.ptr(t), S,
                                             ctypes.cast(c3, ctypes.c_void_p), ctypes.cast(r3, ctypes.c_void_p), _lib.ptr(xyz_min),
@@ -127,7 +127,7 @@ class TrainMarch(torch.autograd.Function):
         grad_grid = torch.zeros(ctx.shape, dtype=torch.float32, device=pts.device)
         if pts.shape[0] > 0:
             g = g_dens.reshape(-1, 1).to(torch.float32).contiguous()
-            with torch.cuda.device(g.device):
+            with _lib.guard(g.device):
                 _lib.check(_L.ugrid_grid_query_backward(_lib.ptr(g), P, C, X, Y, Z, _lib.ptr(pts), _lib.ptr(xyz_min), _lib.ptr(xyz_max),
                                                         ctx.freq_num, pts.shape[0], _lib.ptr(grad_grid), _lib.stream_of(g)),
                            "grid_query_backward")

@@ -25,7 +25,7 @@ def infer_t_minmax(rays_o, rays_d, xyz_min, xyz_max, near, far):
     n = rays_o.size(0)
     t_min = torch.empty(n, dtype=rays_o.dtype, device=rays_o.device)
     t_max = torch.empty_like(t_min)
-    with torch.cuda.device(rays_o.device):
+    with _lib.guard(rays_o.device):
         _lib.check(_L.ugrid_infer_t_minmax(_p(rays_o), _p(rays_d), _p(xyz_min), _p(xyz_max), _f(near), _f(far),
                                            n, _p(t_min), _p(t_max), _s(rays_o)), "infer_t_minmax")
     return [t_min, t_max]
@@ -36,7 +36,7 @@ def infer_n_samples(rays_d, t_min, t_max, stepdist):
     _lib.require_f32(("rays_d", rays_d), ("t_min", t_min), ("t_max", t_max))
     n = t_min.size(0)
     out = torch.empty(n, dtype=torch.int64, device=t_min.device)
-    with torch.cuda.device(t_min.device):
+    with _lib.guard(t_min.device):
         _lib.check(_L.ugrid_infer_n_samples(_p(rays_d), _p(t_min), _p(t_max), _f(stepdist), n, _p(out),
                                             _s(t_min)), "infer_n_samples")
     return out
@@ -47,7 +47,7 @@ def infer_ray_start_dir(rays_o, rays_d, t_min):
     _lib.require_f32(("rays_o", rays_o), ("rays_d", rays_d), ("t_min", t_min))
     start = torch.empty_like(rays_o)
     dirs = torch.empty_like(rays_o)
-    with torch.cuda.device(rays_o.device):
+    with _lib.guard(rays_o.device):
         _lib.check(_L.ugrid_infer_ray_start_dir(_p(rays_o), _p(rays_d), _p(t_min), rays_o.size(0), _p(start),
                                                 _p(dirs), _s(rays_o)), "infer_ray_start_dir")
     return [start, dirs]
@@ -66,7 +66,7 @@ def sample_pts_on_rays(rays_o, rays_d, xyz_min, xyz_max, near, far, stepdist):
     cumsum = torch.empty_like(n_steps)
     total_d = torch.zeros(1, dtype=torch.int64, device=dev)
     ws = torch.empty(max(1, _L.ugrid_scan_ws_bytes(n)), dtype=torch.uint8, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         st = _s(rays_o)
         _lib.check(_L.ugrid_sample_pts_on_rays_count(_p(rays_o), _p(rays_d), _p(xyz_min), _p(xyz_max), _f(near),
                                                      _f(far), _f(stepdist), n, _p(t_min), _p(t_max), _p(n_steps),
@@ -89,7 +89,7 @@ def sample_ndc_pts_on_rays(rays_o, rays_d, xyz_min, xyz_max, N_samples):
     N_samples = int(N_samples)
     pts = torch.empty(n, N_samples, 3, dtype=torch.float32, device=rays_o.device)
     mask = torch.empty(n, N_samples, dtype=torch.bool, device=rays_o.device)
-    with torch.cuda.device(rays_o.device):
+    with _lib.guard(rays_o.device):
         _lib.check(_L.ugrid_sample_ndc_pts_on_rays(_p(rays_o), _p(rays_d), _p(xyz_min), _p(xyz_max), N_samples, n,
                                                    _p(pts), _p(mask), _s(rays_o)), "sample_ndc_pts_on_rays")
     return [pts, mask]
@@ -101,7 +101,7 @@ def sample_bg_pts_on_rays(rays_o, rays_d, t_max, bg_preserve, N_samples):
     n = rays_o.size(0)
     N_samples = int(N_samples)
     pts = torch.empty(n, N_samples, 3, dtype=torch.float32, device=rays_o.device)
-    with torch.cuda.device(rays_o.device):
+    with _lib.guard(rays_o.device):
         _lib.check(_L.ugrid_sample_bg_pts_on_rays(_p(rays_o), _p(rays_d), _p(t_max), _f(bg_preserve), N_samples, n,
                                                   _p(pts), _s(rays_o)), "sample_bg_pts_on_rays")
     return pts
@@ -115,7 +115,7 @@ def maskcache_lookup(world, xyz, xyz2ijk_scale, xyz2ijk_shift):
         raise RuntimeError("world must be a 3-D bool tensor")
     n = xyz.size(0)
     out = torch.empty(n, dtype=torch.bool, device=xyz.device)
-    with torch.cuda.device(xyz.device):
+    with _lib.guard(xyz.device):
         _lib.check(_L.ugrid_maskcache_lookup(_p(world), _p(xyz), _p(xyz2ijk_scale), _p(xyz2ijk_shift),
                                              world.size(0), world.size(1), world.size(2), n, _p(out), _s(xyz)),
                    "maskcache_lookup")
@@ -127,7 +127,7 @@ def raw2alpha(density, shift, interval):
     _lib.require_f32(("density", density))
     exp_d = torch.empty_like(density)
     alpha = torch.empty_like(density)
-    with torch.cuda.device(density.device):
+    with _lib.guard(density.device):
         _lib.check(_L.ugrid_raw2alpha(_p(density), _f(shift), _f(interval), None, density.size(0), _p(exp_d),
                                       _p(alpha), _s(density)), "raw2alpha")
     return [exp_d, alpha]
@@ -138,7 +138,7 @@ def raw2alpha_nonuni(density, shift, interval):
     _lib.require_f32(("density", density), ("interval", interval))
     exp_d = torch.empty_like(density)
     alpha = torch.empty_like(density)
-    with torch.cuda.device(density.device):
+    with _lib.guard(density.device):
         _lib.check(_L.ugrid_raw2alpha(_p(density), _f(shift), 0.0, _p(interval), density.size(0), _p(exp_d),
                                       _p(alpha), _s(density)), "raw2alpha_nonuni")
     return [exp_d, alpha]
@@ -148,7 +148,7 @@ def raw2alpha_backward(exp, grad_back, interval):
     _lib.require_cuda(("exp", exp), ("grad_back", grad_back))
     _lib.require_f32(("exp", exp), ("grad_back", grad_back))
     grad = torch.empty_like(exp)
-    with torch.cuda.device(exp.device):
+    with _lib.guard(exp.device):
         _lib.check(_L.ugrid_raw2alpha_backward(_p(exp), _p(grad_back), _f(interval), None, exp.size(0), _p(grad),
                                                _s(exp)), "raw2alpha_backward")
     return grad
@@ -158,7 +158,7 @@ def raw2alpha_nonuni_backward(exp, grad_back, interval):
     _lib.require_cuda(("exp", exp), ("grad_back", grad_back), ("interval", interval))
     _lib.require_f32(("exp", exp), ("grad_back", grad_back), ("interval", interval))
     grad = torch.empty_like(exp)
-    with torch.cuda.device(exp.device):
+    with _lib.guard(exp.device):
         _lib.check(_L.ugrid_raw2alpha_backward(_p(exp), _p(grad_back), 0.0, _p(interval), exp.size(0), _p(grad),
                                                _s(exp)), "raw2alpha_nonuni_backward")
     return grad
@@ -186,7 +186,7 @@ def alpha2weight(alpha, ray_id, n_rays):
     last = torch.empty(n_rays, dtype=alpha.dtype, device=dev)
     i_start = torch.empty(n_rays, dtype=torch.int64, device=dev)
     i_end = torch.empty(n_rays, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         _lib.check(_L.ugrid_alpha2weight(_p(alpha), _p(ray_id), n, n_rays, _p(weight), _p(T), _p(last), _p(i_start),
                                          _p(i_end), _s(alpha)), "alpha2weight")
     return [weight, T, last, i_start, i_end]
@@ -199,7 +199,7 @@ def alpha2weight_backward(alpha, weight, T, alphainv_last, i_start, i_end, n_ray
     _lib.require_f32(("alpha", alpha), ("weight", weight), ("T", T), ("alphainv_last", alphainv_last),
                      ("grad_weights", grad_weights), ("grad_last", grad_last))
     grad = torch.empty_like(alpha)
-    with torch.cuda.device(alpha.device):
+    with _lib.guard(alpha.device):
         _lib.check(_L.ugrid_alpha2weight_backward(_p(alpha), _p(weight), _p(T), _p(alphainv_last), _p(i_start),
                                                   _p(i_end), alpha.size(0), int(n_rays), _p(grad_weights),
                                                   _p(grad_last), _p(grad), _s(alpha)), "alpha2weight_backward")

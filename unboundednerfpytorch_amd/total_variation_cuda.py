@@ -13,7 +13,7 @@ def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
     _lib.require_f32(("param", param), ("grad", grad))
     if param.dim() != 5 or param.shape != grad.shape:
         raise RuntimeError("param/grad must be 5-D tensors of equal shape")
-    with torch.cuda.device(param.device):
+    with _lib.guard(param.device):
         _lib.check(_L.ugrid_total_variation_add_grad(_lib.ptr(param), _lib.ptr(grad), float(wx), float(wy), float(wz),
                                                      1 if dense_mode else 0, param.size(2), param.size(3),
                                                      param.size(4), param.numel(), _lib.stream_of(param)),

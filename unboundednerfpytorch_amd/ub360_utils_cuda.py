@@ -13,7 +13,7 @@ def cumdist_thres(dist, thres):
     if dist.dim() != 2:
         raise RuntimeError("dist must be [n_rays, n_pts]")
     mask = torch.empty(dist.size(0), dist.size(1), dtype=torch.bool, device=dist.device)
-    with torch.cuda.device(dist.device):
+    with _lib.guard(dist.device):
         _lib.check(_L.ugrid_cumdist_thres(_lib.ptr(dist), float(thres), dist.size(0), dist.size(1), _lib.ptr(mask),
                                           _lib.stream_of(dist)), "cumdist_thres")
     return mask
@@ -37,7 +37,7 @@ def segment_cumsum(w, s, ray_id, n_rays=None):
     if n_rays == 0:
         return w_prefix, w_total, ws_prefix, ws_total
     scratch = torch.empty(2 * n_rays, dtype=torch.int64, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.guard(dev):
         _lib.check(_L.ugrid_segment_cumsum(_lib.ptr(w), _lib.ptr(s), _lib.ptr(ray_id), n, n_rays, _lib.ptr(w_prefix),
                                            _lib.ptr(w_total), _lib.ptr(ws_prefix), _lib.ptr(ws_total),
                                            _lib.ptr(scratch), _lib.stream_of(w)), "segment_cumsum")
