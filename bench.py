@@ -172,8 +172,8 @@ class FrameBench:
         """renderer: test hook (tests/test_host_logic.py drives the sharding / exchange logic over gloo with a stand-in
         that has the renderer's call signature); None = the HIP FourierGridRenderer."""
         from unboundednerfpytorch_amd.dist import shard_bounds, tile_assignment
-        from unboundednerfpytorch_amd.fourier_render import get_rays_of_a_view, get_rays_of_pixels, pixel_grid
-        self.get_rays, self.get_rays_px, self.pixel_grid = get_rays_of_a_view, get_rays_of_pixels, pixel_grid
+        from unboundednerfpytorch_amd.fourier_render import get_rays_of_a_view, get_rays_of_pixel_index
+        self.get_rays, self.get_rays_idx = get_rays_of_a_view, get_rays_of_pixel_index
         self.args, self.device, self.world, self.rank, self.dist = args, device, world, rank, dist
         H, W, G = args.height, args.width, args.grid
         self.H, self.W = H, W
@@ -195,14 +195,12 @@ class FrameBench:
             self.idx = None
             self.bounds = shard_bounds(self.R, world, rank)
             self.per = shard_bounds(self.R, world, 0)[1]
-        # this rank's pixel coordinates (constant over the frames): only its own rays are generated per step
-        ii, jj = self.pixel_grid(H, W, device)
-        ii, jj = ii.reshape(-1), jj.reshape(-1)
+        # this rank's flat pixel indices (constant over the frames): only its own rays are generated per step
         if self.idx is not None:
-            self.px = (ii[self.idx].contiguous(), jj[self.idx].contiguous())
+            self.px = self.idx.to(torch.int64).contiguous()
         else:
             b, e = self.bounds
-            self.px = (ii[b:e].contiguous(), jj[b:e].contiguous())
+            self.px = torch.arange(b, e, dtype=torch.int64, device=device)
         self.gathered = [torch.empty(world * self.per, 5, device=device) for _ in range(2)] if self.use_dist else None
         self.inflight = {"work": None, "n": 0, "tile": None}
         self.last_out = None
@@ -228,7 +226,7 @@ class FrameBench:
         """strong (default): this rank's shard of THE frame; weak: a whole frame of its own camera."""
         # ray generation is inside the step: the whole frame (weak / 1 GPU) or this rank's pixels of it (strong)
         if not weak and self.world > 1:
-            ro, rd, vd = self.get_rays_px(self.px[0], self.px[1], self.K, self.c2w)
+            ro, rd, vd = self.get_rays_idx(self.H, self.W, self.K, self.c2w, self.px)
         else:
             ro, rd, vd = [x.contiguous() for x in self.rays(camera(self.rank, self.device) if weak else None)]
         out = self.rend(ro, rd, vd, stepsize=self.stepsize, render_depth=True, timing=timing)

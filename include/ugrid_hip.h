@@ -262,6 +262,15 @@ int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1, const floa
 int ugrid_mlp_fp16x2_scales(const float *h_w0, const float *h_b0, const float *h_w1, int32_t k0_channels,
                             int32_t viewbase_pe, float k0_absmax, float *scales4);
 
+/* ------------------------------------------------------------------ ray generation
+ * replaces get_rays_of_a_view / get_rays (dvgo.py:493-521,554-559; twin FourierGrid_model.py:21-77), ndc=False: the ~15
+ * torch launches of the elementwise chain as one kernel.  h_K9: HOST 3x3 intrinsics (row-major), c2w: DEVICE [3,4];
+ * mode_center adds 0.5 to the pixel coordinates ('center'; 0 = 'lefttop').  pixel_index == NULL: all H*W pixels in image
+ * order (n = H*W), else n flat indices j*W+i (a rank's shard of a frame).  Outputs [n,3] each. */
+int ugrid_rays_of_a_view(int32_t H, int32_t W, const float *h_K9, const float *c2w, int inverse_y, int flip_x, int flip_y,
+                         int mode_center, const int64_t *pixel_index, int64_t n, float *rays_o, float *rays_d,
+                         float *viewdirs, ugrid_stream_t stream);
+
 /* ------------------------------------------------------------------ fused training forward, stage 1 (new)
  * Replaces the head of FourierGridModel.forward in training mode (FourierGrid_model.py:554-598): sample_ray, the
  * density lookup on all R*S points, Raw2Alpha, the `alpha > fast_color_thres` mask and its boolean-index gathers.

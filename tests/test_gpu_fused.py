@@ -223,3 +223,23 @@ def test_get_rays_of_a_view_matches_golden(fr, golden_dir):
         np.testing.assert_allclose(o.cpu().numpy(), gold[tag + "_o"], rtol=0, atol=0)
         np.testing.assert_allclose(d.cpu().numpy(), gold[tag + "_d"], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(v.cpu().numpy(), gold[tag + "_v"], rtol=1e-6, atol=1e-7)
+
+
+def test_native_ray_generation_matches_the_torch_chain(fr):
+    """ugrid_rays_of_a_view (one kernel) vs the torch elementwise chain of get_rays_of_a_view evaluated on the CPU, a
+    1080p view with all flag combinations; and a shard (flat pixel indices) equals the same rows of the whole view."""
+    H, W = 108, 192
+    K = [[160.0, 0, 96.0], [0, 161.5, 54.0], [0, 0, 1]]
+    ang = 0.7
+    c2w = torch.tensor([[np.cos(ang), 0, np.sin(ang), 0.3], [0.1, 1.0, 0, -0.2], [-np.sin(ang), 0, np.cos(ang), 0.4]], dtype=torch.float32)
+    for kw in (dict(), dict(inverse_y=True, flip_x=True), dict(flip_y=True, mode="lefttop")):
+        ref = fr.get_rays_of_a_view(H, W, K, c2w, **kw)                 # host tensors -> torch chain
+        got = fr.get_rays_of_a_view(H, W, K, c2w.cuda(), **kw)          # device pose -> HIP kernel
+        assert torch.equal(got[0].cpu(), ref[0])
+        for a, b in zip(got[1:], ref[1:]):
+            np.testing.assert_allclose(a.cpu().numpy(), b.numpy(), rtol=1e-6, atol=1e-7)
+    idx = torch.arange(3, H * W, 7, device="cuda")
+    full = fr.get_rays_of_a_view(H, W, K, c2w.cuda())
+    part = fr.get_rays_of_pixel_index(H, W, K, c2w.cuda(), idx)
+    for a, b in zip(part, full):
+        assert torch.equal(a, b.reshape(-1, 3)[idx])

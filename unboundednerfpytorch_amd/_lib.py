@@ -67,6 +67,7 @@ _SIGNATURES = {
     "ugrid_tv_adam_dense": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _L, _L, _L, _L, _I, _F, _F, _F, _F, _I, _P]),
     "ugrid_grid_query": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _L, _P, _P]),
     "ugrid_grid_query_backward": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _L, _P, _P]),
+    "ugrid_rays_of_a_view": (_I, [_c.c_int32, _c.c_int32, _P, _P, _I, _I, _I, _I, _P, _L, _P, _P, _P, _P]),
     "ugrid_train_march": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _L, _P, _c.c_int32, _P, _P, _P, _P, _c.c_double, _I, _F, _F, _F,
                                 _P, _P, _P, _P, _P]),
     "ugrid_train_compact": (_I, [_L, _c.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -46,6 +46,18 @@ __device__ __forceinline__ void ug_sincos(float x, float *s, float *c) {
   *c = __uint_as_float(__float_as_uint(cp) ^ sign);
 }
 
+// The same polynomials without the reduction, for |x| <= pi/2: there rint(x/pi) = 0 and both reduction FMAs return x
+// itself, so the result is BIT-IDENTICAL to ug_sincos at 11 instead of 19 instructions.  Used for the first Fourier
+// frequency, whose argument is the normalised grid coordinate itself (|u| <= 1 after contraction).
+__device__ __forceinline__ void ug_sincos_small(float r, float *s, float *c) {
+  const float z = r * r;
+  const float ps = fmaf(fmaf(fmaf(2.605012241474469e-06f, z, -0.00019808979413937777f), z, 0.008333049714565277f), z,
+                        -0.16666658222675323f);
+  *s = fmaf(r * z, ps, r);
+  *c = fmaf(fmaf(fmaf(fmaf(fmaf(-2.60495482962142e-07f, z, 2.4760051019256935e-05f), z,
+                                -0.0013888359535485506f), z, 0.04166663438081741f), z, -0.5f), z, 1.0f);
+}
+
 // ---- raw density -> alpha ----------------------------------------------------------------------
 // alpha = 1 - (1 + exp(d + shift))^(-interval)   (render_utils_kernel.cu:439-441)
 // evaluated as  t = RN(1+e);  L = log(t);  pw = RN(exp(-interval*L));  alpha = 1 - pw  with log1p / expm1

@@ -649,6 +649,43 @@ k_tv_adam_vec4(const float *__restrict__ param, float *__restrict__ param_out, c
   *(float4 *)(exp_avg_sq + idx) = make_float4(vv[0], vv[1], vv[2], vv[3]);
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// get_rays_of_a_view (dvgo.py:493-521,554-559) as ONE kernel: pixel-centre pinhole rays,
+// rays_d = dirs . c2w[:3,:3]^T, viewdirs = rays_d / |rays_d|, rays_o = c2w[:,3]; the torch chain it replaces is ~15
+// launches per frame.  Operation order of the reference's elementwise chain (products, then ((p0 + p1) + p2); the norm as
+// the fma chain of torch's vector_norm).  pix == nullptr: all H*W pixels in image order; else the listed flat indices.
+// ----------------------------------------------------------------------------------------------
+struct ug_cam { float fx, fy, cx, cy; int W, H, inverse_y, flip_x, flip_y, center; };
+
+__global__ void k_rays_of_a_view(ug_cam c, const float *__restrict__ c2w, const int64_t *__restrict__ pix, int64_t n,
+                                 float *__restrict__ rays_o, float *__restrict__ rays_d, float *__restrict__ viewdirs) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int64_t p = pix ? pix[t] : t;
+  int j = (int)(p / c.W), i = (int)(p - (int64_t)j * c.W);
+  if (c.flip_x) i = c.W - 1 - i;
+  if (c.flip_y) j = c.H - 1 - j;
+  float ii = (float)i, jj = (float)j;
+  if (c.center) { ii = ii + 0.5f; jj = jj + 0.5f; }
+  float dx, dy, dz;
+  if (c.inverse_y) { dx = (ii - c.cx) / c.fx; dy = (jj - c.cy) / c.fy; dz = 1.0f; }
+  else { dx = (ii - c.cx) / c.fx; dy = -(jj - c.cy) / c.fy; dz = -1.0f; }
+  float r[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const float p0 = dx * c2w[4 * a], p1 = dy * c2w[4 * a + 1], p2 = dz * c2w[4 * a + 2];
+    r[a] = (p0 + p1) + p2;
+  }
+  const float nrm = sqrtf(fmaf(r[2], r[2], fmaf(r[1], r[1], r[0] * r[0])));
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    rays_o[3 * t + a] = c2w[4 * a + 3];
+    rays_d[3 * t + a] = r[a];
+    viewdirs[3 * t + a] = r[a] / nrm;
+  }
+}
+
 // ----------------------------------------------------------------------------------------------
 // C ABI
 // ----------------------------------------------------------------------------------------------
@@ -836,6 +873,20 @@ extern "C" int ugrid_segment_cumsum(const float *w, const float *s_, const int64
     hipLaunchKernelGGL(k_segments, dim3(ug_blocks(n, 256)), dim3(256), 0, ST(s), ray_id, n, i_start, i_end);
   hipLaunchKernelGGL(k_segment_cumsum, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), w, s_, n_rays,
                      i_start, i_end, w_prefix, w_total, ws_prefix, ws_total);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ugrid_rays_of_a_view(int32_t H, int32_t W, const float *h_K9, const float *c2w, int inverse_y, int flip_x,
+                                    int flip_y, int mode_center, const int64_t *pixel_index, int64_t n, float *rays_o,
+                                    float *rays_d, float *viewdirs, ugrid_stream_t s) {
+  if (n <= 0) return 0;
+  if (H <= 0 || W <= 0) return (int)hipErrorInvalidValue;
+  ug_cam c;
+  c.fx = h_K9[0]; c.fy = h_K9[4]; c.cx = h_K9[2]; c.cy = h_K9[5];
+  c.W = W; c.H = H; c.inverse_y = inverse_y; c.flip_x = flip_x; c.flip_y = flip_y; c.center = mode_center;
+  hipLaunchKernelGGL(k_rays_of_a_view, dim3(ug_blocks(n, 256)), dim3(256), 0, ST(s), c, c2w, pixel_index, n, rays_o, rays_d,
+                     viewdirs);
   UG_LAUNCH_CHECK();
   return 0;
 }

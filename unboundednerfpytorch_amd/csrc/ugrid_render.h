@@ -281,9 +281,15 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
         sincosf(f * uy, &sy, &cy_);
         sincosf(f * uz, &sz, &cz_);
 #else
-        ug_sincos(f * ux, &sx, &cx_);
-        ug_sincos(f * uy, &sy, &cy_);
-        ug_sincos(f * uz, &sz, &cz_);
+        if (k == 0) {   // |u| <= 1 < pi/2: no range reduction needed, bit-identical (ug_sincos_small)
+          ug_sincos_small(ux, &sx, &cx_);
+          ug_sincos_small(uy, &sy, &cy_);
+          ug_sincos_small(uz, &sz, &cz_);
+        } else {
+          ug_sincos(f * ux, &sx, &cx_);
+          ug_sincos(f * uy, &sy, &cy_);
+          ug_sincos(f * uz, &sz, &cz_);
+        }
 #endif
         dens += ug_density_level(bkb + (size_t)(2 * k + 1) * lvl_bytes, sx, sy, sz, a.X, a.Y, a.Z);
         dens += ug_density_level(bkb + (size_t)(2 * k + 2) * lvl_bytes, cx_, cy_, cz_, a.X, a.Y, a.Z);
@@ -594,7 +600,10 @@ __device__ __forceinline__ void ug_k0_gather_begin(const float *__restrict__ k0b
     float lc[P];
     lc[0] = u;
 #pragma unroll
-    for (int k = 0; k < F; ++k) ug_sincos((float)(1 << k) * u, &lc[2 * k + 1], &lc[2 * k + 2]);
+    for (int k = 0; k < F; ++k) {
+      if (k == 0) ug_sincos_small(u, &lc[1], &lc[2]);       // |u| <= 1: bit-identical without the range reduction
+      else ug_sincos((float)(1 << k) * u, &lc[2 * k + 1], &lc[2 * k + 2]);
+    }
 #pragma unroll
     for (int l = 0; l < P; ++l) {
       const int i = l * NR + r;

@@ -393,9 +393,41 @@ def get_rays_of_pixels(ii, jj, K, c2w, inverse_y=False):
     return rays_o.contiguous(), rays_d.contiguous(), viewdirs.contiguous()
 
 
+def _rays_native(H, W, K, c2w, inverse_y, flip_x, flip_y, mode, pixel_index=None):
+    """One-kernel ray generation (ugrid_rays_of_a_view) for a device-resident camera pose."""
+    if mode not in ("center", "lefttop"):
+        raise NotImplementedError(mode)
+    K9 = (ctypes.c_float * 9)(*[float(x) for x in (K.reshape(-1).tolist() if torch.is_tensor(K) else
+                                                   [v for row in K for v in row])])
+    c2w = c2w[:3, :4].to(torch.float32).contiguous()
+    dev = c2w.device
+    n = H * W if pixel_index is None else int(pixel_index.numel())
+    o = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    d = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    v = torch.empty(n, 3, dtype=torch.float32, device=dev)
+    with _lib.guard(dev):
+        _lib.check(_L.ugrid_rays_of_a_view(H, W, ctypes.cast(K9, ctypes.c_void_p), _p(c2w), int(bool(inverse_y)), int(bool(flip_x)),
+                                           int(bool(flip_y)), int(mode == "center"), _p(pixel_index), n, _p(o), _p(d), _p(v),
+                                           torch.cuda.current_stream(dev).cuda_stream), "rays_of_a_view")
+    return o, d, v
+
+
+def get_rays_of_pixel_index(H, W, K, c2w, pixel_index, inverse_y=False, flip_x=False, flip_y=False, mode="center"):
+    """Rays of the listed flat pixel indices j*W+i (int64, on c2w's device) of a view: [n,3] each -- a rank's shard of a
+    frame in one launch; bit-identical to the corresponding rows of get_rays_of_a_view."""
+    if not c2w.is_cuda:
+        o, d, v = get_rays_of_a_view(H, W, K, c2w, inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y, mode=mode)
+        return o.reshape(-1, 3)[pixel_index], d.reshape(-1, 3)[pixel_index], v.reshape(-1, 3)[pixel_index]
+    return _rays_native(H, W, K, c2w, inverse_y, flip_x, flip_y, mode, pixel_index.contiguous())
+
+
 def get_rays_of_a_view(H, W, K, c2w, inverse_y=False, flip_x=False, flip_y=False, mode="center"):
     """Pinhole rays of one view, pixel centres (+0.5): rays_o, rays_d, viewdirs, each [H,W,3], on c2w's
-    device.  Same conventions as the reference (dvgo.py:493-521,554-559; no NDC)."""
+    device.  Same conventions as the reference (dvgo.py:493-521,554-559; no NDC).  Device-resident pose: one HIP
+    kernel; host tensors: the torch elementwise chain (host-side utility for tests and data preparation)."""
+    if c2w.is_cuda:
+        o, d, v = _rays_native(H, W, K, c2w, inverse_y, flip_x, flip_y, mode)
+        return o.view(H, W, 3), d.view(H, W, 3), v.view(H, W, 3)
     dev = c2w.device
     K = torch.as_tensor(K, dtype=torch.float32, device=dev)
     jj, ii = torch.meshgrid(torch.linspace(0, H - 1, H, device=dev), torch.linspace(0, W - 1, W, device=dev),
