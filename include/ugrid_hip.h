@@ -174,6 +174,26 @@ int ugrid_grid_query_backward(const float *grad_out, int P, int C, int X, int Y,
                               const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
                               float *grad_grid, ugrid_stream_t stream);
 
+/* Channel-last twins (round 2, training layout of multi-channel grids): `grid` / `grad_grid` are the SAME logical
+ * [P,C,X,Y,Z] tensors stored as [P][X][Y][Z][C] (torch.channels_last_3d): the C channels of a voxel form one 4C-byte run,
+ * so the C atomics of a corner in the scatter hit one cache line instead of C planes 4*X*Y*Z bytes apart.  Same
+ * arithmetic and order per channel as the canonical entry points. */
+int ugrid_grid_query_cl(const float *grid, int P, int C, int X, int Y, int Z, const float *xyz,
+                        const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
+                        float *out, ugrid_stream_t stream);
+int ugrid_grid_query_backward_cl(const float *grad_out, int P, int C, int X, int Y, int Z, const float *xyz,
+                                 const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
+                                 float *grad_grid, ugrid_stream_t stream);
+/* total_variation_add_grad and the fused dense TV + Adam pass on channel-last storage [planes][sz_i][sz_j][sz_k][C]
+ * (N = planes*sz_i*sz_j*sz_k*C); C % 4 == 0, N < 2^31 and 16-byte alignment required, else hipErrorNotSupported. */
+int ugrid_total_variation_add_grad_cl(const float *param, float *grad, float wx, float wy, float wz, int dense_mode,
+                                      int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t C, int64_t N,
+                                      ugrid_stream_t stream);
+int ugrid_tv_adam_dense_cl(const float *param, float *param_out, const float *grad, float *exp_avg, float *exp_avg_sq,
+                           float wx, float wy, float wz, int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t C, int64_t N,
+                           int step, float beta1, float beta2, float lr, float eps, int skip_zero_grad,
+                           ugrid_stream_t stream);
+
 /* Brick packing: canonical [P,C,X,Y,Z] -> cell-major 2x2x2 bricks, one contiguous record per
  * trilinear cell: [P*(X-1)(Y-1)(Z-1)][H halves][...] with
  *   C == 1 (density)        : H = 1, [8 entries]                          (32 B / cell)

@@ -99,3 +99,63 @@ def test_mask_grid_constructor_variants(tmp_path):
     direct = render_utils_cuda.maskcache_lookup(m.mask, pts.reshape(-1, 3).contiguous(), m.xyz2ijk_scale, m.xyz2ijk_shift)
     assert torch.equal(a.flatten(), direct)
     assert "mask.shape=[9, 8, 7]" in repr(m)
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last_3d)
+
+
+@pytest.mark.parametrize("shape,F", [((7, 12, 9, 7, 6), 3), ((1, 4, 5, 6, 8), 0), ((5, 8, 6, 6, 6), 2)])
+def test_channel_last_grid_layout_equals_canonical(shape, F):
+    """The training layout of multi-channel grids ([P][X][Y][Z][C] = torch.channels_last_3d of the same logical tensor):
+    lookup bit-identical to the canonical layout, scatter backward equal up to the atomics' summation order and produced
+    in the grid's own layout, TV gradient (dense and masked) and the fused dense TV + Adam pass bit-identical."""
+    from unboundednerfpytorch_amd import adam_upd_cuda, total_variation_cuda
+    from unboundednerfpytorch_amd.grid import GridQuery, grid_query
+    P, C, X, Y, Z = shape
+    n = int(np.prod(shape))
+    g = torch.from_numpy(synth.normal(5, n).reshape(shape)).cuda()
+    pts = torch.from_numpy(synth.uniform(6, 3000 * 3, -1.3, 1.3).reshape(3000, 3)).cuda()
+    lo, hi = torch.full((3,), -1.2).cuda(), torch.full((3,), 1.2).cuda()
+    a = grid_query(g, pts, lo, hi, F)
+    b = grid_query(_cl(g), pts, lo, hi, F)
+    assert torch.equal(a, b)
+    go = torch.from_numpy(synth.normal(7, 3000 * C).reshape(3000, C)).cuda()
+    go[::5] = 0
+    ga = g.clone().requires_grad_(True)
+    gb = _cl(g).clone(memory_format=torch.preserve_format).requires_grad_(True)
+    (GridQuery.apply(ga, pts, lo, hi, F) * go).sum().backward()
+    (GridQuery.apply(gb, pts, lo, hi, F) * go).sum().backward()
+    assert gb.grad.stride() == gb.stride() and not gb.grad.is_contiguous()
+    scale = float(ga.grad.abs().max())
+    assert float((ga.grad - gb.grad).abs().max()) <= 2e-6 * scale
+    assert torch.equal(ga.grad != 0, gb.grad != 0)
+    # TV gradient
+    for dense in (True, False):
+        gr = torch.from_numpy(synth.normal(8, n).reshape(shape)).cuda()
+        gr[gr.abs() < 0.8] = 0
+        gr_a, gr_b = gr.clone(), _cl(gr).clone(memory_format=torch.preserve_format)
+        total_variation_cuda.total_variation_add_grad(g, gr_a, 0.3, 0.3, 0.3, dense)
+        total_variation_cuda.total_variation_add_grad(_cl(g), gr_b, 0.3, 0.3, 0.3, dense)
+        assert torch.equal(gr_a, gr_b)
+    with pytest.raises(RuntimeError, match="mix the canonical and the channel-last"):
+        total_variation_cuda.total_variation_add_grad(_cl(g), gr.clone(), 0.3, 0.3, 0.3, True)
+    # fused dense TV + Adam, and the Adam kernels on channel-last storage
+    m = torch.from_numpy(synth.normal(9, n, 0, 0.1).reshape(shape)).cuda()
+    v = torch.from_numpy(synth.uniform(10, n, 0, 0.01).reshape(shape)).cuda()
+    gr = torch.from_numpy(synth.normal(11, n).reshape(shape)).cuda()
+    args = (4, 0.9, 0.99, 0.1, 1e-8)
+    pa, ma, va = g.clone(), m.clone(), v.clone()
+    gra = gr.clone()
+    total_variation_cuda.total_variation_add_grad(pa, gra, 0.2, 0.2, 0.2, True)
+    adam_upd_cuda.masked_adam_upd(pa, gra, ma, va, *args)
+    pb, mb, vb = _cl(g), _cl(m).clone(memory_format=torch.preserve_format), _cl(v).clone(memory_format=torch.preserve_format)
+    out = torch.empty_like(pb)
+    assert out.stride() == pb.stride()
+    assert adam_upd_cuda.tv_adam_dense(pb, out, _cl(gr), mb, vb, 0.2, 0.2, 0.2, *args, True)
+    assert torch.equal(out, pa) and torch.equal(mb, ma) and torch.equal(vb, va)
+    pc, mc, vc = _cl(g).clone(memory_format=torch.preserve_format), _cl(m).clone(memory_format=torch.preserve_format), _cl(v).clone(memory_format=torch.preserve_format)
+    pd, md, vd = g.clone(), m.clone(), v.clone()
+    adam_upd_cuda.masked_adam_upd(pc, _cl(gr), mc, vc, *args)
+    adam_upd_cuda.masked_adam_upd(pd, gr, md, vd, *args)
+    assert torch.equal(pc, pd) and torch.equal(vc, vd)

@@ -73,6 +73,37 @@ def test_fused_stage1_forward_equals_the_composed_chain_at_scale():
             assert torch.equal(ga != 0, gb != 0), k                            # same touched voxels (MaskedAdam keys on them)
 
 
+def test_channel_last_k0_model_equals_the_canonical_layout_model():
+    """fourier_model.FourierGridModel stores k0 channel-last on the HIP ops; with channels_last_grids=False it keeps the
+    reference's row-major parameter.  Same state dict in, same forward, gradients equal up to the atomics' order,
+    checkpoints written in the canonical layout either way."""
+    import bench_train_step as bts
+    from unboundednerfpytorch_amd.fourier_model import FourierGridModel
+    dev = torch.device("cuda", 0)
+    a = build(dev)
+    assert not a.k0.grid.is_contiguous() and a.k0.grid.is_contiguous(memory_format=torch.channels_last_3d)
+    b = FourierGridModel(xyz_min=[-1, -1, -1], xyz_max=[1, 1, 1], num_voxels_density=G ** 3, num_voxels_base_density=G ** 3,
+                         num_voxels_rgb=G ** 3, num_voxels_base_rgb=G ** 3, num_voxels_viewdir=-1, alpha_init=1e-4,
+                         fast_color_thres=1e-4, fourier_freq_num=F, rgbnet_dim=12, channels_last_grids=False).to(dev)
+    assert b.k0.grid.is_contiguous()
+    b.load_state_dict(a.state_dict())
+    o, d, v, rgb = bts.random_rays(2048, dev, seed=6)
+    outs = []
+    for m in (a, b):
+        out = m(o, d, v, global_step=1, is_train=True, stepsize=0.5, render_depth=True)
+        loss_of(out, rgb).backward()
+        outs.append(out)
+    for k in ("alphainv_last", "weights", "raw_rgb"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    for k in ("rgb_marched", "depth"):          # index_add_ over the ray segments: atomic order
+        assert torch.allclose(outs[0][k], outs[1][k], rtol=0, atol=2e-6), k
+    ga, gb = a.k0.grid.grad, b.k0.grid.grad
+    assert ga.stride() == a.k0.grid.stride() and gb.is_contiguous()
+    assert float((ga - gb).abs().max()) <= 2e-3 * float(gb.abs().max()) and torch.equal(ga != 0, gb != 0)
+    from unboundednerfpytorch_amd.train_utils import _canonical
+    assert all(t.is_contiguous() for t in _canonical(a.state_dict()).values())
+
+
 def test_training_step_at_scale_matches_the_oracle_backend():
     import bench_train_step as bts
     from types import SimpleNamespace

@@ -25,12 +25,12 @@ TRUCK_CFG = dict(  # fine_train of truck_single.py (+ default.py)
     pg_scale=[])
 
 
-def make_model(G, F, device, fused):
+def make_model(G, F, device, fused, channels_last=True):
     import bench
     from unboundednerfpytorch_amd.fourier_model import FourierGridModel
     m = FourierGridModel(xyz_min=[-1, -1, -1], xyz_max=[1, 1, 1], num_voxels_density=G ** 3, num_voxels_base_density=G ** 3,
                          num_voxels_rgb=G ** 3, num_voxels_base_rgb=G ** 3, num_voxels_viewdir=-1, alpha_init=1e-4,
-                         fast_color_thres=1e-4, fourier_freq_num=F, rgbnet_dim=12).to(device)
+                         fast_color_thres=1e-4, fourier_freq_num=F, rgbnet_dim=12, channels_last_grids=bool(channels_last)).to(device)
     if hasattr(m, "fused_forward"):
         m.fused_forward = bool(fused)
     # trained-like fields (bench.make_state_surfaces is the F = 3 version of the same recipe)
@@ -70,11 +70,12 @@ def main():
     ap.add_argument("--freq", type=int, default=4)
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--channels-last", type=int, default=1, help="k0 stored [P][X][Y][Z][C] (the training layout) or row-major")
     args = ap.parse_args()
     from unboundednerfpytorch_amd import train_step as ts
     from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
     dev = torch.device("cuda", 0)
-    model = make_model(args.grid, args.freq, dev, args.fused)
+    model = make_model(args.grid, args.freq, dev, args.fused, args.channels_last)
     opt = create_optimizer_or_freeze_model(model, TRUCK_CFG, global_step=0)
     rk = dict(stepsize=0.5, rand_bkgd=True)
     timers = None
@@ -100,6 +101,7 @@ def main():
     res = {"workload": "S3: truck_single-shaped train step, P=%d, G=%d^3, C=12, %d random rays x S=%d, stepsize 0.5, dense TV + masked Adam"
                        % (1 + 2 * args.freq, args.grid, args.rays, S),
            "fused_forward": bool(getattr(model, "fused_forward", False)),
+           "k0_channels_last": not model.k0.grid.is_contiguous(),
            "ms_per_step": total, "phases_ms": ms, "steps": args.steps, "survivors_M": M, "samples": args.rays * S,
            "rays_per_sec": args.rays / (total * 1e-3), "k0_voxels": n_k0,
            "k0_streaming_floor_ms": {"note": "compulsory HBM passes over the 3.46 GB k0-sized arrays per step at 6.3 TB/s achievable: "

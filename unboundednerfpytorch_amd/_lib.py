@@ -71,6 +71,10 @@ _SIGNATURES = {
     "ugrid_train_march": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _L, _P, _c.c_int32, _P, _P, _P, _P, _c.c_double, _I, _F, _F, _F,
                                 _P, _P, _P, _P, _P]),
     "ugrid_train_compact": (_I, [_L, _c.c_int32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ugrid_grid_query_cl": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _L, _P, _P]),
+    "ugrid_grid_query_backward_cl": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _L, _P, _P]),
+    "ugrid_total_variation_add_grad_cl": (_I, [_P, _P, _F, _F, _F, _I, _L, _L, _L, _L, _L, _P]),
+    "ugrid_tv_adam_dense_cl": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _L, _L, _L, _L, _L, _I, _F, _F, _F, _F, _I, _P]),
     "ugrid_brick_bytes": (_L, [_I, _I, _I, _I, _I, _I]),
     "ugrid_pack_bricks": (_I, [_P, _I, _I, _I, _I, _I, _I, _P, _P]),
     "ugrid_render_ws_bytes": (_L, [_L, _c.c_int32]),
@@ -155,6 +159,32 @@ def require_cuda(*named):
             raise RuntimeError("%s must be a CUDA tensor" % name)
         if not t.is_contiguous():
             raise RuntimeError("%s must be contiguous" % name)
+
+
+def is_channels_last(t):
+    """A 5-D [P,C,X,Y,Z] tensor stored as [P][X][Y][Z][C] (torch.channels_last_3d) -- the training layout of
+    multi-channel grids (C > 1; with C == 1 the two layouts coincide and the tensor counts as canonical)."""
+    return t.dim() == 5 and t.shape[1] > 1 and not t.is_contiguous() and t.is_contiguous(memory_format=torch.channels_last_3d)
+
+
+def require_cuda_grid(*named):
+    """CHECK_INPUT for voxel-grid tensors: device-resident and dense in the canonical OR the channel-last layout.
+    Returns True when they are channel-last (all of them must then be)."""
+    cl = [is_channels_last(t) for _, t in named]
+    for (name, t), c in zip(named, cl):
+        if not t.is_cuda:
+            raise RuntimeError("%s must be a CUDA tensor" % name)
+        if not (c or t.is_contiguous()):
+            raise RuntimeError("%s must be contiguous" % name)
+    if any(cl) and not all(cl):
+        raise RuntimeError("grid tensors %s mix the canonical and the channel-last layout" % ", ".join(n for n, _ in named))
+    return all(cl) and len(cl) > 0
+
+
+def empty_like_grid(shape, channels_last, device, zero=False):
+    fmt = torch.channels_last_3d if channels_last else torch.contiguous_format
+    t = torch.empty(tuple(shape), dtype=torch.float32, device=device, memory_format=fmt)
+    return t.zero_() if zero else t
 
 
 def require_f32(*named):

@@ -11,7 +11,9 @@ def _run(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps, m
     named = [("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)]
     if perlr is not None:
         named.append(("perlr", perlr))
-    _lib.require_cuda(*named)
+    # elementwise over the storage: any dense layout works as long as all operands share it (canonical, or the
+    # channel-last training layout of grid.FourierGrid)
+    _lib.require_cuda_grid(*named) if param.dim() == 5 else _lib.require_cuda(*named)
     _lib.require_f32(*named)
     with _lib.guard(param.device):
         _lib.check(_L.ugrid_adam_upd(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
@@ -37,9 +39,19 @@ def tv_adam_dense(param, param_out, grad, exp_avg, exp_avg_sq, wx, wy, wz, step,
     `param_out`; `grad` is left untouched.  Returns False when the shape cannot take the fused path (the caller then
     runs the two reference calls), True otherwise."""
     named = [("param", param), ("param_out", param_out), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)]
-    _lib.require_cuda(*named)
+    cl = _lib.require_cuda_grid(*named) if param.dim() == 5 else (_lib.require_cuda(*named) or False)
     _lib.require_f32(*named)
     sz_i, sz_j, sz_k = param.shape[-3:]
+    if cl:
+        with _lib.guard(param.device):
+            rc = _L.ugrid_tv_adam_dense_cl(_lib.ptr(param), _lib.ptr(param_out), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
+                                           float(wx), float(wy), float(wz), sz_i, sz_j, sz_k, param.shape[1], param.numel(), int(step),
+                                           float(beta1), float(beta2), float(lr), float(eps), int(bool(skip_zero_grad)),
+                                           _lib.stream_of(param))
+        if rc == 801:
+            return False
+        _lib.check(rc, "tv_adam_dense")
+        return True
     with _lib.guard(param.device):
         rc = _L.ugrid_tv_adam_dense(_lib.ptr(param), _lib.ptr(param_out), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
                                     float(wx), float(wy), float(wz), sz_i, sz_j, sz_k, param.numel(), int(step), float(beta1),

@@ -121,7 +121,11 @@ __device__ __forceinline__ void ug_level_coords(int l, float ux, float uy, float
 }
 
 // forward: 1 lane per point; per level the taps are set up once and reused by every channel; the per-channel sums
-// over levels build up in the output row itself (level 0 first, like the reference's mean over the level axis)
+// over levels build up in the output row itself (level 0 first, like the reference's mean over the level axis).
+// CL = channel-last storage [P][X][Y][Z][C] (torch channels_last_3d of the same logical [P,C,X,Y,Z] tensor: the C
+// channels of a voxel are one contiguous run -- the training layout of multi-channel grids, section 4.4 of DESIGN.md);
+// the arithmetic and its order are the same in both layouts.
+template <bool CL>
 __global__ void k_grid_query(const float *__restrict__ grid, int P, int C, int X, int Y, int Z,
                              const float *__restrict__ xyz, const float *__restrict__ xyz_min,
                              const float *__restrict__ xyz_max, int F, int64_t n, float *__restrict__ out) {
@@ -137,11 +141,12 @@ __global__ void k_grid_query(const float *__restrict__ grid, int P, int C, int X
     ug_level_coords(l, ux, uy, uz, cx, cy, cz);
     const ug_taps t = ug_tap_setup(X, Y, Z, cx, cy, cz);
     for (int ch = 0; ch < C; ++ch) {
-      const float *__restrict__ g = grid + ((int64_t)l * C + ch) * vol;
+      const float *__restrict__ g = CL ? grid + (int64_t)l * vol * C + ch : grid + ((int64_t)l * C + ch) * vol;
+      const int64_t vs = CL ? C : 1;
       float acc = 0.f;
 #pragma unroll
       for (int c = 0; c < 8; ++c)
-        if (t.off[c] >= 0) acc += g[t.off[c]] * t.w[c];
+        if (t.off[c] >= 0) acc += g[t.off[c] * vs] * t.w[c];
       row[ch] = (l == 0) ? acc : row[ch] + acc;
     }
   }
@@ -151,12 +156,19 @@ __global__ void k_grid_query(const float *__restrict__ grid, int P, int C, int X
 
 // backward w.r.t. the grid: 1 lane per (point, level); grad_grid[l, ch, corner] += w * grad_out[p, ch] / P with
 // hardware fp32 atomics (global_atomic_add_f32).  Like torch's grid_sample backward the accumulation order is
-// not fixed, so sums agree to rounding, not bit for bit.
+// not fixed, so sums agree to rounding, not bit for bit.  Canonical layout: the C atomics of a corner land in C
+// different planes (32 MB apart at G = 200) -- every atomic its own 128-byte line; channel-last: one 4C-byte run.
+template <bool CL>
 __global__ void k_grid_query_backward(const float *__restrict__ grad_out, int P, int C, int X, int Y, int Z,
                                       const float *__restrict__ xyz, const float *__restrict__ xyz_min,
                                       const float *__restrict__ xyz_max, int F, int64_t n,
                                       float *__restrict__ grad_grid) {
-  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // canonical layout: one lane per (point, level), channels in a loop (each channel is its own volume).
+  // channel-last layout: one lane per (point, level, channel), channel fastest -- the C lanes of one (point, level) hit
+  // C consecutive floats of one voxel record, so each atomic instruction touches ~64/C records instead of 64 lines.
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t q = CL ? tid / C : tid;
+  const int chl = CL ? (int)(tid - q * C) : 0;
   if (q >= n * P) return;
   const int64_t p = q / P;
   const int l = (int)(q - p * P);
@@ -167,6 +179,16 @@ __global__ void k_grid_query_backward(const float *__restrict__ grad_out, int P,
   ug_level_coords(l, ux, uy, uz, cx, cy, cz);
   const ug_taps t = ug_tap_setup(X, Y, Z, cx, cy, cz);
   const int64_t vol = (int64_t)X * Y * Z;
+  if (CL) {
+    float g = grad_out[p * C + chl];
+    if (F > 0) g = g / (float)P;
+    if (g == 0.f) return;     // exact zeros stay exact zeros in the grid gradient (MaskedAdam keys on them)
+    float *__restrict__ gl = grad_grid + (int64_t)l * vol * C + chl;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (t.off[c] >= 0) unsafeAtomicAdd(gl + t.off[c] * C, g * t.w[c]);
+    return;
+  }
   for (int ch = 0; ch < C; ++ch) {
     float g = grad_out[p * C + ch];
     if (F > 0) g = g / (float)P;
@@ -177,7 +199,6 @@ __global__ void k_grid_query_backward(const float *__restrict__ grad_out, int P,
       if (t.off[c] >= 0) unsafeAtomicAdd(gg + t.off[c], g * t.w[c]);
   }
 }
-
 
 // ----------------------------------------------------------------------------------------------
 // Training forward, stage 1 (new entry points; replace the head of FourierGridModel.forward in training mode,
@@ -335,13 +356,43 @@ extern "C" int64_t ugrid_render_ws_bytes(int64_t n_rays, int32_t S) {
   return 256 + ug_align256(n_tiles * 4) + ug_align256(n_tiles * cap * 16) + ug_align256(n_tiles * cap);
 }
 
+static int ug_grid_query_any(bool cl, const float *grid, int P, int C, int X, int Y, int Z, const float *xyz,
+                             const float *xyz_min, const float *xyz_max, int freq_num, int64_t n, float *out, hipStream_t st) {
+  if (n <= 0) return 0;
+  if (P != (freq_num > 0 ? 2 * freq_num + 1 : 1)) return (int)hipErrorInvalidValue;
+  if (cl)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query<true>), dim3(ug_blocks(n, 256)), dim3(256), 0, st, grid, P, C, X, Y, Z, xyz,
+                       xyz_min, xyz_max, freq_num, n, out);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query<false>), dim3(ug_blocks(n, 256)), dim3(256), 0, st, grid, P, C, X, Y, Z, xyz,
+                       xyz_min, xyz_max, freq_num, n, out);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int ugrid_grid_query(const float *grid, int P, int C, int X, int Y, int Z, const float *xyz,
                                 const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
                                 float *out, ugrid_stream_t s) {
+  return ug_grid_query_any(false, grid, P, C, X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, out, ST(s));
+}
+
+extern "C" int ugrid_grid_query_cl(const float *grid, int P, int C, int X, int Y, int Z, const float *xyz,
+                                   const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
+                                   float *out, ugrid_stream_t s) {
+  return ug_grid_query_any(true, grid, P, C, X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, out, ST(s));
+}
+
+static int ug_grid_query_backward_any(bool cl, const float *grad_out, int P, int C, int X, int Y, int Z, const float *xyz,
+                                      const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
+                                      float *grad_grid, hipStream_t st) {
   if (n <= 0) return 0;
   if (P != (freq_num > 0 ? 2 * freq_num + 1 : 1)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_grid_query, dim3(ug_blocks(n, 256)), dim3(256), 0, ST(s), grid, P, C, X, Y, Z, xyz,
-                     xyz_min, xyz_max, freq_num, n, out);
+  if (cl)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query_backward<true>), dim3(ug_blocks(n * P * C, 256)), dim3(256), 0, st, grad_out, P, C,
+                       X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query_backward<false>), dim3(ug_blocks(n * P, 256)), dim3(256), 0, st, grad_out, P, C,
+                       X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid);
   UG_LAUNCH_CHECK();
   return 0;
 }
@@ -349,12 +400,13 @@ extern "C" int ugrid_grid_query(const float *grid, int P, int C, int X, int Y, i
 extern "C" int ugrid_grid_query_backward(const float *grad_out, int P, int C, int X, int Y, int Z, const float *xyz,
                                          const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
                                          float *grad_grid, ugrid_stream_t s) {
-  if (n <= 0) return 0;
-  if (P != (freq_num > 0 ? 2 * freq_num + 1 : 1)) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_grid_query_backward, dim3(ug_blocks(n * P, 256)), dim3(256), 0, ST(s), grad_out, P, C, X, Y,
-                     Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid);
-  UG_LAUNCH_CHECK();
-  return 0;
+  return ug_grid_query_backward_any(false, grad_out, P, C, X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid, ST(s));
+}
+
+extern "C" int ugrid_grid_query_backward_cl(const float *grad_out, int P, int C, int X, int Y, int Z, const float *xyz,
+                                            const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
+                                            float *grad_grid, ugrid_stream_t s) {
+  return ug_grid_query_backward_any(true, grad_out, P, C, X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid, ST(s));
 }
 
 static inline int ug_brick_ch(int C, int *H) {

@@ -686,6 +686,72 @@ __global__ void k_rays_of_a_view(ug_cam c, const float *__restrict__ c2w, const 
   }
 }
 
+
+// ----------------------------------------------------------------------------------------------
+// Channel-last ([P][X][Y][Z][C], torch channels_last_3d) variants of the TV gradient and of the fused dense TV + Adam
+// pass: one lane = 4 channels of a voxel (C % 4 == 0), neighbours of the SAME channels at +-C (k), +-Z*C (j), +-Y*Z*C
+// (i).  Per element the expression is the canonical kernels' (six sequential adds, the wz-for-x quirk), so the results
+// equal the canonical-layout results element for element.  ADAM: 0 = TV only (grad updated in place), 1 = fused with
+// masked Adam, 2 = fused with dense Adam (param_out written, grad untouched).
+// ----------------------------------------------------------------------------------------------
+template <bool DENSE, int ADAM>
+__global__ void __launch_bounds__(256)
+k_tv_cl_vec4(const float *__restrict__ param, float *__restrict__ param_out, float *__restrict__ grad,
+             float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, float wy, float wz, int sz_i, int sz_j,
+             int sz_k, int C, unsigned n4, float step_size, float beta1, float beta2, float eps) {
+  const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= n4) return;
+  const unsigned idx = q * 4u;
+  const float4 g0 = *(const float4 *)(grad + idx);
+  if (!DENSE && g0.x == 0.f && g0.y == 0.f && g0.z == 0.f && g0.w == 0.f) return;
+  const unsigned c4 = (unsigned)C >> 2;
+  const unsigned vox = q / c4;                                  // (plane * sz_i + i) * sz_j * sz_k + j * sz_k + k
+  const unsigned k = vox % (unsigned)sz_k, j = (vox / (unsigned)sz_k) % (unsigned)sz_j,
+                 i = (vox / ((unsigned)sz_k * (unsigned)sz_j)) % (unsigned)sz_i;
+  const unsigned sk = (unsigned)C, sj = (unsigned)sz_k * sk, si = (unsigned)sz_j * sj;
+  const float4 p = *(const float4 *)(param + idx);
+  float4 nk0 = p, nk1 = p, nj0 = p, nj1 = p, ni0 = p, ni1 = p;
+  if (k != 0) nk0 = *(const float4 *)(param + idx - sk);
+  if (k != (unsigned)sz_k - 1) nk1 = *(const float4 *)(param + idx + sk);
+  if (j != 0) nj0 = *(const float4 *)(param + idx - sj);
+  if (j != (unsigned)sz_j - 1) nj1 = *(const float4 *)(param + idx + sj);
+  if (i != 0) ni0 = *(const float4 *)(param + idx - si);
+  if (i != (unsigned)sz_i - 1) ni1 = *(const float4 *)(param + idx + si);
+  float pv[4] = {p.x, p.y, p.z, p.w};
+  const float pold[4] = {p.x, p.y, p.z, p.w}, gv[4] = {g0.x, g0.y, g0.z, g0.w};
+  const float k0[4] = {nk0.x, nk0.y, nk0.z, nk0.w}, k1[4] = {nk1.x, nk1.y, nk1.z, nk1.w};
+  const float a0[4] = {nj0.x, nj0.y, nj0.z, nj0.w}, a1[4] = {nj1.x, nj1.y, nj1.z, nj1.w};
+  const float b0[4] = {ni0.x, ni0.y, ni0.z, ni0.w}, b1[4] = {ni1.x, ni1.y, ni1.z, ni1.w};
+  float mv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (ADAM) {
+    const float4 m4 = *(const float4 *)(exp_avg + idx), v4 = *(const float4 *)(exp_avg_sq + idx);
+    mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
+    vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
+  }
+  float out[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float g = 0;
+    g += (k == 0 ? 0.f : wz * ug_clamp1(pold[e] - k0[e]));
+    g += (k == (unsigned)sz_k - 1 ? 0.f : wz * ug_clamp1(pold[e] - k1[e]));
+    g += (j == 0 ? 0.f : wy * ug_clamp1(pold[e] - a0[e]));
+    g += (j == (unsigned)sz_j - 1 ? 0.f : wy * ug_clamp1(pold[e] - a1[e]));
+    g += (i == 0 ? 0.f : wz * ug_clamp1(pold[e] - b0[e]));
+    g += (i == (unsigned)sz_i - 1 ? 0.f : wz * ug_clamp1(pold[e] - b1[e]));
+    out[e] = (DENSE || gv[e] != 0.f) ? gv[e] + g : gv[e];
+    if (ADAM) {
+      if (ADAM == 2 || out[e] != 0.f) ug_adam_one<0>(pv[e], out[e], mv[e], vv[e], 1.f, step_size, beta1, beta2, eps);
+    }
+  }
+  if (ADAM) {
+    *(float4 *)(param_out + idx) = make_float4(pv[0], pv[1], pv[2], pv[3]);
+    *(float4 *)(exp_avg + idx) = make_float4(mv[0], mv[1], mv[2], mv[3]);
+    *(float4 *)(exp_avg_sq + idx) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+  } else {
+    *(float4 *)(grad + idx) = make_float4(out[0], out[1], out[2], out[3]);
+  }
+}
+
 // ----------------------------------------------------------------------------------------------
 // C ABI
 // ----------------------------------------------------------------------------------------------
@@ -873,6 +939,50 @@ extern "C" int ugrid_segment_cumsum(const float *w, const float *s_, const int64
     hipLaunchKernelGGL(k_segments, dim3(ug_blocks(n, 256)), dim3(256), 0, ST(s), ray_id, n, i_start, i_end);
   hipLaunchKernelGGL(k_segment_cumsum, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), w, s_, n_rays,
                      i_start, i_end, w_prefix, w_total, ws_prefix, ws_total);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+// channel-last total_variation_add_grad: param / grad are [planes][sz_i][sz_j][sz_k][C] (C % 4 == 0, N < 2^31, 16-byte aligned)
+extern "C" int ugrid_total_variation_add_grad_cl(const float *param, float *grad, float wx, float wy, float wz, int dense_mode,
+                                                 int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t C, int64_t N,
+                                                 ugrid_stream_t s) {
+  if (N <= 0) return 0;
+  (void)wx;
+  if (C % 4 != 0 || N >= ((int64_t)1 << 31) || ((((uintptr_t)param) | ((uintptr_t)grad)) & 15) != 0)
+    return (int)hipErrorNotSupported;
+  wy /= 6;
+  wz /= 6;
+  const unsigned n4 = (unsigned)(N / 4);
+  if (dense_mode)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 0>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, nullptr, grad,
+                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<false, 0>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, nullptr, grad,
+                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ugrid_tv_adam_dense_cl(const float *param, float *param_out, const float *grad, float *exp_avg,
+                                      float *exp_avg_sq, float wx, float wy, float wz, int64_t sz_i, int64_t sz_j,
+                                      int64_t sz_k, int64_t C, int64_t N, int step, float beta1, float beta2, float lr,
+                                      float eps, int skip_zero_grad, ugrid_stream_t s) {
+  if (N <= 0) return 0;
+  (void)wx;
+  const uintptr_t al = (uintptr_t)param | (uintptr_t)param_out | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq;
+  if (C % 4 != 0 || N >= ((int64_t)1 << 31) || (al & 15) != 0 || param == param_out) return (int)hipErrorNotSupported;
+  wy /= 6;
+  wz /= 6;
+  const float step_size = lr * sqrtf(1 - powf(beta2, (float)step)) / (1 - powf(beta1, (float)step));
+  const unsigned n4 = (unsigned)(N / 4);
+  float *g = const_cast<float *>(grad);   // ADAM != 0 never writes the gradient
+  if (skip_zero_grad)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 1>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, param_out, g,
+                       exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, step_size, beta1, beta2, eps);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 2>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, param_out, g,
+                       exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, step_size, beta1, beta2, eps);
   UG_LAUNCH_CHECK();
   return 0;
 }

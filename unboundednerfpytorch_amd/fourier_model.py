@@ -41,6 +41,7 @@ class FourierGridModel(nn.Module):
         # fused stage 1 of the training forward (grid.TrainMarch): on by default with the HIP ops; the composed torch-op
         # chain below remains for injected back-ends, fast_color_thres == 0 and as the A/B reference of the tests
         self.fused_forward = backend is None
+        self.channels_last_grids = backend is None and kwargs.get('channels_last_grids', True)
         lo_s, hi_s = torch.Tensor(xyz_min), torch.Tensor(xyz_max)
         self.register_buffer('scene_center', (lo_s + hi_s) * 0.5)
         self.register_buffer('scene_radius', (hi_s - lo_s) * 0.5)
@@ -86,8 +87,11 @@ class FourierGridModel(nn.Module):
 
     # -- construction helpers ------------------------------------------------------------------------------
     def _make_grid(self, channels, world_size, fourier):
+        # multi-channel grids are stored channel-last on the HIP ops (grid.FourierGrid: same logical parameter, one
+        # 4C-byte run per voxel for the lookup / scatter / TV / Adam kernels); injected back-ends keep the canonical layout
+        cfg = {'channels_last': True} if (self.channels_last_grids and channels > 1 and channels % 4 == 0) else None
         g = _grid.FourierGrid(channels=channels, world_size=world_size, xyz_min=self.xyz_min, xyz_max=self.xyz_max,
-                              use_nerf_pos=fourier, fourier_freq_num=self.fourier_freq_num, config=None)
+                              use_nerf_pos=fourier, fourier_freq_num=self.fourier_freq_num, config=cfg)
         g.query_fn, g.tv_module = self._be.grid_query, self._be.total_variation_cuda
         return g
 

@@ -17,7 +17,8 @@ _L = _lib.load()
 def grid_query(grid, xyz, xyz_min, xyz_max, freq_num):
     """grid [P,C,X,Y,Z]; xyz [...,3] world coords -> [...,C] (squeezed if C==1).  freq_num=F>0: P=1+2F Fourier
     levels, mean over levels; freq_num<=0: plain dense grid (P=1).  Zero padding outside the grid."""
-    _lib.require_cuda(("grid", grid), ("xyz_min", xyz_min), ("xyz_max", xyz_max))
+    cl = _lib.require_cuda_grid(("grid", grid))
+    _lib.require_cuda(("xyz_min", xyz_min), ("xyz_max", xyz_max))
     _lib.require_f32(("grid", grid), ("xyz", xyz), ("xyz_min", xyz_min), ("xyz_max", xyz_max))
     if grid.dim() != 5:
         raise RuntimeError("grid must be [P,C,X,Y,Z]")
@@ -28,8 +29,9 @@ def grid_query(grid, xyz, xyz_min, xyz_max, freq_num):
     if pts.device != grid.device or xyz_min.device != grid.device or xyz_max.device != grid.device:
         raise RuntimeError("grid, xyz, xyz_min and xyz_max must be on the same device")
     out = torch.empty(pts.shape[0], C, dtype=torch.float32, device=grid.device)
+    fn = _L.ugrid_grid_query_cl if cl else _L.ugrid_grid_query
     with _lib.guard(grid.device):
-        _lib.check(_L.ugrid_grid_query(_lib.ptr(grid), P, C, X, Y, Z, _lib.ptr(pts), _lib.ptr(xyz_min),
+        _lib.check(fn(_lib.ptr(grid), P, C, X, Y, Z, _lib.ptr(pts), _lib.ptr(xyz_min),
                                        _lib.ptr(xyz_max), max(int(freq_num), 0), pts.shape[0], _lib.ptr(out),
                                        _lib.stream_of(grid)), "grid_query")
     out = out.reshape(*lead, C)
@@ -47,6 +49,7 @@ class GridQuery(torch.autograd.Function):
             ctx.save_for_backward(xyz.reshape(-1, 3).contiguous(), xyz_min, xyz_max)
             ctx.shape = tuple(grid.shape)
             ctx.freq_num = max(int(freq_num), 0)
+            ctx.channels_last = _lib.is_channels_last(grid)    # the gradient is produced in the grid's own layout
         return out
 
     @staticmethod
@@ -55,11 +58,12 @@ class GridQuery(torch.autograd.Function):
         pts, xyz_min, xyz_max = ctx.saved_tensors
         P, C, X, Y, Z = ctx.shape
         g = grad_out.reshape(-1, C).to(torch.float32).contiguous()
-        grad_grid = torch.zeros(ctx.shape, dtype=torch.float32, device=g.device)
+        grad_grid = _lib.empty_like_grid(ctx.shape, ctx.channels_last, g.device, zero=True)
+        fn = _L.ugrid_grid_query_backward_cl if ctx.channels_last else _L.ugrid_grid_query_backward
         with _lib.guard(g.device):
-            _lib.check(_L.ugrid_grid_query_backward(_lib.ptr(g), P, C, X, Y, Z, _lib.ptr(pts), _lib.ptr(xyz_min),
-                                                    _lib.ptr(xyz_max), ctx.freq_num, pts.shape[0],
-                                                    _lib.ptr(grad_grid), _lib.stream_of(g)), "grid_query_backward")
+            _lib.check(fn(_lib.ptr(g), P, C, X, Y, Z, _lib.ptr(pts), _lib.ptr(xyz_min),
+                          _lib.ptr(xyz_max), ctx.freq_num, pts.shape[0],
+                          _lib.ptr(grad_grid), _lib.stream_of(g)), "grid_query_backward")
         return grad_grid, None, None, None, None
 
 
@@ -151,14 +155,29 @@ class FourierGrid(torch.nn.Module):
         self.world_size = world_size
         self.register_buffer('xyz_min', torch.Tensor(xyz_min))
         self.register_buffer('xyz_max', torch.Tensor(xyz_max))
+        # config={'channels_last': True}: store a multi-channel grid as [P][X][Y][Z][C] (torch.channels_last_3d of the same
+        # logical [P,C,X,Y,Z] parameter -- state_dicts / checkpoints are unchanged): the HIP lookup, its scatter backward,
+        # the TV gradient and the fused TV + Adam pass then touch one 4C-byte run per voxel instead of C planes
+        self.channels_last = bool(config.get('channels_last', False)) if isinstance(config, dict) else False
         if use_nerf_pos:
             self.nerf_pos_num_freq = fourier_freq_num
             self.pos_embed_output_dim = 1 + self.nerf_pos_num_freq * 2
-            self.grid = torch.nn.Parameter(torch.zeros([self.pos_embed_output_dim, channels, *world_size]))
+            self.grid = torch.nn.Parameter(self._alloc([self.pos_embed_output_dim, channels, *world_size]))
         else:
             self.nerf_pos_num_freq = -1
             self.pos_embed_output_dim = -1
-            self.grid = torch.nn.Parameter(torch.zeros([1, channels, *world_size]))
+            self.grid = torch.nn.Parameter(self._alloc([1, channels, *world_size]))
+
+    def _alloc(self, shape):
+        shape = [int(x) for x in shape]
+        if self.channels_last and shape[1] > 1:
+            return torch.zeros(shape).contiguous(memory_format=torch.channels_last_3d)
+        return torch.zeros(shape)
+
+    def _as_stored(self, t):
+        if self.channels_last and t.shape[1] > 1:
+            return t.contiguous(memory_format=torch.channels_last_3d)
+        return t.contiguous()
 
     # test hooks: another implementation of the lookup (differentiable, fourier_grid_query's signature) and of the
     # total_variation_cuda module; None = the HIP kernels
@@ -174,8 +193,8 @@ class FourierGrid(torch.nn.Module):
         if self.channels == 0:
             self.grid = torch.nn.Parameter(torch.zeros([1, self.channels, *new_world_size]))
         else:
-            self.grid = torch.nn.Parameter(
-                F.interpolate(self.grid.data, size=tuple(new_world_size), mode='trilinear', align_corners=True))
+            self.grid = torch.nn.Parameter(self._as_stored(
+                F.interpolate(self.grid.data, size=tuple(int(x) for x in new_world_size), mode='trilinear', align_corners=True)))
 
     def total_variation_add_grad(self, wx, wy, wz, dense_mode):
         """Add the total-variation gradient in place (total_variation_kernel.cu:14-67)."""

@@ -50,6 +50,15 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         return 1, 0
 
     @staticmethod
+    def _flat(t):
+        """1-D view of a dense tensor in STORAGE order (canonical or channel-last grids alike)"""
+        if t.is_contiguous():
+            return t.view(-1)
+        if t.dim() == 5 and t.is_contiguous(memory_format=torch.channels_last_3d):
+            return t.permute(0, 2, 3, 4, 1).reshape(-1)
+        raise RuntimeError("ShardedMaskedAdam needs dense parameters")
+
+    @staticmethod
     def shard_len(numel, world, align=4):
         """Flat elements per rank: ceil(numel / world) rounded up to the update kernels' 4-voxel vectors."""
         per = -(-numel // world)
@@ -76,12 +85,12 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         not written back, bit-identical results); the new parameter values land in a second buffer that is swapped in."""
         w, dense, tv_module = tv
         fused_fn = getattr(self.ops, 'tv_adam_dense', None)
-        if dense and fused_fn is not None and tv_module is None and not use_perlr and param.dim() >= 3 and g.is_contiguous():
+        if dense and fused_fn is not None and tv_module is None and not use_perlr and param.dim() >= 3 and g.stride() == param.stride():
             alt = self._alt.get(param)
-            if alt is None or alt.shape != param.shape or alt.device != param.device:
-                alt = torch.empty_like(param.data, memory_format=torch.contiguous_format)
+            if alt is None or alt.shape != param.shape or alt.device != param.device or alt.stride() != param.stride():
+                alt = torch.empty_like(param.data, memory_format=torch.preserve_format)
             beta1, beta2 = group['betas']
-            if param.data.is_contiguous() and fused_fn(param.data, alt, g, state['exp_avg'], state['exp_avg_sq'], w, w, w,
+            if fused_fn(param.data, alt, g, state['exp_avg'], state['exp_avg_sq'], w, w, w,
                                                        state['step'], beta1, beta2, group['lr'], group['eps'],
                                                        group['skip_zero_grad']):
                 self._alt[param] = param.data
@@ -142,8 +151,11 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                     state['exp_avg_sq'] = torch.zeros(per, dtype=param.dtype, device=param.device)   # range only
                     state['shard'] = (b, e, per)
                 state['step'] += 1
-                flat_p = param.data.view(-1)
-                flat_g = param.grad.contiguous().view(-1)
+                flat_p = self._flat(param.data)
+                g_full = param.grad
+                if g_full.stride() != param.stride():                    # bring a foreign-layout gradient to the parameter's
+                    g_full = torch.empty_like(param.data).copy_(g_full)
+                flat_g = self._flat(g_full)
                 exact = (total == n)       # no padding: collectives run on the parameter / gradient storage itself
                 if not exact:
                     pad_g = torch.zeros(total, dtype=flat_g.dtype, device=flat_g.device)
@@ -154,17 +166,18 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                 if scale is not None:
                     g_shard.mul_(scale)
                 if grad_hook is not None or param in tv_terms:
-                    full_g = torch.zeros(n, dtype=g_shard.dtype, device=g_shard.device)
+                    full = torch.zeros_like(param.data)                 # the parameter's own layout
+                    full_g = self._flat(full)
                     full_g[b:e] = g_shard[: e - b]
                     if grad_hook is not None:
-                        grad_hook(param, full_g.view_as(param))
+                        grad_hook(param, full)
                     if param in tv_terms:
                         w, dense, tv_module = tv_terms[param]
                         if tv_module is None:
                             from . import total_variation_cuda as tv_module
-                        tv_module.total_variation_add_grad(param, full_g.view_as(param), w, w, w, dense)
+                        tv_module.total_variation_add_grad(param, full, w, w, w, dense)
                     g_shard[: e - b] = full_g[b:e]
-                    del full_g
+                    del full_g, full
                 if exact:
                     p_shard = flat_p[b:b + per]                  # a view: updated in place
                 else:
@@ -214,6 +227,15 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                 raise RuntimeError("rank-local optimizer state (written before state_dict() gathered shards) cannot be "
                                    "loaded: it holds one rank's range only")
         super().load_state_dict(state_dict)
+        # moments arrive in the file's (canonical) layout; the kernels need them in the parameter's own
+        for group in self.param_groups:
+            for param in group['params']:
+                st = self.state.get(param)
+                if not st:
+                    continue
+                for k in ('exp_avg', 'exp_avg_sq'):
+                    if k in st and st[k].shape == param.shape and st[k].stride() != param.stride():
+                        st[k] = torch.empty_like(param.data).copy_(st[k])
         world, rank = self._world()
         for group in self.param_groups:
             for param in group['params']:
@@ -225,7 +247,7 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                 b = min(n, rank * per)
                 e = min(n, b + per)
                 for k in ('exp_avg', 'exp_avg_sq'):
-                    full = st[k].reshape(-1)
+                    full = self._flat(st[k])
                     if full.numel() != n:
                         raise RuntimeError("optimizer state %s has %d elements, parameter has %d" % (k, full.numel(), n))
                     shard = torch.zeros(per, dtype=full.dtype, device=full.device)

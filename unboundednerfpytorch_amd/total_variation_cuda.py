@@ -9,10 +9,19 @@ _L = _lib.load()
 def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
     """grad += TV gradient of param, in place; sizes from param.size(2..4) like the reference
     (total_variation_kernel.cu:39-41), so [P,C,X,Y,Z] grids work.  Returns None."""
-    _lib.require_cuda(("param", param), ("grad", grad))
+    cl = _lib.require_cuda_grid(("param", param), ("grad", grad))
     _lib.require_f32(("param", param), ("grad", grad))
     if param.dim() != 5 or param.shape != grad.shape:
         raise RuntimeError("param/grad must be 5-D tensors of equal shape")
+    if cl:      # channel-last storage [P][X][Y][Z][C] of the same logical tensor (training layout, grid.FourierGrid)
+        with _lib.guard(param.device):
+            rc = _L.ugrid_total_variation_add_grad_cl(_lib.ptr(param), _lib.ptr(grad), float(wx), float(wy), float(wz),
+                                                      1 if dense_mode else 0, param.size(2), param.size(3), param.size(4),
+                                                      param.size(1), param.numel(), _lib.stream_of(param))
+        if rc == 801:
+            raise RuntimeError("channel-last total_variation_add_grad needs C % 4 == 0 and fewer than 2^31 elements")
+        _lib.check(rc, "total_variation_add_grad")
+        return
     with _lib.guard(param.device):
         _lib.check(_L.ugrid_total_variation_add_grad(_lib.ptr(param), _lib.ptr(grad), float(wx), float(wy), float(wz),
                                                      1 if dense_mode else 0, param.size(2), param.size(3),

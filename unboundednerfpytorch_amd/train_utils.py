@@ -52,9 +52,21 @@ def create_optimizer_or_freeze_model(model, cfg_train, global_step, verbose=Fals
     return opt
 
 
+def _canonical(obj):
+    """state-dict tensors in the reference's row-major layout (the channel-last training layout of multi-channel grids is
+    a storage detail of this package; files stay byte-compatible with the reference's)"""
+    if torch.is_tensor(obj):
+        return obj.contiguous()
+    if isinstance(obj, dict):
+        return type(obj)((k, _canonical(v)) for k, v in obj.items())
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_canonical(v) for v in obj)
+    return obj
+
+
 def save_checkpoint(path, model, optimizer, global_step):
-    torch.save({'global_step': global_step, 'model_kwargs': model.get_kwargs(), 'model_state_dict': model.state_dict(),
-                'optimizer_state_dict': optimizer.state_dict()}, path)
+    torch.save({'global_step': global_step, 'model_kwargs': model.get_kwargs(), 'model_state_dict': _canonical(model.state_dict()),
+                'optimizer_state_dict': _canonical(optimizer.state_dict())}, path)
 
 
 def load_model(ckpt_path, model_class=None, **model_extra):
