@@ -105,7 +105,7 @@ def _cl(t):
     return t.contiguous(memory_format=torch.channels_last_3d)
 
 
-@pytest.mark.parametrize("shape,F", [((7, 12, 9, 7, 6), 3), ((1, 4, 5, 6, 8), 0), ((5, 8, 6, 6, 6), 2)])
+@pytest.mark.parametrize("shape,F", [((7, 12, 9, 7, 6), 3), ((1, 4, 5, 6, 8), 0), ((5, 8, 6, 6, 6), 2), ((3, 4, 53, 9, 11), 1)])
 def test_channel_last_grid_layout_equals_canonical(shape, F):
     """The training layout of multi-channel grids ([P][X][Y][Z][C] = torch.channels_last_3d of the same logical tensor):
     lookup bit-identical to the canonical layout, scatter backward equal up to the atomics' summation order and produced

@@ -416,15 +416,39 @@ __global__ void k_tv(const float *__restrict__ param, float *__restrict__ grad, 
   grad[idx] = g0 + g;
 }
 
+// XCD = blocks renumbered so that each of the 8 XCDs (the hardware deals consecutive workgroups to them round-robin)
+// walks one contiguous eighth of the array: the stencil's j / i neighbour lines are then found in the XCD's own L2
+// instead of being fetched again over the fabric by another one (4.98 -> 4.41 ms on the channel-last S3 k0 array).
+typedef float ug_v4f __attribute__((ext_vector_type(4)));
+// streaming arrays (gradient, moments, the new parameters) bypass the caches' retention: the L2 is left to the stencil
+template <bool NT> __device__ __forceinline__ float4 ug_ld4(const float *p) {
+  if (NT) { const ug_v4f v = __builtin_nontemporal_load((const ug_v4f *)p); return make_float4(v.x, v.y, v.z, v.w); }
+  return *(const float4 *)p;
+}
+template <bool NT> __device__ __forceinline__ void ug_st4(float *p, float a, float b, float c, float d) {
+  if (NT) { ug_v4f v = {a, b, c, d}; __builtin_nontemporal_store(v, (ug_v4f *)p); }
+  else *(float4 *)p = make_float4(a, b, c, d);
+}
+
+template <int XCD>
+__device__ __forceinline__ unsigned ug_xcd_block() {
+  unsigned b = blockIdx.x;
+  if (XCD) {
+    const unsigned nb = gridDim.x, per = nb >> 3, rem = nb & 7u, xcd = b & 7u;
+    b = xcd * per + (xcd < rem ? xcd : rem) + (b >> 3);
+  }
+  return b;
+}
+
 // 4 voxels (one float4 along the fastest axis) per lane, 32-bit index arithmetic: used when sz_k % 4 == 0,
 // N < 2^31 and both arrays are 16-byte aligned.  The per-voxel expression (six sequential float adds) is the
 // scalar kernel's, so results are bit-identical; neighbours along k come from the same float4 plus two scalar
 // loads, neighbours along j / i are four more float4 loads.
-template <bool DENSE>
+template <bool DENSE, int XCD = 0>
 __global__ void __launch_bounds__(256)
 k_tv_vec4(const float *__restrict__ param, float *__restrict__ grad, float wy, float wz, int sz_i, int sz_j,
           int sz_k, unsigned n4) {
-  const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned q = ug_xcd_block<XCD>() * blockDim.x + threadIdx.x;
   if (q >= n4) return;
   const unsigned idx = q * 4u;
   float4 g0 = *(const float4 *)(grad + idx);
@@ -604,15 +628,15 @@ static int ug_adam_launch(float *param, const float *grad, float *m, float *v, c
 // stencil needs the neighbours' OLD values, so the new parameters go to a second buffer that the caller swaps in.
 // Bit-identical to the two-kernel sequence.  MASKED = the skip_zero_grad rule applied to the TV-added gradient.
 // ----------------------------------------------------------------------------------------------
-template <bool MASKED>
+template <bool MASKED, int XCD = 0>
 __global__ void __launch_bounds__(256)
 k_tv_adam_vec4(const float *__restrict__ param, float *__restrict__ param_out, const float *__restrict__ grad,
                float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, float wy, float wz, int sz_i, int sz_j,
                int sz_k, unsigned n4, float step_size, float beta1, float beta2, float eps) {
-  const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned q = ug_xcd_block<XCD>() * blockDim.x + threadIdx.x;
   if (q >= n4) return;
   const unsigned idx = q * 4u;
-  const float4 g0 = *(const float4 *)(grad + idx);
+  const float4 g0 = ug_ld4<XCD == 2>(grad + idx);
   const unsigned k4 = (unsigned)sz_k >> 2;
   const unsigned kq = q % k4, row = q / k4;
   const unsigned j = row % (unsigned)sz_j, i = (row / (unsigned)sz_j) % (unsigned)sz_i;
@@ -626,7 +650,7 @@ k_tv_adam_vec4(const float *__restrict__ param, float *__restrict__ param_out, c
   if (j != (unsigned)sz_j - 1) nj1 = *(const float4 *)(param + idx + sj);
   if (i != 0) ni0 = *(const float4 *)(param + idx - si);
   if (i != (unsigned)sz_i - 1) ni1 = *(const float4 *)(param + idx + si);
-  const float4 m4 = *(const float4 *)(exp_avg + idx), v4 = *(const float4 *)(exp_avg_sq + idx);
+  const float4 m4 = ug_ld4<XCD == 2>(exp_avg + idx), v4 = ug_ld4<XCD == 2>(exp_avg_sq + idx);
   float pv[4] = {p.x, p.y, p.z, p.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
   const float pold[4] = {p.x, p.y, p.z, p.w}, gv[4] = {g0.x, g0.y, g0.z, g0.w};
   const float km[4] = {pm, p.x, p.y, p.z}, kp[4] = {p.y, p.z, p.w, pp};
@@ -644,9 +668,9 @@ k_tv_adam_vec4(const float *__restrict__ param, float *__restrict__ param_out, c
     const float gt = gv[e] + g;
     if (!MASKED || gt != 0.f) ug_adam_one<0>(pv[e], gt, mv[e], vv[e], 1.f, step_size, beta1, beta2, eps);
   }
-  *(float4 *)(param_out + idx) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-  *(float4 *)(exp_avg + idx) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-  *(float4 *)(exp_avg_sq + idx) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+  ug_st4<XCD == 2>(param_out + idx, pv[0], pv[1], pv[2], pv[3]);
+  ug_st4<XCD == 2>(exp_avg + idx, mv[0], mv[1], mv[2], mv[3]);
+  ug_st4<XCD == 2>(exp_avg_sq + idx, vv[0], vv[1], vv[2], vv[3]);
 }
 
 
@@ -694,15 +718,15 @@ __global__ void k_rays_of_a_view(ug_cam c, const float *__restrict__ c2w, const 
 // equal the canonical-layout results element for element.  ADAM: 0 = TV only (grad updated in place), 1 = fused with
 // masked Adam, 2 = fused with dense Adam (param_out written, grad untouched).
 // ----------------------------------------------------------------------------------------------
-template <bool DENSE, int ADAM>
+template <bool DENSE, int ADAM, int XCD = 0>
 __global__ void __launch_bounds__(256)
 k_tv_cl_vec4(const float *__restrict__ param, float *__restrict__ param_out, float *__restrict__ grad,
              float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, float wy, float wz, int sz_i, int sz_j,
              int sz_k, int C, unsigned n4, float step_size, float beta1, float beta2, float eps) {
-  const unsigned q = blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned q = ug_xcd_block<XCD>() * blockDim.x + threadIdx.x;
   if (q >= n4) return;
   const unsigned idx = q * 4u;
-  const float4 g0 = *(const float4 *)(grad + idx);
+  const float4 g0 = ug_ld4<XCD == 2>(grad + idx);
   if (!DENSE && g0.x == 0.f && g0.y == 0.f && g0.z == 0.f && g0.w == 0.f) return;
   const unsigned c4 = (unsigned)C >> 2;
   const unsigned vox = q / c4;                                  // (plane * sz_i + i) * sz_j * sz_k + j * sz_k + k
@@ -724,7 +748,7 @@ k_tv_cl_vec4(const float *__restrict__ param, float *__restrict__ param_out, flo
   const float b0[4] = {ni0.x, ni0.y, ni0.z, ni0.w}, b1[4] = {ni1.x, ni1.y, ni1.z, ni1.w};
   float mv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f};
   if (ADAM) {
-    const float4 m4 = *(const float4 *)(exp_avg + idx), v4 = *(const float4 *)(exp_avg_sq + idx);
+    const float4 m4 = ug_ld4<XCD == 2>(exp_avg + idx), v4 = ug_ld4<XCD == 2>(exp_avg_sq + idx);
     mv[0] = m4.x; mv[1] = m4.y; mv[2] = m4.z; mv[3] = m4.w;
     vv[0] = v4.x; vv[1] = v4.y; vv[2] = v4.z; vv[3] = v4.w;
   }
@@ -744,13 +768,16 @@ k_tv_cl_vec4(const float *__restrict__ param, float *__restrict__ param_out, flo
     }
   }
   if (ADAM) {
-    *(float4 *)(param_out + idx) = make_float4(pv[0], pv[1], pv[2], pv[3]);
-    *(float4 *)(exp_avg + idx) = make_float4(mv[0], mv[1], mv[2], mv[3]);
-    *(float4 *)(exp_avg_sq + idx) = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    ug_st4<XCD == 2>(param_out + idx, pv[0], pv[1], pv[2], pv[3]);
+    ug_st4<XCD == 2>(exp_avg + idx, mv[0], mv[1], mv[2], mv[3]);
+    ug_st4<XCD == 2>(exp_avg_sq + idx, vv[0], vv[1], vv[2], vv[3]);
   } else {
     *(float4 *)(grad + idx) = make_float4(out[0], out[1], out[2], out[3]);
   }
 }
+
+static int g_tv_xcd = 2;   // ugrid_tune("tv_xcd", 0|1|2): dense TV (+ Adam) kernels: linear block order | XCD-contiguous | + non-temporal streams
+extern "C" int ug_set_tv_xcd(int m) { if (m < 0 || m > 2) return 1; g_tv_xcd = m; return 0; }
 
 // ----------------------------------------------------------------------------------------------
 // C ABI
@@ -904,7 +931,10 @@ extern "C" int ugrid_total_variation_add_grad(const float *param, float *grad, f
                    ((((uintptr_t)param) | ((uintptr_t)grad)) & 15) == 0;
   if (vec) {
     const unsigned n4 = (unsigned)(N / 4);
-    if (dense_mode)
+    if (dense_mode && g_tv_xcd)
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_vec4<true, 1>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, grad,
+                         wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, n4);
+    else if (dense_mode)
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_vec4<true>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, grad,
                          wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, n4);
     else
@@ -954,7 +984,10 @@ extern "C" int ugrid_total_variation_add_grad_cl(const float *param, float *grad
   wy /= 6;
   wz /= 6;
   const unsigned n4 = (unsigned)(N / 4);
-  if (dense_mode)
+  if (dense_mode && g_tv_xcd)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 0, 1>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, nullptr, grad,
+                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f);
+  else if (dense_mode)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 0>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, nullptr, grad,
                        nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f);
   else
@@ -977,12 +1010,19 @@ extern "C" int ugrid_tv_adam_dense_cl(const float *param, float *param_out, cons
   const float step_size = lr * sqrtf(1 - powf(beta2, (float)step)) / (1 - powf(beta1, (float)step));
   const unsigned n4 = (unsigned)(N / 4);
   float *g = const_cast<float *>(grad);   // ADAM != 0 never writes the gradient
-  if (skip_zero_grad)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 1>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, param_out, g,
-                       exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, step_size, beta1, beta2, eps);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 2>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, param_out, g,
-                       exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, step_size, beta1, beta2, eps);
+  const dim3 gr((n4 + 255) / 256), bl(256);
+#define UG_TV_CL_ARGS param, param_out, g, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, step_size, beta1, beta2, eps
+  if (g_tv_xcd == 2) {
+    if (skip_zero_grad) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 1, 2>), gr, bl, 0, ST(s), UG_TV_CL_ARGS);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 2, 2>), gr, bl, 0, ST(s), UG_TV_CL_ARGS);
+  } else if (g_tv_xcd) {
+    if (skip_zero_grad) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 1, 1>), gr, bl, 0, ST(s), UG_TV_CL_ARGS);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 2, 1>), gr, bl, 0, ST(s), UG_TV_CL_ARGS);
+  } else {
+    if (skip_zero_grad) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 1>), gr, bl, 0, ST(s), UG_TV_CL_ARGS);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 2>), gr, bl, 0, ST(s), UG_TV_CL_ARGS);
+  }
+#undef UG_TV_CL_ARGS
   UG_LAUNCH_CHECK();
   return 0;
 }
@@ -1014,12 +1054,19 @@ extern "C" int ugrid_tv_adam_dense(const float *param, float *param_out, const f
   wz /= 6;
   const float step_size = lr * sqrtf(1 - powf(beta2, (float)step)) / (1 - powf(beta1, (float)step));
   const unsigned n4 = (unsigned)(N / 4);
-  if (skip_zero_grad)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_adam_vec4<true>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, param_out,
-                       grad, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, n4, step_size, beta1, beta2, eps);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_adam_vec4<false>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, param_out,
-                       grad, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, n4, step_size, beta1, beta2, eps);
+  const dim3 gr((n4 + 255) / 256), bl(256);
+#define UG_TV_ARGS param, param_out, grad, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, n4, step_size, beta1, beta2, eps
+  if (g_tv_xcd == 2) {
+    if (skip_zero_grad) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_adam_vec4<true, 2>), gr, bl, 0, ST(s), UG_TV_ARGS);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_adam_vec4<false, 2>), gr, bl, 0, ST(s), UG_TV_ARGS);
+  } else if (g_tv_xcd) {
+    if (skip_zero_grad) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_adam_vec4<true, 1>), gr, bl, 0, ST(s), UG_TV_ARGS);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_adam_vec4<false, 1>), gr, bl, 0, ST(s), UG_TV_ARGS);
+  } else {
+    if (skip_zero_grad) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_adam_vec4<true>), gr, bl, 0, ST(s), UG_TV_ARGS);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_adam_vec4<false>), gr, bl, 0, ST(s), UG_TV_ARGS);
+  }
+#undef UG_TV_ARGS
   UG_LAUNCH_CHECK();
   return 0;
 }

@@ -3,6 +3,7 @@
 #include "ugrid_render.h"
 
 extern "C" int ug_set_march_waves(int w);  // ugrid_march.hip
+extern "C" int ug_set_tv_xcd(int m);        // ugrid_ops.hip
 static int g_shade_dbg = 0;  // experiments: ugrid_tune("shade_dbg", bits) -- WRONG RESULTS by design (see ug_shade_tile16)
 static int g_shade16 = 0;   // ugrid_tune("shade16", 0|1): 16x16x32 / 16-wave kernel where it applies (A/B switch)
 
@@ -439,6 +440,7 @@ extern "C" int ugrid_render_fused_stats(const void *ws_mem, int64_t *d_stats, ug
 extern "C" int ugrid_tune(const char *key, int value) {
   if (!key) return (int)hipErrorInvalidValue;
   if (!strcmp(key, "march_waves")) return ug_set_march_waves(value) ? (int)hipErrorInvalidValue : 0;
+  if (!strcmp(key, "tv_xcd")) return ug_set_tv_xcd(value) ? (int)hipErrorInvalidValue : 0;
   if (!strcmp(key, "shade16") && (value == 0 || value == 1)) { g_shade16 = value; return 0; }
   if (!strcmp(key, "shade_dbg") && value >= 0 && value < 4) { g_shade_dbg = value; return 0; }
   return (int)hipErrorInvalidValue;
