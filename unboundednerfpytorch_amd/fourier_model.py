@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import grid as _grid
+from . import ops as _ops
 
 
 def _hip_backend():
@@ -42,6 +43,7 @@ class FourierGridModel(nn.Module):
         # chain below remains for injected back-ends, fast_color_thres == 0 and as the A/B reference of the tests
         self.fused_forward = backend is None
         self.channels_last_grids = backend is None and kwargs.get('channels_last_grids', True)
+        self.splitk_rgbnet = backend is None       # ops.SplitKLinear weight gradients (training on the GPU only)
         lo_s, hi_s = torch.Tensor(xyz_min), torch.Tensor(xyz_max)
         self.register_buffer('scene_center', (lo_s + hi_s) * 0.5)
         self.register_buffer('scene_radius', (hi_s - lo_s) * 0.5)
@@ -276,9 +278,10 @@ class FourierGridModel(nn.Module):
                 ray_id, step_id = ray_id[keep.flatten()], step_id[keep.flatten()]
         weights, alphainv_last = self._be.Alphas2Weights.apply(alpha, ray_id, R)
         if self.fast_color_thres > 0:
-            keep = weights > self.fast_color_thres
-            pts, tt, density, alpha, weights = pts[keep], tt[keep], density[keep], alpha[keep], weights[keep]
-            ray_id, step_id = ray_id[keep], step_id[keep]
+            # one nonzero (one host sync) for the seven gathers of FourierGrid_model.py:620-629, instead of one per tensor
+            keep = torch.nonzero(weights > self.fast_color_thres).squeeze(1)
+            pts, tt, density, alpha, weights = (x.index_select(0, keep) for x in (pts, tt, density, alpha, weights))
+            ray_id, step_id = ray_id.index_select(0, keep), step_id.index_select(0, keep)
         else:
             pts, weights = pts.reshape(-1, 3), weights.reshape(-1)
         k0 = self.k0(pts)
@@ -287,7 +290,11 @@ class FourierGridModel(nn.Module):
         else:
             e = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
             emb = torch.cat([viewdirs, e.sin(), e.cos()], -1).flatten(0, -2)[ray_id]
-            rgb = torch.sigmoid(self.rgbnet(torch.cat([k0, emb], -1)))
+            feat = torch.cat([k0, emb], -1)
+            if self.splitk_rgbnet and feat.is_cuda and torch.is_grad_enabled():
+                rgb = torch.sigmoid(_ops.sequential_splitk(self.rgbnet, feat))
+            else:
+                rgb = torch.sigmoid(self.rgbnet(feat))
         rgb_marched = torch.zeros(R, 3, device=dev).index_add_(0, ray_id, weights.unsqueeze(-1) * rgb)
         if render_kwargs.get('rand_bkgd', False):
             rgb_marched = rgb_marched + alphainv_last.unsqueeze(-1) * torch.rand_like(rgb_marched)

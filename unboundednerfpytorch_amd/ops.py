@@ -127,3 +127,48 @@ class FlattenEffDistLoss(DistortionLoss):
 
 distortion_loss = DistortionLoss.apply          # (w, s, n_max, ray_id): the reference's in-repo class, quirk kept
 flatten_eff_distloss = FlattenEffDistLoss.apply  # (w, m, interval, ray_id): what the training loop uses
+
+
+class SplitKLinear(torch.autograd.Function):
+    """y = x W^T + b for a tall x [M, K] (M = the step's survivors, ~1e5) and a small W [N, K].  Same forward as
+    nn.Linear (FourierGrid_model.py:636 calls the layers of self.rgbnet); the weight gradient go^T x has a 128 x 128 (or
+    3 x 128) result and an M-long reduction, which rocBLAS runs on 16 workgroups (185-225 us at M = 84k): here the rows
+    are cut into SPLIT slabs reduced by one batched GEMM + a sum (55 us).  fp32 throughout; the summation order of the
+    weight gradient differs from the library's single GEMM (rel. 4e-6, tools/microbench/rgbnet_gemms.py)."""
+    SPLIT = 32
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        return torch.addmm(bias, x, weight.t())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go):
+        x, weight = ctx.saved_tensors
+        go = go.contiguous()
+        gx = go @ weight if ctx.needs_input_grad[0] else None
+        M, S = go.shape[0], SplitKLinear.SPLIT
+        m = M // S
+        main = m * S
+        if m >= 64:
+            gw = torch.bmm(go[:main].view(S, m, -1).transpose(1, 2), x[:main].view(S, m, -1)).sum(0)
+            if main < M:
+                gw = gw.addmm_(go[main:].t(), x[main:])
+        else:
+            gw = go.t() @ x
+        return gx, gw, go.sum(0)
+
+
+def sequential_splitk(net, x):
+    """Applies an nn.Sequential of Linear / ReLU / nested Sequential (the rgbnet) with SplitKLinear for the Linear layers."""
+    for layer in net:
+        if isinstance(layer, torch.nn.Linear):
+            x = SplitKLinear.apply(x, layer.weight, layer.bias)
+        elif isinstance(layer, torch.nn.ReLU):
+            x = torch.relu_(x) if layer.inplace else torch.relu(x)
+        elif isinstance(layer, torch.nn.Sequential):
+            x = sequential_splitk(layer, x)
+        else:
+            x = layer(x)
+    return x

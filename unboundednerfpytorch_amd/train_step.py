@@ -50,9 +50,12 @@ def training_loss(render_result, target, cfg_train, n_rays, near_thres=None, dis
         p = render_result['alphainv_last'].clamp(1e-6, 1 - 1e-6)
         loss = loss + _get(cfg_train, 'weight_entropy_last') * (-(p * torch.log(p) + (1 - p) * torch.log(1 - p))).mean()
     if _get(cfg_train, 'weight_nearclip', 0.0) > 0:
-        d = render_result['raw_density'][render_result['t'] < near_thres]
-        if len(d):
-            loss = loss + (_get(cfg_train, 'weight_nearclip') * world_size) * (d - d.detach()).sum()
+        # run_train.py:262-265 selects the near samples with a boolean index and skips the term when there are none; the
+        # value of the term is 0 either way and its gradient is +weight on the selected densities -- a masked sum gives
+        # both without the nonzero + host sync
+        dens = render_result['raw_density']
+        near = (render_result['t'] < near_thres).to(dens.dtype)
+        loss = loss + (_get(cfg_train, 'weight_nearclip') * world_size) * ((dens - dens.detach()) * near).sum()
     if _get(cfg_train, 'weight_distortion', 0.0) > 0 and render_result['weights'].numel() > 0:
         if distortion_fn is None:
             from .ops import flatten_eff_distloss as distortion_fn
