@@ -142,10 +142,13 @@ int ugrid_segment_cumsum(const float *w, const float *s, const int64_t *ray_id, 
  * the same shape: the stencil needs the neighbours' old values; the caller swaps the buffers), exp_avg / exp_avg_sq in
  * place.  Results are bit-identical to ugrid_total_variation_add_grad(dense) followed by ugrid_adam_upd(mode =
  * skip_zero_grad).  Returns hipErrorNotSupported (801) when the shape cannot take the vector path (sz_k % 4 != 0,
- * N >= 2^31, unaligned or aliasing buffers); the caller then uses the two separate entry points. */
+ * N >= 2^31, unaligned or aliasing buffers); the caller then uses the two separate entry points.
+ * flags: bit 0 = skip_zero_grad (the masked_adam_upd rule on the TV-added gradient); bit 1 = rezero_grad: every nonzero
+ * element of grad is overwritten with 0 after it has been read (only the touched cache lines are written), so the
+ * caller can hand the buffer to the next backward as its zero-initialised gradient instead of filling a new one. */
 int ugrid_tv_adam_dense(const float *param, float *param_out, const float *grad, float *exp_avg, float *exp_avg_sq,
                         float wx, float wy, float wz, int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t N, int step,
-                        float beta1, float beta2, float lr, float eps, int skip_zero_grad, ugrid_stream_t stream);
+                        float beta1, float beta2, float lr, float eps, int flags, ugrid_stream_t stream);
 
 int ugrid_adam_upd(float *param, const float *grad, float *exp_avg, float *exp_avg_sq,
                    const float *perlr, int64_t N, int step, float beta1, float beta2, float lr,
@@ -191,7 +194,7 @@ int ugrid_total_variation_add_grad_cl(const float *param, float *grad, float wx,
                                       ugrid_stream_t stream);
 int ugrid_tv_adam_dense_cl(const float *param, float *param_out, const float *grad, float *exp_avg, float *exp_avg_sq,
                            float wx, float wy, float wz, int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t C, int64_t N,
-                           int step, float beta1, float beta2, float lr, float eps, int skip_zero_grad,
+                           int step, float beta1, float beta2, float lr, float eps, int flags,
                            ugrid_stream_t stream);
 
 /* Brick packing: canonical [P,C,X,Y,Z] -> cell-major 2x2x2 bricks, one contiguous record per

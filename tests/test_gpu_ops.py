@@ -422,3 +422,27 @@ def test_fused_dense_tv_adam_is_bit_identical_to_the_two_reference_calls(mods, s
         tv.total_variation_add_grad(pb, pb.grad, w, w, w, True)
         ob.step()
     assert torch.equal(pa.data, pb.data) and torch.equal(oa.state[pa]['exp_avg_sq'], ob.state[pb]['exp_avg_sq'])
+
+
+@pytest.mark.parametrize("channels_last", [False, True])
+def test_fused_tv_adam_rezero_grad_returns_the_gradient_buffer_all_zero(channels_last):
+    from unboundednerfpytorch_amd import adam_upd_cuda
+    shape = (3, 4, 9, 10, 12)
+    n = int(np.prod(shape))
+    fmt = torch.channels_last_3d if channels_last else torch.contiguous_format
+    mk = lambda seed, lo=None: torch.from_numpy(synth.normal(seed, n).reshape(shape)).cuda().contiguous(memory_format=fmt)
+    p, g, m, v = mk(1), mk(2), mk(3) * 0.1, mk(4).abs() * 0.01
+    g[g.abs() < 1.0] = 0            # sparse, like a scattered gradient
+    g[0, 0, 0, 0, 0] = float("nan")
+    outs = []
+    for rezero in (False, True):
+        gi, mi, vi, out = g.clone(memory_format=torch.preserve_format), m.clone(memory_format=torch.preserve_format), \
+            v.clone(memory_format=torch.preserve_format), torch.empty_like(p)
+        assert adam_upd_cuda.tv_adam_dense(p, out, gi, mi, vi, 0.2, 0.2, 0.2, 5, 0.9, 0.99, 0.1, 1e-8, True, rezero_grad=rezero)
+        outs.append((out, mi, vi))
+        if rezero:
+            assert not bool(gi.any())
+        else:
+            assert torch.equal(torch.nan_to_num(gi), torch.nan_to_num(g))
+    for a, b in zip(*outs):
+        assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))

@@ -27,6 +27,12 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 G, F = 100, 4
 
 
+@pytest.fixture(autouse=True)
+def _fixed_rng():
+    """the rgbnet initialisation comes from the global generator: every test starts from the same state, whatever ran before"""
+    torch.manual_seed(0)
+
+
 def build(device, backend=None):
     import bench_train_step as bts
     from unboundednerfpytorch_amd.fourier_model import FourierGridModel
@@ -70,7 +76,12 @@ def test_fused_stage1_forward_equals_the_composed_chain_at_scale():
         scale = float(gb.abs().max()) + 1e-20
         assert float((ga - gb).abs().max()) <= 2e-3 * scale, (k, float((ga - gb).abs().max()) / scale)   # fp32 atomics: run-to-run order
         if "grid" in k:
-            assert torch.equal(ga != 0, gb != 0), k                            # same touched voxels (MaskedAdam keys on them)
+            # same touched voxels (MaskedAdam keys on them); a sample within an ulp of a cell face may land on either side
+            # (the two paths' points differ by ~1e-7): the corners it then adds or drops carry a ~1e-7 trilinear weight
+            odd = (ga != 0) ^ (gb != 0)
+            if bool(odd.any()):
+                assert int(odd.sum()) <= 1024 and float(torch.maximum(ga.abs(), gb.abs())[odd].max()) <= 1e-4 * scale, \
+                    (k, int(odd.sum()), float(torch.maximum(ga.abs(), gb.abs())[odd].max()), scale)
 
 
 def test_channel_last_k0_model_equals_the_canonical_layout_model():
@@ -155,6 +166,51 @@ def test_train_iteration_fused_tv_adam_equals_two_calls_at_scale():
             # running the iteration on a model whose forward is deterministic up to that -- so compare to 1 ulp of lr
             ts.train_iteration(m, opt, o, d, v, rgb, bts.TRUCK_CFG, step, dict(stepsize=0.5, rand_bkgd=False))
         params.append({k: p.detach().clone() for k, p in m.named_parameters()})
+    for k in params[0]:
+        diff = (params[0][k] - params[1][k]).abs()
+        lr = 0.1 if "grid" in k else 1e-3
+        assert float((diff > 0.02 * lr).float().mean()) < 1e-4, (k, float(diff.max()))
+
+
+def test_gradient_buffers_are_recycled_all_zero_between_steps():
+    """_gradpool: the fused dense TV + Adam pass hands the k0 / density gradient buffers back all zero (rezero_grad) and
+    the next backward scatters into them instead of filling new ones -- same buffers every step, exactly zero while
+    parked, and the trained parameters equal those of the run that allocates and fills per step."""
+    import bench_train_step as bts
+    from unboundednerfpytorch_amd import _gradpool, train_step as ts
+    from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
+    dev = torch.device("cuda", 0)
+    params, ptrs = [], []
+    try:
+        for recycle in (True, False):
+            _gradpool.clear()
+            _gradpool.enabled = recycle
+            torch.manual_seed(0)
+            m = build(dev)
+            opt = create_optimizer_or_freeze_model(m, bts.TRUCK_CFG, global_step=0)
+            seen = []
+            inner = opt.step
+
+            def step(*a, _inner=inner, _m=m, _seen=seen, **kw):
+                _seen.append((_m.k0.grid.grad.data_ptr(), _m.density.grid.grad.data_ptr()))
+                return _inner(*a, **kw)
+            opt.step = step
+            for s in (1, 2, 3):
+                o, d, v, rgb = bts.random_rays(2048, dev, seed=20 + s)
+                ts.train_iteration(m, opt, o, d, v, rgb, bts.TRUCK_CFG, s, dict(stepsize=0.5, rand_bkgd=False))
+                if recycle:
+                    assert m.k0.grid.grad is None and m.density.grid.grad is None
+                    for p in (m.k0.grid, m.density.grid):
+                        buf = _gradpool._POOL[id(p)][1]
+                        assert buf is not None and buf.stride() == p.stride() and not bool(buf.any())
+                        del buf      # a second reference would make AccumulateGrad copy the gradient instead of adopting it
+            ptrs.append(seen)
+            params.append({k: p.detach().clone() for k, p in m.named_parameters()})
+            del m, opt
+    finally:
+        _gradpool.enabled = True
+        _gradpool.clear()
+    assert ptrs[0][0] == ptrs[0][1] == ptrs[0][2]          # recycled: one buffer per parameter
     for k in params[0]:
         diff = (params[0][k] - params[1][k]).abs()
         lr = 0.1 if "grid" in k else 1e-3

@@ -33,21 +33,23 @@ def adam_upd_with_perlr(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, be
     _run(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps, 2, "adam_upd_with_perlr")
 
 
-def tv_adam_dense(param, param_out, grad, exp_avg, exp_avg_sq, wx, wy, wz, step, beta1, beta2, lr, eps, skip_zero_grad):
+def tv_adam_dense(param, param_out, grad, exp_avg, exp_avg_sq, wx, wy, wz, step, beta1, beta2, lr, eps, skip_zero_grad,
+                  rezero_grad=False):
     """NEW (not in the reference module): dense total_variation_add_grad + (masked_)adam_upd of one grid parameter
     [.., X, Y, Z] in a single pass (include/ugrid_hip.h: ugrid_tv_adam_dense).  The updated parameter lands in
-    `param_out`; `grad` is left untouched.  Returns False when the shape cannot take the fused path (the caller then
+    `param_out`; `grad` is left untouched, or -- rezero_grad=True -- comes back all zero (its nonzero elements are
+    overwritten after use, so the buffer can serve as the next backward's zero-initialised gradient).  Returns False when the shape cannot take the fused path (the caller then
     runs the two reference calls), True otherwise."""
     named = [("param", param), ("param_out", param_out), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)]
     cl = _lib.require_cuda_grid(*named) if param.dim() == 5 else (_lib.require_cuda(*named) or False)
     _lib.require_f32(*named)
     sz_i, sz_j, sz_k = param.shape[-3:]
+    flags = int(bool(skip_zero_grad)) | (2 if rezero_grad else 0)
     if cl:
         with _lib.guard(param.device):
             rc = _L.ugrid_tv_adam_dense_cl(_lib.ptr(param), _lib.ptr(param_out), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
                                            float(wx), float(wy), float(wz), sz_i, sz_j, sz_k, param.shape[1], param.numel(), int(step),
-                                           float(beta1), float(beta2), float(lr), float(eps), int(bool(skip_zero_grad)),
-                                           _lib.stream_of(param))
+                                           float(beta1), float(beta2), float(lr), float(eps), flags, _lib.stream_of(param))
         if rc == 801:
             return False
         _lib.check(rc, "tv_adam_dense")
@@ -55,7 +57,7 @@ def tv_adam_dense(param, param_out, grad, exp_avg, exp_avg_sq, wx, wy, wz, step,
     with _lib.guard(param.device):
         rc = _L.ugrid_tv_adam_dense(_lib.ptr(param), _lib.ptr(param_out), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
                                     float(wx), float(wy), float(wz), sz_i, sz_j, sz_k, param.numel(), int(step), float(beta1),
-                                    float(beta2), float(lr), float(eps), int(bool(skip_zero_grad)), _lib.stream_of(param))
+                                    float(beta2), float(lr), float(eps), flags, _lib.stream_of(param))
     if rc == 801:      # hipErrorNotSupported
         return False
     _lib.check(rc, "tv_adam_dense")

@@ -430,6 +430,12 @@ template <bool NT> __device__ __forceinline__ void ug_st4(float *p, float a, flo
   else *(float4 *)p = make_float4(a, b, c, d);
 }
 
+// true for all 8 lanes of a 128-byte line (8 consecutive float4 lanes) when any of them says so: whole-line stores
+__device__ __forceinline__ bool ug_line_any(bool mine) {
+  const unsigned long long m = __ballot(mine);
+  return ((m >> (__lane_id() & ~7u)) & 0xFFull) != 0;
+}
+
 template <int XCD>
 __device__ __forceinline__ unsigned ug_xcd_block() {
   unsigned b = blockIdx.x;
@@ -632,11 +638,14 @@ template <bool MASKED, int XCD = 0>
 __global__ void __launch_bounds__(256)
 k_tv_adam_vec4(const float *__restrict__ param, float *__restrict__ param_out, const float *__restrict__ grad,
                float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, float wy, float wz, int sz_i, int sz_j,
-               int sz_k, unsigned n4, float step_size, float beta1, float beta2, float eps) {
+               int sz_k, unsigned n4, float step_size, float beta1, float beta2, float eps, int rezero) {
   const unsigned q = ug_xcd_block<XCD>() * blockDim.x + threadIdx.x;
   if (q >= n4) return;
   const unsigned idx = q * 4u;
   const float4 g0 = ug_ld4<XCD == 2>(grad + idx);
+  // rezero: the gradient buffer goes back to the zero pool (_gradpool.py) -- only the touched 128-byte lines are written
+  if (rezero && ug_line_any(g0.x != 0.f || g0.y != 0.f || g0.z != 0.f || g0.w != 0.f))
+    *(float4 *)(const_cast<float *>(grad) + idx) = make_float4(0.f, 0.f, 0.f, 0.f);
   const unsigned k4 = (unsigned)sz_k >> 2;
   const unsigned kq = q % k4, row = q / k4;
   const unsigned j = row % (unsigned)sz_j, i = (row / (unsigned)sz_j) % (unsigned)sz_i;
@@ -722,7 +731,7 @@ template <bool DENSE, int ADAM, int XCD = 0>
 __global__ void __launch_bounds__(256)
 k_tv_cl_vec4(const float *__restrict__ param, float *__restrict__ param_out, float *__restrict__ grad,
              float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, float wy, float wz, int sz_i, int sz_j,
-             int sz_k, int C, unsigned n4, float step_size, float beta1, float beta2, float eps) {
+             int sz_k, int C, unsigned n4, float step_size, float beta1, float beta2, float eps, int rezero) {
   const unsigned q = ug_xcd_block<XCD>() * blockDim.x + threadIdx.x;
   if (q >= n4) return;
   const unsigned idx = q * 4u;
@@ -771,6 +780,8 @@ k_tv_cl_vec4(const float *__restrict__ param, float *__restrict__ param_out, flo
     ug_st4<XCD == 2>(param_out + idx, pv[0], pv[1], pv[2], pv[3]);
     ug_st4<XCD == 2>(exp_avg + idx, mv[0], mv[1], mv[2], mv[3]);
     ug_st4<XCD == 2>(exp_avg_sq + idx, vv[0], vv[1], vv[2], vv[3]);
+    if (rezero && ug_line_any(g0.x != 0.f || g0.y != 0.f || g0.z != 0.f || g0.w != 0.f))
+      *(float4 *)(grad + idx) = make_float4(0.f, 0.f, 0.f, 0.f);
   } else {
     *(float4 *)(grad + idx) = make_float4(out[0], out[1], out[2], out[3]);
   }
@@ -986,13 +997,13 @@ extern "C" int ugrid_total_variation_add_grad_cl(const float *param, float *grad
   const unsigned n4 = (unsigned)(N / 4);
   if (dense_mode && g_tv_xcd)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 0, 1>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, nullptr, grad,
-                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f);
+                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f, 0);
   else if (dense_mode)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 0>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, nullptr, grad,
-                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f);
+                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f, 0);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<false, 0>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, nullptr, grad,
-                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f);
+                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f, 0);
   UG_LAUNCH_CHECK();
   return 0;
 }
@@ -1000,8 +1011,9 @@ extern "C" int ugrid_total_variation_add_grad_cl(const float *param, float *grad
 extern "C" int ugrid_tv_adam_dense_cl(const float *param, float *param_out, const float *grad, float *exp_avg,
                                       float *exp_avg_sq, float wx, float wy, float wz, int64_t sz_i, int64_t sz_j,
                                       int64_t sz_k, int64_t C, int64_t N, int step, float beta1, float beta2, float lr,
-                                      float eps, int skip_zero_grad, ugrid_stream_t s) {
+                                      float eps, int flags, ugrid_stream_t s) {
   if (N <= 0) return 0;
+  const int skip_zero_grad = flags & 1, rezero = (flags >> 1) & 1;
   (void)wx;
   const uintptr_t al = (uintptr_t)param | (uintptr_t)param_out | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq;
   if (C % 4 != 0 || N >= ((int64_t)1 << 31) || (al & 15) != 0 || param == param_out) return (int)hipErrorNotSupported;
@@ -1011,7 +1023,7 @@ extern "C" int ugrid_tv_adam_dense_cl(const float *param, float *param_out, cons
   const unsigned n4 = (unsigned)(N / 4);
   float *g = const_cast<float *>(grad);   // ADAM != 0 never writes the gradient
   const dim3 gr((n4 + 255) / 256), bl(256);
-#define UG_TV_CL_ARGS param, param_out, g, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, step_size, beta1, beta2, eps
+#define UG_TV_CL_ARGS param, param_out, g, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, step_size, beta1, beta2, eps, rezero
   if (g_tv_xcd == 2) {
     if (skip_zero_grad) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 1, 2>), gr, bl, 0, ST(s), UG_TV_CL_ARGS);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 2, 2>), gr, bl, 0, ST(s), UG_TV_CL_ARGS);
@@ -1044,8 +1056,9 @@ extern "C" int ugrid_rays_of_a_view(int32_t H, int32_t W, const float *h_K9, con
 extern "C" int ugrid_tv_adam_dense(const float *param, float *param_out, const float *grad, float *exp_avg,
                                    float *exp_avg_sq, float wx, float wy, float wz, int64_t sz_i, int64_t sz_j,
                                    int64_t sz_k, int64_t N, int step, float beta1, float beta2, float lr, float eps,
-                                   int skip_zero_grad, ugrid_stream_t s) {
+                                   int flags, ugrid_stream_t s) {
   if (N <= 0) return 0;
+  const int skip_zero_grad = flags & 1, rezero = (flags >> 1) & 1;
   (void)wx;
   const uintptr_t al = (uintptr_t)param | (uintptr_t)param_out | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq;
   if (sz_k % 4 != 0 || N >= ((int64_t)1 << 31) || sz_i * sz_j * sz_k <= 0 || (al & 15) != 0 || param == param_out)
@@ -1055,7 +1068,7 @@ extern "C" int ugrid_tv_adam_dense(const float *param, float *param_out, const f
   const float step_size = lr * sqrtf(1 - powf(beta2, (float)step)) / (1 - powf(beta1, (float)step));
   const unsigned n4 = (unsigned)(N / 4);
   const dim3 gr((n4 + 255) / 256), bl(256);
-#define UG_TV_ARGS param, param_out, grad, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, n4, step_size, beta1, beta2, eps
+#define UG_TV_ARGS param, param_out, grad, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, n4, step_size, beta1, beta2, eps, rezero
   if (g_tv_xcd == 2) {
     if (skip_zero_grad) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_adam_vec4<true, 2>), gr, bl, 0, ST(s), UG_TV_ARGS);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_adam_vec4<false, 2>), gr, bl, 0, ST(s), UG_TV_ARGS);

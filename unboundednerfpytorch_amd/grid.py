@@ -8,7 +8,7 @@
 import torch
 import torch.nn.functional as F
 
-from . import _lib, render_utils_cuda
+from . import _gradpool, _lib, render_utils_cuda
 
 _L = _lib.load()
 
@@ -50,6 +50,7 @@ class GridQuery(torch.autograd.Function):
             ctx.shape = tuple(grid.shape)
             ctx.freq_num = max(int(freq_num), 0)
             ctx.channels_last = _lib.is_channels_last(grid)    # the gradient is produced in the grid's own layout
+            ctx.pool_key, ctx.grid_stride = _gradpool.key_of(grid), tuple(grid.stride())
         return out
 
     @staticmethod
@@ -58,7 +59,9 @@ class GridQuery(torch.autograd.Function):
         pts, xyz_min, xyz_max = ctx.saved_tensors
         P, C, X, Y, Z = ctx.shape
         g = grad_out.reshape(-1, C).to(torch.float32).contiguous()
-        grad_grid = _lib.empty_like_grid(ctx.shape, ctx.channels_last, g.device, zero=True)
+        grad_grid = _gradpool.take(ctx.pool_key, ctx.shape, ctx.grid_stride, g.device)    # all zero, from the last step
+        if grad_grid is None:
+            grad_grid = _lib.empty_like_grid(ctx.shape, ctx.channels_last, g.device, zero=True)
         fn = _L.ugrid_grid_query_backward_cl if ctx.channels_last else _L.ugrid_grid_query_backward
         with _lib.guard(g.device):
             _lib.check(fn(_lib.ptr(g), P, C, X, Y, Z, _lib.ptr(pts), _lib.ptr(xyz_min),
@@ -120,6 +123,7 @@ class TrainMarch(torch.autograd.Function):
                                                   _lib.ptr(step_id), _lib.ptr(tt), st), "train_compact")
         ctx.save_for_backward(pts, xyz_min, xyz_max)
         ctx.shape, ctx.freq_num = tuple(grid.shape), F_
+        ctx.pool_key, ctx.grid_stride = _gradpool.key_of(grid), tuple(grid.stride())
         ctx.mark_non_differentiable(pts, ray_id, step_id, tt)
         return pts, dens, ray_id, step_id, tt
 
@@ -128,7 +132,9 @@ class TrainMarch(torch.autograd.Function):
     def backward(ctx, g_pts, g_dens, g_ray, g_step, g_t):
         pts, xyz_min, xyz_max = ctx.saved_tensors
         P, C, X, Y, Z = ctx.shape
-        grad_grid = torch.zeros(ctx.shape, dtype=torch.float32, device=pts.device)
+        grad_grid = _gradpool.take(ctx.pool_key, ctx.shape, ctx.grid_stride, pts.device)
+        if grad_grid is None:
+            grad_grid = torch.zeros(ctx.shape, dtype=torch.float32, device=pts.device)
         if pts.shape[0] > 0:
             g = g_dens.reshape(-1, 1).to(torch.float32).contiguous()
             with _lib.guard(g.device):

@@ -18,6 +18,8 @@ gradient bit for bit when N is a power of two.
 import torch
 import torch.distributed as dist
 
+from . import _gradpool
+
 
 class ShardedMaskedAdam(torch.optim.Optimizer):
     """Same constructor and param-group keys as MaskedAdam (`skip_zero_grad` per group, masked_adam.py:21-41) plus
@@ -32,6 +34,8 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
             raise ValueError("Invalid epsilon value: {}".format(eps))
         if not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
             raise ValueError("Invalid beta parameters: {}".format(betas))
+        # gradient buffers of grid parameters recycled through _gradpool (the HIP ops' fused dense TV + Adam pass only)
+        self.recycle_grads = ops is None
         if ops is None:
             from . import adam_upd_cuda as ops
         self.ops = ops
@@ -90,11 +94,17 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
             if alt is None or alt.shape != param.shape or alt.device != param.device or alt.stride() != param.stride():
                 alt = torch.empty_like(param.data, memory_format=torch.preserve_format)
             beta1, beta2 = group['betas']
+            # the gradient buffer comes back all zero and is parked for the next backward (_gradpool): no zero fill per step
+            recycle = self.recycle_grads and g is param.grad
+            kw = {'rezero_grad': True} if recycle else {}
             if fused_fn(param.data, alt, g, state['exp_avg'], state['exp_avg_sq'], w, w, w,
                                                        state['step'], beta1, beta2, group['lr'], group['eps'],
-                                                       group['skip_zero_grad']):
+                                                       group['skip_zero_grad'], **kw):
                 self._alt[param] = param.data
                 param.data = alt
+                if recycle:
+                    param.grad = None
+                    _gradpool.give(param, g)
                 return
         if tv_module is None:
             from . import total_variation_cuda as tv_module
