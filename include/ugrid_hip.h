@@ -197,6 +197,28 @@ int ugrid_tv_adam_dense_cl(const float *param, float *param_out, const float *gr
                            int step, float beta1, float beta2, float lr, float eps, int flags,
                            ugrid_stream_t stream);
 
+/* NEW (no reference counterpart; training tail): sigmoid + per-ray compositing + the loss of run_train.py:254-279 in
+ * one pass, and its derivative -- replaces FourierGrid_model.py:636-647 (sigmoid, weights * rgb, segment_coo, background)
+ * and run_train.py:254-279 (mse_loss, entropy_last, nearclip, flatten_eff_distloss, rgbper): ~45 + ~90 launches of the
+ * composed chain.  ray_id ascending (the model's compaction is ray-major); logits [n,3] are the rgbnet outputs before the
+ * sigmoid; bg [n_rays,3] the rand_bkgd draw or NULL; target [n_rays,3]; s may be NULL: s_i = 1 - 1/(1 + t_i) then
+ * (FourierGrid_model.py:649).
+ * h_coef8 (HOST floats): weight_main, weight_entropy_last, weight_distortion, weight_rgbper, weight_nearclip (times the
+ * data-parallel world size), near_thres, interval (= 1/n_max), n_rays (the rgbper denominator).  A weight of 0 disables
+ * its term.  seg_scratch: 2*n_rays int64 (filled by the forward, read by the backward); rgb_marched [n_rays,3];
+ * ray_tot [n_rays,2] (per-ray sums of w and w*s); partial [n_rays,4]; out2 = {loss, mse} on the device.
+ * backward: grad_loss = the incoming scalar gradient (device); writes g_logits [n,3], g_weights [n], g_alphainv_last
+ * [n_rays], g_density [n] (the nearclip term's only effect). */
+int ugrid_render_loss(const float *logits, const float *weights, const float *s, const float *t, const float *alphainv_last,
+                      const float *bg, const float *target, const int64_t *ray_id, int64_t n, int64_t n_rays,
+                      const float *h_coef8, int64_t *seg_scratch, float *rgb_marched, float *ray_tot, float *partial,
+                      float *out2, ugrid_stream_t stream);
+int ugrid_render_loss_backward(const float *logits, const float *weights, const float *s, const float *t,
+                               const float *alphainv_last, const float *bg, const float *target, const int64_t *ray_id,
+                               int64_t n, int64_t n_rays, const float *h_coef8, const int64_t *seg_scratch,
+                               const float *rgb_marched, const float *ray_tot, const float *grad_loss, float *g_logits,
+                               float *g_weights, float *g_alphainv_last, float *g_density, ugrid_stream_t stream);
+
 /* Brick packing: canonical [P,C,X,Y,Z] -> cell-major 2x2x2 bricks, one contiguous record per
  * trilinear cell: [P*(X-1)(Y-1)(Z-1)][H halves][...] with
  *   C == 1 (density)        : H = 1, [8 entries]                          (32 B / cell)

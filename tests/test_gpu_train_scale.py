@@ -215,3 +215,44 @@ def test_gradient_buffers_are_recycled_all_zero_between_steps():
         diff = (params[0][k] - params[1][k]).abs()
         lr = 0.1 if "grid" in k else 1e-3
         assert float((diff > 0.02 * lr).float().mean()) < 1e-4, (k, float(diff.max()))
+
+
+@pytest.mark.parametrize("rand_bkgd", [False, True])
+def test_fused_render_loss_equals_the_composed_tail(rand_bkgd):
+    """ops.RenderLoss (sigmoid + compositing + background + the five loss terms of run_train.py:254-279 in one op, with a
+    hand-written backward) against the torch chain of the same model (FourierGridModel.forward's tail +
+    train_step.training_loss): loss, mse, rgb_marched and every parameter gradient."""
+    import bench_train_step as bts
+    from unboundednerfpytorch_amd import ops, train_step as ts
+    dev = torch.device("cuda", 0)
+    m = build(dev)
+    cfg = dict(bts.TRUCK_CFG)
+    cfg.update(weight_nearclip=0.3, weight_distortion=0.01, weight_rgbper=0.01, weight_entropy_last=0.001)
+    o, d, v, rgb = bts.random_rays(3000, dev, seed=8)
+    near = 0.2
+    kw = dict(stepsize=0.5, rand_bkgd=rand_bkgd)
+    res = []
+    for fused in (True, False):
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(5)
+        if fused:
+            coef = ops.loss_coefficients(cfg, len(o), m.sample_table(0.5, dev).numel(), near, 2)
+            out = m(o, d, v, global_step=1, is_train=True, fused_loss={"target": rgb, "coef": coef}, **kw)
+            loss, mse = out["loss"], out["mse"]
+            assert "raw_rgb" not in out
+        else:
+            out = m(o, d, v, global_step=1, is_train=True, **kw)
+            loss, mse = ts.training_loss(out, rgb, cfg, len(o), near, None, 2)
+        loss.backward()
+        res.append((float(loss), float(mse), out["rgb_marched"].detach().clone(),
+                    {k: p.grad.clone() for k, p in m.named_parameters()}))
+    (la, ma, ra, ga), (lb, mb, rb, gb) = res
+    assert abs(la - lb) <= 2e-6 * max(1.0, abs(lb)) and abs(ma - mb) <= 2e-6 * max(1.0, mb), (la, lb, ma, mb)
+    assert float((ra - rb).abs().max()) <= 2e-6
+    for k in ga:
+        scale = float(gb[k].abs().max()) + 1e-30
+        err = float((ga[k] - gb[k]).abs().max())
+        assert err <= 2e-3 * scale, (k, err, scale)
+        if "grid" in k:
+            odd = (ga[k] != 0) ^ (gb[k] != 0)
+            assert int(odd.sum()) <= 1024, (k, int(odd.sum()))

@@ -70,12 +70,14 @@ def main():
     ap.add_argument("--freq", type=int, default=4)
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--fused-loss", type=int, default=1, help="compositing + loss as one op (ops.RenderLoss) or the torch chain")
     ap.add_argument("--channels-last", type=int, default=1, help="k0 stored [P][X][Y][Z][C] (the training layout) or row-major")
     args = ap.parse_args()
     from unboundednerfpytorch_amd import train_step as ts
     from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
     dev = torch.device("cuda", 0)
     model = make_model(args.grid, args.freq, dev, args.fused, args.channels_last)
+    model.fused_loss = bool(args.fused_loss)
     opt = create_optimizer_or_freeze_model(model, TRUCK_CFG, global_step=0)
     rk = dict(stepsize=0.5, rand_bkgd=True)
     timers = None
@@ -101,7 +103,7 @@ def main():
     res = {"workload": "S3: truck_single-shaped train step, P=%d, G=%d^3, C=12, %d random rays x S=%d, stepsize 0.5, dense TV + masked Adam"
                        % (1 + 2 * args.freq, args.grid, args.rays, S),
            "fused_forward": bool(getattr(model, "fused_forward", False)),
-           "k0_channels_last": not model.k0.grid.is_contiguous(),
+           "k0_channels_last": not model.k0.grid.is_contiguous(), "fused_loss": bool(args.fused_loss),
            "ms_per_step": total, "phases_ms": ms, "steps": args.steps, "survivors_M": M, "samples": args.rays * S,
            "rays_per_sec": args.rays / (total * 1e-3), "k0_voxels": n_k0,
            "k0_streaming_floor_ms": {"note": "compulsory HBM passes over the 3.46 GB k0-sized arrays per step at 6.3 TB/s achievable: "

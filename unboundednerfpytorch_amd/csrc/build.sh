@@ -6,7 +6,7 @@ cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include"
 mkdir -p ../../build/obj
 O=../../build/obj
-rm -f $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_gather_exp.o   # a failed compile must not link a stale object
+rm -f $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_gather_exp.o $O/ugrid_train.o   # a failed compile must not link a stale object
 pids=()
 hipcc $FLAGS -c ugrid_ops.hip -o $O/ugrid_ops.o "$@" &
 pids+=($!)
@@ -18,5 +18,7 @@ hipcc $FLAGS -fno-slp-vectorize ${UG_SHADE_FLAGS} -c ugrid_shade.hip -o $O/ugrid
 pids+=($!)
 hipcc $FLAGS -fno-slp-vectorize -c ugrid_gather_exp.hip -o $O/ugrid_gather_exp.o "$@" &
 pids+=($!)
+hipcc $FLAGS -c ugrid_train.hip -o $O/ugrid_train.o "$@" &
+pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done   # a bare `wait` returns 0 even when a job failed
-hipcc --offload-arch=gfx950 -shared -fPIC -o ${UG_OUT:-../libugrid_hip.so} $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_gather_exp.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o ${UG_OUT:-../libugrid_hip.so} $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_gather_exp.o $O/ugrid_train.o

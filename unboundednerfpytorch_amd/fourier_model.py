@@ -44,6 +44,7 @@ class FourierGridModel(nn.Module):
         self.fused_forward = backend is None
         self.channels_last_grids = backend is None and kwargs.get('channels_last_grids', True)
         self.splitk_rgbnet = backend is None       # ops.SplitKLinear weight gradients (training on the GPU only)
+        self.fused_loss = backend is None          # train_step.train_iteration: compositing + loss as ops.RenderLoss
         lo_s, hi_s = torch.Tensor(xyz_min), torch.Tensor(xyz_max)
         self.register_buffer('scene_center', (lo_s + hi_s) * 0.5)
         self.register_buffer('scene_radius', (hi_s - lo_s) * 0.5)
@@ -285,6 +286,7 @@ class FourierGridModel(nn.Module):
         else:
             pts, weights = pts.reshape(-1, 3), weights.reshape(-1)
         k0 = self.k0(pts)
+        fused_loss = render_kwargs.get('fused_loss')
         if self.rgbnet is None:
             rgb = torch.sigmoid(k0)
         else:
@@ -292,9 +294,19 @@ class FourierGridModel(nn.Module):
             emb = torch.cat([viewdirs, e.sin(), e.cos()], -1).flatten(0, -2)[ray_id]
             feat = torch.cat([k0, emb], -1)
             if self.splitk_rgbnet and feat.is_cuda and torch.is_grad_enabled():
-                rgb = torch.sigmoid(_ops.sequential_splitk(self.rgbnet, feat))
+                logits = _ops.sequential_splitk(self.rgbnet, feat)
             else:
-                rgb = torch.sigmoid(self.rgbnet(feat))
+                logits = self.rgbnet(feat)
+            if fused_loss is not None and logits.is_cuda and self.splitk_rgbnet:
+                # training tail as ONE op (ops.RenderLoss): sigmoid, compositing, background and the loss terms of
+                # run_train.py:254-279.  fused_loss = {'target': [R,3], 'coef': ops.loss_coefficients(...)}
+                bg = torch.rand(R, 3, device=dev) if render_kwargs.get('rand_bkgd', False) else None
+                loss, mse, rgb_marched = _ops.RenderLoss.apply(logits, weights, alphainv_last, density, ray_id, tt, None,
+                                                               fused_loss['target'], bg, fused_loss['coef'])
+                return {'alphainv_last': alphainv_last, 'weights': weights, 'rgb_marched': rgb_marched, 'raw_density': density,
+                        'raw_alpha': alpha, 'raw_logits': logits, 'ray_id': ray_id, 'step_id': step_id, 'n_max': S, 't': tt,
+                        'loss': loss, 'mse': mse}
+            rgb = torch.sigmoid(logits)
         rgb_marched = torch.zeros(R, 3, device=dev).index_add_(0, ray_id, weights.unsqueeze(-1) * rgb)
         if render_kwargs.get('rand_bkgd', False):
             rgb_marched = rgb_marched + alphainv_last.unsqueeze(-1) * torch.rand_like(rgb_marched)

@@ -8,7 +8,9 @@ same value and whose backward IS the derivative of that forward (divided by n_ra
 flatten_eff_distloss below, the default of train_step.training_loss."""
 import torch
 
-from . import render_utils_cuda, ub360_utils_cuda
+from . import _lib, render_utils_cuda, ub360_utils_cuda
+
+_L = _lib.load()
 
 
 class Raw2Alpha(torch.autograd.Function):
@@ -172,3 +174,81 @@ def sequential_splitk(net, x):
         else:
             x = layer(x)
     return x
+
+
+class RenderLoss(torch.autograd.Function):
+    """Training tail in one op (include/ugrid_hip.h: ugrid_render_loss): rgb = sigmoid(logits), rgb_marched = per-ray
+    sum of weights * rgb + alphainv_last * bg, and the loss of run_train.py:254-279 (main MSE, entropy_last, nearclip,
+    flatten_eff_distloss with interval = 1 / n_max, rgbper) -- what fourier_model.FourierGridModel.forward's tail and
+    train_step.training_loss compute with ~45 torch launches (and ~90 in the backward).  ray_id must be ascending.
+
+    forward(logits [M,3], weights [M], alphainv_last [R], raw_density [M], ray_id [M], t [M], s [M] or None (then
+            s = 1 - 1/(1+t)), target [R,3], bg [R,3] or None, coef) -> loss (scalar), mse (scalar, no gradient), rgb_marched [R,3] (no gradient)
+    coef = (weight_main, weight_entropy_last, weight_distortion, weight_rgbper, weight_nearclip * world_size, near_thres,
+            interval, n_rays); gradients flow to logits, weights, alphainv_last and raw_density."""
+
+    @staticmethod
+    def forward(ctx, logits, weights, alphainv_last, raw_density, ray_id, t, s, target, bg, coef):
+        import ctypes
+        named = [("logits", logits), ("weights", weights), ("alphainv_last", alphainv_last), ("t", t), ("target", target)]
+        if s is not None:
+            named.append(("s", s))
+        _lib.require_cuda(*named, ("ray_id", ray_id))
+        _lib.require_f32(*named)
+        M, R = weights.shape[0], alphainv_last.shape[0]
+        if logits.shape != (M, 3) or target.shape != (R, 3) or ray_id.dtype != torch.int64 or (bg is not None and bg.shape != (R, 3)):
+            raise RuntimeError("RenderLoss: logits [M,3], weights [M], ray_id int64 [M], alphainv_last [R], target / bg [R,3]")
+        dev = logits.device
+        logits, weights, alphainv_last, t, target = (x.contiguous() for x in (logits, weights, alphainv_last, t, target))
+        s = s.contiguous() if s is not None else None
+        bg = bg.contiguous() if bg is not None else None
+        ray_id = ray_id.contiguous()
+        h = (ctypes.c_float * 8)(*[float(x) for x in coef])
+        seg = torch.empty(2 * R, dtype=torch.int64, device=dev)
+        rgb_marched = torch.empty(R, 3, device=dev)
+        ray_tot = torch.empty(R, 2, device=dev)
+        partial = torch.empty(R, 4, device=dev)
+        out2 = torch.empty(2, device=dev)
+        with _lib.guard(dev):
+            _lib.check(_L.ugrid_render_loss(_lib.ptr(logits), _lib.ptr(weights), _lib.ptr(s) if s is not None else None, _lib.ptr(t),
+                                            _lib.ptr(alphainv_last),
+                                            _lib.ptr(bg) if bg is not None else None, _lib.ptr(target), _lib.ptr(ray_id), M, R,
+                                            ctypes.cast(h, ctypes.c_void_p), _lib.ptr(seg), _lib.ptr(rgb_marched), _lib.ptr(ray_tot),
+                                            _lib.ptr(partial), _lib.ptr(out2), _lib.stream_of(logits)), "render_loss")
+        ctx.save_for_backward(logits, weights, alphainv_last, ray_id, t, target, seg, rgb_marched, ray_tot)
+        ctx.bg, ctx.h, ctx.s = bg, h, s
+        loss, mse = out2[0], out2[1]
+        ctx.mark_non_differentiable(mse, rgb_marched)
+        return loss, mse, rgb_marched
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_loss, g_mse, g_rm):
+        import ctypes
+        logits, weights, alphainv_last, ray_id, t, target, seg, rgb_marched, ray_tot = ctx.saved_tensors
+        s = ctx.s
+        M, R = weights.shape[0], alphainv_last.shape[0]
+        g_loss = g_loss.to(torch.float32).reshape(1).contiguous()
+        g_logits, g_w, g_ainv, g_dens = torch.empty_like(logits), torch.empty_like(weights), torch.empty_like(alphainv_last), \
+            torch.empty_like(weights)
+        with _lib.guard(logits.device):
+            _lib.check(_L.ugrid_render_loss_backward(
+                _lib.ptr(logits), _lib.ptr(weights), _lib.ptr(s) if s is not None else None, _lib.ptr(t), _lib.ptr(alphainv_last),
+                _lib.ptr(ctx.bg) if ctx.bg is not None else None, _lib.ptr(target), _lib.ptr(ray_id), M, R,
+                ctypes.cast(ctx.h, ctypes.c_void_p), _lib.ptr(seg), _lib.ptr(rgb_marched), _lib.ptr(ray_tot), _lib.ptr(g_loss),
+                _lib.ptr(g_logits), _lib.ptr(g_w), _lib.ptr(g_ainv), _lib.ptr(g_dens), _lib.stream_of(logits)), "render_loss_backward")
+        return g_logits, g_w, g_ainv, g_dens, None, None, None, None, None, None
+
+
+def loss_coefficients(cfg_train, n_rays, n_max, near_thres=None, world_size=1):
+    """the coef tuple of RenderLoss from a cfg_train (dict or attribute object, run_train.py:254-279), or None when the
+    configuration uses a term the fused op does not implement (weight_freq: the image-space Fourier loss)"""
+    get = (lambda k, d=0.0: cfg_train.get(k, d)) if isinstance(cfg_train, dict) else (lambda k, d=0.0: getattr(cfg_train, k, d))
+    if get('weight_freq', 0.0):
+        return None
+    w_near = get('weight_nearclip', 0.0)
+    if w_near > 0 and near_thres is None:
+        return None
+    return (get('weight_main', 1.0), max(get('weight_entropy_last', 0.0), 0.0), max(get('weight_distortion', 0.0), 0.0),
+            max(get('weight_rgbper', 0.0), 0.0), (w_near * world_size) if w_near > 0 else 0.0,
+            near_thres if near_thres is not None else 0.0, 1.0 / n_max, float(n_rays))

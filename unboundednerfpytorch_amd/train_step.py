@@ -86,11 +86,22 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
     REDUCED gradient (grad_hook), so its masked mode sees the voxels any rank touched: the data-parallel step equals
     the single-process step on the whole batch in both TV phases (tests/test_host_logic.py)."""
     _mark(timers, "start")
-    out = model(rays_o, rays_d, viewdirs, global_step=global_step, is_train=True, **render_kwargs)
+    n_rays = len(rays_o)
+    kw = render_kwargs
+    if distortion_fn is None and getattr(model, 'fused_loss', False) and rays_o.is_cuda:
+        # the HIP model composites and evaluates the loss in one op (ops.RenderLoss); n_max is known before the forward
+        from .ops import loss_coefficients
+        coef = loss_coefficients(cfg_train, n_rays, model.sample_table(render_kwargs['stepsize'], rays_o.device).numel(),
+                                 near_thres, world_size)
+        if coef is not None:
+            kw = dict(render_kwargs, fused_loss={'target': target, 'coef': coef})
+    out = model(rays_o, rays_d, viewdirs, global_step=global_step, is_train=True, **kw)
     _mark(timers, "forward")
     optimizer.zero_grad(set_to_none=True)
-    n_rays = len(rays_o)
-    loss, mse = training_loss(out, target, cfg_train, n_rays, near_thres, distortion_fn, world_size)
+    if 'loss' in out:
+        loss, mse = out['loss'], out['mse']
+    else:
+        loss, mse = training_loss(out, target, cfg_train, n_rays, near_thres, distortion_fn, world_size)
     _mark(timers, "loss")
     loss.backward()
     _mark(timers, "backward")
