@@ -256,3 +256,31 @@ def test_fused_render_loss_equals_the_composed_tail(rand_bkgd):
         if "grid" in k:
             odd = (ga[k] != 0) ^ (gb[k] != 0)
             assert int(odd.sum()) <= 1024, (k, int(odd.sum()))
+
+
+def test_k0_update_on_the_side_stream_gives_the_same_training():
+    """train_iteration(overlap_k0_update=True): the k0 TV + Adam pass runs on a second stream beside the next forward's
+    density march; parameters read through state_dict() (which waits for the pending update) after four steps equal those
+    of the in-order run, and the pending event is consumed by the next forward."""
+    import bench_train_step as bts
+    from unboundednerfpytorch_amd import train_step as ts
+    from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
+    dev = torch.device("cuda", 0)
+    params = []
+    for overlap in (True, False):
+        torch.manual_seed(0)
+        m = build(dev)
+        opt = create_optimizer_or_freeze_model(m, bts.TRUCK_CFG, global_step=0)
+        for s in (1, 2, 3, 4):
+            o, d, v, rgb = bts.random_rays(2048, dev, seed=30 + s)
+            ts.train_iteration(m, opt, o, d, v, rgb, bts.TRUCK_CFG, s, dict(stepsize=0.5, rand_bkgd=False), overlap_k0_update=overlap)
+            assert (getattr(m.k0.grid, "_ug_pending", None) is not None) == overlap
+        sd = m.state_dict()
+        assert getattr(m.k0.grid, "_ug_pending", None) is None
+        params.append({k: v.detach().clone() for k, v in sd.items() if v.dtype == torch.float32})
+        osd = opt.state_dict()
+        params[-1].update({"opt%d.%s" % (i, k): v.clone() for i, st in osd["state"].items() for k, v in st.items() if torch.is_tensor(v)})
+    for k in params[0]:
+        diff = (params[0][k] - params[1][k]).abs()
+        lr = 0.1 if "grid" in k else 1e-3
+        assert float((diff > 0.02 * lr).float().mean()) < 1e-4, (k, float(diff.max()))

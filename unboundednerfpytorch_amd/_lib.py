@@ -183,6 +183,15 @@ def require_cuda_grid(*named):
     return all(cl) and len(cl) > 0
 
 
+def wait_pending(param):
+    """A grid parameter whose optimizer update was queued on a side stream (ShardedMaskedAdam.step(overlap=...)) carries
+    the completion event in `_ug_pending`: make the current stream wait for it before the parameter is touched."""
+    ev = getattr(param, '_ug_pending', None)
+    if ev is not None:
+        torch.cuda.current_stream(param.device).wait_event(ev)
+        param._ug_pending = None
+
+
 def empty_like_grid(shape, channels_last, device, zero=False):
     fmt = torch.channels_last_3d if channels_last else torch.contiguous_format
     t = torch.empty(tuple(shape), dtype=torch.float32, device=device, memory_format=fmt)

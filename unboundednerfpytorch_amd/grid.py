@@ -193,9 +193,15 @@ class FourierGrid(torch.nn.Module):
     def forward(self, xyz):
         """xyz [..., 3] world coordinates -> [..., C] (squeezed when C == 1)"""
         q = self.query_fn or GridQuery.apply
+        _lib.wait_pending(self.grid)
         return q(self.grid, xyz, self.xyz_min, self.xyz_max, self.nerf_pos_num_freq)
 
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        _lib.wait_pending(self.grid)
+        super()._save_to_state_dict(destination, prefix, keep_vars)
+
     def scale_volume_grid(self, new_world_size):
+        _lib.wait_pending(self.grid)
         if self.channels == 0:
             self.grid = torch.nn.Parameter(torch.zeros([1, self.channels, *new_world_size]))
         else:
@@ -207,13 +213,16 @@ class FourierGrid(torch.nn.Module):
         tv = self.tv_module
         if tv is None:
             from . import total_variation_cuda as tv
+        _lib.wait_pending(self.grid)
         tv.total_variation_add_grad(self.grid, self.grid.grad, wx, wy, wz, dense_mode)
 
     def get_dense_grid(self):
+        _lib.wait_pending(self.grid)
         return self.grid
 
     @torch.no_grad()
     def __isub__(self, val):
+        _lib.wait_pending(self.grid)
         self.grid.data -= val
         return self
 

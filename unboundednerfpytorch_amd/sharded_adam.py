@@ -19,6 +19,14 @@ import torch
 import torch.distributed as dist
 
 from . import _gradpool
+from ._lib import wait_pending as _lib_wait
+
+
+def _low_priority_stream():
+    """the side stream of step(overlap=...): the lowest priority the device offers (torch maps an out-of-range value to
+    the nearest valid one), so that the caller's stream -- the next forward's latency-bound kernels -- is served first
+    and the bandwidth-bound update fills what is left"""
+    return torch.cuda.Stream(priority=1)
 
 
 class ShardedMaskedAdam(torch.optim.Optimizer):
@@ -83,7 +91,7 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         else:
             self.ops.adam_upd(p, g, m, v, *args)
 
-    def _tv_then_update(self, group, param, g, state, tv, use_perlr):
+    def _tv_then_update(self, group, param, g, state, tv, use_perlr, side=None):
         """Total-variation term (w, dense_mode, tv_module) on the reduced gradient `g`, then the Adam update.  Dense mode
         on the HIP ops: ONE fused pass (adam_upd_cuda.tv_adam_dense -- 7 instead of 13 array transfers, the gradient is
         not written back, bit-identical results); the new parameter values land in a second buffer that is swapped in."""
@@ -97,9 +105,21 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
             # the gradient buffer comes back all zero and is parked for the next backward (_gradpool): no zero fill per step
             recycle = self.recycle_grads and g is param.grad
             kw = {'rezero_grad': True} if recycle else {}
-            if fused_fn(param.data, alt, g, state['exp_avg'], state['exp_avg_sq'], w, w, w,
-                                                       state['step'], beta1, beta2, group['lr'], group['eps'],
-                                                       group['skip_zero_grad'], **kw):
+            args = (param.data, alt, g, state['exp_avg'], state['exp_avg_sq'], w, w, w, state['step'], beta1, beta2,
+                    group['lr'], group['eps'], group['skip_zero_grad'])
+            if side is not None:
+                # the 7-pass update of this grid on a second HIP stream: the caller's stream goes on (the next forward's
+                # density march, its host syncs, the launch-bound glue) and meets it again at _lib.wait_pending
+                side.wait_stream(torch.cuda.current_stream(param.device))
+                with torch.cuda.stream(side):
+                    done = fused_fn(*args, **kw)
+                    if done:
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        param._ug_pending = ev
+            else:
+                done = fused_fn(*args, **kw)
+            if done:
                 self._alt[param] = param.data
                 param.data = alt
                 if recycle:
@@ -113,20 +133,29 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                      self.per_lr if use_perlr else None)
 
     @torch.no_grad()
-    def step(self, grad_hook=None, tv_terms=None):
+    def step(self, grad_hook=None, tv_terms=None, overlap=None):
         """grad_hook(param, grad): optional in-place edit of the REDUCED gradient before the update.  For a sharded
         parameter the hook receives a full-shape gradient that is zero outside this rank's range.
         tv_terms: optional {param: (w, dense_mode, tv_module or None)} -- the total-variation term of the training
         iteration (run_train.py:281-287), applied to the gradient summed over all ranks (a rank-local masked TV would
         give a voxel touched by k of N ranks only k/N of the term); for a replicated parameter in dense mode it is
-        fused with the update (see _tv_then_update)."""
+        fused with the update (see _tv_then_update).
+        overlap: optional collection of grid parameters whose fused dense TV + Adam pass may run on a second HIP stream
+        (single process only).  The caller's stream is not blocked by it; the parameter, its moments and its recycled
+        gradient buffer are complete once `_lib.wait_pending(param)` has been called on the consuming stream -- the grid
+        modules do that in forward / get_dense_grid / state_dict / scale_volume_grid, this optimizer in step and
+        state_dict.  Code that reads `param.data` directly must call it (or torch.cuda.synchronize()) first."""
         world, rank = self._world()
         tv_terms = tv_terms or {}
         scale = (1.0 / world) if (self.average and world > 1) else None
+        side = None
+        if overlap and world == 1:
+            side = self._side = getattr(self, '_side', None) or _low_priority_stream()
         for group in self.param_groups:
             for param in group['params']:
                 if param.grad is None:
                     continue
+                _lib_wait(param)
                 state = self.state[param]
                 n = param.numel()
                 use_perlr = self.per_lr is not None and param.shape == self.per_lr.shape
@@ -146,7 +175,8 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                         state['exp_avg_sq'] = torch.zeros_like(param, memory_format=torch.preserve_format)
                     state['step'] += 1
                     if param in tv_terms:
-                        self._tv_then_update(group, param, g, state, tv_terms[param], use_perlr)
+                        self._tv_then_update(group, param, g, state, tv_terms[param], use_perlr,
+                                             side if (side is not None and any(param is q for q in overlap)) else None)
                     else:
                         self._update(group, param, g, state['exp_avg'], state['exp_avg_sq'], state['step'],
                                      self.per_lr if use_perlr else None)
@@ -212,6 +242,12 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def state_dict(self):
+        for group in self.param_groups:
+            for param in group['params']:
+                _lib_wait(param)
+        return self._state_dict()
+
+    def _state_dict(self):
         """The reference optimizer's layout (utils.py:70-74 saves optimizer.state_dict() verbatim): `exp_avg` /
         `exp_avg_sq` in the PARAMETER's shape, no shard bookkeeping -- so a checkpoint written by a sharded run loads
         into the reference's MaskedAdam (and into MaskedAdam here) and vice versa.  COLLECTIVE when parameters are

@@ -76,7 +76,7 @@ def _mark(timers, name):
 
 
 def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_train, global_step, render_kwargs,
-                    near_thres=None, distortion_fn=None, decay_lr=True, world_size=1, timers=None):
+                    near_thres=None, distortion_fn=None, decay_lr=True, world_size=1, timers=None, overlap_k0_update=False):
     """Forward ... optimizer.step() of one global_step (call maybe_scale_grids first).  Returns (loss, psnr).
     Data-parallel use (ShardedMaskedAdam averages the ranks' gradients): pass world_size so that the total-variation
     term, which the reference scales by 1 / len(rays_o), is scaled by the GLOBAL batch size and the sum-type nearclip
@@ -84,7 +84,9 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
     rays, then mean over ranks; exact when every rank's last ray has a sample, since the distortion loss normalises by
     ray_id.max()+1 like the library).  TV itself runs inside optimizer.step on the
     REDUCED gradient (grad_hook), so its masked mode sees the voxels any rank touched: the data-parallel step equals
-    the single-process step on the whole batch in both TV phases (tests/test_host_logic.py)."""
+    the single-process step on the whole batch in both TV phases (tests/test_host_logic.py).
+    overlap_k0_update (single process, HIP optimizer): see ShardedMaskedAdam.step(overlap=...) -- same results; k0.grid
+    must then be read through the model (forward, state_dict, ...) or after torch.cuda.synchronize()."""
     _mark(timers, "start")
     n_rays = len(rays_o)
     kw = render_kwargs
@@ -122,7 +124,11 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
         if _get(cfg_train, 'weight_tv_k0', 0.0) > 0:
             tv_terms[model.k0.grid] = (float(_get(cfg_train, 'weight_tv_k0') / n_global * model.world_size_rgb.max() / 128),
                                        dense, model.k0.tv_module)
-    if tv_terms:
+    if tv_terms and overlap_k0_update and world_size == 1 and model.k0.grid in tv_terms:
+        # the k0 update (the step's largest kernel, HBM-bound, nothing before the next k0 lookup depends on it) on a second
+        # stream: it runs beside the next iteration's density march, host syncs and launch-bound glue
+        optimizer.step(tv_terms=tv_terms, overlap=[model.k0.grid])
+    elif tv_terms:
         optimizer.step(tv_terms=tv_terms)
     else:
         optimizer.step()
