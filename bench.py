@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--tune", action="append", default=[], help="key=value speed knob (ugrid_tune), repeatable")
     ap.add_argument("--shuffle-rays", action="store_true", help="render the frame's rays in a random order (incoherent 64-ray tiles, "
                     "like a training batch): shows what the kernels owe to neighbouring pixels sharing cells")
+    ap.add_argument("--ray-tile", type=int, default=8, help="the frame's rays are rendered in T x T pixel blocks (one march wave = "
+                    "one 8x8 block, fourier_render.pixel_tile_order -- what render_view does); 0 = 64-pixel row segments")
     ap.add_argument("--cpu-chunks", type=int, default=12, help="8192-ray chunks timed for the CPU baseline (~1 s each)")
     return ap.parse_args()
 
@@ -172,7 +174,7 @@ class FrameBench:
         """renderer: test hook (tests/test_host_logic.py drives the sharding / exchange logic over gloo with a stand-in
         that has the renderer's call signature); None = the HIP FourierGridRenderer."""
         from unboundednerfpytorch_amd.dist import shard_bounds, tile_assignment
-        from unboundednerfpytorch_amd.fourier_render import get_rays_of_a_view, get_rays_of_pixel_index
+        from unboundednerfpytorch_amd.fourier_render import get_rays_of_a_view, get_rays_of_pixel_index, pixel_tile_order
         self.get_rays, self.get_rays_idx = get_rays_of_a_view, get_rays_of_pixel_index
         self.args, self.device, self.world, self.rank, self.dist = args, device, world, rank, dist
         H, W, G = args.height, args.width, args.grid
@@ -195,12 +197,20 @@ class FrameBench:
             self.idx = None
             self.bounds = shard_bounds(self.R, world, rank)
             self.per = shard_bounds(self.R, world, 0)[1]
+        # the frame's ray order: 8 x 8 pixel blocks (one per march wave) unless --ray-tile 0 / --shuffle-rays / odd sizes
+        T = getattr(args, "ray_tile", 0)
+        self.order = None
+        if T > 1 and device.type == "cuda" and not getattr(args, "shuffle_rays", False):
+            self.order = pixel_tile_order(H, W, device, T)
+        self.tile = T
         # this rank's flat pixel indices (constant over the frames): only its own rays are generated per step
         if self.idx is not None:
             self.px = self.idx.to(torch.int64).contiguous()
         else:
             b, e = self.bounds
             self.px = torch.arange(b, e, dtype=torch.int64, device=device)
+        if self.order is not None:
+            self.px = self.order[self.px].contiguous()
         self.gathered = [torch.empty(world * self.per, 5, device=device) for _ in range(2)] if self.use_dist else None
         self.inflight = {"work": None, "n": 0, "tile": None}
         self.last_out = None
@@ -225,11 +235,16 @@ class FrameBench:
     def step(self, timing=None, weak=False):
         """strong (default): this rank's shard of THE frame; weak: a whole frame of its own camera."""
         # ray generation is inside the step: the whole frame (weak / 1 GPU) or this rank's pixels of it (strong)
-        if not weak and self.world > 1:
+        if self.order is not None and (weak or self.world == 1):
+            ro, rd, vd = self.get_rays_idx(self.H, self.W, self.K, camera(self.rank, self.device) if weak else self.c2w, self.order)
+        elif not weak and self.world > 1:
             ro, rd, vd = self.get_rays_idx(self.H, self.W, self.K, self.c2w, self.px)
         else:
             ro, rd, vd = [x.contiguous() for x in self.rays(camera(self.rank, self.device) if weak else None)]
         out = self.rend(ro, rd, vd, stepsize=self.stepsize, render_depth=True, timing=timing)
+        if self.order is not None and (weak or self.world == 1):       # back to image order (inside the timed step)
+            from unboundednerfpytorch_amd.fourier_render import untile
+            out = dict(out, **{k: untile(out[k], self.H, self.W, self.tile) for k in ("rgb_marched", "depth", "alphainv_last") if k in out})
         self.last_out = out
         if self.use_dist and not weak:
             # the one exchange step of the path: rendered tiles [R/N,5] = rgb(3), depth, alphainv_last -> every rank
@@ -260,11 +275,16 @@ class FrameBench:
         from unboundednerfpytorch_amd.dist import shard_bounds, tile_assignment
         full = self.gathered[(self.inflight["n"] - 1) & 1]
         if self.idx is None:
-            return full[:self.R]
-        res = torch.empty(self.R, 5, dtype=full.dtype, device=full.device)
-        for r in range(self.world):
-            ir = tile_assignment(self.R, self.world, r).to(full.device)
-            res[ir] = full[r * self.per: r * self.per + ir.numel()]
+            res = full[:self.R]
+        else:
+            res = torch.empty(self.R, 5, dtype=full.dtype, device=full.device)
+            for r in range(self.world):
+                ir = tile_assignment(self.R, self.world, r).to(full.device)
+                res[ir] = full[r * self.per: r * self.per + ir.numel()]
+        if self.order is not None:       # rendered in 8 x 8 pixel blocks: position k of the ray list is pixel order[k]
+            img = torch.empty_like(res)
+            img[self.order] = res
+            res = img
         return res
 
     def timed(self, steps, warmup, weak=False):
@@ -463,7 +483,9 @@ def main():
                        "rays": R, "samples_per_ray": S, "survivors_M": M, "survivor_frac": M / float(R * S),
                        "terminated_ray_frac": term_frac, "chunks_per_frame": n_chunks,
                        "step": "ray generation + march + shade%s" % (" + all-gather of the tiles" if use_dist else ""),
-                       "ray_order": "shuffled (incoherent tiles)" if args.shuffle_rays else "image order (64-pixel row segments per wave)",
+                       "ray_order": "shuffled (incoherent tiles)" if args.shuffle_rays else (
+                           "%dx%d pixel blocks (one 8x8 block per 64-ray wave), results back in image order" % (args.ray_tile, args.ray_tile)
+                           if args.ray_tile > 1 else "image order (64-pixel row segments per wave)"),
                        "parallelism": ("one frame over %d ranks, %s, 1 all-gather of [R/N,5] tiles per frame (async, overlaps "
                                        "the next frame)" % (world, "contiguous 64-aligned ray bands" if args.contiguous
                                                             else "64-ray tiles dealt round-robin")) if world > 1 else "1 GPU"},

@@ -41,12 +41,14 @@ def test_renderer_from_reference_checkpoint(golden_dir):
 
 
 @pytest.mark.gpu
-def test_render_view_matches_forward(golden_dir):
-    """render_view (on-device ray generation + unsharded dist path) == forward on the same rays, bitwise."""
-    from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer, get_rays_of_a_view
+@pytest.mark.parametrize("H,W", [(45, 77), (48, 80)])
+def test_render_view_matches_forward(golden_dir, H, W):
+    """render_view (on-device ray generation + unsharded dist path) == forward on the same rays, bitwise -- also when
+    the view is rendered in 8 x 8 pixel blocks (H, W multiples of 8: fourier_render.pixel_tile_order) and un-tiled."""
+    from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer, get_rays_of_a_view, pixel_tile_order
     ckpt, _, _, _, _ = _load(golden_dir)
     rend = FourierGridRenderer.from_reference_checkpoint(ckpt, "cuda:0")
-    H, W = 45, 77
+    assert (pixel_tile_order(H, W, "cuda:0") is not None) == (H % 8 == 0 and W % 8 == 0)
     K = [[60.0, 0, W / 2], [0, 60.0, H / 2], [0, 0, 1]]
     c2w = torch.tensor([[1.0, 0, 0, 0.2], [0, 0.8, -0.6, 1.4], [0, 0.6, 0.8, -0.5]])
     rgb, depth, bg = rend.render_view(H, W, K, c2w, stepsize=0.5)

@@ -310,14 +310,22 @@ class FourierGridRenderer:
         """One whole view, like the body of the reference's render_viewpoints loop (run_render.py:41-70) but
         without its 8192-ray chunking: rays are generated on the device, rendered in one fused pass and, when a
         process group is initialised, sharded over its ranks (contiguous 64-aligned ranges, or 64-ray tiles dealt
-        round-robin with interleave=True) with one all-gather of the [R,5] tiles (dist.py).
+        round-robin with interleave=True) with one all-gather of the [R,5] tiles (dist.py).  The rays are rendered in
+        8 x 8 pixel blocks (pixel_tile_order) when H and W allow it and the results put back in image order.
         Returns rgb [H,W,3], depth [H,W], bgmap [H,W] (= alphainv_last) on the device."""
         from .dist import render_sharded
         c2w = torch.as_tensor(c2w, dtype=torch.float32).to(self.device)
-        ro, rd, vd = get_rays_of_a_view(H, W, K, c2w, inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y)
-        ro, rd, vd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous(), vd.reshape(-1, 3).contiguous()
+        order = pixel_tile_order(H, W, self.device) if c2w.is_cuda else None
+        if order is not None:      # rays in 8 x 8 pixel blocks (one block per wave of the march kernel), results un-tiled
+            ro, rd, vd = get_rays_of_pixel_index(H, W, K, c2w, order, inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y)
+        else:
+            ro, rd, vd = get_rays_of_a_view(H, W, K, c2w, inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y)
+            ro, rd, vd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous(), vd.reshape(-1, 3).contiguous()
         out = render_sharded(self.forward, ro, rd, vd, group=group, interleave=interleave, stepsize=stepsize)
-        return (out["rgb_marched"].reshape(H, W, 3), out["depth"].reshape(H, W), out["alphainv_last"].reshape(H, W))
+        rgb, depth, last = out["rgb_marched"], out["depth"], out["alphainv_last"]
+        if order is not None:
+            rgb, depth, last = untile(rgb, H, W), untile(depth, H, W), untile(last, H, W)
+        return rgb.reshape(H, W, 3), depth.reshape(H, W), last.reshape(H, W)
 
     @classmethod
     def from_reference_checkpoint(cls, ckpt, device, **kw):
@@ -361,6 +369,36 @@ def state_from_reference_checkpoint(ckpt):
         "contracted_norm": mk.get("contracted_norm", "inf"),
         "world_len": int(world[0]),
     }
+
+
+_TILE_ORDER = {}
+RAY_TILE = 8      # a wave of the march kernel owns 64 rays: 8 x 8 pixels instead of a 64-pixel row segment
+
+
+def pixel_tile_order(H, W, device, tile=None):
+    """Flat pixel indices j*W+i of a view in tile-major order (tile x tile pixel blocks, row-major inside a block and
+    over the blocks), int64 [H*W] on `device`, cached -- or None when H or W is not a multiple of the tile.  Rendering a
+    frame's rays in this order gives every 64-ray wave of the march kernel an 8 x 8 pixel block: its rays end at similar
+    depths (the wave leaves the sample loop when its LAST ray is done) and share grid cells (5 % on the S1 frame).
+    Per-ray results do not depend on the order."""
+    tile = RAY_TILE if tile is None else int(tile)
+    if tile <= 1 or H % tile or W % tile:
+        return None
+    key = (H, W, tile, str(device))
+    p = _TILE_ORDER.get(key)
+    if p is None:
+        p = torch.arange(H * W, device=device).view(H // tile, tile, W // tile, tile).permute(0, 2, 1, 3).reshape(-1).contiguous()
+        if len(_TILE_ORDER) > 8:
+            _TILE_ORDER.clear()
+        _TILE_ORDER[key] = p
+    return p
+
+
+def untile(x, H, W, tile=None):
+    """per-ray results [H*W, ...] in pixel_tile_order -> image order [H*W, ...]"""
+    tile = RAY_TILE if tile is None else int(tile)
+    rest = x.shape[1:]
+    return x.view(H // tile, W // tile, tile, tile, *rest).permute(0, 2, 1, 3, *range(4, 4 + len(rest))).reshape(H * W, *rest)
 
 
 def pixel_grid(H, W, device, flip_x=False, flip_y=False, mode="center"):
