@@ -129,24 +129,43 @@ template <bool CL>
 __global__ void k_grid_query(const float *__restrict__ grid, int P, int C, int X, int Y, int Z,
                              const float *__restrict__ xyz, const float *__restrict__ xyz_min,
                              const float *__restrict__ xyz_max, int F, int64_t n, float *__restrict__ out) {
-  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // canonical layout: one lane per point, levels and channels in loops.  channel-last: one lane per (point, channel),
+  // channel fastest -- the C lanes of a point read one 4C-byte voxel record per corner; same per-channel operation order
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t p = CL ? tid / C : tid;
   if (p >= n) return;
   const float ux = ug_unorm(xyz[3 * p], xyz_min[0], xyz_max[0]);
   const float uy = ug_unorm(xyz[3 * p + 1], xyz_min[1], xyz_max[1]);
   const float uz = ug_unorm(xyz[3 * p + 2], xyz_min[2], xyz_max[2]);
   const int64_t vol = (int64_t)X * Y * Z;
+  if (CL) {
+    const int ch = (int)(tid - p * C);
+    float sum = 0.f;
+    for (int l = 0; l < P; ++l) {
+      float cx, cy, cz;
+      ug_level_coords(l, ux, uy, uz, cx, cy, cz);
+      const ug_taps t = ug_tap_setup(X, Y, Z, cx, cy, cz);
+      const float *__restrict__ g = grid + (int64_t)l * vol * C + ch;
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (t.off[c] >= 0) acc += g[t.off[c] * C] * t.w[c];
+      sum = (l == 0) ? acc : sum + acc;
+    }
+    out[tid] = (F > 0) ? sum / (float)P : sum;
+    return;
+  }
   float *__restrict__ row = out + p * C;
   for (int l = 0; l < P; ++l) {
     float cx, cy, cz;
     ug_level_coords(l, ux, uy, uz, cx, cy, cz);
     const ug_taps t = ug_tap_setup(X, Y, Z, cx, cy, cz);
     for (int ch = 0; ch < C; ++ch) {
-      const float *__restrict__ g = CL ? grid + (int64_t)l * vol * C + ch : grid + ((int64_t)l * C + ch) * vol;
-      const int64_t vs = CL ? C : 1;
+      const float *__restrict__ g = grid + ((int64_t)l * C + ch) * vol;
       float acc = 0.f;
 #pragma unroll
       for (int c = 0; c < 8; ++c)
-        if (t.off[c] >= 0) acc += g[t.off[c] * vs] * t.w[c];
+        if (t.off[c] >= 0) acc += g[t.off[c]] * t.w[c];
       row[ch] = (l == 0) ? acc : row[ch] + acc;
     }
   }
@@ -361,7 +380,7 @@ static int ug_grid_query_any(bool cl, const float *grid, int P, int C, int X, in
   if (n <= 0) return 0;
   if (P != (freq_num > 0 ? 2 * freq_num + 1 : 1)) return (int)hipErrorInvalidValue;
   if (cl)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query<true>), dim3(ug_blocks(n, 256)), dim3(256), 0, st, grid, P, C, X, Y, Z, xyz,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query<true>), dim3(ug_blocks(n * C, 256)), dim3(256), 0, st, grid, P, C, X, Y, Z, xyz,
                        xyz_min, xyz_max, freq_num, n, out);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query<false>), dim3(ug_blocks(n, 256)), dim3(256), 0, st, grid, P, C, X, Y, Z, xyz,
@@ -507,3 +526,13 @@ extern "C" int ugrid_render_march(const ugrid_render_params *p, const float *ray
   }
 }
 
+
+#ifdef UG_MARCH_STATS
+// lane-efficiency study build only (-DUG_MARCH_STATS): {wave iterations, active lane-iterations, S per wave} since the last read
+extern "C" int ugx_march_stats_read(unsigned long long *host4) {
+  UG_HIP(hipMemcpyFromSymbol(host4, HIP_SYMBOL(g_march_stat), 32));
+  unsigned long long z[4] = {0, 0, 0, 0};
+  UG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_march_stat), z, 32));
+  return 0;
+}
+#endif

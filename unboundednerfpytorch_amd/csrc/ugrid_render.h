@@ -211,6 +211,9 @@ __device__ __forceinline__ float ug_density_level(const char *__restrict__ lvl, 
 
 // March one 64-ray tile (lane = ray): writes alphainv_last / depth for the tile's rays, appends the
 // survivors to ent/slot (this wave's private list) and returns their count (wave-uniform).
+#ifdef UG_MARCH_STATS
+__device__ unsigned long long g_march_stat[4];
+#endif
 template <int F, bool L2>
 __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float *__restrict__ rays_o,
                                              const float *__restrict__ rays_d, const float *__restrict__ t_table,
@@ -238,8 +241,14 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
   bool done = !valid;
   int nsurv = 0;  // wave-uniform
 
+#ifdef UG_MARCH_STATS
+  unsigned long long st_iter = 0, st_act = 0;   // lane-efficiency study (tools/gpu_march_stats.sh): iterations, active lanes
+#endif
   for (int j = 0; j < a.S; ++j) {
     if (__ballot(!done) == 0ull) break;  // every ray of this wave has terminated
+#ifdef UG_MARCH_STATS
+    st_iter += 1; st_act += __popcll(__ballot(!done));
+#endif
     bool surv = false;
     float w = 0.f;
     float px = 0.f, py = 0.f, pz = 0.f;
@@ -326,6 +335,9 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
       nsurv += __popcll(m);
     }
   }
+#ifdef UG_MARCH_STATS
+  if (lane == 0) { atomicAdd(&g_march_stat[0], st_iter); atomicAdd(&g_march_stat[1], st_act); atomicAdd(&g_march_stat[2], (unsigned long long)a.S); }
+#endif
   if (valid) {
     alphainv_last[ray] = T;
     depth[ray] = dsum;
