@@ -11,6 +11,11 @@ for d in $T/pmc_*/; do i=$((i+1)); cp $d/p_counter_collection.csv profiles/r02/p
 cp $T/prof/s1_kernel_stats.csv profiles/r02/bench_s1_kernel_stats.csv
 [ -f $T/dropin_ops.txt ] && cp $T/dropin_ops.txt profiles/r02/dropin_ops_vs_reference_kernels.txt
 [ -f $T/train_step.json ] && cp $T/train_step.json profiles/r02/train_step_s3.json
+[ -s $T/train_step_inorder.json ] && cp $T/train_step_inorder.json profiles/r02/train_step_s3_inorder.json
+[ -s $T/train_step_kernels_per_step.txt ] && cp $T/train_step_kernels_per_step.txt profiles/r02/train_step_s3_kernels_per_step.txt
+[ -s $T/tv_adam_layouts.json ] && cp $T/tv_adam_layouts.json profiles/r02/tv_adam_layouts.json
+[ -s $T/bench_line.json ] && tail -1 $T/bench_line.json > profiles/r02/bench_s1_line.json
+[ -s $T/bench_dist_1rank_rccl.json ] && cp $T/bench_dist_1rank_rccl.json profiles/r02/bench_dist_1rank_rccl.json
 python tools/pmc_summarize.py profiles/r02/pmc $(tail -1 $T/lib_sha16.txt) > /dev/null
 python - <<'PY'
 import json
