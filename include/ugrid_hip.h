@@ -335,7 +335,9 @@ int ugrid_train_compact(int64_t n_rays, int32_t n_samples, const float *scratch_
                         const float *t_table, float *pts, float *density, int64_t *ray_id, int64_t *step_id, float *t,
                         ugrid_stream_t stream);
 
-/* Tuning knobs (speed only, never results): "march_waves" 4..6. */
+/* Tuning knobs (speed only, never results): "march_waves" 4..6 (waves per SIMD of the march kernel); "tv_xcd" 0|1|2
+ * (dense TV / TV + Adam kernels: linear workgroup order | XCD-contiguous | + non-temporal streams, default 2);
+ * "shade16" 0|1 and "shade_dbg" (A/B arms of the shade kernel). */
 int ugrid_tune(const char *key, int value);
 
 /* Total survivors of the last march on this ws -> *d_stats (device int64). */

