@@ -32,7 +32,8 @@ def main():
     args = ap.parse_args()
     import bench
     from unboundednerfpytorch_amd.dist import composite_blocks
-    from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer, get_rays_of_a_view
+    from unboundednerfpytorch_amd.fourier_render import (FourierGridRenderer, get_rays_of_a_view, get_rays_of_pixel_index,
+                                                         pixel_tile_order, untile)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -49,7 +50,11 @@ def main():
     torch.cuda.empty_cache()
     K = [[1600.0 * W / 1920.0, 0, W / 2.0], [0, 1600.0 * W / 1920.0, H / 2.0], [0, 0, 1]]
     c2w = bench.camera(0, dev)
-    ro, rd, vd = [x.reshape(-1, 3).contiguous() for x in get_rays_of_a_view(H, W, K, c2w)]
+    order = pixel_tile_order(H, W, dev)          # 8 x 8 pixel blocks, one per march wave (what render_view does)
+    if order is not None:
+        ro, rd, vd = get_rays_of_pixel_index(H, W, K, c2w, order)
+    else:
+        ro, rd, vd = [x.reshape(-1, 3).contiguous() for x in get_rays_of_a_view(H, W, K, c2w)]
     R = ro.shape[0]
     S = rend.tables(0.5)[2]
     cam = c2w[:, 3].tolist()
@@ -57,7 +62,10 @@ def main():
     centroid = [0.8 * math.cos(ang), 0.8 * math.sin(ang), 0.0]                        # block centroids on a ring
 
     def frame():
-        return composite_blocks(rend.forward, ro, rd, vd, cam, centroid, stepsize=0.5)
+        out = composite_blocks(rend.forward, ro, rd, vd, cam, centroid, stepsize=0.5)
+        if order is not None:                    # the composited frame back in image order
+            out = dict(out, **{k: untile(out[k], H, W) for k in ("rgb_marched", "depth", "alphainv_last") if k in out})
+        return out
 
     for _ in range(args.warmup):
         out = frame()
