@@ -134,7 +134,9 @@ int ugrid_segment_cumsum(const float *w, const float *s, const int64_t *ray_id, 
 /* ------------------------------------------------------------------ adam_upd_cuda */
 
 /* replaces adam_upd / masked_adam_upd / adam_upd_with_perlr (adam_upd.cpp:79-86 ->
- * adam_upd_kernel.cu:9-132).  mode: 0 dense, 1 masked (skip grad==0), 2 per-voxel lr (perlr != NULL).
+ * adam_upd_kernel.cu:9-132).  mode: 0 dense, 1 masked (skip grad==0), 2 per-voxel lr (perlr != NULL); 3 (no reference
+ * counterpart) = masked + the gradient's nonzero elements are overwritten with 0 after use (it then serves as the next
+ * backward's zero-initialised buffer; const-ness of `grad` is waived for this mode).
  * param, exp_avg, exp_avg_sq updated in place. */
 /* NEW (no reference counterpart): dense total_variation_add_grad + (masked_)adam_upd in ONE pass over a grid parameter --
  * what run_train.py:281-288 does with two extension calls while global_step < tv_dense_before.  The TV term is added to

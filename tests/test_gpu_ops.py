@@ -446,3 +446,18 @@ def test_fused_tv_adam_rezero_grad_returns_the_gradient_buffer_all_zero(channels
             assert torch.equal(torch.nan_to_num(gi), torch.nan_to_num(g))
     for a, b in zip(*outs):
         assert torch.equal(torch.nan_to_num(a, nan=7.0), torch.nan_to_num(b, nan=7.0))
+
+
+@pytest.mark.parametrize("n", [4096 * 3 + 2, 1 << 16])
+def test_masked_adam_rezero_grad_returns_the_gradient_buffer_all_zero(n):
+    from unboundednerfpytorch_amd import adam_upd_cuda
+    mk = lambda seed: torch.from_numpy(synth.normal(seed, n)).cuda()
+    p, g, m, v = mk(1), mk(2), mk(3) * 0.1, mk(4).abs() * 0.01
+    g[g.abs() < 1.2] = 0
+    args = (7, 0.9, 0.99, 0.1, 1e-8)
+    pa, ga, ma, va = p.clone(), g.clone(), m.clone(), v.clone()
+    pb, gb, mb, vb = p.clone(), g.clone(), m.clone(), v.clone()
+    adam_upd_cuda.masked_adam_upd(pa, ga, ma, va, *args)
+    adam_upd_cuda.masked_adam_upd_rezero(pb, gb, mb, vb, *args)
+    assert torch.equal(ga, g) and not bool(gb.any())
+    assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)

@@ -172,7 +172,8 @@ def test_train_iteration_fused_tv_adam_equals_two_calls_at_scale():
         assert float((diff > 0.02 * lr).float().mean()) < 1e-4, (k, float(diff.max()))
 
 
-def test_gradient_buffers_are_recycled_all_zero_between_steps():
+@pytest.mark.parametrize("first_step", [1, 10001])        # dense-TV phase (fused TV + Adam) / masked-TV phase (masked Adam)
+def test_gradient_buffers_are_recycled_all_zero_between_steps(first_step):
     """_gradpool: the fused dense TV + Adam pass hands the k0 / density gradient buffers back all zero (rezero_grad) and
     the next backward scatters into them instead of filling new ones -- same buffers every step, exactly zero while
     parked, and the trained parameters equal those of the run that allocates and fills per step."""
@@ -197,7 +198,7 @@ def test_gradient_buffers_are_recycled_all_zero_between_steps():
             opt.step = step
             for s in (1, 2, 3):
                 o, d, v, rgb = bts.random_rays(2048, dev, seed=20 + s)
-                ts.train_iteration(m, opt, o, d, v, rgb, bts.TRUCK_CFG, s, dict(stepsize=0.5, rand_bkgd=False))
+                ts.train_iteration(m, opt, o, d, v, rgb, bts.TRUCK_CFG, first_step - 1 + s, dict(stepsize=0.5, rand_bkgd=False))
                 if recycle:
                     assert m.k0.grid.grad is None and m.density.grid.grad is None
                     for p in (m.k0.grid, m.density.grid):

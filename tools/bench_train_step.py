@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--freq", type=int, default=4)
     ap.add_argument("--rays", type=int, default=4096)
     ap.add_argument("--fused", type=int, default=1)
+    ap.add_argument("--first-step", type=int, default=1, help="global_step of the first iteration: 1 = the dense-TV phase of "
+                    "truck_single (global_step < tv_dense_before = 10000), 10001 = the masked-TV phase that follows")
     ap.add_argument("--overlap", type=int, default=1, help="k0 TV + Adam pass on a second stream (train_iteration overlap_k0_update)")
     ap.add_argument("--fused-loss", type=int, default=1, help="compositing + loss as one op (ops.RenderLoss) or the torch chain")
     ap.add_argument("--channels-last", type=int, default=1, help="k0 stored [P][X][Y][Z][C] (the training layout) or row-major")
@@ -98,7 +100,7 @@ def main():
             t0 = time.perf_counter()
         o, d, v, rgb = batches[step - 1]
         with (torch.cuda.stream(main) if main is not None else contextlib.nullcontext()):
-            loss, psnr = ts.train_iteration(model, opt, o, d, v, rgb, TRUCK_CFG, step, rk, timers=timers,
+            loss, psnr = ts.train_iteration(model, opt, o, d, v, rgb, TRUCK_CFG, args.first_step - 1 + step, rk, timers=timers,
                                             overlap_k0_update=bool(args.overlap))
         stats = {"loss": loss, "psnr": psnr}
     torch.cuda.synchronize()
@@ -118,6 +120,7 @@ def main():
                        % (1 + 2 * args.freq, args.grid, args.rays, S),
            "fused_forward": bool(getattr(model, "fused_forward", False)),
            "k0_channels_last": not model.k0.grid.is_contiguous(), "fused_loss": bool(args.fused_loss), "overlap_k0_update": bool(args.overlap),
+           "tv_phase": "dense" if args.first_step + args.warmup + args.steps - 1 < TRUCK_CFG["tv_dense_before"] else "masked",
            "ms_per_step": total, "phases_ms": ms, "steps": args.steps, "survivors_M": M, "samples": args.rays * S,
            "rays_per_sec": args.rays / (total * 1e-3), "k0_voxels": n_k0,
            "k0_streaming_floor_ms": {"note": "compulsory HBM passes over the 3.46 GB k0-sized arrays per step at 6.3 TB/s achievable: "

@@ -29,6 +29,12 @@ def masked_adam_upd(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2, lr, ep
     _run(param, grad, exp_avg, exp_avg_sq, None, step, beta1, beta2, lr, eps, 1, "masked_adam_upd")
 
 
+def masked_adam_upd_rezero(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2, lr, eps):
+    """NEW (not in the reference module): masked_adam_upd, and `grad` comes back all zero -- its nonzero elements are
+    overwritten after use, so the buffer can serve as the next backward's zero-initialised gradient (_gradpool.py)."""
+    _run(param, grad, exp_avg, exp_avg_sq, None, step, beta1, beta2, lr, eps, 3, "masked_adam_upd_rezero")
+
+
 def adam_upd_with_perlr(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps):
     _run(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps, 2, "adam_upd_with_perlr")
 

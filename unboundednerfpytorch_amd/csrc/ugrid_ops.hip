@@ -561,7 +561,9 @@ __device__ __forceinline__ void ug_adam_one(float &p, float g, float &m, float &
   else p -= step_size * m / (sqrtf(v) + eps);
 }
 
-template <int MODE>
+// RZ (masked mode only): the gradient is overwritten with zeros after use, whole 128-byte lines at a time and only
+// those that held something -- the buffer goes back to the zero pool of the grid's backward (_gradpool.py)
+template <int MODE, bool RZ = false>
 __global__ void __launch_bounds__(256)
 k_adam_vec4(float4 *__restrict__ param, const float4 *__restrict__ grad, float4 *__restrict__ exp_avg,
             float4 *__restrict__ exp_avg_sq, const float4 *__restrict__ perlr, int64_t n4,
@@ -569,6 +571,8 @@ k_adam_vec4(float4 *__restrict__ param, const float4 *__restrict__ grad, float4 
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
     const float4 g = grad[i];
+    if (RZ && ug_line_any(g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f))
+      const_cast<float4 *>(grad)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (MODE == 1 && g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) continue;
     float4 p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
     float4 l = make_float4(1.f, 1.f, 1.f, 1.f);
@@ -583,7 +587,7 @@ k_adam_vec4(float4 *__restrict__ param, const float4 *__restrict__ grad, float4 
   }
 }
 
-template <int MODE>
+template <int MODE, bool RZ = false>
 __global__ void k_adam_scalar(float *__restrict__ param, const float *__restrict__ grad,
                               float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq,
                               const float *__restrict__ perlr, int64_t begin, int64_t N,
@@ -591,6 +595,7 @@ __global__ void k_adam_scalar(float *__restrict__ param, const float *__restrict
   const int64_t i = begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   const float g = grad[i];
+  if (RZ && g != 0.f) const_cast<float *>(grad)[i] = 0.f;
   if (MODE == 1 && !(g != 0.f)) return;
   float p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
   ug_adam_one<MODE>(p, g, m, v, MODE == 2 ? perlr[i] : 1.f, step_size, beta1, beta2, eps);
@@ -599,7 +604,7 @@ __global__ void k_adam_scalar(float *__restrict__ param, const float *__restrict
   exp_avg_sq[i] = v;
 }
 
-template <int MODE>
+template <int MODE, bool RZ = false>
 static int ug_adam_launch(float *param, const float *grad, float *m, float *v, const float *perlr,
                           int64_t N, float step_size, float b1, float b2, float eps, hipStream_t st) {
   const uintptr_t al = (uintptr_t)param | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v |
@@ -611,13 +616,13 @@ static int ug_adam_launch(float *param, const float *grad, float *m, float *v, c
     // the same MI355X (tools/bench_dropin_ops.py), a capped grid of 32 blocks per CU streamed 672 M voxels at
     // 5.5 TB/s where the plain huge grid reaches > 6 TB/s (the loop only serialises independent 16-byte streams)
     const int64_t blocks = (n4 + 255) / 256;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_adam_vec4<MODE>), dim3((unsigned)blocks), dim3(256), 0, st,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_adam_vec4<MODE, RZ>), dim3((unsigned)blocks), dim3(256), 0, st,
                        (float4 *)param, (const float4 *)grad, (float4 *)m, (float4 *)v,
                        (const float4 *)perlr, n4, step_size, b1, b2, eps);
     done = n4 * 4;
   }
   if (done < N)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_adam_scalar<MODE>), dim3(ug_blocks(N - done, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_adam_scalar<MODE, RZ>), dim3(ug_blocks(N - done, 256)), dim3(256), 0,
                        st, param, grad, m, v, perlr, done, N, step_size, b1, b2, eps);
   UG_LAUNCH_CHECK();
   return 0;
@@ -1096,6 +1101,7 @@ extern "C" int ugrid_adam_upd(float *param, const float *grad, float *exp_avg, f
     case 2:
       if (!perlr) return (int)hipErrorInvalidValue;
       return ug_adam_launch<2>(param, grad, exp_avg, exp_avg_sq, perlr, N, step_size, beta1, beta2, eps, ST(s));
+    case 3: return ug_adam_launch<1, true>(param, grad, exp_avg, exp_avg_sq, nullptr, N, step_size, beta1, beta2, eps, ST(s));
     default: return (int)hipErrorInvalidValue;
   }
 }

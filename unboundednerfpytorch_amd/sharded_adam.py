@@ -81,13 +81,22 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         self.per_lr = count.float() / count.max()
 
     # -- one parameter ---------------------------------------------------------------------------------
-    def _update(self, group, p, g, m, v, step, per_lr):
+    def _update(self, group, p, g, m, v, step, per_lr, recycle=None):
+        """recycle: the grid parameter whose .grad `g` is -- after a masked update on the HIP ops the gradient buffer comes
+        back all zero (rezero_grad) and is parked for the parameter's next backward (_gradpool)"""
         beta1, beta2 = group['betas']
         args = (step, beta1, beta2, group['lr'], group['eps'])
         if per_lr is not None:
             self.ops.adam_upd_with_perlr(p, g, m, v, per_lr, *args)
         elif group['skip_zero_grad']:
-            self.ops.masked_adam_upd(p, g, m, v, *args)
+            rz = getattr(self.ops, 'masked_adam_upd_rezero', None)
+            if (rz is not None and recycle is not None and self.recycle_grads and g is recycle.grad and recycle.dim() == 5
+                    and g.is_cuda and g.stride() == recycle.stride()):
+                rz(p, g, m, v, *args)
+                recycle.grad = None
+                _gradpool.give(recycle, g)
+            else:
+                self.ops.masked_adam_upd(p, g, m, v, *args)
         else:
             self.ops.adam_upd(p, g, m, v, *args)
 
@@ -130,7 +139,7 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
             from . import total_variation_cuda as tv_module
         tv_module.total_variation_add_grad(param, g, w, w, w, dense)
         self._update(group, param, g, state['exp_avg'], state['exp_avg_sq'], state['step'],
-                     self.per_lr if use_perlr else None)
+                     self.per_lr if use_perlr else None, recycle=param)
 
     @torch.no_grad()
     def step(self, grad_hook=None, tv_terms=None, overlap=None):
@@ -179,7 +188,7 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                                              side if (side is not None and any(param is q for q in overlap)) else None)
                     else:
                         self._update(group, param, g, state['exp_avg'], state['exp_avg_sq'], state['step'],
-                                     self.per_lr if use_perlr else None)
+                                     self.per_lr if use_perlr else None, recycle=param)
                     continue
                 per = self.shard_len(n, world)
                 total = per * world
