@@ -337,6 +337,10 @@ int ugrid_train_compact(int64_t n_rays, int32_t n_samples, const float *scratch_
                         const float *t_table, float *pts, float *density, int64_t *ray_id, int64_t *step_id, float *t,
                         ugrid_stream_t stream);
 
+/* 1 when ugrid_render_shade / ugrid_render_fused have an rgbnet instantiation (depth 3, width 128) for this
+ * (fourier_freq_num, k0 channels, viewbase_pe) triple, else 0 (they return hipErrorNotSupported for it). */
+int ugrid_shade_supported(int32_t freq_num, int32_t k0_channels, int32_t viewbase_pe);
+
 /* Tuning knobs (speed only, never results): "march_waves" 4..6 (waves per SIMD of the march kernel); "tv_xcd" 0|1|2
  * (dense TV / TV + Adam kernels: linear workgroup order | XCD-contiguous | + non-temporal streams, default 2);
  * "shade16" 0|1 and "shade_dbg" (A/B arms of the shade kernel). */

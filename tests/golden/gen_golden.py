@@ -450,6 +450,34 @@ def gen_checkpoint():
     print("checkpoint world_len", Gd, "ratio", float(model.voxel_size_ratio_density), "M", out["weights"].numel())
 
 
+def gen_checkpoint_odd():
+    """A reference checkpoint OUTSIDE the fused kernels' shapes (llff_default.py:31-32 / waymo_base.py:77 style): rgbnet
+    width 64, depth 4, rgbnet_dim 9, viewbase_pe 8, colour grid at another resolution than the density grid -- rendered
+    by the reference model; exercises fourier_render.ComposedFourierGridRenderer."""
+    mod = install_stubs.import_reference("FourierGrid_model")
+    model = mod.FourierGridModel(xyz_min=[-1.5, -1.0, -2.0], xyz_max=[1.5, 2.0, 1.0],
+                                 num_voxels_density=10 ** 3, num_voxels_base_density=10 ** 3,
+                                 num_voxels_rgb=7 ** 3, num_voxels_base_rgb=7 ** 3, num_voxels_viewdir=-1,
+                                 alpha_init=1e-3, fast_color_thres=1e-4, fourier_freq_num=2, rgbnet_dim=9,
+                                 rgbnet_width=64, rgbnet_depth=4, viewbase_pe=8)
+    g = torch.Generator().manual_seed(77)
+    with torch.no_grad():
+        model.density.grid.copy_(torch.randn(model.density.grid.shape, generator=g) * 8.0 + 3.0)
+        model.k0.grid.copy_(torch.randn(model.k0.grid.shape, generator=g) * 0.7)
+        for p_ in model.rgbnet.parameters():
+            p_.copy_(torch.randn(p_.shape, generator=g) * (0.25 if p_.dim() == 2 else 0.1))
+    assert tuple(model.density.grid.shape[2:]) != tuple(model.k0.grid.shape[2:])
+    ckpt = {'global_step': 7, 'model_kwargs': model.get_kwargs(), 'model_state_dict': model.state_dict()}
+    torch.save(ckpt, os.path.join(OUT, "fg_ckpt_odd.tar"))
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(43, 96, origin_scale=0.5)]
+    o = o + torch.tensor([0.0, 0.5, -0.5])
+    with torch.no_grad():
+        out = model(o, d, v, stepsize=0.5, render_depth=True)
+    np.savez_compressed(os.path.join(OUT, "fg_ckpt_odd_render.npz"),
+                        **{k: out[k].numpy() for k in ("rgb_marched", "depth", "alphainv_last")})
+    print("odd checkpoint: density", tuple(model.density.grid.shape), "k0", tuple(model.k0.grid.shape), "M", out["weights"].numel())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)  # deterministic reduction order in F.linear / grid_sample
     gen_fouriergrid()
@@ -458,6 +486,7 @@ if __name__ == "__main__":
     gen_rays_view()
     gen_dvgo()
     gen_checkpoint()
+    gen_checkpoint_odd()
     gen_distortion()
     gen_train_step()
     gen_dcvgo()

@@ -90,3 +90,31 @@ def test_render_viewpoints_frame_loop(golden_dir):
     assert len(out) == 4 and all(35.0 < p < 45.0 for p in out[3])     # 0.01 offset -> 40 dB
     half = render_viewpoints(model, poses[:1], [(H, W)], [K], kw, render_factor=2)
     assert half[0].shape == (1, H // 2, W // 2, 3)
+
+
+@pytest.mark.gpu
+def test_checkpoint_outside_the_fused_shapes_renders_through_the_composed_path(golden_dir):
+    """rgbnet 4 x 64, rgbnet_dim 9, viewbase_pe 8, colour grid at another resolution than the density grid (a reference
+    checkpoint written by the reference model, tests/golden/gen_golden.py::gen_checkpoint_odd): from_reference_checkpoint
+    returns the composed renderer (drop-in kernels through fourier_model.FourierGridModel), which reproduces the
+    reference's render; the supported shape still gets the fused renderer."""
+    from unboundednerfpytorch_amd.fourier_render import (ComposedFourierGridRenderer, FourierGridRenderer,
+                                                         fused_shape_supported)
+    ckpt = torch.load(os.path.join(golden_dir, "fg_ckpt_odd.tar"), map_location="cpu", weights_only=False)
+    gold = np.load(os.path.join(golden_dir, "fg_ckpt_odd_render.npz"))
+    assert not fused_shape_supported(ckpt)
+    rend = FourierGridRenderer.from_reference_checkpoint(ckpt, "cuda:0")
+    assert isinstance(rend, ComposedFourierGridRenderer)
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(43, 96, origin_scale=0.5)]
+    o = o + torch.tensor([0.0, 0.5, -0.5])
+    rend.rays_per_chunk = 40                                    # three chunks
+    out = rend(o.cuda(), d.cuda(), v.cuda(), stepsize=0.5, render_depth=True)
+    for k in ("rgb_marched", "depth", "alphainv_last"):
+        np.testing.assert_allclose(out[k].cpu().numpy(), gold[k], rtol=0, atol=1e-4, err_msg=k)
+    H, W = 16, 24
+    K = [[30.0, 0, W / 2], [0, 30.0, H / 2], [0, 0, 1]]
+    c2w = torch.tensor([[1.0, 0, 0, 0.1], [0, 0.8, -0.6, 0.9], [0, 0.6, 0.8, -0.4]])
+    rgb, depth, bg = rend.render_view(H, W, K, c2w, stepsize=0.5)
+    assert rgb.shape == (H, W, 3) and bool(torch.isfinite(rgb).all())
+    small, *_ = _load(golden_dir)
+    assert fused_shape_supported(small) and type(FourierGridRenderer.from_reference_checkpoint(small, "cuda:0")) is FourierGridRenderer

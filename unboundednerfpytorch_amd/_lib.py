@@ -90,6 +90,7 @@ _SIGNATURES = {
                             _c.POINTER(_c.c_int32), _P]),
     "ugrid_mlp_fp16x2_scales": (_I, [_P, _P, _P, _c.c_int32, _c.c_int32, _c.c_float, _P]),
     "ugrid_tune": (_I, [_c.c_char_p, _I]),
+    "ugrid_shade_supported": (_I, [_c.c_int32, _c.c_int32, _c.c_int32]),
     "ugrid_render_stats": (_I, [_P, _L, _c.c_int32, _P, _P]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

@@ -515,18 +515,25 @@ extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *vie
   if (p->mlp_width != 128 || p->mlp_in != p->k0_channels + 3 + 6 * p->viewbase_pe) return (int)hipErrorInvalidValue;
   if (p->mlp_mode < UGRID_MLP_FP32 || p->mlp_mode > UGRID_MLP_FP16X2) return (int)hipErrorInvalidValue;
   int32_t *counter = (int32_t *)ws_mem;  // first 256 B of the work list
+// the instantiated (F, C, PE) triples: Mip-NeRF-360 *_single.py (configs/default.py:104-124); tankstemple_unbounded/
+// truck_single.py:105; FourierGridModel's constructor default fourier_freq_num = 5 (FourierGrid_model.py:137); waymo-style
+// rgbnet_dim = 3, viewbase_pe = 2 (configs/waymo/waymo_no_block.py:144-149)
+#define UG_SHADE_TRIPLES(X) X(3, 12, 4) X(4, 12, 4) X(5, 12, 4) X(2, 12, 4) X(1, 12, 4) X(2, 3, 2) X(3, 3, 2)
 #define UG_SHADE_CASE(F_, C_, PE_)                                                          \
   if (p->freq_num == F_ && p->k0_channels == C_ && p->viewbase_pe == PE_)                   \
     return ug_shade_launch<F_, C_, PE_>(a, viewdirs, k0_bricks, mlp_packed, ws, rgb_marched, counter, p->mlp_mode, ST(s));
-  UG_SHADE_CASE(3, 12, 4)  // Mip-NeRF-360 *_single.py  (configs/default.py:104-124)
-  UG_SHADE_CASE(4, 12, 4)  // tankstemple_unbounded/truck_single.py:105
-  UG_SHADE_CASE(5, 12, 4)  // FourierGridModel's constructor default fourier_freq_num=5 (FourierGrid_model.py:137)
-  UG_SHADE_CASE(2, 12, 4)
-  UG_SHADE_CASE(1, 12, 4)
-  UG_SHADE_CASE(2, 3, 2)   // waymo-style rgbnet_dim=3, viewbase_pe=2 (configs/waymo/waymo_no_block.py:144-149)
-  UG_SHADE_CASE(3, 3, 2)
+  UG_SHADE_TRIPLES(UG_SHADE_CASE)
 #undef UG_SHADE_CASE
   return (int)hipErrorNotSupported;
+}
+
+// 1 when ugrid_render_shade has an rgbnet instantiation (depth 3, width 128) for this (fourier_freq_num, k0 channels,
+// viewbase_pe) triple -- callers pick the composed path otherwise (fourier_render.ComposedFourierGridRenderer)
+extern "C" int ugrid_shade_supported(int32_t freq_num, int32_t k0_channels, int32_t viewbase_pe) {
+#define UG_SHADE_HAS(F_, C_, PE_) if (freq_num == F_ && k0_channels == C_ && viewbase_pe == PE_) return 1;
+  UG_SHADE_TRIPLES(UG_SHADE_HAS)
+#undef UG_SHADE_HAS
+  return 0;
 }
 
 extern "C" int ugrid_render_stats(void *ws_mem, int64_t n_rays, int32_t S, int64_t *d_stats, ugrid_stream_t s) {

@@ -330,8 +330,68 @@ class FourierGridRenderer:
     @classmethod
     def from_reference_checkpoint(cls, ckpt, device, **kw):
         """ckpt: the dict the reference saves (`model_kwargs`, `model_state_dict`;
-        FourierGrid_ckpt_manager.py:44-51), e.g. torch.load('fine_last.tar', weights_only=False)."""
+        FourierGrid_ckpt_manager.py:44-51), e.g. torch.load('fine_last.tar', weights_only=False).
+        Models outside the fused kernels' shapes (rgbnet other than 3 x 128 wide, (F, C, viewbase_pe) triples that
+        ugrid_shade.hip does not instantiate, colour grid at another resolution than the density grid) come back as a
+        ComposedFourierGridRenderer: same call signature and outputs, the drop-in kernels composed instead of fused."""
+        if cls is FourierGridRenderer and not fused_shape_supported(ckpt):
+            return ComposedFourierGridRenderer(ckpt, device)
         return cls(state_from_reference_checkpoint(ckpt), device, **kw)
+
+
+# (F, C, viewbase_pe) triples instantiated by csrc/ugrid_shade.hip for rgbnet models
+_FUSED_TRIPLES = None
+
+
+def fused_shape_supported(ckpt):
+    """Can the fused march / shade kernels render this reference checkpoint?  (rgbnet depth 3 x width 128 or no rgbnet,
+    one grid resolution, fast_color_thres > 0, an instantiated (F, C, viewbase_pe) triple)"""
+    kw, sd = ckpt['model_kwargs'], ckpt['model_state_dict']
+    if kw.get('fast_color_thres', 0) <= 0 or tuple(sd['density.grid'].shape[2:]) != tuple(sd['k0.grid'].shape[2:]):
+        return False
+    F, C, pe = int(kw.get('fourier_freq_num', 5)), int(sd['k0.grid'].shape[1]), int(kw.get('viewbase_pe', 4))
+    if kw.get('rgbnet_dim', 0) <= 0:
+        return C == 3 and sd['k0.grid'].shape[0] == 1
+    if kw.get('rgbnet_depth', 3) != 3 or kw.get('rgbnet_width', 128) != 128:
+        return False
+    return bool(_L.ugrid_shade_supported(F, C, pe))
+
+
+class ComposedFourierGridRenderer:
+    """Inference for FourierGrid models the fused kernels do not cover: the drop-in HIP kernels composed by
+    fourier_model.FourierGridModel in eval mode (TrainMarch stage 1, grid lookups on the canonical / channel-last layout,
+    rgbnet through the BLAS, per-ray sums) -- any rgbnet width / depth, any (F, C, viewbase_pe), separate grid
+    resolutions.  Same forward / render_view interface and output keys as FourierGridRenderer; rays are processed in
+    chunks of `rays_per_chunk` like the reference's render loop (run_render.py:52-58)."""
+
+    def __init__(self, ckpt, device, rays_per_chunk=8192):
+        from .fourier_model import FourierGridModel
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("ComposedFourierGridRenderer needs a HIP device (no CPU path)")
+        self.device = dev
+        self.rays_per_chunk = int(rays_per_chunk)
+        self.model = FourierGridModel(**dict(ckpt['model_kwargs']))
+        self.model.load_state_dict(ckpt['model_state_dict'])
+        self.model.to(dev).eval()
+
+    @torch.no_grad()
+    def forward(self, rays_o, rays_d, viewdirs, global_step=None, is_train=False, **render_kwargs):
+        if is_train or global_step is not None:
+            raise RuntimeError("inference-only; train through fourier_model.FourierGridModel")
+        keys = ("rgb_marched", "alphainv_last") + (("depth",) if render_kwargs.get("render_depth", False) else ())
+        kw = {k: v for k, v in render_kwargs.items() if k != "timing"}
+        outs = []
+        for b in range(0, rays_o.shape[0], self.rays_per_chunk):
+            e = b + self.rays_per_chunk
+            r = self.model(rays_o[b:e].contiguous(), rays_d[b:e].contiguous(), viewdirs[b:e].contiguous(), **kw)
+            outs.append({k: r[k] for k in keys})
+        if not outs:
+            return {k: torch.empty((0, 3) if k == "rgb_marched" else (0,), device=self.device) for k in keys}
+        return {k: torch.cat([o[k] for o in outs]) for k in keys}
+
+    __call__ = forward
+    render_view = FourierGridRenderer.render_view
 
 
 def state_from_reference_checkpoint(ckpt):
