@@ -413,6 +413,10 @@ def main():
                              "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+    # UGRID_BENCH_SHARE_GPU=1 (debugging only): all ranks on one device, e.g. two gloo ranks on a single-GPU box to exercise
+    # the multi-rank frame path (tile dealing, exchange, frame assembly) on the real renderer
+    if os.environ.get("UGRID_BENCH_SHARE_GPU") == "1":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -421,7 +425,11 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        backend = os.environ.get("UGRID_BENCH_BACKEND", "nccl")      # RCCL; "gloo" only for the shared-GPU debugging run
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from unboundednerfpytorch_amd.fourier_render import tune
     for kv in args.tune:
@@ -464,6 +472,13 @@ def main():
     # survivor statistics + parity inputs from one extra, untimed full frame on this rank
     rays_full, out_full, M = fb.full_frame()
     R, S = fb.R, fb.S
+    # self-check of the strong-scaled path: the frame assembled from all ranks' tiles must be, bit for bit, the frame one
+    # rank renders on its own (per-ray results do not depend on which rank or wave rendered them)
+    frame_ok = None
+    if use_dist:
+        asm = fb.assembled_frame()
+        frame_ok = bool(torch.equal(asm[:, 0:3], out_full["rgb_marched"]) and torch.equal(asm[:, 3], out_full["depth"])
+                        and torch.equal(asm[:, 4], out_full["alphainv_last"]))
     term_frac = float((out_full["alphainv_last"] < 1e-3).float().mean())
     shade_passes = (M + 31) // 32 + R // 64 // 2      # ~ sum over tiles of ceil(count / 32)
 
@@ -498,6 +513,8 @@ def main():
             res["roofline"] = None
         if per_rank is not None:
             res["per_rank"] = per_rank
+        if frame_ok is not None:
+            res["assembled_frame_equals_single_rank_frame"] = frame_ok
         if weak is not None:
             res["weak_scaling"] = weak
         if cpu_state is not None:
