@@ -106,12 +106,18 @@ def _adam_worker(rank, world, port, q):
     from unboundednerfpytorch_amd.sharded_adam import ShardedMaskedAdam
     params, grads = _adam_case(11)
     P = {k: torch.nn.Parameter(v.clone()) for k, v in params.items()}
-    opt = ShardedMaskedAdam([{'params': [P["k0"], P["dens"]], 'lr': 0.1, 'skip_zero_grad': True},
+    # the training layout of multi-channel grids: the same logical tensor stored channel-last; its flat shards follow the
+    # STORAGE order, the result must be the same logical tensor (Adam is elementwise)
+    cl = lambda t: t.clone().contiguous(memory_format=torch.channels_last_3d)
+    P["k0cl"] = torch.nn.Parameter(cl(params["k0"]))
+    opt = ShardedMaskedAdam([{'params': [P["k0"], P["dens"], P["k0cl"]], 'lr': 0.1, 'skip_zero_grad': True},
                              {'params': [P["w"]], 'lr': 1e-3, 'skip_zero_grad': False}],
                             min_shard_numel=512, ops=ref_ops)
     for step in range(3):
         for k in P:
-            P[k].grad = grads[step][rank][k].clone()
+            P[k].grad = cl(grads[step][rank]["k0"]) if k == "k0cl" else grads[step][rank][k].clone()
+        if step == 1:
+            P["k0cl"].grad = grads[step][rank]["k0"].clone()      # a row-major gradient for a channel-last parameter
         opt.step()
     # single-process reference: the same kernels on the rank-averaged gradient with full-size state
     R = {k: v.clone() for k, v in params.items()}
@@ -123,6 +129,29 @@ def _adam_worker(rank, world, port, q):
             fn = ref_ops.adam_upd if k == "w" else ref_ops.masked_adam_upd
             fn(R[k], gsum, M[k], V[k], step + 1, 0.9, 0.99, 1e-3 if k == "w" else 0.1, 1e-8)
     ok = all(torch.equal(P[k].data, R[k]) for k in R)
+    ok = ok and torch.equal(P["k0cl"].data, R["k0"]) and not P["k0cl"].data.is_contiguous() \
+        and P["k0cl"].data.is_contiguous(memory_format=torch.channels_last_3d)
+    m_cl, v_cl = opt.gather_full_state(P["k0cl"])
+    ok = ok and torch.equal(m_cl, M["k0"]) and torch.equal(v_cl, V["k0"])
+    sd = opt.state_dict()                                   # collective; the reference's full-shape layout
+    ok = ok and torch.equal(sd['state'][2]['exp_avg'], M["k0"]) and tuple(sd['state'][2]['exp_avg'].shape) == tuple(R["k0"].shape)
+    # ... and loads back into a fresh sharded optimizer over channel-last / row-major parameters alike: one more step on
+    # both optimizers gives identical parameters
+    import copy
+    P2 = {k: torch.nn.Parameter(v.data.clone(memory_format=torch.preserve_format)) for k, v in P.items()}
+    opt2 = ShardedMaskedAdam([{'params': [P2["k0"], P2["dens"], P2["k0cl"]], 'lr': 0.1, 'skip_zero_grad': True},
+                              {'params': [P2["w"]], 'lr': 1e-3, 'skip_zero_grad': False}], min_shard_numel=512, ops=ref_ops)
+    opt2.load_state_dict(copy.deepcopy(sd))
+    for PP, oo in ((P, opt), (P2, opt2)):
+        for k in PP:
+            PP[k].grad = cl(grads[0][rank]["k0"]) if k == "k0cl" else grads[0][rank][k].clone()
+        oo.step()
+    ok = ok and all(torch.equal(P[k].data, P2[k].data) for k in P) and torch.equal(P2["k0cl"].data, P2["k0"].data)
+    for k in R:                                             # (the reference run follows with the same fourth step)
+        gsum = (grads[0][0][k] + grads[0][1][k]) * 0.5
+        fn = ref_ops.adam_upd if k == "w" else ref_ops.masked_adam_upd
+        fn(R[k], gsum, M[k], V[k], 4, 0.9, 0.99, 1e-3 if k == "w" else 0.1, 1e-8)
+    ok = ok and all(torch.equal(P[k].data, R[k]) for k in R)
     m_full, v_full = opt.gather_full_state(P["dens"])
     ok = ok and torch.equal(m_full, M["dens"]) and torch.equal(v_full, V["dens"])
     # state memory really is sharded: k0's moments live only for this rank's half

@@ -323,5 +323,9 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         for k in ('exp_avg', 'exp_avg_sq'):
             full = torch.empty(st['shard'][2] * world, dtype=st[k].dtype, device=st[k].device)
             dist.all_gather_into_tensor(full, st[k], group=self.group)
-            out.append(full[:n].reshape(param.shape))
+            # the shards follow the parameter's STORAGE order (a channel-last grid is not row-major): put them back through
+            # a tensor of the parameter's own strides, so that the result is the right LOGICAL [P,C,X,Y,Z] tensor
+            t = torch.empty_like(param.data, memory_format=torch.preserve_format)
+            self._flat(t).copy_(full[:n])
+            out.append(t)
         return tuple(out)
