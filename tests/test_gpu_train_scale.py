@@ -285,3 +285,41 @@ def test_k0_update_on_the_side_stream_gives_the_same_training():
         diff = (params[0][k] - params[1][k]).abs()
         lr = 0.1 if "grid" in k else 1e-3
         assert float((diff > 0.02 * lr).float().mean()) < 1e-4, (k, float(diff.max()))
+
+
+def test_checkpoint_round_trip_with_the_channel_last_layout(tmp_path):
+    """save_checkpoint writes the reference's row-major file whatever the training layout; load_model + load_checkpoint
+    bring parameters and Adam moments back into the channel-last storage bit for bit, and training continues alike."""
+    import bench_train_step as bts
+    from unboundednerfpytorch_amd import train_step as ts
+    from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model, load_checkpoint, load_model, save_checkpoint
+    dev = torch.device("cuda", 0)
+    m = build(dev)
+    opt = create_optimizer_or_freeze_model(m, bts.TRUCK_CFG, global_step=0)
+    rk = dict(stepsize=0.5, rand_bkgd=False)
+    for s in (1, 2):
+        o, d, v, rgb = bts.random_rays(2048, dev, seed=50 + s)
+        ts.train_iteration(m, opt, o, d, v, rgb, bts.TRUCK_CFG, s, rk, overlap_k0_update=True)
+    path = str(tmp_path / "fine_last.tar")
+    save_checkpoint(path, m, opt, 2)                       # state_dict() waits for the k0 update on the side stream
+    raw = torch.load(path, map_location="cpu", weights_only=False)
+    assert raw["model_state_dict"]["k0.grid"].is_contiguous()
+    assert all(t.is_contiguous() for st in raw["optimizer_state_dict"]["state"].values() for t in st.values() if torch.is_tensor(t))
+    m2, _ = load_model(path)
+    m2 = m2.to(dev)
+    opt2 = create_optimizer_or_freeze_model(m2, bts.TRUCK_CFG, global_step=0)
+    m2, opt2, start = load_checkpoint(m2, opt2, path, no_reload_optimizer=False)
+    assert start == 2 and not m2.k0.grid.is_contiguous()
+    for (n1, p1), (n2, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert n1 == n2 and torch.equal(p1, p2), n1
+    for p1, p2 in zip(m.parameters(), m2.parameters()):
+        for k in ("exp_avg", "exp_avg_sq"):
+            a, b = opt.state[p1][k], opt2.state[p2][k]
+            assert torch.equal(a, b) and b.stride() == p2.stride(), k
+        assert opt.state[p1]["step"] == opt2.state[p2]["step"]
+    o, d, v, rgb = bts.random_rays(2048, dev, seed=53)
+    for mm, oo in ((m, opt), (m2, opt2)):
+        ts.train_iteration(mm, oo, o, d, v, rgb, bts.TRUCK_CFG, 3, rk)
+    for (k, a), (_, b) in zip(m.named_parameters(), m2.named_parameters()):
+        lr = 0.1 if "grid" in k else 1e-3
+        assert float(((a - b).abs() > 0.02 * lr).float().mean()) < 1e-4, k
