@@ -383,7 +383,11 @@ def roofline_block(kern, M, R, S, shade_passes):
         per[name] = e
     if not per:
         return None
-    dom = max(per, key=lambda k: per[k]["ms"])
+    # the dominant kernel = the longest one; march and shade are within a few per cent of each other on S1, so among
+    # kernels within 5 % of the longest the one FURTHEST from its roof is reported (stable between runs, conservative)
+    t_max = max(p["ms"] for p in per.values())
+    near = [k for k in per if per[k]["ms"] >= 0.95 * t_max]
+    dom = min(near, key=lambda k: max(v for kk, v in per[k].items() if kk.endswith("_frac")))
     d = per[dom]
     units = {"hbm": ("GB/s", d.get("hbm_GBps"), HBM_PEAK_GBS), "l1": ("GB/s", d["algorithmic_GBps"], L1_PEAK_GBS),
              "mfma": ("TFLOP/s", d["mfma_TFLOPs"], MFMA_F16_PEAK_TFLOPS),
