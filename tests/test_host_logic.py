@@ -478,3 +478,21 @@ def test_bench_strong_scaled_step_over_gloo(contiguous):
         np.testing.assert_array_equal(frame[:, 3], want["depth"].numpy())
         np.testing.assert_array_equal(frame[:, 4], want["alphainv_last"].numpy())
     assert res[0][2] + res[1][2] == R and abs(res[0][2] - res[1][2]) <= 128    # every ray rendered once, shards balanced to the 64-ray tile
+
+
+def test_pixel_tile_order_is_a_permutation_and_untile_inverts_it():
+    """fourier_render.pixel_tile_order / untile (8 x 8 pixel blocks per march wave): a permutation of the frame's pixels in
+    which every run of 64 indices is one 8 x 8 block, inverted exactly by untile; None when H or W is not a multiple."""
+    from unboundednerfpytorch_amd.fourier_render import pixel_tile_order, untile
+    H, W = 24, 40
+    order = pixel_tile_order(H, W, "cpu")
+    assert order.dtype == torch.int64 and sorted(order.tolist()) == list(range(H * W))
+    blk = order[64 * 7: 64 * 8]
+    rows, cols = blk // W, blk % W
+    assert int(rows.max() - rows.min()) == 7 and int(cols.max() - cols.min()) == 7           # one 8 x 8 block
+    assert rows[:8].unique().numel() == 1 and cols[:8].tolist() == list(range(int(cols[0]), int(cols[0]) + 8))
+    x = torch.arange(H * W * 3, dtype=torch.float32).view(H * W, 3)
+    assert torch.equal(untile(x[order], H, W), x) and torch.equal(untile(x[order][:, 0].contiguous(), H, W), x[:, 0])
+    assert pixel_tile_order(45, 77, "cpu") is None and pixel_tile_order(H, W, "cpu", tile=1) is None
+    o4 = pixel_tile_order(H, W, "cpu", tile=4)
+    assert torch.equal(untile(x[o4], H, W, tile=4), x)
