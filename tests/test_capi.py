@@ -147,3 +147,63 @@ def test_shade_shape_dispatch_table_and_loss_coefficients():
     assert ops.loss_coefficients(dict(cfg, weight_freq=0.1), 4096, 668, 0.2) is None          # image-space Fourier loss: composed path
     assert ops.loss_coefficients(cfg, 4096, 668, near_thres=None) is None                     # nearclip needs its threshold
     assert ops.loss_coefficients(dict(cfg, weight_nearclip=0.0), 4096, 668)[4:6] == (0.0, 0.0)
+
+
+def _kernel_metadata(so):
+    """per-kernel {vgpr_count, vgpr_spill_count, sgpr_spill_count, private_segment_fixed_size} of every gfx950 code object
+    embedded in the library (.hip_fatbin = one clang offload bundle per translation unit)"""
+    import os
+    import re
+    import tempfile
+    llvm = "/opt/rocm/lib/llvm/bin"
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        fat = os.path.join(td, "fat.bin")
+        subprocess.check_call([llvm + "/llvm-objcopy", "--dump-section", ".hip_fatbin=" + fat, so])
+        blob = open(fat, "rb").read()
+        starts = [m.start() for m in re.finditer(re.escape(b"__CLANG_OFFLOAD_BUNDLE__"), blob)]
+        for i, s in enumerate(starts):
+            part, co = os.path.join(td, "b%d.bin" % i), os.path.join(td, "b%d.co" % i)
+            open(part, "wb").write(blob[s:(starts[i + 1] if i + 1 < len(starts) else len(blob))])
+            r = subprocess.run([llvm + "/clang-offload-bundler", "--unbundle", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                "--input=" + part, "--output=" + co], capture_output=True, text=True)
+            if r.returncode or not os.path.exists(co):
+                continue
+            cur = None
+            for line in subprocess.run([llvm + "/llvm-readelf", "--notes", co], capture_output=True, text=True).stdout.splitlines():
+                m = re.match(r"\s+\.name:\s+(\S+)", line)
+                if m:
+                    cur = out.setdefault(m.group(1), {})
+                    continue
+                m = re.match(r"\s+\.(vgpr_count|vgpr_spill_count|sgpr_spill_count|private_segment_fixed_size):\s+(\d+)", line)
+                if m and cur is not None:
+                    cur[m.group(1)] = int(m.group(2))
+    return out
+
+
+def test_product_kernels_fit_their_register_budget_without_scratch(lib_path):
+    """Build-quality guard (no GPU needed): the kernels on the product path keep everything in registers -- no VGPR / SGPR
+    spills, no scratch -- and stay inside the occupancy their design assumes: k_march <= 80 VGPR (6 waves / SIMD), the shade
+    kernel <= 256 (2 waves / SIMD with 8 waves per CU), streaming kernels <= 64.  (The measured-and-rejected A/B arms
+    k_shade_mlp16 / k_render_fused do spill; they are not checked.)"""
+    meta = _kernel_metadata(lib_path)
+    assert len(meta) > 100
+
+    def find(prefix):
+        ks = [k for k in meta if k.startswith(prefix)]
+        assert ks, prefix
+        return ks
+    budget = {"_Z7k_marchILi": 80, "_Z11k_shade_mlpILi": 256, "_Z14k_shade_direct": 128, "_Z13k_train_march": 128,
+              "_Z15k_train_compact": 64, "_Z12k_grid_queryILb": 64, "_Z21k_grid_query_backwardILb": 64, "_Z12k_tv_cl_vec4ILb": 64,
+              "_Z14k_tv_adam_vec4ILb": 64, "_Z9k_tv_vec4ILb": 64, "_Z11k_adam_vec4ILi": 64, "_Z17k_render_loss_fwd": 64,
+              "_Z17k_render_loss_bwd": 64, "_Z14k_alpha2weight": 64, "_Z18k_alpha2weight_bwd": 64, "_Z16k_rays_of_a_view": 64,
+              "_Z11k_pack_quad": 128}
+    import re
+    for prefix, limit in budget.items():
+        for k in find(prefix):
+            m = meta[k]
+            w = re.match(r"_Z7k_marchILi\dELb[01]ELi(\d)EE", k)
+            if w:                                           # k_march<F, L2, W>: W waves per SIMD -> 512 / W registers
+                limit = {4: 128, 5: 96, 6: 80}[int(w.group(1))]
+            assert m.get("vgpr_spill_count", 0) == 0 and m.get("sgpr_spill_count", 0) == 0 and m.get("private_segment_fixed_size", 0) == 0, (k, m)
+            assert m["vgpr_count"] <= limit, (k, m)
