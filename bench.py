@@ -34,7 +34,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 # peaks used by the roofline block (/opt/skills/guides/MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0               # HBM3E spec peak (~6.3 TB/s achievable)
 N_CU, N_SIMD, CLK_HZ = 256, 1024, 2.4e9
-L1_PEAK_GBS = N_CU * 64 * CLK_HZ / 1e9          # vector L1 / texture path: 64 B per clock per CU = 39.3 TB/s
+L1_PEAK_GBS = N_CU * 64 * CLK_HZ / 1e9          # vector L1 / texture path, NOMINAL: 64 B per clock per CU = 39.3 TB/s
+# ... and as MEASURED on an MI355X by tools/microbench/l1_dwordx4.hip (pure L1-hit global_load_dwordx4 stream on every CU;
+# profiles/r03/microbench_l1_dwordx4.json); None until that file exists
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r03")
 MFMA_F16_PEAK_TFLOPS = 2500.0       # dense f16/bf16 MFMA peak
 VALU_PEAK_GINST = N_SIMD * CLK_HZ / 2 / 1e9     # one wave64 VALU instruction per 2 cycles per SIMD
 
@@ -167,6 +170,33 @@ def lib_sha16():
     return hashlib.sha256(open(_lib.LIB_PATH, "rb").read()).hexdigest()[:16]
 
 
+def elf_section(path, name, with_offset=False):
+    """bytes of one section of an ELF64 file (no external tools needed); with_offset: (file offset, bytes)"""
+    import struct
+    b = open(path, "rb").read()
+    assert b[:4] == b"\x7fELF" and b[4] == 2, "not an ELF64 file"
+    shoff, = struct.unpack_from("<Q", b, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+    sec = lambda i: struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize)
+    stroff, strsize = sec(shstrndx)[4], sec(shstrndx)[5]
+    strtab = b[stroff: stroff + strsize]
+    for i in range(shnum):
+        h = sec(i)
+        nm = strtab[h[0]: strtab.index(b"\0", h[0])].decode()
+        if nm == name:
+            return (h[4], b[h[4]: h[4] + h[5]]) if with_offset else b[h[4]: h[4] + h[5]]
+    return None
+
+
+def device_code_sha16(path=None):
+    """sha256 of the library's .hip_fatbin section = the gfx950 code objects themselves.  The whole-file hash also covers
+    .comment / .symtab / .strtab, which differ between two builds of identical device code (the driver's
+    box and the profiling box disagreed on the file hash, not on the code); static PMC counters are keyed on THIS."""
+    from unboundednerfpytorch_amd import _lib
+    sec = elf_section(path or _lib.LIB_PATH, ".hip_fatbin")
+    return hashlib.sha256(sec).hexdigest()[:16] if sec is not None else None
+
+
 class FrameBench:
     """One scene on this rank: renderer + camera + the timed step (ray generation, shard, render, tile exchange)."""
 
@@ -200,7 +230,7 @@ class FrameBench:
         # the frame's ray order: 8 x 8 pixel blocks (one per march wave) unless --ray-tile 0 / --shuffle-rays / odd sizes
         T = getattr(args, "ray_tile", 0)
         self.order = None
-        if T > 1 and device.type == "cuda" and not getattr(args, "shuffle_rays", False):
+        if T > 1 and not getattr(args, "shuffle_rays", False):
             self.order = pixel_tile_order(H, W, device, T)
         self.tile = T
         # this rank's flat pixel indices (constant over the frames): only its own rays are generated per step
@@ -214,6 +244,23 @@ class FrameBench:
         self.gathered = [torch.empty(world * self.per, 5, device=device) for _ in range(2)] if self.use_dist else None
         self.inflight = {"work": None, "n": 0, "tile": None}
         self.last_out = None
+        self.frame = None
+        # row of the gathered [world*per,5] buffer that holds image pixel i: undoes the tile dealing (or the bands) and the
+        # 8 x 8 pixel-block ray order in ONE index_select per frame, inside the timed step
+        self.src_index = None
+        if self.use_dist:
+            pix_of_row = torch.full((world * self.per,), -1, dtype=torch.int64)
+            for r in range(world):
+                if self.idx is not None:
+                    ir = tile_assignment(self.R, world, r)
+                else:
+                    b, e = shard_bounds(self.R, world, r)
+                    ir = torch.arange(b, e, dtype=torch.int64)
+                pix_of_row[r * self.per: r * self.per + ir.numel()] = ir if self.order is None else self.order.cpu()[ir]
+            rows = torch.nonzero(pix_of_row >= 0).reshape(-1)
+            src = torch.empty(self.R, dtype=torch.int64)
+            src[pix_of_row[rows]] = rows
+            self.src_index = src.to(device)
 
     def rays(self, c2w=None):
         ro, rd, vd = self.get_rays(self.H, self.W, self.K, self.c2w if c2w is None else c2w)
@@ -256,36 +303,31 @@ class FrameBench:
             fl = self.inflight
             if fl["work"] is not None:
                 fl["work"].wait()                # stream-level wait for the previous frame's exchange
+                self._assemble()                 # ... whose image is put together while this frame's exchange runs
             fl["work"] = self.dist.all_gather_into_tensor(self.gathered[fl["n"] & 1], tile, async_op=True)
             fl["tile"] = tile                    # keep the send buffer alive until the collective has run
             fl["n"] += 1
         return out
 
+    def _assemble(self):
+        """gathered tiles -> the frame in image order [R,5] (un-deal + un-tile: one index_select), part of the step"""
+        full = self.gathered[(self.inflight["n"] - 1) & 1]
+        self.frame = torch.index_select(full, 0, self.src_index)
+
     def barrier(self):
         if self.use_dist:
             if self.inflight["work"] is not None:
-                self.inflight["work"].wait()     # the last exchange is inside the timed region
+                self.inflight["work"].wait()     # the last exchange and its assembly are inside the timed region
                 self.inflight["work"] = None
+                self._assemble()
             self.dist.barrier()
         if self.device.type == "cuda":
             torch.cuda.synchronize()
 
     def assembled_frame(self):
-        """The last exchanged frame in ray order, [R,5] = rgb(3), depth, alphainv_last (every rank holds it)."""
-        from unboundednerfpytorch_amd.dist import shard_bounds, tile_assignment
-        full = self.gathered[(self.inflight["n"] - 1) & 1]
-        if self.idx is None:
-            res = full[:self.R]
-        else:
-            res = torch.empty(self.R, 5, dtype=full.dtype, device=full.device)
-            for r in range(self.world):
-                ir = tile_assignment(self.R, self.world, r).to(full.device)
-                res[ir] = full[r * self.per: r * self.per + ir.numel()]
-        if self.order is not None:       # rendered in 8 x 8 pixel blocks: position k of the ray list is pixel order[k]
-            img = torch.empty_like(res)
-            img[self.order] = res
-            res = img
-        return res
+        """The last exchanged frame in image order, [R,5] = rgb(3), depth, alphainv_last (every rank holds it): assembled
+        inside the timed step by _assemble()."""
+        return self.frame
 
     def timed(self, steps, warmup, weak=False):
         for _ in range(warmup):
@@ -335,23 +377,40 @@ def kernel_ms(timing, steps, single_launch):
             "render_shade": sum(ev[-2].elapsed_time(ev[-1]) for ev, _ in timing) / steps}
 
 
-def roofline_block(kern, M, R, S, shade_passes):
-    """Per-kernel utilisation of the four candidate limits -- no single 'HBM fraction' describes these kernels: the
-    algorithmic gather bytes of SURVEY 8d are served by L1/L2 (fraction of HBM peak > 1), so they are priced against the
-    vector-L1 path they actually go through, HBM against the PMC-measured traffic, VALU against instruction counts, the
-    matrix pipe against executed MFMA flops.  Static per-launch counters come from profiles/r02/pmc_summary.json (same
-    scene, same binary: `lib_sha16`); times are live HIP events."""
-    pmc = {}
-    ppath = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
-    if os.path.exists(ppath):
-        try:
-            pmc = json.load(open(ppath))
-        except Exception:
-            pmc = {}
+def _load_json(path):
+    try:
+        return json.load(open(path))
+    except Exception:
+        return None
+
+
+def roofline_block(kern, M, R, S, shade_passes, frame_rays=None):
+    """Per-kernel utilisation of the candidate limits.  M / R: survivors and rays THIS rank's kernels processed (the whole
+    frame at N = 1).  No single 'HBM fraction' describes these kernels: the algorithmic gather bytes of SURVEY 8d are
+    served by L1/L2 (their fraction of the HBM peak is > 1 and is printed as `frac_of_hbm_algorithmic`, labelled), so they
+    are priced against the vector-L1 path they go through -- nominal 64 B/clk/CU and, when the micro-benchmark result is
+    committed, the MEASURED L1-hit dwordx4 rate --, HBM against the PMC-measured traffic, VALU against instruction counts,
+    the matrix pipe against executed MFMA flops.  Static per-launch counters come from profiles/r03/pmc_summary.json and
+    are merged ONLY when that file was taken on the same device code (`device_code_sha16` = sha256 of .hip_fatbin);
+    times are live HIP events."""
+    ppath = os.path.join(PROFILE_DIR, "pmc_summary.json")
+    pmc = _load_json(ppath) or {}
+    code = device_code_sha16()
+    pmc_refused = None
+    if pmc and pmc.get("device_code_sha16") != code:
+        pmc_refused = "counters of %s were taken on device code %s, this library is %s" % (
+            os.path.relpath(ppath, ROOT), pmc.get("device_code_sha16"), code)
+        pmc = {}
+    scale = 1.0 if not frame_rays else R / float(frame_rays)     # counters are per whole-frame launch: a rank's share
+    l1m = _load_json(os.path.join(PROFILE_DIR, "microbench_l1_dwordx4.json")) or {}
+    l1_meas_bpc = l1m.get("quad64_B_per_clk_per_CU")             # the shade gather's access shape: 64 B per lane quad
+    l1_meas_lin = l1m.get("linear_B_per_clk_per_CU")
     alg = {"render_march": R * S * 224 + R * 32,     # 8 coefficients x 7 levels x 4 B per sample + rays in / (depth, alphainv) out
            "render_shade": M * 2688 + R * 24}        # x 12 channels per survivor + viewdirs in / rgb out
-    # executed f16 MFMA flops of the fp16x2 rgbnet: 132 MFMAs (32x32x16) per 32-survivor pass
+    # executed f16 MFMA flops of the fp16x2 rgbnet: 132 MFMAs (32x32x16) per 32-survivor pass; USEFUL rgbnet flops:
+    # 2 x (39 x 128 + 128 x 128 + 128 x 3) = 43 520 per survivor (SURVEY 8d)
     mfma_flops = {"render_march": 0.0, "render_shade": shade_passes * 132 * 32 * 32 * 16 * 2.0}
+    useful_flops = {"render_march": 0.0, "render_shade": M * 43520.0}
     per = {}
     for name, ms in kern.items():
         if name not in alg:
@@ -359,16 +418,21 @@ def roofline_block(kern, M, R, S, shade_passes):
         t = ms * 1e-3
         c = pmc.get(name, {})
         e = {"ms": ms, "algorithmic_bytes": alg[name], "algorithmic_GBps": alg[name] / t / 1e9,
+             "frac_of_hbm_algorithmic": alg[name] / t / 1e9 / HBM_PEAK_GBS,
+             "frac_of_hbm_algorithmic_note": "> 1 = cache-served: SURVEY 8d's logical gather bytes never reach HBM, NOT a roofline fraction",
              "l1_frac": alg[name] / t / 1e9 / L1_PEAK_GBS,
-             "mfma_TFLOPs": mfma_flops[name] / t / 1e12, "mfma_frac": mfma_flops[name] / t / 1e12 / MFMA_F16_PEAK_TFLOPS}
+             "mfma_TFLOPs": mfma_flops[name] / t / 1e12, "mfma_frac": mfma_flops[name] / t / 1e12 / MFMA_F16_PEAK_TFLOPS,
+             "mfma_useful_TFLOPs": useful_flops[name] / t / 1e12}
+        if l1_meas_bpc:
+            e["l1_frac_of_measured_peak"] = alg[name] / t / (N_CU * l1_meas_bpc * CLK_HZ)
         if "hbm_bytes" in c:
-            e["hbm_bytes_pmc"] = c["hbm_bytes"]
-            e["hbm_GBps"] = c["hbm_bytes"] / t / 1e9
+            e["hbm_bytes_pmc"] = c["hbm_bytes"] * scale
+            e["hbm_GBps"] = e["hbm_bytes_pmc"] / t / 1e9
             e["hbm_frac"] = e["hbm_GBps"] / HBM_PEAK_GBS
         if "valu_insts" in c:
-            e["valu_Ginst_per_s"] = c["valu_insts"] / t / 1e9
+            e["valu_Ginst_per_s"] = c["valu_insts"] * scale / t / 1e9
             e["valu_frac"] = e["valu_Ginst_per_s"] / VALU_PEAK_GINST
-        if "gui_active_cycles" in c:
+        if "gui_active_cycles" in c and scale == 1.0:
             # the chip runs these kernels at its power-limited clock, well below the 2.4 GHz the peaks assume: the same
             # counts against the cycles the kernel actually had (profiled launch) = how busy the units were
             cyc = c["gui_active_cycles"]
@@ -378,6 +442,8 @@ def roofline_block(kern, M, R, S, shade_passes):
             if "mfma_busy_cycles" in c:
                 e["mfma_pipe_busy"] = c["mfma_busy_cycles"] / N_SIMD / cyc
             e["l1_path_busy"] = alg[name] / (N_CU * 64.0) / cyc
+            if l1_meas_bpc:
+                e["l1_path_busy_vs_measured_peak"] = alg[name] / (N_CU * float(l1_meas_bpc)) / cyc
         fr = {k[:-5]: v for k, v in e.items() if k.endswith("_frac")}
         e["bound"] = max(fr, key=fr.get)
         per[name] = e
@@ -397,13 +463,68 @@ def roofline_block(kern, M, R, S, shade_passes):
     frame_ms = sum(p["ms"] for p in per.values())
     return {"kernel": dom, "bound": d["bound"], "achieved": ach, "peak": peak, "unit": unit, "frac": ach / peak,
             "traffic": d.get("hbm_bytes_pmc"),
-            "peaks": {"hbm_GBps": HBM_PEAK_GBS, "l1_GBps": L1_PEAK_GBS, "mfma_f16_TFLOPs": MFMA_F16_PEAK_TFLOPS,
+            "peaks": {"hbm_GBps": HBM_PEAK_GBS, "l1_GBps_nominal_64B_per_clk_per_CU": L1_PEAK_GBS,
+                      "l1_B_per_clk_per_CU_measured": {"quad_64B_gather": l1_meas_bpc, "linear_1KiB_per_wave": l1_meas_lin,
+                                                       "source": "profiles/r03/microbench_l1_dwordx4.json" if l1m else None},
+                      "mfma_f16_TFLOPs": MFMA_F16_PEAK_TFLOPS,
                       "valu_Ginst_per_s": VALU_PEAK_GINST, "clock_GHz_assumed": CLK_HZ / 1e9},
             "frame": {"algorithmic_bytes_formula": "R*S*224 + M*2688 + R*56 = %d" % (sum(alg.values())),
+                      "frac_of_hbm_algorithmic": sum(alg.values()) / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       "hbm_bytes_pmc": frame_hbm or None,
                       "hbm_frac": (frame_hbm / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if frame_hbm else None},
-            "pmc_source": "profiles/r02/pmc_summary.json" if pmc else None, "pmc_lib_sha16": pmc.get("lib_sha16"),
+            "pmc_source": "profiles/r03/pmc_summary.json" if pmc else None, "pmc_device_code_sha16": pmc.get("device_code_sha16"),
+            "pmc_refused": pmc_refused, "pmc_scaled_to_rank_share": scale if scale != 1.0 else None,
             "per_kernel": per}
+
+
+def s3_train_step_block(device):
+    """BASELINE.json configs[2] (S3: truck_single-shaped training step, P = 9, G = 200, 4096 random rays x S = 668) under the
+    driver's clock: tools/bench_train_step.run for the dense-TV phase (global_step < tv_dense_before) and the masked-TV
+    phase that follows.  Secondary: a failure here never costs the headline line."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_train_step as bts
+        out = {}
+        for phase, first in (("dense_tv", 1), ("masked_tv", 10001)):
+            r = bts.run(bts.parse(["--steps", "8", "--warmup", "3", "--first-step", str(first)]))
+            out[phase] = {k: r[k] for k in ("ms_per_step", "phases_ms", "survivors_M", "samples", "rays_per_sec", "tv_phase", "loss", "psnr")}
+            out["workload"] = r["workload"]
+            torch.cuda.empty_cache()
+        return out
+    except Exception as e:          # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves through
+    torch.distributed.run on 127.0.0.1 -- the command the driver uses for N > 1 -- and pass their exit code on.  On a box
+    with fewer than N GPUs the run is refused unless UGRID_BENCH_SHARE_GPU=1 (debugging: all ranks on the devices there
+    are, over gloo, since RCCL refuses two ranks on one device)."""
+    import socket
+    import subprocess
+    env = os.environ.copy()
+    standin = env.get("UGRID_BENCH_STANDIN")
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if not standin and ndev < args.gpus:
+        if env.get("UGRID_BENCH_SHARE_GPU") != "1" or ndev == 0:
+            raise SystemExit("bench.py --gpus %d needs %d MI355X (found %d); UGRID_BENCH_SHARE_GPU=1 runs the ranks on the devices "
+                             "present over gloo (debugging only)" % (args.gpus, args.gpus, ndev))
+        env.setdefault("UGRID_BENCH_BACKEND", "gloo")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def _standin_renderer(spec):
+    """UGRID_BENCH_STANDIN=module:factory (CI only, tests/test_host_logic.py): a stand-in with the renderer's call
+    signature on the CPU, so that the launch / sharding / exchange / assembly logic of this file runs without a GPU.  The
+    JSON line then says "renderer": "stand-in" and carries no roofline / cpu_baseline -- it is not a measurement."""
+    import importlib
+    mod, fn = spec.split(":")
+    return getattr(importlib.import_module(mod), fn)()
 
 
 def main():
@@ -412,53 +533,64 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
-    # UGRID_BENCH_SHARE_GPU=1 (debugging only): all ranks on one device, e.g. two gloo ranks on a single-GPU box to exercise
-    # the multi-rank frame path (tile dealing, exchange, frame assembly) on the real renderer
-    if os.environ.get("UGRID_BENCH_SHARE_GPU") == "1":
-        local_rank = local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            raise SystemExit(self_launch(args))
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d" % (world, args.gpus))
+    standin = os.environ.get("UGRID_BENCH_STANDIN")
+    if standin:
+        device = torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no CPU fallback for the measured path)")
+        # UGRID_BENCH_SHARE_GPU=1 (debugging only): all ranks on the devices present, e.g. two gloo ranks on a single-GPU box
+        # to exercise the multi-rank frame path (tile dealing, exchange, frame assembly) on the real renderer
+        if os.environ.get("UGRID_BENCH_SHARE_GPU") == "1":
+            local_rank = local_rank % torch.cuda.device_count()
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     dist = None
     use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("UGRID_BENCH_FORCE_DIST") == "1")
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        backend = os.environ.get("UGRID_BENCH_BACKEND", "nccl")      # RCCL; "gloo" only for the shared-GPU debugging run
+        backend = os.environ.get("UGRID_BENCH_BACKEND", "gloo" if standin else "nccl")   # "nccl" = RCCL; gloo: debugging / CI
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from unboundednerfpytorch_amd.fourier_render import tune
-    for kv in args.tune:
-        k, v = kv.split("=")
-        tune(k, int(v))
+    if not standin:
+        from unboundednerfpytorch_amd.fourier_render import tune
+        for kv in args.tune:
+            k, v = kv.split("=")
+            tune(k, int(v))
 
     make = {"s1": make_state, "s1b": make_state_surfaces}
     scene_desc = {"s1": "white-noise grids N(%g,%g^2)" % (DENS_MEAN, DENS_STD),
                   "s1b": "smooth fields with opaque surfaces (make_state_surfaces)"}
     G = args.grid
-    state = make[args.scene](G, device, seed=0)  # same model on every rank (replicated read-only grids)
-    fb = FrameBench(args, state, device, world, rank, dist)
-    want_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if standin:
+        state = None
+        fb = FrameBench(args, None, device, world, rank, dist, renderer=_standin_renderer(standin))
+    else:
+        state = make[args.scene](G, device, seed=0)  # same model on every rank (replicated read-only grids)
+        fb = FrameBench(args, state, device, world, rank, dist)
+    want_cpu = rank == 0 and not args.no_cpu_baseline and not standin
     cpu_state = None
     if want_cpu:
         cpu_state = {k: ([x.cpu() for x in v] if isinstance(v, list) else (v.cpu() if torch.is_tensor(v) else v))
                      for k, v in state.items()}
     del state
-    torch.cuda.empty_cache()
+    if not standin:
+        torch.cuda.empty_cache()
 
     dt, timing = fb.timed(args.steps, args.warmup)
     fb.check_exchange()
     kern = kernel_ms(timing, args.steps, args.single_launch)
     n_chunks = len(timing) // max(1, args.steps)
     rays_this_rank = sum(n for _, n in timing) // max(1, args.steps)
+    M_rank = fb.rend.survivors_of_last_chunk() if (not standin and n_chunks == 1 and not args.single_launch) else None
     # per-rank kernel times (load imbalance of the strong-scaled frame)
     per_rank = None
     if use_dist:
@@ -476,15 +608,21 @@ def main():
     # survivor statistics + parity inputs from one extra, untimed full frame on this rank
     rays_full, out_full, M = fb.full_frame()
     R, S = fb.R, fb.S
-    # self-check of the strong-scaled path: the frame assembled from all ranks' tiles must be, bit for bit, the frame one
-    # rank renders on its own (per-ray results do not depend on which rank or wave rendered them)
+    # self-check of the strong-scaled path: the frame assembled from all ranks' tiles INSIDE the timed step must be, bit
+    # for bit, the frame one rank renders on its own (per-ray results do not depend on which rank or wave rendered them)
     frame_ok = None
     if use_dist:
         asm = fb.assembled_frame()
         frame_ok = bool(torch.equal(asm[:, 0:3], out_full["rgb_marched"]) and torch.equal(asm[:, 3], out_full["depth"])
                         and torch.equal(asm[:, 4], out_full["alphainv_last"]))
+        if world > 1:
+            ok_all = torch.tensor([1.0 if frame_ok else 0.0], device=device)
+            dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
+            frame_ok = bool(ok_all.item() > 0)
     term_frac = float((out_full["alphainv_last"] < 1e-3).float().mean())
-    shade_passes = (M + 31) // 32 + R // 64 // 2      # ~ sum over tiles of ceil(count / 32)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()     # everything below is rank 0's own (CPU baseline: the other ranks are done)
 
     res = None
     if rank == 0:
@@ -501,20 +639,28 @@ def main():
                                    % (args.scene.upper(), fb.W, fb.H, S, G, fb.stepsize, scene_desc[args.scene]),
                        "rays": R, "samples_per_ray": S, "survivors_M": M, "survivor_frac": M / float(R * S),
                        "terminated_ray_frac": term_frac, "chunks_per_frame": n_chunks,
-                       "step": "ray generation + march + shade%s" % (" + all-gather of the tiles" if use_dist else ""),
+                       "step": "ray generation + march + shade + %s" % (
+                           "all-gather of the tiles + frame assembly (un-deal, un-tile)" if use_dist else "un-tiling to image order"),
                        "ray_order": "shuffled (incoherent tiles)" if args.shuffle_rays else (
                            "%dx%d pixel blocks (one 8x8 block per 64-ray wave), results back in image order" % (args.ray_tile, args.ray_tile)
-                           if args.ray_tile > 1 else "image order (64-pixel row segments per wave)"),
+                           if fb.order is not None else "image order (64-pixel row segments per wave)"),
                        "parallelism": ("one frame over %d ranks, %s, 1 all-gather of [R/N,5] tiles per frame (async, overlaps "
                                        "the next frame)" % (world, "contiguous 64-aligned ray bands" if args.contiguous
                                                             else "64-ray tiles dealt round-robin")) if world > 1 else "1 GPU"},
-            "lib_sha16": lib_sha16(),
             "kernels": {k: {"ms": v} for k, v in kern.items()},
         }
-        if not args.single_launch and world == 1:
-            res["roofline"] = roofline_block(kern, M, R, S, shade_passes)
-        else:
+        if standin:
+            res["renderer"] = "stand-in (%s): CI run of the launch / exchange / assembly logic, NOT a measurement" % standin
             res["roofline"] = None
+        else:
+            res["lib_sha16"] = lib_sha16()
+            res["device_code_sha16"] = device_code_sha16()
+            if not args.single_launch and M_rank is not None:
+                # rank 0's own kernels: its share of the frame's rays and survivors (the whole frame at N = 1)
+                shade_passes = (M_rank + 31) // 32 + rays_this_rank // 64 // 2      # ~ sum over tiles of ceil(count / 32)
+                res["roofline"] = roofline_block(kern, M_rank, rays_this_rank, S, shade_passes, frame_rays=R)
+            else:
+                res["roofline"] = None
         if per_rank is not None:
             res["per_rank"] = per_rank
         if frame_ok is not None:
@@ -522,9 +668,9 @@ def main():
         if weak is not None:
             res["weak_scaling"] = weak
         if cpu_state is not None:
-            res["cpu_baseline"] = cpu_baseline(cpu_state, rays_full, out_full, fb.stepsize, S, args.cpu_chunks)
+            res["cpu_baseline"] = cpu_baseline(cpu_state, rays_full, out_full, fb.stepsize, S, args.cpu_chunks, device)
     # secondary scene (single GPU only: it re-packs 23 GB of bricks)
-    if world == 1 and not args.no_secondary and args.scene == "s1":
+    if world == 1 and not use_dist and not args.no_secondary and args.scene == "s1" and not standin:
         del fb, out_full, rays_full
         cpu_state = None
         torch.cuda.empty_cache()
@@ -546,22 +692,31 @@ def main():
                "survivor_frac": M2 / float(fb2.R * fb2.S), "terminated_ray_frac": float((out2["alphainv_last"] < 1e-3).float().mean()),
                "kernels": {k: {"ms": v} for k, v in kern2.items()}}
         if cpu2 is not None:
-            cb = cpu_baseline(cpu2, rays2, out2, fb2.stepsize, fb2.S, max(4, args.cpu_chunks // 2))
+            cb = cpu_baseline(cpu2, rays2, out2, fb2.stepsize, fb2.S, max(4, args.cpu_chunks // 2), device, ref_gpu=False)
             sec["cpu_baseline_Msamples"] = cb["value"]
             sec["gpu_vs_oracle"] = cb["gpu_vs_oracle"]
         res["secondary"] = sec
+        del fb2, out2, rays2
+        torch.cuda.empty_cache()
+        s3 = s3_train_step_block(device)
+        if s3 is not None:
+            res["secondary_s3_train_step"] = s3
     if rank == 0:
         print(json.dumps(res))
-    if use_dist:
-        dist.destroy_process_group()
 
 
-def cpu_baseline(cpu_state, rays, gpu_out, stepsize, S, n_chunks):
-    """The oracle (CPU restatement of the reference's pure-PyTorch F.grid_sample forward, kind='port') timed on
-    this box's host cores on a bounded sample of the same frame: n_chunks x 8192 rays spread over the image.
-    (BASELINE.md section 3 asks for the reference's own Python over stub modules; /root/reference does not exist on the
-    GPU box, so the restatement -- pinned bit for bit on that Python in the build container -- is what runs here.)"""
-    from oracle import model_oracle
+def cpu_baseline(cpu_state, rays, gpu_out, stepsize, S, n_chunks, device=None, ref_gpu=True):
+    """The CPU baseline timed on this box's host cores on a bounded sample of the same frame (n_chunks x 8192 rays spread
+    over the image), and the parity of the GPU frame against it.
+
+    kind "reference" (whenever the reference's Python is present -- /root/reference in the build
+    container, the git-ignored archive oracle/_ref/reference_py.tar on the GPU box): the reference's OWN
+    FourierGridModel.forward (FourierGrid_model.py:554-672, pure-PyTorch F.grid_sample path) in its own 8192-ray render
+    chunks, its four CUDA-only extension modules served by the C restatement (oracle/ref_ops.c; the reference has no CPU
+    build of them).  kind "port" otherwise: oracle/model_oracle.py, the torch-CPU restatement pinned bit for bit on that
+    Python.  With oracle/_ref present (ref_gpu) the same rays also go through the reference executing on THIS GPU -- its
+    Python over its own compiled kernels -- and the three pairwise L-inf are reported (`arbitration`)."""
+    from oracle import model_oracle, ref_model
     # torch's intra-op threading stops scaling early on this op mix: on the 256-core GPU-box host 8 threads
     # gave 8.6 Msamples/s, 64 -> 5.4, 256 -> 0.13 (tools/cpu_threads_sweep.py); use the fastest setting.
     cores = min(8, os.cpu_count() or 1)
@@ -570,32 +725,66 @@ def cpu_baseline(cpu_state, rays, gpu_out, stepsize, S, n_chunks):
     R = ro.shape[0]
     chunk = 8192
     starts = [int(i * (R - chunk) / max(1, n_chunks - 1)) // 64 * 64 for i in range(n_chunks)] if n_chunks > 1 else [0]
+    kind = "reference" if ref_model.available("oracle") else "port"
+    model = ref_model.reference_model(cpu_state, "cpu", "oracle") if kind == "reference" else None
     t_total, n_samples = 0.0, 0
     errs = {k: [] for k in ("rgb_marched", "depth", "alphainv_last")}
+    refs = {k: [] for k in errs}
     margins, sq = [], 0.0
     for i, b in enumerate([starts[0]] + starts):  # first pass = warm-up, not timed
         o, d, v = ro[b:b + chunk].cpu(), rd[b:b + chunk].cpu(), vd[b:b + chunk].cpu()
         t0 = time.perf_counter()
-        ref = model_oracle.fouriergrid_render(cpu_state, o, d, v, stepsize, render_depth=True, return_margin=True)
+        if model is not None:
+            ref = ref_model.render(model, o, d, v, stepsize, chunk=chunk)
+        else:
+            ref = model_oracle.fouriergrid_render(cpu_state, o, d, v, stepsize, render_depth=True, return_margin=True)
         t1 = time.perf_counter()
         if i == 0:
             continue
         t_total += t1 - t0
         n_samples += chunk * S
+        if model is not None:      # the threshold margins of the sampled rays come from the restatement (untimed)
+            margins.append(model_oracle.fouriergrid_render(cpu_state, o, d, v, stepsize, render_depth=True, return_margin=True)["margin"])
+        else:
+            margins.append(ref["margin"])
         for k in errs:
             err = (gpu_out[k][b:b + chunk].cpu() - ref[k]).abs()
             errs[k].append(err.amax(dim=1) if err.dim() == 2 else err)
-        margins.append(ref["margin"])
+            refs[k].append(ref[k])
         sq += float(((gpu_out["rgb_marched"][b:b + chunk].cpu() - ref["rgb_marched"]).double() ** 2).sum())
     errs = {k: torch.cat(v) for k, v in errs.items()}
     stats = parity_stats(errs, torch.cat(margins), sq)
-    return {"value": n_samples / t_total / 1e6, "unit": "Msamples/s", "cores": cores, "host_cores": os.cpu_count(), "kind": "port",
-            "sample": "%d chunks x 8192 rays x %d samples of the same frame (oracle/model_oracle.py, torch CPU "
-                      "grid_sample path, %d threads: the fastest setting on this host), 1 warm-up chunk" % (n_chunks, S, cores),
-            "rays_per_sec": n_chunks * chunk / t_total,
-            "gpu_vs_oracle_linf_rgb": stats["rgb_marched"]["linf_all"], "gpu_vs_oracle_linf_depth": stats["depth"]["linf_all"],
-            "gpu_vs_oracle_linf_alphainv_last": stats["alphainv_last"]["linf_all"],
-            "gpu_vs_oracle": stats}
+    out = {"value": n_samples / t_total / 1e6, "unit": "Msamples/s", "cores": cores, "host_cores": os.cpu_count(), "kind": kind,
+           "sample": "%d chunks x 8192 rays x %d samples of the same frame (%s, torch CPU grid_sample path, %d threads: the "
+                     "fastest setting on this host), 1 warm-up chunk"
+                     % (n_chunks, S, "the reference's own FourierGridModel.forward over the C restatement of its extension modules"
+                        if kind == "reference" else "oracle/model_oracle.py", cores),
+           "rays_per_sec": n_chunks * chunk / t_total,
+           "gpu_vs_oracle_linf_rgb": stats["rgb_marched"]["linf_all"], "gpu_vs_oracle_linf_depth": stats["depth"]["linf_all"],
+           "gpu_vs_oracle_linf_alphainv_last": stats["alphainv_last"]["linf_all"],
+           "gpu_vs_oracle": stats}
+    del model
+    if ref_gpu and device is not None and device.type == "cuda" and ref_model.available("kernels:fma"):
+        gmodel = ref_model.reference_model(cpu_state, device, "kernels:fma")
+        arb = {}
+        lin = lambda a, b: float(((a - b).abs().amax(dim=1) if a.dim() == 2 else (a - b).abs()).max())
+        rg = {k: [] for k in errs}
+        for b in starts:
+            r = ref_model.render(gmodel, ro[b:b + chunk], rd[b:b + chunk], vd[b:b + chunk], stepsize, chunk=chunk)
+            for k in rg:
+                rg[k].append(r[k].cpu())
+        del gmodel
+        torch.cuda.empty_cache()
+        idx = torch.cat([torch.arange(b, b + chunk) for b in starts])
+        for k in rg:
+            g_ref = torch.cat(rg[k])
+            c_ref = torch.cat(refs[k])
+            fused = gpu_out[k].cpu()[idx]
+            arb[k] = {"fused_vs_ref_on_gpu": lin(fused, g_ref), "ref_on_gpu_vs_ref_on_cpu": lin(g_ref, c_ref),
+                      "fused_vs_ref_on_cpu": lin(fused, c_ref)}
+        out["arbitration"] = {"note": "L-inf over the sampled rays; ref_on_gpu = the reference's own Python + its own compiled "
+                                      "kernels (oracle/_ref/fma) + torch-ROCm grid_sample on this MI355X", "rays": int(idx.numel()), **arb}
+    return out
 
 
 def parity_stats(errs, margin, sq_rgb):

@@ -356,6 +356,50 @@ def test_sharded_masked_adam_degenerates_to_masked_adam_on_one_gpu():
     assert torch.equal(oa.state[a]['exp_avg_sq'], ob.state[b]['exp_avg_sq'])
 
 
+def test_masked_adam_keeps_the_gradient_like_the_reference_unless_recycling_is_requested():
+    """The reference's MaskedAdam leaves `.grad` untouched by step() (masked_adam.py:43-75).  The drop-in class does the same
+    by default; `recycle_grads=True` (this package's training loop) re-zeroes the buffer inside the update kernel, parks it
+    for the next backward and sets `.grad = None`.  With the pool switched off nothing is dropped, whatever the flag says
+    (a refused `give` must not free a buffer a side-stream kernel is still using).  Same parameter update in
+    all three cases, with and without the TV term on a second stream."""
+    from unboundednerfpytorch_amd import _gradpool
+    from unboundednerfpytorch_amd.masked_adam import MaskedAdam
+    shape = (3, 4, 8, 8, 8)
+    n = int(np.prod(shape))
+    base = torch.from_numpy(synth.normal(161, n).reshape(shape)).cuda()
+    g0 = torch.from_numpy(synth.normal(162, n).reshape(shape))
+    g0 = torch.where(torch.from_numpy(synth.uniform(163, n).reshape(shape)) < 0.3, g0, torch.zeros_like(g0)).cuda()
+    for tv in (None, "main", "side"):
+        res = []
+        for recycle, pool in ((False, True), (True, True), (True, False)):
+            _gradpool.clear()
+            _gradpool.enabled = pool
+            try:
+                p = torch.nn.Parameter(base.clone())
+                opt = MaskedAdam([{'params': [p], 'lr': 0.1, 'skip_zero_grad': True}], recycle_grads=recycle)
+                p.grad = g0.clone()
+                if tv is None:
+                    opt.step()
+                else:
+                    opt.step(tv_terms={p: (1e-3, True, None)}, overlap=[p] if tv == "side" else None)
+                torch.cuda.synchronize()
+                from unboundednerfpytorch_amd._lib import wait_pending
+                wait_pending(p)
+                if recycle and pool:
+                    assert p.grad is None
+                    buf = _gradpool._POOL[id(p)][1]
+                    assert buf is not None and float(buf.abs().max()) == 0.0
+                else:
+                    assert p.grad is not None                       # never dropped
+                    if not recycle:
+                        assert tv is not None or torch.equal(p.grad, g0)      # untouched (the TV term is added in place, as in the reference)
+                res.append(p.detach().clone())
+            finally:
+                _gradpool.enabled = True
+                _gradpool.clear()
+        assert torch.equal(res[0], res[1]) and torch.equal(res[0], res[2]), tv
+
+
 def test_segment_cumsum_and_distortion_loss(mods, golden_dir):
     """segment_cumsum (HIP, wave per ray, serial fp32 chains) is bit-exact against the oracle op; DistortionLoss on
     top of it reproduces the loss and gradient of the reference's own class (tests/golden/distortion.npz)."""

@@ -223,20 +223,24 @@ def _dist2_worker(rank, world, port, q):
     o, d, v = [torch.randn(R, 3, generator=g) for _ in range(3)]
     cam = torch.tensor([0.5, -0.2, 0.1])
     cents = [torch.tensor([1.0, 0.0, 0.0]), torch.tensor([-2.0, 1.0, 0.5])]
-    for min_op in (0.05, 0.0):
+    # single-process evaluation of the merging rule (eval_block_nerf.py:95-133,215-225): blocks with mean visibility
+    # <= min_opacity are dropped, the others blended with normalised |cam - centroid|^-4 weights; when none is left the
+    # reference skips the frame -- composite_blocks then returns the inverse-distance blend of all blocks (min_op = 2)
+    for min_op in (0.05, 0.0, 2.0):
         got = composite_blocks(_block_forward(rank), o, d, v, cam, cents[rank], p=4.0, min_opacity=min_op)
         outs = [_block_forward(b)(o, d, v) for b in range(2)]
-        ws_ = []
-        for b in range(2):
-            op = float((1 - outs[b]["alphainv_last"]).mean())
-            ws_.append(float((cam.double() - cents[b].double()).norm() ** -4.0) if op > min_op else 0.0)
+        dws = [float((cam.double() - cents[b].double()).norm() ** -4.0) for b in range(2)]
+        vis = [float((1 - outs[b]["alphainv_last"]).mean()) > min_op for b in range(2)]
+        ws_ = [dws[b] if (vis[b] or not any(vis)) else 0.0 for b in range(2)]
         tot = sum(ws_)
         for k in ("rgb_marched", "depth", "alphainv_last"):
             want = sum(outs[b][k] * ws_[b] for b in range(2)) / tot
             ok = ok and torch.allclose(got[k], want, rtol=1e-5, atol=1e-6)
-        ok = ok and abs(got["block_weight"] - ws_[rank]) <= 1e-12 * max(1.0, ws_[rank])
+        ok = ok and abs(float(got["block_weight"]) - ws_[rank] / tot) <= 1e-6 and int(got["visible_blocks"]) == sum(vis)
         if min_op == 0.05:
-            ok = ok and ws_[1] == 0.0 and ws_[0] > 0.0      # the case really exercises the visibility rule
+            ok = ok and vis == [True, False]                # the case really exercises the visibility rule
+        if min_op == 2.0:
+            ok = ok and vis == [False, False]
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
@@ -419,33 +423,20 @@ def test_data_parallel_training_matches_single_process_gloo():
 # ---------------------------------------------------------------------------------------------------------
 # bench.py's strong-scaled step (one frame over N ranks + the tile all-gather) over gloo, with a stand-in renderer
 # ---------------------------------------------------------------------------------------------------------
-class _FakeRenderer:
-    """Call signature of FourierGridRenderer; per-ray outputs are a deterministic function of the ray alone."""
-    pipeline = 0
-
-    def tables(self, stepsize):
-        return None, None, 16
-
-    def __call__(self, ro, rd, vd, stepsize=None, render_depth=True, timing=None):
-        if timing is not None:
-            timing.append(((_FakeEvent(), _FakeEvent(), _FakeEvent()), ro.shape[0]))
-        return {"rgb_marched": torch.sin(vd * 3.0), "depth": (rd * vd).sum(-1), "alphainv_last": torch.cos(vd[:, 0] * 5.0), "n_max": 16}
+from bench_standin import Renderer as _FakeRenderer  # noqa: E402  (per-ray outputs = a function of the ray alone)
 
 
-class _FakeEvent:
-    def elapsed_time(self, other):
-        return 0.0
-
-
-def _bench_worker(rank, world, port, q, contiguous):
+def _bench_worker(rank, world, port, q, contiguous, hw):
     import argparse
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
     import bench
-    args = argparse.Namespace(height=37, width=101, grid=200, contiguous=contiguous, single_launch=False, pipeline=0, mlp_mode=None)
+    args = argparse.Namespace(height=hw[0], width=hw[1], grid=200, contiguous=contiguous, single_launch=False, pipeline=0, mlp_mode=None,
+                              ray_tile=8)
     fb = bench.FrameBench(args, None, torch.device("cpu"), world, rank, dist, renderer=_FakeRenderer())
+    assert (fb.order is not None) == (hw[0] % 8 == 0 and hw[1] % 8 == 0)
     dt, timing = fb.timed(3, 1)
     fb.check_exchange()
     frame = fb.assembled_frame()
@@ -454,30 +445,76 @@ def _bench_worker(rank, world, port, q, contiguous):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("contiguous", [False, True])
-def test_bench_strong_scaled_step_over_gloo(contiguous):
+@pytest.mark.parametrize("contiguous,hw", [(False, (37, 101)), (True, (37, 101)), (False, (40, 104)), (True, (40, 104))])
+def test_bench_strong_scaled_step_over_gloo(contiguous, hw):
+    """the frame every rank assembles INSIDE the timed step (un-deal / un-band + un-tile of the 8 x 8 pixel-block ray order:
+    one index_select) is the single-process frame in image order"""
     import argparse
     import bench
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 37500 + os.getpid() % 2000 + (1 if contiguous else 0)
-    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q, contiguous)) for r in range(2)]
+    port = 37500 + os.getpid() % 2000 + (1 if contiguous else 0) + (2 if hw[0] == 40 else 0)
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q, contiguous, hw)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
-    args = argparse.Namespace(height=37, width=101, grid=200, contiguous=contiguous, single_launch=False, pipeline=0, mlp_mode=None)
+    args = argparse.Namespace(height=hw[0], width=hw[1], grid=200, contiguous=contiguous, single_launch=False, pipeline=0, mlp_mode=None,
+                              ray_tile=0)
     fb = bench.FrameBench(args, None, torch.device("cpu"), 1, 0, None, renderer=_FakeRenderer())
-    ro, rd, vd = fb.rays()
+    ro, rd, vd = fb.rays()                    # image order
     want = _FakeRenderer()(ro, rd, vd)
-    R = 37 * 101
+    R = hw[0] * hw[1]
     for rank, frame, rays, ok in res:
         assert ok and frame.shape == (R, 5)
         np.testing.assert_array_equal(frame[:, 0:3], want["rgb_marched"].numpy())
         np.testing.assert_array_equal(frame[:, 3], want["depth"].numpy())
         np.testing.assert_array_equal(frame[:, 4], want["alphainv_last"].numpy())
     assert res[0][2] + res[1][2] == R and abs(res[0][2] - res[1][2]) <= 128    # every ray rendered once, shards balanced to the 64-ray tile
+
+
+def test_bench_launches_itself_for_n_gt_1():
+    """`python bench.py --gpus 2` with no launcher in the environment (how the driver starts the N = 1 line, with N = 2):
+    bench.py re-executes itself through torch.distributed.run on 127.0.0.1 and rank 0 prints the ONE JSON line.  CI runs it
+    with the CPU stand-in renderer over gloo (UGRID_BENCH_STANDIN); on a GPU box the same path runs the HIP renderer."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["UGRID_BENCH_STANDIN"] = "bench_standin:Renderer"
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "40",
+                        "--width", "104"], env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "strong"
+    assert res["assembled_frame_equals_single_rank_frame"] is True
+    assert sum(r["rays"] for r in res["per_rank"]) == 40 * 104 and "stand-in" in res["renderer"]
+    assert "frame assembly" in res["config"]["step"] and res["weak_scaling"]["value"] > 0
+    # a wrong launcher environment is refused, not silently run at another size
+    env2 = dict(env, WORLD_SIZE="3", RANK="0")
+    p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=120)
+    assert p2.returncode != 0 and "WORLD_SIZE=3" in (p2.stderr + p2.stdout)
+
+
+def test_device_code_hash_ignores_the_non_loaded_sections(tmp_path):
+    """bench.device_code_sha16 = sha256 of .hip_fatbin: two builds of the same device code whose files differ only in
+    .comment / .symtab / .strtab (what happened between the profiling box and the driver's box in round 2) hash alike."""
+    import bench
+    from unboundednerfpytorch_amd import _lib
+    a = bench.device_code_sha16()
+    assert a is not None and len(a) == 16
+    blob = bytearray(open(_lib.LIB_PATH, "rb").read())
+    off, sec = bench.elf_section(_lib.LIB_PATH, ".comment", with_offset=True)
+    assert len(sec) > 4
+    blob[off] = blob[off] ^ 0x20
+    other = tmp_path / "lib_copy.so"
+    other.write_bytes(bytes(blob))
+    import hashlib
+    assert hashlib.sha256(bytes(blob)).hexdigest()[:16] != bench.lib_sha16()
+    assert bench.device_code_sha16(str(other)) == a
 
 
 def test_pixel_tile_order_is_a_permutation_and_untile_inverts_it():

@@ -62,7 +62,7 @@ def random_rays(n, device, seed):
     return o.contiguous(), d.contiguous(), v.contiguous(), rgb
 
 
-def main():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -75,7 +75,11 @@ def main():
     ap.add_argument("--overlap", type=int, default=1, help="k0 TV + Adam pass on a second stream (train_iteration overlap_k0_update)")
     ap.add_argument("--fused-loss", type=int, default=1, help="compositing + loss as one op (ops.RenderLoss) or the torch chain")
     ap.add_argument("--channels-last", type=int, default=1, help="k0 stored [P][X][Y][Z][C] (the training layout) or row-major")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def run(args):
+    """One measurement; returns the result dict (bench.py embeds it as `secondary_s3_train_step`)."""
     from unboundednerfpytorch_amd import train_step as ts
     from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
     dev = torch.device("cuda", 0)
@@ -127,7 +131,11 @@ def main():
                                              "grad zero-fill (1x write), dense TV (param read + grad read/write), masked Adam (grad read)",
                                      "value": 5 * n_k0 * 4 / 6.3e12 * 1e3},
            **stats}
-    print(json.dumps(res))
+    return res
+
+
+def main():
+    print(json.dumps(run(parse())))
 
 
 if __name__ == "__main__":

@@ -896,6 +896,209 @@ struct ug_prof { };
 #define UG_PROF_MARK(pr, i)
 #endif
 
+// One 32-survivor pass of the rgbnet + the ordered per-ray accumulation, shared by the classic shade tile loop
+// (ug_shade_tile) and the consumer waves of the producer / consumer kernel (ugrid_shade_pc.h).  Lane (h = lane >> 5,
+// sv = lane & 31) holds x[KL] = its half of survivor sv's layer-1 inputs, the survivor's weight `ww` and ray slot `sl`;
+// `ok`: the survivor exists.  amask [64] / aval [32] float4: the wave's LDS scratch.  accr/accg/accb: lane = ray slot.
+template <int C, int PE, int BF>
+__device__ __forceinline__ void ug_rgbnet_pass(const float (&x)[(2 * UG_CH(C) + 3 + 6 * PE + 1) / 2], float ww, int sl, bool ok,
+                                               const ug_mlp_lds &M, unsigned *amask, float4 *aval, float &accr, float &accg,
+                                               float &accb, ug_prof &prof) {
+  constexpr int CH = UG_CH(C);
+  constexpr int NEMB = 3 + 6 * PE;
+  constexpr int KL = (2 * CH + NEMB + 1) / 2;
+  const int lane = ug_lane();
+  const int h = lane >> 5, sv = lane & 31;
+  // ---- layers 1 and 2 on the matrix cores, transposed (H^T = W . X^T): accumulators feed the next layer
+  UG_PROF_MARK(prof, 2)
+  f32x16 acc1[4], acc2[4];
+  int bo = h * 64;
+  asm volatile("" : "+v"(bo));  // keeps the 128 bias reads inside the pass (LICM would hoist + spill them)
+  {
+    const float4 *b1p = (const float4 *)(M.B1 + bo);     // 16-byte aligned: 16 ds_read_b128 instead of 32 ds_read2_b32
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = b1p[o * 4 + q];
+        acc1[o][4 * q] = b.x; acc1[o][4 * q + 1] = b.y; acc1[o][4 * q + 2] = b.z; acc1[o][4 * q + 3] = b.w;
+      }
+  }
+  if constexpr (!BF) {
+    // exact fp32: v_mfma_f32_32x32x2_f32, B operand = one register (k = lane>>5 picks feature +0/+4)
+#pragma unroll
+    for (int s = 0; s < KL; ++s) {
+      const float4 wa = M.A1[s * 64 + lane];
+      acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, x[s], acc1[0], 0, 0, 0);
+      acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, x[s], acc1[1], 0, 0, 0);
+      acc1[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, x[s], acc1[2], 0, 0, 0);
+      acc1[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, x[s], acc1[3], 0, 0, 0);
+      if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the A-operand prefetch depth
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc1[o][r] = ug_relu(acc1[o][r]);
+        acc2[o][r] = ((const float4 *)(M.B2 + bo))[o * 4 + (r >> 2)][r & 3];
+      }
+#pragma unroll
+    for (int st = 0; st < 64; ++st) {
+      const float4 wa = M.A2[st * 64 + lane];
+      const float xb = acc1[st >> 4][st & 15];
+      acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, xb, acc2[0], 0, 0, 0);
+      acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, xb, acc2[1], 0, 0, 0);
+      acc2[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, xb, acc2[2], 0, 0, 0);
+      acc2[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, xb, acc2[3], 0, 0, 0);
+      if ((st & 1) == 1) __builtin_amdgcn_sched_barrier(0);
+    }
+  } else if constexpr (BF == 2) {
+    // fp32-accurate through fp16x2 splitting of power-of-two-scaled operands: v_mfma_f32_32x32x16_f16, three
+    // products per k-step; accumulators carry the factor sW*sX (biases / W3 are pre-scaled in the image)
+    const f16x8 *A1h = (const f16x8 *)M.A1, *A2h = (const f16x8 *)M.A2;
+    constexpr int KB1 = (KL + 7) / 8;
+    ug_hpart wl = ug_load_hpart(A1h + lane, 1);
+    ug_split2 xs, xn;
+    {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (e < KL) ? x[e < KL ? e : 0] : 0.f;
+      xs = ug_split8h(v, M.sx1);
+    }
+    ug_fence_operands();
+#pragma unroll
+    for (int s = 0; s < KB1; ++s) {
+      float vn[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vn[e] = (8 * (s + 1) + e < KL) ? x[(8 * (s + 1) + e < KL) ? 8 * (s + 1) + e : 0] : 0.f;
+      ug_mfma3x4(A1h + (s * 8) * 64 + lane, (s + 1 < KB1 ? A1h + ((s + 1) * 8) * 64 : A2h) + lane, xs, vn, M.sx1, xn, acc1, wl);
+      xs = xn;
+    }
+    ug_fence_results();
+    UG_PROF_MARK(prof, 3)
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc1[o][r] = ug_relu(acc1[o][r]);
+        acc2[o][r] = ((const float4 *)(M.B2 + bo))[o * 4 + (r >> 2)][r & 3];
+      }
+    {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = acc1[0][e];
+      xs = ug_split8h(v, M.c12);
+    }
+    ug_fence_operands();
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      float vn[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vn[e] = acc1[(st + 1 < 8 ? st + 1 : st) >> 1][8 * ((st + 1 < 8 ? st + 1 : st) & 1) + e];
+      ug_mfma3x4(A2h + (st * 8) * 64 + lane, A2h + ((st + 1 < 8 ? st + 1 : st) * 8) * 64 + lane, xs, vn, M.c12, xn, acc2, wl);
+      xs = xn;
+    }
+    ug_fence_results();
+  } else {
+    // fp32-accurate through bf16x3 splitting: v_mfma_f32_32x32x16_bf16, B operand = 8 values of this lane
+    // (lane half h supplies k = 8h..8h+7), i.e. 8 layer-1 inputs / 8 accumulator registers per k-step
+    const bf16x8 *A1b = (const bf16x8 *)M.A1, *A2b = (const bf16x8 *)M.A2;
+    constexpr int KB1 = (KL + 7) / 8;
+    ug_wpart wm = ug_load_part(A1b + lane, 1);
+    ug_split3 xs, xn;
+    {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (e < KL) ? x[e < KL ? e : 0] : 0.f;
+      xs = ug_split8(v);
+    }
+    ug_fence_operands();
+#pragma unroll
+    for (int s = 0; s < KB1; ++s) {
+      float vn[8];   // inputs of the next layer-1 step (dummy zeros after the last one)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vn[e] = (8 * (s + 1) + e < KL) ? x[(8 * (s + 1) + e < KL) ? 8 * (s + 1) + e : 0] : 0.f;
+      ug_mfma6x4(A1b + (s * 12) * 64 + lane, (s + 1 < KB1 ? A1b + ((s + 1) * 12) * 64 : A2b) + lane, xs, vn, xn, acc1, wm);
+      xs = xn;
+    }
+    ug_fence_results();
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        acc1[o][r] = ug_relu(acc1[o][r]);
+        acc2[o][r] = ((const float4 *)(M.B2 + bo))[o * 4 + (r >> 2)][r & 3];
+      }
+    {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = acc1[0][e];
+      xs = ug_split8(v);
+    }
+    ug_fence_operands();
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      float vn[8];   // accumulator registers feeding the next k-step (re-reads the last one at the end)
+      constexpr int dummy = 0; (void)dummy;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vn[e] = acc1[(st + 1 < 8 ? st + 1 : st) >> 1][8 * ((st + 1 < 8 ? st + 1 : st) & 1) + e];
+      ug_mfma6x4(A2b + (st * 12) * 64 + lane, A2b + ((st + 1 < 8 ? st + 1 : st) * 12) * 64 + lane, xs, vn, xn, acc2, wm);
+      xs = xn;
+    }
+    ug_fence_results();
+  }
+  // ---- layer 3 (3 outputs) on the VALU: each lane of the pair reduces its 64 features
+  UG_PROF_MARK(prof, 4)
+  float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+  // W3 comes from LDS 16 rows at a time, all 16 reads issued before the first use: left to itself hipcc emits
+  // read -> s_waitcnt -> 3 FMAs 64 times, one exposed LDS latency per hidden feature (phase profile: 3.3 k ticks)
+  constexpr int W3B = 16;   // rows per batch
+#pragma unroll
+  for (int sb = 0; sb < 64; sb += W3B) {
+    float4 w3[W3B];
+#pragma unroll
+    for (int i = 0; i < W3B; ++i) w3[i] = M.W3[bo + sb + i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < W3B; ++i) {
+      const float hv = ug_relu(acc2[(sb + i) >> 4][(sb + i) & 15]);
+      l0 = fmaf(w3[i].x, hv, l0);
+      l1 = fmaf(w3[i].y, hv, l1);
+      l2 = fmaf(w3[i].z, hv, l2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  l0 = (l0 + __shfl_xor(l0, 32)) + M.b3[0];
+  l1 = (l1 + __shfl_xor(l1, 32)) + M.b3[1];
+  l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
+  // weights.unsqueeze(-1) * rgb, then a per-ray sum in sample order (segment_coo semantics)
+  const float pr = ww * ug_sigmoid(l0), pg = ww * ug_sigmoid(l1), pb = ww * ug_sigmoid(l2);
+  UG_PROF_MARK(prof, 5)
+  {
+    // per-ray sum in list (= sample) order through LDS: survivors publish their value and set their bit in the
+    // owning ray's mask (ds_or: commutative, so deterministic); each ray lane then walks its bits upwards.
+    // Each phase is closed with s_waitcnt lgkmcnt(0) + a wave barrier: with the scheduling barrier alone the fp32
+    // build lost contributions on MI355X (reset / OR / read of the masks not kept in order).  The walk takes as
+    // many rounds as the busiest ray has entries in the pass (1-3), against 32 readlane rounds before.
+    amask[lane] = 0u;
+    ug_wave_lds_sync();
+    if (ok && h == 0) {
+      aval[sv] = make_float4(pr, pg, pb, 0.f);
+      atomicOr(&amask[sl], 1u << sv);
+    }
+    ug_wave_lds_sync();
+    unsigned m = amask[lane];
+    while (m) {
+      const int k = __builtin_ctz(m);
+      const float4 t = aval[k];
+      accr += t.x; accg += t.y; accb += t.z;
+      m &= m - 1;
+    }
+    __builtin_amdgcn_wave_barrier();   // the next pass rewrites aval / amask
+  }
+  UG_PROF_MARK(prof, 6)
+}
+
 // Shade one tile's survivor list (32 survivors per pass, lanes l / l+32 pair up) and write the tile's
 // rgb_marched.  C = 2*CH or 2*CH-1 k0 channels, PE view-direction frequencies; rgbnet 128 wide, 3 layers.
 // C == 12: k0 bricks in the quad layout, gathered 16 survivors at a time by lane quads and transposed into the MFMA
@@ -959,21 +1162,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     if (qs < count) pg0_n = ef[4 * qs + (qg < 2 ? qg : 2)];
     if (16 + qs < count) pg1_n = ef[4 * (16 + qs) + (qg < 2 ? qg : 2)];
   }
-  // UG_SHADE_XPASS (experiment, default OFF): start the gather of pass i+1 (cell set-up, first 2 items = 12 loads in
-  // flight) at the end of pass i so that its first memory round trip runs under the per-ray accumulation.  Measured on
-  // MI355X: the 56 set-up values + 48 load registers carried over the loop edge do not fit beside the rgbnet's
-  // accumulators -- hipcc spills 47-120 VGPRs and the kernel runs 10.2 ms instead of 4.8 ms.
-#ifndef UG_SHADE_XPASS
-#define UG_SHADE_XPASS 0
-#endif
-  constexpr int GNBL = UG_SHADE_XPASS ? 2 : 4;
-  ug_gather_state<F, GNBL, 2> gst;
-  if constexpr (QUAD && UG_SHADE_XPASS) {
-    if (count > 0) {
-      const float pgs[2] = {pg0_n, pg1_n};
-      ug_k0_gather_begin<F, GNBL, 2>(k0b, a, qa, pgs, gst);
-    }
-  }
+  ug_gather_state<F, 4, 2> gst;
   UG_PROF_MARK(prof, 0)
   for (int base = 0; base < count; base += 32) {
     const int e = base + sv;
@@ -1003,13 +1192,9 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
         // picks its 6 channels.  LDS operations of a wave execute in order: write -> read -> next round's write.
         float *xp = scr;
         float f3[2][3];
-        if constexpr (UG_SHADE_XPASS) {
-          ug_k0_gather_finish<F, GNBL, 2>(k0b, a, gst, f3);
-        } else {
-          const float pgs[2] = {pg0, pg1};
-          ug_k0_gather_begin<F, GNBL, 2>(k0b, a, qa, pgs, gst);
-          ug_k0_gather_finish<F, GNBL, 2>(k0b, a, gst, f3);
-        }
+        const float pgs[2] = {pg0, pg1};
+        ug_k0_gather_begin<F, 4, 2>(k0b, a, qa, pgs, gst);
+        ug_k0_gather_finish<F, 4, 2>(k0b, a, gst, f3);
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           xp[qs * 12 + 3 * qg + 0] = f3[it][0]; xp[qs * 12 + 3 * qg + 1] = f3[it][1]; xp[qs * 12 + 3 * qg + 2] = f3[it][2];
@@ -1056,200 +1241,8 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
         }
       }
     }
-    // ---- layers 1 and 2 on the matrix cores, transposed (H^T = W . X^T): accumulators feed the next layer
     UG_PROF_MARK(prof, 2)
-    f32x16 acc1[4], acc2[4];
-    int bo = h * 64;
-    asm volatile("" : "+v"(bo));  // keeps the 128 bias reads inside the pass (LICM would hoist + spill them)
-    {
-      const float4 *b1p = (const float4 *)(M.B1 + bo);     // 16-byte aligned: 16 ds_read_b128 instead of 32 ds_read2_b32
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float4 b = b1p[o * 4 + q];
-          acc1[o][4 * q] = b.x; acc1[o][4 * q + 1] = b.y; acc1[o][4 * q + 2] = b.z; acc1[o][4 * q + 3] = b.w;
-        }
-    }
-    if constexpr (!BF) {
-      // exact fp32: v_mfma_f32_32x32x2_f32, B operand = one register (k = lane>>5 picks feature +0/+4)
-#pragma unroll
-      for (int s = 0; s < KL; ++s) {
-        const float4 wa = M.A1[s * 64 + lane];
-        acc1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, x[s], acc1[0], 0, 0, 0);
-        acc1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, x[s], acc1[1], 0, 0, 0);
-        acc1[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, x[s], acc1[2], 0, 0, 0);
-        acc1[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, x[s], acc1[3], 0, 0, 0);
-        if ((s & 1) == 1) __builtin_amdgcn_sched_barrier(0);  // bound the A-operand prefetch depth
-      }
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc1[o][r] = ug_relu(acc1[o][r]);
-          acc2[o][r] = ((const float4 *)(M.B2 + bo))[o * 4 + (r >> 2)][r & 3];
-        }
-#pragma unroll
-      for (int st = 0; st < 64; ++st) {
-        const float4 wa = M.A2[st * 64 + lane];
-        const float xb = acc1[st >> 4][st & 15];
-        acc2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, xb, acc2[0], 0, 0, 0);
-        acc2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, xb, acc2[1], 0, 0, 0);
-        acc2[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, xb, acc2[2], 0, 0, 0);
-        acc2[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, xb, acc2[3], 0, 0, 0);
-        if ((st & 1) == 1) __builtin_amdgcn_sched_barrier(0);
-      }
-    } else if constexpr (BF == 2) {
-      // fp32-accurate through fp16x2 splitting of power-of-two-scaled operands: v_mfma_f32_32x32x16_f16, three
-      // products per k-step; accumulators carry the factor sW*sX (biases / W3 are pre-scaled in the image)
-      const f16x8 *A1h = (const f16x8 *)M.A1, *A2h = (const f16x8 *)M.A2;
-      constexpr int KB1 = (KL + 7) / 8;
-      ug_hpart wl = ug_load_hpart(A1h + lane, 1);
-      ug_split2 xs, xn;
-      {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (e < KL) ? x[e < KL ? e : 0] : 0.f;
-        xs = ug_split8h(v, M.sx1);
-      }
-      ug_fence_operands();
-#pragma unroll
-      for (int s = 0; s < KB1; ++s) {
-        float vn[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) vn[e] = (8 * (s + 1) + e < KL) ? x[(8 * (s + 1) + e < KL) ? 8 * (s + 1) + e : 0] : 0.f;
-        ug_mfma3x4(A1h + (s * 8) * 64 + lane, (s + 1 < KB1 ? A1h + ((s + 1) * 8) * 64 : A2h) + lane, xs, vn, M.sx1, xn, acc1, wl);
-        xs = xn;
-      }
-      ug_fence_results();
-      UG_PROF_MARK(prof, 3)
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc1[o][r] = ug_relu(acc1[o][r]);
-          acc2[o][r] = ((const float4 *)(M.B2 + bo))[o * 4 + (r >> 2)][r & 3];
-        }
-      {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc1[0][e];
-        xs = ug_split8h(v, M.c12);
-      }
-      ug_fence_operands();
-#pragma unroll
-      for (int st = 0; st < 8; ++st) {
-        float vn[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) vn[e] = acc1[(st + 1 < 8 ? st + 1 : st) >> 1][8 * ((st + 1 < 8 ? st + 1 : st) & 1) + e];
-        ug_mfma3x4(A2h + (st * 8) * 64 + lane, A2h + ((st + 1 < 8 ? st + 1 : st) * 8) * 64 + lane, xs, vn, M.c12, xn, acc2, wl);
-        xs = xn;
-      }
-      ug_fence_results();
-    } else {
-      // fp32-accurate through bf16x3 splitting: v_mfma_f32_32x32x16_bf16, B operand = 8 values of this lane
-      // (lane half h supplies k = 8h..8h+7), i.e. 8 layer-1 inputs / 8 accumulator registers per k-step
-      const bf16x8 *A1b = (const bf16x8 *)M.A1, *A2b = (const bf16x8 *)M.A2;
-      constexpr int KB1 = (KL + 7) / 8;
-      ug_wpart wm = ug_load_part(A1b + lane, 1);
-      ug_split3 xs, xn;
-      {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (e < KL) ? x[e < KL ? e : 0] : 0.f;
-        xs = ug_split8(v);
-      }
-      ug_fence_operands();
-#pragma unroll
-      for (int s = 0; s < KB1; ++s) {
-        float vn[8];   // inputs of the next layer-1 step (dummy zeros after the last one)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) vn[e] = (8 * (s + 1) + e < KL) ? x[(8 * (s + 1) + e < KL) ? 8 * (s + 1) + e : 0] : 0.f;
-        ug_mfma6x4(A1b + (s * 12) * 64 + lane, (s + 1 < KB1 ? A1b + ((s + 1) * 12) * 64 : A2b) + lane, xs, vn, xn, acc1, wm);
-        xs = xn;
-      }
-      ug_fence_results();
-#pragma unroll
-      for (int o = 0; o < 4; ++o)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          acc1[o][r] = ug_relu(acc1[o][r]);
-          acc2[o][r] = ((const float4 *)(M.B2 + bo))[o * 4 + (r >> 2)][r & 3];
-        }
-      {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc1[0][e];
-        xs = ug_split8(v);
-      }
-      ug_fence_operands();
-#pragma unroll
-      for (int st = 0; st < 8; ++st) {
-        float vn[8];   // accumulator registers feeding the next k-step (re-reads the last one at the end)
-        constexpr int dummy = 0; (void)dummy;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) vn[e] = acc1[(st + 1 < 8 ? st + 1 : st) >> 1][8 * ((st + 1 < 8 ? st + 1 : st) & 1) + e];
-        ug_mfma6x4(A2b + (st * 12) * 64 + lane, A2b + ((st + 1 < 8 ? st + 1 : st) * 12) * 64 + lane, xs, vn, xn, acc2, wm);
-        xs = xn;
-      }
-      ug_fence_results();
-    }
-    // ---- layer 3 (3 outputs) on the VALU: each lane of the pair reduces its 64 features
-    UG_PROF_MARK(prof, 4)
-    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
-    // W3 comes from LDS 16 rows at a time, all 16 reads issued before the first use: left to itself hipcc emits
-    // read -> s_waitcnt -> 3 FMAs 64 times, one exposed LDS latency per hidden feature (phase profile: 3.3 k ticks)
-    constexpr int W3B = UG_SHADE_XPASS ? 8 : 16;   // rows per batch (the started gather holds ~100 registers meanwhile)
-#pragma unroll
-    for (int sb = 0; sb < 64; sb += W3B) {
-      float4 w3[W3B];
-#pragma unroll
-      for (int i = 0; i < W3B; ++i) w3[i] = M.W3[bo + sb + i];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < W3B; ++i) {
-        const float hv = ug_relu(acc2[(sb + i) >> 4][(sb + i) & 15]);
-        l0 = fmaf(w3[i].x, hv, l0);
-        l1 = fmaf(w3[i].y, hv, l1);
-        l2 = fmaf(w3[i].z, hv, l2);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    l0 = (l0 + __shfl_xor(l0, 32)) + M.b3[0];
-    l1 = (l1 + __shfl_xor(l1, 32)) + M.b3[1];
-    l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
-    // weights.unsqueeze(-1) * rgb, then a per-ray sum in sample order (segment_coo semantics)
-    const float pr = en.w * ug_sigmoid(l0), pg = en.w * ug_sigmoid(l1), pb = en.w * ug_sigmoid(l2);
-    if constexpr (QUAD && UG_SHADE_XPASS) {
-      if (base + 32 < count) {      // wave-uniform
-        const float pgs[2] = {pg0_n, pg1_n};
-        ug_k0_gather_begin<F, GNBL, 2>(k0b, a, qa, pgs, gst);
-      }
-    }
-    UG_PROF_MARK(prof, 5)
-    {
-      // per-ray sum in list (= sample) order through LDS: survivors publish their value and set their bit in the
-      // owning ray's mask (ds_or: commutative, so deterministic); each ray lane then walks its bits upwards.
-      // Each phase is closed with s_waitcnt lgkmcnt(0) + a wave barrier: with the scheduling barrier alone the fp32
-      // build lost contributions on MI355X (reset / OR / read of the masks not kept in order).  The walk takes as
-      // many rounds as the busiest ray has entries in the pass (1-3), against 32 readlane rounds before.
-      amask[lane] = 0u;
-      ug_wave_lds_sync();
-      if (ok && h == 0) {
-        aval[sv] = make_float4(pr, pg, pb, 0.f);
-        atomicOr(&amask[sl], 1u << sv);
-      }
-      ug_wave_lds_sync();
-      unsigned m = amask[lane];
-      while (m) {
-        const int k = __builtin_ctz(m);
-        const float4 t = aval[k];
-        accr += t.x; accg += t.y; accb += t.z;
-        m &= m - 1;
-      }
-      __builtin_amdgcn_wave_barrier();   // the next pass rewrites aval / amask
-    }
-    UG_PROF_MARK(prof, 6)
+    ug_rgbnet_pass<C, PE, BF>(x, en.w, sl, ok, M, amask, aval, accr, accg, accb, prof);
   }
   const int64_t ray = tile * UG_WAVE + lane;
   if (ray < a.n_rays) {
@@ -1260,6 +1253,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
 }
 
 
+#ifdef UG_EXPERIMENTS   // rejected A/B arm, built only by UG_EXPERIMENTS=1 csrc/build.sh
 // ================================================================================================================
 // 16x16x32 variant of the shade tile (C = 12, PE = 4, fp16x2 arithmetic): 16 survivors per pass, half the accumulator
 // registers of the 32x32 chain, so the kernel fits 128 VGPRs and runs 16 waves per CU (4 per SIMD) instead of 8.
@@ -1502,6 +1496,8 @@ __device__ __forceinline__ void ug_shade_tile16(const ug_shade_args &a, const fl
     rgb_marched[3 * ray + 2] = accb;
   }
 }
+
+#endif  // UG_EXPERIMENTS
 
 // dynamic tile scheduling with XCD affinity: the tile range is cut into 8 contiguous eighths, one atomic
 // counter each; a workgroup (XCD = blockIdx % 8) drains its own eighth first, then steals from the others.

@@ -10,7 +10,7 @@ scenes sky and dense regions cluster in the image, and the fused kernels' time p
 count, so contiguous row bands can be badly unbalanced.
 
 `composite_blocks` is the one-model-per-GPU layout of BASELINE.json configs[4] (Waymo-style blocks): every rank
-renders ITS block for ALL rays and one all-reduce(sum) of [R,6] merges them.
+renders ITS block for ALL rays and one all-reduce(sum) of [R+1,5] merges them.
 """
 import torch
 import torch.distributed as dist
@@ -76,9 +76,12 @@ def render_sharded(renderer_forward, rays_o, rays_d, viewdirs, group=None, inter
             "alphainv_last": full[:, 4].contiguous()}
 
 
+INVISIBLE_SCALE = 2.0 ** -60   # weight factor of a block that fails the visibility test (see composite_blocks)
+
+
 def composite_blocks(renderer_forward, rays_o, rays_d, viewdirs, cam_origin, block_centroid, p=4.0, min_opacity=0.05,
                      group=None, **render_kwargs):
-    """One block model per rank, the same rays on every rank, one all-reduce(sum).
+    """One block model per rank, the same rays on every rank, ONE all-reduce(sum) of [R+1,5] fp32, no host sync.
 
     The reference's FourierGrid path never composites blocks (it renders each block's own image subset,
     run_render.py:146-207); the only merging rule in the repository is the legacy Block-NeRF evaluation
@@ -86,28 +89,35 @@ def composite_blocks(renderer_forward, rays_o, rays_d, viewdirs, cam_origin, blo
     camera-to-centroid distance to the power p (IDW_Power = 4), normalise the weights, blend the images.  This
     function applies that rule to the fused renderer's float outputs: visibility of a block := its mean
     accumulated opacity 1 - alphainv_last over the rays (the FourierGrid model has no visibility network), weight
-    w_b = |cam_origin - block_centroid|^-p if visible else 0, result = sum_b w_b * [rgb, depth, alphainv_last] /
-    sum_b w_b (rays no visible block covers get the unweighted mean).  Traffic: [R,6] fp32 per rank."""
+    w_b = |cam_origin - block_centroid|^-p if visible, result = sum_b w_b * [rgb, depth, alphainv_last] / sum_b w_b.
+
+    Everything stays on the device: the visibility test is a device-side comparison folded into w_b, and row R of the
+    reduced buffer carries (sum_b w_b, number of visible blocks, 0, 0, 0), so one collective returns both the numerators
+    and the normaliser.  A block that FAILS the test is not dropped but scaled by 2^-60: next to any visible block its
+    contribution is below fp32 resolution (the blend is bit-identical to excluding it unless its distance weight exceeds
+    the visible ones' by > 10^10), and when NO block is visible -- the reference skips such a frame
+    (eval_block_nerf.py:225-226) -- the common factor cancels and the frame is the inverse-distance blend of all blocks,
+    without a second collective or a host decision."""
     ws = dist.get_world_size(group) if dist.is_initialized() else 1
     kw = dict(render_kwargs)
     kw["render_depth"] = True
     out = renderer_forward(rays_o, rays_d, viewdirs, **kw)
     R = rays_o.shape[0]
-    opacity = float((1.0 - out["alphainv_last"]).mean()) if R > 0 else 0.0
+    dev = rays_o.device
     dvec = torch.as_tensor(cam_origin, dtype=torch.float64).reshape(3) - torch.as_tensor(block_centroid, dtype=torch.float64).reshape(3)
-    w = float(dvec.norm() ** (-float(p))) if opacity > min_opacity else 0.0
-    acc = torch.empty(R, 7, dtype=torch.float32, device=rays_o.device)
-    acc[:, 0:3] = out["rgb_marched"] * w
-    acc[:, 3] = out["depth"] * w
-    acc[:, 4] = out["alphainv_last"] * w
-    acc[:, 5] = w
-    # fallback numerators for views no block claims: plain mean over the blocks
-    plain = torch.cat([out["rgb_marched"], out["depth"][:, None], out["alphainv_last"][:, None]], dim=1)
-    acc[:, 6] = 1.0
+    dw = (dvec.norm() ** (-float(p))).to(device=dev, dtype=torch.float32)   # host inputs: host arithmetic + one scalar upload
+    opacity = (1.0 - out["alphainv_last"]).mean() if R > 0 else torch.zeros((), device=dev)
+    visible = (opacity > min_opacity).to(torch.float32)                  # 0-d device tensor
+    w = dw * (visible + (1.0 - visible) * INVISIBLE_SCALE)
+    acc = torch.empty(R + 1, 5, dtype=torch.float32, device=dev)
+    acc[:R, 0:3] = out["rgb_marched"] * w
+    acc[:R, 3] = out["depth"] * w
+    acc[:R, 4] = out["alphainv_last"] * w
+    acc[R, 0] = w
+    acc[R, 1] = visible
+    acc[R, 2:] = 0.0
     if ws > 1:
         dist.all_reduce(acc, group=group)
-        dist.all_reduce(plain, group=group)
-    wsum = acc[:, 5:6]
-    blended = torch.where(wsum > 0, acc[:, 0:5] / wsum.clamp_min(1e-30), plain / acc[:, 6:7])
+    blended = acc[:R] / acc[R, 0]
     return {"rgb_marched": blended[:, 0:3].contiguous(), "depth": blended[:, 3].contiguous(),
-            "alphainv_last": blended[:, 4].contiguous(), "block_weight": w}
+            "alphainv_last": blended[:, 4].contiguous(), "block_weight": w / acc[R, 0], "visible_blocks": acc[R, 1]}

@@ -92,7 +92,11 @@ class FourierGridModel(nn.Module):
     def _make_grid(self, channels, world_size, fourier):
         # multi-channel grids are stored channel-last on the HIP ops (grid.FourierGrid: same logical parameter, one
         # 4C-byte run per voxel for the lookup / scatter / TV / Adam kernels); injected back-ends keep the canonical layout
-        cfg = {'channels_last': True} if (self.channels_last_grids and channels > 1 and channels % 4 == 0) else None
+        # (the channel-last TV / fused TV + Adam kernels index with 32 bits: a grid of >= 2^31 elements keeps the canonical
+        # layout, whose kernels have a scalar 64-bit path -- ADVICE r2)
+        n_levels = (1 + 2 * self.fourier_freq_num) if fourier else 1
+        numel = n_levels * channels * int(world_size[0]) * int(world_size[1]) * int(world_size[2])
+        cfg = {'channels_last': True} if (self.channels_last_grids and channels > 1 and channels % 4 == 0 and numel < 2 ** 31) else None
         g = _grid.FourierGrid(channels=channels, world_size=world_size, xyz_min=self.xyz_min, xyz_max=self.xyz_max,
                               use_nerf_pos=fourier, fourier_freq_num=self.fourier_freq_num, config=cfg)
         g.query_fn, g.tv_module = self._be.grid_query, self._be.total_variation_cuda

@@ -44,6 +44,7 @@ class GridQuery(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, grid, xyz, xyz_min, xyz_max, freq_num):
+        _lib.wait_pending(grid)      # an optimizer update of this grid may still run on a side stream (step(overlap=...))
         out = grid_query(grid, xyz, xyz_min, xyz_max, freq_num)
         if grid.requires_grad:
             ctx.save_for_backward(xyz.reshape(-1, 3).contiguous(), xyz_min, xyz_max)
@@ -86,6 +87,7 @@ class TrainMarch(torch.autograd.Function):
     def forward(ctx, grid, rays_o, rays_d, t, scene_center, scene_radius, xyz_min, xyz_max, bg_len, norm_l2, act_shift,
                 interval, thres, freq_num):
         import ctypes
+        _lib.wait_pending(grid)      # an optimizer update of this grid may still run on a side stream (step(overlap=...))
         _lib.require_cuda(("grid", grid), ("rays_o", rays_o), ("rays_d", rays_d), ("t", t), ("xyz_min", xyz_min), ("xyz_max", xyz_max))
         _lib.require_f32(("grid", grid), ("rays_o", rays_o), ("rays_d", rays_d), ("t", t))
         if grid.dim() != 5 or grid.shape[1] != 1:

@@ -10,5 +10,6 @@ from .sharded_adam import ShardedMaskedAdam
 
 
 class MaskedAdam(ShardedMaskedAdam):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.99), eps=1e-8):
-        super().__init__(params, lr=lr, betas=betas, eps=eps, group=None, local_only=True)
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, recycle_grads=False):
+        """recycle_grads: see ShardedMaskedAdam (default off = the reference's contract: `.grad` survives step())"""
+        super().__init__(params, lr=lr, betas=betas, eps=eps, group=None, local_only=True, recycle_grads=recycle_grads)

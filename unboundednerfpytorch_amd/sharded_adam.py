@@ -35,15 +35,18 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
     adam_upd_cuda)."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.99), eps=1e-8, group=None, average=True,
-                 min_shard_numel=1 << 16, ops=None, local_only=False):
+                 min_shard_numel=1 << 16, ops=None, local_only=False, recycle_grads=False):
         if not 0.0 <= lr:
             raise ValueError("Invalid learning rate: {}".format(lr))
         if not 0.0 <= eps:
             raise ValueError("Invalid epsilon value: {}".format(eps))
         if not (0.0 <= betas[0] < 1.0 and 0.0 <= betas[1] < 1.0):
             raise ValueError("Invalid beta parameters: {}".format(betas))
-        # gradient buffers of grid parameters recycled through _gradpool (the HIP ops' fused dense TV + Adam pass only)
-        self.recycle_grads = ops is None
+        # recycle_grads (OPT-IN; train_utils.create_optimizer_or_freeze_model turns it on for this package's training
+        # loop): after step() the gradient buffer of a 5-D grid parameter has been re-zeroed by the update kernel, `.grad`
+        # is None and the buffer is parked in _gradpool for the parameter's next backward (no 3.5 GB zero fill per step).
+        # Off (the reference's behaviour, masked_adam.py:43-75): `.grad` survives step() untouched.  HIP ops only.
+        self.recycle_grads = bool(recycle_grads) and ops is None
         if ops is None:
             from . import adam_upd_cuda as ops
         self.ops = ops
@@ -90,11 +93,11 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
             self.ops.adam_upd_with_perlr(p, g, m, v, per_lr, *args)
         elif group['skip_zero_grad']:
             rz = getattr(self.ops, 'masked_adam_upd_rezero', None)
-            if (rz is not None and recycle is not None and self.recycle_grads and g is recycle.grad and recycle.dim() == 5
-                    and g.is_cuda and g.stride() == recycle.stride()):
+            if (rz is not None and recycle is not None and self.recycle_grads and _gradpool.enabled and g is recycle.grad
+                    and recycle.dim() == 5 and g.is_cuda and g.stride() == recycle.stride()):
                 rz(p, g, m, v, *args)
-                recycle.grad = None
-                _gradpool.give(recycle, g)
+                if _gradpool.give(recycle, g):      # parked: the pool now owns the (all-zero) buffer
+                    recycle.grad = None
             else:
                 self.ops.masked_adam_upd(p, g, m, v, *args)
         else:
@@ -112,7 +115,7 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                 alt = torch.empty_like(param.data, memory_format=torch.preserve_format)
             beta1, beta2 = group['betas']
             # the gradient buffer comes back all zero and is parked for the next backward (_gradpool): no zero fill per step
-            recycle = self.recycle_grads and g is param.grad
+            recycle = self.recycle_grads and _gradpool.enabled and g is param.grad
             kw = {'rezero_grad': True} if recycle else {}
             args = (param.data, alt, g, state['exp_avg'], state['exp_avg_sq'], w, w, w, state['step'], beta1, beta2,
                     group['lr'], group['eps'], group['skip_zero_grad'])
@@ -120,6 +123,11 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                 # the 7-pass update of this grid on a second HIP stream: the caller's stream goes on (the next forward's
                 # density march, its host syncs, the launch-bound glue) and meets it again at _lib.wait_pending
                 side.wait_stream(torch.cuda.current_stream(param.device))
+                # every array the side-stream kernel touches was allocated on the caller's stream: tell the caching
+                # allocator, so that a buffer whose last reference dies before the pass has run (zero_grad(set_to_none),
+                # a pool that refuses it, a replaced `alt`) is not handed to another tensor while it is still in use
+                for t_ in (g, alt, param.data, state['exp_avg'], state['exp_avg_sq']):
+                    t_.record_stream(side)
                 with torch.cuda.stream(side):
                     done = fused_fn(*args, **kw)
                     if done:
@@ -131,9 +139,8 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
             if done:
                 self._alt[param] = param.data
                 param.data = alt
-                if recycle:
+                if recycle and _gradpool.give(param, g):     # parked (all zero once the pass has run); else .grad keeps it alive
                     param.grad = None
-                    _gradpool.give(param, g)
                 return
         if tv_module is None:
             from . import total_variation_cuda as tv_module

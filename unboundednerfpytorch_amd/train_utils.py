@@ -16,11 +16,15 @@ def _cfg_get(cfg, key):
     return cfg[key] if isinstance(cfg, dict) else getattr(cfg, key)
 
 
-def create_optimizer_or_freeze_model(model, cfg_train, global_step, verbose=False, sharded=False, group=None, ops=None):
+def create_optimizer_or_freeze_model(model, cfg_train, global_step, verbose=False, sharded=False, group=None, ops=None,
+                                     recycle_grads=True):
     """cfg_train: mapping or attribute object with `lrate_<field>` entries, `lrate_decay` (in thousands of steps) and
     `skip_zero_grad_fields`.  Every `lrate_<field>` whose <field> is an attribute of the model becomes one param group
     with lr = lrate * 0.1 ** (global_step / (lrate_decay * 1000)); lr <= 0 freezes the field instead.
-    sharded=True builds a ShardedMaskedAdam over `group` (data-parallel training), otherwise a MaskedAdam."""
+    sharded=True builds a ShardedMaskedAdam over `group` (data-parallel training), otherwise a MaskedAdam.
+    recycle_grads (this package's training loop, train_step.train_iteration: on): the grid gradients' buffers are
+    re-zeroed by the update kernels and recycled, `.grad` is None after step() -- pass False for code that reads gradients
+    after the step (the drop-in MaskedAdam class itself defaults to the reference's behaviour)."""
     keys = list(cfg_train.keys())
     decay = 0.1 ** (global_step / (_cfg_get(cfg_train, 'lrate_decay') * 1000))
     skip_fields = _cfg_get(cfg_train, 'skip_zero_grad_fields')
@@ -45,8 +49,8 @@ def create_optimizer_or_freeze_model(model, cfg_train, global_step, verbose=Fals
             else:
                 target.requires_grad = False
     if sharded:
-        return ShardedMaskedAdam(groups, group=group, ops=ops)
-    opt = MaskedAdam(groups)
+        return ShardedMaskedAdam(groups, group=group, ops=ops, recycle_grads=recycle_grads)
+    opt = MaskedAdam(groups, recycle_grads=recycle_grads and ops is None)
     if ops is not None:
         opt.ops = ops
     return opt
@@ -58,7 +62,10 @@ def _canonical(obj):
     if torch.is_tensor(obj):
         return obj.contiguous()
     if isinstance(obj, dict):
-        return type(obj)((k, _canonical(v)) for k, v in obj.items())
+        out = type(obj)((k, _canonical(v)) for k, v in obj.items())
+        if hasattr(obj, '_metadata'):            # nn.Module.state_dict()'s version metadata (load_state_dict reads it)
+            out._metadata = obj._metadata
+        return out
     if isinstance(obj, (list, tuple)):
         return type(obj)(_canonical(v) for v in obj)
     return obj
