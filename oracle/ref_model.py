@@ -105,8 +105,11 @@ def render(model, rays_o, rays_d, viewdirs, stepsize, chunk=8192):
     """run_render.py:52-58: the reference's own chunked render loop (8192 rays per forward), per-ray outputs only."""
     keys = ("rgb_marched", "depth", "alphainv_last")
     outs = {k: [] for k in keys}
-    for b in range(0, rays_o.shape[0], chunk):
-        r = model(rays_o[b:b + chunk], rays_d[b:b + chunk], viewdirs[b:b + chunk], stepsize=stepsize, render_depth=True)
-        for k in keys:
-            outs[k].append(r[k])
+    # the reference creates its sample table without a device (FourierGrid_model.py:526-532) and relies on the program
+    # having made CUDA the default tensor type (run_FourierGrid.py: torch.set_default_tensor_type('torch.cuda.FloatTensor'))
+    with torch.device(rays_o.device):
+        for b in range(0, rays_o.shape[0], chunk):
+            r = model(rays_o[b:b + chunk], rays_d[b:b + chunk], viewdirs[b:b + chunk], stepsize=stepsize, render_depth=True)
+            for k in keys:
+                outs[k].append(r[k])
     return {k: torch.cat(v) for k, v in outs.items()}

@@ -155,8 +155,19 @@ def test_fused_render_deterministic_chunk_and_order_invariant(fr):
     state = make_state(99, G, F, C, 4, "inf", 1e-4, 6.0, 12.0)
     o, d, v = [torch.from_numpy(a).cuda() for a in synth.rays(5, R)]
     rend = fr.FourierGridRenderer(state, "cuda:0")
-    a = rend(o, d, v, stepsize=0.5, render_depth=True)
-    b = rend(o, d, v, stepsize=0.5, render_depth=True)
+    # these rays are random (64 unrelated rays per wave).  ray_order="coherent": rendered in the order given; the default
+    # ("auto") detects the incoherent list, warns once, renders it in direction / origin Morton order and puts the results
+    # back -- per-ray results must not depend on the order, so every variant below has to agree bit for bit
+    a = rend(o, d, v, stepsize=0.5, render_depth=True, ray_order="coherent")
+    fr.FourierGridRenderer._warned_incoherent = False
+    with pytest.warns(UserWarning, match="pixel-block order"):
+        b = rend(o, d, v, stepsize=0.5, render_depth=True)
+    assert float(rend.tile_spread(o, v)) > rend.INCOHERENT_TILE_SPREAD
+    srt = rend.morton_ray_order(o, v)
+    assert sorted(srt.tolist()) == list(range(R))
+    o0 = torch.zeros_like(o)                        # one camera: the sort gathers neighbouring directions into the tiles
+    srt0 = rend.morton_ray_order(o0, v)
+    assert float(rend.tile_spread(o0[srt0], v[srt0])) < 0.5 * float(rend.tile_spread(o0, v))
     for _ in range(3):  # a race shows up as a lost / duplicated survivor in a few of many thousand rays
         b2 = rend(o, d, v, stepsize=0.5, render_depth=True)
         assert torch.equal(a["rgb_marched"], b2["rgb_marched"])
@@ -178,12 +189,14 @@ def test_fused_render_deterministic_chunk_and_order_invariant(fr):
         for k in ("rgb_marched", "depth", "alphainv_last"):
             assert torch.equal(a[k], c3[k]), k
     perm = torch.from_numpy(np.random.RandomState(0).permutation(R)).cuda()
-    e = rend(o[perm].contiguous(), d[perm].contiguous(), v[perm].contiguous(), stepsize=0.5, render_depth=True)
+    e = rend(o[perm].contiguous(), d[perm].contiguous(), v[perm].contiguous(), stepsize=0.5, render_depth=True, ray_order="coherent")
+    e2 = rend(o[perm].contiguous(), d[perm].contiguous(), v[perm].contiguous(), stepsize=0.5, render_depth=True, ray_order="sort")
     for k in ("rgb_marched", "depth", "alphainv_last"):
         assert torch.equal(a[k], b[k]), k
         assert torch.equal(a[k], c[k]), k      # any chunking of the work list; single launch == two kernels
         assert torch.equal(a1[k], c2[k]), k
         assert torch.equal(a[k][perm], e[k]), k
+        assert torch.equal(a[k][perm], e2[k]), k
     assert float(a["rgb_marched"].min()) >= 0 and float(a["rgb_marched"].max()) <= 1 + 1e-5
     assert float(a["alphainv_last"].min()) >= 0 and float(a["alphainv_last"].max()) <= 1
 

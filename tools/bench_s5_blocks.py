@@ -78,7 +78,8 @@ def main():
     centroid = centroid_of(rank)
 
     def frame():
-        out = composite_blocks(rend.forward, ro, rd, vd, cam, centroid, stepsize=0.5)
+        out = composite_blocks(rend.forward, ro, rd, vd, cam, centroid, stepsize=0.5,
+                               ray_order="coherent" if order is not None else "auto")
         if order is not None:                    # the composited frame back in image order
             out = dict(out, **{k: untile(out[k], H, W) for k in ("rgb_marched", "depth", "alphainv_last") if k in out})
         return out

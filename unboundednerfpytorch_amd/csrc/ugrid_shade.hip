@@ -2,6 +2,9 @@
 // single-launch variant and the rgbnet packing kernel.
 #include "ugrid_render.h"
 #include "ugrid_shade_pc.h"
+#ifdef UG_SHADE_PROF
+extern "C" int ugx_pc_dbg_set(int bits) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pc_dbg), &bits, sizeof(int)); }
+#endif
 
 extern "C" int ug_set_march_waves(int w);  // ugrid_march.hip
 extern "C" int ug_set_tv_xcd(int m);        // ugrid_ops.hip

@@ -27,7 +27,11 @@
 #ifndef UG_PC_NBL
 // gather items (x 6 dwordx4) in flight per producer wave: 6 at F <= 3; the set-up state grows with the level count
 // (4 registers per (round, level)), so F = 4 keeps 5 and F = 5 keeps 4 in flight to stay inside 256 VGPRs without scratch
+#ifdef UG_PC_NBL_FIXED            // A/B builds
+#define UG_PC_NBL(F) UG_PC_NBL_FIXED
+#else
 #define UG_PC_NBL(F) ((F) <= 3 ? 6 : ((F) == 4 ? 5 : 4))
+#endif
 #endif
 // ring slot (floats): feat [32][12] | w [32] | sl [32] (int) | hdr {tile, count, base, -} (int)
 #define UG_PC_FEAT 0
@@ -62,9 +66,14 @@ __device__ __forceinline__ void ug_lds_publish(unsigned off, int v) {
 }
 
 #ifdef UG_SHADE_PROF
+// instrumented A/B builds only (tools/gpu_shade_pc_prof.py): g_pc_dbg bit 0 = producers skip the k0 loads (features :=
+// positions: WRONG RESULTS, shows the consumer-bound time), bit 1 = consumers skip the rgbnet (shows the producer-bound time)
+__device__ int g_pc_dbg;
+#define UG_PC_DBG(bit) (g_pc_dbg & (bit))
 #define UG_PC_T0(t) const unsigned long long t = __builtin_amdgcn_s_memtime();
 #define UG_PC_ADD(acc, t) acc += __builtin_amdgcn_s_memtime() - t;
 #else
+#define UG_PC_DBG(bit) 0
 #define UG_PC_T0(t)
 #define UG_PC_ADD(acc, t)
 #endif
@@ -86,6 +95,8 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
   int victim = 0;
 #ifdef UG_SHADE_PROF
   unsigned long long t_wait = 0, t_gather = 0, n_pass = 0;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+  const int dbg_nogather = UG_PC_DBG(1);
 #endif
   for (;;) {
     const int64_t tile = ug_next_tile(tile_counter, ws.n_tiles, blockIdx.x & 7, victim);
@@ -118,6 +129,11 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
       }
       UG_PC_T0(tg)
       float f3[2][3];
+#ifdef UG_SHADE_PROF
+      if (dbg_nogather) {
+        f3[0][0] = pg0; f3[0][1] = pg0 * 0.5f; f3[0][2] = pg0 * 0.25f; f3[1][0] = pg1; f3[1][1] = pg1 * 0.5f; f3[1][2] = pg1 * 0.25f;
+      } else
+#endif
       {
         ug_gather_state<F, NBL, 2> gst;
         const float pgs[2] = {pg0, pg1};
@@ -156,7 +172,8 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
   ++seq;
   ug_lds_publish(ctl, seq);
 #ifdef UG_SHADE_PROF
-  if (lane == 0) { atomicAdd(pstat + 0, t_gather); atomicAdd(pstat + 1, t_wait); atomicAdd(pstat + 2, n_pass); }
+  if (lane == 0) { atomicAdd(pstat + 0, t_gather); atomicAdd(pstat + 1, t_wait); atomicAdd(pstat + 2, n_pass);
+                   atomicAdd(pstat + 3, __builtin_amdgcn_s_memtime() - t_begin); }
 #endif
 }
 
@@ -178,7 +195,9 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
   int seq = 0, head_seen = 0;
   ug_prof prof_unused;
 #ifdef UG_SHADE_PROF
-  unsigned long long t_wait = 0, t_mlp = 0;
+  unsigned long long t_wait = 0, t_mlp = 0, t_tile = 0;
+  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
+  const int dbg_nomlp = UG_PC_DBG(2);
 #endif
   for (;;) {
     UG_PC_T0(tw)
@@ -203,6 +222,7 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
     ++seq;
     ug_lds_publish(ctl + 4, seq);     // the slot's values are in registers: hand it back before the rgbnet starts
     const bool ok = base + sv < count;
+    UG_PC_T0(tt_)
     if (tile != cur_tile) {
       if (cur_tile >= 0) {
         const int64_t ray = (int64_t)cur_tile * UG_WAVE + lane;
@@ -239,7 +259,11 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
 #pragma unroll
       for (int s = CH; s < KL; ++s) x[s] = er[s - CH];
     }
+    UG_PC_ADD(t_tile, tt_)
     UG_PC_T0(tm)
+#ifdef UG_SHADE_PROF
+    if (dbg_nomlp) { if (ok && h == 0 && sl == lane) { accr += x[0] * ww; accg += x[1] * ww; accb += x[KL - 1] * ww; } } else
+#endif
     ug_rgbnet_pass<C, PE, 2>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, prof_unused);
     UG_PC_ADD(t_mlp, tm)
   }
@@ -248,6 +272,7 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
     if (ray < a.n_rays) { rgb_marched[3 * ray] = accr; rgb_marched[3 * ray + 1] = accg; rgb_marched[3 * ray + 2] = accb; }
   }
 #ifdef UG_SHADE_PROF
-  if (lane == 0) { atomicAdd(pstat + 4, t_mlp); atomicAdd(pstat + 5, t_wait); }
+  if (lane == 0) { atomicAdd(pstat + 4, t_mlp); atomicAdd(pstat + 5, t_wait); atomicAdd(pstat + 6, __builtin_amdgcn_s_memtime() - t_begin);
+                   atomicAdd(pstat + 7, t_tile); }
 #endif
 }

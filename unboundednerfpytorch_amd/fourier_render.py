@@ -168,13 +168,81 @@ class FourierGridRenderer:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
+    # -- ray order ---------------------------------------------------------------------------------
+    # The march kernel gives a wave 64 CONSECUTIVE rays of the list; when those are neighbouring pixels they hit 1-6 grid
+    # cells per load and share cache lines, and the kernel runs at L1 / VALU speed.  The reference API accepts any ray list;
+    # 64 unrelated rays per wave make every lane fetch its own bricks from HBM: 8.6x slower on the S1 frame
+    # (profiles/r02/bench_s1_shuffled_rays.json).  forward(..., ray_order=...) therefore takes
+    #   "coherent"  the caller vouches for the order (render_view, bench.py: 8 x 8 pixel blocks) -- no check, no sync;
+    #   "sort"      sort the rays into direction / origin Morton order, render, put the results back (all on the device);
+    #   "auto"      (default) measure the coherence of a sample of 64-ray tiles (one small reduction + one host read),
+    #               then behave like "coherent" or "sort" (+ a one-time warning).  Lists under 4096 rays are not checked.
+    INCOHERENT_TILE_SPREAD = 0.08     # max |viewdir - viewdir of the tile's first ray|_inf; an 8 x 8 pixel block at 1080p: ~0.005
+    _warned_incoherent = False
+
+    @staticmethod
+    def tile_spread(rays_o, viewdirs, n_tiles=256):
+        """mean over a sample of 64-ray tiles of the largest direction + origin deviation from the tile's first ray (0-d tensor)"""
+        R = rays_o.shape[0]
+        T = R // 64
+        pick = torch.linspace(0, T - 1, min(n_tiles, T), device=rays_o.device).long()
+        idx = (pick[:, None] * 64 + torch.arange(64, device=rays_o.device)[None, :]).reshape(-1)
+        v = viewdirs.index_select(0, idx).view(-1, 64, 3)
+        o = rays_o.index_select(0, idx).view(-1, 64, 3)
+        dev_v = (v - v[:, :1]).abs().amax(dim=(1, 2))
+        dev_o = (o - o[:, :1]).abs().amax(dim=(1, 2))
+        return (dev_v + dev_o).mean()
+
+    def morton_ray_order(self, rays_o, viewdirs):
+        """permutation that puts rays with similar origin (coarse) and direction (fine) next to each other: int64 keys =
+        origin cell (4 bits per axis of the normalised origin) | 2 x 12-bit Morton code of the octahedral direction map"""
+        c = torch.tensor(self._vec["scene_center"], device=rays_o.device)
+        r = torch.tensor(self._vec["scene_radius"], device=rays_o.device)
+        on = ((rays_o - c) / r).clamp(-1.0, 1.0)
+        oc = ((on + 1.0) * 7.999).long()                                        # 0..15 per axis
+        v = viewdirs / viewdirs.abs().sum(-1, keepdim=True).clamp_min(1e-20)    # octahedral projection
+        uv = v[:, :2]
+        fold = (1.0 - uv.abs().flip(-1)) * torch.where(uv >= 0, 1.0, -1.0)
+        uv = torch.where(v[:, 2:3] < 0, fold, uv)
+        q = ((uv + 1.0) * 2047.999).long().clamp_(0, 4095)                      # 12 bits each
+
+        def spread(x):      # 12 bits -> every other bit of 24
+            x = (x | (x << 8)) & 0x00FF00FF
+            x = (x | (x << 4)) & 0x0F0F0F0F
+            x = (x | (x << 2)) & 0x33333333
+            return (x | (x << 1)) & 0x55555555
+        key = (((oc[:, 0] << 8) | (oc[:, 1] << 4) | oc[:, 2]) << 24) | (spread(q[:, 0]) << 1) | spread(q[:, 1])
+        return torch.sort(key).indices
+
     # -- the reference-shaped entry point ----------------------------------------------------------
     @torch.no_grad()
     def forward(self, rays_o, rays_d, viewdirs, global_step=None, is_train=False, **render_kwargs):
         """Volume rendering of R rays.  render_kwargs: stepsize (required), render_depth (depth is always
-        produced by the fused kernel; the key is returned when requested, like the reference)."""
+        produced by the fused kernel; the key is returned when requested, like the reference), ray_order
+        ("auto" | "coherent" | "sort", see above)."""
         if is_train or global_step is not None:
             raise RuntimeError("the fused renderer is inference-only; train through unboundednerfpytorch_amd.ops")
+        order = render_kwargs.get("ray_order", "auto")
+        if order not in ("auto", "coherent", "sort"):
+            raise ValueError("ray_order must be 'auto', 'coherent' or 'sort'")
+        if order != "coherent" and rays_o.dim() == 2 and rays_o.shape[0] >= 4096 and rays_o.is_cuda:
+            if order == "auto" and float(self.tile_spread(rays_o, viewdirs)) > self.INCOHERENT_TILE_SPREAD:
+                order = "sort"
+                if not FourierGridRenderer._warned_incoherent:
+                    FourierGridRenderer._warned_incoherent = True
+                    import warnings
+                    warnings.warn("FourierGridRenderer: the ray list is not in pixel-block order (64 consecutive rays are "
+                                  "unrelated); sorting it on the device -- pass ray_order='coherent' to skip the check, "
+                                  "or use render_view / pixel_tile_order", stacklevel=2)
+            if order == "sort":
+                perm = self.morton_ray_order(rays_o, viewdirs)
+                kw = dict(render_kwargs, ray_order="coherent")
+                res = self.forward(rays_o.index_select(0, perm), rays_d.index_select(0, perm), viewdirs.index_select(0, perm), **kw)
+                out = dict(res)
+                for k in ("rgb_marched", "depth", "alphainv_last"):
+                    if k in res:
+                        out[k] = torch.empty_like(res[k]).index_copy_(0, perm, res[k])
+                return out
         assert rays_o.dim() == 2 and rays_o.shape[-1] == 3, "Only support point queries in [N, 3] format"
         _lib.require_cuda(("rays_o", rays_o), ("rays_d", rays_d), ("viewdirs", viewdirs))
         _lib.require_f32(("rays_o", rays_o), ("rays_d", rays_d), ("viewdirs", viewdirs))
@@ -321,7 +389,8 @@ class FourierGridRenderer:
         else:
             ro, rd, vd = get_rays_of_a_view(H, W, K, c2w, inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y)
             ro, rd, vd = ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous(), vd.reshape(-1, 3).contiguous()
-        out = render_sharded(self.forward, ro, rd, vd, group=group, interleave=interleave, stepsize=stepsize)
+        out = render_sharded(self.forward, ro, rd, vd, group=group, interleave=interleave, stepsize=stepsize,
+                             ray_order="coherent" if order is not None else "auto")
         rgb, depth, last = out["rgb_marched"], out["depth"], out["alphainv_last"]
         if order is not None:
             rgb, depth, last = untile(rgb, H, W), untile(depth, H, W), untile(last, H, W)
