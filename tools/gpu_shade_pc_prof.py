@@ -25,6 +25,8 @@ def main():
     L = _lib.load()
     L.ugx_shade_prof_read.restype = ctypes.c_int
     L.ugx_shade_prof_read.argtypes = [ctypes.c_void_p]
+    L.ugx_shade_prof2_read.restype = ctypes.c_int
+    L.ugx_shade_prof2_read.argtypes = [ctypes.c_void_p]
     L.ugx_pc_dbg_set.restype = ctypes.c_int
     L.ugx_pc_dbg_set.argtypes = [ctypes.c_int]
     dev = torch.device("cuda", 0)
@@ -36,6 +38,7 @@ def main():
     K = [[1600.0, 0, W / 2.0], [0, 1600.0, H / 2.0], [0, 0, 1]]
     ro, rd, vd = get_rays_of_pixel_index(H, W, K, bench.camera(0, dev), pixel_tile_order(H, W, dev))
     buf = (ctypes.c_uint64 * 8)()
+    buf2 = (ctypes.c_uint64 * 8)()
     n = 3
     print("scene %s, lib %s" % (scene, os.environ.get("UGRID_LIB", "default")))
     for dbg, what in ((0, "normal"), (1, "producers skip the k0 loads (consumer-bound)"), (2, "consumers skip the rgbnet (producer-bound)"),
@@ -44,19 +47,24 @@ def main():
         rend(ro, rd, vd, stepsize=1.31, render_depth=True, ray_order="coherent")
         torch.cuda.synchronize()
         L.ugx_shade_prof_read(buf)      # discard the warm-up frame
+        L.ugx_shade_prof2_read(buf2)
         timing = []
         for _ in range(n):
             rend(ro, rd, vd, stepsize=1.31, render_depth=True, timing=timing, ray_order="coherent")
         torch.cuda.synchronize()
         L.ugx_shade_prof_read(buf)
+        L.ugx_shade_prof2_read(buf2)
         M = rend.survivors_of_last_chunk()
         v = [int(x) / n for x in buf]
+        v2 = [int(x) / n for x in buf2]
         passes = v[2]
         shade_ms = sum(ev[-2].elapsed_time(ev[-1]) for ev, _ in timing) / n
         march_ms = sum(ev[0].elapsed_time(ev[1]) for ev, _ in timing) / n
         print("== %s: shade %.3f ms (march %.3f), %d survivors, %.0f passes" % (what, shade_ms, march_ms, M, passes))
         print("   producer per pass: gather %6.0f  wait-for-slot %6.0f  total %6.0f   (1024 producer waves)" % (v[0] / passes, v[1] / passes, v[3] / passes))
         print("   consumer per pass: rgbnet %6.0f  wait-for-data %6.0f  per-tile %6.0f  total %6.0f" % (v[4] / passes, v[5] / passes, v[7] / passes, v[6] / passes))
+        print("   rgbnet phases per pass: layer 1 %6.0f  layer 2 %6.0f  layer 3 + sigmoid %6.0f  accumulation %6.0f" % (
+            v2[3] / passes, v2[4] / passes, v2[5] / passes, v2[6] / passes))
         if shade_ms > 0:
             print("   effective clock %.2f GHz (consumer ticks / kernel time per wave)" % (v[6] / 1024.0 / (shade_ms * 1e-3) / 1e9))
     L.ugx_pc_dbg_set(0)

@@ -885,6 +885,48 @@ __device__ __forceinline__ void ug_mfma3x4(const f16x8 *__restrict__ Ap, const f
   for (int o = 0; o < 4; ++o) { UG_MFMA_F16(acc[o], wh.w[o], x.h); }
 }
 
+// v2 of the k-step (UG_MLP_V2, default): the same 12 MFMAs in the same order, but (a) the NEXT step's activation split
+// (16 v_fma_mix + 8 relu) is cut into four pieces issued behind the four MFMAs of the first group -- an in-order wave can
+// only issue VALU work while an MFMA it has just issued occupies the pipe, so the split used to run exposed after the
+// group's last MFMA (phase profile: ~100 cycles per k-step) --, and (b) BOTH weight parts of the next step are requested
+// one whole MFMA group earlier (behind the first MFMA of groups 2 and 3): every ds_read_b128 has 7-8 MFMAs (> 220 cycles)
+// of cover instead of 4.  `RELU`: the next step's values are hidden activations (layer 2) and pass through max(x, 0)
+// here instead of in a separate 64-instruction loop between the layers.
+struct ug_kops { ug_hpart wl, wh; };
+template <bool RELU>
+__device__ __forceinline__ void ug_mfma3x4_v2(const f16x8 *__restrict__ Ap_next, const ug_split2 &x, const float (&v_next)[8],
+                                              float scale, ug_split2 &x_next, f32x16 (&acc)[4], ug_kops &k) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  u32x4 hh, ll;
+  ug_hpart nwl, nwh;
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    UG_MFMA_F16(acc[o], k.wl.w[o], x.h);
+    const float a = RELU ? ug_relu(v_next[2 * o]) : v_next[2 * o], b = RELU ? ug_relu(v_next[2 * o + 1]) : v_next[2 * o + 1];
+    unsigned h_, l_;
+    ug_split_pair(a, b, scale, h_, l_);
+    hh[o] = h_; ll[o] = l_;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  x_next.h = __builtin_bit_cast(f16x8, hh);
+  x_next.l = __builtin_bit_cast(f16x8, ll);
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    UG_MFMA_F16(acc[o], k.wh.w[o], x.l);
+    if (o == 0) { nwl = ug_load_hpart(Ap_next, 1); __builtin_amdgcn_sched_barrier(0); }
+  }
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    UG_MFMA_F16(acc[o], k.wh.w[o], x.h);
+    if (o == 0) { nwh = ug_load_hpart(Ap_next, 0); __builtin_amdgcn_sched_barrier(0); }
+  }
+  k.wl = nwl; k.wh = nwh;
+}
+
+#ifndef UG_MLP_V2
+#define UG_MLP_V2 1
+#endif
+
 // Optional phase profile (-DUG_SHADE_PROF, tools/gpu_shade_phases.sh): shader-clock ticks per phase of ug_shade_tile,
 // summed over all waves into g_shade_prof; phases: 0 tile set-up, 1 gather round 0, 2 gather round 1, 3 layer 1,
 // 4 layer 2, 5 layer 3 + sigmoid, 6 per-ray accumulation, 7 tile scheduling (outside this function)
@@ -957,6 +999,53 @@ __device__ __forceinline__ void ug_rgbnet_pass(const float (&x)[(2 * UG_CH(C) + 
     // products per k-step; accumulators carry the factor sW*sX (biases / W3 are pre-scaled in the image)
     const f16x8 *A1h = (const f16x8 *)M.A1, *A2h = (const f16x8 *)M.A2;
     constexpr int KB1 = (KL + 7) / 8;
+#if UG_MLP_V2
+    // layer 2's biases go straight into its accumulators now: the 16 ds_read_b128 land while layer 1 runs
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = ((const float4 *)(M.B2 + bo))[o * 4 + q];
+        acc2[o][4 * q] = b.x; acc2[o][4 * q + 1] = b.y; acc2[o][4 * q + 2] = b.z; acc2[o][4 * q + 3] = b.w;
+      }
+    ug_kops kop;
+    kop.wl = ug_load_hpart(A1h + lane, 1);
+    kop.wh = ug_load_hpart(A1h + lane, 0);
+    ug_split2 xs, xn;
+    {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (e < KL) ? x[e < KL ? e : 0] : 0.f;
+      xs = ug_split8h(v, M.sx1);
+    }
+    ug_fence_operands();
+#pragma unroll
+    for (int s = 0; s < KB1; ++s) {
+      float vn[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vn[e] = (8 * (s + 1) + e < KL) ? x[(8 * (s + 1) + e < KL) ? 8 * (s + 1) + e : 0] : 0.f;
+      ug_mfma3x4_v2<false>((s + 1 < KB1 ? A1h + ((s + 1) * 8) * 64 : A2h) + lane, xs, vn, M.sx1, xn, acc1, kop);
+      xs = xn;
+    }
+    ug_fence_results();
+    UG_PROF_MARK(prof, 3)
+    {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ug_relu(acc1[0][e]);
+      xs = ug_split8h(v, M.c12);
+    }
+    ug_fence_operands();
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      float vn[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vn[e] = acc1[(st + 1 < 8 ? st + 1 : st) >> 1][8 * ((st + 1 < 8 ? st + 1 : st) & 1) + e];
+      ug_mfma3x4_v2<true>(A2h + ((st + 1 < 8 ? st + 1 : st) * 8) * 64 + lane, xs, vn, M.c12, xn, acc2, kop);
+      xs = xn;
+    }
+    ug_fence_results();
+#else
     ug_hpart wl = ug_load_hpart(A1h + lane, 1);
     ug_split2 xs, xn;
     {
@@ -999,6 +1088,7 @@ __device__ __forceinline__ void ug_rgbnet_pass(const float (&x)[(2 * UG_CH(C) + 
       xs = xn;
     }
     ug_fence_results();
+#endif
   } else {
     // fp32-accurate through bf16x3 splitting: v_mfma_f32_32x32x16_bf16, B operand = 8 values of this lane
     // (lane half h supplies k = 8h..8h+7), i.e. 8 layer-1 inputs / 8 accumulator registers per k-step
@@ -1091,6 +1181,206 @@ __device__ __forceinline__ void ug_rgbnet_pass(const float (&x)[(2 * UG_CH(C) + 
     while (m) {
       const int k = __builtin_ctz(m);
       const float4 t = aval[k];
+      accr += t.x; accg += t.y; accb += t.z;
+      m &= m - 1;
+    }
+    __builtin_amdgcn_wave_barrier();   // the next pass rewrites aval / amask
+  }
+  UG_PROF_MARK(prof, 6)
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp16x2 rgbnet pass, hand-scheduled (UG_MLP_H2, default): same arithmetic and operation order as the BF == 2 branch of
+// ug_rgbnet_pass -- results are bit-identical -- but laid out for a wave that has its SIMD's matrix pipe to itself (the
+// consumer waves of the producer / consumer kernel; the classic kernel uses it too).  Phase profile of the previous
+// version (profiles/r03/shade_pc_phases_*.txt): 10.4 k ticks per pass of which the 132 MFMAs need 4.2 k; the rest was VALU
+// and LDS latency sitting BETWEEN MFMAs of an in-order wave:
+//   * the activation split of the next k-step (8 relu + 16 v_fma_mix + the wait states between a mixlo / mixhi pair) ran
+//     behind the four MFMAs of one group: ~56 cycles of VALU per 32-cycle MFMA shadow.  Now two VALU instructions follow
+//     EACH of the 12 MFMAs of a k-step (relu in group 1, the high parts in group 2, the low parts in group 3; consecutive
+//     v_fma_mix write different registers, so no wait state is needed);
+//   * both weight parts of the next k-step are requested a whole MFMA group ahead (7-8 MFMAs of cover per ds_read_b128);
+//   * layer 2's biases are read into its accumulators before layer 1 starts, layer 1's biases for the NEXT pass while
+//     layer 3 runs (ug_h2_state carries those accumulators across passes) -- no bias read is waited for any more;
+//   * layer 3 streams W3 from LDS in double-buffered batches of 8 rows, the first one requested before layer 2's last
+//     MFMAs drain;
+//   * the per-ray survivor masks are cleared by the lane that has just read them, not in a separate LDS round trip at the
+//     start of the accumulation (MASK_ZEROED: the caller keeps amask for this purpose only).
+// ---------------------------------------------------------------------------------------------------------------------
+#ifndef UG_MLP_H2
+#define UG_MLP_H2 1
+#endif
+struct ug_h2_state { f32x16 acc1[4]; };     // layer-1 accumulators, pre-loaded with the layer's biases
+
+__device__ __forceinline__ void ug_h2_preload(const ug_mlp_lds &M, int bo, ug_h2_state &st) {
+  const float4 *b1p = (const float4 *)(M.B1 + bo);
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b = b1p[o * 4 + q];
+      st.acc1[o][4 * q] = b.x; st.acc1[o][4 * q + 1] = b.y; st.acc1[o][4 * q + 2] = b.z; st.acc1[o][4 * q + 3] = b.w;
+    }
+}
+
+__device__ __forceinline__ void ug_mix_h_lo(unsigned &h, float x0, float s) { asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(h) : "v"(x0), "v"(s)); }
+__device__ __forceinline__ void ug_mix_h_hi(unsigned &h, float x1, float s) { asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(h) : "v"(x1), "v"(s)); }
+__device__ __forceinline__ void ug_mix_l_lo(unsigned &l, float x0, float s, unsigned h) {
+  asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(l) : "v"(x0), "v"(s), "v"(h));
+}
+__device__ __forceinline__ void ug_mix_l_hi(unsigned &l, float x1, float s, unsigned h) {
+  asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(l) : "v"(x1), "v"(s), "v"(h));
+}
+
+// one k-step, 12 MFMAs in ug_mfma3x4's order, two VALU instructions of the NEXT step's operand split behind each
+template <bool RELU>
+__device__ __forceinline__ void ug_mfma3x4_v3(const f16x8 *__restrict__ Ap_next, const ug_split2 &x, const float (&v_next)[8],
+                                              float scale, ug_split2 &x_next, f32x16 (&acc)[4], ug_kops &k) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  float a[8];
+  u32x4 hh, ll;
+  unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+  ug_hpart nwl, nwh;
+  // group 1: Wl . xh   (+ relu of the next step's 8 values)
+#pragma unroll
+  for (int o = 0; o < 4; ++o) {
+    UG_MFMA_F16(acc[o], k.wl.w[o], x.h);
+    a[2 * o] = RELU ? ug_relu(v_next[2 * o]) : v_next[2 * o];
+    a[2 * o + 1] = RELU ? ug_relu(v_next[2 * o + 1]) : v_next[2 * o + 1];
+    if (RELU) asm volatile("" :: "v"(a[2 * o]), "v"(a[2 * o + 1]));
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // group 2: Wh . xl   (+ high parts; the next step's low weights are requested behind the first MFMA)
+  UG_MFMA_F16(acc[0], k.wh.w[0], x.l); ug_mix_h_lo(h0, a[0], scale); ug_mix_h_lo(h1, a[2], scale);
+  nwl = ug_load_hpart(Ap_next, 1); __builtin_amdgcn_sched_barrier(0);
+  UG_MFMA_F16(acc[1], k.wh.w[1], x.l); ug_mix_h_hi(h0, a[1], scale); ug_mix_h_hi(h1, a[3], scale); __builtin_amdgcn_sched_barrier(0);
+  UG_MFMA_F16(acc[2], k.wh.w[2], x.l); ug_mix_h_lo(h2, a[4], scale); ug_mix_h_lo(h3, a[6], scale); __builtin_amdgcn_sched_barrier(0);
+  UG_MFMA_F16(acc[3], k.wh.w[3], x.l); ug_mix_h_hi(h2, a[5], scale); ug_mix_h_hi(h3, a[7], scale); __builtin_amdgcn_sched_barrier(0);
+  // group 3: Wh . xh   (+ low parts; the next step's high weights behind the first MFMA)
+  UG_MFMA_F16(acc[0], k.wh.w[0], x.h); ug_mix_l_lo(l0, a[0], scale, h0); ug_mix_l_lo(l1, a[2], scale, h1);
+  nwh = ug_load_hpart(Ap_next, 0); __builtin_amdgcn_sched_barrier(0);
+  UG_MFMA_F16(acc[1], k.wh.w[1], x.h); ug_mix_l_hi(l0, a[1], scale, h0); ug_mix_l_hi(l1, a[3], scale, h1); __builtin_amdgcn_sched_barrier(0);
+  UG_MFMA_F16(acc[2], k.wh.w[2], x.h); ug_mix_l_lo(l2, a[4], scale, h2); ug_mix_l_lo(l3, a[6], scale, h3); __builtin_amdgcn_sched_barrier(0);
+  UG_MFMA_F16(acc[3], k.wh.w[3], x.h); ug_mix_l_hi(l2, a[5], scale, h2); ug_mix_l_hi(l3, a[7], scale, h3); __builtin_amdgcn_sched_barrier(0);
+  hh[0] = h0; hh[1] = h1; hh[2] = h2; hh[3] = h3;
+  ll[0] = l0; ll[1] = l1; ll[2] = l2; ll[3] = l3;
+  x_next.h = __builtin_bit_cast(f16x8, hh);
+  x_next.l = __builtin_bit_cast(f16x8, ll);
+  k.wl = nwl; k.wh = nwh;
+}
+
+// CARRY: the caller's state holds the layer-1 accumulators (pre-loaded with the biases) across passes -- a consumer wave has
+// the registers for that; the classic kernel, whose gather needs them, loads the biases at the start of the pass instead.
+template <int C, int PE, bool MASK_ZEROED, bool CARRY>
+__device__ __forceinline__ void ug_rgbnet_pass_h2(const float (&x)[(2 * UG_CH(C) + 3 + 6 * PE + 1) / 2], float ww, int sl, bool ok,
+                                                  const ug_mlp_lds &M, unsigned *amask, float4 *aval, float &accr, float &accg,
+                                                  float &accb, ug_h2_state &st, ug_prof &prof) {
+  constexpr int CH = UG_CH(C);
+  constexpr int NEMB = 3 + 6 * PE;
+  constexpr int KL = (2 * CH + NEMB + 1) / 2;
+  constexpr int KB1 = (KL + 7) / 8;
+  const int lane = ug_lane();
+  const int h = lane >> 5, sv = lane & 31;
+  UG_PROF_MARK(prof, 2)
+  int bo = h * 64;
+  asm volatile("" : "+v"(bo));  // keeps the bias / W3 reads inside the pass (LICM would hoist + spill them)
+  f32x16 acc2[4];
+  const f16x8 *A1h = (const f16x8 *)M.A1, *A2h = (const f16x8 *)M.A2;
+  if constexpr (!CARRY) ug_h2_preload(M, bo, st);
+  // layer 2's biases: straight into its accumulators, landing while layer 1 runs
+#pragma unroll
+  for (int o = 0; o < 4; ++o)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 b = ((const float4 *)(M.B2 + bo))[o * 4 + q];
+      acc2[o][4 * q] = b.x; acc2[o][4 * q + 1] = b.y; acc2[o][4 * q + 2] = b.z; acc2[o][4 * q + 3] = b.w;
+    }
+  ug_kops kop;
+  kop.wl = ug_load_hpart(A1h + lane, 1);
+  kop.wh = ug_load_hpart(A1h + lane, 0);
+  ug_split2 xs, xn;
+  {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (e < KL) ? x[e < KL ? e : 0] : 0.f;
+    xs = ug_split8h(v, M.sx1);
+  }
+  ug_fence_operands();
+#pragma unroll
+  for (int s = 0; s < KB1; ++s) {
+    float vn[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vn[e] = (8 * (s + 1) + e < KL) ? x[(8 * (s + 1) + e < KL) ? 8 * (s + 1) + e : 0] : 0.f;
+    ug_mfma3x4_v3<false>((s + 1 < KB1 ? A1h + ((s + 1) * 8) * 64 : A2h) + lane, xs, vn, M.sx1, xn, st.acc1, kop);
+    xs = xn;
+  }
+  ug_fence_results();
+  UG_PROF_MARK(prof, 3)
+  {
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = ug_relu(st.acc1[0][e]);
+    xs = ug_split8h(v, M.c12);
+  }
+  ug_fence_operands();
+  constexpr int W3B = 8;        // W3 rows per batch, two batches in registers
+  float4 w3[2][W3B];
+#pragma unroll
+  for (int st8 = 0; st8 < 8; ++st8) {
+    float vn[8];
+    const int nx = st8 + 1 < 8 ? st8 + 1 : st8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) vn[e] = st.acc1[nx >> 1][8 * (nx & 1) + e];
+    ug_mfma3x4_v3<true>(A2h + (nx * 8) * 64 + lane, xs, vn, M.c12, xn, acc2, kop);
+    xs = xn;
+  }
+  // first batch of layer 3's weights: requested before layer 2's last MFMAs have drained
+#pragma unroll
+  for (int i = 0; i < W3B; ++i) w3[0][i] = M.W3[bo + i];
+  ug_fence_results();
+  UG_PROF_MARK(prof, 4)
+  // the NEXT pass's layer-1 biases into the (now dead) layer-1 accumulators: they land while layer 3 runs
+  if constexpr (CARRY) ug_h2_preload(M, bo, st);
+  // ---- layer 3 (3 outputs) on the VALU: each lane of the pair reduces its 64 hidden features
+  float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+#pragma unroll
+  for (int sb = 0; sb < 64; sb += W3B) {
+    const int cur = (sb / W3B) & 1;
+    if (sb + W3B < 64) {
+#pragma unroll
+      for (int i = 0; i < W3B; ++i) w3[cur ^ 1][i] = M.W3[bo + sb + W3B + i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < W3B; ++i) {
+      const float hv = ug_relu(acc2[(sb + i) >> 4][(sb + i) & 15]);
+      l0 = fmaf(w3[cur][i].x, hv, l0);
+      l1 = fmaf(w3[cur][i].y, hv, l1);
+      l2 = fmaf(w3[cur][i].z, hv, l2);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  l0 = (l0 + __shfl_xor(l0, 32)) + M.b3[0];
+  l1 = (l1 + __shfl_xor(l1, 32)) + M.b3[1];
+  l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
+  const float pr = ww * ug_sigmoid(l0), pg = ww * ug_sigmoid(l1), pb = ww * ug_sigmoid(l2);
+  UG_PROF_MARK(prof, 5)
+  {
+    // ordered per-ray sum through LDS, as in ug_rgbnet_pass
+    if constexpr (!MASK_ZEROED) {
+      amask[lane] = 0u;
+      ug_wave_lds_sync();
+    }
+    if (ok && h == 0) {
+      aval[sv] = make_float4(pr, pg, pb, 0.f);
+      atomicOr(&amask[sl], 1u << sv);
+    }
+    ug_wave_lds_sync();
+    unsigned m = amask[lane];
+    if constexpr (MASK_ZEROED) amask[lane] = 0u;     // ready for the next pass (LDS operations of a wave execute in order)
+    while (m) {
+      const int kk = __builtin_ctz(m);
+      const float4 t = aval[kk];
       accr += t.x; accg += t.y; accb += t.z;
       m &= m - 1;
     }
@@ -1242,7 +1532,11 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
       }
     }
     UG_PROF_MARK(prof, 2)
-    ug_rgbnet_pass<C, PE, BF>(x, en.w, sl, ok, M, amask, aval, accr, accg, accb, prof);
+    if constexpr (BF == 2 && UG_MLP_H2) {
+      ug_h2_state h2st;
+      ug_rgbnet_pass_h2<C, PE, false, false>(x, en.w, sl, ok, M, amask, aval, accr, accg, accb, h2st, prof);
+    }
+    else ug_rgbnet_pass<C, PE, BF>(x, en.w, sl, ok, M, amask, aval, accr, accg, accb, prof);
   }
   const int64_t ray = tile * UG_WAVE + lane;
   if (ray < a.n_rays) {

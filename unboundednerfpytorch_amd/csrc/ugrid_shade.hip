@@ -138,11 +138,17 @@ __global__ void k_pack_mlp(const float *__restrict__ w0, const float *__restrict
 }
 
 #ifdef UG_SHADE_PROF
-__device__ unsigned long long g_shade_prof[8];
+__device__ unsigned long long g_shade_prof[16];   // [8..15]: rgbnet phases of the producer / consumer kernel
 extern "C" int ugx_shade_prof_read(unsigned long long *host8) {
   UG_HIP(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_shade_prof), 64));
   unsigned long long z[8] = {0};
   UG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_shade_prof), z, 64));
+  return 0;
+}
+extern "C" int ugx_shade_prof2_read(unsigned long long *host8) {
+  UG_HIP(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_shade_prof), 64, 64));
+  unsigned long long z[8] = {0};
+  UG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_shade_prof), z, 64, 64));
   return 0;
 }
 #define UG_PROF_INIT(pr) ug_prof pr; pr.t = __builtin_amdgcn_s_memtime(); for (int i_ = 0; i_ < 8; ++i_) pr.acc[i_] = 0;

@@ -193,7 +193,18 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
   float accr = 0.f, accg = 0.f, accb = 0.f;    // lane = ray slot of the current tile
   int cur_tile = -1;
   int seq = 0, head_seen = 0;
+#if UG_MLP_H2
+  ug_h2_state h2st;
+  ug_h2_preload(M, h * 64, h2st);
+  amask[lane] = 0u;                // the hand-scheduled pass keeps the per-ray masks cleared between passes
+  ug_wave_lds_sync();
+#endif
+#ifdef UG_SHADE_PROF
+  ug_prof prof_unused;          // phases of ug_rgbnet_pass: acc[3] layer 1, [4] layer 2, [5] layer 3 + sigmoid, [6] accumulation
+  for (int i_ = 0; i_ < 8; ++i_) prof_unused.acc[i_] = 0;
+#else
   ug_prof prof_unused;
+#endif
 #ifdef UG_SHADE_PROF
   unsigned long long t_wait = 0, t_mlp = 0, t_tile = 0;
   const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
@@ -262,9 +273,14 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
     UG_PC_ADD(t_tile, tt_)
     UG_PC_T0(tm)
 #ifdef UG_SHADE_PROF
+    prof_unused.t = tm;
     if (dbg_nomlp) { if (ok && h == 0 && sl == lane) { accr += x[0] * ww; accg += x[1] * ww; accb += x[KL - 1] * ww; } } else
 #endif
+#if UG_MLP_H2
+    ug_rgbnet_pass_h2<C, PE, true, true>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, h2st, prof_unused);
+#else
     ug_rgbnet_pass<C, PE, 2>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, prof_unused);
+#endif
     UG_PC_ADD(t_mlp, tm)
   }
   if (cur_tile >= 0) {
@@ -273,6 +289,7 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
   }
 #ifdef UG_SHADE_PROF
   if (lane == 0) { atomicAdd(pstat + 4, t_mlp); atomicAdd(pstat + 5, t_wait); atomicAdd(pstat + 6, __builtin_amdgcn_s_memtime() - t_begin);
-                   atomicAdd(pstat + 7, t_tile); }
+                   atomicAdd(pstat + 7, t_tile);
+                   for (int i_ = 3; i_ < 7; ++i_) atomicAdd(pstat + 8 + i_, prof_unused.acc[i_]); }
 #endif
 }
