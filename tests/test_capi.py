@@ -249,24 +249,25 @@ def test_shade_kernel_instruction_stream_regression(lib_path):
         MFMA issued right before it (the gfx950 dependent-MFMA observation, tools/microbench/mfma_dep_hazard.hip);
       * the hand-off polls sleep (s_sleep) instead of spinning."""
     import re
-    asm = _kernel_disassembly(lib_path, "_Z10k_shade_pcILi3ELi4E")
-    assert asm and len(asm) > 2000
-    ops = [l.split()[0] for l in asm]
-    assert not [o for o in ops if o.startswith(("flat_", "scratch_"))]
-    seq = [("L", None) if o == "global_load_dwordx4" else ("W", int(re.search(r"vmcnt\((\d+)\)", l).group(1)))
-           for o, l in zip(ops, asm) if o == "global_load_dwordx4" or (o == "s_waitcnt" and "vmcnt" in l)]
-    # find the gather: 36 loads, then [wait 30, 6 loads] x 8, wait 30, wait 24 ... wait 0
-    flat = "".join("L" if k == "L" else "<%d>" % n for k, n in seq)
-    want = "L" * 36 + ("<30>" + "L" * 6) * 8 + "<30><24><18><12><6><0>"
-    assert want in flat, flat[-400:]
-    mf = [l for l in asm if l.startswith("v_mfma")]
-    assert len(mf) == 132 and all(l.startswith("v_mfma_f32_32x32x16_f16") for l in mf), len(mf)
-    dst = [re.match(r"\S+\s+([av]\[\d+:\d+\])", l).group(1) for l in mf]
-    assert all(a != b for a, b in zip(dst[:-1], dst[1:])), "back-to-back MFMAs on one accumulator"
-    for l in mf:                                      # D = A x B + C with C = D: the accumulator chain the order protects
-        regs = re.findall(r"[av]\[\d+:\d+\]", l)
-        assert regs[0] == regs[-1], l
-    assert ops.count("s_sleep") >= 2
+    # (geometry, gather pattern): 8 waves = 6 items (36 loads) in flight, 12 waves = 3 items (18 loads)
+    for sym, want in (("_Z10k_shade_pcILi3ELi4ELi4ELi4ELi6ELb0E", "L" * 36 + ("<30>" + "L" * 6) * 8 + "<30><24><18><12><6><0>"),
+                      ("_Z10k_shade_pcILi3ELi4ELi6ELi2ELi3ELb1E", "L" * 18 + ("<12>" + "L" * 6) * 11 + "<12><6><0>")):
+        asm = _kernel_disassembly(lib_path, sym)
+        assert asm and len(asm) > 2000, sym
+        ops = [l.split()[0] for l in asm]
+        assert not [o for o in ops if o.startswith(("flat_", "scratch_"))], sym
+        seq = [("L", None) if o == "global_load_dwordx4" else ("W", int(re.search(r"vmcnt\((\d+)\)", l).group(1)))
+               for o, l in zip(ops, asm) if o == "global_load_dwordx4" or (o == "s_waitcnt" and "vmcnt" in l)]
+        flat = "".join("L" if k == "L" else "<%d>" % n for k, n in seq)
+        assert want in flat, (sym, flat[-400:])
+        mf = [l for l in asm if l.startswith("v_mfma")]
+        assert len(mf) == 132 and all(l.startswith("v_mfma_f32_32x32x16_f16") for l in mf), (sym, len(mf))
+        dst = [re.match(r"\S+\s+([av]\[\d+:\d+\])", l).group(1) for l in mf]
+        assert all(a != b for a, b in zip(dst[:-1], dst[1:])), "back-to-back MFMAs on one accumulator: " + sym
+        for l in mf:                                      # D = A x B + C with C = D: the accumulator chain the order protects
+            regs = re.findall(r"[av]\[\d+:\d+\]", l)
+            assert regs[0] == regs[-1], l
+        assert ops.count("s_sleep") >= 2, sym
     # the classic kernel keeps the same gather with 24 loads in flight
     asm2 = _kernel_disassembly(lib_path, "_Z11k_shade_mlpILi3ELi12ELi4ELi8ELi2E")
     ops2 = [l.split()[0] for l in asm2]

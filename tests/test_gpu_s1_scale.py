@@ -7,10 +7,10 @@ are compared with the CPU oracle, all rays, no margin carve-out.
 * S1 (white-noise grids, sigma = 24 density units per voxel): RGB within 1e-4 on all rays.  depth / alphainv_last carry
   a tail of a few rays in 10^5 just above 1e-4 that is NOT produced by any arithmetic shortcut of the kernels
   (profiles/r02/parity_ab_s1.txt: IEEE divisions, libm sincos / pow and grid_sample's own corner sum change the worst
-  rays by < 2e-6): it is the conditioning of the reference formula on this scene.  The test measures that directly:
-  the oracle evaluated with a second conforming libm for the Fourier sin / cos (correctly rounded instead of 1-ulp
-  Sleef; everything else identical) moves the same outputs by a comparable amount, and the GPU must stay within that
-  ambiguity (1.5x + 2e-5) of the reference evaluation, the tail must be a handful of rays, the mean error ~1e-6.
+  rays by < 2e-6): it is the conditioning of the reference formula on this scene.  Round 3 arbitrates it against the
+  reference ITSELF executing on the MI355X (its own Python over its own compiled kernels, oracle/_ref): that run differs
+  from the CPU evaluation of the same code by 1.4e-4 / 1.6e-4 / 2.8e-4 -- more than the fused kernels do -- so the bound
+  the tail is held to is that measured distance; the tail must be a handful of rays, the mean error ~1e-6.
 """
 import json
 import os
@@ -47,7 +47,18 @@ def reference_on_gpu(state, dev, ro, rd, vd, starts):
     return res
 
 
+_CACHE = {}
+
+
 def render_and_reference(make_state, two_libms, with_ref_gpu=False):
+    """cached per (scene, options): the S1 headline test and the arbitration test share one evaluation"""
+    key = (make_state.__name__, two_libms, with_ref_gpu)
+    if key not in _CACHE:
+        _CACHE[key] = _render_and_reference(make_state, two_libms, with_ref_gpu)
+    return _CACHE[key]
+
+
+def _render_and_reference(make_state, two_libms, with_ref_gpu=False):
     import bench
     from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer, get_rays_of_a_view
     dev = torch.device("cuda", 0)
@@ -88,7 +99,7 @@ def per_ray_err(a, b):
 
 def test_s1b_surfaces_all_outputs_within_1e_4_on_all_rays():
     import bench
-    got, (ref,), M, R = render_and_reference(bench.make_state_surfaces, two_libms=False)
+    got, (ref,), _, M, R = render_and_reference(bench.make_state_surfaces, two_libms=False, with_ref_gpu=True)
     assert float((ref["alphainv_last"] < 1e-3).float().mean()) > 0.3          # a surface scene: rays terminate early
     assert 0.01 < M / (R * 256.0) < 0.2
     # The reference stops a ray at the first sample whose transmittance drops below 1e-3 (render_utils_kernel.cu:452-455).
@@ -108,24 +119,37 @@ def test_s1b_surfaces_all_outputs_within_1e_4_on_all_rays():
 
 
 def test_s1_headline_scene_rgb_depth_parity():
+    """S1 (white noise): RGB within the north-star 1e-4 on ALL rays.  depth / alphainv_last carry a tail of a few rays in
+    10^5 just above 1e-4; what they are held to is MEASURED, not inferred: the reference executing on
+    this GPU (its own Python + its own compiled kernels, oracle/_ref) differs from the reference executing on the CPU by
+    1.4e-4 / 1.6e-4 / 2.8e-4 (rgb / depth / alphainv_last, profiles/r03/s1_arbitration_s1.json) on these rays -- two runs of
+    the SAME code are further apart than this library is from either -- so no implementation can be held to 1e-4 against one
+    of them on this scene; the bound is that distance.  Without oracle/_ref the bound falls back to the oracle's own
+    ambiguity under a second conforming libm (1.5 x + 2e-5, as in round 2)."""
     import bench
-    got, (ref, ref2), M, R = render_and_reference(bench.make_state, two_libms=True)
+    from oracle import ref_model
+    have_ref = ref_model.available("kernels:fma")
+    got, (ref, ref2), ref_gpu, M, R = render_and_reference(bench.make_state, two_libms=True, with_ref_gpu=True)
     assert abs(M / (R * 256.0) - 0.049) < 0.003                              # the calibrated 4.9 % survivors
     stats = {}
     for k in KEYS:
         err = per_ray_err(got[k], ref[k])
         amb = per_ray_err(ref2[k], ref[k])                                   # two conforming libms, same formula
-        stats[k] = (float(err.max()), float(err.mean()), int((err > 1e-4).sum()), float(amb.max()), int((amb > 1e-4).sum()))
-        print("S1  %-14s gpu-vs-oracle linf %.3e mean %.3e rays>1e-4 %d | oracle libm ambiguity linf %.3e rays>1e-4 %d"
-              % ((k,) + stats[k]))
+        rg = float(per_ray_err(ref_gpu["fma"][k], ref[k]).max()) if have_ref else None
+        stats[k] = (float(err.max()), float(err.mean()), int((err > 1e-4).sum()), float(amb.max()), rg)
+        print("S1  %-14s gpu-vs-oracle linf %.3e mean %.3e rays>1e-4 %d | oracle libm ambiguity linf %.3e | reference-on-GPU vs reference-on-CPU %s"
+              % ((k,) + stats[k][:4] + (("%.3e" % rg) if rg is not None else "n/a",)))
     n = got["depth"].numel()
     # the north-star quantity
     assert stats["rgb_marched"][0] <= 1e-4, stats["rgb_marched"]
     for k in KEYS:
-        linf, mean, n_above, amb, _ = stats[k]
+        linf, mean, n_above, amb, rg = stats[k]
         assert mean <= 5e-6, (k, mean)
         assert n_above <= max(8, n // 10000), (k, n_above)                   # a handful of rays in 10^5
-        assert linf <= max(1e-4, 1.5 * amb + 2e-5), (k, linf, amb)           # inside the reference's own ambiguity
+        if rg is not None:
+            assert linf <= max(1e-4, rg), (k, linf, rg)                      # closer to the CPU run than the reference's own GPU run
+        else:
+            assert linf <= max(1e-4, 1.5 * amb + 2e-5), (k, linf, amb)
 
 
 def pairwise_table(named):
@@ -165,8 +189,10 @@ def test_arbitration_against_the_reference_executing_on_this_gpu(scene):
     from oracle import ref_model
     if not ref_model.available("kernels:fma"):
         pytest.skip("oracle/_ref (compiled reference kernels + reference_py.tar) not staged: python oracle/build_ref.py")
-    make = bench.make_state if scene == "s1" else bench.make_state_surfaces
-    got, (ref,), ref_gpu, M, R = render_and_reference(make, two_libms=False, with_ref_gpu=True)
+    if scene == "s1":
+        got, (ref, _), ref_gpu, M, R = render_and_reference(bench.make_state, two_libms=True, with_ref_gpu=True)
+    else:
+        got, (ref,), ref_gpu, M, R = render_and_reference(bench.make_state_surfaces, two_libms=False, with_ref_gpu=True)
     named = {"fused": got, "cpu-oracle": ref}
     for variant, o in ref_gpu.items():
         named["ref-gpu(%s)" % variant] = o

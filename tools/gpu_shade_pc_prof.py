@@ -32,6 +32,10 @@ def main():
     dev = torch.device("cuda", 0)
     G, H, W = 200, 1080, 1920
     scene = sys.argv[1] if len(sys.argv) > 1 else "s1"
+    pc = int(sys.argv[2]) if len(sys.argv) > 2 else 2           # 2 = 12-wave geometry (6 + 6 waves per CU), 1 = 8-wave (4 + 4)
+    from unboundednerfpytorch_amd.fourier_render import tune
+    tune("shade_pc", pc)
+    n_pairs = 256 * (6 if pc == 2 else 4)
     state = (bench.make_state if scene == "s1" else bench.make_state_surfaces)(G, dev, seed=0)
     rend = FourierGridRenderer(state, dev)
     del state
@@ -40,7 +44,7 @@ def main():
     buf = (ctypes.c_uint64 * 8)()
     buf2 = (ctypes.c_uint64 * 8)()
     n = 3
-    print("scene %s, lib %s" % (scene, os.environ.get("UGRID_LIB", "default")))
+    print("scene %s, lib %s, shade_pc=%d: %d producer + %d consumer waves" % (scene, os.environ.get("UGRID_LIB", "default"), pc, n_pairs, n_pairs))
     for dbg, what in ((0, "normal"), (1, "producers skip the k0 loads (consumer-bound)"), (2, "consumers skip the rgbnet (producer-bound)"),
                       (3, "both skipped (hand-off + scheduling only)")):
         L.ugx_pc_dbg_set(dbg)
@@ -61,12 +65,12 @@ def main():
         shade_ms = sum(ev[-2].elapsed_time(ev[-1]) for ev, _ in timing) / n
         march_ms = sum(ev[0].elapsed_time(ev[1]) for ev, _ in timing) / n
         print("== %s: shade %.3f ms (march %.3f), %d survivors, %.0f passes" % (what, shade_ms, march_ms, M, passes))
-        print("   producer per pass: gather %6.0f  wait-for-slot %6.0f  total %6.0f   (1024 producer waves)" % (v[0] / passes, v[1] / passes, v[3] / passes))
+        print("   producer per pass: gather %6.0f  wait-for-slot %6.0f  total %6.0f" % (v[0] / passes, v[1] / passes, v[3] / passes))
         print("   consumer per pass: rgbnet %6.0f  wait-for-data %6.0f  per-tile %6.0f  total %6.0f" % (v[4] / passes, v[5] / passes, v[7] / passes, v[6] / passes))
         print("   rgbnet phases per pass: layer 1 %6.0f  layer 2 %6.0f  layer 3 + sigmoid %6.0f  accumulation %6.0f" % (
             v2[3] / passes, v2[4] / passes, v2[5] / passes, v2[6] / passes))
         if shade_ms > 0:
-            print("   effective clock %.2f GHz (consumer ticks / kernel time per wave)" % (v[6] / 1024.0 / (shade_ms * 1e-3) / 1e9))
+            print("   effective clock %.2f GHz (consumer ticks / kernel time per wave)" % (v[6] / float(n_pairs) / (shade_ms * 1e-3) / 1e9))
     L.ugx_pc_dbg_set(0)
 
 

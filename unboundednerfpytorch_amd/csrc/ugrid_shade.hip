@@ -8,8 +8,9 @@ extern "C" int ugx_pc_dbg_set(int bits) { return (int)hipMemcpyToSymbol(HIP_SYMB
 
 extern "C" int ug_set_march_waves(int w);  // ugrid_march.hip
 extern "C" int ug_set_tv_xcd(int m);        // ugrid_ops.hip
-static int g_shade_pc = 1;   // ugrid_tune("shade_pc", 0|1): producer / consumer shade kernel where it applies (default) or the
-                             // classic one-wave-does-everything kernel -- bit-identical results, A/B switch for measurements
+static int g_shade_pc = 2;   // ugrid_tune("shade_pc", 0|1|2): 2 = 12-wave producer / consumer shade kernel where it applies (default),
+                             // 1 = its 8-wave form, 0 = the classic one-wave-does-everything kernel -- bit-identical results,
+                             // A/B switch for measurements
 #ifdef UG_EXPERIMENTS        // csrc/build.sh with UG_EXPERIMENTS=1: the rejected A/B arms, never in the shipped library
 static int g_shade_dbg = 0;  // ugrid_tune("shade_dbg", bits) -- WRONG RESULTS by design (see ug_shade_tile16)
 static int g_shade16 = 0;    // ugrid_tune("shade16", 0|1): 16x16x32 / 16-wave kernel where it applies
@@ -178,32 +179,33 @@ k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__
   UG_PROF_FLUSH(prof)
 }
 
-// producer / consumer shade kernel (ugrid_shade_pc.h): C = 12 quad bricks, fp16x2 rgbnet; 4 gather waves + 4 rgbnet waves
-// per workgroup, one workgroup per CU
-template <int F, int PE>
-__global__ void __launch_bounds__(512, 2)
+// producer / consumer shade kernels (ugrid_shade_pc.h): C = 12 quad bricks, fp16x2 rgbnet; NPAIR gather waves + NPAIR rgbnet
+// waves per workgroup, one workgroup per CU.  <4, 4 slots, 6 in flight, 4-tile pass> = 8 waves of 256 VGPRs;
+// <6, 2 slots, 3 in flight, lean pass> = 12 waves of <= 168 VGPRs
+template <int F, int PE, int NPAIR, int SLOTS, int NBL, bool LEAN>
+__global__ void __launch_bounds__(NPAIR * 128, (NPAIR * 2 + 3) / 4)
 k_shade_pc(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
            const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
            int32_t *__restrict__ tile_counter) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int MLPF = ug_mlp_lds_floats<12, PE, 2>();
   float *pairs = lds + MLPF;
-  if (threadIdx.x < 16)      // head / tail counters of the four rings
-    ((int *)(pairs + (threadIdx.x >> 2) * UG_PC_PAIR_FLOATS + UG_PC_SLOTS * UG_PC_SLOT_FLOATS))[threadIdx.x & 3] = 0;
+  if (threadIdx.x < 4 * NPAIR)      // head / tail counters of the rings
+    ((int *)(pairs + (threadIdx.x >> 2) * UG_PC_PAIR_FLOATS(SLOTS) + SLOTS * UG_PC_SLOT_FLOATS))[threadIdx.x & 3] = 0;
   const ug_mlp_lds M = ug_mlp_stage<12, PE, 2>(lds, mlp);     // ends with __syncthreads()
-  const int wv = threadIdx.x >> 6, pair = wv & 3;
-  float *ring = pairs + pair * UG_PC_PAIR_FLOATS;
-  const unsigned ctl = ug_lds_off(ring + UG_PC_SLOTS * UG_PC_SLOT_FLOATS);
+  const int wv = threadIdx.x >> 6, pair = wv % NPAIR;
+  float *ring = pairs + pair * UG_PC_PAIR_FLOATS(SLOTS);
+  const unsigned ctl = ug_lds_off(ring + SLOTS * UG_PC_SLOT_FLOATS);
 #ifdef UG_SHADE_PROF
   unsigned long long *pstat = g_shade_prof;
 #else
   unsigned long long *pstat = nullptr;
 #endif
-  if (wv < 4) {
-    ug_pc_producer<F>(a, k0b, ws, rgb_marched, tile_counter, ring, ctl, pstat);
+  if (wv < NPAIR) {
+    ug_pc_producer<F, NBL, SLOTS>(a, k0b, ws, rgb_marched, tile_counter, ring, ctl, pstat);
   } else {
-    float *scr = pairs + 4 * UG_PC_PAIR_FLOATS + pair * ug_pc_consumer_scratch_floats<PE>();
-    ug_pc_consumer<PE>(a, viewdirs, M, rgb_marched, ring, ctl, scr, pstat);
+    float *scr = pairs + NPAIR * UG_PC_PAIR_FLOATS(SLOTS) + pair * ug_pc_consumer_scratch_floats<PE>();
+    ug_pc_consumer<PE, SLOTS, LEAN>(a, viewdirs, M, rgb_marched, ring, ctl, scr, pstat);
   }
 }
 
@@ -486,7 +488,7 @@ extern "C" int ugrid_tune(const char *key, int value) {
   if (!key) return (int)hipErrorInvalidValue;
   if (!strcmp(key, "march_waves")) return ug_set_march_waves(value) ? (int)hipErrorInvalidValue : 0;
   if (!strcmp(key, "tv_xcd")) return ug_set_tv_xcd(value) ? (int)hipErrorInvalidValue : 0;
-  if (!strcmp(key, "shade_pc") && (value == 0 || value == 1)) { g_shade_pc = value; return 0; }
+  if (!strcmp(key, "shade_pc") && value >= 0 && value <= 2) { g_shade_pc = value; return 0; }
 #ifdef UG_EXPERIMENTS
   if (!strcmp(key, "shade16") && (value == 0 || value == 1)) { g_shade16 = value; return 0; }
   if (!strcmp(key, "shade_dbg") && value >= 0 && value < 4) { g_shade_dbg = value; return 0; }
@@ -515,23 +517,23 @@ static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, con
 }
 
 
-template <int F, int PE>
+template <int F, int PE, int NPAIR, int SLOTS, int NBL, bool LEAN>
 static int ug_shade_pc_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
                               ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
-  const int lds_bytes = ug_pc_lds_bytes<PE>();
+  const int lds_bytes = ug_pc_lds_bytes<PE, NPAIR, SLOTS>();
   if (lds_bytes > 160 * 1024) return (int)hipErrorInvalidValue;   // the CU's LDS
   static bool attr_set = false;
   if (!attr_set) {
-    UG_HIP(hipFuncSetAttribute((const void *)k_shade_pc<F, PE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    UG_HIP(hipFuncSetAttribute((const void *)k_shade_pc<F, PE, NPAIR, SLOTS, NBL, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
   UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
-  // persistent, one workgroup per CU: 4 producer waves pull tiles, so a workgroup covers >= 4 tiles
-  int64_t wgs = (ws.n_tiles + 3) / 4;
+  // persistent, one workgroup per CU: NPAIR producer waves pull tiles, so a workgroup covers >= NPAIR tiles
+  int64_t wgs = (ws.n_tiles + NPAIR - 1) / NPAIR;
   if (wgs > 256) wgs = 256;
   wgs = (wgs + 7) / 8 * 8;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_pc<F, PE>), dim3((unsigned)wgs), dim3(512), lds_bytes, st, a, viewdirs, k0b, mlp,
-                     ws, rgb, counter);
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_pc<F, PE, NPAIR, SLOTS, NBL, LEAN>), dim3((unsigned)wgs), dim3(NPAIR * 128), lds_bytes, st,
+                     a, viewdirs, k0b, mlp, ws, rgb, counter);
   UG_LAUNCH_CHECK();
   return 0;
 }
@@ -567,7 +569,12 @@ static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const 
   }
 #endif
   if constexpr (C == 12) {
-    if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc) return ug_shade_pc_launch<F, PE>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+    if constexpr (F <= 3) {      // the producers' set-up state grows with the level count: F >= 4 does not fit 168 VGPRs
+      if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc == 2)
+        return ug_shade_pc_launch<F, PE, 6, 2, 3, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+    }
+    if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc >= 1)
+      return ug_shade_pc_launch<F, PE, 4, 4, UG_PC_NBL(F), false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
   }
   // every variant runs 8 waves per workgroup (2 per SIMD, <= 256 registers each).  A 12-wave bf16x3 build needed
   // spills and gained 4 %; it is not instantiated.

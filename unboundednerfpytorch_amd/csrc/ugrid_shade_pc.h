@@ -13,7 +13,7 @@
 //               the fp16x2 MFMA chain + layer 3 + the ordered per-ray accumulation (ug_rgbnet_pass, unchanged arithmetic).
 //
 // Wave w and w + 4 of a workgroup land on the same SIMD: every SIMD has exactly one wave on its matrix pipe and one wave
-// feeding the vector-memory path, so neither competes with a twin for its unit.  The ring (UG_PC_SLOTS slots per pair)
+// feeding the vector-memory path, so neither competes with a twin for its unit.  The ring (SLOTS slots per pair)
 // decouples memory latency from the MFMA chain.  Hand-off = two monotone LDS counters per pair (head: written by the
 // producer only, tail: by the consumer only), polled with ds_read + s_sleep; LDS operations of a wave complete in order, a
 // counter is published after `s_waitcnt lgkmcnt(0)`.  Results are bit-identical to k_shade_mlp: same gather, same rgbnet,
@@ -21,11 +21,15 @@
 #pragma once
 #include "ugrid_render.h"
 
-#ifndef UG_PC_SLOTS
-#define UG_PC_SLOTS 4
-#endif
+// Two geometries are built (ugrid_shade.hip):
+//   k_shade_pc   <F, PE>  8 waves / CU (256 VGPRs each):  4 producers (6 gather items in flight) + 4 consumers running the
+//                         hand-scheduled 4-tile rgbnet pass, 4-slot rings;
+//   k_shade_pc12 <F, PE> 12 waves / CU (<= 168 VGPRs each): 6 producers (3 items in flight) + 6 consumers running the LEAN
+//                         pass (layer 2 two output tiles at a time, ug_rgbnet_pass_lean), 2-slot rings.  Why: the rgbnet chain
+//                         of ONE wave is latency-bound (9-11 k ticks per pass against 4.2 k of MFMA issue, phase profiles in
+//                         profiles/r03/); three waves per SIMD overlap each other's stalls, two cannot.
 #ifndef UG_PC_NBL
-// gather items (x 6 dwordx4) in flight per producer wave: 6 at F <= 3; the set-up state grows with the level count
+// 8-wave geometry: gather items (x 6 dwordx4) in flight per producer wave: 6 at F <= 3; the set-up state grows with the level count
 // (4 registers per (round, level)), so F = 4 keeps 5 and F = 5 keeps 4 in flight to stay inside 256 VGPRs without scratch
 #ifdef UG_PC_NBL_FIXED            // A/B builds
 #define UG_PC_NBL(F) UG_PC_NBL_FIXED
@@ -40,15 +44,15 @@
 #define UG_PC_HDR 448
 #define UG_PC_SLOT_FLOATS 452
 // per pair: ring | ctl {head, tail, -, -}
-#define UG_PC_PAIR_FLOATS (UG_PC_SLOTS * UG_PC_SLOT_FLOATS + 4)
+#define UG_PC_PAIR_FLOATS(SLOTS) ((SLOTS) * UG_PC_SLOT_FLOATS + 4)
 
 template <int PE>
 __host__ __device__ static inline int ug_pc_consumer_scratch_floats() {
   return ug_wave_scratch_floats<12, PE, 2>();      // amask | aval | per-tile embedding table
 }
-template <int PE>
+template <int PE, int NPAIR, int SLOTS>
 __host__ __device__ static inline int ug_pc_lds_bytes() {
-  return (int)sizeof(float) * (ug_mlp_lds_floats<12, PE, 2>() + 4 * UG_PC_PAIR_FLOATS + 4 * ug_pc_consumer_scratch_floats<PE>());
+  return (int)sizeof(float) * (ug_mlp_lds_floats<12, PE, 2>() + NPAIR * UG_PC_PAIR_FLOATS(SLOTS) + NPAIR * ug_pc_consumer_scratch_floats<PE>());
 }
 
 // ---- LDS counters: explicit ds_ instructions on the 32-bit LDS offset (no flat_ access may sneak in: flat operations
@@ -79,13 +83,168 @@ __device__ int g_pc_dbg;
 #endif
 
 // ---------------------------------------------------------------------------------------------------------------------
+// LEAN fp16x2 rgbnet pass for the 12-wave geometry (<= 168 VGPRs): same products, same accumulation order per output
+// element and the same layer-3 / per-ray summation order as ug_rgbnet_pass_h2 -- bit-identical results -- with a smaller
+// register footprint:
+//   * layer 1 as before (4 output tiles = 64 accumulator registers, the 20 inputs die as they are split);
+//   * the hidden activations are rectified and split ONCE into their fp16 (h, l) operand form, in place of the layer-1
+//     accumulators (8 k-steps x 8 registers = the same 64 registers);
+//   * layer 2 runs TWO of its four output tiles at a time (32 accumulator registers instead of 64), each half followed by
+//     its 32 rows of layer 3 on the VALU; the second half re-uses the split operands.
+// The wave leaves stalls exposed (dependent MFMAs two apart, layer 3 not overlapped with MFMAs): its two SIMD neighbours
+// fill them.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ug_hpair { f16x8 w[2]; };
+__device__ __forceinline__ ug_hpair ug_load_hpair(const f16x8 *__restrict__ Ap, int o0, int part) {
+  ug_hpair p;
+  p.w[0] = Ap[((o0 + 0) * 2 + part) * 64];
+  p.w[1] = Ap[((o0 + 1) * 2 + part) * 64];
+  return p;
+}
+
+template <int C, int PE>
+__device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(C) + 3 + 6 * PE + 1) / 2], float ww, int sl, bool ok,
+                                                    const ug_mlp_lds &M, unsigned *amask, float4 *aval, float &accr, float &accg,
+                                                    float &accb, ug_prof &prof) {
+  constexpr int CH = UG_CH(C);
+  constexpr int NEMB = 3 + 6 * PE;
+  constexpr int KL = (2 * CH + NEMB + 1) / 2;
+  constexpr int KB1 = (KL + 7) / 8;
+  const int lane = ug_lane();
+  const int h = lane >> 5, sv = lane & 31;
+  UG_PROF_MARK(prof, 2)
+  int bo = h * 64;
+  asm volatile("" : "+v"(bo));
+  const f16x8 *A1h = (const f16x8 *)M.A1, *A2h = (const f16x8 *)M.A2;
+  ug_split2 hs[8];                      // layer-2 B operands: relu(layer 1) * c12, split, k-step major
+  {
+    // ---- layer 1
+    f32x16 acc1[4];
+    {
+      const float4 *b1p = (const float4 *)(M.B1 + bo);
+#pragma unroll
+      for (int o = 0; o < 4; ++o)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 b = b1p[o * 4 + q];
+          acc1[o][4 * q] = b.x; acc1[o][4 * q + 1] = b.y; acc1[o][4 * q + 2] = b.z; acc1[o][4 * q + 3] = b.w;
+        }
+    }
+    ug_hpart wl = ug_load_hpart(A1h + lane, 1);
+    ug_split2 xs, xn;
+    {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (e < KL) ? x[e < KL ? e : 0] : 0.f;
+      xs = ug_split8h(v, M.sx1);
+    }
+    ug_fence_operands();
+#pragma unroll
+    for (int s = 0; s < KB1; ++s) {
+      float vn[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) vn[e] = (8 * (s + 1) + e < KL) ? x[(8 * (s + 1) + e < KL) ? 8 * (s + 1) + e : 0] : 0.f;
+      ug_mfma3x4(A1h + (s * 8) * 64 + lane, (s + 1 < KB1 ? A1h + ((s + 1) * 8) * 64 : A2h) + lane, xs, vn, M.sx1, xn, acc1, wl);
+      xs = xn;
+    }
+    ug_fence_results();
+    UG_PROF_MARK(prof, 3)
+    // ---- hidden activations -> operand form, once
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = ug_relu(acc1[st >> 1][8 * (st & 1) + e]);
+      hs[st] = ug_split8h(v, M.c12);
+    }
+  }
+  ug_fence_operands();
+  float l0 = 0.f, l1 = 0.f, l2 = 0.f;
+#pragma unroll
+  for (int pr2 = 0; pr2 < 2; ++pr2) {
+    // ---- layer 2, output tiles 2 pr2 and 2 pr2 + 1
+    f32x16 acc2[2];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 b = ((const float4 *)(M.B2 + bo))[(2 * pr2 + o) * 4 + q];
+        acc2[o][4 * q] = b.x; acc2[o][4 * q + 1] = b.y; acc2[o][4 * q + 2] = b.z; acc2[o][4 * q + 3] = b.w;
+      }
+    ug_hpair wl2 = ug_load_hpair(A2h + lane, 2 * pr2, 1);
+#pragma unroll
+    for (int st = 0; st < 8; ++st) {
+      const f16x8 *Ap = A2h + (st * 8) * 64 + lane;
+      const f16x8 *An = A2h + ((st + 1 < 8 ? st + 1 : st) * 8) * 64 + lane;
+      const ug_hpair wh2 = ug_load_hpair(Ap, 2 * pr2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      UG_MFMA_F16(acc2[0], wl2.w[0], hs[st].h);
+      UG_MFMA_F16(acc2[1], wl2.w[1], hs[st].h);
+      UG_MFMA_F16(acc2[0], wh2.w[0], hs[st].l);
+      UG_MFMA_F16(acc2[1], wh2.w[1], hs[st].l);
+      wl2 = ug_load_hpair(An, 2 * pr2, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      UG_MFMA_F16(acc2[0], wh2.w[0], hs[st].h);
+      UG_MFMA_F16(acc2[1], wh2.w[1], hs[st].h);
+    }
+    // first rows of this half's layer-3 weights, requested before the MFMAs have drained
+    constexpr int W3B = 4;      // rows per batch, two batches in registers (the split operands of layer 2 are still live)
+    float4 w3[2][W3B];
+#pragma unroll
+    for (int i = 0; i < W3B; ++i) w3[0][i] = M.W3[bo + 32 * pr2 + i];
+    ug_fence_results();
+    if (pr2 == 1) { UG_PROF_MARK(prof, 4) }
+    // ---- layer 3, rows 32 pr2 .. 32 pr2 + 31 (same order as the 4-tile pass: rows ascending)
+#pragma unroll
+    for (int sb = 0; sb < 32; sb += W3B) {
+      const int cur = (sb / W3B) & 1;
+      if (sb + W3B < 32) {
+#pragma unroll
+        for (int i = 0; i < W3B; ++i) w3[cur ^ 1][i] = M.W3[bo + 32 * pr2 + sb + W3B + i];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < W3B; ++i) {
+        const float hv = ug_relu(acc2[(sb + i) >> 4][(sb + i) & 15]);
+        l0 = fmaf(w3[cur][i].x, hv, l0);
+        l1 = fmaf(w3[cur][i].y, hv, l1);
+        l2 = fmaf(w3[cur][i].z, hv, l2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  l0 = (l0 + __shfl_xor(l0, 32)) + M.b3[0];
+  l1 = (l1 + __shfl_xor(l1, 32)) + M.b3[1];
+  l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
+  const float pr = ww * ug_sigmoid(l0), pg = ww * ug_sigmoid(l1), pb = ww * ug_sigmoid(l2);
+  UG_PROF_MARK(prof, 5)
+  {
+    // ordered per-ray sum through LDS (masks pre-cleared, see ug_rgbnet_pass_h2)
+    if (ok && h == 0) {
+      aval[sv] = make_float4(pr, pg, pb, 0.f);
+      atomicOr(&amask[sl], 1u << sv);
+    }
+    ug_wave_lds_sync();
+    unsigned m = amask[lane];
+    amask[lane] = 0u;
+    while (m) {
+      const int kk = __builtin_ctz(m);
+      const float4 t = aval[kk];
+      accr += t.x; accg += t.y; accb += t.z;
+      m &= m - 1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  UG_PROF_MARK(prof, 6)
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // producer wave
 // ---------------------------------------------------------------------------------------------------------------------
-template <int F>
+template <int F, int NBL, int SLOTS>
 __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const float *__restrict__ k0b, const ug_ws_view &ws,
                                                float *__restrict__ rgb_marched, int32_t *__restrict__ tile_counter,
                                                float *ring, unsigned ctl, unsigned long long *pstat) {
-  constexpr int NBL = UG_PC_NBL(F);
   const int lane = ug_lane();
   const int qs = lane >> 2, qg = lane & 3;
   const ug_quad_axis qa = ug_quad_axis_of(a, qg);
@@ -143,12 +302,12 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
       UG_PC_ADD(t_gather, tg)
       // a free slot: the consumer has taken pass seq - SLOTS (waited for AFTER the gather: the features sit in registers)
       UG_PC_T0(tw)
-      while (seq - tail_seen >= UG_PC_SLOTS) {
+      while (seq - tail_seen >= SLOTS) {
         tail_seen = ug_lds_peek(ctl + 4);
-        if (seq - tail_seen >= UG_PC_SLOTS) __builtin_amdgcn_s_sleep(2);
+        if (seq - tail_seen >= SLOTS) __builtin_amdgcn_s_sleep(2);
       }
       UG_PC_ADD(t_wait, tw)
-      float *sp = ring + (seq % UG_PC_SLOTS) * UG_PC_SLOT_FLOATS;
+      float *sp = ring + (seq % SLOTS) * UG_PC_SLOT_FLOATS;
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         float *fp = sp + UG_PC_FEAT + (16 * it + qs) * 12 + 3 * qg;
@@ -164,11 +323,11 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
     }
   }
   // end marker
-  while (seq - tail_seen >= UG_PC_SLOTS) {
+  while (seq - tail_seen >= SLOTS) {
     tail_seen = ug_lds_peek(ctl + 4);
-    if (seq - tail_seen >= UG_PC_SLOTS) __builtin_amdgcn_s_sleep(2);
+    if (seq - tail_seen >= SLOTS) __builtin_amdgcn_s_sleep(2);
   }
-  if (lane == 0) ((int *)(ring + (seq % UG_PC_SLOTS) * UG_PC_SLOT_FLOATS))[UG_PC_HDR] = -1;
+  if (lane == 0) ((int *)(ring + (seq % SLOTS) * UG_PC_SLOT_FLOATS))[UG_PC_HDR] = -1;
   ++seq;
   ug_lds_publish(ctl, seq);
 #ifdef UG_SHADE_PROF
@@ -180,7 +339,7 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
 // ---------------------------------------------------------------------------------------------------------------------
 // consumer wave
 // ---------------------------------------------------------------------------------------------------------------------
-template <int PE>
+template <int PE, int SLOTS, bool LEAN>
 __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const float *__restrict__ viewdirs, const ug_mlp_lds &M,
                                                float *__restrict__ rgb_marched, const float *ring, unsigned ctl, float *scr,
                                                unsigned long long *pstat) {
@@ -193,12 +352,10 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
   float accr = 0.f, accg = 0.f, accb = 0.f;    // lane = ray slot of the current tile
   int cur_tile = -1;
   int seq = 0, head_seen = 0;
-#if UG_MLP_H2
   ug_h2_state h2st;
-  ug_h2_preload(M, h * 64, h2st);
-  amask[lane] = 0u;                // the hand-scheduled pass keeps the per-ray masks cleared between passes
+  if constexpr (!LEAN) ug_h2_preload(M, h * 64, h2st);
+  amask[lane] = 0u;                // the hand-scheduled passes keep the per-ray masks cleared between passes
   ug_wave_lds_sync();
-#endif
 #ifdef UG_SHADE_PROF
   ug_prof prof_unused;          // phases of ug_rgbnet_pass: acc[3] layer 1, [4] layer 2, [5] layer 3 + sigmoid, [6] accumulation
   for (int i_ = 0; i_ < 8; ++i_) prof_unused.acc[i_] = 0;
@@ -217,7 +374,7 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
       if (head_seen <= seq) __builtin_amdgcn_s_sleep(2);
     }
     UG_PC_ADD(t_wait, tw)
-    const float *sp = ring + (seq % UG_PC_SLOTS) * UG_PC_SLOT_FLOATS;
+    const float *sp = ring + (seq % SLOTS) * UG_PC_SLOT_FLOATS;
     const int tile = __builtin_amdgcn_readfirstlane(((const int *)sp)[UG_PC_HDR]);
     if (tile < 0) break;
     const int count = __builtin_amdgcn_readfirstlane(((const int *)sp)[UG_PC_HDR + 1]);
@@ -276,11 +433,10 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
     prof_unused.t = tm;
     if (dbg_nomlp) { if (ok && h == 0 && sl == lane) { accr += x[0] * ww; accg += x[1] * ww; accb += x[KL - 1] * ww; } } else
 #endif
-#if UG_MLP_H2
-    ug_rgbnet_pass_h2<C, PE, true, true>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, h2st, prof_unused);
-#else
-    ug_rgbnet_pass<C, PE, 2>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, prof_unused);
-#endif
+    {
+      if constexpr (LEAN) ug_rgbnet_pass_lean<C, PE>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, prof_unused);
+      else ug_rgbnet_pass_h2<C, PE, true, true>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, h2st, prof_unused);
+    }
     UG_PC_ADD(t_mlp, tm)
   }
   if (cur_tile >= 0) {
