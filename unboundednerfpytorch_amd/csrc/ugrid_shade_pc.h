@@ -117,6 +117,7 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
   asm volatile("" : "+v"(bo));
   const f16x8 *A1h = (const f16x8 *)M.A1, *A2h = (const f16x8 *)M.A2;
   ug_split2 hs[8];                      // layer-2 B operands: relu(layer 1) * c12, split, k-step major
+  float hraw[64];                       // layer-1 outputs until they are split (dies 8 values per k-step of the first half)
   {
     // ---- layer 1
     f32x16 acc1[4];
@@ -149,14 +150,17 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
     }
     ug_fence_results();
     UG_PROF_MARK(prof, 3)
-    // ---- hidden activations -> operand form, once
-#pragma unroll
-    for (int st = 0; st < 8; ++st) {
+    // ---- hidden activations -> operand form: k-step 0 now, k-step st + 1 behind the MFMAs of k-step st of the first half
+    {
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = ug_relu(acc1[st >> 1][8 * (st & 1) + e]);
-      hs[st] = ug_split8h(v, M.c12);
+      for (int e = 0; e < 8; ++e) v[e] = ug_relu(acc1[0][e]);
+      hs[0] = ug_split8h(v, M.c12);
     }
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) hraw[o * 16 + r] = acc1[o][r];
   }
   ug_fence_operands();
   float l0 = 0.f, l1 = 0.f, l2 = 0.f;
@@ -172,20 +176,35 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
         acc2[o][4 * q] = b.x; acc2[o][4 * q + 1] = b.y; acc2[o][4 * q + 2] = b.z; acc2[o][4 * q + 3] = b.w;
       }
     ug_hpair wl2 = ug_load_hpair(A2h + lane, 2 * pr2, 1);
+    ug_hpair wh2 = ug_load_hpair(A2h + lane, 2 * pr2, 0);
 #pragma unroll
     for (int st = 0; st < 8; ++st) {
-      const f16x8 *Ap = A2h + (st * 8) * 64 + lane;
       const f16x8 *An = A2h + ((st + 1 < 8 ? st + 1 : st) * 8) * 64 + lane;
-      const ug_hpair wh2 = ug_load_hpair(Ap, 2 * pr2, 0);
-      __builtin_amdgcn_sched_barrier(0);
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 hh, ll;
+      const bool split_next = (pr2 == 0 && st + 1 < 8);
+      const float *hv = hraw + 8 * (st + 1 < 8 ? st + 1 : st);
+      // two MFMAs per group (tiles 0 / 1 of this half); the next k-step's weights are requested one whole k-step ahead, and
+      // in the first half the next k-step's activations are rectified and split behind the MFMAs (4 VALU each)
       UG_MFMA_F16(acc2[0], wl2.w[0], hs[st].h);
+      if (split_next) { unsigned h_, l_; ug_split_pair(ug_relu(hv[0]), ug_relu(hv[1]), M.c12, h_, l_); hh[0] = h_; ll[0] = l_; }
+      __builtin_amdgcn_sched_barrier(0);
       UG_MFMA_F16(acc2[1], wl2.w[1], hs[st].h);
+      if (split_next) { unsigned h_, l_; ug_split_pair(ug_relu(hv[2]), ug_relu(hv[3]), M.c12, h_, l_); hh[1] = h_; ll[1] = l_; }
+      const ug_hpair nwl = ug_load_hpair(An, 2 * pr2, 1);
+      __builtin_amdgcn_sched_barrier(0);
       UG_MFMA_F16(acc2[0], wh2.w[0], hs[st].l);
+      if (split_next) { unsigned h_, l_; ug_split_pair(ug_relu(hv[4]), ug_relu(hv[5]), M.c12, h_, l_); hh[2] = h_; ll[2] = l_; }
+      __builtin_amdgcn_sched_barrier(0);
       UG_MFMA_F16(acc2[1], wh2.w[1], hs[st].l);
-      wl2 = ug_load_hpair(An, 2 * pr2, 1);
+      if (split_next) { unsigned h_, l_; ug_split_pair(ug_relu(hv[6]), ug_relu(hv[7]), M.c12, h_, l_); hh[3] = h_; ll[3] = l_; }
       __builtin_amdgcn_sched_barrier(0);
       UG_MFMA_F16(acc2[0], wh2.w[0], hs[st].h);
       UG_MFMA_F16(acc2[1], wh2.w[1], hs[st].h);
+      const ug_hpair nwh = ug_load_hpair(An, 2 * pr2, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (split_next) { hs[st + 1].h = __builtin_bit_cast(f16x8, hh); hs[st + 1].l = __builtin_bit_cast(f16x8, ll); }
+      wl2 = nwl; wh2 = nwh;
     }
     // first rows of this half's layer-3 weights, requested before the MFMAs have drained
     constexpr int W3B = 4;      // rows per batch, two batches in registers (the split operands of layer 2 are still live)
