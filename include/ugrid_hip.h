@@ -239,7 +239,7 @@ int ugrid_pack_bricks(const float *grid, int P, int C, int X, int Y, int Z, int 
 typedef struct ugrid_render_params {
   int64_t n_rays;
   int32_t n_samples;              /* S = len(t) */
-  int32_t freq_num;               /* F; P = 1+2F levels (1..5) */
+  int32_t freq_num;               /* F; P = 1+2F levels (1..5; 0 = single-level DenseGrid models: ugrid_render_march_dcvgo) */
   int32_t grid_x, grid_y, grid_z; /* density == k0 resolution */
   int32_t k0_channels;            /* C (12, or 3) */
   int32_t mlp_in;                 /* C + 3 + 6*viewbase_pe; 0 => no rgbnet (rgb = sigmoid(k0), C==3) */
@@ -268,6 +268,25 @@ int64_t ugrid_render_ws_bytes(int64_t n_rays, int32_t n_samples);
 int ugrid_render_march(const ugrid_render_params *h_params, const float *rays_o, const float *rays_d,
                        const float *t_table, const float *s_table, const float *density_bricks,
                        float *alphainv_last, float *depth, void *ws, ugrid_stream_t stream);
+
+/* Fused march of the reference's DirectContractedVoxGO.forward (dcvgo.py:228-345; single-level grids, h_params->freq_num
+ * = 0): the march above plus, per sample, the "skip oversampled points" rule -- a contracted sample is evaluated only
+ * when the running sum of inter-sample distances has just exceeded dist_thres (ub360_utils_cuda.cumdist_thres,
+ * ub360_utils_kernel.cu:24-31; dcvgo.py:283-289) -- and the mask cache (render_utils_cuda.maskcache_lookup,
+ * render_utils_kernel.cu:374-392; grid.py:229-237: nearest voxel of a DEVICE bool grid [mask_x, mask_y, mask_z] at
+ * round(p * xyz2ijk_scale + xyz2ijk_shift)).  Also writes wsum_mid [R], the weight sum of the surviving un-contracted
+ * samples (dcvgo.py:354-358).  t_table / s_table: dcvgo's sample distances (boundary 2, dcvgo.py:243-250) and
+ * s = 1 - 1/(1+t).  The survivor list in ws feeds ugrid_render_shade (freq_num = 0). */
+typedef struct ugrid_dcvgo_params {
+  const uint8_t *mask;              /* DEVICE bool [mask_x][mask_y][mask_z] (MaskGrid.mask, grid.py:221-228) */
+  int32_t mask_x, mask_y, mask_z;
+  float xyz2ijk_scale[3], xyz2ijk_shift[3];
+  float dist_thres;                 /* (2 + 2 bg_len) / world_len * stepsize * 0.95 */
+} ugrid_dcvgo_params;
+int ugrid_render_march_dcvgo(const ugrid_render_params *h_params, const ugrid_dcvgo_params *h_dc, const float *rays_o,
+                             const float *rays_d, const float *t_table, const float *s_table,
+                             const float *density_bricks, float *alphainv_last, float *depth, float *wsum_mid,
+                             void *ws, ugrid_stream_t stream);
 
 /* Fused shade: survivors -> P-level k0 bricks -> [k0, viewdir emb] -> rgbnet (MFMA, h_params->mlp_mode) -> sigmoid
  * -> weighted per-ray sum in sample order; writes rgb_marched [R,3].  mlp_packed: ugrid_pack_mlp(). */

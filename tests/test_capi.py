@@ -135,7 +135,8 @@ def test_shade_shape_dispatch_table_and_loss_coefficients():
     from unboundednerfpytorch_amd.fourier_render import fused_shape_supported
     L = _lib.load()
     assert [L.ugrid_shade_supported(*t) for t in ((3, 12, 4), (4, 12, 4), (5, 12, 4), (2, 3, 2), (3, 3, 2))] == [1] * 5
-    assert [L.ugrid_shade_supported(*t) for t in ((3, 12, 8), (3, 9, 4), (6, 12, 4), (0, 12, 4))] == [0] * 4
+    assert [L.ugrid_shade_supported(*t) for t in ((3, 12, 8), (3, 9, 4), (6, 12, 4), (0, 3, 2))] == [0] * 4
+    assert L.ugrid_shade_supported(0, 12, 4) == 1           # single-level k0: the fused DirectContractedVoxGO path
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     small = torch.load(os.path.join(gold, "fg_ckpt_small.tar"), map_location="cpu", weights_only=False)
     odd = torch.load(os.path.join(gold, "fg_ckpt_odd.tar"), map_location="cpu", weights_only=False)
@@ -260,10 +261,13 @@ def test_shade_kernel_instruction_stream_regression(lib_path):
                for o, l in zip(ops, asm) if o == "global_load_dwordx4" or (o == "s_waitcnt" and "vmcnt" in l)]
         flat = "".join("L" if k == "L" else "<%d>" % n for k, n in seq)
         assert want in flat, (sym, flat[-400:])
-        mf = [l for l in asm if l.startswith("v_mfma")]
+        mfi = [i for i, l in enumerate(asm) if l.startswith("v_mfma")]
+        mf = [asm[i] for i in mfi]
         assert len(mf) == 132 and all(l.startswith("v_mfma_f32_32x32x16_f16") for l in mf), (sym, len(mf))
         dst = [re.match(r"\S+\s+([av]\[\d+:\d+\])", l).group(1) for l in mf]
-        assert all(a != b for a, b in zip(dst[:-1], dst[1:])), "back-to-back MFMAs on one accumulator: " + sym
+        # (the same registers may serve another accumulator much later, e.g. the second half of the lean pass after its
+        # layer-3 block: only MFMAs within a few instructions of each other count as back to back)
+        assert all(a != b or j - i > 16 for a, b, i, j in zip(dst[:-1], dst[1:], mfi[:-1], mfi[1:])), "back-to-back MFMAs on one accumulator: " + sym
         for l in mf:                                      # D = A x B + C with C = D: the accumulator chain the order protects
             regs = re.findall(r"[av]\[\d+:\d+\]", l)
             assert regs[0] == regs[-1], l

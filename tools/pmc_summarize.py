@@ -1,6 +1,6 @@
 """Turn the rocprofv3 --pmc passes of tools/gpu_pmc.sh (gpurun_out/<tag>/pmc_*/.../*counter_collection.csv) into
-profiles/r02/pmc_summary.json, the static per-launch counters bench.py's roofline block combines with its live times.
-usage: python tools/pmc_summarize.py gpurun_out/<tag> [lib_sha16]
+profiles/r03/pmc_summary.json, the static per-launch counters bench.py's roofline block combines with its live times.
+usage: python tools/pmc_summarize.py gpurun_out/<tag> [device_code_sha16]      (bench.device_code_sha16: sha256 of .hip_fatbin)
 
 hbm_bytes per launch = 2 x FETCH_SIZE [KB] x 1024 (the gfx950 correction of MI355X_MICROARCH.md, section HBM: FETCH_SIZE
 tallies 128-byte requests at 64 B) + WRITE_SIZE [KB] x 1024; Infinity-Cache hits are included in these counters."""
@@ -12,7 +12,7 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-NAMES = {"k_march": "render_march", "k_shade_mlp": "render_shade"}
+NAMES = {"k_march": "render_march", "k_shade_mlp": "render_shade", "k_shade_pc": "render_shade"}
 
 
 def main():
@@ -25,7 +25,8 @@ def main():
                 if k in r["Kernel_Name"]:
                     agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
     out = {"_comment": "per-launch means over the profiled launches of `python bench.py --steps 2 --warmup 1 --no-cpu-baseline "
-                       "--no-secondary` (S1 frame); source csv files next to this file", "lib_sha16": sys.argv[2] if len(sys.argv) > 2 else None}
+                       "--no-secondary` (S1 frame); source csv files next to this file",
+           "device_code_sha16": sys.argv[2] if len(sys.argv) > 2 else None}
     for name, d in agg.items():
         m = {c: sum(v) / len(v) for c, v in d.items()}
         e = {"counters": m, "launches": max(len(v) for v in d.values())}
@@ -44,7 +45,7 @@ def main():
         if "TCC_HIT_sum" in m and "TCC_REQ_sum" in m:
             e["l2_hit_rate"] = m["TCC_HIT_sum"] / max(1.0, m["TCC_REQ_sum"])
         out[name] = e
-    dst = os.path.join(ROOT, "profiles", "r02", "pmc_summary.json")
+    dst = os.path.join(ROOT, "profiles", "r03", "pmc_summary.json")
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1)[:3000])
 

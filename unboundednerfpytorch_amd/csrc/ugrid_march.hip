@@ -367,6 +367,22 @@ k_march(ug_march_args a, const float *__restrict__ rays_o, const float *__restri
 }
 
 
+// DirectContractedVoxGO march (single-level grids: F = 0): k_march + the cumdist_thres rule + the mask cache + wsum_mid
+template <bool L2>
+__global__ void __launch_bounds__(256, 5)
+k_march_dcvgo(ug_march_args a, ug_dc_args dc, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+              const float *__restrict__ t_table, const float *__restrict__ s_table, const float *__restrict__ bricks,
+              float *__restrict__ alphainv_last, float *__restrict__ depth, float *__restrict__ wsum_mid, ug_ws_view ws,
+              int64_t nblocks) {
+  const int64_t blk = ug_xcd_remap(blockIdx.x, nblocks);
+  if (blk >= nblocks) return;
+  const int64_t tile = blk * 4 + (threadIdx.x >> 6);
+  if (tile >= ws.n_tiles) return;
+  const int n = ug_march_tile<0, L2, true>(a, rays_o, rays_d, t_table, s_table, bricks, alphainv_last, depth, tile,
+                                           ws.ent + tile * ws.cap, ws.slot + tile * ws.cap, dc, wsum_mid);
+  if (ug_lane() == 0) ws.count[tile] = n;
+}
+
 // ----------------------------------------------------------------------------------------------
 // C ABI
 // ----------------------------------------------------------------------------------------------
@@ -524,6 +540,34 @@ extern "C" int ugrid_render_march(const ugrid_render_params *p, const float *ray
     case 5: return ug_march_launch<5>(p, a, rays_o, rays_d, t_table, s_table, density_bricks, alphainv_last, depth, ws, ST(s));
     default: return (int)hipErrorInvalidValue;
   }
+}
+
+
+extern "C" int ugrid_render_march_dcvgo(const ugrid_render_params *p, const ugrid_dcvgo_params *q, const float *rays_o,
+                                        const float *rays_d, const float *t_table, const float *s_table,
+                                        const float *density_bricks, float *alphainv_last, float *depth, float *wsum_mid,
+                                        void *ws_mem, ugrid_stream_t s) {
+  if (p->n_rays <= 0) return 0;
+  if (p->freq_num != 0 || !q || !q->mask || q->mask_x < 1 || q->mask_y < 1 || q->mask_z < 1) return (int)hipErrorInvalidValue;
+  ug_march_args a;
+  const int rc = ug_fill_march_args(p, a);
+  if (rc) return rc;
+  ug_dc_args dc;
+  dc.mask = q->mask; dc.mi = q->mask_x; dc.mj = q->mask_y; dc.mk = q->mask_z;
+  dc.sx = q->xyz2ijk_scale[0]; dc.sy = q->xyz2ijk_scale[1]; dc.sz = q->xyz2ijk_scale[2];
+  dc.hx = q->xyz2ijk_shift[0]; dc.hy = q->xyz2ijk_shift[1]; dc.hz = q->xyz2ijk_shift[2];
+  dc.dist_thres = q->dist_thres;
+  ug_ws_view ws = ug_ws_make(ws_mem, p->n_rays, p->n_samples);
+  const int64_t nblocks = (ws.n_tiles + 3) / 4;
+  const int64_t grid = ((nblocks + 7) / 8) * 8;  // room for the XCD remap
+  if (p->norm_l2)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_march_dcvgo<true>), dim3((unsigned)grid), dim3(256), 0, ST(s), a, dc, rays_o, rays_d, t_table,
+                       s_table, density_bricks, alphainv_last, depth, wsum_mid, ws, nblocks);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_march_dcvgo<false>), dim3((unsigned)grid), dim3(256), 0, ST(s), a, dc, rays_o, rays_d, t_table,
+                       s_table, density_bricks, alphainv_last, depth, wsum_mid, ws, nblocks);
+  UG_LAUNCH_CHECK();
+  return 0;
 }
 
 

@@ -209,17 +209,30 @@ __device__ __forceinline__ float ug_density_level(const char *__restrict__ lvl, 
   return fmaf(fmaf(p11, ty, p10), tx, fmaf(p01, ty, p00));
 }
 
+// DirectContractedVoxGO additions to the march (dcvgo.py:228-310; DC = true, single-level grids, F = 0): of the contracted
+// samples only those are evaluated whose running inter-sample distance has just exceeded dist_thres (cumdist_thres,
+// ub360_utils_kernel.cu:24-31 -- the serial recurrence is a register of the lane that owns the ray), and only where the
+// mask cache (maskcache_lookup, render_utils_kernel.cu:374-392: nearest voxel of a bool grid) says "not known free space";
+// wsum_mid = sum of the weights of the surviving UN-contracted samples (dcvgo.py:354-358).
+struct ug_dc_args {
+  const uint8_t *mask;
+  int32_t mi, mj, mk;
+  float sx, sy, sz, hx, hy, hz;     // xyz2ijk_scale / xyz2ijk_shift
+  float dist_thres;
+};
+
 // March one 64-ray tile (lane = ray): writes alphainv_last / depth for the tile's rays, appends the
 // survivors to ent/slot (this wave's private list) and returns their count (wave-uniform).
 #ifdef UG_MARCH_STATS
 __device__ unsigned long long g_march_stat[4];
 #endif
-template <int F, bool L2>
+template <int F, bool L2, bool DC = false>
 __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float *__restrict__ rays_o,
                                              const float *__restrict__ rays_d, const float *__restrict__ t_table,
                                              const float *__restrict__ s_table, const float *__restrict__ bricks,
                                              float *__restrict__ alphainv_last, float *__restrict__ depth,
-                                             int64_t tile, float4 *__restrict__ ent, uint8_t *__restrict__ slot) {
+                                             int64_t tile, float4 *__restrict__ ent, uint8_t *__restrict__ slot,
+                                             const ug_dc_args &dc = ug_dc_args{}, float *__restrict__ wsum_mid = nullptr) {
   constexpr int P = 2 * F + 1;
   const int lane = ug_lane();
   const int64_t ray = tile * UG_WAVE + lane;
@@ -240,6 +253,7 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
   float T = 1.f, dsum = 0.f;
   bool done = !valid;
   int nsurv = 0;  // wave-uniform
+  [[maybe_unused]] float cum = 0.f, ppx = 0.f, ppy = 0.f, ppz = 0.f, wmid = 0.f;   // DC: cumdist recurrence, previous point
 
 #ifdef UG_MARCH_STATS
   unsigned long long st_iter = 0, st_act = 0;   // lane-efficiency study (tools/gpu_march_stats.sh): iterations, active lanes
@@ -280,48 +294,71 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
       const float uy = ug_div_r(py - a.loy, a.ey, a.iry) * 2.f - 1.f;
       const float uz = ug_div_r(pz - a.loz, a.ez, a.irz) * 2.f - 1.f;
 #endif
-      float dens = ug_density_level(bkb, ux, uy, uz, a.X, a.Y, a.Z);
-#pragma unroll
-      for (int k = 0; k < F; ++k) {
-        const float f = (float)(1 << k);
-        float sx, cx_, sy, cy_, sz, cz_;
-#ifdef UG_LIBM_SINCOS
-        sincosf(f * ux, &sx, &cx_);
-        sincosf(f * uy, &sy, &cy_);
-        sincosf(f * uz, &sz, &cz_);
-#else
-        if (k == 0) {   // |u| <= 1 < pi/2: no range reduction needed, bit-identical (ug_sincos_small)
-          ug_sincos_small(ux, &sx, &cx_);
-          ug_sincos_small(uy, &sy, &cy_);
-          ug_sincos_small(uz, &sz, &cz_);
-        } else {
-          ug_sincos(f * ux, &sx, &cx_);
-          ug_sincos(f * uy, &sy, &cy_);
-          ug_sincos(f * uz, &sz, &cz_);
+      bool keep = true;
+      [[maybe_unused]] bool inner = true;
+      if constexpr (DC) {
+        inner = nrm <= 1.0f;
+        keep = inner;
+        if (j > 0) {      // dist = |p_j - p_{j-1}| over ALL consecutive samples (dcvgo.py:287), serial cumdist_thres recurrence
+          cum += ug_norm3_torch(px - ppx, py - ppy, pz - ppz);
+          const bool over = cum > dc.dist_thres;
+          cum *= over ? 0.f : 1.f;
+          keep = keep || over;
         }
-#endif
-        dens += ug_density_level(bkb + (size_t)(2 * k + 1) * lvl_bytes, sx, sy, sz, a.X, a.Y, a.Z);
-        dens += ug_density_level(bkb + (size_t)(2 * k + 2) * lvl_bytes, cx_, cy_, cz_, a.X, a.Y, a.Z);
+        ppx = px; ppy = py; ppz = pz;
+        if (keep) {       // mask cache: nearest voxel, C round(), NaN -> 0 like the device conversion (k_maskcache)
+          float fi = roundf(px * dc.sx + dc.hx), fj = roundf(py * dc.sy + dc.hy), fk = roundf(pz * dc.sz + dc.hz);
+          fi = (fi != fi) ? 0.f : fi; fj = (fj != fj) ? 0.f : fj; fk = (fk != fk) ? 0.f : fk;
+          keep = false;
+          if (fi >= 0.f && fi < (float)dc.mi && fj >= 0.f && fj < (float)dc.mj && fk >= 0.f && fk < (float)dc.mk)
+            keep = dc.mask[((int64_t)fi * dc.mj + (int64_t)fj) * dc.mk + (int64_t)fk] != 0;
+        }
       }
-#ifdef UG_EXACT_DIV
-      dens = dens / (float)P;
+      if (keep) {
+        float dens = ug_density_level(bkb, ux, uy, uz, a.X, a.Y, a.Z);
+#pragma unroll
+        for (int k = 0; k < F; ++k) {
+          const float f = (float)(1 << k);
+          float sx, cx_, sy, cy_, sz, cz_;
+#ifdef UG_LIBM_SINCOS
+          sincosf(f * ux, &sx, &cx_);
+          sincosf(f * uy, &sy, &cy_);
+          sincosf(f * uz, &sz, &cz_);
 #else
-      dens = ug_div_r(dens, (float)P, 1.0f / (float)P);   // mean over levels: Markstein division, 3 VALU instead of 10
+          if (k == 0) {   // |u| <= 1 < pi/2: no range reduction needed, bit-identical (ug_sincos_small)
+            ug_sincos_small(ux, &sx, &cx_);
+            ug_sincos_small(uy, &sy, &cy_);
+            ug_sincos_small(uz, &sz, &cz_);
+          } else {
+            ug_sincos(f * ux, &sx, &cx_);
+            ug_sincos(f * uy, &sy, &cy_);
+            ug_sincos(f * uz, &sz, &cz_);
+          }
 #endif
-      const float xs = dens + a.shift;
-#ifdef UG_LIBM_ALPHA
-      const float alpha = 1.0f - powf(1.0f + expf(xs), -a.interval);
-#else
-      const float alpha = ug_alpha(xs, a.interval);
-#endif
-      if (alpha > a.thres) {
-        w = T * alpha;
-        T = (float)((double)T * (1. - (double)alpha));
-        if (w > a.thres) {
-          surv = true;
-          dsum += w * s_table[j];
+          dens += ug_density_level(bkb + (size_t)(2 * k + 1) * lvl_bytes, sx, sy, sz, a.X, a.Y, a.Z);
+          dens += ug_density_level(bkb + (size_t)(2 * k + 2) * lvl_bytes, cx_, cy_, cz_, a.X, a.Y, a.Z);
         }
-        if ((double)T < 1e-3) done = true;
+#ifdef UG_EXACT_DIV
+        dens = dens / (float)P;
+#else
+        dens = ug_div_r(dens, (float)P, 1.0f / (float)P);   // mean over levels: Markstein division, 3 VALU instead of 10
+#endif
+        const float xs = dens + a.shift;
+#ifdef UG_LIBM_ALPHA
+        const float alpha = 1.0f - powf(1.0f + expf(xs), -a.interval);
+#else
+        const float alpha = ug_alpha(xs, a.interval);
+#endif
+        if (alpha > a.thres) {
+          w = T * alpha;
+          T = (float)((double)T * (1. - (double)alpha));
+          if (w > a.thres) {
+            surv = true;
+            dsum += w * s_table[j];
+            if constexpr (DC) { if (inner) wmid += w; }
+          }
+          if ((double)T < 1e-3) done = true;
+        }
       }
     }
     const unsigned long long m = __ballot(surv);
@@ -341,6 +378,7 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
   if (valid) {
     alphainv_last[ray] = T;
     depth[ray] = dsum;
+    if constexpr (DC) wsum_mid[ray] = wmid;
   }
   return nsurv;
 }

@@ -602,7 +602,8 @@ extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *vie
 // the instantiated (F, C, PE) triples: Mip-NeRF-360 *_single.py (configs/default.py:104-124); tankstemple_unbounded/
 // truck_single.py:105; FourierGridModel's constructor default fourier_freq_num = 5 (FourierGrid_model.py:137); waymo-style
 // rgbnet_dim = 3, viewbase_pe = 2 (configs/waymo/waymo_no_block.py:144-149)
-#define UG_SHADE_TRIPLES(X) X(3, 12, 4) X(4, 12, 4) X(5, 12, 4) X(2, 12, 4) X(1, 12, 4) X(2, 3, 2) X(3, 3, 2)
+// F = 0: single-level k0 (DirectContractedVoxGO / DenseGrid models, configs/nerf_unbounded/*.py: rgbnet_dim 12)
+#define UG_SHADE_TRIPLES(X) X(3, 12, 4) X(4, 12, 4) X(5, 12, 4) X(2, 12, 4) X(1, 12, 4) X(0, 12, 4) X(2, 3, 2) X(3, 3, 2)
 #define UG_SHADE_CASE(F_, C_, PE_)                                                          \
   if (p->freq_num == F_ && p->k0_channels == C_ && p->viewbase_pe == PE_)                   \
     return ug_shade_launch<F_, C_, PE_>(a, viewdirs, k0_bricks, mlp_packed, ws, rgb_marched, counter, p->mlp_mode, ST(s));

@@ -63,6 +63,50 @@ class DirectContractedVoxGORenderer:
                       ([x.to(dev).contiguous() for x in v] if isinstance(v, list) else v)) for k, v in state.items()}
         self.viewfreq = torch.tensor([float(2 ** i) for i in range(int(state["viewbase_pe"]))], device=dev)
         self._tables = {}
+        self._fused = None if ops is None else False      # fused render kernels: HIP library only, built on first use
+
+    # -- fused inference path ----------------------------------------------------------------------------------
+    def fused_supported(self):
+        """the fused march (ugrid_render_march_dcvgo) + shade kernels cover: the default HIP ops, fast_color_thres > 0, one
+        resolution for both grids, and either no rgbnet (3-channel k0, rgb = sigmoid(k0)) or the 3 x 128 rgbnet on
+        [k0 (12), view embedding] that ugrid_shade_supported(0, C, viewbase_pe) lists"""
+        if self._fused is False:
+            return False
+        s = self.s
+        if float(s['fast_color_thres']) <= 0 or tuple(s['density_grid'].shape[2:]) != tuple(s['k0_grid'].shape[2:]):
+            return False
+        C = int(s['k0_grid'].shape[1])
+        if len(s['rgbnet_weights']) == 0:
+            return C == 3
+        from . import _lib
+        w = s['rgbnet_weights']
+        return (len(w) == 3 and tuple(w[1].shape) == (128, 128) and w[2].shape[0] == 3 and w[0].shape[1] == C + 3 + 6 * int(s['viewbase_pe'])
+                and bool(_lib.load().ugrid_shade_supported(0, C, int(s['viewbase_pe']))))
+
+    @torch.no_grad()
+    def render_rays(self, rays_o, rays_d, viewdirs, **render_kwargs):
+        """Per-ray outputs of forward() -- rgb_marched, depth, alphainv_last, wsum_mid (what the render program consumes,
+        run_render.py:46) -- through the FUSED kernels: the whole chain of dcvgo.py:228-384 in two launches, no [N,S,3]
+        point tensor, no boolean compactions.  Falls back to forward() for models outside fused_supported().
+        render_kwargs as forward(): stepsize, bg, render_depth, plus FourierGridRenderer's ray_order."""
+        if not self.fused_supported():
+            out = self.forward(rays_o, rays_d, viewdirs, **render_kwargs)
+            return {k: out[k] for k in ('rgb_marched', 'depth', 'alphainv_last', 'wsum_mid') if k in out}
+        if self._fused is None:
+            from .fourier_render import FourierGridRenderer
+            s = self.s
+            st = {'density_grid': s['density_grid'], 'k0_grid': s['k0_grid'], 'rgbnet_weights': s['rgbnet_weights'],
+                  'rgbnet_biases': s['rgbnet_biases'], 'scene_center': s['scene_center'], 'scene_radius': s['scene_radius'],
+                  'xyz_min': s['xyz_min'], 'xyz_max': s['xyz_max'], 'bg_len': s['bg_len'], 'fourier_freq_num': 0,
+                  'viewbase_pe': s['viewbase_pe'], 'act_shift': float(s['act_shift']), 'voxel_size_ratio': float(s['voxel_size_ratio']),
+                  'fast_color_thres': float(s['fast_color_thres']), 'contracted_norm': s['contracted_norm'], 'world_len': s['world_len'],
+                  'dcvgo': {'mask': s['mask'], 'xyz2ijk_scale': s['xyz2ijk_scale'], 'xyz2ijk_shift': s['xyz2ijk_shift']}}
+            self._fused = FourierGridRenderer(st, self.device)
+        kw = dict(render_kwargs)
+        if 'bg' in kw and torch.is_tensor(kw['bg']):
+            kw['bg'] = kw['bg'].to(self.device)
+        out = self._fused(rays_o.contiguous(), rays_d.contiguous(), viewdirs.contiguous(), **kw)
+        return {k: out[k] for k in ('rgb_marched', 'depth', 'alphainv_last', 'wsum_mid') if k in out}
 
     def _t_table(self, stepsize):
         key = float(stepsize)

@@ -30,7 +30,7 @@ def tune(key, value):
     _lib.check(_L.ugrid_tune(key.encode(), int(value)), "ugrid_tune(%s)" % key)
 
 
-def sample_table(world_len, stepsize, bg_len, t_boundary=1.5):
+def sample_table(world_len, stepsize, bg_len, t_boundary=1.5):  # noqa: E302  (dcvgo.py:243-250 uses t_boundary = 2)
     """Sample distances t [S] and s = 1 - 1/(1+t), computed with the same torch ops as the reference
     (FourierGrid_model.py:524-532,649) on the host; shared by every ray."""
     n_inner = int(2 / (2 + 2 * bg_len) * world_len / stepsize) + 1
@@ -50,6 +50,10 @@ class FourierGridRenderer:
       scene_center[3], scene_radius[3], xyz_min[3], xyz_max[3] (contracted bounds, fp32 tensors),
       bg_len, fourier_freq_num, viewbase_pe, act_shift, voxel_size_ratio, fast_color_thres,
       contracted_norm ('inf' | 'l2'), world_len.
+    Optional `dcvgo` = {'mask' bool [mx,my,mz], 'xyz2ijk_scale' [3], 'xyz2ijk_shift' [3]} with fourier_freq_num = 0
+    (single-level grids): the DirectContractedVoxGO forward (dcvgo.py:228-384) -- sample table with boundary 2, the
+    cumdist_thres rule and the mask cache inside the march (ugrid_render_march_dcvgo), `wsum_mid` among the outputs and
+    `bg` honoured (rgb_marched += alphainv_last * bg).  dcvgo_render.DirectContractedVoxGORenderer.render_rays builds it.
     """
 
     def __init__(self, state, device, max_ws_bytes=48 << 30, fused=False, pipeline=0, mlp_mode=None):
@@ -84,6 +88,17 @@ class FourierGridRenderer:
         self.voxel_size_ratio = float(state["voxel_size_ratio"])
         self.norm_l2 = {"inf": 0, "l2": 1}[state.get("contracted_norm", "inf")]
         self._vec = {k: [float(v) for v in state[k]] for k in ("scene_center", "scene_radius", "xyz_min", "xyz_max")}
+        self.dc = None
+        if state.get("dcvgo") is not None:
+            if self.F != 0:
+                raise RuntimeError("the DirectContractedVoxGO march is for single-level grids (fourier_freq_num = 0)")
+            d = state["dcvgo"]
+            self.dc = {"mask": d["mask"].to(dev).to(torch.bool).contiguous(),
+                       "scale": [float(x) for x in d["xyz2ijk_scale"]], "shift": [float(x) for x in d["xyz2ijk_shift"]]}
+            if self.dc["mask"].dim() != 3:
+                raise RuntimeError("dcvgo mask must be a [mx,my,mz] bool grid")
+        elif self.F == 0:
+            raise RuntimeError("fourier_freq_num = 0 is the DirectContractedVoxGO path: pass state['dcvgo']")
         if self.thres <= 0:
             raise RuntimeError("fast_color_thres must be > 0 (the reference forward is not usable at 0 either, "
                                "FourierGrid_model.py:600-614)")
@@ -134,7 +149,7 @@ class FourierGridRenderer:
     def tables(self, stepsize):
         key = float(stepsize)
         if key not in self._tables:
-            t, s = sample_table(self.world_len, key, self.bg_len)
+            t, s = sample_table(self.world_len, key, self.bg_len, t_boundary=2 if self.dc is not None else 1.5)
             self._tables[key] = (t.to(self.device), s.to(self.device), int(t.numel()))
         return self._tables[key]
 
@@ -239,7 +254,7 @@ class FourierGridRenderer:
                 kw = dict(render_kwargs, ray_order="coherent")
                 res = self.forward(rays_o.index_select(0, perm), rays_d.index_select(0, perm), viewdirs.index_select(0, perm), **kw)
                 out = dict(res)
-                for k in ("rgb_marched", "depth", "alphainv_last"):
+                for k in ("rgb_marched", "depth", "alphainv_last", "wsum_mid"):
                     if k in res:
                         out[k] = torch.empty_like(res[k]).index_copy_(0, perm, res[k])
                 return out
@@ -256,8 +271,17 @@ class FourierGridRenderer:
         rgb = torch.empty(R, 3, dtype=torch.float32, device=dev)
         depth = torch.empty(R, dtype=torch.float32, device=dev)
         last = torch.empty(R, dtype=torch.float32, device=dev)
+        wmid = torch.empty(R, dtype=torch.float32, device=dev) if self.dc is not None else None
+        dcp = None
+        if self.dc is not None:
+            dcp = _lib.DcvgoParams()
+            dcp.mask = self.dc["mask"].data_ptr()
+            dcp.mask_x, dcp.mask_y, dcp.mask_z = [int(x) for x in self.dc["mask"].shape]
+            for i in range(3):
+                dcp.xyz2ijk_scale[i], dcp.xyz2ijk_shift[i] = self.dc["scale"][i], self.dc["shift"][i]
+            dcp.dist_thres = (2 + 2 * self.bg_len) / self.world_len * stepsize * 0.95      # dcvgo.py:285
         timing = render_kwargs.get("timing")  # optional list collecting ([ev0, ev1, ev2], n_rays) per launch group
-        fused = self.use_fused and self.has_mlp and (self.F, self.C, self.pe) in ((3, 12, 4), (4, 12, 4))
+        fused = self.use_fused and self.has_mlp and self.dc is None and (self.F, self.C, self.pe) in ((3, 12, 4), (4, 12, 4))
         with _lib.guard(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
             if fused:
@@ -276,7 +300,7 @@ class FourierGridRenderer:
                     ev[1].record()
                     timing.append((ev, R))
                 self._last = ("fused", R, S)
-            elif self.pipeline > 1 and R >= 64 * 64 * self.pipeline:
+            elif self.pipeline > 1 and R >= 64 * 64 * self.pipeline and self.dc is None:
                 self._forward_pipelined(rays_o, rays_d, viewdirs, t_tab, s_tab, S, stepsize, last, depth, rgb, timing)
             else:
                 chunk = self.rays_per_chunk(S)
@@ -289,8 +313,13 @@ class FourierGridRenderer:
                     if timing is not None:
                         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                         ev[0].record()
-                    _lib.check(_L.ugrid_render_march(p, _p(o_), _p(d_), _p(t_tab), _p(s_tab), _p(self.density_bricks),
-                                                     _p(last[b:e]), _p(depth[b:e]), _p(ws), st), "render_march")
+                    if dcp is not None:
+                        _lib.check(_L.ugrid_render_march_dcvgo(p, ctypes.byref(dcp), _p(o_), _p(d_), _p(t_tab), _p(s_tab),
+                                                               _p(self.density_bricks), _p(last[b:e]), _p(depth[b:e]), _p(wmid[b:e]),
+                                                               _p(ws), st), "render_march_dcvgo")
+                    else:
+                        _lib.check(_L.ugrid_render_march(p, _p(o_), _p(d_), _p(t_tab), _p(s_tab), _p(self.density_bricks),
+                                                         _p(last[b:e]), _p(depth[b:e]), _p(ws), st), "render_march")
                     if timing is not None:
                         ev[1].record()
                     _lib.check(_L.ugrid_render_shade(p, _p(v_), _p(self.k0_bricks), _p(self.mlp_packed), _p(ws),
@@ -300,6 +329,10 @@ class FourierGridRenderer:
                         timing.append((ev, n))
                     self._last = ("split", n, S)
         out = {"alphainv_last": last, "rgb_marched": rgb, "n_max": S}
+        if self.dc is not None:
+            out["wsum_mid"] = wmid
+            if "bg" in render_kwargs:                      # dcvgo.py:349-352: rgb_marched += alphainv_last * bg
+                rgb += last.unsqueeze(-1) * render_kwargs["bg"]
         if render_kwargs.get("render_depth", False):
             out["depth"] = depth
         return out
