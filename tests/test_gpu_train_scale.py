@@ -33,9 +33,10 @@ def _fixed_rng():
     torch.manual_seed(0)
 
 
-def build(device, backend=None):
+def build(device, backend=None, G=None):
     import bench_train_step as bts
     from unboundednerfpytorch_amd.fourier_model import FourierGridModel
+    G = globals()["G"] if G is None else G
     if backend is None:
         return bts.make_model(G, F, device, fused=True)
     m = FourierGridModel(xyz_min=[-1, -1, -1], xyz_max=[1, 1, 1], num_voxels_density=G ** 3, num_voxels_base_density=G ** 3,
@@ -115,16 +116,17 @@ def test_channel_last_k0_model_equals_the_canonical_layout_model():
     assert all(t.is_contiguous() for t in _canonical(a.state_dict()).values())
 
 
-def test_training_step_at_scale_matches_the_oracle_backend():
+@pytest.mark.parametrize("grid", [100, 200])      # 200 = the S3 configuration's own grid (P = 9, G = 200^3: VERDICT r2 "missing" 9)
+def test_training_step_at_scale_matches_the_oracle_backend(grid):
     import bench_train_step as bts
     from types import SimpleNamespace
     dev = torch.device("cuda", 0)
-    m = build(dev)
+    m = build(dev, G=grid)
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     R2A, A2W = model_oracle.make_autograd_ops(ref_ops)
     be = SimpleNamespace(Raw2Alpha=R2A, Alphas2Weights=A2W, grid_query=model_oracle.fourier_grid_query,
                          total_variation_cuda=ref_ops.total_variation_cuda, render_utils_cuda=ref_ops.render_utils_cuda)
-    ref = build("cpu", backend=be)
+    ref = build("cpu", backend=be, G=grid)
     ref.load_state_dict({k: v.cpu() for k, v in m.state_dict().items()})
     o, d, v, rgb = bts.random_rays(1024, dev, seed=4)
     out = m(o, d, v, global_step=1, is_train=True, stepsize=0.5, render_depth=True)
