@@ -476,7 +476,8 @@ extern "C" int ugrid_pack_bricks(const float *grid, int P, int C, int X, int Y, 
   int64_t blocks = (total + 255) / 256;
   if (blocks > 256 * 64) blocks = 256 * 64;
   if (C == 12 && !direct) {   // 384 B per cell in the quad layout (same size as two 192-byte halves)
-    if ((int64_t)(X - 1) * (Y - 1) * (Z - 1) * 384 >= ((int64_t)1 << 32)) return (int)hipErrorInvalidValue;
+    // multi-level grids are addressed with 32-bit byte offsets inside a level; a single-level grid (P == 1) with 64-bit ones
+    if (P > 1 && (int64_t)(X - 1) * (Y - 1) * (Z - 1) * 384 >= ((int64_t)1 << 32)) return (int)hipErrorInvalidValue;
     hipLaunchKernelGGL(k_pack_quad, dim3((unsigned)blocks), dim3(256), 0, ST(s), grid, P, C, X, Y, Z, bricks, total);
     UG_LAUNCH_CHECK();
     return 0;

@@ -591,6 +591,14 @@ __device__ __forceinline__ ug_f4 ug_gload4(unsigned voff, const float *sbase) {
   asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(sbase), "n"(IMM) : "memory");
   return r;
 }
+// 64-bit address form (single-level k0 grids, F = 0: a 320^3 x 12-channel level is 12.5 GB, beyond the 32-bit offset of
+// the saddr + voffset form; with P = 1 the two extra address registers per item cost nothing)
+template <int IMM>
+__device__ __forceinline__ ug_f4 ug_gload4v(const char *vaddr) {
+  ug_f4 r;
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(vaddr), "n"(IMM) : "memory");
+  return r;
+}
 template <int N>
 __device__ __forceinline__ void ug_vmwait6(ug_f4 (&v)[6]) {
   asm volatile("s_waitcnt vmcnt(%6)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]) : "n"(N));
@@ -643,7 +651,12 @@ struct ug_gather_state {
 };
 
 #define UG_ISSUE_ITEM(st_, i_)                                                                                     \
-  {                                                                                                                \
+  if constexpr (F == 0) {   /* st.off = CELL index; 64-bit address = level 0 + cell * 384 + the lane's 16-byte column */   \
+    const char *pa = (const char *)k0b + (uint64_t)st_.off[i_] * 384ull + (uint64_t)((ug_lane() & 3) * 16);        \
+    st_.v[(i_) % NBL][0] = ug_gload4v<0>(pa);   st_.v[(i_) % NBL][1] = ug_gload4v<64>(pa);                          \
+    st_.v[(i_) % NBL][2] = ug_gload4v<128>(pa); st_.v[(i_) % NBL][3] = ug_gload4v<192>(pa);                         \
+    st_.v[(i_) % NBL][4] = ug_gload4v<256>(pa); st_.v[(i_) % NBL][5] = ug_gload4v<320>(pa);                         \
+  } else {                                                                                                         \
     const float *lb = k0b + (int64_t)((i_) / NR) * lvl_floats;                                                     \
     st_.v[(i_) % NBL][0] = ug_gload4<0>(st_.off[i_], lb);   st_.v[(i_) % NBL][1] = ug_gload4<64>(st_.off[i_], lb);  \
     st_.v[(i_) % NBL][2] = ug_gload4<128>(st_.off[i_], lb); st_.v[(i_) % NBL][3] = ug_gload4<192>(st_.off[i_], lb); \
@@ -677,7 +690,8 @@ __device__ __forceinline__ void ug_k0_gather_begin(const float *__restrict__ k0b
       st.tx[i] = ug_quad_bcast<0>(wh); st.ty[i] = ug_quad_bcast<1>(wh); st.tz[i] = ug_quad_bcast<2>(wh);
       const unsigned row = (unsigned)fmaf(cxf, (float)(a.Y - 1), cyf);     // exact in fp32: (X-1)(Y-1) < 2^24
       const unsigned cell = __umul24(row, (unsigned)(a.Z - 1)) + (unsigned)czf;
-      st.off[i] = __umul24(cell, 384u) + qa.goff;                           // bytes inside the level (< 4 GiB)
+      if constexpr (F == 0) st.off[i] = cell;                               // cell index: 64-bit address formed at issue
+      else st.off[i] = __umul24(cell, 384u) + qa.goff;                      // bytes inside the level (< 4 GiB)
     }
   }
   const int64_t lvl_floats = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1) * 96;
