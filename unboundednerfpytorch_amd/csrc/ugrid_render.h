@@ -949,47 +949,8 @@ __device__ __forceinline__ void ug_mfma3x4(const f16x8 *__restrict__ Ap, const f
   for (int o = 0; o < 4; ++o) { UG_MFMA_F16(acc[o], wh.w[o], x.h); }
 }
 
-// v2 of the k-step (UG_MLP_V2, default): the same 12 MFMAs in the same order, but (a) the NEXT step's activation split
-// (16 v_fma_mix + 8 relu) is cut into four pieces issued behind the four MFMAs of the first group -- an in-order wave can
-// only issue VALU work while an MFMA it has just issued occupies the pipe, so the split used to run exposed after the
-// group's last MFMA (phase profile: ~100 cycles per k-step) --, and (b) BOTH weight parts of the next step are requested
-// one whole MFMA group earlier (behind the first MFMA of groups 2 and 3): every ds_read_b128 has 7-8 MFMAs (> 220 cycles)
-// of cover instead of 4.  `RELU`: the next step's values are hidden activations (layer 2) and pass through max(x, 0)
-// here instead of in a separate 64-instruction loop between the layers.
+// operands of one k-step of the hand-scheduled fp16x2 pass (both weight parts, loaded during the previous step)
 struct ug_kops { ug_hpart wl, wh; };
-template <bool RELU>
-__device__ __forceinline__ void ug_mfma3x4_v2(const f16x8 *__restrict__ Ap_next, const ug_split2 &x, const float (&v_next)[8],
-                                              float scale, ug_split2 &x_next, f32x16 (&acc)[4], ug_kops &k) {
-  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-  u32x4 hh, ll;
-  ug_hpart nwl, nwh;
-#pragma unroll
-  for (int o = 0; o < 4; ++o) {
-    UG_MFMA_F16(acc[o], k.wl.w[o], x.h);
-    const float a = RELU ? ug_relu(v_next[2 * o]) : v_next[2 * o], b = RELU ? ug_relu(v_next[2 * o + 1]) : v_next[2 * o + 1];
-    unsigned h_, l_;
-    ug_split_pair(a, b, scale, h_, l_);
-    hh[o] = h_; ll[o] = l_;
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  x_next.h = __builtin_bit_cast(f16x8, hh);
-  x_next.l = __builtin_bit_cast(f16x8, ll);
-#pragma unroll
-  for (int o = 0; o < 4; ++o) {
-    UG_MFMA_F16(acc[o], k.wh.w[o], x.l);
-    if (o == 0) { nwl = ug_load_hpart(Ap_next, 1); __builtin_amdgcn_sched_barrier(0); }
-  }
-#pragma unroll
-  for (int o = 0; o < 4; ++o) {
-    UG_MFMA_F16(acc[o], k.wh.w[o], x.h);
-    if (o == 0) { nwh = ug_load_hpart(Ap_next, 0); __builtin_amdgcn_sched_barrier(0); }
-  }
-  k.wl = nwl; k.wh = nwh;
-}
-
-#ifndef UG_MLP_V2
-#define UG_MLP_V2 1
-#endif
 
 // Optional phase profile (-DUG_SHADE_PROF, tools/gpu_shade_phases.sh): shader-clock ticks per phase of ug_shade_tile,
 // summed over all waves into g_shade_prof; phases: 0 tile set-up, 1 gather round 0, 2 gather round 1, 3 layer 1,
@@ -1063,53 +1024,6 @@ __device__ __forceinline__ void ug_rgbnet_pass(const float (&x)[(2 * UG_CH(C) + 
     // products per k-step; accumulators carry the factor sW*sX (biases / W3 are pre-scaled in the image)
     const f16x8 *A1h = (const f16x8 *)M.A1, *A2h = (const f16x8 *)M.A2;
     constexpr int KB1 = (KL + 7) / 8;
-#if UG_MLP_V2
-    // layer 2's biases go straight into its accumulators now: the 16 ds_read_b128 land while layer 1 runs
-#pragma unroll
-    for (int o = 0; o < 4; ++o)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float4 b = ((const float4 *)(M.B2 + bo))[o * 4 + q];
-        acc2[o][4 * q] = b.x; acc2[o][4 * q + 1] = b.y; acc2[o][4 * q + 2] = b.z; acc2[o][4 * q + 3] = b.w;
-      }
-    ug_kops kop;
-    kop.wl = ug_load_hpart(A1h + lane, 1);
-    kop.wh = ug_load_hpart(A1h + lane, 0);
-    ug_split2 xs, xn;
-    {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (e < KL) ? x[e < KL ? e : 0] : 0.f;
-      xs = ug_split8h(v, M.sx1);
-    }
-    ug_fence_operands();
-#pragma unroll
-    for (int s = 0; s < KB1; ++s) {
-      float vn[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) vn[e] = (8 * (s + 1) + e < KL) ? x[(8 * (s + 1) + e < KL) ? 8 * (s + 1) + e : 0] : 0.f;
-      ug_mfma3x4_v2<false>((s + 1 < KB1 ? A1h + ((s + 1) * 8) * 64 : A2h) + lane, xs, vn, M.sx1, xn, acc1, kop);
-      xs = xn;
-    }
-    ug_fence_results();
-    UG_PROF_MARK(prof, 3)
-    {
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = ug_relu(acc1[0][e]);
-      xs = ug_split8h(v, M.c12);
-    }
-    ug_fence_operands();
-#pragma unroll
-    for (int st = 0; st < 8; ++st) {
-      float vn[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) vn[e] = acc1[(st + 1 < 8 ? st + 1 : st) >> 1][8 * ((st + 1 < 8 ? st + 1 : st) & 1) + e];
-      ug_mfma3x4_v2<true>(A2h + ((st + 1 < 8 ? st + 1 : st) * 8) * 64 + lane, xs, vn, M.c12, xn, acc2, kop);
-      xs = xn;
-    }
-    ug_fence_results();
-#else
     ug_hpart wl = ug_load_hpart(A1h + lane, 1);
     ug_split2 xs, xn;
     {
@@ -1152,7 +1066,6 @@ __device__ __forceinline__ void ug_rgbnet_pass(const float (&x)[(2 * UG_CH(C) + 
       xs = xn;
     }
     ug_fence_results();
-#endif
   } else {
     // fp32-accurate through bf16x3 splitting: v_mfma_f32_32x32x16_bf16, B operand = 8 values of this lane
     // (lane half h supplies k = 8h..8h+7), i.e. 8 layer-1 inputs / 8 accumulator registers per k-step
