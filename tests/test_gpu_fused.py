@@ -201,6 +201,30 @@ def test_fused_render_deterministic_chunk_and_order_invariant(fr):
     assert float(a["alphainv_last"].min()) >= 0 and float(a["alphainv_last"].max()) <= 1
 
 
+def test_shade_kernel_geometries_are_bit_identical(fr):
+    """The shade kernels -- classic (0), 8-wave producer / consumer with the hand-scheduled pass (1), 12-wave with the lean
+    pass (2, default) -- issue the same products and keep every summation order: their
+    rgb_marched must agree bit for bit on a frame with many partially filled passes and empty tiles."""
+    G, F, C, R = 32, 3, 12, 50_000
+    state = make_state(123, G, F, C, 4, "inf", 1e-4, 5.0, 12.0)
+    o, d, v = [torch.from_numpy(a).cuda() for a in synth.rays(9, R)]
+    o[:4096] = o[0]                              # a block of identical rays: full tiles next to sparse ones
+    rend = fr.FourierGridRenderer(state, "cuda:0")
+    assert rend.mlp_mode == 2
+    outs = {}
+    try:
+        for pc in (0, 1, 2):
+            fr.tune("shade_pc", pc)
+            outs[pc] = rend(o, d, v, stepsize=0.5, render_depth=True, ray_order="coherent")["rgb_marched"].clone()
+            again = rend(o, d, v, stepsize=0.5, render_depth=True, ray_order="coherent")["rgb_marched"]
+            assert torch.equal(outs[pc], again), pc
+    finally:
+        fr.tune("shade_pc", 2)
+    assert float(outs[0].abs().max()) > 0.1
+    for pc in (1, 2):
+        assert torch.equal(outs[0], outs[pc]), (pc, float((outs[0] - outs[pc]).abs().max()))
+
+
 def test_grid_query_matches_reference_golden(golden_dir):
     """FourierGrid.forward / DenseGrid.forward vectors from the reference (grid_sample + mean): the device
     sin/cos differ from torch's by <= 2 ulp, which moves a tap by <= 1e-6 of a voxel."""

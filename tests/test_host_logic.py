@@ -517,6 +517,45 @@ def test_device_code_hash_ignores_the_non_loaded_sections(tmp_path):
     assert bench.device_code_sha16(str(other)) == a
 
 
+def test_roofline_block_merges_counters_only_for_the_same_device_code(tmp_path, monkeypatch):
+    """bench.roofline_block: static PMC counters (profiles/r03/pmc_summary.json) are merged only when they were taken on
+    the SAME device code (sha256 of .hip_fatbin); otherwise the block says so and carries live times + algorithmic rates
+    only.  The algorithmic-bytes-over-HBM-peak figure is printed, labelled, and never chosen as the bound; the measured
+    L1 peak of the micro-benchmark is used when its file is there; a rank's share scales the per-frame counters."""
+    import json
+    import bench
+    code = bench.device_code_sha16()
+    R, S, M = 2073600, 256, 26065245
+    kern = {"render_march": 4.3, "render_shade": 4.5}
+    pmc = {"device_code_sha16": code,
+           "render_march": {"hbm_bytes": 6.2e9, "valu_insts": 3.65e9, "mfma_busy_cycles": 0.0, "gui_active_cycles": 9.4e6},
+           "render_shade": {"hbm_bytes": 6.7e9, "valu_insts": 1.2e9, "mfma_busy_cycles": 3.5e9, "gui_active_cycles": 9.2e6}}
+    monkeypatch.setattr(bench, "PROFILE_DIR", str(tmp_path))
+    # 1. no files at all
+    r = bench.roofline_block(kern, M, R, S, M // 32)
+    assert r["traffic"] is None and r["pmc_source"] is None and r["pmc_refused"] is None
+    assert r["frame"]["frac_of_hbm_algorithmic"] > 1.0 and r["bound"] in ("l1", "mfma") and 0 < r["frac"] < 1
+    assert "cache-served" in r["per_kernel"]["render_march"]["frac_of_hbm_algorithmic_note"]
+    assert r["per_kernel"]["render_shade"]["mfma_useful_TFLOPs"] < r["per_kernel"]["render_shade"]["mfma_TFLOPs"]
+    # 2. counters of this very device code + the L1 calibration
+    (tmp_path / "pmc_summary.json").write_text(json.dumps(pmc))
+    (tmp_path / "microbench_l1_dwordx4.json").write_text(json.dumps({"quad64_B_per_clk_per_CU": 61.6, "linear_B_per_clk_per_CU": 63.8}))
+    r = bench.roofline_block(kern, M, R, S, M // 32)
+    assert r["pmc_refused"] is None and r["pmc_device_code_sha16"] == code
+    assert r["traffic"] in (6.2e9, 6.7e9) and abs(r["frame"]["hbm_bytes_pmc"] - 12.9e9) < 1e6
+    sh = r["per_kernel"]["render_shade"]
+    assert abs(sh["hbm_frac"] - 6.7e9 / 4.5e-3 / 1e9 / 8000.0) < 1e-9 and 0.3 < sh["mfma_pipe_busy"] < 0.45
+    assert abs(sh["l1_frac_of_measured_peak"] / sh["l1_frac"] - 64.0 / 61.6) < 1e-9
+    assert r["peaks"]["l1_B_per_clk_per_CU_measured"]["quad_64B_gather"] == 61.6
+    # 3. a rank's half of the frame: counters scaled by its share
+    r2 = bench.roofline_block({k: v / 2 for k, v in kern.items()}, M // 2, R // 2, S, M // 64, frame_rays=R)
+    assert r2["pmc_scaled_to_rank_share"] == 0.5 and abs(r2["per_kernel"]["render_shade"]["hbm_bytes_pmc"] - 3.35e9) < 1e3
+    # 4. counters of ANOTHER build: refused, nothing merged
+    (tmp_path / "pmc_summary.json").write_text(json.dumps(dict(pmc, device_code_sha16="0123456789abcdef")))
+    r = bench.roofline_block(kern, M, R, S, M // 32)
+    assert r["traffic"] is None and "0123456789abcdef" in r["pmc_refused"] and "hbm_frac" not in r["per_kernel"]["render_shade"]
+
+
 def test_pixel_tile_order_is_a_permutation_and_untile_inverts_it():
     """fourier_render.pixel_tile_order / untile (8 x 8 pixel blocks per march wave): a permutation of the frame's pixels in
     which every run of 64 indices is one 8 x 8 block, inverted exactly by untile; None when H or W is not a multiple."""

@@ -182,7 +182,7 @@ k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__
 // producer / consumer shade kernels (ugrid_shade_pc.h): C = 12 quad bricks, fp16x2 rgbnet; NPAIR gather waves + NPAIR rgbnet
 // waves per workgroup, one workgroup per CU.  <4, 4 slots, 6 in flight, 4-tile pass> = 8 waves of 256 VGPRs;
 // <6, 2 slots, 3 in flight, lean pass> = 12 waves of <= 168 VGPRs
-template <int F, int PE, int NPAIR, int SLOTS, int NBL, bool LEAN>
+template <int F, int PE, int NPAIR, int SLOTS, int NBL, int MODE>
 __global__ void __launch_bounds__(NPAIR * 128, (NPAIR * 2 + 3) / 4)
 k_shade_pc(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
            const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
@@ -205,7 +205,7 @@ k_shade_pc(ug_shade_args a, const float *__restrict__ viewdirs, const float *__r
     ug_pc_producer<F, NBL, SLOTS>(a, k0b, ws, rgb_marched, tile_counter, ring, ctl, pstat);
   } else {
     float *scr = pairs + NPAIR * UG_PC_PAIR_FLOATS(SLOTS) + pair * ug_pc_consumer_scratch_floats<PE>();
-    ug_pc_consumer<PE, SLOTS, LEAN>(a, viewdirs, M, rgb_marched, ring, ctl, scr, pstat);
+    ug_pc_consumer<PE, SLOTS, MODE>(a, viewdirs, M, rgb_marched, ring, ctl, scr, pstat);
   }
 }
 
@@ -517,14 +517,14 @@ static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, con
 }
 
 
-template <int F, int PE, int NPAIR, int SLOTS, int NBL, bool LEAN>
+template <int F, int PE, int NPAIR, int SLOTS, int NBL, int MODE>
 static int ug_shade_pc_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
                               ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
   const int lds_bytes = ug_pc_lds_bytes<PE, NPAIR, SLOTS>();
   if (lds_bytes > 160 * 1024) return (int)hipErrorInvalidValue;   // the CU's LDS
   static bool attr_set = false;
   if (!attr_set) {
-    UG_HIP(hipFuncSetAttribute((const void *)k_shade_pc<F, PE, NPAIR, SLOTS, NBL, LEAN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    UG_HIP(hipFuncSetAttribute((const void *)k_shade_pc<F, PE, NPAIR, SLOTS, NBL, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
     attr_set = true;
   }
   UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
@@ -532,7 +532,7 @@ static int ug_shade_pc_launch(const ug_shade_args &a, const float *viewdirs, con
   int64_t wgs = (ws.n_tiles + NPAIR - 1) / NPAIR;
   if (wgs > 256) wgs = 256;
   wgs = (wgs + 7) / 8 * 8;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_pc<F, PE, NPAIR, SLOTS, NBL, LEAN>), dim3((unsigned)wgs), dim3(NPAIR * 128), lds_bytes, st,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_pc<F, PE, NPAIR, SLOTS, NBL, MODE>), dim3((unsigned)wgs), dim3(NPAIR * 128), lds_bytes, st,
                      a, viewdirs, k0b, mlp, ws, rgb, counter);
   UG_LAUNCH_CHECK();
   return 0;
@@ -571,10 +571,10 @@ static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const 
   if constexpr (C == 12) {
     if constexpr (F <= 3) {      // the producers' set-up state grows with the level count: F >= 4 does not fit 168 VGPRs
       if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc == 2)
-        return ug_shade_pc_launch<F, PE, 6, 2, 3, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+        return ug_shade_pc_launch<F, PE, 6, 2, 3, 1>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
     }
     if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc >= 1)
-      return ug_shade_pc_launch<F, PE, 4, 4, UG_PC_NBL(F), false>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+      return ug_shade_pc_launch<F, PE, 4, 4, UG_PC_NBL(F), 0>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
   }
   // every variant runs 8 waves per workgroup (2 per SIMD, <= 256 registers each).  A 12-wave bf16x3 build needed
   // spills and gained 4 %; it is not instantiated.

@@ -358,7 +358,10 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
 // ---------------------------------------------------------------------------------------------------------------------
 // consumer wave
 // ---------------------------------------------------------------------------------------------------------------------
-template <int PE, int SLOTS, bool LEAN>
+// MODE: 0 = hand-scheduled 4-tile pass (ug_rgbnet_pass_h2), 1 = lean pass.  (A third mode -- two passes of a tile per
+// consumer wave in lock step, every weight fragment feeding two MFMAs, layer 3 of a tile behind the next tile's MFMAs, 251
+// VGPRs -- was built, verified bit-identical and measured at 4.53-4.56 ms against 4.39 ms: profiles/r03/shade_dual_pass_ab.txt.)
+template <int PE, int SLOTS, int MODE>
 __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const float *__restrict__ viewdirs, const ug_mlp_lds &M,
                                                float *__restrict__ rgb_marched, const float *ring, unsigned ctl, float *scr,
                                                unsigned long long *pstat) {
@@ -372,7 +375,7 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
   int cur_tile = -1;
   int seq = 0, head_seen = 0;
   ug_h2_state h2st;
-  if constexpr (!LEAN) ug_h2_preload(M, h * 64, h2st);
+  if constexpr (MODE == 0) ug_h2_preload(M, h * 64, h2st);
   amask[lane] = 0u;                // the hand-scheduled passes keep the per-ray masks cleared between passes
   ug_wave_lds_sync();
 #ifdef UG_SHADE_PROF
@@ -453,8 +456,11 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
     if (dbg_nomlp) { if (ok && h == 0 && sl == lane) { accr += x[0] * ww; accg += x[1] * ww; accb += x[KL - 1] * ww; } } else
 #endif
     {
-      if constexpr (LEAN) ug_rgbnet_pass_lean<C, PE>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, prof_unused);
-      else ug_rgbnet_pass_h2<C, PE, true, true>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, h2st, prof_unused);
+      if constexpr (MODE == 1) {
+        ug_rgbnet_pass_lean<C, PE>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, prof_unused);
+      } else {
+        ug_rgbnet_pass_h2<C, PE, true, true>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, h2st, prof_unused);
+      }
     }
     UG_PC_ADD(t_mlp, tm)
   }
