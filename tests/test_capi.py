@@ -251,8 +251,8 @@ def test_shade_kernel_instruction_stream_regression(lib_path):
       * the hand-off polls sleep (s_sleep) instead of spinning."""
     import re
     # (geometry, gather pattern): 8 waves = 6 items (36 loads) in flight, 12 waves = 3 items (18 loads)
-    for sym, want in (("_Z10k_shade_pcILi3ELi4ELi4ELi4ELi6ELb0E", "L" * 36 + ("<30>" + "L" * 6) * 8 + "<30><24><18><12><6><0>"),
-                      ("_Z10k_shade_pcILi3ELi4ELi6ELi2ELi3ELb1E", "L" * 18 + ("<12>" + "L" * 6) * 11 + "<12><6><0>")):
+    for sym, want in (("_Z10k_shade_pcILi3ELi4ELi4ELi4ELi6ELi0E", "L" * 36 + ("<30>" + "L" * 6) * 8 + "<30><24><18><12><6><0>"),
+                      ("_Z10k_shade_pcILi3ELi4ELi6ELi2ELi3ELi1E", "L" * 18 + ("<12>" + "L" * 6) * 11 + "<12><6><0>")):
         asm = _kernel_disassembly(lib_path, sym)
         assert asm and len(asm) > 2000, sym
         ops = [l.split()[0] for l in asm]
