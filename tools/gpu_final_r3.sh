@@ -32,5 +32,5 @@ UGRID_LIB=build/ab/lib_pc12_prof.so timeout 300 python tools/gpu_shade_pc_prof.p
 timeout 300 python tools/gpu_ray_order.py > $OUT/ray_order_guard.json 2>/dev/null; cat $OUT/ray_order_guard.json | cut -c1-500
 # 6. smoke + the whole -m gpu suite
 timeout 600 python __graft_entry__.py smoke 2>&1 | tail -2 | tee $OUT/smoke.log
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | grep -v "Warning\|warn" | tail -8 | tee $OUT/pytest_gpu.log
+timeout 2400 python -m pytest tests -m gpu -q -p no:warnings 2>&1 | tail -6 | tee $OUT/pytest_gpu.log
 ls -la $OUT
