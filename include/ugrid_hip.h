@@ -288,6 +288,24 @@ int ugrid_render_march_dcvgo(const ugrid_render_params *h_params, const ugrid_dc
                              const float *density_bricks, float *alphainv_last, float *depth, float *wsum_mid,
                              void *ws, ugrid_stream_t stream);
 
+/* Fused march of the reference's bounded DirectVoxGO.forward (dvgo.py:306-400; single-level grids, h_params->freq_num = 0,
+ * h_params->xyz_min / xyz_max = the scene box): ray / box clipping (infer_t_minmax, render_utils_kernel.cu:16-41), per-ray
+ * step counts (infer_n_samples :43-57) and point generation (sample_pts_on_rays :100-260) inside the march -- a lane loops
+ * to its own ray's count, no count / cumsum / host read / fill --, mask_outbbox and the mask cache (maskcache_lookup :374-392)
+ * before the lookup, then alpha, thresholds, compositing as above; depth = sum w * step_id (dvgo.py:419-423).
+ * h_params->n_samples = an upper bound of the steps of a ray (sizes the survivor list in ws: the box diagonal / stepdist + 1;
+ * rays are clamped to it).  The survivor list feeds ugrid_render_shade (freq_num = 0). */
+typedef struct ugrid_dvgo_params {
+  const uint8_t *mask;              /* DEVICE bool [mask_x][mask_y][mask_z] */
+  int32_t mask_x, mask_y, mask_z;
+  float xyz2ijk_scale[3], xyz2ijk_shift[3];
+  float near_clip, far_clip;        /* render_kwargs['near'], 1e9 (dvgo.py:318) */
+  float stepdist;                   /* stepsize * voxel_size */
+} ugrid_dvgo_params;
+int ugrid_render_march_dvgo(const ugrid_render_params *h_params, const ugrid_dvgo_params *h_dv, const float *rays_o,
+                            const float *rays_d, const float *density_bricks, float *alphainv_last, float *depth,
+                            void *ws, ugrid_stream_t stream);
+
 /* Fused shade: survivors -> P-level k0 bricks -> [k0, viewdir emb] -> rgbnet (MFMA, h_params->mlp_mode) -> sigmoid
  * -> weighted per-ray sum in sample order; writes rgb_marched [R,3].  mlp_packed: ugrid_pack_mlp(). */
 int ugrid_render_shade(const ugrid_render_params *h_params, const float *viewdirs,

@@ -49,6 +49,13 @@ class DcvgoParams(_c.Structure):
                 ("xyz2ijk_scale", _c.c_float * 3), ("xyz2ijk_shift", _c.c_float * 3), ("dist_thres", _c.c_float)]
 
 
+class DvgoParams(_c.Structure):
+    """Mirror of `ugrid_dvgo_params` (include/ugrid_hip.h)."""
+    _fields_ = [("mask", _c.c_void_p), ("mask_x", _c.c_int32), ("mask_y", _c.c_int32), ("mask_z", _c.c_int32),
+                ("xyz2ijk_scale", _c.c_float * 3), ("xyz2ijk_shift", _c.c_float * 3), ("near_clip", _c.c_float),
+                ("far_clip", _c.c_float), ("stepdist", _c.c_float)]
+
+
 # name -> (restype, argtypes); every int-returning entry point returns a hipError_t
 _SIGNATURES = {
     "ugrid_abi_version": (_I, []),
@@ -88,6 +95,7 @@ _SIGNATURES = {
     "ugrid_render_ws_bytes": (_L, [_L, _c.c_int32]),
     "ugrid_render_march": (_I, [_c.POINTER(RenderParams), _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ugrid_render_march_dcvgo": (_I, [_c.POINTER(RenderParams), _c.POINTER(DcvgoParams), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "ugrid_render_march_dvgo": (_I, [_c.POINTER(RenderParams), _c.POINTER(DvgoParams), _P, _P, _P, _P, _P, _P, _P]),
     "ugrid_render_shade": (_I, [_c.POINTER(RenderParams), _P, _P, _P, _P, _P, _P]),
     "ugrid_render_fused_ws_bytes": (_L, [_c.c_int32]),
     "ugrid_render_fused": (_I, [_c.POINTER(RenderParams)] + [_P] * 13),

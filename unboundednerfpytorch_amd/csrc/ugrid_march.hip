@@ -383,6 +383,20 @@ k_march_dcvgo(ug_march_args a, ug_dc_args dc, const float *__restrict__ rays_o, 
   if (ug_lane() == 0) ws.count[tile] = n;
 }
 
+// bounded DirectVoxGO march (ug_march_tile_dvgo): variable-length rays clipped against the scene box
+__global__ void __launch_bounds__(256, 6)
+k_march_dvgo(ug_march_args a, ug_dv_args dv, const float *__restrict__ rays_o, const float *__restrict__ rays_d,
+             const float *__restrict__ bricks, float *__restrict__ alphainv_last, float *__restrict__ depth, ug_ws_view ws,
+             int64_t nblocks) {
+  const int64_t blk = ug_xcd_remap(blockIdx.x, nblocks);
+  if (blk >= nblocks) return;
+  const int64_t tile = blk * 4 + (threadIdx.x >> 6);
+  if (tile >= ws.n_tiles) return;
+  const int n = ug_march_tile_dvgo(a, dv, rays_o, rays_d, bricks, alphainv_last, depth, tile, ws.ent + tile * ws.cap,
+                                   ws.slot + tile * ws.cap, a.S);
+  if (ug_lane() == 0) ws.count[tile] = n;
+}
+
 // ----------------------------------------------------------------------------------------------
 // C ABI
 // ----------------------------------------------------------------------------------------------
@@ -567,6 +581,30 @@ extern "C" int ugrid_render_march_dcvgo(const ugrid_render_params *p, const ugri
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_march_dcvgo<false>), dim3((unsigned)grid), dim3(256), 0, ST(s), a, dc, rays_o, rays_d, t_table,
                        s_table, density_bricks, alphainv_last, depth, wsum_mid, ws, nblocks);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+
+extern "C" int ugrid_render_march_dvgo(const ugrid_render_params *p, const ugrid_dvgo_params *q, const float *rays_o,
+                                       const float *rays_d, const float *density_bricks, float *alphainv_last, float *depth,
+                                       void *ws_mem, ugrid_stream_t s) {
+  if (p->n_rays <= 0) return 0;
+  if (p->freq_num != 0 || !q || !q->mask || q->mask_x < 1 || q->mask_y < 1 || q->mask_z < 1 || !(q->stepdist > 0.f))
+    return (int)hipErrorInvalidValue;
+  ug_march_args a;
+  const int rc = ug_fill_march_args(p, a);
+  if (rc) return rc;
+  ug_dv_args dv;
+  dv.mask = q->mask; dv.mi = q->mask_x; dv.mj = q->mask_y; dv.mk = q->mask_z;
+  dv.sx = q->xyz2ijk_scale[0]; dv.sy = q->xyz2ijk_scale[1]; dv.sz = q->xyz2ijk_scale[2];
+  dv.hx = q->xyz2ijk_shift[0]; dv.hy = q->xyz2ijk_shift[1]; dv.hz = q->xyz2ijk_shift[2];
+  dv.near = q->near_clip; dv.far = q->far_clip; dv.stepdist = q->stepdist;
+  ug_ws_view ws = ug_ws_make(ws_mem, p->n_rays, p->n_samples);
+  const int64_t nblocks = (ws.n_tiles + 3) / 4;
+  const int64_t grid = ((nblocks + 7) / 8) * 8;  // room for the XCD remap
+  hipLaunchKernelGGL(k_march_dvgo, dim3((unsigned)grid), dim3(256), 0, ST(s), a, dv, rays_o, rays_d, density_bricks, alphainv_last,
+                     depth, ws, nblocks);
   UG_LAUNCH_CHECK();
   return 0;
 }

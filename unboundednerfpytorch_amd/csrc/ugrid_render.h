@@ -396,6 +396,99 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
 }
 
 // ----------------------------------------------------------------------------------------------
+// Bounded DirectVoxGO march (dvgo.py:306-400): per-ray clipping against the scene box and VARIABLE-length marching
+// (render_utils_kernel.cu: infer_t_minmax :16-41, infer_n_samples :43-57, sample_pts_on_rays :100-260) without the
+// reference's count -> cumsum -> host read -> fill round trip: a lane owns a ray and simply loops to its own step count,
+// the wave until its longest ray is done.  Points outside the box (mask_outbbox) and in known free space (mask cache)
+// are exec-masked before the brick load; depth = sum w * step_id (dvgo.py:419-423).
+// ----------------------------------------------------------------------------------------------
+struct ug_dv_args {
+  const uint8_t *mask;
+  int32_t mi, mj, mk;
+  float sx, sy, sz, hx, hy, hz;     // xyz2ijk_scale / xyz2ijk_shift
+  float near, far, stepdist;
+};
+
+__device__ __forceinline__ int ug_march_tile_dvgo(const ug_march_args &a, const ug_dv_args &dv, const float *__restrict__ rays_o,
+                                                  const float *__restrict__ rays_d, const float *__restrict__ bricks,
+                                                  float *__restrict__ alphainv_last, float *__restrict__ depth, int64_t tile,
+                                                  float4 *__restrict__ ent, uint8_t *__restrict__ slot, int cap) {
+  const int lane = ug_lane();
+  const int64_t ray = tile * UG_WAVE + lane;
+  const bool valid = ray < a.n_rays;
+  float sx = 0.f, sy = 0.f, sz = 0.f, dx = 0.f, dy = 0.f, dz = 0.f;
+  int n = 0;
+  if (valid) {
+    const float ox = rays_o[3 * ray], oy = rays_o[3 * ray + 1], oz = rays_o[3 * ray + 2];
+    const float rx = rays_d[3 * ray], ry = rays_d[3 * ray + 1], rz = rays_d[3 * ray + 2];
+    // ray / box slab test; a zero direction component is replaced by float(1e-6) (infer_t_minmax)
+    const float vx = (rx == 0.f) ? (float)1e-6 : rx, vy = (ry == 0.f) ? (float)1e-6 : ry, vz = (rz == 0.f) ? (float)1e-6 : rz;
+    const float ax = (a.hix - ox) / vx, ay = (a.hiy - oy) / vy, az = (a.hiz - oz) / vz;
+    const float bx = (a.lox - ox) / vx, by = (a.loy - oy) / vy, bz = (a.loz - oz) / vz;
+    const float tmin = fmaxf(fminf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), dv.far), dv.near);
+    const float tmax = fmaxf(fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), dv.far), dv.near);
+    const float rn = sqrtf(rx * rx + ry * ry + rz * rz);
+    const double c = (double)ceilf((tmax - tmin) * rn / dv.stepdist);        // infer_n_samples
+    const double nn = c > 1. ? c : 1.;
+    n = nn > (double)cap ? cap : (int)nn;        // (the host sizes the work list for the box diagonal: never binding)
+    sx = ox + rx * tmin; sy = oy + ry * tmin; sz = oz + rz * tmin;            // rays_start
+    dx = rx / rn; dy = ry / rn; dz = rz / rn;                                  // rays_dir
+  }
+  const char *__restrict__ bkb = (const char *)bricks;
+  float T = 1.f, dsum = 0.f;
+  bool done = !valid;
+  int nsurv = 0;  // wave-uniform
+  for (int j = 0;; ++j) {
+    done = done || j >= n;
+    if (__ballot(!done) == 0ull) break;
+    bool surv = false;
+    float w = 0.f, px = 0.f, py = 0.f, pz = 0.f;
+    if (!done) {
+      const float dist = dv.stepdist * (float)j;
+      px = sx + dx * dist; py = sy + dy * dist; pz = sz + dz * dist;
+      bool keep = !((a.lox > px) | (a.loy > py) | (a.loz > pz) | (a.hix < px) | (a.hiy < py) | (a.hiz < pz));   // mask_outbbox
+      if (keep) {       // mask cache (k_maskcache semantics)
+        float fi = roundf(px * dv.sx + dv.hx), fj = roundf(py * dv.sy + dv.hy), fk = roundf(pz * dv.sz + dv.hz);
+        fi = (fi != fi) ? 0.f : fi; fj = (fj != fj) ? 0.f : fj; fk = (fk != fk) ? 0.f : fk;
+        keep = false;
+        if (fi >= 0.f && fi < (float)dv.mi && fj >= 0.f && fj < (float)dv.mj && fk >= 0.f && fk < (float)dv.mk)
+          keep = dv.mask[((int64_t)fi * dv.mj + (int64_t)fj) * dv.mk + (int64_t)fk] != 0;
+      }
+      if (keep) {
+        const float ux = ug_div_r(px - a.lox, a.ex, a.irx) * 2.f - 1.f;
+        const float uy = ug_div_r(py - a.loy, a.ey, a.iry) * 2.f - 1.f;
+        const float uz = ug_div_r(pz - a.loz, a.ez, a.irz) * 2.f - 1.f;
+        const float dens = ug_density_level(bkb, ux, uy, uz, a.X, a.Y, a.Z);
+        const float alpha = ug_alpha(dens + a.shift, a.interval);
+        if (alpha > a.thres) {
+          w = T * alpha;
+          T = (float)((double)T * (1. - (double)alpha));
+          if (w > a.thres) {
+            surv = true;
+            dsum += w * (float)j;
+          }
+          if ((double)T < 1e-3) done = true;
+        }
+      }
+    }
+    const unsigned long long m = __ballot(surv);
+    if (m != 0ull) {
+      if (surv) {
+        const int idx = nsurv + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        ent[idx] = make_float4(px, py, pz, w);
+        slot[idx] = (uint8_t)lane;
+      }
+      nsurv += __popcll(m);
+    }
+  }
+  if (valid) {
+    alphainv_last[ray] = T;
+    depth[ray] = dsum;
+  }
+  return nsurv;
+}
+
+// ----------------------------------------------------------------------------------------------
 // rgbnet packing for the transposed MFMA chain
 // packed (floats): A1 [KL][64][4] | A2 [64][64][4] | bias1 [2][64] | bias2 [2][64] | W3 [2][64][4] | b3 [4]
 // ----------------------------------------------------------------------------------------------

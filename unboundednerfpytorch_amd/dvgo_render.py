@@ -17,6 +17,43 @@ import torch
 import torch.nn.functional as F
 
 
+def dvgo_state_from_params(xyz_min, xyz_max, num_voxels, num_voxels_base, alpha_init, density_grid, k0_grid, rgbnet_weights,
+                           rgbnet_biases, mask, fast_color_thres, rgbnet_direct, viewbase_pe=4):
+    """The renderer's `state` from DirectVoxGO's constructor arguments and learned tensors: voxel sizes and world size as
+    __init__ / _set_grid_resolution derive them (dvgo.py:40-56, 154-163), act_shift = log(1/(1-alpha_init) - 1) (:49), the
+    world -> mask index map of its MaskGrid (grid.py:221-228).  All fp32 tensor arithmetic, like the reference."""
+    import math
+    lo, hi = torch.Tensor(xyz_min), torch.Tensor(xyz_max)
+    vol = (hi - lo).prod()
+    voxel_size = (vol / num_voxels).pow(1 / 3)
+    scale = (torch.Tensor(list(mask.shape)) - 1) / (hi - lo)
+    return {'xyz_min': lo, 'xyz_max': hi, 'voxel_size': voxel_size, 'voxel_size_ratio': voxel_size / (vol / num_voxels_base).pow(1 / 3),
+            'world_size': ((hi - lo) / voxel_size).long(), 'act_shift': torch.FloatTensor([math.log(1 / (1 - alpha_init) - 1)]),
+            'density_grid': density_grid, 'k0_grid': k0_grid, 'rgbnet_weights': list(rgbnet_weights),
+            'rgbnet_biases': list(rgbnet_biases), 'mask': mask.bool(), 'xyz2ijk_scale': scale, 'xyz2ijk_shift': -lo * scale,
+            'fast_color_thres': fast_color_thres, 'rgbnet_direct': bool(rgbnet_direct), 'viewbase_pe': int(viewbase_pe)}
+
+
+def dvgo_state_from_reference_checkpoint(ckpt):
+    """`state` from a checkpoint the reference's trainer wrote for a DirectVoxGO model ({'model_kwargs', 'model_state_dict'},
+    run_train.py / utils.load_model): dense grids only (density_type = k0_type = 'DenseGrid', the default)."""
+    kw, sd = ckpt['model_kwargs'], ckpt['model_state_dict']
+    if kw.get('density_type', 'DenseGrid') != 'DenseGrid' or kw.get('k0_type', 'DenseGrid') != 'DenseGrid':
+        raise NotImplementedError("only DenseGrid checkpoints (TensoRFGrid is outside the hot path, SURVEY.md section 8)")
+    if kw.get('rgbnet_full_implicit', False):
+        raise NotImplementedError("rgbnet_full_implicit models have no feature grid")
+    lin = sorted({k[:-len('.weight')] for k in sd if k.startswith('rgbnet.') and k.endswith('.weight')},
+                 key=lambda n: [int(x) for x in n.split('.')[1:]])
+    st = dvgo_state_from_params(
+        kw['xyz_min'], kw['xyz_max'], kw['num_voxels'], kw['num_voxels_base'], kw['alpha_init'], sd['density.grid'], sd['k0.grid'],
+        [sd[n + '.weight'] for n in lin], [sd[n + '.bias'] for n in lin], sd['mask_cache.mask'], kw.get('fast_color_thres', 0),
+        kw.get('rgbnet_direct', False), kw.get('viewbase_pe', 4))
+    for k in ('xyz2ijk_scale', 'xyz2ijk_shift'):          # the stored buffers win over the re-derived ones
+        if 'mask_cache.' + k in sd:
+            st[k] = sd['mask_cache.' + k]
+    return st
+
+
 class DirectVoxGORenderer:
     """state: xyz_min/xyz_max [3], density_grid [1,1,X,Y,Z], k0_grid [1,C,X,Y,Z], rgbnet_weights/biases (lists),
     mask [mx,my,mz] bool, xyz2ijk_scale/shift [3], act_shift, voxel_size, voxel_size_ratio (0-d tensors or floats),
@@ -36,6 +73,56 @@ class DirectVoxGORenderer:
         self.s = {k: (v.to(dev).contiguous() if torch.is_tensor(v) else
                       ([x.to(dev).contiguous() for x in v] if isinstance(v, list) else v)) for k, v in state.items()}
         self.viewfreq = torch.tensor([float(2 ** i) for i in range(int(state["viewbase_pe"]))], device=dev)
+        self._fused = None if ops is None else False      # fused render kernels: HIP library only, built on first use
+
+    # -- fused inference path ----------------------------------------------------------------------------------
+    def fused_supported(self):
+        """the fused march (ugrid_render_march_dvgo) + shade kernels cover: the default HIP ops, fast_color_thres > 0, one
+        resolution for both grids, and either no rgbnet (3-channel k0, rgb = sigmoid(k0)) or the DIRECT 3 x 128 rgbnet on
+        [k0 (12), view embedding] that ugrid_shade_supported(0, C, viewbase_pe) lists (rgbnet_direct = False, the diffuse +
+        residual colour of dvgo.py:411-414, stays on the composed forward)"""
+        if self._fused is False:
+            return False
+        s = self.s
+        if float(s['fast_color_thres']) <= 0 or tuple(s['density_grid'].shape[2:]) != tuple(s['k0_grid'].shape[2:]):
+            return False
+        C = int(s['k0_grid'].shape[1])
+        if len(s['rgbnet_weights']) == 0:
+            return C == 3
+        from . import _lib
+        w = s['rgbnet_weights']
+        return (bool(s['rgbnet_direct']) and len(w) == 3 and tuple(w[1].shape) == (128, 128) and w[2].shape[0] == 3
+                and w[0].shape[1] == C + 3 + 6 * int(s['viewbase_pe'])
+                and bool(_lib.load().ugrid_shade_supported(0, C, int(s['viewbase_pe']))))
+
+    @torch.no_grad()
+    def render_rays(self, rays_o, rays_d, viewdirs, **render_kwargs):
+        """Per-ray outputs of forward() -- rgb_marched, depth, alphainv_last (what the render program consumes,
+        run_render.py:46) -- through the FUSED kernels: the whole chain of dvgo.py:306-425 in two launches.  The reference
+        (and forward()) size the sample list by a count kernel, a cumsum and a HOST READ of the total before the fill
+        (render_utils_kernel.cu:100-260, `.item()` in sample_pts_on_rays); here a lane marches its ray to the ray's own
+        step count, so nothing is read back.  Falls back to forward() for models outside fused_supported().
+        render_kwargs as forward(): near, stepsize, bg, render_depth, plus FourierGridRenderer's ray_order."""
+        if not self.fused_supported():
+            out = self.forward(rays_o, rays_d, viewdirs, **render_kwargs)
+            return {k: out[k] for k in ('rgb_marched', 'depth', 'alphainv_last') if k in out}
+        if self._fused is None:
+            from .fourier_render import FourierGridRenderer
+            s = self.s
+            lo, hi = s['xyz_min'], s['xyz_max']
+            st = {'density_grid': s['density_grid'], 'k0_grid': s['k0_grid'], 'rgbnet_weights': s['rgbnet_weights'],
+                  'rgbnet_biases': s['rgbnet_biases'], 'scene_center': (lo + hi) * 0.5, 'scene_radius': (hi - lo) * 0.5,
+                  'xyz_min': lo, 'xyz_max': hi, 'bg_len': 0.0, 'fourier_freq_num': 0, 'viewbase_pe': s['viewbase_pe'],
+                  'act_shift': float(s['act_shift']), 'voxel_size_ratio': float(s['voxel_size_ratio']),
+                  'fast_color_thres': float(s['fast_color_thres']), 'contracted_norm': 'inf', 'world_len': 0,
+                  'dvgo': {'mask': s['mask'], 'xyz2ijk_scale': s['xyz2ijk_scale'], 'xyz2ijk_shift': s['xyz2ijk_shift'],
+                           'voxel_size': s['voxel_size']}}
+            self._fused = FourierGridRenderer(st, self.device)
+        kw = dict(render_kwargs)
+        if 'bg' in kw and torch.is_tensor(kw['bg']):
+            kw['bg'] = kw['bg'].to(self.device)
+        out = self._fused(rays_o.contiguous(), rays_d.contiguous(), viewdirs.contiguous(), **kw)
+        return {k: out[k] for k in ('rgb_marched', 'depth', 'alphainv_last') if k in out}
 
     @torch.no_grad()
     def forward(self, rays_o, rays_d, viewdirs, global_step=None, **render_kwargs):

@@ -54,6 +54,10 @@ class FourierGridRenderer:
     (single-level grids): the DirectContractedVoxGO forward (dcvgo.py:228-384) -- sample table with boundary 2, the
     cumdist_thres rule and the mask cache inside the march (ugrid_render_march_dcvgo), `wsum_mid` among the outputs and
     `bg` honoured (rgb_marched += alphainv_last * bg).  dcvgo_render.DirectContractedVoxGORenderer.render_rays builds it.
+    Optional `dvgo` = {'mask', 'xyz2ijk_scale', 'xyz2ijk_shift', 'voxel_size'} with fourier_freq_num = 0: the BOUNDED
+    DirectVoxGO forward (dvgo.py:306-425, rgbnet_direct) -- xyz_min / xyz_max are the scene box, rays are clipped against it
+    and marched with their own step counts inside ugrid_render_march_dvgo (no contraction, no sample table); render kwargs
+    `near` and `bg` as the reference, depth = sum w * step_id.  dvgo_render.DirectVoxGORenderer.render_rays builds it.
     """
 
     def __init__(self, state, device, max_ws_bytes=48 << 30, fused=False, pipeline=0, mlp_mode=None):
@@ -97,8 +101,18 @@ class FourierGridRenderer:
                        "scale": [float(x) for x in d["xyz2ijk_scale"]], "shift": [float(x) for x in d["xyz2ijk_shift"]]}
             if self.dc["mask"].dim() != 3:
                 raise RuntimeError("dcvgo mask must be a [mx,my,mz] bool grid")
-        elif self.F == 0:
-            raise RuntimeError("fourier_freq_num = 0 is the DirectContractedVoxGO path: pass state['dcvgo']")
+        self.dv = None
+        if state.get("dvgo") is not None:
+            if self.F != 0 or self.dc is not None:
+                raise RuntimeError("the DirectVoxGO march is for single-level grids (fourier_freq_num = 0), without 'dcvgo'")
+            d = state["dvgo"]
+            self.dv = {"mask": d["mask"].to(dev).to(torch.bool).contiguous(), "voxel_size": d["voxel_size"],
+                       "scale": [float(x) for x in d["xyz2ijk_scale"]], "shift": [float(x) for x in d["xyz2ijk_shift"]]}
+            if self.dv["mask"].dim() != 3:
+                raise RuntimeError("dvgo mask must be a [mx,my,mz] bool grid")
+        elif self.F == 0 and self.dc is None:
+            raise RuntimeError("fourier_freq_num = 0 is the DirectContractedVoxGO / DirectVoxGO path: pass state['dcvgo'] "
+                               "or state['dvgo']")
         if self.thres <= 0:
             raise RuntimeError("fast_color_thres must be > 0 (the reference forward is not usable at 0 either, "
                                "FourierGrid_model.py:600-614)")
@@ -146,8 +160,17 @@ class FourierGridRenderer:
         self._last = None
 
     # -- helpers ---------------------------------------------------------------------------------
+    def stepdist(self, stepsize):
+        # python float * 0-d fp32 tensor -> fp32 product (dvgo.py:319)
+        return float(stepsize * torch.as_tensor(self.dv["voxel_size"], dtype=torch.float32))
+
     def tables(self, stepsize):
         key = float(stepsize)
+        if self.dv is not None:
+            # no sample table: S = an upper bound of a ray's step count, ceil(box diagonal / stepdist) + 1 (sizes the work list)
+            ext = [self._vec["xyz_max"][i] - self._vec["xyz_min"][i] for i in range(3)]
+            diag = (ext[0] ** 2 + ext[1] ** 2 + ext[2] ** 2) ** 0.5
+            return None, None, int(diag * (1 + 1e-5) / self.stepdist(stepsize)) + 2
         if key not in self._tables:
             t, s = sample_table(self.world_len, key, self.bg_len, t_boundary=2 if self.dc is not None else 1.5)
             self._tables[key] = (t.to(self.device), s.to(self.device), int(t.numel()))
@@ -280,6 +303,15 @@ class FourierGridRenderer:
             for i in range(3):
                 dcp.xyz2ijk_scale[i], dcp.xyz2ijk_shift[i] = self.dc["scale"][i], self.dc["shift"][i]
             dcp.dist_thres = (2 + 2 * self.bg_len) / self.world_len * stepsize * 0.95      # dcvgo.py:285
+        dvp = None
+        if self.dv is not None:
+            dvp = _lib.DvgoParams()
+            dvp.mask = self.dv["mask"].data_ptr()
+            dvp.mask_x, dvp.mask_y, dvp.mask_z = [int(x) for x in self.dv["mask"].shape]
+            for i in range(3):
+                dvp.xyz2ijk_scale[i], dvp.xyz2ijk_shift[i] = self.dv["scale"][i], self.dv["shift"][i]
+            dvp.near_clip, dvp.far_clip = float(render_kwargs["near"]), 1e9       # dvgo.py:318: the given far is ignored
+            dvp.stepdist = self.stepdist(stepsize)
         timing = render_kwargs.get("timing")  # optional list collecting ([ev0, ev1, ev2], n_rays) per launch group
         fused = self.use_fused and self.has_mlp and self.dc is None and (self.F, self.C, self.pe) in ((3, 12, 4), (4, 12, 4))
         with _lib.guard(dev):
@@ -300,7 +332,7 @@ class FourierGridRenderer:
                     ev[1].record()
                     timing.append((ev, R))
                 self._last = ("fused", R, S)
-            elif self.pipeline > 1 and R >= 64 * 64 * self.pipeline and self.dc is None:
+            elif self.pipeline > 1 and R >= 64 * 64 * self.pipeline and self.dc is None and self.dv is None:
                 self._forward_pipelined(rays_o, rays_d, viewdirs, t_tab, s_tab, S, stepsize, last, depth, rgb, timing)
             else:
                 chunk = self.rays_per_chunk(S)
@@ -317,6 +349,9 @@ class FourierGridRenderer:
                         _lib.check(_L.ugrid_render_march_dcvgo(p, ctypes.byref(dcp), _p(o_), _p(d_), _p(t_tab), _p(s_tab),
                                                                _p(self.density_bricks), _p(last[b:e]), _p(depth[b:e]), _p(wmid[b:e]),
                                                                _p(ws), st), "render_march_dcvgo")
+                    elif dvp is not None:
+                        _lib.check(_L.ugrid_render_march_dvgo(p, ctypes.byref(dvp), _p(o_), _p(d_), _p(self.density_bricks),
+                                                              _p(last[b:e]), _p(depth[b:e]), _p(ws), st), "render_march_dvgo")
                     else:
                         _lib.check(_L.ugrid_render_march(p, _p(o_), _p(d_), _p(t_tab), _p(s_tab), _p(self.density_bricks),
                                                          _p(last[b:e]), _p(depth[b:e]), _p(ws), st), "render_march")
@@ -331,8 +366,8 @@ class FourierGridRenderer:
         out = {"alphainv_last": last, "rgb_marched": rgb, "n_max": S}
         if self.dc is not None:
             out["wsum_mid"] = wmid
-            if "bg" in render_kwargs:                      # dcvgo.py:349-352: rgb_marched += alphainv_last * bg
-                rgb += last.unsqueeze(-1) * render_kwargs["bg"]
+        if (self.dc is not None or self.dv is not None) and "bg" in render_kwargs:
+            rgb += last.unsqueeze(-1) * render_kwargs["bg"]   # dcvgo.py:349-352 / dvgo.py:405: rgb_marched += alphainv_last * bg
         if render_kwargs.get("render_depth", False):
             out["depth"] = depth
         return out
