@@ -332,8 +332,9 @@ int ugrid_render_fused_stats(const void *ws, int64_t *d_stats, ugrid_stream_t st
  * a convex combination of grid values averaged over levels); it sizes the power-of-two activation scales of
  * the fp16x2 image (view directions are assumed unit length like the reference's, dvgo.py:517).  Pass <= 0
  * if unknown.  *best_mode (HOST int, may be NULL) receives the fastest usable mode: UGRID_MLP_FP16X2 when
- * the weights and the propagated activation bounds fit fp16's range after scaling, else UGRID_MLP_BF16X3.
- * Synchronises the stream once (the weights are read back to derive the scales). */
+ * the weights and the propagated activation bounds fit fp16's range after scaling and viewbase_pe <= 4 (the fp16x2
+ * kernels keep a per-wave view-embedding table in LDS that does not fit beside the rgbnet image for wider embeddings),
+ * else UGRID_MLP_BF16X3.  Synchronises the stream once (the weights are read back to derive the scales). */
 int64_t ugrid_mlp_packed_bytes(int32_t k0_channels, int32_t viewbase_pe);
 int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1, const float *b1,
                    const float *w2, const float *b2, int32_t k0_channels, int32_t viewbase_pe,

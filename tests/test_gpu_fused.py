@@ -72,6 +72,9 @@ def test_fused_render_matches_reference_golden(fr, case, golden_dir):
     (33, 4, 12, 4, "inf", 3000, 0.8, 3.0, 10.0),
     (28, 2, 3, 2, "l2", 4099, 0.5, 5.0, 12.0),
     (20, 3, 0, 4, "inf", 2000, 0.5, 6.0, 12.0),
+    (30, 3, 12, 8, "inf", 3000, 0.5, 6.0, 12.0),     # configs/waymo/waymo_base.py, configs/mega/*.py: viewbase_pe = 8
+    (26, 3, 3, 8, "l2", 3000, 0.5, 5.0, 12.0),       # configs/mega/building_no_block.py
+    (30, 3, 15, 4, "inf", 3000, 0.5, 6.0, 12.0),     # configs/tankstemple_unbounded/train_single.py: rgbnet_dim = 15
 ])
 def test_fused_render_vs_oracle(fr, G, F, C, pe, norm, R, stepsize, dm, ds):
     torch.set_num_threads(max(1, os.cpu_count() or 1))
@@ -201,12 +204,12 @@ def test_fused_render_deterministic_chunk_and_order_invariant(fr):
     assert float(a["alphainv_last"].min()) >= 0 and float(a["alphainv_last"].max()) <= 1
 
 
-def test_shade_kernel_geometries_are_bit_identical(fr):
+def test_shade_kernel_geometries_are_bit_identical(fr, pe=4):
     """The shade kernels -- classic (0), 8-wave producer / consumer with the hand-scheduled pass (1), 12-wave with the lean
     pass (2, default) -- issue the same products and keep every summation order: their
     rgb_marched must agree bit for bit on a frame with many partially filled passes and empty tiles."""
     G, F, C, R = 32, 3, 12, 50_000
-    state = make_state(123, G, F, C, 4, "inf", 1e-4, 5.0, 12.0)
+    state = make_state(123, G, F, C, pe, "inf", 1e-4, 5.0, 12.0)
     o, d, v = [torch.from_numpy(a).cuda() for a in synth.rays(9, R)]
     o[:4096] = o[0]                              # a block of identical rays: full tiles next to sparse ones
     rend = fr.FourierGridRenderer(state, "cuda:0")

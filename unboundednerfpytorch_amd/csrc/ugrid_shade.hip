@@ -395,7 +395,8 @@ extern "C" int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1,
   const ug_mlp_scales sc = {sc4[0], sc4[1], sc4[2], sc4[3]};
   hipLaunchKernelGGL(k_pack_mlp, dim3(64), dim3(256), 0, ST(s), w0, b0, w1, b1, w2, b2, C, n_emb, sc, packed);
   UG_LAUNCH_CHECK();
-  if (best_mode) *best_mode = ok ? UGRID_MLP_FP16X2 : UGRID_MLP_BF16X3;
+  // (viewbase_pe > 4: the fp16x2 kernels' LDS geometry does not fit, see ug_shade_launch)
+  if (best_mode) *best_mode = (ok && viewbase_pe <= 4) ? UGRID_MLP_FP16X2 : UGRID_MLP_BF16X3;
   return 0;
 }
 
@@ -568,7 +569,13 @@ static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const 
     if (mlp_mode == UGRID_MLP_FP16X2 && g_shade16) return ug_shade16_launch<F>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
   }
 #endif
-  if constexpr (C == 12) {
+  // fp16x2 keeps a per-wave view-embedding table in LDS next to the rgbnet image: with viewbase_pe = 8 that is 14 KB per
+  // consumer wave on top of a 99 KB image -- no 8-wave geometry fits the CU's 160 KB.  ugrid_pack_mlp reports bf16x3 as the
+  // best mode for such networks and the fp16x2 kernels are not instantiated for them.
+  if constexpr (PE > 4) {
+    if (mlp_mode == UGRID_MLP_FP16X2) return (int)hipErrorInvalidValue;
+  }
+  if constexpr (C == 12 && PE <= 4) {
     if constexpr (F <= 3) {      // the producers' set-up state grows with the level count: F >= 4 does not fit 168 VGPRs
       if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc == 2)
         return ug_shade_pc_launch<F, PE, 6, 2, 3, 1>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
@@ -578,7 +585,9 @@ static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const 
   }
   // every variant runs 8 waves per workgroup (2 per SIMD, <= 256 registers each).  A 12-wave bf16x3 build needed
   // spills and gained 4 %; it is not instantiated.
-  if (mlp_mode == UGRID_MLP_FP16X2) return ug_shade_launch_nw<F, C, PE, 8, 2>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  if constexpr (PE <= 4) {
+    if (mlp_mode == UGRID_MLP_FP16X2) return ug_shade_launch_nw<F, C, PE, 8, 2>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  }
   if (mlp_mode == UGRID_MLP_BF16X3) return ug_shade_launch_nw<F, C, PE, 8, 1>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
   return ug_shade_launch_nw<F, C, PE, 8, 0>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
 }
@@ -603,7 +612,9 @@ extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *vie
 // truck_single.py:105; FourierGridModel's constructor default fourier_freq_num = 5 (FourierGrid_model.py:137); waymo-style
 // rgbnet_dim = 3, viewbase_pe = 2 (configs/waymo/waymo_no_block.py:144-149)
 // F = 0: single-level k0 (DirectContractedVoxGO / DenseGrid models, configs/nerf_unbounded/*.py: rgbnet_dim 12)
-#define UG_SHADE_TRIPLES(X) X(3, 12, 4) X(4, 12, 4) X(5, 12, 4) X(2, 12, 4) X(1, 12, 4) X(0, 12, 4) X(2, 3, 2) X(3, 3, 2)
+// viewbase_pe = 8 (configs/waymo/waymo_base.py, configs/mega/*.py; rgbnet_dim 3 in mega/building_no_block.py); rgbnet_dim = 15
+// (configs/tankstemple_unbounded/train_single.py)
+#define UG_SHADE_TRIPLES(X) X(3, 12, 4) X(4, 12, 4) X(5, 12, 4) X(2, 12, 4) X(1, 12, 4) X(0, 12, 4) X(2, 3, 2) X(3, 3, 2) X(3, 12, 8) X(3, 3, 8) X(3, 15, 4)
 #define UG_SHADE_CASE(F_, C_, PE_)                                                          \
   if (p->freq_num == F_ && p->k0_channels == C_ && p->viewbase_pe == PE_)                   \
     return ug_shade_launch<F_, C_, PE_>(a, viewdirs, k0_bricks, mlp_packed, ws, rgb_marched, counter, p->mlp_mode, ST(s));
