@@ -199,6 +199,49 @@ int ugrid_tv_adam_dense_cl(const float *param, float *param_out, const float *gr
                            int step, float beta1, float beta2, float lr, float eps, int flags,
                            ugrid_stream_t stream);
 
+/* Touched-line bitmap of a recycled gradient buffer (NEW, training; channel-last grids).  The lookup backward of a training
+ * step touches a few per cent of the 256-byte lines of the grid-sized gradient (S3: ~5 % of 3.46 GB); the reference's masked
+ * TV and masked Adam (total_variation_kernel.cu:14-67 masked, adam_upd_kernel.cu:26-41) find them by scanning the whole array
+ * for non-zeros, twice per step.  Here the backward marks what it touches -- bit (e >> 6) & 31 of word e >> 11 for element e of
+ * grad_grid, ugrid_touch_words(N) uint32 words, all zero initially -- and the passes below read the bitmap and only the
+ * marked lines.  Contract: between the backward and the passes nobody writes a non-zero into an unmarked line (results are
+ * then identical to the scanning kernels: within a marked line the per-element `grad != 0` rule still decides).
+ *   ugrid_grid_query_backward_cl_touch       ugrid_grid_query_backward_cl + marking
+ *   ugrid_total_variation_add_grad_cl_touch  masked mode (dense_mode = 0) on the marked lines
+ *   ugrid_masked_adam_upd_touch              masked_adam_upd on the marked lines; grad comes back all zero, touch cleared
+ *   ugrid_tv_adam_dense_cl_touch             the fused dense pass without reading unmarked gradient lines; with the rezero
+ *                                            flag (flags & 2) touch is cleared as well */
+int64_t ugrid_touch_words(int64_t N);
+int ugrid_grid_query_backward_cl_touch(const float *grad_out, int P, int C, int X, int Y, int Z, const float *xyz,
+                                       const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
+                                       float *grad_grid, uint32_t *touch, ugrid_stream_t stream);
+int ugrid_total_variation_add_grad_cl_touch(const float *param, float *grad, float wx, float wy, float wz,
+                                            int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t C, int64_t N,
+                                            const uint32_t *touch, ugrid_stream_t stream);
+int ugrid_masked_adam_upd_touch(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t N, int step,
+                                float beta1, float beta2, float lr, float eps, uint32_t *touch, ugrid_stream_t stream);
+int ugrid_tv_adam_dense_cl_touch(const float *param, float *param_out, const float *grad, float *exp_avg, float *exp_avg_sq,
+                                 float wx, float wy, float wz, int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t C, int64_t N,
+                                 int step, float beta1, float beta2, float lr, float eps, int flags, uint32_t *touch,
+                                 ugrid_stream_t stream);
+
+/* The rgbnet of the training step (FourierGrid_model.py:233-241, :636: Linear(mlp_in,128)-ReLU-Linear(128,128)-ReLU-Linear(128,3)
+ * on the M surviving samples) and its derivative as fp32-MFMA kernels (csrc/ugrid_train_mlp.hip), replacing the library GEMMs of
+ * torch's nn.Linear forward / backward whose host overhead dominates at M ~ 1e5.  nn.Linear layouts: w0 [128, mlp_in], w1 [128,128],
+ * w2 [3,128]; feat [M, mlp_in] row-major.  forward: h1, h2 [M,128] (post-ReLU activations, kept for the backward), logits [M,3].
+ * backward: g_w*, g_b* (overwritten, not accumulated), g_feat [M, n_feat_grad] = the gradient of the first n_feat_grad input
+ * columns (the k0 features; 0 / NULL = none); scratch: ugrid_rgbnet_train_scratch_floats(M) floats.  fp32 products and
+ * accumulation; the weight gradients are sums of <= 256 slab partials added in a fixed order (deterministic).  width must be
+ * 128, mlp_in <= 128. */
+int64_t ugrid_rgbnet_train_scratch_floats(int64_t M);
+int ugrid_rgbnet_train_forward(const float *feat, int64_t M, int32_t mlp_in, const float *w0, const float *b0, const float *w1,
+                               const float *b1, const float *w2, const float *b2, int32_t width, float *h1, float *h2,
+                               float *logits, ugrid_stream_t stream);
+int ugrid_rgbnet_train_backward(const float *g_logits, const float *feat, const float *h1, const float *h2, int64_t M,
+                                int32_t mlp_in, int32_t n_feat_grad, const float *w0, const float *w1, const float *w2,
+                                int32_t width, float *g_feat, float *g_w0, float *g_b0, float *g_w1, float *g_b1, float *g_w2,
+                                float *g_b2, float *scratch, ugrid_stream_t stream);
+
 /* NEW (no reference counterpart; training tail): sigmoid + per-ray compositing + the loss of run_train.py:254-279 in
  * one pass, and its derivative -- replaces FourierGrid_model.py:636-647 (sigmoid, weights * rgb, segment_coo, background)
  * and run_train.py:254-279 (mse_loss, entropy_last, nearclip, flatten_eff_distloss, rgbper): ~45 + ~90 launches of the

@@ -505,3 +505,41 @@ def test_masked_adam_rezero_grad_returns_the_gradient_buffer_all_zero(n):
     adam_upd_cuda.masked_adam_upd_rezero(pb, gb, mb, vb, *args)
     assert torch.equal(ga, g) and not bool(gb.any())
     assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,C,E", [(5000, 12, 27), (33, 12, 27), (1, 3, 15), (4097, 15, 27), (2500, 12, 51), (70000, 12, 27)])
+def test_fused_rgbnet_matches_torch_linear_layers(M, C, E):
+    """ops.FusedRgbnet (fp32-MFMA kernels, csrc/ugrid_train_mlp.hip) vs the same three nn.Linear layers through torch: logits and
+    every gradient (k0 features, weights, biases); fp32 products on both sides, so only the summation order differs"""
+    from unboundednerfpytorch_amd import ops
+    torch.manual_seed(M + C)
+    net = torch.nn.Sequential(torch.nn.Linear(C + E, 128), torch.nn.ReLU(inplace=True),
+                              torch.nn.Sequential(torch.nn.Linear(128, 128), torch.nn.ReLU(inplace=True)), torch.nn.Linear(128, 3)).cuda()
+    with torch.no_grad():
+        net[3].bias.normal_(0, 0.1)
+    lin = ops.rgbnet_linears(net)
+    assert lin is not None and [l.in_features for l in lin] == [C + E, 128, 128]
+    assert ops.rgbnet_linears(torch.nn.Sequential(torch.nn.Linear(C + E, 64), torch.nn.ReLU(), torch.nn.Linear(64, 3))) is None
+    k0 = torch.randn(M, C, device="cuda", requires_grad=True)
+    emb = torch.randn(M, E, device="cuda")
+    go = torch.randn(M, 3, device="cuda")
+    ref = net(torch.cat([k0, emb], -1))
+    ref.backward(go)
+    want = [k0.grad.clone()] + [p.grad.clone() for l in lin for p in (l.weight, l.bias)]
+    k0.grad = None
+    net.zero_grad(set_to_none=True)
+    out = ops.FusedRgbnet.apply(k0, emb, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight, lin[2].bias)
+    out.backward(go)
+    got = [k0.grad] + [p.grad for l in lin for p in (l.weight, l.bias)]
+    torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-5)
+    # a pre-activation within rounding of zero can land on either side of the ReLU in the two summation orders: that sample's
+    # gradient then differs by a whole term (1 of 70 000 x 256 activations in the largest case).  Rows: at most M / 20000 + 1
+    # such samples; weight gradients: one sample's contribution of slack on top of the rounding-level bound.
+    row_err = (got[0] - want[0]).abs().amax(dim=1)
+    flips = int((row_err > 3e-5 * float(want[0].abs().max()) + 1e-6).sum())
+    assert flips <= M // 20000 + 1, flips
+    for n, a, b in zip(["w0", "b0", "w1", "b1", "w2", "b2"], got[1:], want[1:]):
+        scale = float(b.abs().max()) + 1e-12
+        tol = (3e-5 if flips == 0 else 1e-2) * scale + 1e-6
+        assert float((a - b).abs().max()) <= tol, (n, float((a - b).abs().max()), scale, flips)

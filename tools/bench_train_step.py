@@ -74,6 +74,8 @@ def parse(argv=None):
                     "truck_single (global_step < tv_dense_before = 10000), 10001 = the masked-TV phase that follows")
     ap.add_argument("--overlap", type=int, default=1, help="k0 TV + Adam pass on a second stream (train_iteration overlap_k0_update)")
     ap.add_argument("--fused-loss", type=int, default=1, help="compositing + loss as one op (ops.RenderLoss) or the torch chain")
+    ap.add_argument("--touch", type=int, default=1, help="touched-line bitmap of the recycled k0 gradient (_gradpool.touch_enabled): "
+                    "the masked TV / Adam passes visit only the lines the backward marked; 0 = the scanning kernels")
     ap.add_argument("--channels-last", type=int, default=1, help="k0 stored [P][X][Y][Z][C] (the training layout) or row-major")
     return ap.parse_args(argv)
 
@@ -82,6 +84,8 @@ def run(args):
     """One measurement; returns the result dict (bench.py embeds it as `secondary_s3_train_step`)."""
     from unboundednerfpytorch_amd import train_step as ts
     from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
+    from unboundednerfpytorch_amd import _gradpool
+    _gradpool.touch_enabled = bool(getattr(args, "touch", 1))
     dev = torch.device("cuda", 0)
     model = make_model(args.grid, args.freq, dev, args.fused, args.channels_last)
     model.fused_loss = bool(args.fused_loss)
@@ -115,6 +119,16 @@ def run(args):
     for a, b in zip(order[:-1], order[1:]):
         ms[b] = sum(x.elapsed_time(y) for x, y in zip(timers[a], timers[b])) / args.steps
     total = wall_ms        # all streams, host clock around the timed steps; the phase split is the main stream's
+    # fraction of the k0 gradient's 256-byte lines one backward marks (a fresh backward; the optimizer clears the bitmap)
+    touched = None
+    if _gradpool.touch_enabled:
+        out = model(o, d, v, global_step=step, is_train=True, **rk)
+        out["rgb_marched"].sum().backward()
+        tb = _gradpool.touch_of(model.k0.grid, model.k0.grid.grad)
+        if tb is not None:
+            w = tb.to(torch.int64) & 0xFFFFFFFF
+            bits = sum(int(((w >> i) & 1).sum()) for i in range(32))
+            touched = bits / float((model.k0.grid.numel() + 63) // 64)
     with torch.no_grad():
         out = model(o, d, v, global_step=step, is_train=True, **rk)
     M = int(out["weights"].numel())
@@ -125,6 +139,7 @@ def run(args):
            "fused_forward": bool(getattr(model, "fused_forward", False)),
            "k0_channels_last": not model.k0.grid.is_contiguous(), "fused_loss": bool(args.fused_loss), "overlap_k0_update": bool(args.overlap),
            "tv_phase": "dense" if args.first_step + args.warmup + args.steps - 1 < TRUCK_CFG["tv_dense_before"] else "masked",
+           "touch_bitmap": bool(_gradpool.touch_enabled), "k0_grad_lines_touched_frac": touched,
            "ms_per_step": total, "phases_ms": ms, "steps": args.steps, "survivors_M": M, "samples": args.rays * S,
            "rays_per_sec": args.rays / (total * 1e-3), "k0_voxels": n_k0,
            "k0_streaming_floor_ms": {"note": "compulsory HBM passes over the 3.46 GB k0-sized arrays per step at 6.3 TB/s achievable: "

@@ -8,13 +8,22 @@ up (`take`) instead of allocating and filling a new one.
 
 Invariants: a parked buffer is all zero, has the parameter's shape, strides, dtype and device, and nothing else references
 it (AccumulateGrad adopts a gradient without copying only while it holds the sole reference).  One buffer per parameter;
-entries die with their parameter."""
+entries die with their parameter.
+
+Touched-line bitmaps (channel-last grids): the backward also marks which 256-byte lines of the buffer it adds to
+(`touch_for_backward`, include/ugrid_hip.h: ugrid_grid_query_backward_cl_touch), and the optimizer's masked TV / masked Adam /
+fused dense pass visit only those (`touch_of`).  Invariant: an UNSET bit means the line is all zero.  Stale SET bits are
+harmless (the line is read and found zero), so the bitmap is only ever cleared by a pass that has just re-zeroed the buffer.
+The bitmap is bound to the buffer's address and to its most recent backward: a gradient that autograd accumulated from two
+backward calls, or any tensor that is not the very buffer the last backward filled, gets no bitmap and the scanning kernels."""
 import weakref
 
 import torch
 
 _POOL = {}          # id(param) -> (weakref to param, buffer)
+_TOUCH = {}         # id(param) -> [data_ptr of the buffer, bitmap (int32 tensor), numel]
 enabled = True
+touch_enabled = True
 
 
 def key_of(t):
@@ -32,6 +41,7 @@ def give(param, buf):
     k = id(param)
     if k not in _POOL:
         weakref.finalize(param, _POOL.pop, k, None)
+        weakref.finalize(param, _TOUCH.pop, k, None)
     _POOL[k] = (weakref.ref(param), buf)
     return True
 
@@ -49,6 +59,31 @@ def take(key, shape, stride, device):
     return buf
 
 
+def touch_for_backward(key, buf, lib):
+    """the bitmap the backward of parameter `key` must mark while it scatters into `buf` (all zero on entry): the buffer's
+    own bitmap if it has one, else a fresh cleared one.  None when bitmaps are off or `key` is not poolable."""
+    if key is None or not (enabled and touch_enabled):
+        return None
+    ent = _TOUCH.get(key)
+    if ent is not None and ent[0] == buf.data_ptr() and ent[2] == buf.numel() and ent[1].device == buf.device:
+        return ent[1]
+    words = int(lib.ugrid_touch_words(buf.numel()))
+    t = torch.zeros(words, dtype=torch.int32, device=buf.device)
+    _TOUCH[key] = [buf.data_ptr(), t, buf.numel()]
+    return t
+
+
+def touch_of(param, g):
+    """the valid bitmap of gradient `g` of `param` (see the module docstring), or None"""
+    if not (enabled and touch_enabled) or g is None:
+        return None
+    ent = _TOUCH.get(id(param))
+    if ent is None or g is not param.grad or ent[0] != g.data_ptr() or ent[2] != g.numel() or g.stride() != param.stride():
+        return None
+    return ent[1]
+
+
 def clear():
+    _TOUCH.clear()
     for k, (ref, _) in list(_POOL.items()):
         _POOL[k] = (ref, None)

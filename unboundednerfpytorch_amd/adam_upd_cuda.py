@@ -29,10 +29,21 @@ def masked_adam_upd(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2, lr, ep
     _run(param, grad, exp_avg, exp_avg_sq, None, step, beta1, beta2, lr, eps, 1, "masked_adam_upd")
 
 
-def masked_adam_upd_rezero(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2, lr, eps):
+def masked_adam_upd_rezero(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2, lr, eps, touch=None):
     """NEW (not in the reference module): masked_adam_upd, and `grad` comes back all zero -- its nonzero elements are
-    overwritten after use, so the buffer can serve as the next backward's zero-initialised gradient (_gradpool.py)."""
-    _run(param, grad, exp_avg, exp_avg_sq, None, step, beta1, beta2, lr, eps, 3, "masked_adam_upd_rezero")
+    overwritten after use, so the buffer can serve as the next backward's zero-initialised gradient (_gradpool.py).
+    touch: the touched-line bitmap of `grad` (_gradpool.touch_of) -- only the marked lines are visited, and the bitmap comes
+    back cleared."""
+    if touch is None:
+        _run(param, grad, exp_avg, exp_avg_sq, None, step, beta1, beta2, lr, eps, 3, "masked_adam_upd_rezero")
+        return
+    named = [("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq)]
+    _lib.require_cuda_grid(*named) if param.dim() == 5 else _lib.require_cuda(*named)
+    _lib.require_f32(*named)
+    with _lib.guard(param.device):
+        _lib.check(_L.ugrid_masked_adam_upd_touch(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
+                                                  param.numel(), int(step), float(beta1), float(beta2), float(lr), float(eps),
+                                                  _lib.ptr(touch), _lib.stream_of(param)), "masked_adam_upd_touch")
 
 
 def adam_upd_with_perlr(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps):
@@ -40,7 +51,7 @@ def adam_upd_with_perlr(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, be
 
 
 def tv_adam_dense(param, param_out, grad, exp_avg, exp_avg_sq, wx, wy, wz, step, beta1, beta2, lr, eps, skip_zero_grad,
-                  rezero_grad=False):
+                  rezero_grad=False, touch=None):
     """NEW (not in the reference module): dense total_variation_add_grad + (masked_)adam_upd of one grid parameter
     [.., X, Y, Z] in a single pass (include/ugrid_hip.h: ugrid_tv_adam_dense).  The updated parameter lands in
     `param_out`; `grad` is left untouched, or -- rezero_grad=True -- comes back all zero (its nonzero elements are
@@ -51,6 +62,16 @@ def tv_adam_dense(param, param_out, grad, exp_avg, exp_avg_sq, wx, wy, wz, step,
     _lib.require_f32(*named)
     sz_i, sz_j, sz_k = param.shape[-3:]
     flags = int(bool(skip_zero_grad)) | (2 if rezero_grad else 0)
+    if cl and touch is not None:       # gradient lines the backward did not mark are known zeros: not read
+        with _lib.guard(param.device):
+            rc = _L.ugrid_tv_adam_dense_cl_touch(_lib.ptr(param), _lib.ptr(param_out), _lib.ptr(grad), _lib.ptr(exp_avg),
+                                                 _lib.ptr(exp_avg_sq), float(wx), float(wy), float(wz), sz_i, sz_j, sz_k, param.shape[1],
+                                                 param.numel(), int(step), float(beta1), float(beta2), float(lr), float(eps), flags,
+                                                 _lib.ptr(touch), _lib.stream_of(param))
+        if rc == 801:
+            return False
+        _lib.check(rc, "tv_adam_dense (touch)")
+        return True
     if cl:
         with _lib.guard(param.device):
             rc = _L.ugrid_tv_adam_dense_cl(_lib.ptr(param), _lib.ptr(param_out), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),

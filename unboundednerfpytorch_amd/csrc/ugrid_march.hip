@@ -177,11 +177,15 @@ __global__ void k_grid_query(const float *__restrict__ grid, int P, int C, int X
 // hardware fp32 atomics (global_atomic_add_f32).  Like torch's grid_sample backward the accumulation order is
 // not fixed, so sums agree to rounding, not bit for bit.  Canonical layout: the C atomics of a corner land in C
 // different planes (32 MB apart at G = 200) -- every atomic its own 128-byte line; channel-last: one 4C-byte run.
+// `touch` (channel-last only, may be null): one bit per 256-byte line (64 floats) of grad_grid, set for every line this
+// launch adds to -- the masked TV / Adam passes then visit only those lines instead of scanning the whole gradient for
+// non-zeros (ugrid_touch_words; the marking happens before the lane's own zero test, so that a record any channel of which
+// receives a gradient is always marked).
 template <bool CL>
 __global__ void k_grid_query_backward(const float *__restrict__ grad_out, int P, int C, int X, int Y, int Z,
                                       const float *__restrict__ xyz, const float *__restrict__ xyz_min,
                                       const float *__restrict__ xyz_max, int F, int64_t n,
-                                      float *__restrict__ grad_grid) {
+                                      float *__restrict__ grad_grid, uint32_t *__restrict__ touch) {
   // canonical layout: one lane per (point, level), channels in a loop (each channel is its own volume).
   // channel-last layout: one lane per (point, level, channel), channel fastest -- the C lanes of one (point, level) hit
   // C consecutive floats of one voxel record, so each atomic instruction touches ~64/C records instead of 64 lines.
@@ -199,6 +203,21 @@ __global__ void k_grid_query_backward(const float *__restrict__ grad_out, int P,
   const ug_taps t = ug_tap_setup(X, Y, Z, cx, cy, cz);
   const int64_t vol = (int64_t)X * Y * Z;
   if (CL) {
+    if (touch) {
+      // the two z-neighbours of a corner pair are adjacent records: one run of <= 2C floats, marked by one lane
+      const int64_t e0 = (int64_t)l * vol * C;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if ((C >= 4 ? k : 0) != chl) continue;          // pair k is lane k's (a record with < 4 channels: all lane 0's)
+        const int64_t lo = t.off[2 * k] >= 0 ? t.off[2 * k] : t.off[2 * k + 1];
+        const int64_t hi = t.off[2 * k + 1] >= 0 ? t.off[2 * k + 1] : t.off[2 * k];
+        if (lo < 0) continue;
+        for (int64_t line = (e0 + lo * C) >> 6; line <= (e0 + hi * C + C - 1) >> 6; ++line) {
+          const uint32_t bit = 1u << (line & 31);
+          if (!(touch[line >> 5] & bit)) atomicOr(touch + (line >> 5), bit);
+        }
+      }
+    }
     float g = grad_out[p * C + chl];
     if (F > 0) g = g / (float)P;
     if (g == 0.f) return;     // exact zeros stay exact zeros in the grid gradient (MaskedAdam keys on them)
@@ -433,15 +452,15 @@ extern "C" int ugrid_grid_query_cl(const float *grid, int P, int C, int X, int Y
 
 static int ug_grid_query_backward_any(bool cl, const float *grad_out, int P, int C, int X, int Y, int Z, const float *xyz,
                                       const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
-                                      float *grad_grid, hipStream_t st) {
+                                      float *grad_grid, hipStream_t st, uint32_t *touch = nullptr) {
   if (n <= 0) return 0;
   if (P != (freq_num > 0 ? 2 * freq_num + 1 : 1)) return (int)hipErrorInvalidValue;
   if (cl)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query_backward<true>), dim3(ug_blocks(n * P * C, 256)), dim3(256), 0, st, grad_out, P, C,
-                       X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid);
+                       X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid, touch);
   else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query_backward<false>), dim3(ug_blocks(n * P, 256)), dim3(256), 0, st, grad_out, P, C,
-                       X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid);
+                       X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid, (uint32_t *)nullptr);
   UG_LAUNCH_CHECK();
   return 0;
 }
@@ -456,6 +475,12 @@ extern "C" int ugrid_grid_query_backward_cl(const float *grad_out, int P, int C,
                                             const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
                                             float *grad_grid, ugrid_stream_t s) {
   return ug_grid_query_backward_any(true, grad_out, P, C, X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid, ST(s));
+}
+
+extern "C" int ugrid_grid_query_backward_cl_touch(const float *grad_out, int P, int C, int X, int Y, int Z, const float *xyz,
+                                                  const float *xyz_min, const float *xyz_max, int freq_num, int64_t n,
+                                                  float *grad_grid, uint32_t *touch, ugrid_stream_t s) {
+  return ug_grid_query_backward_any(true, grad_out, P, C, X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid, ST(s), touch);
 }
 
 static inline int ug_brick_ch(int C, int *H) {

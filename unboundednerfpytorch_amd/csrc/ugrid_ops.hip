@@ -436,6 +436,12 @@ __device__ __forceinline__ bool ug_line_any(bool mine) {
   return ((m >> (__lane_id() & ~7u)) & 0xFFull) != 0;
 }
 
+// touched-line bitmap of a recycled gradient buffer (k_grid_query_backward): float4 lane q belongs to the 256-byte line
+// q >> 4; null = no bitmap, every line counts as touched
+__device__ __forceinline__ bool ug_touched(const uint32_t *__restrict__ touch, unsigned q) {
+  return !touch || ((touch[q >> 9] >> ((q >> 4) & 31u)) & 1u);
+}
+
 template <int XCD>
 __device__ __forceinline__ unsigned ug_xcd_block() {
   unsigned b = blockIdx.x;
@@ -563,28 +569,61 @@ __device__ __forceinline__ void ug_adam_one(float &p, float g, float &m, float &
 
 // RZ (masked mode only): the gradient is overwritten with zeros after use, whole 128-byte lines at a time and only
 // those that held something -- the buffer goes back to the zero pool of the grid's backward (_gradpool.py)
+template <int MODE, bool RZ>
+__device__ __forceinline__ void ug_adam_vec4_one(float4 *__restrict__ param, const float4 *__restrict__ grad, float4 *__restrict__ exp_avg,
+                                                 float4 *__restrict__ exp_avg_sq, const float4 *__restrict__ perlr, int64_t i,
+                                                 float step_size, float beta1, float beta2, float eps) {
+  const float4 g = grad[i];
+  if (RZ && ug_line_any(g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f))
+    const_cast<float4 *>(grad)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (MODE == 1 && g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) return;
+  float4 p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
+  float4 l = make_float4(1.f, 1.f, 1.f, 1.f);
+  if (MODE == 2) l = perlr[i];
+  if (MODE != 1 || g.x != 0.f) ug_adam_one<MODE>(p.x, g.x, m.x, v.x, l.x, step_size, beta1, beta2, eps);
+  if (MODE != 1 || g.y != 0.f) ug_adam_one<MODE>(p.y, g.y, m.y, v.y, l.y, step_size, beta1, beta2, eps);
+  if (MODE != 1 || g.z != 0.f) ug_adam_one<MODE>(p.z, g.z, m.z, v.z, l.z, step_size, beta1, beta2, eps);
+  if (MODE != 1 || g.w != 0.f) ug_adam_one<MODE>(p.w, g.w, m.w, v.w, l.w, step_size, beta1, beta2, eps);
+  param[i] = p;
+  exp_avg[i] = m;
+  exp_avg_sq[i] = v;
+}
+
 template <int MODE, bool RZ = false>
 __global__ void __launch_bounds__(256)
 k_adam_vec4(float4 *__restrict__ param, const float4 *__restrict__ grad, float4 *__restrict__ exp_avg,
             float4 *__restrict__ exp_avg_sq, const float4 *__restrict__ perlr, int64_t n4,
             float step_size, float beta1, float beta2, float eps) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const float4 g = grad[i];
-    if (RZ && ug_line_any(g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f))
-      const_cast<float4 *>(grad)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (MODE == 1 && g.x == 0.f && g.y == 0.f && g.z == 0.f && g.w == 0.f) continue;
-    float4 p = param[i], m = exp_avg[i], v = exp_avg_sq[i];
-    float4 l = make_float4(1.f, 1.f, 1.f, 1.f);
-    if (MODE == 2) l = perlr[i];
-    if (MODE != 1 || g.x != 0.f) ug_adam_one<MODE>(p.x, g.x, m.x, v.x, l.x, step_size, beta1, beta2, eps);
-    if (MODE != 1 || g.y != 0.f) ug_adam_one<MODE>(p.y, g.y, m.y, v.y, l.y, step_size, beta1, beta2, eps);
-    if (MODE != 1 || g.z != 0.f) ug_adam_one<MODE>(p.z, g.z, m.z, v.z, l.z, step_size, beta1, beta2, eps);
-    if (MODE != 1 || g.w != 0.f) ug_adam_one<MODE>(p.w, g.w, m.w, v.w, l.w, step_size, beta1, beta2, eps);
-    param[i] = p;
-    exp_avg[i] = m;
-    exp_avg_sq[i] = v;
+       i += (int64_t)gridDim.x * blockDim.x)
+    ug_adam_vec4_one<MODE, RZ>(param, grad, exp_avg, exp_avg_sq, perlr, i, step_size, beta1, beta2, eps);
+}
+
+// Walk over the touched-line bitmap of a recycled gradient (k_grid_query_backward): one wave per 32-bit word = 32 lines of
+// 256 bytes; the word's set bits are dealt to the wave's four 16-lane quarters, so a word with <= 4 marked lines (the usual
+// case at a few per cent of lines marked) costs one round.  `q` handed to the body is the float4 index of the lane.
+#define UG_TOUCH_WALK(touch, n_words, n4, BODY)                                                                        \
+  {                                                                                                                    \
+    const int64_t word = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;                                        \
+    if (word >= (n_words)) return;                                                                                     \
+    const uint32_t mask = __builtin_amdgcn_readfirstlane((touch)[word]);                                               \
+    if (mask == 0u) return;                                                                                            \
+    const int cnt = __popc(mask), quarter = ug_lane() >> 4;                                                            \
+    for (int base = 0; base < cnt; base += 4) {                                                                        \
+      const int k = base + quarter;                                                                                    \
+      uint32_t m = mask;                                                                                               \
+      for (int i = 0; i < k; ++i) m &= m - 1u;                                                                         \
+      const int64_t q = ((word << 5) + (int64_t)(__ffs(m) - 1)) * 16 + (ug_lane() & 15);                               \
+      if (k < cnt && q < (int64_t)(n4)) { BODY }                                                                       \
+    }                                                                                                                  \
   }
+
+// masked Adam on the marked lines only; the gradient comes back all zero (RZ)
+__global__ void __launch_bounds__(256)
+k_adam_vec4_touch(float4 *__restrict__ param, const float4 *__restrict__ grad, float4 *__restrict__ exp_avg,
+                  float4 *__restrict__ exp_avg_sq, int64_t n4, float step_size, float beta1, float beta2, float eps,
+                  const uint32_t *__restrict__ touch, int64_t n_words) {
+  UG_TOUCH_WALK(touch, n_words, n4, (ug_adam_vec4_one<1, true>(param, grad, exp_avg, exp_avg_sq, nullptr, q, step_size, beta1, beta2, eps));)
 }
 
 template <int MODE, bool RZ = false>
@@ -732,15 +771,15 @@ __global__ void k_rays_of_a_view(ug_cam c, const float *__restrict__ c2w, const 
 // equal the canonical-layout results element for element.  ADAM: 0 = TV only (grad updated in place), 1 = fused with
 // masked Adam, 2 = fused with dense Adam (param_out written, grad untouched).
 // ----------------------------------------------------------------------------------------------
-template <bool DENSE, int ADAM, int XCD = 0>
-__global__ void __launch_bounds__(256)
-k_tv_cl_vec4(const float *__restrict__ param, float *__restrict__ param_out, float *__restrict__ grad,
-             float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, float wy, float wz, int sz_i, int sz_j,
-             int sz_k, int C, unsigned n4, float step_size, float beta1, float beta2, float eps, int rezero) {
-  const unsigned q = ug_xcd_block<XCD>() * blockDim.x + threadIdx.x;
-  if (q >= n4) return;
+template <bool DENSE, int ADAM, int XCD>
+__device__ __forceinline__ void ug_tv_cl_one(const float *__restrict__ param, float *__restrict__ param_out, float *__restrict__ grad,
+                                             float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, float wy, float wz, int sz_i,
+                                             int sz_j, int sz_k, int C, unsigned q, float step_size, float beta1, float beta2, float eps,
+                                             int rezero, bool hit) {
   const unsigned idx = q * 4u;
-  const float4 g0 = ug_ld4<XCD == 2>(grad + idx);
+  // hit = false: an unmarked line of a recycled gradient is all zero and is not read (dense mode only; the masked mode
+  // does not come here for such a line)
+  const float4 g0 = hit ? ug_ld4<XCD == 2>(grad + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
   if (!DENSE && g0.x == 0.f && g0.y == 0.f && g0.z == 0.f && g0.w == 0.f) return;
   const unsigned c4 = (unsigned)C >> 2;
   const unsigned vox = q / c4;                                  // (plane * sz_i + i) * sz_j * sz_k + j * sz_k + k
@@ -786,10 +825,30 @@ k_tv_cl_vec4(const float *__restrict__ param, float *__restrict__ param_out, flo
     ug_st4<XCD == 2>(exp_avg + idx, mv[0], mv[1], mv[2], mv[3]);
     ug_st4<XCD == 2>(exp_avg_sq + idx, vv[0], vv[1], vv[2], vv[3]);
     if (rezero && ug_line_any(g0.x != 0.f || g0.y != 0.f || g0.z != 0.f || g0.w != 0.f))
-      *(float4 *)(grad + idx) = make_float4(0.f, 0.f, 0.f, 0.f);
+      *(float4 *)(grad + idx) = make_float4(0.f, 0.f, 0.f, 0.f);     // (a 128-byte line lies inside one 256-byte bitmap line)
   } else {
     *(float4 *)(grad + idx) = make_float4(out[0], out[1], out[2], out[3]);
   }
+}
+
+template <bool DENSE, int ADAM, int XCD = 0>
+__global__ void __launch_bounds__(256)
+k_tv_cl_vec4(const float *__restrict__ param, float *__restrict__ param_out, float *__restrict__ grad,
+             float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, float wy, float wz, int sz_i, int sz_j,
+             int sz_k, int C, unsigned n4, float step_size, float beta1, float beta2, float eps, int rezero,
+             const uint32_t *__restrict__ touch) {
+  const unsigned q = ug_xcd_block<XCD>() * blockDim.x + threadIdx.x;
+  if (q >= n4) return;
+  ug_tv_cl_one<DENSE, ADAM, XCD>(param, param_out, grad, exp_avg, exp_avg_sq, wy, wz, sz_i, sz_j, sz_k, C, q, step_size, beta1, beta2,
+                                 eps, rezero, ug_touched(touch, q));
+}
+
+// masked TV gradient on the marked lines of a recycled gradient (UG_TOUCH_WALK)
+__global__ void __launch_bounds__(256)
+k_tv_cl_touch(const float *__restrict__ param, float *__restrict__ grad, float wy, float wz, int sz_i, int sz_j, int sz_k, int C,
+              unsigned n4, const uint32_t *__restrict__ touch, int64_t n_words) {
+  UG_TOUCH_WALK(touch, n_words, n4, (ug_tv_cl_one<false, 0, 0>(param, nullptr, grad, nullptr, nullptr, wy, wz, sz_i, sz_j, sz_k, C,
+                                                               (unsigned)q, 0.f, 0.f, 0.f, 0.f, 0, true));)
 }
 
 static int g_tv_xcd = 2;   // ugrid_tune("tv_xcd", 0|1|2): dense TV (+ Adam) kernels: linear block order | XCD-contiguous | + non-temporal streams
@@ -990,9 +1049,26 @@ extern "C" int ugrid_segment_cumsum(const float *w, const float *s_, const int64
 }
 
 // channel-last total_variation_add_grad: param / grad are [planes][sz_i][sz_j][sz_k][C] (C % 4 == 0, N < 2^31, 16-byte aligned)
+static int ug_tv_cl(const float *param, float *grad, float wx, float wy, float wz, int dense_mode, int64_t sz_i, int64_t sz_j,
+                    int64_t sz_k, int64_t C, int64_t N, const uint32_t *touch, ugrid_stream_t s);
+
 extern "C" int ugrid_total_variation_add_grad_cl(const float *param, float *grad, float wx, float wy, float wz, int dense_mode,
                                                  int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t C, int64_t N,
                                                  ugrid_stream_t s) {
+  return ug_tv_cl(param, grad, wx, wy, wz, dense_mode, sz_i, sz_j, sz_k, C, N, nullptr, s);
+}
+
+// masked mode with the touched-line bitmap of the gradient (ugrid_grid_query_backward_cl_touch): only marked lines are read
+extern "C" int ugrid_total_variation_add_grad_cl_touch(const float *param, float *grad, float wx, float wy, float wz,
+                                                       int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t C, int64_t N,
+                                                       const uint32_t *touch, ugrid_stream_t s) {
+  return ug_tv_cl(param, grad, wx, wy, wz, 0, sz_i, sz_j, sz_k, C, N, touch, s);
+}
+
+extern "C" int64_t ugrid_touch_words(int64_t N) { return ((N + 63) / 64 + 31) / 32; }
+
+static int ug_tv_cl(const float *param, float *grad, float wx, float wy, float wz, int dense_mode, int64_t sz_i, int64_t sz_j,
+                    int64_t sz_k, int64_t C, int64_t N, const uint32_t *touch, ugrid_stream_t s) {
   if (N <= 0) return 0;
   (void)wx;
   if (C % 4 != 0 || N >= ((int64_t)1 << 31) || ((((uintptr_t)param) | ((uintptr_t)grad)) & 15) != 0)
@@ -1002,21 +1078,46 @@ extern "C" int ugrid_total_variation_add_grad_cl(const float *param, float *grad
   const unsigned n4 = (unsigned)(N / 4);
   if (dense_mode && g_tv_xcd)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 0, 1>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, nullptr, grad,
-                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f, 0);
+                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f, 0, (const uint32_t *)nullptr);
   else if (dense_mode)
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 0>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, nullptr, grad,
-                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f, 0);
-  else
+                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f, 0, (const uint32_t *)nullptr);
+  else if (touch) {
+    const int64_t n_words = ugrid_touch_words(N);
+    hipLaunchKernelGGL(k_tv_cl_touch, dim3(ug_blocks(n_words * UG_WAVE, 256)), dim3(256), 0, ST(s), param, grad, wy, wz, (int)sz_i,
+                       (int)sz_j, (int)sz_k, (int)C, n4, touch, n_words);
+  } else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<false, 0>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, nullptr, grad,
-                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f, 0);
+                       nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f, 0, (const uint32_t *)nullptr);
   UG_LAUNCH_CHECK();
   return 0;
 }
+
+static int ug_tv_adam_dense_cl(const float *param, float *param_out, const float *grad, float *exp_avg, float *exp_avg_sq,
+                               float wx, float wy, float wz, int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t C, int64_t N, int step,
+                               float beta1, float beta2, float lr, float eps, int flags, uint32_t *touch, ugrid_stream_t s);
 
 extern "C" int ugrid_tv_adam_dense_cl(const float *param, float *param_out, const float *grad, float *exp_avg,
                                       float *exp_avg_sq, float wx, float wy, float wz, int64_t sz_i, int64_t sz_j,
                                       int64_t sz_k, int64_t C, int64_t N, int step, float beta1, float beta2, float lr,
                                       float eps, int flags, ugrid_stream_t s) {
+  return ug_tv_adam_dense_cl(param, param_out, grad, exp_avg, exp_avg_sq, wx, wy, wz, sz_i, sz_j, sz_k, C, N, step, beta1, beta2, lr,
+                             eps, flags, nullptr, s);
+}
+
+// + the touched-line bitmap of the gradient: lines not marked are known to be zero and are not read; with the rezero flag
+// the bitmap is cleared after the pass (the gradient is all zero again)
+extern "C" int ugrid_tv_adam_dense_cl_touch(const float *param, float *param_out, const float *grad, float *exp_avg,
+                                            float *exp_avg_sq, float wx, float wy, float wz, int64_t sz_i, int64_t sz_j,
+                                            int64_t sz_k, int64_t C, int64_t N, int step, float beta1, float beta2, float lr,
+                                            float eps, int flags, uint32_t *touch, ugrid_stream_t s) {
+  return ug_tv_adam_dense_cl(param, param_out, grad, exp_avg, exp_avg_sq, wx, wy, wz, sz_i, sz_j, sz_k, C, N, step, beta1, beta2, lr,
+                             eps, flags, touch, s);
+}
+
+static int ug_tv_adam_dense_cl(const float *param, float *param_out, const float *grad, float *exp_avg, float *exp_avg_sq,
+                               float wx, float wy, float wz, int64_t sz_i, int64_t sz_j, int64_t sz_k, int64_t C, int64_t N, int step,
+                               float beta1, float beta2, float lr, float eps, int flags, uint32_t *touch, ugrid_stream_t s) {
   if (N <= 0) return 0;
   const int skip_zero_grad = flags & 1, rezero = (flags >> 1) & 1;
   (void)wx;
@@ -1028,7 +1129,7 @@ extern "C" int ugrid_tv_adam_dense_cl(const float *param, float *param_out, cons
   const unsigned n4 = (unsigned)(N / 4);
   float *g = const_cast<float *>(grad);   // ADAM != 0 never writes the gradient
   const dim3 gr((n4 + 255) / 256), bl(256);
-#define UG_TV_CL_ARGS param, param_out, g, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, step_size, beta1, beta2, eps, rezero
+#define UG_TV_CL_ARGS param, param_out, g, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, step_size, beta1, beta2, eps, rezero, (const uint32_t *)touch
   if (g_tv_xcd == 2) {
     if (skip_zero_grad) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 1, 2>), gr, bl, 0, ST(s), UG_TV_CL_ARGS);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 2, 2>), gr, bl, 0, ST(s), UG_TV_CL_ARGS);
@@ -1041,6 +1142,7 @@ extern "C" int ugrid_tv_adam_dense_cl(const float *param, float *param_out, cons
   }
 #undef UG_TV_CL_ARGS
   UG_LAUNCH_CHECK();
+  if (touch && rezero) UG_HIP(hipMemsetAsync(touch, 0, sizeof(uint32_t) * (size_t)ugrid_touch_words(N), ST(s)));
   return 0;
 }
 
@@ -1086,6 +1188,27 @@ extern "C" int ugrid_tv_adam_dense(const float *param, float *param_out, const f
   }
 #undef UG_TV_ARGS
   UG_LAUNCH_CHECK();
+  return 0;
+}
+
+// masked_adam_upd with the touched-line bitmap of a recycled gradient buffer: only marked lines are visited; the gradient
+// comes back all zero and the bitmap cleared (mode 3 of ugrid_adam_upd restricted to the marked lines)
+extern "C" int ugrid_masked_adam_upd_touch(float *param, float *grad, float *exp_avg, float *exp_avg_sq, int64_t N, int step,
+                                           float beta1, float beta2, float lr, float eps, uint32_t *touch, ugrid_stream_t s) {
+  if (N <= 0) return 0;
+  if (!touch) return (int)hipErrorInvalidValue;
+  const float step_size = lr * sqrtf(1 - powf(beta2, (float)step)) / (1 - powf(beta1, (float)step));
+  const uintptr_t al = (uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq;
+  if ((al & 15) != 0) return (int)hipErrorNotSupported;
+  const int64_t n4 = N / 4, n_words = ugrid_touch_words(N);
+  if (n4 > 0)
+    hipLaunchKernelGGL(k_adam_vec4_touch, dim3(ug_blocks(n_words * UG_WAVE, 256)), dim3(256), 0, ST(s), (float4 *)param,
+                       (const float4 *)grad, (float4 *)exp_avg, (float4 *)exp_avg_sq, n4, step_size, beta1, beta2, eps, touch, n_words);
+  if (n4 * 4 < N)      // the last 1-3 elements, whatever their line says
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_adam_scalar<1, true>), dim3(1), dim3(256), 0, ST(s), param, grad, exp_avg, exp_avg_sq,
+                       (const float *)nullptr, n4 * 4, N, step_size, beta1, beta2, eps);
+  UG_LAUNCH_CHECK();
+  UG_HIP(hipMemsetAsync(touch, 0, sizeof(uint32_t) * (size_t)n_words, ST(s)));
   return 0;
 }
 

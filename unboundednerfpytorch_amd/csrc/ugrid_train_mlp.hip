@@ -1,0 +1,358 @@
+// The rgbnet of the TRAINING step (FourierGrid_model.py:233-241, :636: nn.Linear(mlp_in, 128) - ReLU - nn.Linear(128, 128) -
+// ReLU - nn.Linear(128, 3) on the step's M ~ 1e5 surviving samples) as hand-written fp32-MFMA kernels.
+//
+// Why: at M = 84k the three layers are 3.6 GFLOP forward and 7.3 backward -- ~70 us of matrix-pipe time -- but through
+// torch.addmm / mm / bmm (rocBLAS, hipBLASLt) the 13 library GEMMs and the elementwise kernels between them leave the GPU
+// idle for 50-150 us of host time EACH: 1.46 ms of a 4.4 ms step (profiles/r03/train_step_timeline_*.txt).  Three kernel
+// shapes cover the network and its derivative; everything is fp32 (v_mfma_f32_32x32x2_f32: exact fp32 products, fp32
+// accumulation -- the arithmetic class of the library SGEMMs, another summation order).
+//
+//   k_lin    Y[s][c] = act( sum_k X[s][k] * Wm[c][k] + b[c] ) [* (G[s][c] > 0)]         one wave = 32 samples x NT*32 outputs
+//            D[m = s][n = c] = sum_k A[m][k] B[k][n]:  A = the lane's own sample row (registers), B = weights from LDS (k-major
+//            image, lanes read consecutive floats).  The MFMA's two k-slots are lane halves (lane >> 5):
+//            half h owns the k-range [h * kh, (h + 1) * kh), kh = ceil(K / 2) -- a reordering of the reduction that lets a lane
+//            stream ONE contiguous piece of its row instead of every other element.
+//            Serves the three forward layers (w_in_major = 0: Wm = weight [out][in]) and the two input-gradient products
+//            dX = dY . W (w_in_major = 1: the same weight array read as [in][out], no transpose needed), the latter with the
+//            ReLU mask of the layer below folded into the store.
+//   k_wgrad  dW[c][k] += sum_s dY[s][c] * X[s][k],  db[c] += sum_s dY[s][c]              one wave = 256 samples x 32 c x all k
+//            D[m = c][n = k] with the SAMPLES as the reduction: both operands are read in their natural row-major layout
+//            (lanes = consecutive features: coalesced); <= 256 slab partials, added in a fixed order by k_wgrad_reduce
+//            (deterministic).  Replaces the library GEMM with a 128 x 128 result and an M-long reduction that runs on 16
+//            workgroups (185-225 us at M = 84k; ops.SplitKLinear cut it into a batched GEMM + a sum).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ugrid_common.h"
+#include "ugrid_hip.h"
+
+#define ST(s) ((hipStream_t)(s))
+
+typedef float mlp_f32x16 __attribute__((ext_vector_type(16)));
+
+// v_mfma_f32_32x32x2_f32 operand / result mapping (lane l, h = l >> 5):
+//   a: A[m = l & 31][k = h]     b: B[k = h][n = l & 31]     d[i]: D[m = 8 * (i >> 2) + 4 * h + (i & 3)][n = l & 31]
+// (operand mapping pinned by tests/test_gpu_ops.py::test_fused_rgbnet_matches_torch_linear_layers)
+
+// KH: k-steps = elements of the lane's half row (compile time; the weight image is zero padded to 2 * KH rows); NT: 32-wide
+// output tiles (outputs = NT * 32, padded); VEC: the half rows are read as 16-byte loads (K = 2 * KH, aligned rows)
+#ifndef UG_LIN_THREADS
+#define UG_LIN_THREADS 1024
+#endif
+template <int KH, int NT, bool VEC>
+__global__ void __launch_bounds__(UG_LIN_THREADS)
+k_lin(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__restrict__ W, int ldw, int n_out, int w_in_major,
+      const float *__restrict__ bias, int relu, const float *__restrict__ G, int ldg, float *__restrict__ Y, int ldy) {
+  extern __shared__ float lds[];                  // weight image Ws[k][c], rows of NP + 1 floats (zero padded)
+  constexpr int NP = NT * 32, NPP = NP + 1, K2 = 2 * KH;
+  static_assert(KH % 4 == 0, "k-steps come in rounds of four");
+  // coalesced reads of the weight array in ITS order; the odd row pitch keeps the transposing writes off one LDS bank.  All of
+  // a thread's elements are fetched before the first is stored (one round trip to L2, not one per element).
+  {
+    constexpr int N_EL = K2 * NP, ITER = (N_EL + UG_LIN_THREADS - 1) / UG_LIN_THREADS;
+    float v[ITER];
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int e = threadIdx.x + i * UG_LIN_THREADS;
+      int k, c;
+      if (w_in_major) { k = e / NP; c = e - k * NP; } else { c = e / K2; k = e - c * K2; }
+      v[i] = (e < N_EL && k < K && c < n_out) ? (w_in_major ? W[(int64_t)k * ldw + c] : W[(int64_t)c * ldw + k]) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+      const int e = threadIdx.x + i * UG_LIN_THREADS;
+      int k, c;
+      if (w_in_major) { k = e / NP; c = e - k * NP; } else { c = e / K2; k = e - c * K2; }
+      if (e < N_EL) lds[k * NPP + c] = v[i];
+    }
+  }
+  __syncthreads();
+  const int lane = ug_lane(), h = lane >> 5, col = lane & 31;
+  const int64_t n_tiles = (M + 31) >> 5;
+  constexpr int WAVES = UG_LIN_THREADS / 64;
+  const float *__restrict__ wl = lds + (h * KH) * NPP + col;
+  for (int64_t tile = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6); tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
+    const int64_t s = tile * 32 + col;
+    const bool row_ok = s < M;
+    const float *__restrict__ xr = X + (row_ok ? s : 0) * ldx + h * KH;
+    const int k_base = h * KH;
+    auto load4 = [&](int j0) -> float4 {           // elements j0 .. j0 + 3 of the lane's half row
+#if defined(UG_LIN_DBG) && UG_LIN_DBG == 2
+      return make_float4(1.f, 0.5f, 0.25f, (float)j0);
+#endif
+      if (VEC) return row_ok ? *(const float4 *)(xr + j0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 v;
+      v.x = (row_ok && k_base + j0 + 0 < K) ? xr[j0 + 0] : 0.f;
+      v.y = (row_ok && k_base + j0 + 1 < K) ? xr[j0 + 1] : 0.f;
+      v.z = (row_ok && k_base + j0 + 2 < K) ? xr[j0 + 2] : 0.f;
+      v.w = (row_ok && k_base + j0 + 3 < K) ? xr[j0 + 3] : 0.f;
+      return v;
+    };
+    mlp_f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    // D[m = sample][n = output]: the sample rows are the A operand, so that a store instruction writes two runs of 32
+    // consecutive outputs (one per lane half).  Four k-steps per round: their 4 * NT weights come from LDS first, the next
+    // four row elements are already on their way.
+    float4 xv = load4(0), xn = load4(4 < KH ? 4 : 0);
+#pragma unroll 1
+    for (int j0 = 0; j0 < KH; j0 += 4) {
+      const float4 xnn = load4(j0 + 8 < KH ? j0 + 8 : j0);      // two rounds ahead
+      float w[4][NT];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[jj][t] = wl[(j0 + jj) * NPP + 32 * t];
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#if defined(UG_LIN_DBG) && UG_LIN_DBG == 1
+          acc[t][jj] += xs[jj] * w[jj][t];
+#else
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[jj], w[jj][t], acc[t], 0, 0, 0);
+#endif
+        }
+      xv = xn;
+      xn = xnn;
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int c = 32 * t + col;
+      if (c >= n_out) continue;
+      const float bc = bias ? bias[c] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t sr = tile * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+        if (sr >= M) continue;
+        float r = acc[t][i];
+        if (bias) r = r + bc;
+        if (relu) r = fmaxf(r, 0.f);
+        if (G && !(G[sr * ldg + c] > 0.f)) r = 0.f;
+#if defined(UG_LIN_DBG) && UG_LIN_DBG == 3
+        if (r == 123.456f)
+#endif
+        Y[sr * ldy + c] = r;
+      }
+    }
+  }
+}
+
+// one wave: 32 output rows (features c of dY) x NT*32 columns (features k of X) over the sample chunks of its SLAB (chunk =
+// UG_WG_CHUNK samples; slab b owns chunks b, b + n_slabs, ...); the operands of UG_WG_BATCH reduction steps are fetched before
+// their MFMAs are issued.  The slab's tile goes to partial[slab] and k_wgrad_reduce adds the slabs in a fixed order: the
+// weight gradient is deterministic (two runs give the same bits), unlike a sum of atomics.
+#define UG_WG_CHUNK 128
+#define UG_WG_BATCH 8
+#define UG_WG_MAX_SLABS 256
+template <int NT>
+__global__ void __launch_bounds__(256)
+k_wgrad(const float *__restrict__ dY, int ldd, int n_out, const float *__restrict__ X, int ldx, int K, int64_t M,
+        float *__restrict__ partial_w, float *__restrict__ partial_b, int mt_count, int n_slabs) {
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int mt = (int)(wave % mt_count);
+  const int slab = (int)(wave / mt_count);
+  if (slab >= n_slabs) return;
+  const int lane = ug_lane(), h = lane >> 5, col = lane & 31;
+  const int c = 32 * mt + col;
+  const bool c_ok = c < n_out;
+  mlp_f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float bsum = 0.f;
+  bool k_ok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) k_ok[t] = 32 * t + col < K;
+  for (int64_t s0 = (int64_t)slab * UG_WG_CHUNK; s0 < M; s0 += (int64_t)n_slabs * UG_WG_CHUNK) {
+    const int64_t s1 = (s0 + UG_WG_CHUNK < M) ? s0 + UG_WG_CHUNK : M;
+    for (int64_t sb = s0; sb < s1; sb += 2 * UG_WG_BATCH) {      // rows >= s1 contribute zeros
+      float a[UG_WG_BATCH], b[UG_WG_BATCH][NT];
+#pragma unroll
+      for (int u = 0; u < UG_WG_BATCH; ++u) {
+        const int64_t s = sb + 2 * u + h;
+        const bool on = s < s1;
+        a[u] = (on && c_ok) ? dY[s * ldd + c] : 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[u][t] = (on && k_ok[t]) ? X[s * ldx + 32 * t + col] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UG_WG_BATCH; ++u) {
+        bsum += a[u];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][t], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // D[m = 8 g + 4 h + e][n = col]: row = output feature, column = input feature
+  float *__restrict__ pw = partial_w + (int64_t)slab * n_out * K;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int k = 32 * t + col;
+    if (k >= K) continue;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int cc = 32 * mt + 8 * (i >> 2) + 4 * h + (i & 3);
+      if (cc < n_out) pw[(int64_t)cc * K + k] = acc[t][i];
+    }
+  }
+  if (partial_b) {
+    bsum += __shfl_xor(bsum, 32, UG_WAVE);
+    if (h == 0 && c_ok) partial_b[(int64_t)slab * n_out + c] = bsum;
+  }
+}
+
+// out[e] = sum over slabs (ascending) of partial[slab][e]; 16 slabs are fetched per round (independent loads), then added
+// in order -- a fixed summation order, not a serial chain of load latencies
+__global__ void __launch_bounds__(64)
+k_wgrad_reduce(const float *__restrict__ partial, int n_slabs, int n, float *__restrict__ out) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float acc = 0.f;
+  for (int b0 = 0; b0 < n_slabs; b0 += 16) {
+    float v[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) v[u] = (b0 + u < n_slabs) ? partial[(int64_t)(b0 + u) * n + e] : 0.f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc += v[u];
+  }
+  out[e] = acc;
+}
+
+// Y[s][c] = (G[s][c] > 0) ? sum_{j < K} X[s][j] * W[j][c] : 0 for K <= 4 (the gradient of the 3-channel logits pushed through the
+// last layer): three FMAs per element, one float4 of outputs per lane -- no matrix pipe needed
+__global__ void __launch_bounds__(256)
+k_lin_smallk(const float *__restrict__ X, int64_t M, int K, const float *__restrict__ W, int n_out, const float *__restrict__ G,
+             float *__restrict__ Y) {
+  const int q4 = n_out >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * q4) return;
+  const int64_t s = idx / q4;
+  const int c = (int)(idx - s * q4) * 4;
+  float r[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < K; ++j) {
+    const float x = X[s * K + j];
+    const float4 w = *(const float4 *)(W + (int64_t)j * n_out + c);
+    r[0] += x * w.x; r[1] += x * w.y; r[2] += x * w.z; r[3] += x * w.w;
+  }
+  if (G) {
+    const float4 g = *(const float4 *)(G + s * n_out + c);
+    if (!(g.x > 0.f)) r[0] = 0.f;
+    if (!(g.y > 0.f)) r[1] = 0.f;
+    if (!(g.z > 0.f)) r[2] = 0.f;
+    if (!(g.w > 0.f)) r[3] = 0.f;
+  }
+  *(float4 *)(Y + s * n_out + c) = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+static inline int ug_lin_launch(const float *X, int64_t M, int K, int ldx, const float *W, int ldw, int n_out, int w_in_major, const float *bias,
+                                int relu, const float *G, int ldg, float *Y, int ldy, hipStream_t st) {
+  if (M <= 0) return 0;
+  if (K < 1 || K > 128 || n_out < 1 || n_out > 128) return (int)hipErrorNotSupported;
+  const int kh = (K + 1) / 2, nt = n_out <= 32 ? 1 : 4;
+  const int64_t tiles = (M + 31) / 32;
+  constexpr int WAVES = UG_LIN_THREADS / 64;
+  int64_t wgs = (tiles + WAVES - 1) / WAVES;
+  if (wgs > 256) wgs = 256;                        // one persistent 16-wave workgroup per CU: the weights are staged once
+#define UG_LIN_GO(KH, NT_, VEC_)                                                                                                 \
+  {                                                                                                                              \
+    constexpr int lds = 2 * KH * (NT_ * 32 + 1) * 4;                                                                             \
+    static bool attr_set = false;                                                                                                \
+    if (!attr_set) {                                                                                                             \
+      UG_HIP(hipFuncSetAttribute((const void *)k_lin<KH, NT_, VEC_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));          \
+      attr_set = true;                                                                                                           \
+    }                                                                                                                            \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lin<KH, NT_, VEC_>), dim3((unsigned)wgs), dim3(UG_LIN_THREADS), lds, st, X, M, K, ldx, W, ldw, \
+                       n_out, w_in_major, bias, relu, G, ldg, Y, ldy);                                                           \
+  }
+  const bool vec = K == 128 && (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0;
+  if (K <= 4 && w_in_major && !bias && !relu && ldx == K && ldw == n_out && ldy == n_out && (!G || ldg == n_out) && (n_out & 3) == 0 &&
+      ((((uintptr_t)W) | ((uintptr_t)Y) | ((uintptr_t)G)) & 15) == 0) {
+    hipLaunchKernelGGL(k_lin_smallk, dim3((unsigned)((M * (n_out >> 2) + 255) / 256)), dim3(256), 0, st, X, M, K, W, n_out, G, Y);
+    UG_LAUNCH_CHECK();
+    return 0;
+  }
+  if (nt == 4) {
+    if (kh <= 12) UG_LIN_GO(12, 4, false)
+    else if (kh <= 20) UG_LIN_GO(20, 4, false)
+    else if (kh <= 24) UG_LIN_GO(24, 4, false)
+    else if (kh <= 32) UG_LIN_GO(32, 4, false)
+    else if (vec) UG_LIN_GO(64, 4, true)
+    else UG_LIN_GO(64, 4, false)
+  } else {
+    if (kh <= 32) UG_LIN_GO(32, 1, false)
+    else if (vec) UG_LIN_GO(64, 1, true)
+    else UG_LIN_GO(64, 1, false)
+  }
+#undef UG_LIN_GO
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+// partial: UG_WG_MAX_SLABS * (n_out * K + n_out) floats of scratch
+static inline int ug_wgrad_launch(const float *dY, int ldd, int n_out, const float *X, int ldx, int K, int64_t M, float *dW, float *db,
+                                  float *partial, hipStream_t st) {
+  if (K < 1 || K > 128 || n_out < 1 || n_out > 128) return (int)hipErrorNotSupported;
+  if (M <= 0) {
+    UG_HIP(hipMemsetAsync(dW, 0, sizeof(float) * (size_t)n_out * K, st));
+    if (db) UG_HIP(hipMemsetAsync(db, 0, sizeof(float) * (size_t)n_out, st));
+    return 0;
+  }
+  const int mt_count = (n_out + 31) / 32;
+  const int64_t chunks = (M + UG_WG_CHUNK - 1) / UG_WG_CHUNK;
+  const int n_slabs = (int)(chunks < UG_WG_MAX_SLABS ? chunks : UG_WG_MAX_SLABS);
+  float *pw = partial, *pb = db ? partial + (size_t)UG_WG_MAX_SLABS * n_out * K : nullptr;
+  const int64_t waves = (int64_t)n_slabs * mt_count;
+  const dim3 gr((unsigned)((waves + 3) / 4)), bl(256);
+  if (K <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<1>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs);
+  else if (K <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<2>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<4>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((n_out * K + 63) / 64), dim3(64), 0, st, pw, n_slabs, n_out * K, dW);
+  if (db) hipLaunchKernelGGL(k_wgrad_reduce, dim3((n_out + 63) / 64), dim3(64), 0, st, pb, n_slabs, n_out, db);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// C ABI (declared in include/ugrid_hip.h)
+// ----------------------------------------------------------------------------------------------
+extern "C" int64_t ugrid_rgbnet_train_scratch_floats(int64_t M) {
+  return 2 * M * 128 + (int64_t)UG_WG_MAX_SLABS * (128 * 128 + 128);
+}
+
+extern "C" int ugrid_rgbnet_train_forward(const float *feat, int64_t M, int32_t mlp_in, const float *w0, const float *b0,
+                                          const float *w1, const float *b1, const float *w2, const float *b2, int32_t width,
+                                          float *h1, float *h2, float *logits, ugrid_stream_t s) {
+  if (width != 128 || mlp_in < 1 || mlp_in > 128) return (int)hipErrorNotSupported;
+  int rc = ug_lin_launch(feat, M, mlp_in, mlp_in, w0, mlp_in, 128, 0, b0, 1, nullptr, 0, h1, 128, ST(s));
+  if (rc) return rc;
+  rc = ug_lin_launch(h1, M, 128, 128, w1, 128, 128, 0, b1, 1, nullptr, 0, h2, 128, ST(s));
+  if (rc) return rc;
+  return ug_lin_launch(h2, M, 128, 128, w2, 128, 3, 0, b2, 0, nullptr, 0, logits, 3, ST(s));
+}
+
+extern "C" int ugrid_rgbnet_train_backward(const float *g_logits, const float *feat, const float *h1, const float *h2, int64_t M,
+                                           int32_t mlp_in, int32_t n_feat_grad, const float *w0, const float *w1, const float *w2,
+                                           int32_t width, float *g_feat, float *g_w0, float *g_b0, float *g_w1, float *g_b1,
+                                           float *g_w2, float *g_b2, float *scratch, ugrid_stream_t s) {
+  if (width != 128 || mlp_in < 1 || mlp_in > 128 || n_feat_grad < 0 || n_feat_grad > mlp_in) return (int)hipErrorNotSupported;
+  float *g_h2 = scratch, *g_h1 = scratch + (size_t)M * 128;         // [M,128] each
+  float *part = scratch + (size_t)2 * M * 128;                      // slab partials of the weight gradients
+  int rc = ug_wgrad_launch(g_logits, 3, 3, h2, 128, 128, M, g_w2, g_b2, part, ST(s));                        // dW3, db3
+  if (rc) return rc;
+  rc = ug_lin_launch(g_logits, M, 3, 3, w2, 128, 128, 1, nullptr, 0, h2, 128, g_h2, 128, ST(s));                   // dH2 = dL . W3, ReLU mask
+  if (rc) return rc;
+  rc = ug_wgrad_launch(g_h2, 128, 128, h1, 128, 128, M, g_w1, g_b1, part, ST(s));                             // dW2, db2
+  if (rc) return rc;
+  rc = ug_lin_launch(g_h2, M, 128, 128, w1, 128, 128, 1, nullptr, 0, h1, 128, g_h1, 128, ST(s));                   // dH1 = dH2 . W2, ReLU mask
+  if (rc) return rc;
+  rc = ug_wgrad_launch(g_h1, 128, 128, feat, mlp_in, mlp_in, M, g_w0, g_b0, part, ST(s));                     // dW1, db1
+  if (rc) return rc;
+  if (n_feat_grad > 0 && g_feat)                                                                            // d feat[:, :n] = dH1 . W1[:, :n]
+    rc = ug_lin_launch(g_h1, M, 128, 128, w0, mlp_in, n_feat_grad, 1, nullptr, 0, nullptr, 0, g_feat, n_feat_grad, ST(s));
+  return rc;
+}

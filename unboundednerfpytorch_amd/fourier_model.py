@@ -44,6 +44,7 @@ class FourierGridModel(nn.Module):
         self.fused_forward = backend is None
         self.channels_last_grids = backend is None and kwargs.get('channels_last_grids', True)
         self.splitk_rgbnet = backend is None       # ops.SplitKLinear weight gradients (training on the GPU only)
+        self.fused_rgbnet = backend is None        # ops.FusedRgbnet: the default 3 x 128 rgbnet fwd / bwd on the MFMA kernels
         self.fused_loss = backend is None          # train_step.train_iteration: compositing + loss as ops.RenderLoss
         lo_s, hi_s = torch.Tensor(xyz_min), torch.Tensor(xyz_max)
         self.register_buffer('scene_center', (lo_s + hi_s) * 0.5)
@@ -296,11 +297,17 @@ class FourierGridModel(nn.Module):
         else:
             e = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
             emb = torch.cat([viewdirs, e.sin(), e.cos()], -1).flatten(0, -2)[ray_id]
-            feat = torch.cat([k0, emb], -1)
-            if self.splitk_rgbnet and feat.is_cuda and torch.is_grad_enabled():
-                logits = _ops.sequential_splitk(self.rgbnet, feat)
+            lin = _ops.rgbnet_linears(self.rgbnet) if (self.fused_rgbnet and k0.is_cuda and torch.is_grad_enabled()) else None
+            if lin is not None:
+                # the rgbnet and its derivative on the hand-written fp32-MFMA kernels (ops.FusedRgbnet): no library GEMMs
+                logits = _ops.FusedRgbnet.apply(k0, emb, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight,
+                                                lin[2].bias)
             else:
-                logits = self.rgbnet(feat)
+                feat = torch.cat([k0, emb], -1)
+                if self.splitk_rgbnet and feat.is_cuda and torch.is_grad_enabled():
+                    logits = _ops.sequential_splitk(self.rgbnet, feat)
+                else:
+                    logits = self.rgbnet(feat)
             if fused_loss is not None and logits.is_cuda and self.splitk_rgbnet:
                 # training tail as ONE op (ops.RenderLoss): sigmoid, compositing, background and the loss terms of
                 # run_train.py:254-279.  fused_loss = {'target': [R,3], 'coef': ops.loss_coefficients(...)}

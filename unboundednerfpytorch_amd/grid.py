@@ -63,11 +63,18 @@ class GridQuery(torch.autograd.Function):
         grad_grid = _gradpool.take(ctx.pool_key, ctx.shape, ctx.grid_stride, g.device)    # all zero, from the last step
         if grad_grid is None:
             grad_grid = _lib.empty_like_grid(ctx.shape, ctx.channels_last, g.device, zero=True)
-        fn = _L.ugrid_grid_query_backward_cl if ctx.channels_last else _L.ugrid_grid_query_backward
+        # channel-last: the scatter also marks the 256-byte lines it adds to (the optimizer's masked passes visit only those)
+        touch = _gradpool.touch_for_backward(ctx.pool_key, grad_grid, _L) if ctx.channels_last else None
         with _lib.guard(g.device):
-            _lib.check(fn(_lib.ptr(g), P, C, X, Y, Z, _lib.ptr(pts), _lib.ptr(xyz_min),
-                          _lib.ptr(xyz_max), ctx.freq_num, pts.shape[0],
-                          _lib.ptr(grad_grid), _lib.stream_of(g)), "grid_query_backward")
+            if touch is not None:
+                _lib.check(_L.ugrid_grid_query_backward_cl_touch(
+                    _lib.ptr(g), P, C, X, Y, Z, _lib.ptr(pts), _lib.ptr(xyz_min), _lib.ptr(xyz_max), ctx.freq_num, pts.shape[0],
+                    _lib.ptr(grad_grid), _lib.ptr(touch), _lib.stream_of(g)), "grid_query_backward (touch)")
+            else:
+                fn = _L.ugrid_grid_query_backward_cl if ctx.channels_last else _L.ugrid_grid_query_backward
+                _lib.check(fn(_lib.ptr(g), P, C, X, Y, Z, _lib.ptr(pts), _lib.ptr(xyz_min),
+                              _lib.ptr(xyz_max), ctx.freq_num, pts.shape[0],
+                              _lib.ptr(grad_grid), _lib.stream_of(g)), "grid_query_backward")
         return grad_grid, None, None, None, None
 
 

@@ -162,6 +162,68 @@ class SplitKLinear(torch.autograd.Function):
         return gx, gw, go.sum(0)
 
 
+def rgbnet_linears(net):
+    """the three nn.Linear layers of an rgbnet of the reference's default shape (Linear(k,128)-ReLU-[Linear(128,128)-ReLU]-
+    Linear(128,3), FourierGrid_model.py:233-241) or None for any other network (depth, width, extra layers)"""
+    lin, other = [], []
+    for m in net.modules():
+        if isinstance(m, torch.nn.Linear):
+            lin.append(m)
+        elif not isinstance(m, (torch.nn.Sequential, torch.nn.ReLU)):
+            other.append(m)
+    if other or len(lin) != 3 or any(l.bias is None for l in lin):
+        return None
+    if lin[0].out_features != 128 or lin[1].in_features != 128 or lin[1].out_features != 128 or lin[2].in_features != 128 \
+            or lin[2].out_features != 3 or lin[0].in_features > 128:
+        return None
+    return lin
+
+
+class FusedRgbnet(torch.autograd.Function):
+    """logits = rgbnet(cat([k0, emb])) for the default 3 x 128 rgbnet, forward and backward on the hand-written fp32-MFMA
+    kernels of csrc/ugrid_train_mlp.hip (include/ugrid_hip.h: ugrid_rgbnet_train_forward / _backward) instead of 13 library
+    GEMMs + elementwise kernels.  k0 [M,C] (gradient returned), emb [M,E] (view embedding rows, no gradient), then the three
+    weights and biases in nn.Linear layout.  fp32; deterministic (the weight gradients are fixed-order sums of slab partials)."""
+
+    @staticmethod
+    def forward(ctx, k0, emb, w0, b0, w1, b1, w2, b2):
+        feat = torch.cat([k0, emb], -1).contiguous()
+        M, K = feat.shape
+        ws = [t.contiguous() for t in (w0, b0, w1, b1, w2, b2)]
+        _lib.require_cuda(("k0", k0), ("emb", emb), *[("rgbnet", t) for t in ws])
+        _lib.require_f32(("k0", k0), ("emb", emb), *[("rgbnet", t) for t in ws])
+        dev = feat.device
+        h1 = torch.empty(M, 128, device=dev)
+        h2 = torch.empty(M, 128, device=dev)
+        logits = torch.empty(M, 3, device=dev)
+        with _lib.guard(dev):
+            _lib.check(_L.ugrid_rgbnet_train_forward(_lib.ptr(feat), M, K, *[_lib.ptr(t) for t in ws], 128, _lib.ptr(h1), _lib.ptr(h2),
+                                                     _lib.ptr(logits), _lib.stream_of(feat)), "rgbnet_train_forward")
+        ctx.save_for_backward(feat, h1, h2, ws[0], ws[2], ws[4])
+        ctx.C = k0.shape[1]
+        ctx.need_k0 = k0.requires_grad
+        return logits
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_logits):
+        feat, h1, h2, w0, w1, w2 = ctx.saved_tensors
+        M, K = feat.shape
+        dev = feat.device
+        g_logits = g_logits.to(torch.float32).contiguous()
+        n_fg = ctx.C if ctx.need_k0 else 0
+        g_k0 = torch.empty(M, n_fg, device=dev) if n_fg else None
+        g = [torch.empty_like(w0), torch.empty(128, device=dev), torch.empty_like(w1), torch.empty(128, device=dev),
+             torch.empty_like(w2), torch.empty(3, device=dev)]
+        scratch = torch.empty(int(_L.ugrid_rgbnet_train_scratch_floats(M)), device=dev)
+        with _lib.guard(dev):
+            _lib.check(_L.ugrid_rgbnet_train_backward(_lib.ptr(g_logits), _lib.ptr(feat), _lib.ptr(h1), _lib.ptr(h2), M, K, n_fg,
+                                                      _lib.ptr(w0), _lib.ptr(w1), _lib.ptr(w2), 128, _lib.ptr(g_k0) if n_fg else None,
+                                                      *[_lib.ptr(t) for t in g], _lib.ptr(scratch), _lib.stream_of(feat)),
+                       "rgbnet_train_backward")
+        return (g_k0, None, *g)
+
+
 def sequential_splitk(net, x):
     """Applies an nn.Sequential of Linear / ReLU / nested Sequential (the rgbnet) with SplitKLinear for the Linear layers."""
     for layer in net:

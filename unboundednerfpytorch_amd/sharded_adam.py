@@ -84,9 +84,10 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         self.per_lr = count.float() / count.max()
 
     # -- one parameter ---------------------------------------------------------------------------------
-    def _update(self, group, p, g, m, v, step, per_lr, recycle=None):
+    def _update(self, group, p, g, m, v, step, per_lr, recycle=None, touch=None):
         """recycle: the grid parameter whose .grad `g` is -- after a masked update on the HIP ops the gradient buffer comes
-        back all zero (rezero_grad) and is parked for the parameter's next backward (_gradpool)"""
+        back all zero (rezero_grad) and is parked for the parameter's next backward (_gradpool).  touch: the buffer's
+        touched-line bitmap (_gradpool.touch_of), used by the rezero path only"""
         beta1, beta2 = group['betas']
         args = (step, beta1, beta2, group['lr'], group['eps'])
         if per_lr is not None:
@@ -95,7 +96,10 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
             rz = getattr(self.ops, 'masked_adam_upd_rezero', None)
             if (rz is not None and recycle is not None and self.recycle_grads and _gradpool.enabled and g is recycle.grad
                     and recycle.dim() == 5 and g.is_cuda and g.stride() == recycle.stride()):
-                rz(p, g, m, v, *args)
+                if touch is not None:
+                    rz(p, g, m, v, *args, touch=touch)
+                else:
+                    rz(p, g, m, v, *args)
                 if _gradpool.give(recycle, g):      # parked: the pool now owns the (all-zero) buffer
                     recycle.grad = None
             else:
@@ -103,7 +107,14 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         else:
             self.ops.adam_upd(p, g, m, v, *args)
 
-    def _tv_then_update(self, group, param, g, state, tv, use_perlr, side=None):
+    def _touch_of(self, param, g, grad_hook):
+        """the touched-line bitmap of `g` when this step may rely on it: single process, HIP ops, recycled gradients, nobody
+        edited the gradient (grad_hook) -- see _gradpool"""
+        if grad_hook is not None or not self.recycle_grads or self._world()[0] != 1:
+            return None
+        return _gradpool.touch_of(param, g)
+
+    def _tv_then_update(self, group, param, g, state, tv, use_perlr, side=None, touch=None):
         """Total-variation term (w, dense_mode, tv_module) on the reduced gradient `g`, then the Adam update.  Dense mode
         on the HIP ops: ONE fused pass (adam_upd_cuda.tv_adam_dense -- 7 instead of 13 array transfers, the gradient is
         not written back, bit-identical results); the new parameter values land in a second buffer that is swapped in."""
@@ -117,6 +128,8 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
             # the gradient buffer comes back all zero and is parked for the next backward (_gradpool): no zero fill per step
             recycle = self.recycle_grads and _gradpool.enabled and g is param.grad
             kw = {'rezero_grad': True} if recycle else {}
+            if recycle and touch is not None:
+                kw['touch'] = touch
             args = (param.data, alt, g, state['exp_avg'], state['exp_avg_sq'], w, w, w, state['step'], beta1, beta2,
                     group['lr'], group['eps'], group['skip_zero_grad'])
             if side is not None:
@@ -126,7 +139,7 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                 # every array the side-stream kernel touches was allocated on the caller's stream: tell the caching
                 # allocator, so that a buffer whose last reference dies before the pass has run (zero_grad(set_to_none),
                 # a pool that refuses it, a replaced `alt`) is not handed to another tensor while it is still in use
-                for t_ in (g, alt, param.data, state['exp_avg'], state['exp_avg_sq']):
+                for t_ in (g, alt, param.data, state['exp_avg'], state['exp_avg_sq']) + ((touch,) if 'touch' in kw else ()):
                     t_.record_stream(side)
                 with torch.cuda.stream(side):
                     done = fused_fn(*args, **kw)
@@ -142,11 +155,17 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                 if recycle and _gradpool.give(param, g):     # parked (all zero once the pass has run); else .grad keeps it alive
                     param.grad = None
                 return
-        if tv_module is None:
+        ours = tv_module is None
+        if ours:
             from . import total_variation_cuda as tv_module
-        tv_module.total_variation_add_grad(param, g, w, w, w, dense)
+        if dense:
+            touch = None      # the dense term writes every element: the bitmap does not describe the gradient any more
+        if touch is not None and ours and not dense and g.dim() == 5 and g.shape[1] % 4 == 0:
+            tv_module.total_variation_add_grad_touched(param, g, w, w, w, touch)
+        else:
+            tv_module.total_variation_add_grad(param, g, w, w, w, dense)
         self._update(group, param, g, state['exp_avg'], state['exp_avg_sq'], state['step'],
-                     self.per_lr if use_perlr else None, recycle=param)
+                     self.per_lr if use_perlr else None, recycle=param, touch=touch)
 
     @torch.no_grad()
     def step(self, grad_hook=None, tv_terms=None, overlap=None):
@@ -190,12 +209,13 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                         state['exp_avg'] = torch.zeros_like(param, memory_format=torch.preserve_format)
                         state['exp_avg_sq'] = torch.zeros_like(param, memory_format=torch.preserve_format)
                     state['step'] += 1
+                    touch = self._touch_of(param, g, grad_hook)
                     if param in tv_terms:
                         self._tv_then_update(group, param, g, state, tv_terms[param], use_perlr,
-                                             side if (side is not None and any(param is q for q in overlap)) else None)
+                                             side if (side is not None and any(param is q for q in overlap)) else None, touch=touch)
                     else:
                         self._update(group, param, g, state['exp_avg'], state['exp_avg_sq'], state['step'],
-                                     self.per_lr if use_perlr else None, recycle=param)
+                                     self.per_lr if use_perlr else None, recycle=param, touch=touch)
                     continue
                 per = self.shard_len(n, world)
                 total = per * world
