@@ -418,6 +418,37 @@ int ugrid_train_compact(int64_t n_rays, int32_t n_samples, const float *scratch_
                         const float *t_table, float *pts, float *density, int64_t *ray_id, int64_t *step_id, float *t,
                         ugrid_stream_t stream);
 
+/* Stages 1 AND 2 of the training forward's sampling in one march (FourierGrid_model.py:554-629: ... Raw2Alpha, the alpha mask,
+ * Alphas2Weights (render_utils_kernel.cu:598-637), the weight mask and its seven boolean-index gathers).  ugrid_train_sample =
+ * ugrid_train_march + the transmittance recurrence over the kept samples, in order, as alpha2weight runs it (same float /
+ * double arithmetic, early stop below 1e-3), the weight threshold and alphainv_last [n_rays]; a ray's march ENDS where its
+ * transmittance does (the reference evaluates the rest of the ray and discards it: weight 0, gradient 0).  scratch_w /
+ * scratch_T: [n_rays * n_samples] like scratch_density; count2 [n_rays] = samples above the weight threshold.  After the caller
+ * has prefix-summed count and count2 (int64, inclusive), ugrid_train_sample_compact writes
+ *   the M1 = sum(count) stage-1 samples the backward walks: pts1 [M1,3], density1, weights1, T1 [M1], pos2 [M1] (index of the
+ *   sample among the stage-2 samples, or -1), and
+ *   the M2 = sum(count2) stage-2 samples: pts2 [M2,3], density2, alpha2, weights2, t2 [M2], ray_id2 / step_id2 [M2] int64.
+ * ugrid_train_sample_backward: gradients of the stage-2 weights [M2], of alphainv_last [n_rays] and -- added on top -- of the
+ * stage-2 raw densities [M2] (any may be NULL) -> g_density1 [M1], the input of ugrid_grid_query_backward on pts1
+ * (Alphas2Weights' and Raw2Alpha's backward formulas, render_utils_kernel.cu:639-672, :515-520, evaluated in one pass). */
+int ugrid_train_sample(const float *density_grid, int P, int X, int Y, int Z, int freq_num, const float *rays_o,
+                       const float *rays_d, int64_t n_rays, const float *t_table, int32_t n_samples,
+                       const float *scene_center3, const float *scene_radius3, const float *xyz_min, const float *xyz_max,
+                       double bg_len, int norm_l2, float act_shift, float interval, float thres, float *scratch_pts,
+                       float *scratch_density, int32_t *scratch_step, float *scratch_w, float *scratch_T, int32_t *count,
+                       int32_t *count2, float *alphainv_last, ugrid_stream_t stream);
+int ugrid_train_sample_compact(int64_t n_rays, int32_t n_samples, float act_shift, float interval, float thres,
+                               const float *scratch_pts, const float *scratch_density, const int32_t *scratch_step,
+                               const float *scratch_w, const float *scratch_T, const int32_t *count, const int64_t *offset_end,
+                               const int32_t *count2, const int64_t *offset_end2, const float *t_table, float *pts1,
+                               float *density1, float *weights1, float *T1, int32_t *pos2, float *pts2, float *density2,
+                               float *alpha2, float *weights2, int64_t *ray_id2, int64_t *step_id2, float *t2,
+                               ugrid_stream_t stream);
+int ugrid_train_sample_backward(int64_t n_rays, float act_shift, float interval, const float *density1, const float *weights1,
+                                const float *T1, const int32_t *pos2, const int32_t *count, const int64_t *offset_end,
+                                const float *alphainv_last, const float *g_weights2, const float *g_alphainv_last,
+                                const float *g_density2, float *g_density1, ugrid_stream_t stream);
+
 /* 1 when ugrid_render_shade / ugrid_render_fused have an rgbnet instantiation (depth 3, width 128) for this
  * (fourier_freq_num, k0 channels, viewbase_pe) triple, else 0 (they return hipErrorNotSupported for it). */
 int ugrid_shade_supported(int32_t freq_num, int32_t k0_channels, int32_t viewbase_pe);

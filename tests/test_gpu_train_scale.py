@@ -85,6 +85,37 @@ def test_fused_stage1_forward_equals_the_composed_chain_at_scale():
                     (k, int(odd.sum()), float(torch.maximum(ga.abs(), gb.abs())[odd].max()), scale)
 
 
+def test_fused_sampling_stage2_equals_the_separate_ops_bit_for_bit():
+    """grid.TrainSample (march + transmittance + weight threshold + gathers in one op, rays end where their transmittance does)
+    vs grid.TrainMarch + Raw2Alpha + Alphas2Weights + nonzero + index_select: the stage-2 samples and every per-ray output are
+    the SAME BITS (same recurrence, same order); gradients equal up to the order of the scatter's atomics"""
+    import bench_train_step as bts
+    dev = torch.device("cuda", 0)
+    m = build(dev)
+    m.fused_rgbnet = False            # rocBLAS rgbnet on both sides: deterministic, so that only the sampling differs
+    o, d, v, rgb = bts.random_rays(4096, dev, seed=5)
+    o[:7] = o[0] * 30.0               # rays from far outside
+    res = {}
+    for s2 in (True, False):
+        m.fused_sampling2 = s2
+        m.zero_grad(set_to_none=True)
+        out = m(o, d, v, global_step=1, is_train=True, stepsize=0.5, render_depth=True)
+        (loss_of(out, rgb) + 0.3 * out["raw_density"].sum() * 1e-3).backward()      # incl. a direct use of the raw densities
+        res[s2] = (out, {k: p.grad.clone() for k, p in m.named_parameters()})
+    a, b = res[True][0], res[False][0]
+    assert a["weights"].numel() > 20000 and float((a["alphainv_last"] < 1e-3).float().mean()) > 0.05      # early stops happen
+    for k in ("ray_id", "step_id", "t", "weights", "raw_alpha", "raw_density", "alphainv_last"):
+        assert torch.equal(a[k], b[k]), k
+    for k in ("rgb_marched", "depth"):          # torch's index_add_ sums with atomics: equal up to the order
+        assert float((a[k] - b[k]).abs().max()) <= 1e-6, k
+    for k in res[True][1]:
+        ga, gb = res[True][1][k], res[False][1][k]
+        scale = float(gb.abs().max()) + 1e-20
+        assert float((ga - gb).abs().max()) <= 1e-4 * scale, (k, float((ga - gb).abs().max()) / scale)
+        if "grid" in k:
+            assert torch.equal(ga != 0, gb != 0), k             # the same voxels are touched (MaskedAdam keys on them)
+
+
 def test_channel_last_k0_model_equals_the_canonical_layout_model():
     """fourier_model.FourierGridModel stores k0 channel-last on the HIP ops; with channels_last_grids=False it keeps the
     reference's row-major parameter.  Same state dict in, same forward, gradients equal up to the atomics' order,

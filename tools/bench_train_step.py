@@ -76,6 +76,7 @@ def parse(argv=None):
     ap.add_argument("--fused-loss", type=int, default=1, help="compositing + loss as one op (ops.RenderLoss) or the torch chain")
     ap.add_argument("--touch", type=int, default=1, help="touched-line bitmap of the recycled k0 gradient (_gradpool.touch_enabled): "
                     "the masked TV / Adam passes visit only the lines the backward marked; 0 = the scanning kernels")
+    ap.add_argument("--tune", action="append", default=[], help="key=value for ugrid_tune (A/B switches), repeatable")
     ap.add_argument("--channels-last", type=int, default=1, help="k0 stored [P][X][Y][Z][C] (the training layout) or row-major")
     return ap.parse_args(argv)
 
@@ -84,7 +85,10 @@ def run(args):
     """One measurement; returns the result dict (bench.py embeds it as `secondary_s3_train_step`)."""
     from unboundednerfpytorch_amd import train_step as ts
     from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
-    from unboundednerfpytorch_amd import _gradpool
+    from unboundednerfpytorch_amd import _gradpool, _lib
+    for kv in getattr(args, "tune", []):
+        k, v = kv.split("=")
+        _lib.check(_lib.load().ugrid_tune(k.encode(), int(v)), "tune " + kv)
     _gradpool.touch_enabled = bool(getattr(args, "touch", 1))
     dev = torch.device("cuda", 0)
     model = make_model(args.grid, args.freq, dev, args.fused, args.channels_last)

@@ -257,11 +257,25 @@ struct ug_train_args {
   float shift, interval, thres;
 };
 
+// alpha of a raw density exactly as k_raw2alpha forms it (e = expf(density + shift) is what its backward keeps)
+__device__ __forceinline__ float ug_train_alpha(float dens, float shift, float interval, float *e_out) {
+  const float e = expf(dens + shift);
+  *e_out = e;
+  return 1 - powf(1 + e, -interval);
+}
+
+// W2 = true (ugrid_train_sample): ALSO stage 2 of the sampling -- the transmittance recurrence of Alphas2Weights over the
+// kept samples, in order, exactly as k_alpha2weight runs it (T in float, the product in double, early stop below 1e-3),
+// the weight threshold, alphainv_last -- and the march of a ray ENDS where its transmittance does (the reference looks up
+// all S samples and throws the tail away: weight 0, gradient 0).  s_w / s_T: weight and transmittance per kept sample,
+// count2: kept samples whose weight exceeds the threshold.
+template <bool W2>
 __global__ void __launch_bounds__(256)
 k_train_march(ug_train_args a, const float *__restrict__ grid, const float *__restrict__ rays_o,
               const float *__restrict__ rays_d, const float *__restrict__ t_table, const float *__restrict__ xyz_min,
               const float *__restrict__ xyz_max, float *__restrict__ s_pts, float *__restrict__ s_dens,
-              int32_t *__restrict__ s_step, int32_t *__restrict__ count) {
+              int32_t *__restrict__ s_step, int32_t *__restrict__ count, float *__restrict__ s_w, float *__restrict__ s_T,
+              int32_t *__restrict__ count2, float *__restrict__ alphainv_last) {
   const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (ray >= a.n_rays) return;
   const int lane = ug_lane();
@@ -272,11 +286,13 @@ k_train_march(ug_train_args a, const float *__restrict__ grid, const float *__re
   const float lox = xyz_min[0], loy = xyz_min[1], loz = xyz_min[2], hix = xyz_max[0], hiy = xyz_max[1], hiz = xyz_max[2];
   const int64_t vol = (int64_t)a.X * a.Y * a.Z;
   const int64_t slot = ray * a.S;
-  int kept = 0;   // wave-uniform
-  for (int j0 = 0; j0 < a.S; j0 += UG_WAVE) {
+  int kept = 0, kept2 = 0;   // wave-uniform
+  float T_cum = 1.f;         // wave-uniform
+  bool stopped = false;
+  for (int j0 = 0; j0 < a.S && !stopped; j0 += UG_WAVE) {
     const int j = j0 + lane;
     bool keep = false;
-    float px = 0.f, py = 0.f, pz = 0.f, dens = 0.f;
+    float px = 0.f, py = 0.f, pz = 0.f, dens = 0.f, alpha = 0.f;
     if (j < a.S) {
       const float t = t_table[j];
       px = ox + dx * t; py = oy + dy * t; pz = oz + dz * t;
@@ -298,22 +314,133 @@ k_train_march(ug_train_args a, const float *__restrict__ grid, const float *__re
         dens = (l == 0) ? acc : dens + acc;
       }
       if (a.F > 0) dens = dens / (float)a.P;
-      const float e = expf(dens + a.shift);
-      const float alpha = 1 - powf(1 + e, -a.interval);
+      float e;
+      alpha = ug_train_alpha(dens, a.shift, a.interval, &e);
       keep = alpha > a.thres;
     }
-    const unsigned long long m = __ballot(keep);
+    unsigned long long m = __ballot(keep);
+    float myT = 1.f, myW = 0.f;
+    if (W2) {
+      unsigned long long mm = m;
+      while (mm != 0ull) {
+        const int k = __builtin_ctzll(mm);
+        mm &= mm - 1ull;
+        const float ak = ug_readlane_f(alpha, k);
+        if (lane == k) {
+          myT = T_cum;
+          myW = T_cum * ak;
+        }
+        T_cum = (float)((double)T_cum * (1. - (double)ak));
+        if ((double)T_cum < 1e-3) {          // the sample that crosses keeps its weight; the ray ends here
+          stopped = true;
+          m &= (2ull << k) - 1ull;
+          keep = keep && lane <= k;
+          break;
+        }
+      }
+    }
     if (m != 0ull) {
       if (keep) {
         const int64_t idx = slot + kept + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
         s_pts[3 * idx] = px; s_pts[3 * idx + 1] = py; s_pts[3 * idx + 2] = pz;
         s_dens[idx] = dens;
         s_step[idx] = j;
+        if (W2) { s_w[idx] = myW; s_T[idx] = myT; }
       }
       kept += __popcll(m);
+      if (W2) kept2 += __popcll(__ballot(keep && myW > a.thres));
     }
   }
-  if (lane == 0) count[ray] = kept;
+  if (lane == 0) {
+    count[ray] = kept;
+    if (W2) { count2[ray] = kept2; alphainv_last[ray] = T_cum; }
+  }
+}
+
+// after the two cumsums: one wave per ray copies its slot to the ray-major arrays of stage 1 (M1 samples: what the backward
+// walks) and of stage 2 (M2 samples above the weight threshold: what the k0 lookup, the rgbnet and the loss consume);
+// pos2[i] = the stage-2 index of stage-1 sample i or -1
+__global__ void __launch_bounds__(256)
+k_train_compact2(int64_t n_rays, int32_t S, float shift, float interval, float thres, const float *__restrict__ s_pts,
+                 const float *__restrict__ s_dens, const int32_t *__restrict__ s_step, const float *__restrict__ s_w,
+                 const float *__restrict__ s_T, const int32_t *__restrict__ count, const int64_t *__restrict__ end1,
+                 const int32_t *__restrict__ count2, const int64_t *__restrict__ end2, const float *__restrict__ t_table,
+                 float *__restrict__ pts1, float *__restrict__ dens1, float *__restrict__ w1, float *__restrict__ T1,
+                 int32_t *__restrict__ pos2, float *__restrict__ pts2, float *__restrict__ dens2, float *__restrict__ alpha2,
+                 float *__restrict__ w2, int64_t *__restrict__ ray_id2, int64_t *__restrict__ step_id2, float *__restrict__ tt2) {
+  const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (ray >= n_rays) return;
+  const int lane = ug_lane();
+  const int n = count[ray];
+  const int64_t d1 = end1[ray] - n, src = ray * (int64_t)S;
+  int64_t d2 = end2[ray] - count2[ray];
+  for (int i0 = 0; i0 < n; i0 += UG_WAVE) {
+    const int i = i0 + lane;
+    const bool on = i < n;
+    float px = 0.f, py = 0.f, pz = 0.f, dn = 0.f, w = 0.f;
+    int st = 0;
+    if (on) {
+      px = s_pts[3 * (src + i)]; py = s_pts[3 * (src + i) + 1]; pz = s_pts[3 * (src + i) + 2];
+      dn = s_dens[src + i]; w = s_w[src + i]; st = s_step[src + i];
+      pts1[3 * (d1 + i)] = px; pts1[3 * (d1 + i) + 1] = py; pts1[3 * (d1 + i) + 2] = pz;
+      dens1[d1 + i] = dn; w1[d1 + i] = w; T1[d1 + i] = s_T[src + i];
+    }
+    const bool k2 = on && w > thres;
+    const unsigned long long m = __ballot(k2);
+    const int64_t o = d2 + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+    if (on) pos2[d1 + i] = k2 ? (int32_t)o : -1;
+    if (k2) {
+      float e;
+      pts2[3 * o] = px; pts2[3 * o + 1] = py; pts2[3 * o + 2] = pz;
+      dens2[o] = dn;
+      alpha2[o] = ug_train_alpha(dn, shift, interval, &e);
+      w2[o] = w;
+      ray_id2[o] = ray;
+      step_id2[o] = st;
+      tt2[o] = t_table[st];
+    }
+    d2 += __popcll(m);
+  }
+}
+
+// backward of stage 2 of the sampling in one pass over the stage-1 samples of a ray, last to first: Alphas2Weights' backward
+// (k_alpha2weight_bwd: float running sum from the last sample, per-sample double expression), Raw2Alpha's (k_raw2alpha_bwd:
+// exp clamped at 1e10, double product), and the gradient that reaches the raw density directly (the loss's nearclip term on
+// the stage-2 samples) added on top -- g_dens1[i] is what the density lookup's scatter consumes.
+__global__ void __launch_bounds__(256)
+k_train_sample_bwd(int64_t n_rays, float shift, float interval, const float *__restrict__ dens1, const float *__restrict__ w1,
+                   const float *__restrict__ T1, const int32_t *__restrict__ pos2, const int32_t *__restrict__ count,
+                   const int64_t *__restrict__ end1, const float *__restrict__ alphainv_last, const float *__restrict__ g_w2,
+                   const float *__restrict__ g_last, const float *__restrict__ g_dens2, float *__restrict__ g_dens1) {
+  const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (r >= n_rays) return;
+  const int lane = ug_lane();
+  const int64_t i_e = end1[r], i_s = i_e - count[r];
+  float back = g_last ? g_last[r] * alphainv_last[r] : 0.f;
+  for (int64_t top = i_e; top > i_s; top -= UG_WAVE) {
+    const int64_t i = top - 1 - lane;          // lane k holds sample top-1-k
+    const bool ok = i >= i_s;
+    const int p2 = ok ? pos2[i] : -1;
+    const float gw = (p2 >= 0 && g_w2) ? g_w2[p2] : 0.f;
+    const float prod = ok ? gw * w1[i] : 0.f;
+    const int cnt = (int)((top - i_s) < UG_WAVE ? (top - i_s) : UG_WAVE);
+    float my_back = 0.f;
+    for (int k = 0; k < cnt; ++k) {
+      if (lane == k) my_back = back;
+      back += ug_readlane_f(prod, k);
+    }
+    if (ok) {
+      float ef;
+      const float a = ug_train_alpha(dens1[i], shift, interval, &ef);
+      const float g_alpha = (float)((double)(gw * T1[i]) - (double)my_back / ((double)(1 - a) + 1e-10));
+      const double e = (double)ef;
+      const double em = e < 1e10 ? e : 1e10;
+      const float pw = powf(1 + ef, -interval - 1);
+      float g = (float)(em * (double)pw * (double)interval * (double)g_alpha);
+      if (p2 >= 0 && g_dens2) g = g + g_dens2[p2];
+      g_dens1[i] = g;
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -338,12 +465,13 @@ k_train_compact(int64_t n_rays, int32_t S, const float *__restrict__ s_pts, cons
   }
 }
 
-extern "C" int ugrid_train_march(const float *density_grid, int P, int X, int Y, int Z, int freq_num, const float *rays_o,
-                                 const float *rays_d, int64_t n_rays, const float *t_table, int32_t n_samples,
-                                 const float *scene_center3, const float *scene_radius3, const float *xyz_min,
-                                 const float *xyz_max, double bg_len, int norm_l2, float act_shift, float interval,
-                                 float thres, float *scratch_pts, float *scratch_density, int32_t *scratch_step,
-                                 int32_t *count, ugrid_stream_t s) {
+static int ug_train_march_any(const float *density_grid, int P, int X, int Y, int Z, int freq_num, const float *rays_o,
+                              const float *rays_d, int64_t n_rays, const float *t_table, int32_t n_samples,
+                              const float *scene_center3, const float *scene_radius3, const float *xyz_min,
+                              const float *xyz_max, double bg_len, int norm_l2, float act_shift, float interval,
+                              float thres, float *scratch_pts, float *scratch_density, int32_t *scratch_step,
+                              int32_t *count, float *scratch_w, float *scratch_T, int32_t *count2, float *alphainv_last,
+                              ugrid_stream_t s) {
   if (n_rays <= 0) return 0;
   if (P != (freq_num > 0 ? 2 * freq_num + 1 : 1) || n_samples <= 0) return (int)hipErrorInvalidValue;
   ug_train_args a;
@@ -353,8 +481,65 @@ extern "C" int ugrid_train_march(const float *density_grid, int P, int X, int Y,
   const double Bd = 1.0 + bg_len;
   a.B = (float)Bd; a.A = (float)(Bd * 1.0 - 1.0);
   a.shift = act_shift; a.interval = interval; a.thres = thres;
-  hipLaunchKernelGGL(k_train_march, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), a, density_grid, rays_o,
-                     rays_d, t_table, xyz_min, xyz_max, scratch_pts, scratch_density, scratch_step, count);
+  if (scratch_w)
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_train_march<true>), dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), a, density_grid,
+                       rays_o, rays_d, t_table, xyz_min, xyz_max, scratch_pts, scratch_density, scratch_step, count, scratch_w, scratch_T,
+                       count2, alphainv_last);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_train_march<false>), dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), a, density_grid,
+                       rays_o, rays_d, t_table, xyz_min, xyz_max, scratch_pts, scratch_density, scratch_step, count, (float *)nullptr,
+                       (float *)nullptr, (int32_t *)nullptr, (float *)nullptr);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ugrid_train_march(const float *density_grid, int P, int X, int Y, int Z, int freq_num, const float *rays_o,
+                                 const float *rays_d, int64_t n_rays, const float *t_table, int32_t n_samples,
+                                 const float *scene_center3, const float *scene_radius3, const float *xyz_min,
+                                 const float *xyz_max, double bg_len, int norm_l2, float act_shift, float interval,
+                                 float thres, float *scratch_pts, float *scratch_density, int32_t *scratch_step,
+                                 int32_t *count, ugrid_stream_t s) {
+  return ug_train_march_any(density_grid, P, X, Y, Z, freq_num, rays_o, rays_d, n_rays, t_table, n_samples, scene_center3, scene_radius3,
+                            xyz_min, xyz_max, bg_len, norm_l2, act_shift, interval, thres, scratch_pts, scratch_density, scratch_step,
+                            count, nullptr, nullptr, nullptr, nullptr, s);
+}
+
+extern "C" int ugrid_train_sample(const float *density_grid, int P, int X, int Y, int Z, int freq_num, const float *rays_o,
+                                  const float *rays_d, int64_t n_rays, const float *t_table, int32_t n_samples,
+                                  const float *scene_center3, const float *scene_radius3, const float *xyz_min,
+                                  const float *xyz_max, double bg_len, int norm_l2, float act_shift, float interval,
+                                  float thres, float *scratch_pts, float *scratch_density, int32_t *scratch_step,
+                                  float *scratch_w, float *scratch_T, int32_t *count, int32_t *count2, float *alphainv_last,
+                                  ugrid_stream_t s) {
+  if (!scratch_w || !scratch_T || !count2 || !alphainv_last) return (int)hipErrorInvalidValue;
+  return ug_train_march_any(density_grid, P, X, Y, Z, freq_num, rays_o, rays_d, n_rays, t_table, n_samples, scene_center3, scene_radius3,
+                            xyz_min, xyz_max, bg_len, norm_l2, act_shift, interval, thres, scratch_pts, scratch_density, scratch_step,
+                            count, scratch_w, scratch_T, count2, alphainv_last, s);
+}
+
+extern "C" int ugrid_train_sample_compact(int64_t n_rays, int32_t n_samples, float act_shift, float interval, float thres,
+                                          const float *scratch_pts, const float *scratch_density, const int32_t *scratch_step,
+                                          const float *scratch_w, const float *scratch_T, const int32_t *count,
+                                          const int64_t *offset_end, const int32_t *count2, const int64_t *offset_end2,
+                                          const float *t_table, float *pts1, float *density1, float *weights1, float *T1,
+                                          int32_t *pos2, float *pts2, float *density2, float *alpha2, float *weights2,
+                                          int64_t *ray_id2, int64_t *step_id2, float *t2, ugrid_stream_t s) {
+  if (n_rays <= 0) return 0;
+  hipLaunchKernelGGL(k_train_compact2, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), n_rays, n_samples, act_shift, interval,
+                     thres, scratch_pts, scratch_density, scratch_step, scratch_w, scratch_T, count, offset_end, count2, offset_end2,
+                     t_table, pts1, density1, weights1, T1, pos2, pts2, density2, alpha2, weights2, ray_id2, step_id2, t2);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ugrid_train_sample_backward(int64_t n_rays, float act_shift, float interval, const float *density1,
+                                           const float *weights1, const float *T1, const int32_t *pos2, const int32_t *count,
+                                           const int64_t *offset_end, const float *alphainv_last, const float *g_weights2,
+                                           const float *g_alphainv_last, const float *g_density2, float *g_density1,
+                                           ugrid_stream_t s) {
+  if (n_rays <= 0) return 0;
+  hipLaunchKernelGGL(k_train_sample_bwd, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), n_rays, act_shift, interval,
+                     density1, weights1, T1, pos2, count, offset_end, alphainv_last, g_weights2, g_alphainv_last, g_density2, g_density1);
   UG_LAUNCH_CHECK();
   return 0;
 }

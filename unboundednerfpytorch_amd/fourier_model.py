@@ -42,6 +42,7 @@ class FourierGridModel(nn.Module):
         # fused stage 1 of the training forward (grid.TrainMarch): on by default with the HIP ops; the composed torch-op
         # chain below remains for injected back-ends, fast_color_thres == 0 and as the A/B reference of the tests
         self.fused_forward = backend is None
+        self.fused_sampling2 = backend is None     # grid.TrainSample: stage 2 of the sampling inside the march as well
         self.channels_last_grids = backend is None and kwargs.get('channels_last_grids', True)
         self.splitk_rgbnet = backend is None       # ops.SplitKLinear weight gradients (training on the GPU only)
         self.fused_rgbnet = backend is None        # ops.FusedRgbnet: the default 3 x 128 rgbnet fwd / bwd on the MFMA kernels
@@ -257,39 +258,52 @@ class FourierGridModel(nn.Module):
             self.fast_color_thres = self._fast_color_thres[global_step]
         R = rays_o.shape[0]
         interval = render_kwargs['stepsize'] * self.voxel_size_ratio_density
-        if self.fused_forward and self.fast_color_thres > 0 and rays_o.is_cuda:
-            # stage 1 in two HIP kernels: no [R,S,3] point tensor, no [R,S] density / alpha, no boolean-index gathers
+        fused_sampling = self.fused_forward and self.fast_color_thres > 0 and rays_o.is_cuda
+        if fused_sampling and self.fused_sampling2:
+            # stages 1 + 2 of the sampling as one op (grid.TrainSample): march with the transmittance recurrence inside, one
+            # host read, one compaction -- no Raw2Alpha / Alphas2Weights / nonzero / index_select launches
             dev = rays_o.device
             t = self.sample_table(render_kwargs['stepsize'], dev)
             S = t.numel()
             hc = self._host_consts()
-            pts, density, ray_id, step_id, tt = _grid.TrainMarch.apply(
+            pts, density, alpha, weights, alphainv_last, ray_id, step_id, tt = _grid.TrainSample.apply(
                 self.density.grid, rays_o.contiguous(), rays_d.contiguous(), t, hc[0], hc[1], self.xyz_min, self.xyz_max,
                 self.bg_len, self.contracted_norm == 'l2', hc[2], float(interval), float(self.fast_color_thres),
                 self.fourier_freq_num)
-            alpha = self.activate_density(density, interval)
-            inner = None
         else:
-            pts, inner, t = self.sample_ray(rays_o, rays_d, **render_kwargs)
-            S = t.numel()
-            dev = pts.device
-            ray_id = torch.arange(R, device=dev).view(-1, 1).expand(R, S).flatten()
-            step_id = torch.arange(S, device=dev).view(1, -1).expand(R, S).flatten()
-            tt = t[None].repeat(R, 1)
-            density = self.density(pts)
-            alpha = self.activate_density(density, interval)
+            if fused_sampling:
+                # stage 1 in two HIP kernels: no [R,S,3] point tensor, no [R,S] density / alpha, no boolean-index gathers
+                dev = rays_o.device
+                t = self.sample_table(render_kwargs['stepsize'], dev)
+                S = t.numel()
+                hc = self._host_consts()
+                pts, density, ray_id, step_id, tt = _grid.TrainMarch.apply(
+                    self.density.grid, rays_o.contiguous(), rays_d.contiguous(), t, hc[0], hc[1], self.xyz_min, self.xyz_max,
+                    self.bg_len, self.contracted_norm == 'l2', hc[2], float(interval), float(self.fast_color_thres),
+                    self.fourier_freq_num)
+                alpha = self.activate_density(density, interval)
+                inner = None
+            else:
+                pts, inner, t = self.sample_ray(rays_o, rays_d, **render_kwargs)
+                S = t.numel()
+                dev = pts.device
+                ray_id = torch.arange(R, device=dev).view(-1, 1).expand(R, S).flatten()
+                step_id = torch.arange(S, device=dev).view(1, -1).expand(R, S).flatten()
+                tt = t[None].repeat(R, 1)
+                density = self.density(pts)
+                alpha = self.activate_density(density, interval)
+                if self.fast_color_thres > 0:
+                    keep = alpha > self.fast_color_thres
+                    pts, inner, tt, density, alpha = pts[keep], inner[keep], tt[keep], density[keep], alpha[keep]
+                    ray_id, step_id = ray_id[keep.flatten()], step_id[keep.flatten()]
+            weights, alphainv_last = self._be.Alphas2Weights.apply(alpha, ray_id, R)
             if self.fast_color_thres > 0:
-                keep = alpha > self.fast_color_thres
-                pts, inner, tt, density, alpha = pts[keep], inner[keep], tt[keep], density[keep], alpha[keep]
-                ray_id, step_id = ray_id[keep.flatten()], step_id[keep.flatten()]
-        weights, alphainv_last = self._be.Alphas2Weights.apply(alpha, ray_id, R)
-        if self.fast_color_thres > 0:
-            # one nonzero (one host sync) for the seven gathers of FourierGrid_model.py:620-629, instead of one per tensor
-            keep = torch.nonzero(weights > self.fast_color_thres).squeeze(1)
-            pts, tt, density, alpha, weights = (x.index_select(0, keep) for x in (pts, tt, density, alpha, weights))
-            ray_id, step_id = ray_id.index_select(0, keep), step_id.index_select(0, keep)
-        else:
-            pts, weights = pts.reshape(-1, 3), weights.reshape(-1)
+                # one nonzero (one host sync) for the seven gathers of FourierGrid_model.py:620-629, instead of one per tensor
+                keep = torch.nonzero(weights > self.fast_color_thres).squeeze(1)
+                pts, tt, density, alpha, weights = (x.index_select(0, keep) for x in (pts, tt, density, alpha, weights))
+                ray_id, step_id = ray_id.index_select(0, keep), step_id.index_select(0, keep)
+            else:
+                pts, weights = pts.reshape(-1, 3), weights.reshape(-1)
         k0 = self.k0(pts)
         fused_loss = render_kwargs.get('fused_loss')
         if self.rgbnet is None:

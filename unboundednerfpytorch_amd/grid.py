@@ -153,6 +153,91 @@ class TrainMarch(torch.autograd.Function):
         return (grad_grid,) + (None,) * 13
 
 
+class TrainSample(torch.autograd.Function):
+    """Stages 1 and 2 of the training forward's sampling (FourierGrid_model.py:554-629) as ONE op: TrainMarch, Raw2Alpha,
+    Alphas2Weights, the weight mask and its gathers -- include/ugrid_hip.h: ugrid_train_sample / _compact / _backward.  One
+    march kernel (a ray ends where its transmittance does), one cumsum + ONE host read (M1, M2), one compaction; the backward
+    is one pass over the stage-1 samples + the density lookup's scatter.  Returns the stage-2 samples
+    (pts, raw density, alpha, weights, ray_id, step_id, t) and alphainv_last [R]; differentiable in the density grid through
+    `weights`, `alphainv_last` and the raw `density` output."""
+    _scratch = {}
+
+    @staticmethod
+    def forward(ctx, grid, rays_o, rays_d, t, scene_center, scene_radius, xyz_min, xyz_max, bg_len, norm_l2, act_shift,
+                interval, thres, freq_num):
+        import ctypes
+        _lib.wait_pending(grid)
+        _lib.require_cuda(("grid", grid), ("rays_o", rays_o), ("rays_d", rays_d), ("t", t), ("xyz_min", xyz_min), ("xyz_max", xyz_max))
+        _lib.require_f32(("grid", grid), ("rays_o", rays_o), ("rays_d", rays_d), ("t", t))
+        if grid.dim() != 5 or grid.shape[1] != 1:
+            raise RuntimeError("density grid must be [P,1,X,Y,Z]")
+        P, _, X, Y, Z = grid.shape
+        R, S = rays_o.shape[0], t.numel()
+        dev = grid.device
+        key = (dev, R * S)
+        sc = TrainSample._scratch.get(key)
+        if sc is None:
+            TrainSample._scratch.clear()          # one ray-batch shape at a time: 32 B per (ray, sample)
+            sc = (torch.empty(R * S, 3, device=dev), torch.empty(R * S, device=dev), torch.empty(R * S, dtype=torch.int32, device=dev),
+                  torch.empty(R * S, device=dev), torch.empty(R * S, device=dev))
+            TrainSample._scratch[key] = sc
+        counts = torch.empty(2, R, dtype=torch.int32, device=dev)
+        ainv = torch.empty(R, device=dev)
+        c3 = (ctypes.c_float * 3)(*[float(x) for x in scene_center])
+        r3 = (ctypes.c_float * 3)(*[float(x) for x in scene_radius])
+        F_ = max(int(freq_num), 0)
+        with _lib.guard(dev):
+            st = _lib.stream_of(grid)
+            _lib.check(_L.ugrid_train_sample(_lib.ptr(grid), P, X, Y, Z, F_, _lib.ptr(rays_o), _lib.ptr(rays_d), R, _lib.ptr(t), S,
+                                             ctypes.cast(c3, ctypes.c_void_p), ctypes.cast(r3, ctypes.c_void_p), _lib.ptr(xyz_min),
+                                             _lib.ptr(xyz_max), float(bg_len), int(bool(norm_l2)), float(act_shift), float(interval),
+                                             float(thres), *[_lib.ptr(x) for x in sc], _lib.ptr(counts[0]), _lib.ptr(counts[1]),
+                                             _lib.ptr(ainv), st), "train_sample")
+            off = torch.cumsum(counts, 1, dtype=torch.int64)            # [2,R] inclusive
+            M1, M2 = (int(x) for x in off[:, -1].tolist()) if R > 0 else (0, 0)     # the one host read
+            pts1, dens1, w1, T1 = torch.empty(M1, 3, device=dev), torch.empty(M1, device=dev), torch.empty(M1, device=dev), \
+                torch.empty(M1, device=dev)
+            pos2 = torch.empty(M1, dtype=torch.int32, device=dev)
+            pts2, dens2, alpha2, w2, tt2 = torch.empty(M2, 3, device=dev), torch.empty(M2, device=dev), torch.empty(M2, device=dev), \
+                torch.empty(M2, device=dev), torch.empty(M2, device=dev)
+            ray2, step2 = torch.empty(M2, dtype=torch.int64, device=dev), torch.empty(M2, dtype=torch.int64, device=dev)
+            if M1 > 0:
+                _lib.check(_L.ugrid_train_sample_compact(
+                    R, S, float(act_shift), float(interval), float(thres), *[_lib.ptr(x) for x in sc], _lib.ptr(counts[0]),
+                    _lib.ptr(off[0]), _lib.ptr(counts[1]), _lib.ptr(off[1]), _lib.ptr(t), _lib.ptr(pts1), _lib.ptr(dens1), _lib.ptr(w1),
+                    _lib.ptr(T1), _lib.ptr(pos2), _lib.ptr(pts2), _lib.ptr(dens2), _lib.ptr(alpha2), _lib.ptr(w2), _lib.ptr(ray2),
+                    _lib.ptr(step2), _lib.ptr(tt2), st), "train_sample_compact")
+        ctx.save_for_backward(pts1, dens1, w1, T1, pos2, counts, off, ainv, xyz_min, xyz_max)
+        ctx.shape, ctx.freq_num, ctx.consts = tuple(grid.shape), F_, (float(act_shift), float(interval))
+        ctx.pool_key, ctx.grid_stride = _gradpool.key_of(grid), tuple(grid.stride())
+        ctx.mark_non_differentiable(pts2, alpha2, ray2, step2, tt2)
+        return pts2, dens2, alpha2, w2, ainv, ray2, step2, tt2
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_pts, g_dens2, g_alpha, g_w2, g_ainv, g_ray, g_step, g_t):
+        pts1, dens1, w1, T1, pos2, counts, off, ainv, xyz_min, xyz_max = ctx.saved_tensors
+        P, C, X, Y, Z = ctx.shape
+        dev = pts1.device
+        grad_grid = _gradpool.take(ctx.pool_key, ctx.shape, ctx.grid_stride, dev)
+        if grad_grid is None:
+            grad_grid = torch.zeros(ctx.shape, dtype=torch.float32, device=dev)
+        M1, R = pts1.shape[0], ainv.shape[0]
+        if M1 > 0:
+            f32 = lambda g: None if g is None else g.to(torch.float32).contiguous()
+            g_dens2, g_w2, g_ainv = f32(g_dens2), f32(g_w2), f32(g_ainv)
+            g1 = torch.empty(M1, 1, device=dev)
+            with _lib.guard(dev):
+                st = _lib.stream_of(pts1)
+                _lib.check(_L.ugrid_train_sample_backward(R, ctx.consts[0], ctx.consts[1], _lib.ptr(dens1), _lib.ptr(w1), _lib.ptr(T1),
+                                                          _lib.ptr(pos2), _lib.ptr(counts[0]), _lib.ptr(off[0]), _lib.ptr(ainv),
+                                                          _lib.ptr(g_w2), _lib.ptr(g_ainv), _lib.ptr(g_dens2), _lib.ptr(g1), st),
+                           "train_sample_backward")
+                _lib.check(_L.ugrid_grid_query_backward(_lib.ptr(g1), P, C, X, Y, Z, _lib.ptr(pts1), _lib.ptr(xyz_min), _lib.ptr(xyz_max),
+                                                        ctx.freq_num, M1, _lib.ptr(grad_grid), st), "grid_query_backward")
+        return (grad_grid,) + (None,) * 13
+
+
 def create_grid(type, **kwargs):
     if type == 'DenseGrid':
         return FourierGrid(**kwargs)
