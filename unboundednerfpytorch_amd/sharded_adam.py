@@ -160,12 +160,60 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
             from . import total_variation_cuda as tv_module
         if dense:
             touch = None      # the dense term writes every element: the bitmap does not describe the gradient any more
-        if touch is not None and ours and not dense and g.dim() == 5 and g.shape[1] % 4 == 0:
-            tv_module.total_variation_add_grad_touched(param, g, w, w, w, touch)
+
+        def run():
+            if touch is not None and ours and not dense and g.dim() == 5 and g.shape[1] % 4 == 0:
+                tv_module.total_variation_add_grad_touched(param, g, w, w, w, touch)
+            else:
+                tv_module.total_variation_add_grad(param, g, w, w, w, dense)
+            self._update(group, param, g, state['exp_avg'], state['exp_avg_sq'], state['step'],
+                         self.per_lr if use_perlr else None, recycle=param, touch=touch)
+        if side is not None and ours and touch is not None and not dense:
+            # masked TV + masked Adam on the marked lines, queued on the second stream like the dense pass (they update the
+            # parameter in place: consumers meet them at _lib.wait_pending)
+            side.wait_stream(torch.cuda.current_stream(param.device))
+            for t_ in (g, param.data, state['exp_avg'], state['exp_avg_sq'], touch):
+                t_.record_stream(side)
+            with torch.cuda.stream(side):
+                run()
+                ev = torch.cuda.Event()
+                ev.record(side)
+                param._ug_pending = ev
         else:
-            tv_module.total_variation_add_grad(param, g, w, w, w, dense)
-        self._update(group, param, g, state['exp_avg'], state['exp_avg_sq'], state['step'],
-                     self.per_lr if use_perlr else None, recycle=param, touch=touch)
+            run()
+
+    @torch.no_grad()
+    def step_param(self, param, tv_term=None, overlap=False):
+        """The update of ONE replicated parameter, as step() would do it, callable as soon as its gradient is complete -- e.g.
+        from a post-accumulate-grad hook during loss.backward(), so that the largest grid's update (optionally on the side
+        stream, overlap=True) starts while the rest of the backward still runs.  The following step() skips the parameter.
+        Single process only; returns False (nothing done) otherwise or when the parameter has no gradient."""
+        if self._world()[0] != 1 or param.grad is None:
+            return False
+        group = next((g for g in self.param_groups if any(param is q for q in g['params'])), None)
+        if group is None:
+            return False
+        _lib_wait(param)
+        state = self.state[param]
+        g = param.grad
+        if len(state) == 0:
+            state['step'] = 0
+            state['exp_avg'] = torch.zeros_like(param, memory_format=torch.preserve_format)
+            state['exp_avg_sq'] = torch.zeros_like(param, memory_format=torch.preserve_format)
+        state['step'] += 1
+        use_perlr = self.per_lr is not None and param.shape == self.per_lr.shape
+        touch = self._touch_of(param, g, None)
+        if tv_term is not None:
+            side = None
+            if overlap:
+                side = self._side = getattr(self, '_side', None) or _low_priority_stream()
+            self._tv_then_update(group, param, g, state, tv_term, use_perlr, side, touch=touch)
+        else:
+            self._update(group, param, g, state['exp_avg'], state['exp_avg_sq'], state['step'],
+                         self.per_lr if use_perlr else None, recycle=param, touch=touch)
+        self._early = getattr(self, '_early', set())
+        self._early.add(id(param))
+        return True
 
     @torch.no_grad()
     def step(self, grad_hook=None, tv_terms=None, overlap=None):
@@ -186,9 +234,10 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         side = None
         if overlap and world == 1:
             side = self._side = getattr(self, '_side', None) or _low_priority_stream()
+        early, self._early = getattr(self, '_early', set()), set()
         for group in self.param_groups:
             for param in group['params']:
-                if param.grad is None:
+                if param.grad is None or id(param) in early:       # (updated already by step_param during the backward)
                     continue
                 _lib_wait(param)
                 state = self.state[param]

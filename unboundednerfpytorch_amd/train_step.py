@@ -105,8 +105,6 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
     else:
         loss, mse = training_loss(out, target, cfg_train, n_rays, near_thres, distortion_fn, world_size)
     _mark(timers, "loss")
-    loss.backward()
-    _mark(timers, "backward")
     tv_on = (global_step < _get(cfg_train, 'tv_before', 0) and global_step > _get(cfg_train, 'tv_after', 0)
              and global_step % _get(cfg_train, 'tv_every', 1) == 0)
     tv_terms = None
@@ -124,10 +122,25 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
         if _get(cfg_train, 'weight_tv_k0', 0.0) > 0:
             tv_terms[model.k0.grid] = (float(_get(cfg_train, 'weight_tv_k0') / n_global * model.world_size_rgb.max() / 128),
                                        dense, model.k0.tv_module)
-    if tv_terms and overlap_k0_update and world_size == 1 and model.k0.grid in tv_terms:
-        # the k0 update (the step's largest kernel, HBM-bound, nothing before the next k0 lookup depends on it) on a second
-        # stream: it runs beside the next iteration's density march, host syncs and launch-bound glue
-        optimizer.step(tv_terms=tv_terms, overlap=[model.k0.grid])
+    overlap = bool(tv_terms and overlap_k0_update and world_size == 1 and model.k0.grid in tv_terms)
+    hook = None
+    if overlap and hasattr(optimizer, 'step_param') and hasattr(model.k0.grid, 'register_post_accumulate_grad_hook'):
+        # the k0 update (the step's largest pass, HBM-bound) is queued on the second stream THE MOMENT the k0 gradient is
+        # complete -- the k0 lookup's backward runs before the density path's in the autograd order -- and so runs beside the
+        # density backward, the density / rgbnet updates, the next iteration's march, host syncs and launch-bound glue
+        k0_term = tv_terms[model.k0.grid]
+
+        def _early_k0_update(p):          # (an autograd hook must return None)
+            optimizer.step_param(p, k0_term, overlap=True)
+        hook = model.k0.grid.register_post_accumulate_grad_hook(_early_k0_update)
+    try:
+        loss.backward()
+    finally:
+        if hook is not None:
+            hook.remove()
+    _mark(timers, "backward")
+    if overlap:
+        optimizer.step(tv_terms=tv_terms, overlap=[model.k0.grid])     # (k0 is skipped here when the hook has updated it)
     elif tv_terms:
         optimizer.step(tv_terms=tv_terms)
     else:
