@@ -199,7 +199,8 @@ def test_product_kernels_fit_their_register_budget_without_scratch(lib_path):
               "_Z15k_train_compact": 64, "_Z12k_grid_queryILb": 64, "_Z21k_grid_query_backwardILb": 64, "_Z12k_tv_cl_vec4ILb": 64,
               "_Z14k_tv_adam_vec4ILb": 64, "_Z9k_tv_vec4ILb": 64, "_Z11k_adam_vec4ILi": 64, "_Z17k_render_loss_fwd": 64,
               "_Z17k_render_loss_bwd": 64, "_Z14k_alpha2weight": 64, "_Z18k_alpha2weight_bwd": 64, "_Z16k_rays_of_a_view": 64,
-              "_Z11k_pack_quad": 128}
+              "_Z11k_pack_quad": 128, "_Z5k_linILi": 128, "_Z7k_wgradILi": 256, "_Z16k_train_compact2": 64, "_Z18k_train_sample_bwd": 64,
+              "_Z17k_adam_vec4_touch": 64, "_Z13k_tv_cl_touch": 64, "_Z12k_lin_smallk": 64, "_Z12k_march_dvgo": 80}
     import re
     for prefix, limit in budget.items():
         for k in find(prefix):

@@ -76,6 +76,7 @@ def parse(argv=None):
     ap.add_argument("--fused-loss", type=int, default=1, help="compositing + loss as one op (ops.RenderLoss) or the torch chain")
     ap.add_argument("--touch", type=int, default=1, help="touched-line bitmap of the recycled k0 gradient (_gradpool.touch_enabled): "
                     "the masked TV / Adam passes visit only the lines the backward marked; 0 = the scanning kernels")
+    ap.add_argument("--lazy-loss", type=int, default=0, help="train_iteration(return_tensors=True): no host read of loss / psnr per step")
     ap.add_argument("--tune", action="append", default=[], help="key=value for ugrid_tune (A/B switches), repeatable")
     ap.add_argument("--channels-last", type=int, default=1, help="k0 stored [P][X][Y][Z][C] (the training layout) or row-major")
     return ap.parse_args(argv)
@@ -113,10 +114,11 @@ def run(args):
         o, d, v, rgb = batches[step - 1]
         with (torch.cuda.stream(main) if main is not None else contextlib.nullcontext()):
             loss, psnr = ts.train_iteration(model, opt, o, d, v, rgb, TRUCK_CFG, args.first_step - 1 + step, rk, timers=timers,
-                                            overlap_k0_update=bool(args.overlap))
+                                            overlap_k0_update=bool(args.overlap), return_tensors=bool(getattr(args, "lazy_loss", 0)))
         stats = {"loss": loss, "psnr": psnr}
     torch.cuda.synchronize()
     wall_ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    stats = {k: float(v) for k, v in stats.items()}
     phases = ["forward", "loss", "backward", "tv+adam"]
     order = ["start"] + phases
     ms = {}
@@ -143,7 +145,7 @@ def run(args):
            "fused_forward": bool(getattr(model, "fused_forward", False)),
            "k0_channels_last": not model.k0.grid.is_contiguous(), "fused_loss": bool(args.fused_loss), "overlap_k0_update": bool(args.overlap),
            "tv_phase": "dense" if args.first_step + args.warmup + args.steps - 1 < TRUCK_CFG["tv_dense_before"] else "masked",
-           "touch_bitmap": bool(_gradpool.touch_enabled), "k0_grad_lines_touched_frac": touched,
+           "touch_bitmap": bool(_gradpool.touch_enabled), "lazy_loss": bool(getattr(args, "lazy_loss", 0)), "k0_grad_lines_touched_frac": touched,
            "ms_per_step": total, "phases_ms": ms, "steps": args.steps, "survivors_M": M, "samples": args.rays * S,
            "rays_per_sec": args.rays / (total * 1e-3), "k0_voxels": n_k0,
            "k0_streaming_floor_ms": {"note": "compulsory HBM passes over the 3.46 GB k0-sized arrays per step at 6.3 TB/s achievable: "

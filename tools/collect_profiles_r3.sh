@@ -11,7 +11,7 @@ cp $T/pmc_csv/*.csv $P/pmc/
 cp $T/pmc_summary.json $P/pmc_summary.json
 cp $T/prof/s1_kernel_stats.csv $P/bench_s1_kernel_stats.csv
 tail -1 $T/bench_line.json > $P/bench_s1_line.json
-for f in bench_2rank_shared_gpu.json bench_dist_1rank_rccl.json dcvgo_1080p.json shade_pc12_phases.txt ray_order_guard.json pytest_gpu.log smoke.log; do
+for f in bench_2rank_shared_gpu.json bench_dist_1rank_rccl.json dcvgo_1080p.json dvgo_lego_800.json train_step_s3.jsonl train_step_timeline_masked_final.txt shade_pc12_phases.txt ray_order_guard.json pytest_gpu.log smoke.log; do
   [ -s $T/$f ] && cp $T/$f $P/$f
 done
 python - <<'PY'

@@ -30,6 +30,21 @@ timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --mast
 timeout 900 python tools/bench_dcvgo.py --out $OUT/dcvgo_1080p.json 2>$OUT/dcvgo_err.txt | cut -c1-600; tail -2 $OUT/dcvgo_err.txt | grep -v amdgpu.ids
 UGRID_LIB=build/ab/lib_pc12_prof.so timeout 300 python tools/gpu_shade_pc_prof.py s1 2 2>/dev/null > $OUT/shade_pc12_phases.txt; head -8 $OUT/shade_pc12_phases.txt
 timeout 300 python tools/gpu_ray_order.py > $OUT/ray_order_guard.json 2>/dev/null; cat $OUT/ray_order_guard.json | cut -c1-500
+# 5b. bounded DVGO at the lego size; S3 training step, both TV phases (+ without the per-step host read of loss / psnr); kernel
+#     timeline of one masked-phase step
+timeout 600 python tools/bench_dvgo.py --out $OUT/dvgo_lego_800.json 2>/dev/null | cut -c1-400
+: > $OUT/train_step_s3.jsonl
+for ph in 1 10001; do
+  timeout 600 python tools/bench_train_step.py --steps 30 --first-step $ph 2>/dev/null | tail -1 >> $OUT/train_step_s3.jsonl
+  timeout 600 python tools/bench_train_step.py --steps 30 --first-step $ph --lazy-loss 1 2>/dev/null | tail -1 >> $OUT/train_step_s3.jsonl
+done
+python - $OUT/train_step_s3.jsonl <<'PY'
+import json, sys
+for l in open(sys.argv[1]):
+    d = json.loads(l); print(d['tv_phase'], '%.3f ms' % d['ms_per_step'], {k: round(v, 3) for k, v in d['phases_ms'].items()}, d['survivors_M'], d.get('k0_grad_lines_touched_frac'))
+PY
+( cd /tmp && timeout 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_ts -o p -- python $R/tools/bench_train_step.py --steps 20 --first-step 10001 > /tmp/log_ts.txt 2>&1 < /dev/null )
+f=$(find /tmp/prof_ts -name "*kernel_trace.csv" | head -1); [ -n "$f" ] && python tools/step_timeline.py "$f" --step 15 > $OUT/train_step_timeline_masked_final.txt; tail -1 $OUT/train_step_timeline_masked_final.txt
 # 6. smoke + the whole -m gpu suite
 timeout 600 python __graft_entry__.py smoke 2>&1 | tail -2 | tee $OUT/smoke.log
 timeout 2400 python -m pytest tests -m gpu -q -p no:warnings 2>&1 | tail -6 | tee $OUT/pytest_gpu.log

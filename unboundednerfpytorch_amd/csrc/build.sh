@@ -8,7 +8,7 @@ cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include"
 mkdir -p ../../build/obj
 O=../../build/obj
-rm -f $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_gather_exp.o $O/ugrid_train.o   # a failed compile must not link a stale object
+rm -f $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_gather_exp.o $O/ugrid_train.o $O/ugrid_train_mlp.o   # a failed compile must not link a stale object
 OBJS="$O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_train.o $O/ugrid_train_mlp.o"
 pids=()
 hipcc $FLAGS -c ugrid_ops.hip -o $O/ugrid_ops.o "$@" &
@@ -26,6 +26,7 @@ fi
 hipcc $FLAGS -fno-slp-vectorize ${UG_SHADE_FLAGS} -c ugrid_shade.hip -o $O/ugrid_shade.o "$@" &
 pids+=($!)
 hipcc $FLAGS -c ugrid_train.hip -o $O/ugrid_train.o "$@" &
+pids+=($!)
 hipcc $FLAGS -c ugrid_train_mlp.hip -o $O/ugrid_train_mlp.o "$@" &
 pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done   # a bare `wait` returns 0 even when a job failed

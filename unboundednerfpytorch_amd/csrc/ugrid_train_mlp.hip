@@ -77,9 +77,6 @@ k_lin(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__res
     const float *__restrict__ xr = X + (row_ok ? s : 0) * ldx + h * KH;
     const int k_base = h * KH;
     auto load4 = [&](int j0) -> float4 {           // elements j0 .. j0 + 3 of the lane's half row
-#if defined(UG_LIN_DBG) && UG_LIN_DBG == 2
-      return make_float4(1.f, 0.5f, 0.25f, (float)j0);
-#endif
       if (VEC) return row_ok ? *(const float4 *)(xr + j0) : make_float4(0.f, 0.f, 0.f, 0.f);
       float4 v;
       v.x = (row_ok && k_base + j0 + 0 < K) ? xr[j0 + 0] : 0.f;
@@ -109,13 +106,7 @@ k_lin(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__res
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#if defined(UG_LIN_DBG) && UG_LIN_DBG == 1
-          acc[t][jj] += xs[jj] * w[jj][t];
-#else
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[jj], w[jj][t], acc[t], 0, 0, 0);
-#endif
-        }
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(xs[jj], w[jj][t], acc[t], 0, 0, 0);
       xv = xn;
       xn = xnn;
     }
@@ -132,9 +123,6 @@ k_lin(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__res
         if (bias) r = r + bc;
         if (relu) r = fmaxf(r, 0.f);
         if (G && !(G[sr * ldg + c] > 0.f)) r = 0.f;
-#if defined(UG_LIN_DBG) && UG_LIN_DBG == 3
-        if (r == 123.456f)
-#endif
         Y[sr * ldy + c] = r;
       }
     }

@@ -76,7 +76,8 @@ def _mark(timers, name):
 
 
 def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_train, global_step, render_kwargs,
-                    near_thres=None, distortion_fn=None, decay_lr=True, world_size=1, timers=None, overlap_k0_update=False):
+                    near_thres=None, distortion_fn=None, decay_lr=True, world_size=1, timers=None, overlap_k0_update=False,
+                    return_tensors=False):
     """Forward ... optimizer.step() of one global_step (call maybe_scale_grids first).  Returns (loss, psnr).
     Data-parallel use (ShardedMaskedAdam averages the ranks' gradients): pass world_size so that the total-variation
     term, which the reference scales by 1 / len(rays_o), is scaled by the GLOBAL batch size and the sum-type nearclip
@@ -86,7 +87,9 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
     REDUCED gradient (grad_hook), so its masked mode sees the voxels any rank touched: the data-parallel step equals
     the single-process step on the whole batch in both TV phases (tests/test_host_logic.py).
     overlap_k0_update (single process, HIP optimizer): see ShardedMaskedAdam.step(overlap=...) -- same results; k0.grid
-    must then be read through the model (forward, state_dict, ...) or after torch.cuda.synchronize()."""
+    must then be read through the model (forward, state_dict, ...) or after torch.cuda.synchronize().
+    return_tensors: return (loss, psnr) as 0-d device tensors instead of Python floats -- no host sync at the end of the
+    iteration (the reference reads psnr.item() every step, run_train.py:297; a caller that logs every N steps need not)."""
     _mark(timers, "start")
     n_rays = len(rays_o)
     kw = render_kwargs
@@ -151,4 +154,6 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
         for g in optimizer.param_groups:
             g['lr'] = g['lr'] * factor
     psnr = -10.0 * torch.log10(mse.detach())
+    if return_tensors:
+        return loss.detach(), psnr
     return float(loss.detach()), float(psnr)
