@@ -4,6 +4,8 @@ import sys
 
 import numpy as np
 import pytest
+import types
+
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -188,6 +190,83 @@ def test_sharded_masked_adam_single_process_equals_plain_loop():
         ref_ops.masked_adam_upd(r, grads[step][0]["dens"], m, v, step + 1, 0.9, 0.99, 0.1, 1e-8)
     assert torch.equal(p.data, r)
     assert ShardedMaskedAdam.shard_len(1050, 2) == 528 and ShardedMaskedAdam.shard_len(6048, 8) == 756
+
+
+def test_step_param_updates_one_parameter_early_and_step_skips_it():
+    """ShardedMaskedAdam.step_param (what the post-accumulate-grad hook of train_iteration calls for the k0 grid): the parameter
+    is updated exactly once per iteration -- by step_param, with its TV term -- and the following step() handles the others"""
+    from oracle import ref_ops
+    from unboundednerfpytorch_amd.sharded_adam import ShardedMaskedAdam
+    params, grads = _adam_case(7)
+    tv = types.SimpleNamespace(total_variation_add_grad=ref_ops.total_variation_add_grad)
+
+    def run(early):
+        a = torch.nn.Parameter(params["k0"].clone())
+        b = torch.nn.Parameter(params["dens"].clone())
+        opt = ShardedMaskedAdam([{'params': [a, b], 'lr': 0.1, 'skip_zero_grad': True}], ops=ref_ops)
+        for step in range(2):
+            a.grad, b.grad = grads[step][0]["k0"].clone(), grads[step][0]["dens"].clone()
+            terms = {a: (1e-3, step == 0, tv), b: (2e-3, False, tv)}
+            if early:
+                assert opt.step_param(a, terms[a], overlap=False) is True
+            opt.step(tv_terms=terms)
+        assert opt.state[a]['step'] == 2 and opt.state[b]['step'] == 2
+        return a.detach().clone(), b.detach().clone()
+    (a1, b1), (a0, b0) = run(True), run(False)
+    assert torch.equal(a1, a0) and torch.equal(b1, b0)
+    p = torch.nn.Parameter(params["dens"].clone())
+    opt = ShardedMaskedAdam([{'params': [p], 'lr': 0.1, 'skip_zero_grad': True}], ops=ref_ops)
+    assert opt.step_param(p) is False                                  # no gradient: nothing done
+    q = torch.nn.Parameter(params["dens"].clone()); q.grad = torch.ones_like(q)
+    assert opt.step_param(q) is False                                  # not one of the optimizer's parameters
+
+
+def test_touched_line_bitmap_is_bound_to_buffer_and_backward():
+    """_gradpool.touch_for_backward / touch_of (host logic of the touched-line bitmap): one bitmap per gradient buffer, served
+    only for the very tensor the last backward filled, dropped when marking is off"""
+    from unboundednerfpytorch_amd import _gradpool
+    lib = types.SimpleNamespace(ugrid_touch_words=lambda n: ((n + 63) // 64 + 31) // 32)
+    _gradpool.clear()
+    try:
+        p = torch.nn.Parameter(torch.zeros(3, 4, 5, 6, 7))
+        key = id(p)
+        buf = torch.zeros_like(p)
+        t = _gradpool.touch_for_backward(key, buf, lib)
+        assert t.dtype == torch.int32 and t.numel() == ((p.numel() + 63) // 64 + 31) // 32 and not bool(t.any())
+        p.grad = buf
+        assert _gradpool.touch_of(p, p.grad) is t
+        assert _gradpool.touch_for_backward(key, buf, lib) is t           # the same buffer comes back from the pool: same bitmap
+        other = torch.zeros_like(p)
+        assert _gradpool.touch_of(p, other) is None                       # not .grad
+        p.grad = other
+        assert _gradpool.touch_of(p, p.grad) is None                      # .grad is another buffer (accumulated, user-made)
+        t2 = _gradpool.touch_for_backward(key, other, lib)                 # a second backward into a fresh buffer: new bitmap
+        assert t2 is not t and _gradpool.touch_of(p, p.grad) is t2
+        p.grad = buf
+        assert _gradpool.touch_of(p, p.grad) is None                      # the first buffer's bitmap is gone with it
+        _gradpool.touch_enabled = False
+        assert _gradpool.touch_of(p, other) is None and _gradpool.touch_for_backward(key, other, lib) is None
+        _gradpool.touch_enabled = True
+        p.grad = other
+        assert _gradpool.touch_of(p, p.grad) is None                      # an unmarked backward invalidated the bitmap
+        assert _gradpool.touch_for_backward(None, buf, lib) is None       # not a poolable parameter
+    finally:
+        _gradpool.touch_enabled = True
+        _gradpool.clear()
+
+
+def test_rgbnet_linears_recognises_only_the_default_network():
+    from unboundednerfpytorch_amd import ops
+    nn = torch.nn
+    ok = nn.Sequential(nn.Linear(39, 128), nn.ReLU(inplace=True), nn.Sequential(nn.Linear(128, 128), nn.ReLU(inplace=True)), nn.Linear(128, 3))
+    lin = ops.rgbnet_linears(ok)
+    assert lin is not None and [l.in_features for l in lin] == [39, 128, 128] and lin[2].out_features == 3
+    for bad in (nn.Sequential(nn.Linear(39, 64), nn.ReLU(), nn.Linear(64, 3)),                                  # width 64, depth 2
+                nn.Sequential(nn.Linear(39, 128), nn.ReLU(), nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 3)),
+                nn.Sequential(nn.Linear(39, 128), nn.Sigmoid(), nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 3)),   # another activation
+                nn.Sequential(nn.Linear(39, 128, bias=False), nn.ReLU(), nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 3)),
+                nn.Sequential(nn.Linear(200, 128), nn.ReLU(), nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 3))):    # input wider than 128
+        assert ops.rgbnet_linears(bad) is None
 
 
 # ---------------------------------------------------------------------------------------------------------

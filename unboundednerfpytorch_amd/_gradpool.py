@@ -63,6 +63,7 @@ def touch_for_backward(key, buf, lib):
     """the bitmap the backward of parameter `key` must mark while it scatters into `buf` (all zero on entry): the buffer's
     own bitmap if it has one, else a fresh cleared one.  None when bitmaps are off or `key` is not poolable."""
     if key is None or not (enabled and touch_enabled):
+        _TOUCH.pop(key, None)      # this backward marks nothing: a bitmap of the buffer would no longer describe it
         return None
     ent = _TOUCH.get(key)
     if ent is not None and ent[0] == buf.data_ptr() and ent[2] == buf.numel() and ent[1].device == buf.device:
