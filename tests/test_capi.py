@@ -136,7 +136,8 @@ def test_shade_shape_dispatch_table_and_loss_coefficients():
     L = _lib.load()
     assert [L.ugrid_shade_supported(*t) for t in ((3, 12, 4), (4, 12, 4), (5, 12, 4), (2, 3, 2), (3, 3, 2))] == [1] * 5
     assert [L.ugrid_shade_supported(*t) for t in ((3, 12, 8), (3, 3, 8), (3, 15, 4))] == [1] * 3   # waymo_base / mega / train_single shapes
-    assert [L.ugrid_shade_supported(*t) for t in ((4, 12, 8), (3, 9, 4), (6, 12, 4), (0, 3, 2))] == [0] * 4
+    assert L.ugrid_shade_supported(3, 9, 4) == 1                                                     # free_dataset shapes (width 64 padded)
+    assert [L.ugrid_shade_supported(*t) for t in ((4, 12, 8), (2, 9, 8), (6, 12, 4), (0, 3, 2))] == [0] * 4
     assert L.ugrid_shade_supported(0, 12, 4) == 1           # single-level k0: the fused DirectContractedVoxGO path
     gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
     small = torch.load(os.path.join(gold, "fg_ckpt_small.tar"), map_location="cpu", weights_only=False)

@@ -95,6 +95,21 @@ def test_fused_render_vs_oracle(fr, G, F, C, pe, norm, R, stepsize, dm, ds):
     assert abs(M - ref["weights"].numel()) <= max(3, int(2e-4 * M))
 
 
+def test_fused_render_narrow_rgbnet_is_zero_padded(fr):
+    """configs/free_dataset/*.py: rgbnet_dim = 9, rgbnet_width = 64 -- the renderer pads the network to the 128-wide one the
+    shade kernels are built for (zero units: same function) and must agree with the oracle evaluating the 64-wide network"""
+    G, F, C, R = 30, 3, 9, 3000
+    state = make_state(97, G, F, C, 4, "inf", 1e-4, 6.0, 12.0, width=64)
+    assert state["rgbnet_weights"][1].shape == (64, 64) and fr.rgbnet_fits_fused(state["rgbnet_weights"])
+    ws, bs = fr.pad_rgbnet_to_128(state["rgbnet_weights"], state["rgbnet_biases"])
+    assert ws[0].shape == (128, C + 27) and ws[1].shape == (128, 128) and ws[2].shape == (3, 128) and float(ws[1][64:].abs().max()) == 0
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(98, R)]
+    ref = model_oracle.fouriergrid_render(state, o, d, v, 0.5, render_depth=True, return_margin=True)
+    rend = fr.FourierGridRenderer(state, "cuda:0")
+    worst = check_render(rend(o.cuda(), d.cuda(), v.cuda(), stepsize=0.5, render_depth=True), ref, R)
+    assert ref["weights"].numel() > R and worst["rgb_marched"] < 5e-5
+
+
 def test_fused_render_non_cubic_grid(fr):
     """X != Y != Z: the cell addressing of the packed bricks (fp32 row index, 24-bit multiplies, z-fastest records)
     must use the right extent per axis in the pack, march and shade kernels."""

@@ -19,10 +19,10 @@ FG_CASES = [
 ]
 
 
-def make_state(seed, G, F, C, pe, norm, thres, dm, ds):
+def make_state(seed, G, F, C, pe, norm, thres, dm, ds, width=128):
     """Plain-tensor model state equivalent to FourierGridModel(xyz_min=-1, xyz_max=1, num_voxels=G^3,
     alpha_init=1e-4, bg_len=0.2) with synthetic parameters."""
-    p = synth.fouriergrid_params(seed, G, F, C, viewbase_pe=pe, dens_mean=dm, dens_std=ds)
+    p = synth.fouriergrid_params(seed, G, F, C, width=width, viewbase_pe=pe, dens_mean=dm, dens_std=ds)
     names = ['rgbnet.0'] + ['rgbnet.%d.0' % i for i in range(2, 3)] + ['rgbnet.3']
     ws = [torch.from_numpy(p[n + '.weight']) for n in names] if C > 0 else []
     bs = [torch.from_numpy(p[n + '.bias']) for n in names] if C > 0 else []

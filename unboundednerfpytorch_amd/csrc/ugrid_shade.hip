@@ -589,7 +589,8 @@ static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const 
     if (mlp_mode == UGRID_MLP_FP16X2) return ug_shade_launch_nw<F, C, PE, 8, 2>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
   }
   if (mlp_mode == UGRID_MLP_BF16X3) return ug_shade_launch_nw<F, C, PE, 8, 1>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-  return ug_shade_launch_nw<F, C, PE, 8, 0>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+  if constexpr (C == 9) return (int)hipErrorNotSupported;      // (the exact-fp32 MFMA variant of this shape needs scratch: not built)
+  else return ug_shade_launch_nw<F, C, PE, 8, 0>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
 }
 
 extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *viewdirs, const float *k0_bricks,
@@ -613,8 +614,9 @@ extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *vie
 // rgbnet_dim = 3, viewbase_pe = 2 (configs/waymo/waymo_no_block.py:144-149)
 // F = 0: single-level k0 (DirectContractedVoxGO / DenseGrid models, configs/nerf_unbounded/*.py: rgbnet_dim 12)
 // viewbase_pe = 8 (configs/waymo/waymo_base.py, configs/mega/*.py; rgbnet_dim 3 in mega/building_no_block.py); rgbnet_dim = 15
-// (configs/tankstemple_unbounded/train_single.py)
-#define UG_SHADE_TRIPLES(X) X(3, 12, 4) X(4, 12, 4) X(5, 12, 4) X(2, 12, 4) X(1, 12, 4) X(0, 12, 4) X(2, 3, 2) X(3, 3, 2) X(3, 12, 8) X(3, 3, 8) X(3, 15, 4)
+// (configs/tankstemple_unbounded/train_single.py); rgbnet_dim = 9 (configs/free_dataset/*.py, whose rgbnet_width = 64 the host
+// pads to 128: fourier_render.pad_rgbnet_to_128)
+#define UG_SHADE_TRIPLES(X) X(3, 12, 4) X(4, 12, 4) X(5, 12, 4) X(2, 12, 4) X(1, 12, 4) X(0, 12, 4) X(2, 3, 2) X(3, 3, 2) X(3, 12, 8) X(3, 3, 8) X(3, 15, 4) X(3, 9, 4)
 #define UG_SHADE_CASE(F_, C_, PE_)                                                          \
   if (p->freq_num == F_ && p->k0_channels == C_ && p->viewbase_pe == PE_)                   \
     return ug_shade_launch<F_, C_, PE_>(a, viewdirs, k0_bricks, mlp_packed, ws, rgb_marched, counter, p->mlp_mode, ST(s));

@@ -79,8 +79,9 @@ class DirectContractedVoxGORenderer:
         if len(s['rgbnet_weights']) == 0:
             return C == 3
         from . import _lib
+        from .fourier_render import rgbnet_fits_fused
         w = s['rgbnet_weights']
-        return (len(w) == 3 and tuple(w[1].shape) == (128, 128) and w[2].shape[0] == 3 and w[0].shape[1] == C + 3 + 6 * int(s['viewbase_pe'])
+        return (rgbnet_fits_fused(w) and w[0].shape[1] == C + 3 + 6 * int(s['viewbase_pe'])
                 and bool(_lib.load().ugrid_shade_supported(0, C, int(s['viewbase_pe']))))
 
     @torch.no_grad()

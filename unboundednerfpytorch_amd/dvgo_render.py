@@ -90,8 +90,9 @@ class DirectVoxGORenderer:
         if len(s['rgbnet_weights']) == 0:
             return C == 3
         from . import _lib
+        from .fourier_render import rgbnet_fits_fused
         w = s['rgbnet_weights']
-        return (bool(s['rgbnet_direct']) and len(w) == 3 and tuple(w[1].shape) == (128, 128) and w[2].shape[0] == 3
+        return (bool(s['rgbnet_direct']) and rgbnet_fits_fused(w)
                 and w[0].shape[1] == C + 3 + 6 * int(s['viewbase_pe'])
                 and bool(_lib.load().ugrid_shade_supported(0, C, int(s['viewbase_pe']))))
 

@@ -41,6 +41,26 @@ def sample_table(world_len, stepsize, bg_len, t_boundary=1.5):  # noqa: E302  (d
     return t, s
 
 
+def rgbnet_fits_fused(ws):
+    """rgbnet_depth = 3 with any width up to 128 (configs/default.py:104-105; free_dataset/*.py: width 64)"""
+    return (len(ws) == 3 and ws[0].dim() == 2 and ws[1].dim() == 2 and ws[1].shape[0] == ws[1].shape[1] == ws[0].shape[0] <= 128
+            and tuple(ws[2].shape) == (3, ws[1].shape[0]))
+
+
+def pad_rgbnet_to_128(ws, bs):
+    """A depth-3 rgbnet of width w < 128 as the 128-wide network the shade kernels are built for: units w..127 get zero weights
+    and zero biases, so they output relu(0) = 0 and contribute exact zeros to the next layer's sums -- the function is unchanged."""
+    w = ws[1].shape[0]
+    if w == 128:
+        return list(ws), list(bs)
+    w0 = ws[0].new_zeros(128, ws[0].shape[1]); w0[:w] = ws[0]
+    w1 = ws[1].new_zeros(128, 128); w1[:w, :w] = ws[1]
+    w2 = ws[2].new_zeros(3, 128); w2[:, :w] = ws[2]
+    b0 = bs[0].new_zeros(128); b0[:w] = bs[0]
+    b1 = bs[1].new_zeros(128); b1[:w] = bs[1]
+    return [w0, w1, w2], [b0, b1, bs[2]]
+
+
 class FourierGridRenderer:
     """Fused render of a trained FourierGridModel.
 
@@ -127,9 +147,10 @@ class FourierGridRenderer:
                 self.k0_bricks = torch.empty(_L.ugrid_brick_bytes(P, self.C, X, Y, Z, 0) // 4, dtype=torch.float32, device=dev)
                 _lib.check(_L.ugrid_pack_bricks(_p(kg), P, self.C, X, Y, Z, 0, _p(self.k0_bricks), st), "pack k0")
                 ws_, bs_ = state["rgbnet_weights"], state["rgbnet_biases"]
-                if len(ws_) != 3 or ws_[1].shape != (128, 128) or ws_[2].shape[0] != 3:
-                    raise RuntimeError("fused shade supports rgbnet_depth=3, rgbnet_width=128 "
+                if not rgbnet_fits_fused(ws_):
+                    raise RuntimeError("fused shade supports rgbnet_depth=3, rgbnet_width <= 128 "
                                        "(configs/default.py:104-105)")
+                ws_, bs_ = pad_rgbnet_to_128([x.to(dev, torch.float32) for x in ws_], [x.to(dev, torch.float32) for x in bs_])
                 self.mlp_in = int(ws_[0].shape[1])
                 if self.mlp_in != self.C + 3 + 6 * self.pe:
                     raise RuntimeError("rgbnet input width must be C + 3 + 6*viewbase_pe")
@@ -481,7 +502,7 @@ _FUSED_TRIPLES = None
 
 
 def fused_shape_supported(ckpt):
-    """Can the fused march / shade kernels render this reference checkpoint?  (rgbnet depth 3 x width 128 or no rgbnet,
+    """Can the fused march / shade kernels render this reference checkpoint?  (rgbnet depth 3 x width <= 128 or no rgbnet,
     one grid resolution, fast_color_thres > 0, an instantiated (F, C, viewbase_pe) triple)"""
     kw, sd = ckpt['model_kwargs'], ckpt['model_state_dict']
     if kw.get('fast_color_thres', 0) <= 0 or tuple(sd['density.grid'].shape[2:]) != tuple(sd['k0.grid'].shape[2:]):
@@ -489,7 +510,7 @@ def fused_shape_supported(ckpt):
     F, C, pe = int(kw.get('fourier_freq_num', 5)), int(sd['k0.grid'].shape[1]), int(kw.get('viewbase_pe', 4))
     if kw.get('rgbnet_dim', 0) <= 0:
         return C == 3 and sd['k0.grid'].shape[0] == 1
-    if kw.get('rgbnet_depth', 3) != 3 or kw.get('rgbnet_width', 128) != 128:
+    if kw.get('rgbnet_depth', 3) != 3 or not (1 <= kw.get('rgbnet_width', 128) <= 128):
         return False
     return bool(_L.ugrid_shade_supported(F, C, pe))
 
