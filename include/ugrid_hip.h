@@ -228,11 +228,12 @@ int ugrid_tv_adam_dense_cl_touch(const float *param, float *param_out, const flo
 /* The rgbnet of the training step (FourierGrid_model.py:233-241, :636: Linear(mlp_in,128)-ReLU-Linear(128,128)-ReLU-Linear(128,3)
  * on the M surviving samples) and its derivative as fp32-MFMA kernels (csrc/ugrid_train_mlp.hip), replacing the library GEMMs of
  * torch's nn.Linear forward / backward whose host overhead dominates at M ~ 1e5.  nn.Linear layouts: w0 [128, mlp_in], w1 [128,128],
- * w2 [3,128]; feat [M, mlp_in] row-major.  forward: h1, h2 [M,128] (post-ReLU activations, kept for the backward), logits [M,3].
+ * w2 [3,128] (128 = `width`); feat [M, mlp_in] row-major.  forward: h1, h2 [M,128] (post-ReLU activations, kept for the backward),
+ * logits [M,3].
  * backward: g_w*, g_b* (overwritten, not accumulated), g_feat [M, n_feat_grad] = the gradient of the first n_feat_grad input
  * columns (the k0 features; 0 / NULL = none); scratch: ugrid_rgbnet_train_scratch_floats(M) floats.  fp32 products and
- * accumulation; the weight gradients are sums of <= 256 slab partials added in a fixed order (deterministic).  width must be
- * 128, mlp_in <= 128. */
+ * accumulation; the weight gradients are sums of <= 256 slab partials added in a fixed order (deterministic).  width <= 128
+ * (h1 / h2 are [M, width], w0 [width, mlp_in], w1 [width, width], w2 [3, width]), mlp_in <= 128. */
 int64_t ugrid_rgbnet_train_scratch_floats(int64_t M);
 int ugrid_rgbnet_train_forward(const float *feat, int64_t M, int32_t mlp_in, const float *w0, const float *b0, const float *w1,
                                const float *b1, const float *w2, const float *b2, int32_t width, float *h1, float *h2,

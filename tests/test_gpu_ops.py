@@ -508,18 +508,19 @@ def test_masked_adam_rezero_grad_returns_the_gradient_buffer_all_zero(n):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("M,C,E", [(5000, 12, 27), (33, 12, 27), (1, 3, 15), (4097, 15, 27), (2500, 12, 51), (70000, 12, 27)])
-def test_fused_rgbnet_matches_torch_linear_layers(M, C, E):
+@pytest.mark.parametrize("M,C,E,W", [(5000, 12, 27, 128), (33, 12, 27, 128), (1, 3, 15, 128), (4097, 15, 27, 128), (2500, 12, 51, 128),
+                                     (70000, 12, 27, 128), (3000, 9, 27, 64), (777, 9, 27, 40)])
+def test_fused_rgbnet_matches_torch_linear_layers(M, C, E, W):
     """ops.FusedRgbnet (fp32-MFMA kernels, csrc/ugrid_train_mlp.hip) vs the same three nn.Linear layers through torch: logits and
     every gradient (k0 features, weights, biases); fp32 products on both sides, so only the summation order differs"""
     from unboundednerfpytorch_amd import ops
     torch.manual_seed(M + C)
-    net = torch.nn.Sequential(torch.nn.Linear(C + E, 128), torch.nn.ReLU(inplace=True),
-                              torch.nn.Sequential(torch.nn.Linear(128, 128), torch.nn.ReLU(inplace=True)), torch.nn.Linear(128, 3)).cuda()
+    net = torch.nn.Sequential(torch.nn.Linear(C + E, W), torch.nn.ReLU(inplace=True),
+                              torch.nn.Sequential(torch.nn.Linear(W, W), torch.nn.ReLU(inplace=True)), torch.nn.Linear(W, 3)).cuda()
     with torch.no_grad():
         net[3].bias.normal_(0, 0.1)
     lin = ops.rgbnet_linears(net)
-    assert lin is not None and [l.in_features for l in lin] == [C + E, 128, 128]
+    assert lin is not None and [l.in_features for l in lin] == [C + E, W, W]
     assert ops.rgbnet_linears(torch.nn.Sequential(torch.nn.Linear(C + E, 64), torch.nn.ReLU(), torch.nn.Linear(64, 3))) is None
     k0 = torch.randn(M, C, device="cuda", requires_grad=True)
     emb = torch.randn(M, E, device="cuda")

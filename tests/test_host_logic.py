@@ -261,7 +261,11 @@ def test_rgbnet_linears_recognises_only_the_default_network():
     ok = nn.Sequential(nn.Linear(39, 128), nn.ReLU(inplace=True), nn.Sequential(nn.Linear(128, 128), nn.ReLU(inplace=True)), nn.Linear(128, 3))
     lin = ops.rgbnet_linears(ok)
     assert lin is not None and [l.in_features for l in lin] == [39, 128, 128] and lin[2].out_features == 3
-    for bad in (nn.Sequential(nn.Linear(39, 64), nn.ReLU(), nn.Linear(64, 3)),                                  # width 64, depth 2
+    narrow = nn.Sequential(nn.Linear(36, 64), nn.ReLU(), nn.Linear(64, 64), nn.ReLU(), nn.Linear(64, 3))               # free_dataset: width 64
+    assert [l.out_features for l in ops.rgbnet_linears(narrow)] == [64, 64, 3]
+    for bad in (nn.Sequential(nn.Linear(39, 64), nn.ReLU(), nn.Linear(64, 3)),                                  # depth 2
+                nn.Sequential(nn.Linear(39, 256), nn.ReLU(), nn.Linear(256, 256), nn.ReLU(), nn.Linear(256, 3)),    # wider than 128
+                nn.Sequential(nn.Linear(39, 64), nn.ReLU(), nn.Linear(64, 128), nn.ReLU(), nn.Linear(128, 3)),      # unequal widths
                 nn.Sequential(nn.Linear(39, 128), nn.ReLU(), nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 3)),
                 nn.Sequential(nn.Linear(39, 128), nn.Sigmoid(), nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 3)),   # another activation
                 nn.Sequential(nn.Linear(39, 128, bias=False), nn.ReLU(), nn.Linear(128, 128), nn.ReLU(), nn.Linear(128, 3)),

@@ -315,32 +315,34 @@ extern "C" int64_t ugrid_rgbnet_train_scratch_floats(int64_t M) {
 extern "C" int ugrid_rgbnet_train_forward(const float *feat, int64_t M, int32_t mlp_in, const float *w0, const float *b0,
                                           const float *w1, const float *b1, const float *w2, const float *b2, int32_t width,
                                           float *h1, float *h2, float *logits, ugrid_stream_t s) {
-  if (width != 128 || mlp_in < 1 || mlp_in > 128) return (int)hipErrorNotSupported;
-  int rc = ug_lin_launch(feat, M, mlp_in, mlp_in, w0, mlp_in, 128, 0, b0, 1, nullptr, 0, h1, 128, ST(s));
+  if (width < 1 || width > 128 || mlp_in < 1 || mlp_in > 128) return (int)hipErrorNotSupported;
+  const int W = width;
+  int rc = ug_lin_launch(feat, M, mlp_in, mlp_in, w0, mlp_in, W, 0, b0, 1, nullptr, 0, h1, W, ST(s));
   if (rc) return rc;
-  rc = ug_lin_launch(h1, M, 128, 128, w1, 128, 128, 0, b1, 1, nullptr, 0, h2, 128, ST(s));
+  rc = ug_lin_launch(h1, M, W, W, w1, W, W, 0, b1, 1, nullptr, 0, h2, W, ST(s));
   if (rc) return rc;
-  return ug_lin_launch(h2, M, 128, 128, w2, 128, 3, 0, b2, 0, nullptr, 0, logits, 3, ST(s));
+  return ug_lin_launch(h2, M, W, W, w2, W, 3, 0, b2, 0, nullptr, 0, logits, 3, ST(s));
 }
 
 extern "C" int ugrid_rgbnet_train_backward(const float *g_logits, const float *feat, const float *h1, const float *h2, int64_t M,
                                            int32_t mlp_in, int32_t n_feat_grad, const float *w0, const float *w1, const float *w2,
                                            int32_t width, float *g_feat, float *g_w0, float *g_b0, float *g_w1, float *g_b1,
                                            float *g_w2, float *g_b2, float *scratch, ugrid_stream_t s) {
-  if (width != 128 || mlp_in < 1 || mlp_in > 128 || n_feat_grad < 0 || n_feat_grad > mlp_in) return (int)hipErrorNotSupported;
-  float *g_h2 = scratch, *g_h1 = scratch + (size_t)M * 128;         // [M,128] each
+  if (width < 1 || width > 128 || mlp_in < 1 || mlp_in > 128 || n_feat_grad < 0 || n_feat_grad > mlp_in) return (int)hipErrorNotSupported;
+  const int W = width;
+  float *g_h2 = scratch, *g_h1 = scratch + (size_t)M * 128;         // [M,W] each (room for W = 128)
   float *part = scratch + (size_t)2 * M * 128;                      // slab partials of the weight gradients
-  int rc = ug_wgrad_launch(g_logits, 3, 3, h2, 128, 128, M, g_w2, g_b2, part, ST(s));                        // dW3, db3
+  int rc = ug_wgrad_launch(g_logits, 3, 3, h2, W, W, M, g_w2, g_b2, part, ST(s));                            // dW3, db3
   if (rc) return rc;
-  rc = ug_lin_launch(g_logits, M, 3, 3, w2, 128, 128, 1, nullptr, 0, h2, 128, g_h2, 128, ST(s));                   // dH2 = dL . W3, ReLU mask
+  rc = ug_lin_launch(g_logits, M, 3, 3, w2, W, W, 1, nullptr, 0, h2, W, g_h2, W, ST(s));                      // dH2 = dL . W3, ReLU mask
   if (rc) return rc;
-  rc = ug_wgrad_launch(g_h2, 128, 128, h1, 128, 128, M, g_w1, g_b1, part, ST(s));                             // dW2, db2
+  rc = ug_wgrad_launch(g_h2, W, W, h1, W, W, M, g_w1, g_b1, part, ST(s));                                     // dW2, db2
   if (rc) return rc;
-  rc = ug_lin_launch(g_h2, M, 128, 128, w1, 128, 128, 1, nullptr, 0, h1, 128, g_h1, 128, ST(s));                   // dH1 = dH2 . W2, ReLU mask
+  rc = ug_lin_launch(g_h2, M, W, W, w1, W, W, 1, nullptr, 0, h1, W, g_h1, W, ST(s));                          // dH1 = dH2 . W2, ReLU mask
   if (rc) return rc;
-  rc = ug_wgrad_launch(g_h1, 128, 128, feat, mlp_in, mlp_in, M, g_w0, g_b0, part, ST(s));                     // dW1, db1
+  rc = ug_wgrad_launch(g_h1, W, W, feat, mlp_in, mlp_in, M, g_w0, g_b0, part, ST(s));                         // dW1, db1
   if (rc) return rc;
   if (n_feat_grad > 0 && g_feat)                                                                            // d feat[:, :n] = dH1 . W1[:, :n]
-    rc = ug_lin_launch(g_h1, M, 128, 128, w0, mlp_in, n_feat_grad, 1, nullptr, 0, nullptr, 0, g_feat, n_feat_grad, ST(s));
+    rc = ug_lin_launch(g_h1, M, W, W, w0, mlp_in, n_feat_grad, 1, nullptr, 0, nullptr, 0, g_feat, n_feat_grad, ST(s));
   return rc;
 }

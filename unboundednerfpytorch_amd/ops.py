@@ -163,8 +163,8 @@ class SplitKLinear(torch.autograd.Function):
 
 
 def rgbnet_linears(net):
-    """the three nn.Linear layers of an rgbnet of the reference's default shape (Linear(k,128)-ReLU-[Linear(128,128)-ReLU]-
-    Linear(128,3), FourierGrid_model.py:233-241) or None for any other network (depth, width, extra layers)"""
+    """the three nn.Linear layers of an rgbnet of the reference's default depth (Linear(k,W)-ReLU-[Linear(W,W)-ReLU]-Linear(W,3),
+    W <= 128, k <= 128: FourierGrid_model.py:233-241) or None for any other network (depth, wider, extra layers)"""
     lin, other = [], []
     for m in net.modules():
         if isinstance(m, torch.nn.Linear):
@@ -173,7 +173,8 @@ def rgbnet_linears(net):
             other.append(m)
     if other or len(lin) != 3 or any(l.bias is None for l in lin):
         return None
-    if lin[0].out_features != 128 or lin[1].in_features != 128 or lin[1].out_features != 128 or lin[2].in_features != 128 \
+    W = lin[0].out_features
+    if not (1 <= W <= 128) or lin[1].in_features != W or lin[1].out_features != W or lin[2].in_features != W \
             or lin[2].out_features != 3 or lin[0].in_features > 128:
         return None
     return lin
@@ -193,11 +194,12 @@ class FusedRgbnet(torch.autograd.Function):
         _lib.require_cuda(("k0", k0), ("emb", emb), *[("rgbnet", t) for t in ws])
         _lib.require_f32(("k0", k0), ("emb", emb), *[("rgbnet", t) for t in ws])
         dev = feat.device
-        h1 = torch.empty(M, 128, device=dev)
-        h2 = torch.empty(M, 128, device=dev)
+        W = ws[0].shape[0]
+        h1 = torch.empty(M, W, device=dev)
+        h2 = torch.empty(M, W, device=dev)
         logits = torch.empty(M, 3, device=dev)
         with _lib.guard(dev):
-            _lib.check(_L.ugrid_rgbnet_train_forward(_lib.ptr(feat), M, K, *[_lib.ptr(t) for t in ws], 128, _lib.ptr(h1), _lib.ptr(h2),
+            _lib.check(_L.ugrid_rgbnet_train_forward(_lib.ptr(feat), M, K, *[_lib.ptr(t) for t in ws], W, _lib.ptr(h1), _lib.ptr(h2),
                                                      _lib.ptr(logits), _lib.stream_of(feat)), "rgbnet_train_forward")
         ctx.save_for_backward(feat, h1, h2, ws[0], ws[2], ws[4])
         ctx.C = k0.shape[1]
@@ -213,12 +215,13 @@ class FusedRgbnet(torch.autograd.Function):
         g_logits = g_logits.to(torch.float32).contiguous()
         n_fg = ctx.C if ctx.need_k0 else 0
         g_k0 = torch.empty(M, n_fg, device=dev) if n_fg else None
-        g = [torch.empty_like(w0), torch.empty(128, device=dev), torch.empty_like(w1), torch.empty(128, device=dev),
+        W = w0.shape[0]
+        g = [torch.empty_like(w0), torch.empty(W, device=dev), torch.empty_like(w1), torch.empty(W, device=dev),
              torch.empty_like(w2), torch.empty(3, device=dev)]
         scratch = torch.empty(int(_L.ugrid_rgbnet_train_scratch_floats(M)), device=dev)
         with _lib.guard(dev):
             _lib.check(_L.ugrid_rgbnet_train_backward(_lib.ptr(g_logits), _lib.ptr(feat), _lib.ptr(h1), _lib.ptr(h2), M, K, n_fg,
-                                                      _lib.ptr(w0), _lib.ptr(w1), _lib.ptr(w2), 128, _lib.ptr(g_k0) if n_fg else None,
+                                                      _lib.ptr(w0), _lib.ptr(w1), _lib.ptr(w2), W, _lib.ptr(g_k0) if n_fg else None,
                                                       *[_lib.ptr(t) for t in g], _lib.ptr(scratch), _lib.stream_of(feat)),
                        "rgbnet_train_backward")
         return (g_k0, None, *g)
