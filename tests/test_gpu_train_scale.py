@@ -116,6 +116,33 @@ def test_fused_sampling_stage2_equals_the_separate_ops_bit_for_bit():
             assert torch.equal(ga != 0, gb != 0), k             # the same voxels are touched (MaskedAdam keys on them)
 
 
+def test_training_iteration_survives_an_empty_scene():
+    """every density far below the alpha threshold: no stage-1 sample, no stage-2 sample -- the fused sampling, the k0 lookup,
+    the rgbnet kernels, the loss and the optimizer must all cope with M = 0 (gradients zero, alphainv_last = 1)"""
+    import bench_train_step as bts
+    from unboundednerfpytorch_amd import train_step as ts
+    from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
+    dev = torch.device("cuda", 0)
+    m = build(dev, G=40)
+    with torch.no_grad():
+        m.density.grid.fill_(-60.0)
+    o, d, v, rgb = bts.random_rays(777, dev, seed=11)
+    out = m(o, d, v, global_step=1, is_train=True, stepsize=0.5, render_depth=True)
+    assert out["weights"].numel() == 0 and out["ray_id"].numel() == 0 and out["raw_density"].numel() == 0
+    assert torch.equal(out["alphainv_last"], torch.ones(777, device=dev)) and float(out["rgb_marched"].abs().max()) == 0
+    opt = create_optimizer_or_freeze_model(m, bts.TRUCK_CFG, global_step=0)
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    for step in (1, 10001):                       # dense-TV phase, masked-TV phase
+        loss, psnr = ts.train_iteration(m, opt, o, d, v, rgb, bts.TRUCK_CFG, step, dict(stepsize=0.5, rand_bkgd=False),
+                                        overlap_k0_update=True)
+        assert loss == loss and psnr == psnr      # finite
+    torch.cuda.synchronize()
+    for k, p in m.named_parameters():
+        assert torch.isfinite(p).all(), k
+        if "rgbnet" in k:
+            assert torch.equal(p, before[k]), k   # no sample reached the network: zero gradient, Adam leaves it alone
+
+
 def test_channel_last_k0_model_equals_the_canonical_layout_model():
     """fourier_model.FourierGridModel stores k0 channel-last on the HIP ops; with channels_last_grids=False it keeps the
     reference's row-major parameter.  Same state dict in, same forward, gradients equal up to the atomics' order,

@@ -222,7 +222,7 @@ extern "C" int ugrid_render_loss(const float *logits, const float *weights, cons
                                  const float *bg, const float *target, const int64_t *ray_id, int64_t n, int64_t n_rays,
                                  const float *h_coef8, int64_t *seg_scratch, float *rgb_marched, float *ray_tot,
                                  float *partial, float *out2, ugrid_stream_t st) {
-  if (n_rays <= 0 || (!s && !t)) return (int)hipErrorInvalidValue;
+  if (n_rays <= 0 || (n > 0 && !s && !t)) return (int)hipErrorInvalidValue;      // (no samples: empty arrays have no address)
   int64_t *i_start = seg_scratch, *i_end = seg_scratch + n_rays;
   UG_HIP(hipMemsetAsync(seg_scratch, 0, sizeof(int64_t) * 2 * n_rays, ST(st)));
   if (n > 0) hipLaunchKernelGGL(k_loss_segments, dim3(ug_blocks(n, 256)), dim3(256), 0, ST(st), ray_id, n, i_start, i_end);
