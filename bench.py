@@ -489,7 +489,7 @@ def s3_train_step_block(device):
         import bench_train_step as bts
         out = {}
         for phase, first in (("dense_tv", 1), ("masked_tv", 10001)):
-            r = bts.run(bts.parse(["--steps", "8", "--warmup", "3", "--first-step", str(first)]))
+            r = bts.run(bts.parse(["--steps", "20", "--warmup", "4", "--first-step", str(first)]))
             out[phase] = {k: r[k] for k in ("ms_per_step", "phases_ms", "survivors_M", "samples", "rays_per_sec", "tv_phase", "loss", "psnr")}
             out["workload"] = r["workload"]
             torch.cuda.empty_cache()
