@@ -119,3 +119,22 @@ def test_dcvgo_fused_render_equals_the_composed_forward_at_scale(norm, C):
     out2 = rend.render_rays(o, d, v, stepsize=0.5, bg=bg, render_depth=True, ray_order="coherent")
     for k in ("alphainv_last", "rgb_marched", "depth", "wsum_mid"):
         assert torch.equal(out[k], out2[k]), k
+
+
+@pytest.mark.gpu
+def test_dcvgo_render_view_equals_render_rays_on_the_image_rays():
+    from unboundednerfpytorch_amd.dcvgo_render import DirectContractedVoxGORenderer
+    from unboundednerfpytorch_amd.fourier_render import get_rays_of_a_view
+    state, _ = dcvgo_state(81, 40, 40, 12, "inf", 2.0, 6.0)
+    rend = DirectContractedVoxGORenderer(state, "cuda:0")
+    assert rend.fused_supported()
+    H, W = 64, 96
+    K = [[90.0, 0, W / 2], [0, 90.0, H / 2], [0, 0, 1]]
+    c2w = torch.tensor([[1.0, 0, 0, 0.1], [0, 0.8, 0.6, -0.2], [0, -0.6, 0.8, 0.3]])
+    bg = torch.tensor([0.2, 0.5, 0.9], device="cuda")
+    img = rend.render_view(H, W, K, c2w, stepsize=0.5, bg=bg, render_depth=True)
+    o, d, v = [x.reshape(-1, 3).contiguous().cuda() for x in get_rays_of_a_view(H, W, K, c2w)]
+    ref = rend.render_rays(o, d, v, stepsize=0.5, bg=bg, render_depth=True)
+    assert set(img) == {"rgb_marched", "depth", "alphainv_last", "wsum_mid"} and img["rgb_marched"].shape == (H, W, 3)
+    for k in img:
+        assert torch.equal(img[k].reshape(ref[k].shape), ref[k]), k

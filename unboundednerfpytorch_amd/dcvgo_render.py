@@ -117,6 +117,15 @@ class DirectContractedVoxGORenderer:
             self._tables[key] = t.to(self.device)
         return self._tables[key]
 
+    def render_view(self, H, W, K, c2w, inverse_y=False, flip_x=False, flip_y=False, **render_kwargs):
+        """One whole view through render_rays (fourier_render.render_view_of): {key: [H,W(,3)]} of the per-ray outputs."""
+        from .fourier_render import render_view_of
+        if not self.fused_supported():      # the composed forward takes no ray_order
+            rr = lambda o, d, v, ray_order=None, **kw: self.render_rays(o, d, v, **kw)
+        else:
+            rr = self.render_rays
+        return render_view_of(rr, self.device, H, W, K, c2w, inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y, **render_kwargs)
+
     @torch.no_grad()
     def forward(self, rays_o, rays_d, viewdirs, global_step=None, **render_kwargs):
         s = self.s

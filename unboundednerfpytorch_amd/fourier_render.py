@@ -497,6 +497,23 @@ class FourierGridRenderer:
         return cls(state_from_reference_checkpoint(ckpt), device, **kw)
 
 
+def render_view_of(render_rays, device, H, W, K, c2w, inverse_y=False, flip_x=False, flip_y=False, **render_kwargs):
+    """One whole view through a per-ray renderer (`render_rays(rays_o, rays_d, viewdirs, **render_kwargs)` -> dict of per-ray
+    tensors: the bounded / contracted VoxGO renderers' fused paths): rays generated on the device in 8 x 8 pixel blocks, one
+    pass, results put back in image order -- the body of the reference's render loop (run_render.py:41-70) without its 8192-ray
+    chunks.  Returns {key: [H,W(,3)]} on the device."""
+    dev = torch.device(device)
+    c2w = torch.as_tensor(c2w, dtype=torch.float32).to(dev)
+    order = pixel_tile_order(H, W, dev)
+    if order is not None:
+        ro, rd, vd = get_rays_of_pixel_index(H, W, K, c2w, order, inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y)
+        out = render_rays(ro, rd, vd, ray_order="coherent", **render_kwargs)
+        return {k: untile(v, H, W).reshape(H, W, *v.shape[1:]) for k, v in out.items() if torch.is_tensor(v)}
+    ro, rd, vd = get_rays_of_a_view(H, W, K, c2w, inverse_y=inverse_y, flip_x=flip_x, flip_y=flip_y)
+    out = render_rays(ro.reshape(-1, 3).contiguous(), rd.reshape(-1, 3).contiguous(), vd.reshape(-1, 3).contiguous(), **render_kwargs)
+    return {k: v.reshape(H, W, *v.shape[1:]) for k, v in out.items() if torch.is_tensor(v)}
+
+
 # (F, C, viewbase_pe) triples instantiated by csrc/ugrid_shade.hip for rgbnet models
 _FUSED_TRIPLES = None
 
