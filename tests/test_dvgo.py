@@ -211,6 +211,12 @@ def test_dvgo_render_view_equals_render_rays_on_the_image_rays(C):
     ref = rend.render_rays(o, d, v, **kw)
     assert set(img) == {"rgb_marched", "depth", "alphainv_last"} and img["rgb_marched"].shape == (H, W, 3) and img["depth"].shape == (H, W)
     assert float((img["alphainv_last"] < 0.99).float().mean()) > 0.05
+    if C == 12:       # the render driver's frame loop over the same renderer (run_render.render_viewpoints)
+        from unboundednerfpytorch_amd.run_render import render_viewpoints
+        rgbs, depths, bgmaps = render_viewpoints(rend, [c2w.numpy(), c2w.numpy()], [[H, W]] * 2, [K, K], kw)
+        assert rgbs.shape == (2, H, W, 3) and depths.shape == (2, H, W, 1) and bgmaps.shape == (2, H, W, 1)
+        assert np.array_equal(rgbs[0], img["rgb_marched"].cpu().numpy()) and np.array_equal(rgbs[1], rgbs[0])
+        assert np.array_equal(bgmaps[0][..., 0], img["alphainv_last"].cpu().numpy())
     for k in img:
         a, b = img[k].reshape(ref[k].shape), ref[k]
         if C == 12:

@@ -14,7 +14,8 @@ import torch
 @torch.no_grad()
 def render_viewpoints(model, render_poses, HW, Ks, render_kwargs, gt_imgs=None, render_factor=0,
                       flip_x=False, flip_y=False, group=None, verbose=False):
-    """model: FourierGridRenderer; render_poses [N,3or4,4] camera-to-world; HW [N,2]; Ks [N,3,3];
+    """model: FourierGridRenderer, or a DirectVoxGORenderer / DirectContractedVoxGORenderer (their render_view takes the
+    reference's render_kwargs 'near', 'far', 'bg' as well); render_poses [N,3or4,4] camera-to-world; HW [N,2]; Ks [N,3,3];
     render_kwargs: needs 'stepsize', may carry 'inverse_y' (the keys run_render.py passes; others are ignored).
     Returns (rgbs, depths, bgmaps) or (rgbs, depths, bgmaps, psnrs) when gt_imgs is given."""
     assert len(render_poses) == len(HW) and len(HW) == len(Ks)
@@ -38,9 +39,15 @@ def render_viewpoints(model, render_poses, HW, Ks, render_kwargs, gt_imgs=None, 
     pending = []                  # (slot, H, W) of copies in flight, oldest first
     for i in range(n):
         H, W = int(HW[i][0]), int(HW[i][1])
-        rgb, depth, bg = model.render_view(H, W, Ks[i], render_poses[i], render_kwargs["stepsize"],
-                                           inverse_y=bool(render_kwargs.get("inverse_y", False)),
-                                           flip_x=flip_x, flip_y=flip_y, group=group)
+        if hasattr(model, "fused_supported"):          # bounded / contracted VoxGO renderers: dict of per-ray outputs
+            kw = {k: render_kwargs[k] for k in ("near", "far", "stepsize", "bg") if k in render_kwargs}
+            out = model.render_view(H, W, Ks[i], render_poses[i], inverse_y=bool(render_kwargs.get("inverse_y", False)),
+                                    flip_x=flip_x, flip_y=flip_y, render_depth=True, **kw)
+            rgb, depth, bg = out["rgb_marched"], out["depth"], out["alphainv_last"]
+        else:
+            rgb, depth, bg = model.render_view(H, W, Ks[i], render_poses[i], render_kwargs["stepsize"],
+                                               inverse_y=bool(render_kwargs.get("inverse_y", False)),
+                                               flip_x=flip_x, flip_y=flip_y, group=group)
         packed = torch.cat([rgb.reshape(-1, 3), depth.reshape(-1, 1), bg.reshape(-1, 1)], dim=1).reshape(-1)
         slot = i & 1
         if len(pending) == 2:     # the buffer about to be re-used must have been read out
