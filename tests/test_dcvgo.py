@@ -138,3 +138,30 @@ def test_dcvgo_render_view_equals_render_rays_on_the_image_rays():
     assert set(img) == {"rgb_marched", "depth", "alphainv_last", "wsum_mid"} and img["rgb_marched"].shape == (H, W, 3)
     for k in img:
         assert torch.equal(img[k].reshape(ref[k].shape), ref[k]), k
+
+
+def test_dcvgo_state_from_reference_checkpoint_equals_state_from_params():
+    """the checkpoint route (model_kwargs as DirectContractedVoxGO.get_kwargs writes them, numpy bounds included) gives the state
+    the constructor-argument route gives, key by key"""
+    from unboundednerfpytorch_amd.dcvgo_render import dcvgo_state_from_reference_checkpoint
+    G, Gb, C, norm = 20, 18, 12, "l2"
+    ref, _ = dcvgo_state(5, G, Gb, C, norm, 2.0, 6.0)
+    sd = {"density.grid": ref["density_grid"], "k0.grid": ref["k0_grid"], "mask_cache.mask": ref["mask"],
+          "mask_cache.xyz2ijk_scale": ref["xyz2ijk_scale"], "mask_cache.xyz2ijk_shift": ref["xyz2ijk_shift"],
+          "rgbnet.0.weight": ref["rgbnet_weights"][0], "rgbnet.0.bias": ref["rgbnet_biases"][0],
+          "rgbnet.2.0.weight": ref["rgbnet_weights"][1], "rgbnet.2.0.bias": ref["rgbnet_biases"][1],
+          "rgbnet.3.weight": ref["rgbnet_weights"][2], "rgbnet.3.bias": ref["rgbnet_biases"][2]}
+    kw = {"xyz_min": np.asarray(synth.DCVGO_BOX[0], dtype=np.float32), "xyz_max": np.asarray(synth.DCVGO_BOX[1], dtype=np.float32),
+          "num_voxels": G ** 3, "num_voxels_base": Gb ** 3, "alpha_init": 1e-2, "fast_color_thres": 1e-4, "contracted_norm": norm,
+          "density_type": "DenseGrid", "k0_type": "DenseGrid", "rgbnet_dim": C, "viewbase_pe": 4}
+    got = dcvgo_state_from_reference_checkpoint({"model_kwargs": kw, "model_state_dict": sd})
+    assert set(got) == set(ref)
+    for k, v in ref.items():
+        if torch.is_tensor(v):
+            assert torch.equal(got[k], v), k
+        elif isinstance(v, list):
+            assert len(got[k]) == len(v) and all(torch.equal(a, b) for a, b in zip(got[k], v)), k
+        else:
+            assert got[k] == v, k
+    with pytest.raises(NotImplementedError):
+        dcvgo_state_from_reference_checkpoint({"model_kwargs": dict(kw, density_type="TensoRFGrid"), "model_state_dict": sd})

@@ -39,6 +39,28 @@ def dcvgo_state_from_params(xyz_min, xyz_max, num_voxels, num_voxels_base, alpha
     }
 
 
+def dcvgo_state_from_reference_checkpoint(ckpt):
+    """`state` from a checkpoint the reference's trainer wrote for a DirectContractedVoxGO model ({'model_kwargs',
+    'model_state_dict'}, dcvgo.py:139-155 get_kwargs): dense grids only; bg_len is not among the saved kwargs (the constructor
+    default 0.2 applies on reload, dcvgo.py:29)."""
+    kw, sd = ckpt['model_kwargs'], ckpt['model_state_dict']
+    if kw.get('density_type', 'DenseGrid') != 'DenseGrid' or kw.get('k0_type', 'DenseGrid') != 'DenseGrid':
+        raise NotImplementedError("only DenseGrid checkpoints (TensoRFGrid is outside the hot path, SURVEY.md section 8)")
+    if kw.get('rgbnet_full_implicit', False):
+        raise NotImplementedError("rgbnet_full_implicit models have no feature grid")
+    lin = sorted({k[:-len('.weight')] for k in sd if k.startswith('rgbnet.') and k.endswith('.weight')},
+                 key=lambda n: [int(x) for x in n.split('.')[1:]])
+    st = dcvgo_state_from_params(
+        [float(x) for x in kw['xyz_min']], [float(x) for x in kw['xyz_max']], kw['num_voxels'], kw['num_voxels_base'], kw['alpha_init'],
+        sd['density.grid'], sd['k0.grid'], [sd[n + '.weight'] for n in lin], [sd[n + '.bias'] for n in lin], sd['mask_cache.mask'],
+        kw.get('fast_color_thres', 0), bg_len=kw.get('bg_len', 0.2), contracted_norm=kw.get('contracted_norm', 'inf'),
+        viewbase_pe=kw.get('viewbase_pe', 4))
+    for k in ('xyz2ijk_scale', 'xyz2ijk_shift'):          # the stored buffers win over the re-derived ones
+        if 'mask_cache.' + k in sd:
+            st[k] = sd['mask_cache.' + k]
+    return st
+
+
 class _HipOps:
     """The product's extension modules + grid query, resolved lazily (importing them loads libugrid_hip.so)."""
 
@@ -64,6 +86,11 @@ class DirectContractedVoxGORenderer:
         self.viewfreq = torch.tensor([float(2 ** i) for i in range(int(state["viewbase_pe"]))], device=dev)
         self._tables = {}
         self._fused = None if ops is None else False      # fused render kernels: HIP library only, built on first use
+
+    @classmethod
+    def from_reference_checkpoint(cls, ckpt, device):
+        """ckpt: the dict the reference saves for a DirectContractedVoxGO model (torch.load('fine_last.tar', weights_only=False))"""
+        return cls(dcvgo_state_from_reference_checkpoint(ckpt), device)
 
     # -- fused inference path ----------------------------------------------------------------------------------
     def fused_supported(self):

@@ -45,7 +45,7 @@ def dvgo_state_from_reference_checkpoint(ckpt):
     lin = sorted({k[:-len('.weight')] for k in sd if k.startswith('rgbnet.') and k.endswith('.weight')},
                  key=lambda n: [int(x) for x in n.split('.')[1:]])
     st = dvgo_state_from_params(
-        kw['xyz_min'], kw['xyz_max'], kw['num_voxels'], kw['num_voxels_base'], kw['alpha_init'], sd['density.grid'], sd['k0.grid'],
+        [float(x) for x in kw['xyz_min']], [float(x) for x in kw['xyz_max']], kw['num_voxels'], kw['num_voxels_base'], kw['alpha_init'], sd['density.grid'], sd['k0.grid'],
         [sd[n + '.weight'] for n in lin], [sd[n + '.bias'] for n in lin], sd['mask_cache.mask'], kw.get('fast_color_thres', 0),
         kw.get('rgbnet_direct', False), kw.get('viewbase_pe', 4))
     for k in ('xyz2ijk_scale', 'xyz2ijk_shift'):          # the stored buffers win over the re-derived ones
@@ -74,6 +74,11 @@ class DirectVoxGORenderer:
                       ([x.to(dev).contiguous() for x in v] if isinstance(v, list) else v)) for k, v in state.items()}
         self.viewfreq = torch.tensor([float(2 ** i) for i in range(int(state["viewbase_pe"]))], device=dev)
         self._fused = None if ops is None else False      # fused render kernels: HIP library only, built on first use
+
+    @classmethod
+    def from_reference_checkpoint(cls, ckpt, device):
+        """ckpt: the dict the reference saves for a DirectVoxGO model (torch.load('fine_last.tar', weights_only=False))"""
+        return cls(dvgo_state_from_reference_checkpoint(ckpt), device)
 
     # -- fused inference path ----------------------------------------------------------------------------------
     def fused_supported(self):
