@@ -453,7 +453,9 @@ def roofline_block(kern, M, R, S, shade_passes, frame_rays=None):
     if not per:
         return None
     # the dominant kernel = the longest one; march and shade are within a few per cent of each other on S1, so among
-    # kernels within 5 % of the longest the one FURTHEST from its roof is reported (stable between runs, conservative)
+    # kernels within 5 % of the longest the one FURTHEST from its roof is reported (conservative).  On S1 the march is the
+    # longer kernel by 3-6 %: depending on the run the block names render_march (~0.65 of the L1 path) or render_shade
+    # (~0.40); per_kernel always carries both.
     t_max = max(p["ms"] for p in per.values())
     near = [k for k in per if per[k]["ms"] >= 0.95 * t_max]
     dom = min(near, key=lambda k: max(v for kk, v in per[k].items() if kk.endswith("_frac")))
