@@ -146,6 +146,7 @@ def test_optimizer_uses_the_bitmap_and_recycles_it():
             opt = MaskedAdam([{"params": [p], "lr": 0.1, "skip_zero_grad": True}], recycle_grads=True)
             seen = []
             for it in range(3):
+                _gradpool.certify([p])          # what train_step.train_iteration does for the model's own loss graph
                 out = GridQuery.apply(p, pts, lo, hi, 1)
                 (out * go).sum().backward()
                 t = _gradpool.touch_of(p, p.grad)
@@ -163,7 +164,51 @@ def test_optimizer_uses_the_bitmap_and_recycles_it():
         finally:
             _gradpool.touch_enabled = True
             _gradpool.clear()
+    _gradpool.clear()
     # (the scatter's atomics make a gradient that cancels to ~0 land on either side of zero: Adam's first steps then differ by
     #  up to 2 lr on that element -- allow a 1e-5 fraction of such elements, everything else agrees to rounding)
     diff = (res[True] - res[False]).abs()
     assert int((diff > 1e-4).sum()) <= max(2, int(1e-5 * diff.numel())), (float(diff.max()), int((diff > 1e-4).sum()))
+
+
+def test_a_second_gradient_producer_never_meets_a_bitmap():
+    """AccumulateGrad adds a second producer's gradient IN PLACE into the first-arrived buffer, so
+    `p.pow(2).sum() + GridQuery(p)` leaves .grad at the lookup's buffer address holding dense values its bitmap never saw.
+    Without a certificate (the drop-in MaskedAdam on a user's own graph) no bitmap exists and the scanning kernels see every
+    element: the recycling optimizer equals the non-recycling one and the parked buffer is all zero afterwards.  With a certificate
+    wrongly given, a second lookup still voids it."""
+    from unboundednerfpytorch_amd import _gradpool
+    from unboundednerfpytorch_amd.grid import GridQuery
+    from unboundednerfpytorch_amd.masked_adam import MaskedAdam
+    _lib, grid0, pts, go, lo, hi = _setup(seed=5)
+    _gradpool.clear()
+    try:
+        res = []
+        for recycle in (True, False):
+            p = torch.nn.Parameter(grid0.clone(memory_format=torch.preserve_format))
+            opt = MaskedAdam([{"params": [p], "lr": 0.1, "skip_zero_grad": True}], recycle_grads=recycle)
+            for it in range(2):
+                out = GridQuery.apply(p, pts, lo, hi, 1)
+                ((out * go).sum() + 1e-3 * p.pow(2).sum()).backward()        # a regulariser on the raw grid: dense gradient
+                assert _gradpool.touch_of(p, p.grad) is None
+                assert int((p.grad != 0).sum()) > p.numel() // 2
+                opt.step()
+                if recycle:
+                    assert p.grad is None
+                    buf = _gradpool.take(id(p), p.shape, p.stride(), p.device)
+                    assert buf is not None and int((buf != 0).sum()) == 0     # the all-zero invariant of the pool survived
+                    _gradpool.give(p, buf)
+                else:
+                    opt.zero_grad(set_to_none=True)
+            res.append(p.detach().clone())
+        diff = (res[0] - res[1]).abs()
+        assert int((diff > 1e-4).sum()) <= max(2, int(1e-5 * diff.numel())), float(diff.max())
+        # two lookups of one certified parameter in one graph: the second marking backward voids the certificate
+        p = torch.nn.Parameter(grid0.clone(memory_format=torch.preserve_format))
+        _gradpool.certify([p])
+        (GridQuery.apply(p, pts, lo, hi, 1) * go).sum().backward()
+        assert _gradpool.touch_of(p, p.grad) is not None
+        (GridQuery.apply(p, pts, lo, hi, 1) * go).sum().backward()
+        assert _gradpool.touch_of(p, p.grad) is None
+    finally:
+        _gradpool.clear()

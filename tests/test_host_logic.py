@@ -222,8 +222,10 @@ def test_step_param_updates_one_parameter_early_and_step_skips_it():
 
 
 def test_touched_line_bitmap_is_bound_to_buffer_and_backward():
-    """_gradpool.touch_for_backward / touch_of (host logic of the touched-line bitmap): one bitmap per gradient buffer, served
-    only for the very tensor the last backward filled, dropped when marking is off"""
+    """_gradpool.touch_for_backward / touch_of (host logic of the touched-line bitmap): bitmaps exist only for parameters the
+    training step has CERTIFIED for the running backward (the buffer address alone does not prove that nothing else
+    contributed to .grad); one bitmap per gradient buffer, served only for the very tensor the single marking backward filled,
+    dropped when marking is off"""
     from unboundednerfpytorch_amd import _gradpool
     lib = types.SimpleNamespace(ugrid_touch_words=lambda n: ((n + 63) // 64 + 31) // 32)
     _gradpool.clear()
@@ -231,24 +233,35 @@ def test_touched_line_bitmap_is_bound_to_buffer_and_backward():
         p = torch.nn.Parameter(torch.zeros(3, 4, 5, 6, 7))
         key = id(p)
         buf = torch.zeros_like(p)
+        assert _gradpool.touch_for_backward(key, buf, lib) is None        # not certified: no bitmap, nothing is marked
+        p.grad = buf
+        assert _gradpool.touch_of(p, p.grad) is None
+        _gradpool.certify([p])
         t = _gradpool.touch_for_backward(key, buf, lib)
         assert t.dtype == torch.int32 and t.numel() == ((p.numel() + 63) // 64 + 31) // 32 and not bool(t.any())
-        p.grad = buf
         assert _gradpool.touch_of(p, p.grad) is t
-        assert _gradpool.touch_for_backward(key, buf, lib) is t           # the same buffer comes back from the pool: same bitmap
+        assert _gradpool.touch_for_backward(key, buf, lib) is t           # a SECOND marking backward in the same step ...
+        assert _gradpool.touch_of(p, p.grad) is None                      # ... voids the bitmap (.grad is a sum of two scatters)
+        _gradpool.certify([p])                                            # next step: the same buffer comes back from the pool
+        assert _gradpool.touch_for_backward(key, buf, lib) is t and _gradpool.touch_of(p, p.grad) is t      # same bitmap
         other = torch.zeros_like(p)
         assert _gradpool.touch_of(p, other) is None                       # not .grad
         p.grad = other
         assert _gradpool.touch_of(p, p.grad) is None                      # .grad is another buffer (accumulated, user-made)
-        t2 = _gradpool.touch_for_backward(key, other, lib)                 # a second backward into a fresh buffer: new bitmap
+        _gradpool.certify([p])
+        t2 = _gradpool.touch_for_backward(key, other, lib)                 # a backward into a fresh buffer: new bitmap
         assert t2 is not t and _gradpool.touch_of(p, p.grad) is t2
         p.grad = buf
         assert _gradpool.touch_of(p, p.grad) is None                      # the first buffer's bitmap is gone with it
+        _gradpool.decertify([p])
+        p.grad = other
+        assert _gradpool.touch_of(p, p.grad) is None                      # the step is over: the certificate is spent
+        _gradpool.certify([p])
         _gradpool.touch_enabled = False
         assert _gradpool.touch_of(p, other) is None and _gradpool.touch_for_backward(key, other, lib) is None
         _gradpool.touch_enabled = True
-        p.grad = other
         assert _gradpool.touch_of(p, p.grad) is None                      # an unmarked backward invalidated the bitmap
+        assert _gradpool.touch_for_backward(key, other, lib) is not None and _gradpool.touch_of(p, p.grad) is None   # and the certificate
         assert _gradpool.touch_for_backward(None, buf, lib) is None       # not a poolable parameter
     finally:
         _gradpool.touch_enabled = True

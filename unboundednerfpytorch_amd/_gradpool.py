@@ -15,13 +15,21 @@ Touched-line bitmaps (channel-last grids): the backward also marks which 256-byt
 fused dense pass visit only those (`touch_of`).  Invariant: an UNSET bit means the line is all zero.  Stale SET bits are
 harmless (the line is read and found zero), so the bitmap is only ever cleared by a pass that has just re-zeroed the buffer.
 The bitmap is bound to the buffer's address and to its most recent backward: a gradient that autograd accumulated from two
-backward calls, or any tensor that is not the very buffer the last backward filled, gets no bitmap and the scanning kernels."""
+backward calls, or any tensor that is not the very buffer the last backward filled, gets no bitmap and the scanning kernels.
+
+The address alone does not prove that: autograd's AccumulateGrad sums a second producer's contribution IN PLACE into the
+first-arrived tensor, so `p.pow(2).sum() + GridQuery(p)` leaves `.grad` at the lookup's buffer address with dense values the
+bitmap knows nothing about.  A bitmap is therefore only created, marked and served for parameters the training step has
+CERTIFIED for the current backward (`certify`: "this parameter's only gradient producer in this graph is one marking lookup") --
+`train_step.train_iteration` does that for the model's own loss graph -- and only when exactly one marking backward has run since.
+Everything else (the drop-in MaskedAdam on a user's own graph, world > 1, injected ops) gets the scanning kernels."""
 import weakref
 
 import torch
 
 _POOL = {}          # id(param) -> (weakref to param, buffer)
 _TOUCH = {}         # id(param) -> [data_ptr of the buffer, bitmap (int32 tensor), numel]
+_CERT = {}          # id(param) -> marking backward calls since certify() (the bitmap is valid only at exactly 1)
 enabled = True
 touch_enabled = True
 
@@ -41,9 +49,26 @@ def give(param, buf):
     k = id(param)
     if k not in _POOL:
         weakref.finalize(param, _POOL.pop, k, None)
-        weakref.finalize(param, _TOUCH.pop, k, None)
     _POOL[k] = (weakref.ref(param), buf)
     return True
+
+
+def certify(params):
+    """The caller vouches, for the backward it is about to run, that each of `params` receives gradient from exactly ONE
+    marking grid lookup and from nothing else (no regulariser on the raw grid, no second lookup, no hook that edits .grad).
+    Only certified parameters get touched-line bitmaps.  Pair with `decertify` (try / finally) once the optimizer has stepped."""
+    for p in params:
+        if isinstance(p, torch.nn.Parameter) and p.requires_grad:
+            k = id(p)
+            if k not in _CERT:
+                weakref.finalize(p, _CERT.pop, k, None)
+                weakref.finalize(p, _TOUCH.pop, k, None)
+            _CERT[k] = 0
+
+
+def decertify(params):
+    for p in params:
+        _CERT.pop(id(p), None)
 
 
 def take(key, shape, stride, device):
@@ -62,9 +87,12 @@ def take(key, shape, stride, device):
 def touch_for_backward(key, buf, lib):
     """the bitmap the backward of parameter `key` must mark while it scatters into `buf` (all zero on entry): the buffer's
     own bitmap if it has one, else a fresh cleared one.  None when bitmaps are off or `key` is not poolable."""
-    if key is None or not (enabled and touch_enabled):
+    if key is None or not (enabled and touch_enabled) or key not in _CERT:
         _TOUCH.pop(key, None)      # this backward marks nothing: a bitmap of the buffer would no longer describe it
+        if key in _CERT:
+            _CERT[key] += 2        # ... and an unmarked contribution voids the certificate for this backward
         return None
+    _CERT[key] += 1
     ent = _TOUCH.get(key)
     if ent is not None and ent[0] == buf.data_ptr() and ent[2] == buf.numel() and ent[1].device == buf.device:
         return ent[1]
@@ -78,6 +106,8 @@ def touch_of(param, g):
     """the valid bitmap of gradient `g` of `param` (see the module docstring), or None"""
     if not (enabled and touch_enabled) or g is None:
         return None
+    if _CERT.get(id(param)) != 1:      # not certified for this backward, or more than one lookup contributed
+        return None
     ent = _TOUCH.get(id(param))
     if ent is None or g is not param.grad or ent[0] != g.data_ptr() or ent[2] != g.numel() or g.stride() != param.stride():
         return None
@@ -86,5 +116,6 @@ def touch_of(param, g):
 
 def clear():
     _TOUCH.clear()
+    _CERT.clear()
     for k, (ref, _) in list(_POOL.items()):
         _POOL[k] = (ref, None)

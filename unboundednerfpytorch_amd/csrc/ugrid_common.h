@@ -19,6 +19,22 @@
     if (_e != hipSuccess) return (int)_e;         \
   } while (0)
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device's copy of the function: remember it per
+// (call site, device), not per process -- a second GPU in the process would otherwise launch with the 64 KB default and
+// fail.  `done` is the call site's own `static unsigned long long` bit set (devices 0..63); racing threads (forward on the
+// main thread, backward on the autograd thread) at worst set the attribute twice, which is harmless.
+#define UG_SET_DYN_LDS(func, bytes)                                                                           \
+  do {                                                                                                        \
+    static unsigned long long done_ = 0ull;                                                                   \
+    int dev_ = 0;                                                                                             \
+    UG_HIP(hipGetDevice(&dev_));                                                                              \
+    const unsigned long long bit_ = 1ull << (dev_ & 63);                                                      \
+    if (dev_ > 63 || !(__atomic_load_n(&done_, __ATOMIC_RELAXED) & bit_)) {                                   \
+      UG_HIP(hipFuncSetAttribute((const void *)(func), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes))); \
+      __atomic_fetch_or(&done_, bit_, __ATOMIC_RELAXED);                                                      \
+    }                                                                                                         \
+  } while (0)
+
 static inline unsigned ug_blocks(int64_t n, int threads) {
   return (unsigned)((n + threads - 1) / threads);
 }

@@ -416,11 +416,7 @@ static int ug_fused_launch_nw(const ug_march_args &am, const ug_shade_args &as, 
                            const float *s_table, const float *dens_bricks, const float *k0b, const float *mlp,
                            float *alphainv_last, float *depth, float *rgb, void *ws_mem, hipStream_t st) {
   const int lds_bytes = ug_shade_lds_bytes<C, PE, BF, NW>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    UG_HIP(hipFuncSetAttribute((const void *)k_render_fused<F, L2, C, PE, NW, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    attr_set = true;
-  }
+  UG_SET_DYN_LDS((k_render_fused<F, L2, C, PE, NW, BF>), lds_bytes);
   const int64_t n_tiles = (am.n_rays + UG_WAVE - 1) / UG_WAVE;
   const int64_t slots = (int64_t)UG_FUSED_MAX_WGS * NW, cap = (int64_t)UG_WAVE * am.S;
   char *base = (char *)ws_mem;
@@ -501,11 +497,7 @@ template <int F, int C, int PE, int NW, int BF>
 static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
                               ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
   const int lds_bytes = ug_shade_lds_bytes<C, PE, BF, NW>();
-  static bool attr_set = false;
-  if (!attr_set) {
-    UG_HIP(hipFuncSetAttribute((const void *)k_shade_mlp<F, C, PE, NW, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    attr_set = true;
-  }
+  UG_SET_DYN_LDS((k_shade_mlp<F, C, PE, NW, BF>), lds_bytes);
   UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
   // persistent: one workgroup per CU (LDS holds the packed rgbnet image of the mode: 89 / 138 / 93 KB)
   int64_t wgs = (ws.n_tiles + NW - 1) / NW;
@@ -523,11 +515,7 @@ static int ug_shade_pc_launch(const ug_shade_args &a, const float *viewdirs, con
                               ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
   const int lds_bytes = ug_pc_lds_bytes<PE, NPAIR, SLOTS>();
   if (lds_bytes > 160 * 1024) return (int)hipErrorInvalidValue;   // the CU's LDS
-  static bool attr_set = false;
-  if (!attr_set) {
-    UG_HIP(hipFuncSetAttribute((const void *)k_shade_pc<F, PE, NPAIR, SLOTS, NBL, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    attr_set = true;
-  }
+  UG_SET_DYN_LDS((k_shade_pc<F, PE, NPAIR, SLOTS, NBL, MODE>), lds_bytes);
   UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
   // persistent, one workgroup per CU: NPAIR producer waves pull tiles, so a workgroup covers >= NPAIR tiles
   int64_t wgs = (ws.n_tiles + NPAIR - 1) / NPAIR;
@@ -544,11 +532,7 @@ template <int F>
 static int ug_shade16_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
                              ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
   const int lds_bytes = (int)sizeof(float) * (ug_mlp16_lds_floats() + 16 * UG_ACC16_SCRATCH_FLOATS);
-  static bool attr_set = false;
-  if (!attr_set) {
-    UG_HIP(hipFuncSetAttribute((const void *)k_shade_mlp16<F>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    attr_set = true;
-  }
+  UG_SET_DYN_LDS((k_shade_mlp16<F>), lds_bytes);
   UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
   int64_t wgs = (ws.n_tiles + 15) / 16;
   if (wgs > 256) wgs = 256;

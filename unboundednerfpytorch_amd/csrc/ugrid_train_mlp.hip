@@ -249,11 +249,7 @@ static inline int ug_lin_launch(const float *X, int64_t M, int K, int ldx, const
 #define UG_LIN_GO(KH, NT_, VEC_)                                                                                                 \
   {                                                                                                                              \
     constexpr int lds = 2 * KH * (NT_ * 32 + 1) * 4;                                                                             \
-    static bool attr_set = false;                                                                                                \
-    if (!attr_set) {                                                                                                             \
-      UG_HIP(hipFuncSetAttribute((const void *)k_lin<KH, NT_, VEC_>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));          \
-      attr_set = true;                                                                                                           \
-    }                                                                                                                            \
+    UG_SET_DYN_LDS((k_lin<KH, NT_, VEC_>), lds);   /* per device */                                                   \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lin<KH, NT_, VEC_>), dim3((unsigned)wgs), dim3(UG_LIN_THREADS), lds, st, X, M, K, ldx, W, ldw, \
                        n_out, w_in_major, bias, relu, G, ldg, Y, ldy);                                                           \
   }

@@ -80,7 +80,7 @@ INVISIBLE_SCALE = 2.0 ** -60   # weight factor of a block that fails the visibil
 
 
 def composite_blocks(renderer_forward, rays_o, rays_d, viewdirs, cam_origin, block_centroid, p=4.0, min_opacity=0.05,
-                     group=None, **render_kwargs):
+                     group=None, ref_distance=None, **render_kwargs):
     """One block model per rank, the same rays on every rank, ONE all-reduce(sum) of [R+1,5] fp32, no host sync.
 
     The reference's FourierGrid path never composites blocks (it renders each block's own image subset,
@@ -97,7 +97,13 @@ def composite_blocks(renderer_forward, rays_o, rays_d, viewdirs, cam_origin, blo
     contribution is below fp32 resolution (the blend is bit-identical to excluding it unless its distance weight exceeds
     the visible ones' by > 10^10), and when NO block is visible -- the reference skips such a frame
     (eval_block_nerf.py:225-226) -- the common factor cancels and the frame is the inverse-distance blend of all blocks,
-    without a second collective or a host decision."""
+    without a second collective or a host decision.
+
+    ref_distance (same value on every rank, e.g. the block spacing; default 1): the distance weight is formed in relative
+    space, (|cam - centroid| / ref_distance)^-p in float64, and kept inside [2^-40, 2^40] so that w_b * 2^-60 stays a normal
+    fp32 number for any scene scale (un-centred coordinates put cameras ~1e5 units from the centroids: 1e-20 * 2^-60 would
+    be denormal); the normaliser is clamped away from zero.  Returned `block_weight` is this rank's NORMALISED weight as a
+    0-d device tensor (w_b / sum_b w_b), `visible_blocks` the number of blocks that passed the test."""
     ws = dist.get_world_size(group) if dist.is_initialized() else 1
     kw = dict(render_kwargs)
     kw["render_depth"] = True
@@ -105,7 +111,8 @@ def composite_blocks(renderer_forward, rays_o, rays_d, viewdirs, cam_origin, blo
     R = rays_o.shape[0]
     dev = rays_o.device
     dvec = torch.as_tensor(cam_origin, dtype=torch.float64).reshape(3) - torch.as_tensor(block_centroid, dtype=torch.float64).reshape(3)
-    dw = (dvec.norm() ** (-float(p))).to(device=dev, dtype=torch.float32)   # host inputs: host arithmetic + one scalar upload
+    rel = dvec.norm() / float(ref_distance if ref_distance is not None else 1.0)
+    dw = (rel ** (-float(p))).clamp(2.0 ** -40, 2.0 ** 40).to(device=dev, dtype=torch.float32)   # host arithmetic + one scalar upload
     opacity = (1.0 - out["alphainv_last"]).mean() if R > 0 else torch.zeros((), device=dev)
     visible = (opacity > min_opacity).to(torch.float32)                  # 0-d device tensor
     w = dw * (visible + (1.0 - visible) * INVISIBLE_SCALE)
@@ -118,6 +125,7 @@ def composite_blocks(renderer_forward, rays_o, rays_d, viewdirs, cam_origin, blo
     acc[R, 2:] = 0.0
     if ws > 1:
         dist.all_reduce(acc, group=group)
-    blended = acc[:R] / acc[R, 0]
+    norm = acc[R, 0].clamp_min(2.0 ** -120)
+    blended = acc[:R] / norm
     return {"rgb_marched": blended[:, 0:3].contiguous(), "depth": blended[:, 3].contiguous(),
-            "alphainv_last": blended[:, 4].contiguous(), "block_weight": w / acc[R, 0], "visible_blocks": acc[R, 1]}
+            "alphainv_last": blended[:, 4].contiguous(), "block_weight": w / norm, "visible_blocks": acc[R, 1]}

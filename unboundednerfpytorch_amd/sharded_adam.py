@@ -15,6 +15,8 @@ so the skip_zero_grad semantics are unchanged, and with `average=True` (default,
 is a mean over its own rays) the result equals the single-process optimizer stepping on the rank-averaged
 gradient bit for bit when N is a power of two.
 """
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -211,8 +213,10 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         else:
             self._update(group, param, g, state['exp_avg'], state['exp_avg_sq'], state['step'],
                          self.per_lr if use_perlr else None, recycle=param, touch=touch)
-        self._early = getattr(self, '_early', set())
-        self._early.add(id(param))
+        # remembered by OBJECT (a weak reference beside the id): a parameter that is replaced -- scale_volume_grid makes new
+        # ones -- may get the id of a dead one, and must not be skipped by the next step() on the strength of that
+        self._early = getattr(self, '_early', None) or {}
+        self._early[id(param)] = weakref.ref(param)
         return True
 
     @torch.no_grad()
@@ -234,10 +238,11 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         side = None
         if overlap and world == 1:
             side = self._side = getattr(self, '_side', None) or _low_priority_stream()
-        early, self._early = getattr(self, '_early', set()), set()
+        early, self._early = (getattr(self, '_early', None) or {}), {}
         for group in self.param_groups:
             for param in group['params']:
-                if param.grad is None or id(param) in early:       # (updated already by step_param during the backward)
+                ref = early.get(id(param))
+                if param.grad is None or (ref is not None and ref() is param):   # (updated already by step_param during the backward)
                     continue
                 _lib_wait(param)
                 state = self.state[param]

@@ -6,6 +6,7 @@ Data loading, ray-batch sampling, logging and checkpoint scheduling stay with th
 import torch
 import torch.nn.functional as F
 
+from . import _gradpool
 from .train_utils import create_optimizer_or_freeze_model
 
 
@@ -136,18 +137,32 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
         def _early_k0_update(p):          # (an autograd hook must return None)
             optimizer.step_param(p, k0_term, overlap=True)
         hook = model.k0.grid.register_post_accumulate_grad_hook(_early_k0_update)
+    # Touched-line bitmaps (_gradpool): in THIS loss graph the feature grid receives gradient from exactly one lookup (the
+    # model's k0 query; every loss term reaches the grid through it), which is what the bitmap's validity rests on -- so the
+    # step certifies it for its own backward only.  A caller-supplied loss that regularises k0.grid directly must not use
+    # train_iteration's certificate: pass distortion_fn / losses through `out`, or call _gradpool.decertify first.
+    certified = [model.k0.grid] if (world_size == 1 and hasattr(model, 'k0') and isinstance(getattr(model.k0, 'grid', None), torch.nn.Parameter)) else []
+    _gradpool.certify(certified)
     try:
-        loss.backward()
+        try:
+            loss.backward()
+        except BaseException:
+            early = getattr(optimizer, '_early', None)     # a hook may have stepped k0 before the backward failed: the next
+            if early:                                       # step() must not skip a parameter on the strength of this one
+                early.clear()
+            raise
+        finally:
+            if hook is not None:
+                hook.remove()
+        _mark(timers, "backward")
+        if overlap:
+            optimizer.step(tv_terms=tv_terms, overlap=[model.k0.grid])     # (k0 is skipped here when the hook has updated it)
+        elif tv_terms:
+            optimizer.step(tv_terms=tv_terms)
+        else:
+            optimizer.step()
     finally:
-        if hook is not None:
-            hook.remove()
-    _mark(timers, "backward")
-    if overlap:
-        optimizer.step(tv_terms=tv_terms, overlap=[model.k0.grid])     # (k0 is skipped here when the hook has updated it)
-    elif tv_terms:
-        optimizer.step(tv_terms=tv_terms)
-    else:
-        optimizer.step()
+        _gradpool.decertify(certified)
     _mark(timers, "tv+adam")
     if decay_lr:                      # run_train.py:290-295 (the reference skips this for FourierGrid on tankstemple)
         factor = 0.1 ** (1 / (_get(cfg_train, 'lrate_decay') * 1000))
