@@ -625,6 +625,15 @@ def main():
             dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)
             frame_ok = bool(ok_all.item() > 0)
     term_frac = float((out_full["alphainv_last"] < 1e-3).float().mean())
+    # sha256 over the bytes of the frame (rgb, depth, alphainv_last): per-ray results are bitwise independent of the kernel
+    # geometry, chunking and rank layout, so two builds that claim "same arithmetic" must print the same value
+    frame_sha = None
+    if rank == 0 and not standin:
+        import hashlib
+        hh = hashlib.sha256()
+        for k_ in ("rgb_marched", "depth", "alphainv_last"):
+            hh.update(out_full[k_].contiguous().cpu().numpy().tobytes())
+        frame_sha = hh.hexdigest()[:16]
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()     # everything below is rank 0's own (CPU baseline: the other ranks are done)
@@ -659,6 +668,7 @@ def main():
             res["roofline"] = None
         else:
             res["lib_sha16"] = lib_sha16()
+            res["frame_sha16"] = frame_sha
             res["device_code_sha16"] = device_code_sha16()
             if not args.single_launch and M_rank is not None:
                 # rank 0's own kernels: its share of the frame's rays and survivors (the whole frame at N = 1)

@@ -47,3 +47,59 @@ def render_fp64(state, rays_o, rays_d, viewdirs, stepsize, grids64=None):
             out['rgb_marched'][r] = (wt[:, None] * rgb).sum(0)
             out['depth'][r] = (wt * s_tab[idx]).sum()
     return out
+
+
+KEYS = ("rgb_marched", "depth", "alphainv_last")
+
+
+def _err(a, b):
+    e = (a.double() - b.double()).abs()
+    return e.amax(dim=1) if e.dim() == 2 else e
+
+
+def ground_truth_study(cpu_state, rays_cpu, evaluations, stepsize, n_random=1024, seed=0, slack=2e-5, bound=1e-4):
+    """replace "the reference disagrees with itself by that much" with a GROUND TRUTH.
+
+    `evaluations`: {"fused": {...}, "ref_cpu": {...}, "ref_gpu": {...} (optional)} -- fp32 outputs (rgb_marched [n,3], depth [n],
+    alphainv_last [n]) of the same n rays `rays_cpu` = (rays_o, rays_d, viewdirs).  The fp64 evaluation (render_fp64: the
+    same formula, thresholds and sample table, every tensor and every libm call in double) is run on
+      * every ray where the fused render is further than `bound` from ANY fp32 reference in ANY output, and
+      * `n_random` rays drawn uniformly (seeded),
+    and for each selected ray and output the distances |x - fp64| of the evaluations are compared.  Returns a dict with, per
+    output: L-inf / mean / rays above `bound` of each evaluation against fp64, and per fp32 reference `name`
+      violations[name] = rays where |fused - fp64| > |name - fp64| + slack        (the fused render is further from the truth
+                                                                                   than that reference by more than the slack)
+      bound_where_ref_ok[name] = L-inf of |fused - fp64| over the rays where |name - fp64| <= bound in all outputs
+    """
+    import torch
+    ro, rd, vd = rays_cpu
+    n = ro.shape[0]
+    fused = evaluations["fused"]
+    refs = {k: v for k, v in evaluations.items() if k != "fused" and v is not None}
+    far = torch.zeros(n, dtype=torch.bool)
+    for r in refs.values():
+        for k in KEYS:
+            far |= _err(fused[k], r[k]) > bound
+    g = torch.Generator().manual_seed(seed)
+    pick = torch.zeros(n, dtype=torch.bool)
+    pick[torch.randperm(n, generator=g)[:min(n_random, n)]] = True
+    sel = torch.nonzero(far | pick).flatten()
+    grids64 = (cpu_state["density_grid"].double(), cpu_state["k0_grid"].double())
+    truth = render_fp64(cpu_state, ro[sel], rd[sel], vd[sel], stepsize, grids64=grids64)
+    del grids64
+    res = {"rays_total": int(n), "rays_evaluated_in_fp64": int(sel.numel()), "rays_selected_because_fused_is_far_from_a_reference": int(far.sum()),
+           "rays_random": int(pick.sum()), "slack": slack, "bound": bound, "distance_to_fp64": {}, "violations": {}, "bound_where_ref_ok": {}}
+    dist = {name: {k: _err(ev[k][sel], truth[k]) for k in KEYS} for name, ev in [("fused", fused)] + list(refs.items())}
+    for name, d in dist.items():
+        res["distance_to_fp64"][name] = {k: {"linf": float(e.max()), "mean_abs": float(e.mean()), "rays_above_bound": int((e > bound).sum())}
+                                         for k, e in d.items()}
+    for name in refs:
+        viol, ok_all = {}, torch.ones(sel.numel(), dtype=torch.bool)
+        for k in KEYS:
+            v = dist["fused"][k] > dist[name][k] + slack
+            viol[k] = {"rays": int(v.sum()), "worst_excess": float((dist["fused"][k] - dist[name][k]).max())}
+            ok_all &= dist[name][k] <= bound
+        res["violations"][name] = viol
+        res["bound_where_ref_ok"][name] = {"rays_where_ref_within_bound_of_fp64": int(ok_all.sum()),
+                                           **{k: (float(dist["fused"][k][ok_all].max()) if bool(ok_all.any()) else None) for k in KEYS}}
+    return res

@@ -1,13 +1,13 @@
 #!/bin/bash
 # Build libugrid_hip.so for gfx950 (MI355X).  Usage: csrc/build.sh [extra hipcc flags]
-#   UG_OUT=path        alternative output (A/B builds)
+#   UG_OUT=path        alternative output (A/B builds); UG_OBJ=dir its object directory; UG_SHADE_FLAGS / UG_MARCH_FLAGS extra -D
 #   UG_EXPERIMENTS=1   also build the rejected A/B arms and the stand-alone gather variants (ugx_* symbols, the 16-wave
 #                      shade kernel, ugrid_tune("shade_dbg")): tools/ only, never the shipped library
 set -e
 cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include"
-mkdir -p ../../build/obj
-O=../../build/obj
+O=${UG_OBJ:-../../build/obj}      # UG_OBJ: separate object directory (parallel A/B builds)
+mkdir -p $O
 rm -f $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_gather_exp.o $O/ugrid_train.o $O/ugrid_train_mlp.o   # a failed compile must not link a stale object
 OBJS="$O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_train.o $O/ugrid_train_mlp.o"
 pids=()

@@ -182,8 +182,15 @@ __device__ __forceinline__ float ug_density_level(const char *__restrict__ lvl, 
   // byte offset of the cell record: the row index cx*(Y-1)+cy is exact in fp32 ((X-1)(Y-1) < 2^24), so it costs one
   // FMA + one convert; row * rowbytes is a full-rate 24-bit multiply (level < 4 GiB), then + cz*32.  The plain
   // integer form compiled to quarter-rate v_mad_u64_u32 pairs.
+#ifdef UG_MARCH_FCELL
+  // A/B arm (march diet, profiles/r04/march_ab.txt): the whole cell index in fp32 -- exact while (X-1)(Y-1)(Z-1) < 2^24
+  // (G <= 256; the host refuses the build's use otherwise) -- one convert and one shift instead of two converts, a shift and
+  // a 24-bit multiply-add
+  const unsigned off = (unsigned)fmaf(fmaf(ax.cellf, (float)(Y - 1), ay.cellf), (float)(Z - 1), az.cellf) << 5;
+#else
   const unsigned row = (unsigned)fmaf(ax.cellf, (float)(Y - 1), ay.cellf);
   const unsigned off = __umul24(row, (unsigned)(Z - 1) << 5) + ((unsigned)az.cell << 5);
+#endif
   const float4 *b = (const float4 *)(lvl + off);
   const float4 v0 = b[0], v1 = b[1];
 #ifdef UG_CORNER_SUM
@@ -860,6 +867,22 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // (BF=1: bf16x3) or f16x8 units (BF=2: fp16x2, with the activation scales sx1 / c12)
 struct ug_mlp_lds { const float4 *A1, *A2, *W3; const float *B1, *B2, *b3; float sx1, c12; };
 
+// four consecutive rows of the fp16x2 image's DENSE W3 ([h][64][3] floats, k_pack_mlp): rows row0 .. row0+3 of half bo / 64
+// as three 16-byte reads; row0 % 4 == 0
+struct ug_w3x4 { float4 a, b, c; };
+__device__ __forceinline__ ug_w3x4 ug_w3_load4(const ug_mlp_lds &M, int bo, int row0) {
+  const float4 *p = (const float4 *)((const float *)M.W3 + (bo + row0) * 3);
+  ug_w3x4 w;
+  w.a = p[0]; w.b = p[1]; w.c = p[2];
+  return w;
+}
+// l += W3[row0 + i] * hv for i = 0..3, rows ascending (same order as the row-per-read form)
+#define UG_W3_FMA4(Q_, h0_, h1_, h2_, h3_)                                                  \
+  l0 = fmaf((Q_).a.x, h0_, l0); l1 = fmaf((Q_).a.y, h0_, l1); l2 = fmaf((Q_).a.z, h0_, l2);   \
+  l0 = fmaf((Q_).a.w, h1_, l0); l1 = fmaf((Q_).b.x, h1_, l1); l2 = fmaf((Q_).b.y, h1_, l2);   \
+  l0 = fmaf((Q_).b.z, h2_, l0); l1 = fmaf((Q_).b.w, h2_, l1); l2 = fmaf((Q_).c.x, h2_, l2);   \
+  l0 = fmaf((Q_).c.y, h3_, l0); l1 = fmaf((Q_).c.z, h3_, l1); l2 = fmaf((Q_).c.w, h3_, l2)
+
 template <int C, int PE, int BF>
 __host__ __device__ static inline int ug_mlp_lds_floats() {
   const ug_mlp_layout ML = ug_mlp_lay(C, 3 + 6 * PE);
@@ -1215,16 +1238,30 @@ __device__ __forceinline__ void ug_rgbnet_pass(const float (&x)[(2 * UG_CH(C) + 
   constexpr int W3B = 16;   // rows per batch
 #pragma unroll
   for (int sb = 0; sb < 64; sb += W3B) {
-    float4 w3[W3B];
+    if constexpr (BF == 2) {      // dense W3 of the fp16x2 image: 12 reads per 16 rows
+      ug_w3x4 w3[W3B / 4];
 #pragma unroll
-    for (int i = 0; i < W3B; ++i) w3[i] = M.W3[bo + sb + i];
-    __builtin_amdgcn_sched_barrier(0);
+      for (int i = 0; i < W3B / 4; ++i) w3[i] = ug_w3_load4(M, bo, sb + 4 * i);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < W3B; ++i) {
-      const float hv = ug_relu(acc2[(sb + i) >> 4][(sb + i) & 15]);
-      l0 = fmaf(w3[i].x, hv, l0);
-      l1 = fmaf(w3[i].y, hv, l1);
-      l2 = fmaf(w3[i].z, hv, l2);
+      for (int i = 0; i < W3B / 4; ++i) {
+        const int r0 = sb + 4 * i;
+        const float h0 = ug_relu(acc2[r0 >> 4][r0 & 15]), h1 = ug_relu(acc2[r0 >> 4][(r0 & 15) + 1]);
+        const float h2 = ug_relu(acc2[r0 >> 4][(r0 & 15) + 2]), h3 = ug_relu(acc2[r0 >> 4][(r0 & 15) + 3]);
+        UG_W3_FMA4(w3[i], h0, h1, h2, h3);
+      }
+    } else {
+      float4 w3[W3B];
+#pragma unroll
+      for (int i = 0; i < W3B; ++i) w3[i] = M.W3[bo + sb + i];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < W3B; ++i) {
+        const float hv = ug_relu(acc2[(sb + i) >> 4][(sb + i) & 15]);
+        l0 = fmaf(w3[i].x, hv, l0);
+        l1 = fmaf(w3[i].y, hv, l1);
+        l2 = fmaf(w3[i].z, hv, l2);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -1393,8 +1430,8 @@ __device__ __forceinline__ void ug_rgbnet_pass_h2(const float (&x)[(2 * UG_CH(C)
     xs = ug_split8h(v, M.c12);
   }
   ug_fence_operands();
-  constexpr int W3B = 8;        // W3 rows per batch, two batches in registers
-  float4 w3[2][W3B];
+  constexpr int W3B = 8;        // W3 rows per batch, two batches in registers (dense image: 6 ds_read_b128 per batch)
+  ug_w3x4 w3[2][W3B / 4];
 #pragma unroll
   for (int st8 = 0; st8 < 8; ++st8) {
     float vn[8];
@@ -1406,7 +1443,7 @@ __device__ __forceinline__ void ug_rgbnet_pass_h2(const float (&x)[(2 * UG_CH(C)
   }
   // first batch of layer 3's weights: requested before layer 2's last MFMAs have drained
 #pragma unroll
-  for (int i = 0; i < W3B; ++i) w3[0][i] = M.W3[bo + i];
+  for (int i = 0; i < W3B / 4; ++i) w3[0][i] = ug_w3_load4(M, bo, 4 * i);
   ug_fence_results();
   UG_PROF_MARK(prof, 4)
   // the NEXT pass's layer-1 biases into the (now dead) layer-1 accumulators: they land while layer 3 runs
@@ -1418,15 +1455,15 @@ __device__ __forceinline__ void ug_rgbnet_pass_h2(const float (&x)[(2 * UG_CH(C)
     const int cur = (sb / W3B) & 1;
     if (sb + W3B < 64) {
 #pragma unroll
-      for (int i = 0; i < W3B; ++i) w3[cur ^ 1][i] = M.W3[bo + sb + W3B + i];
+      for (int i = 0; i < W3B / 4; ++i) w3[cur ^ 1][i] = ug_w3_load4(M, bo, sb + W3B + 4 * i);
     }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < W3B; ++i) {
-      const float hv = ug_relu(acc2[(sb + i) >> 4][(sb + i) & 15]);
-      l0 = fmaf(w3[cur][i].x, hv, l0);
-      l1 = fmaf(w3[cur][i].y, hv, l1);
-      l2 = fmaf(w3[cur][i].z, hv, l2);
+    for (int i = 0; i < W3B / 4; ++i) {
+      const int r0 = sb + 4 * i;
+      const float h0 = ug_relu(acc2[r0 >> 4][r0 & 15]), h1 = ug_relu(acc2[r0 >> 4][(r0 & 15) + 1]);
+      const float h2 = ug_relu(acc2[r0 >> 4][(r0 & 15) + 2]), h3 = ug_relu(acc2[r0 >> 4][(r0 & 15) + 3]);
+      UG_W3_FMA4(w3[cur][i], h0, h1, h2, h3);
     }
     __builtin_amdgcn_sched_barrier(0);
   }

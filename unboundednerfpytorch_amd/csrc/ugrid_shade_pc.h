@@ -207,27 +207,21 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
       wl2 = nwl; wh2 = nwh;
     }
     // first rows of this half's layer-3 weights, requested before the MFMAs have drained
-    constexpr int W3B = 4;      // rows per batch, two batches in registers (the split operands of layer 2 are still live)
-    float4 w3[2][W3B];
-#pragma unroll
-    for (int i = 0; i < W3B; ++i) w3[0][i] = M.W3[bo + 32 * pr2 + i];
+    constexpr int W3B = 4;      // rows per batch = three 16-byte reads of the dense W3 image, two batches in registers
+    ug_w3x4 w3[2];
+    w3[0] = ug_w3_load4(M, bo, 32 * pr2);
     ug_fence_results();
     if (pr2 == 1) { UG_PROF_MARK(prof, 4) }
     // ---- layer 3, rows 32 pr2 .. 32 pr2 + 31 (same order as the 4-tile pass: rows ascending)
 #pragma unroll
     for (int sb = 0; sb < 32; sb += W3B) {
       const int cur = (sb / W3B) & 1;
-      if (sb + W3B < 32) {
-#pragma unroll
-        for (int i = 0; i < W3B; ++i) w3[cur ^ 1][i] = M.W3[bo + 32 * pr2 + sb + W3B + i];
-      }
+      if (sb + W3B < 32) w3[cur ^ 1] = ug_w3_load4(M, bo, 32 * pr2 + sb + W3B);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int i = 0; i < W3B; ++i) {
-        const float hv = ug_relu(acc2[(sb + i) >> 4][(sb + i) & 15]);
-        l0 = fmaf(w3[cur][i].x, hv, l0);
-        l1 = fmaf(w3[cur][i].y, hv, l1);
-        l2 = fmaf(w3[cur][i].z, hv, l2);
+      {
+        const float h0 = ug_relu(acc2[sb >> 4][sb & 15]), h1 = ug_relu(acc2[sb >> 4][(sb & 15) + 1]);
+        const float h2 = ug_relu(acc2[sb >> 4][(sb & 15) + 2]), h3 = ug_relu(acc2[sb >> 4][(sb & 15) + 3]);
+        UG_W3_FMA4(w3[cur], h0, h1, h2, h3);
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -237,6 +231,20 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
   l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
   const float pr = ww * ug_sigmoid(l0), pg = ww * ug_sigmoid(l1), pb = ww * ug_sigmoid(l2);
   UG_PROF_MARK(prof, 5)
+#ifdef UG_ACC_DSADD
+  {
+    // A/B arm (profiles/r04/shade_ab.txt): the per-ray sums live in LDS ([64 rays][3] floats in the wave's scratch) and every
+    // survivor adds its colour with three fire-and-forget ds_add_f32 -- no mask round trip, no wait.  LDS operations of a wave
+    // complete in program order, so passes are summed in order; WITHIN one instruction the order in which the LDS serialises
+    // lanes that hit the same ray is the hardware's (observed ascending = list order = bit-identical, but not architected).
+    if (ok && h == 0) {
+      const unsigned ra = ug_lds_off((const float *)amask + 3 * sl);
+      asm volatile("ds_add_f32 %0, %1\n\tds_add_f32 %0, %2 offset:4\n\tds_add_f32 %0, %3 offset:8"
+                   :: "v"(ra), "v"(pr), "v"(pg), "v"(pb) : "memory");
+    }
+    (void)aval; (void)accr; (void)accg; (void)accb;
+  }
+#else
   {
     // ordered per-ray sum through LDS (masks pre-cleared, see ug_rgbnet_pass_h2)
     if (ok && h == 0) {
@@ -254,6 +262,7 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
     }
     __builtin_amdgcn_wave_barrier();
   }
+#endif
   UG_PROF_MARK(prof, 6)
 }
 
@@ -377,6 +386,12 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
   ug_h2_state h2st;
   if constexpr (MODE == 0) ug_h2_preload(M, h * 64, h2st);
   amask[lane] = 0u;                // the hand-scheduled passes keep the per-ray masks cleared between passes
+#ifdef UG_ACC_DSADD
+  amask[64 + lane] = 0u; amask[128 + lane] = 0u;     // (A/B arm: [64][3] per-ray sums in the same 192 floats)
+#endif
+#ifdef UG_PC_CONSUMER_PRIO
+  __builtin_amdgcn_s_setprio(UG_PC_CONSUMER_PRIO);   // A/B arm: the matrix-pipe waves win issue arbitration over the gather waves
+#endif
   ug_wave_lds_sync();
 #ifdef UG_SHADE_PROF
   ug_prof prof_unused;          // phases of ug_rgbnet_pass: acc[3] layer 1, [4] layer 2, [5] layer 3 + sigmoid, [6] accumulation
@@ -414,6 +429,13 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
     const bool ok = base + sv < count;
     UG_PC_T0(tt_)
     if (tile != cur_tile) {
+#ifdef UG_ACC_DSADD
+      if constexpr (MODE == 1) {        // the sums of the finished tile sit in LDS: fetch and clear (in order behind the adds)
+        float *ra = (float *)amask + 3 * lane;
+        accr = ra[0]; accg = ra[1]; accb = ra[2];
+        ra[0] = 0.f; ra[1] = 0.f; ra[2] = 0.f;
+      }
+#endif
       if (cur_tile >= 0) {
         const int64_t ray = (int64_t)cur_tile * UG_WAVE + lane;
         if (ray < a.n_rays) { rgb_marched[3 * ray] = accr; rgb_marched[3 * ray + 1] = accg; rgb_marched[3 * ray + 2] = accb; }
@@ -464,6 +486,12 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
     }
     UG_PC_ADD(t_mlp, tm)
   }
+#ifdef UG_ACC_DSADD
+  if constexpr (MODE == 1) {
+    const float *ra = (const float *)amask + 3 * lane;
+    accr = ra[0]; accg = ra[1]; accb = ra[2];
+  }
+#endif
   if (cur_tile >= 0) {
     const int64_t ray = (int64_t)cur_tile * UG_WAVE + lane;
     if (ray < a.n_rays) { rgb_marched[3 * ray] = accr; rgb_marched[3 * ray + 1] = accg; rgb_marched[3 * ray + 2] = accb; }
