@@ -1,0 +1,27 @@
+// Shared helpers of the four pybind modules that bind libugrid_hip.so under the reference's extension-module names
+// (INTEGRATION.md section B).  What a maintainer of the reference would commit in place of FourierGrid/cuda/*.cu: the
+// same m.def() names, argument lists and return values as FourierGrid/cuda/render_utils.cpp:168-184,
+// total_variation.cpp:21-24, ub360_utils.cpp:19-22, adam_upd.cpp:77-87 -- the device work goes to the C ABI of
+// include/ugrid_hip.h on the tensor's device (device guard) and torch's CURRENT stream.
+#pragma once
+#include <torch/extension.h>
+#include <c10/hip/HIPGuard.h>
+#include <c10/hip/HIPStream.h>
+
+#include <vector>
+
+#include "ugrid_hip.h"
+
+// the reference's own input checks (render_utils.cpp:98-100), same wording
+#define CHECK_CUDA(x) TORCH_CHECK(x.is_cuda(), #x " must be a CUDA tensor")
+#define CHECK_CONTIGUOUS(x) TORCH_CHECK(x.is_contiguous(), #x " must be contiguous")
+#define CHECK_INPUT(x) CHECK_CUDA(x); CHECK_CONTIGUOUS(x)
+#define CHECK_F32(x) TORCH_CHECK(x.scalar_type() == at::kFloat, #x " must be float32 (the MI355X library instantiates fp32 only)")
+
+static inline void ug_check(int err, const char *what) {
+  TORCH_CHECK(err == 0, "libugrid_hip: ", what, " failed with hipError_t ", err);
+}
+static inline ugrid_stream_t ug_stream() { return (ugrid_stream_t)c10::hip::getCurrentHIPStream().stream(); }
+#define UG_GUARD(t) const c10::hip::HIPGuard ug_device_guard_((t).device())
+static inline const float *fp(const torch::Tensor &t) { return t.data_ptr<float>(); }
+static inline float *fpm(torch::Tensor &t) { return t.data_ptr<float>(); }

@@ -26,8 +26,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def regenerated(golden_dir):
+@pytest.fixture(scope="module", params=["ctypes", "pybind"])
+def regenerated(golden_dir, request):
+    """params: the reference's Python over (a) this package's ctypes mirrors, (b) the NATIVE pybind11 modules of binding/
+    (INTEGRATION.md section B built as code) -- the same 18 functions of the same C ABI either way"""
     from oracle import build_ref, install_stubs
     ref_root = build_ref.reference_python_root()
     if ref_root is None:
@@ -36,7 +38,16 @@ def regenerated(golden_dir):
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
     for m in [k for k in sys.modules if k == "FourierGrid" or k.startswith("FourierGrid.")]:
         del sys.modules[m]
-    names = compat.install_as_reference_extensions()
+    if request.param == "pybind":
+        from binding import build as binding_build
+        if not binding_build.available():
+            pytest.skip("binding/_build not built (python binding/build.py; __graft_entry__.build() does it)")
+        names = compat.install_as_reference_extensions(native=True)
+        render_utils_cuda, total_variation_cuda, ub360_utils_cuda, adam_upd_cuda = [sys.modules[n] for n in (
+            "render_utils_cuda", "total_variation_cuda", "ub360_utils_cuda", "adam_upd_cuda")]
+        assert render_utils_cuda.__file__.endswith(os.path.join("binding", "_build", "render_utils_cuda.so"))
+    else:
+        names = compat.install_as_reference_extensions()
     assert sys.modules["render_utils_cuda"] is render_utils_cuda and len(names) == 4
     hip = types.SimpleNamespace(render_utils_cuda=render_utils_cuda, total_variation_cuda=total_variation_cuda,
                                 ub360_utils_cuda=ub360_utils_cuda, adam_upd_cuda=adam_upd_cuda)
@@ -68,6 +79,8 @@ def regenerated(golden_dir):
         install_stubs.REFERENCE_ROOT, install_stubs.OPS_BACKEND = old
         for m in [k for k in sys.modules if k == "FourierGrid" or k.startswith("FourierGrid.")]:
             del sys.modules[m]
+        for n in ("render_utils_cuda", "total_variation_cuda", "ub360_utils_cuda", "adam_upd_cuda"):
+            sys.modules.pop(n, None)
     yield out, golden_dir
     shutil.rmtree(out, ignore_errors=True)
 

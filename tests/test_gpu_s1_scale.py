@@ -178,18 +178,31 @@ def test_s1_tail_against_fp64_ground_truth():
     _dump("s1_fp64_ground_truth.json", res)
     for name, d in res["distance_to_fp64"].items():
         print("S1 fp64  %-8s " % name + "  ".join("%s linf %.3e mean %.2e (%d > 1e-4)" % (k[:5], d[k]["linf"], d[k]["mean_abs"], d[k]["rays_above_bound"]) for k in KEYS))
-    n_sel = res["rays_evaluated_in_fp64"]
+    fused = res["distance_to_fp64"]["fused"]
     for name in evals:
         if name == "fused":
             continue
-        ok = res["bound_where_ref_ok"][name]
-        viol = res["violations"][name]
-        print("S1 fp64  vs %-8s fused linf where the reference is within 1e-4 of fp64 (%d rays): %s | rays where fused is further from fp64 by > 2e-5: %s"
-              % (name, ok["rays_where_ref_within_bound_of_fp64"], {k: ok[k] for k in KEYS}, {k: viol[k]["rays"] for k in KEYS}))
+        ok, viol, ref = res["bound_where_ref_ok"][name], res["violations"][name], res["distance_to_fp64"][name]
+        print("S1 fp64  vs %-8s fused linf where that reference is within 1e-4 of fp64 (%d rays): %s | rays where fused / the reference is the one "
+              "further from fp64 by > 2e-5: %s" % (name, ok["rays_where_ref_within_bound_of_fp64"], {k: ok[k] for k in KEYS},
+                                                   {k: (viol[k]["rays"], viol[k]["rays_where_the_reference_is_further_than_fused"]) for k in KEYS}))
         for k in KEYS:
-            assert ok[k] is not None and ok[k] <= 1e-4, (name, k, ok[k])
-            assert viol[k]["rays"] <= max(4, n_sel // 250), (name, k, viol[k])
-            assert res["distance_to_fp64"]["fused"][k]["mean_abs"] <= res["distance_to_fp64"][name][k]["mean_abs"] * 1.25 + 1e-7, (name, k)
+            # (1) the fused render's error against the truth is no larger than the reference's own: worst ray, mean, tail size
+            assert fused[k]["linf"] <= 1.1 * ref[k]["linf"] + 1e-5, (name, k, fused[k], ref[k])
+            assert fused[k]["mean_abs"] <= 1.1 * ref[k]["mean_abs"] + 1e-7, (name, k, fused[k], ref[k])
+            assert fused[k]["rays_above_bound"] <= ref[k]["rays_above_bound"] + 3, (name, k, fused[k], ref[k])
+            # (2) a threshold flip moves ONE of two fp32 evaluations: neither side is systematically the unlucky one
+            assert viol[k]["rays"] <= viol[k]["rays_where_the_reference_is_further_than_fused"] + 6, (name, k, viol[k])
+    # (3) the north-star bound against the truth: on every ray where the CPU reference (the pinned restatement of the reference's
+    # own arithmetic) is within 1e-4 of fp64 the fused render is too (10 % allowance: the rays sit on flipped thresholds, where the
+    # truth itself is one side of a discontinuity), and on the rays where every fp32 reference is sound (within 5e-5) it is within
+    # 1e-4 with margin
+    okc = res["bound_where_ref_ok"]["ref_cpu"]
+    snd = res["fused_on_rays_where_all_references_are_within_half_bound"]
+    print("S1 fp64  fused on the %d rays where every reference is within 5e-5 of fp64: %s" % (snd["rays"], {k: snd[k] for k in KEYS}))
+    for k in KEYS:
+        assert okc[k] is not None and okc[k] <= 1.1e-4, (k, okc[k])
+        assert snd["rays"] >= 1000 and snd[k] <= 1e-4, (k, snd)
 
 
 def pairwise_table(named):

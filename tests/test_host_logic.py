@@ -668,3 +668,66 @@ def test_pixel_tile_order_is_a_permutation_and_untile_inverts_it():
     assert pixel_tile_order(45, 77, "cpu") is None and pixel_tile_order(H, W, "cpu", tile=1) is None
     o4 = pixel_tile_order(H, W, "cpu", tile=4)
     assert torch.equal(untile(x[o4], H, W, tile=4), x)
+
+
+def _sparse_exchange_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
+    from oracle import ref_ops
+    from unboundednerfpytorch_amd.sharded_adam import ShardedMaskedAdam
+    res = {}
+    n_lines = 64 * world          # 64 lines per rank: n = 8192 floats, divisible by 64 * world
+    for mode in ("masked", "dense_tv", "unmasked"):
+        for sparse in (True, False):
+            g = torch.Generator().manual_seed(7)
+            p0 = torch.randn(n_lines * 64, generator=g).reshape(2, 4, 8, 8, 16)
+            p = torch.nn.Parameter(p0.clone())
+            opt = ShardedMaskedAdam([{'params': [p], 'lr': 0.05, 'skip_zero_grad': mode != "unmasked"}], min_shard_numel=256, ops=ref_ops,
+                                    sparse_exchange=sparse)
+            ex = []
+            for it in range(3):
+                gg = torch.Generator().manual_seed(100 * it + rank)
+                grad = torch.zeros(n_lines, 64)
+                hit = torch.randperm(n_lines, generator=gg)[:6 + rank]          # a few lines per rank, different on each
+                grad[hit] = torch.randn(hit.numel(), 64, generator=gg) * (torch.rand(hit.numel(), 64, generator=gg) > 0.3)
+                p.grad = grad.reshape(p.shape).clone()
+                tv = {p: (1e-3, mode == "dense_tv", None)} if mode != "unmasked" else None
+                if tv is not None:
+                    tv = {p: (1e-3, mode == "dense_tv", ref_ops)}
+                opt.step(tv_terms=tv)
+                ex.append(dict(opt.last_exchange[id(p)]))
+            res[(mode, sparse)] = (p.detach().numpy().copy(), ex)
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_sparse_touched_line_exchange_equals_the_dense_collectives_gloo():
+    """ShardedMaskedAdam exchanges the 256-byte lines some rank touched (bitmap all-gather + OR, packed
+    reduce-scatter, packed all-gather of the updated rows) instead of the dense gradient / parameter ranges.  Two gloo ranks,
+    three update modes (masked TV + masked Adam; dense TV: sparse gradient exchange, dense parameter gather; plain Adam): the
+    parameters after three steps equal the dense collectives' bit for bit on every rank, and the bytes on the wire shrink."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36100 + os.getpid() % 2000
+    procs = [ctx.Process(target=_sparse_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for mode in ("masked", "dense_tv", "unmasked"):
+        a0, ex_s = out[0][1][(mode, True)]
+        a1, _ = out[1][1][(mode, True)]
+        d0, ex_d = out[0][1][(mode, False)]
+        assert np.array_equal(a0, a1), mode                     # every rank holds the same parameters
+        assert np.array_equal(a0, d0), mode                     # = the dense collectives, bit for bit
+        assert all(e["mode"] == "dense" for e in ex_d)
+        for e in ex_s:
+            assert e["reduce_scatter_bytes"] < e["dense_bytes_each_way"] // 3, e
+            if mode == "masked":
+                assert e["mode"] == "sparse" and e["all_gather_bytes"] < e["dense_bytes_each_way"] // 3, e
+            else:                                               # every element of the range moves: the gather stays dense
+                assert e["all_gather_bytes"] == e["dense_bytes_each_way"], e

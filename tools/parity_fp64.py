@@ -93,13 +93,23 @@ def ground_truth_study(cpu_state, rays_cpu, evaluations, stepsize, n_random=1024
     for name, d in dist.items():
         res["distance_to_fp64"][name] = {k: {"linf": float(e.max()), "mean_abs": float(e.mean()), "rays_above_bound": int((e > bound).sum())}
                                          for k, e in d.items()}
+    sound = torch.ones(sel.numel(), dtype=torch.bool)          # rays on which EVERY fp32 reference is within bound / 2 of the truth
     for name in refs:
         viol, ok_all = {}, torch.ones(sel.numel(), dtype=torch.bool)
         for k in KEYS:
             v = dist["fused"][k] > dist[name][k] + slack
-            viol[k] = {"rays": int(v.sum()), "worst_excess": float((dist["fused"][k] - dist[name][k]).max())}
+            rv = dist[name][k] > dist["fused"][k] + slack
+            viol[k] = {"rays": int(v.sum()), "worst_excess": float((dist["fused"][k] - dist[name][k]).max()),
+                       "rays_where_the_reference_is_further_than_fused": int(rv.sum()),
+                       "worst_excess_of_the_reference": float((dist[name][k] - dist["fused"][k]).max())}
             ok_all &= dist[name][k] <= bound
+            sound &= dist[name][k] <= 0.5 * bound
         res["violations"][name] = viol
         res["bound_where_ref_ok"][name] = {"rays_where_ref_within_bound_of_fp64": int(ok_all.sum()),
                                            **{k: (float(dist["fused"][k][ok_all].max()) if bool(ok_all.any()) else None) for k in KEYS}}
+    res["fused_on_rays_where_all_references_are_within_half_bound"] = {
+        "rays": int(sound.sum()), **{k: (float(dist["fused"][k][sound].max()) if bool(sound.any()) else None) for k in KEYS}}
+    # per-ray distances (for offline analysis; 3 x n_eval floats per evaluation)
+    res["per_ray"] = {"selected_because_far": far[sel].tolist(),
+                      **{name: {k: [float("%.4g" % x) for x in d[k].tolist()] for k in KEYS} for name, d in dist.items()}}
     return res

@@ -6,7 +6,19 @@ reference call the MI355X kernels unchanged.  Call before importing any referenc
 import sys
 
 
-def install_as_reference_extensions():
+def install_as_reference_extensions(native=False):
+    """native=False: the ctypes mirrors of this package (always available).  native=True: the pybind11 modules of binding/
+    (what a maintainer would build in place of FourierGrid/cuda/*.cu; `python binding/build.py`)."""
+    if native:
+        import os
+        import sys as _sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        if root not in _sys.path:
+            _sys.path.insert(0, root)
+        from binding import build as _b
+        if not _b.available():
+            raise RuntimeError("binding/_build is empty: run `python binding/build.py` (needs torch headers and libugrid_hip.so)")
+        return tuple(_b.install())
     from . import adam_upd_cuda, render_utils_cuda, total_variation_cuda, ub360_utils_cuda
     for mod in (render_utils_cuda, total_variation_cuda, ub360_utils_cuda, adam_upd_cuda):
         sys.modules[mod.__name__.rsplit(".", 1)[-1]] = mod

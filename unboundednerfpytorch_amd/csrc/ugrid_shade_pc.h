@@ -82,6 +82,16 @@ __device__ int g_pc_dbg;
 #define UG_PC_ADD(acc, t)
 #endif
 
+// A/B arm UG_PC_PRIO_PHASED=hi: the consumer raises its issue priority only while it feeds the matrix pipe (layers 1 and 2) and
+// drops back for the VALU-only layer 3 / accumulation, where the gather waves' address arithmetic should win
+#ifdef UG_PC_PRIO_PHASED
+#define UG_PRIO_HI() __builtin_amdgcn_s_setprio(UG_PC_PRIO_PHASED)
+#define UG_PRIO_LO() __builtin_amdgcn_s_setprio(0)
+#else
+#define UG_PRIO_HI()
+#define UG_PRIO_LO()
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 // LEAN fp16x2 rgbnet pass for the 12-wave geometry (<= 168 VGPRs): same products, same accumulation order per output
 // element and the same layer-3 / per-ray summation order as ug_rgbnet_pass_h2 -- bit-identical results -- with a smaller
@@ -113,6 +123,7 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
   const int lane = ug_lane();
   const int h = lane >> 5, sv = lane & 31;
   UG_PROF_MARK(prof, 2)
+  UG_PRIO_HI();
   int bo = h * 64;
   asm volatile("" : "+v"(bo));
   const f16x8 *A1h = (const f16x8 *)M.A1, *A2h = (const f16x8 *)M.A2;
@@ -167,6 +178,7 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
 #pragma unroll
   for (int pr2 = 0; pr2 < 2; ++pr2) {
     // ---- layer 2, output tiles 2 pr2 and 2 pr2 + 1
+    if (pr2 == 1) { UG_PRIO_HI(); }
     f32x16 acc2[2];
 #pragma unroll
     for (int o = 0; o < 2; ++o)
@@ -211,6 +223,7 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
     ug_w3x4 w3[2];
     w3[0] = ug_w3_load4(M, bo, 32 * pr2);
     ug_fence_results();
+    UG_PRIO_LO();
     if (pr2 == 1) { UG_PROF_MARK(prof, 4) }
     // ---- layer 3, rows 32 pr2 .. 32 pr2 + 31 (same order as the 4-tile pass: rows ascending)
 #pragma unroll

@@ -141,7 +141,8 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
     # model's k0 query; every loss term reaches the grid through it), which is what the bitmap's validity rests on -- so the
     # step certifies it for its own backward only.  A caller-supplied loss that regularises k0.grid directly must not use
     # train_iteration's certificate: pass distortion_fn / losses through `out`, or call _gradpool.decertify first.
-    certified = [model.k0.grid] if (world_size == 1 and hasattr(model, 'k0') and isinstance(getattr(model.k0, 'grid', None), torch.nn.Parameter)) else []
+    # (data-parallel runs use the bitmap to pick the lines they exchange, sharded_adam._line_bits)
+    certified = [model.k0.grid] if (hasattr(model, 'k0') and isinstance(getattr(model.k0, 'grid', None), torch.nn.Parameter)) else []
     _gradpool.certify(certified)
     try:
         try:
