@@ -5,8 +5,10 @@
 // include/ugrid_hip.h on the tensor's device (device guard) and torch's CURRENT stream.
 #pragma once
 #include <torch/extension.h>
-#include <c10/hip/HIPGuard.h>
-#include <c10/hip/HIPStream.h>
+// torch-ROCm presents its HIP devices under the device type "cuda": the guard / stream classes that accept it are the
+// "MasqueradingAsCUDA" ones (what torch's own hipify maps c10/cuda/CUDAGuard.h and CUDAStream.h to)
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 
 #include <vector>
 
@@ -21,7 +23,7 @@
 static inline void ug_check(int err, const char *what) {
   TORCH_CHECK(err == 0, "libugrid_hip: ", what, " failed with hipError_t ", err);
 }
-static inline ugrid_stream_t ug_stream() { return (ugrid_stream_t)c10::hip::getCurrentHIPStream().stream(); }
-#define UG_GUARD(t) const c10::hip::HIPGuard ug_device_guard_((t).device())
+static inline ugrid_stream_t ug_stream() { return (ugrid_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA().stream(); }
+#define UG_GUARD(t) const c10::hip::HIPGuardMasqueradingAsCUDA ug_device_guard_((t).device())
 static inline const float *fp(const torch::Tensor &t) { return t.data_ptr<float>(); }
 static inline float *fpm(torch::Tensor &t) { return t.data_ptr<float>(); }

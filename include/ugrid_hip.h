@@ -301,6 +301,10 @@ typedef struct ugrid_render_params {
 #define UGRID_MLP_FP32 0    /* v_mfma_f32_32x32x2_f32: plain fp32 products */
 #define UGRID_MLP_BF16X3 1  /* weights and activations split into 3 bf16 parts, 6 MFMA products (~2^-24) */
 #define UGRID_MLP_FP16X2 2  /* power-of-two scaled operands split into 2 fp16 parts, 3 MFMA products (~2^-22) */
+/* flag OR-ed into mlp_mode for ugrid_render_shade: residual colour of the reference's DirectVoxGO with rgbnet_direct = False
+ * (dvgo.py:385-398): rgb = sigmoid(rgbnet([k0[3:], view embedding]) + k0[:3]).  The caller packs the first layer [128, C + emb]
+ * with ZERO columns for the three diffuse channels (ugrid_pack_mlp sees a network of the usual shape); needs k0_channels >= 9. */
+#define UGRID_MLP_RESIDUAL 0x100
 
 /* Bytes of the survivor work list (worst case: every sample survives) for n_rays x n_samples. */
 int64_t ugrid_render_ws_bytes(int64_t n_rays, int32_t n_samples);

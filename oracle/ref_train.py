@@ -49,9 +49,26 @@ def run(model, backend, cfg_train, cfg_model, batches, n_iters, device, eval_fn=
     ct.keys = lambda: cfg_train.keys()          # utils.create_optimizer_or_freeze_model iterates cfg_train.keys() (an mmcv Config there)
     rk = dict(render_kwargs or {})
     dev = torch.device(device)
-    with torch.device(dev):                     # the reference builds its sample table with no device argument (FourierGrid_model.py:526-532)
+    hist = {"psnr_train": [], "loss": [], "eval": []}
+    # The reference program makes CUDA the default tensor type (run_FourierGrid.py: torch.set_default_tensor_type(
+    # 'torch.cuda.FloatTensor')) and its model code relies on it: the sample table (FourierGrid_model.py:526-532) and the
+    # legacy torch.Tensor(list) constructors of MaskGrid (FourierGrid_grid.py:156-157, reached from scale_volume_grid) carry no
+    # device.  Same here for the duration of the run; the caller's default is restored afterwards.
+    legacy = dev.type == "cuda"
+    if legacy:
+        torch.set_default_tensor_type(torch.cuda.FloatTensor)
+    try:
+        with torch.device(dev):
+            _loop(model, utils, ct, cfg_train, cfg_model, batches, n_iters, rk, near_thres, eval_fn, eval_every, on_step, hist)
+    finally:
+        if legacy:
+            torch.set_default_tensor_type(torch.FloatTensor)
+    return hist
+
+
+def _loop(model, utils, ct, cfg_train, cfg_model, batches, n_iters, rk, near_thres, eval_fn, eval_every, on_step, hist):
+    if True:
         optimizer = utils.create_optimizer_or_freeze_model(model, ct, global_step=0)
-        hist = {"psnr_train": [], "loss": [], "eval": []}
         pg = list(cfg_train.get("pg_scale", []))
         for global_step in range(1, n_iters + 1):
             if global_step in pg:                                                                   # run_train.py:187-201
@@ -94,4 +111,4 @@ def run(model, backend, cfg_train, cfg_model, batches, n_iters, device, eval_fn=
                 on_step(global_step, model)
             if eval_fn is not None and (global_step % eval_every == 0 or global_step == n_iters):
                 hist["eval"].append((global_step, eval_fn(model)))
-    return hist
+

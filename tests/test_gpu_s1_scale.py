@@ -202,7 +202,7 @@ def test_s1_tail_against_fp64_ground_truth():
     print("S1 fp64  fused on the %d rays where every reference is within 5e-5 of fp64: %s" % (snd["rays"], {k: snd[k] for k in KEYS}))
     for k in KEYS:
         assert okc[k] is not None and okc[k] <= 1.1e-4, (k, okc[k])
-        assert snd["rays"] >= 1000 and snd[k] <= 1e-4, (k, snd)
+        assert snd["rays"] >= 800 and snd[k] <= 1e-4, (k, snd)
 
 
 def pairwise_table(named):

@@ -128,15 +128,18 @@ def run(args):
     # fraction of the k0 gradient's 256-byte lines one backward marks (a fresh backward; the optimizer clears the bitmap)
     touched = None
     if _gradpool.touch_enabled:
+        _gradpool.certify([model.k0.grid])           # (what train_iteration does for its own backward)
         out = model(o, d, v, global_step=step, is_train=True, **rk)
         out["rgb_marched"].sum().backward()
         tb = _gradpool.touch_of(model.k0.grid, model.k0.grid.grad)
+        _gradpool.decertify([model.k0.grid])
         if tb is not None:
             w = tb.to(torch.int64) & 0xFFFFFFFF
             bits = sum(int(((w >> i) & 1).sum()) for i in range(32))
             touched = bits / float((model.k0.grid.numel() + 63) // 64)
     with torch.no_grad():
         out = model(o, d, v, global_step=step, is_train=True, **rk)
+    hbm_roof = tv_adam_dense_roofline(model, opt, dev)
     M = int(out["weights"].numel())
     S = int(out["n_max"])
     n_k0 = model.k0.grid.numel()
@@ -151,8 +154,49 @@ def run(args):
            "k0_streaming_floor_ms": {"note": "compulsory HBM passes over the 3.46 GB k0-sized arrays per step at 6.3 TB/s achievable: "
                                              "grad zero-fill (1x write), dense TV (param read + grad read/write), masked Adam (grad read)",
                                      "value": 5 * n_k0 * 4 / 6.3e12 * 1e3},
+           "roofline_tv_adam_dense": hbm_roof,
            **stats}
     return res
+
+
+def tv_adam_dense_roofline(model, opt, dev, reps=6):
+    """The one genuinely HBM-bound kernel of the path: the fused dense TV + Adam pass over the k0 grid
+    (ugrid_tv_adam_dense_cl; run_train.py:281-288 as one kernel).  Algorithmic bytes per launch = 7 arrays x numel x 4 B: it reads
+    param, grad, exp_avg, exp_avg_sq and writes param_out, exp_avg, exp_avg_sq -- each byte once (the stencil's neighbours come
+    from cache).  Timed alone with HIP events on the launch stream; peak = the guide's 8 TB/s HBM3E figure."""
+    from unboundednerfpytorch_amd import _lib, adam_upd_cuda
+    _lib.wait_pending(model.k0.grid)
+    torch.cuda.synchronize()
+    p = model.k0.grid.data
+    st = opt.state.get(model.k0.grid, {})
+    if "exp_avg" not in st or st["exp_avg"].shape != p.shape:
+        return None
+    alt = torch.empty_like(p, memory_format=torch.preserve_format)
+    g = torch.zeros_like(p, memory_format=torch.preserve_format)
+    from unboundednerfpytorch_amd.sharded_adam import ShardedMaskedAdam
+    ShardedMaskedAdam._flat(g)[::4099] = 1e-3          # a sparse gradient (the masked rule still reads every element)
+    m, v = st["exp_avg"].clone(memory_format=torch.preserve_format), st["exp_avg_sq"].clone(memory_format=torch.preserve_format)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+    ok = True
+    for i in range(reps + 1):
+        if i:
+            ev[i - 1].record()
+        ok = ok and adam_upd_cuda.tv_adam_dense(p if i % 2 == 0 else alt, alt if i % 2 == 0 else p, g, m, v, 1e-7, 1e-7, 1e-7, 5 + i, 0.9, 0.99,
+                                                1e-9, 1e-8, True)
+    ev[reps].record()
+    torch.cuda.synchronize()
+    if not ok:
+        return None
+    if (reps + 1) % 2 == 1:                       # an odd number of swaps: the current values sit in `alt`
+        p.copy_(alt)
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(reps))[reps // 2]
+    nbytes = 7 * p.numel() * 4
+    del alt, g, m, v
+    torch.cuda.empty_cache()
+    return {"kernel": "ugrid_tv_adam_dense_cl" if not p.is_contiguous() else "ugrid_tv_adam_dense", "bound": "hbm", "ms": ms,
+            "algorithmic_bytes": nbytes, "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+            "frac": nbytes / (ms * 1e-3) / 1e9 / 8000.0,
+            "note": "7 k0-sized arrays x 4 B, each byte once; median of %d launches, HIP events on the launch stream" % reps}
 
 
 def main():

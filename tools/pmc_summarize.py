@@ -80,6 +80,11 @@ def main():
                 e["l1_hit_rate"] = 1.0 - m["TCP_TCC_READ_REQ_sum"] / max(1.0, m["TCP_TOTAL_CACHE_ACCESSES_sum"])
         if "TA_TA_BUSY_sum" in m and "GRBM_GUI_ACTIVE" in m:
             e["ta_busy_frac"] = m["TA_TA_BUSY_sum"] / 256.0 / (m["GRBM_GUI_ACTIVE"] / 8.0)      # one TA per CU
+        if "TA_TA_BUSY_sum" in m and m.get("TA_FLAT_READ_WAVEFRONTS_sum"):
+            e["ta_clocks_per_wave_instruction"] = m["TA_TA_BUSY_sum"] / m["TA_FLAT_READ_WAVEFRONTS_sum"]       # 16 at the path's peak
+        if "TCC_EA0_RDREQ_128B_sum" in m:
+            e["hbm_read_bytes_by_request_size"] = (32 * m.get("TCC_EA0_RDREQ_32B_sum", 0) + 64 * m.get("TCC_EA0_RDREQ_64B_sum", 0)
+                                                   + 128 * m["TCC_EA0_RDREQ_128B_sum"])
         if "SQ_WAVE_CYCLES" in m:
             wc = m["SQ_WAVE_CYCLES"]
             for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_WAIT_INST_LDS", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM",

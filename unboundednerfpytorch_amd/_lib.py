@@ -25,6 +25,7 @@ _L = _c.c_int64
 
 
 MLP_FP32, MLP_BF16X3, MLP_FP16X2 = 0, 1, 2   # ugrid_render_params.mlp_mode (include/ugrid_hip.h)
+MLP_RESIDUAL = 0x100                         # flag: rgb = sigmoid(rgbnet([k0[3:], emb]) + k0[:3])  (DirectVoxGO, rgbnet_direct = False)
 
 
 class RenderParams(_c.Structure):

@@ -598,6 +598,7 @@ __host__ __device__ static inline int ug_in_col(int s, int h, int C, int n_emb, 
 struct ug_shade_args {
   int64_t n_rays;
   int32_t X, Y, Z;
+  int32_t residual;                 // 1: rgb = sigmoid(rgbnet([k0[3:], emb]) + k0[:3])  (DirectVoxGO rgbnet_direct = False, dvgo.py:385-398)
   float lox, loy, loz, hix, hiy, hiz;
   float ex, ey, ez, irx, iry, irz;  // extent hi-lo and RN(1/extent)
 };
@@ -865,7 +866,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // LDS-resident packed rgbnet (A operands of the transposed MFMA chain); A1/A2 are fp32 (BF=0), bf16x8 units
 // (BF=1: bf16x3) or f16x8 units (BF=2: fp16x2, with the activation scales sx1 / c12)
-struct ug_mlp_lds { const float4 *A1, *A2, *W3; const float *B1, *B2, *b3; float sx1, c12; };
+struct ug_mlp_lds { const float4 *A1, *A2, *W3; const float *B1, *B2, *b3; float sx1, c12; int resid; };
 
 // four consecutive rows of the fp16x2 image's DENSE W3 ([h][64][3] floats, k_pack_mlp): rows row0 .. row0+3 of half bo / 64
 // as three 16-byte reads; row0 % 4 == 0
@@ -903,8 +904,15 @@ __host__ __device__ static inline int ug_shade_lds_bytes() {
   return (int)sizeof(float) * (ug_mlp_lds_floats<C, PE, BF>() + NW * ug_wave_scratch_floats<C, PE, BF>());
 }
 
+// Residual colour (DirectVoxGO with rgbnet_direct = False, dvgo.py:385-398: the first three k0 channels are a view-independent
+// "diffuse" logit added to the rgbnet's output; the rgbnet reads the remaining channels + the view embedding).  The host packs
+// the first layer with ZERO columns for channels 0..2, so the MFMA chain ignores them; the passes add them to the logits.  Lane
+// (h = 0, sv) holds channels 0..5 of its survivor in x[0..5]; only the h == 0 lanes publish a colour.
+#define UG_RESIDUAL_ADD(M_, x_, l0_, l1_, l2_) \
+  if ((M_).resid) { l0_ += (x_)[0]; l1_ += (x_)[1]; l2_ += (x_)[2]; }
+
 template <int C, int PE, int BF>
-__device__ __forceinline__ ug_mlp_lds ug_mlp_stage(float *lds, const float *__restrict__ mlp) {
+__device__ __forceinline__ ug_mlp_lds ug_mlp_stage(float *lds, const float *__restrict__ mlp, int residual = 0) {
   const ug_mlp_layout ML = ug_mlp_lay(C, 3 + 6 * PE);
   const int base = BF == 2 ? ML.hxA1 : (BF == 1 ? ML.bfA1 : 0), n = ug_mlp_lds_floats<C, PE, BF>();
   const float4 *src = (const float4 *)(mlp + base);
@@ -920,6 +928,7 @@ __device__ __forceinline__ ug_mlp_lds ug_mlp_stage(float *lds, const float *__re
   m.b3 = lds + (BF == 2 ? ML.hxb3 : (BF == 1 ? ML.bfb3 : ML.offb3)) - base;
   m.sx1 = BF == 2 ? mlp[ML.hxS] : 1.f;
   m.c12 = BF == 2 ? mlp[ML.hxS + 1] : 1.f;
+  m.resid = residual;
   return m;
 }
 
@@ -1268,6 +1277,7 @@ __device__ __forceinline__ void ug_rgbnet_pass(const float (&x)[(2 * UG_CH(C) + 
   l0 = (l0 + __shfl_xor(l0, 32)) + M.b3[0];
   l1 = (l1 + __shfl_xor(l1, 32)) + M.b3[1];
   l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
+  UG_RESIDUAL_ADD(M, x, l0, l1, l2)
   // weights.unsqueeze(-1) * rgb, then a per-ray sum in sample order (segment_coo semantics)
   const float pr = ww * ug_sigmoid(l0), pg = ww * ug_sigmoid(l1), pb = ww * ug_sigmoid(l2);
   UG_PROF_MARK(prof, 5)
@@ -1470,6 +1480,7 @@ __device__ __forceinline__ void ug_rgbnet_pass_h2(const float (&x)[(2 * UG_CH(C)
   l0 = (l0 + __shfl_xor(l0, 32)) + M.b3[0];
   l1 = (l1 + __shfl_xor(l1, 32)) + M.b3[1];
   l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
+  UG_RESIDUAL_ADD(M, x, l0, l1, l2)
   const float pr = ww * ug_sigmoid(l0), pg = ww * ug_sigmoid(l1), pb = ww * ug_sigmoid(l2);
   UG_PROF_MARK(prof, 5)
   {
@@ -1945,5 +1956,6 @@ static inline void ug_fill_shade_args(const ugrid_render_params *p, ug_shade_arg
   a.hix = p->xyz_max[0]; a.hiy = p->xyz_max[1]; a.hiz = p->xyz_max[2];
   a.ex = a.hix - a.lox; a.ey = a.hiy - a.loy; a.ez = a.hiz - a.loz;
   a.irx = 1.0f / a.ex; a.iry = 1.0f / a.ey; a.irz = 1.0f / a.ez;
+  a.residual = (p->mlp_mode & UGRID_MLP_RESIDUAL) ? 1 : 0;
 }
 

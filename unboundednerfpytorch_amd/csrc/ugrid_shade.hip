@@ -177,7 +177,7 @@ k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__
             const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
             int32_t *__restrict__ tile_counter) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const ug_mlp_lds M = ug_mlp_stage<C, PE, BF>(lds, mlp);
+  const ug_mlp_lds M = ug_mlp_stage<C, PE, BF>(lds, mlp, a.residual);
   float *scr = lds + ug_mlp_lds_floats<C, PE, BF>() + (threadIdx.x >> 6) * ug_wave_scratch_floats<C, PE, BF>();
   int victim = 0;
   UG_PROF_INIT(prof)
@@ -203,7 +203,7 @@ k_shade_pc(ug_shade_args a, const float *__restrict__ viewdirs, const float *__r
   float *pairs = lds + MLPF;
   if (threadIdx.x < 4 * NPAIR)      // head / tail counters of the rings
     ((int *)(pairs + (threadIdx.x >> 2) * UG_PC_PAIR_FLOATS(SLOTS) + SLOTS * UG_PC_SLOT_FLOATS))[threadIdx.x & 3] = 0;
-  const ug_mlp_lds M = ug_mlp_stage<12, PE, 2>(lds, mlp);     // ends with __syncthreads()
+  const ug_mlp_lds M = ug_mlp_stage<12, PE, 2>(lds, mlp, a.residual);     // ends with __syncthreads()
   const int wv = threadIdx.x >> 6, pair = wv % NPAIR;
   float *ring = pairs + pair * UG_PC_PAIR_FLOATS(SLOTS);
   const unsigned ctl = ug_lds_off(ring + SLOTS * UG_PC_SLOT_FLOATS);
@@ -466,6 +466,7 @@ extern "C" int ugrid_render_fused(const ugrid_render_params *p, const float *ray
   if (p->n_rays <= 0) return 0;
   if (p->mlp_in == 0 || p->mlp_width != 128 || p->mlp_in != p->k0_channels + 3 + 6 * p->viewbase_pe)
     return (int)hipErrorNotSupported;  // rgbnet-less models use the two-kernel path
+  if (p->mlp_mode & UGRID_MLP_RESIDUAL) return (int)hipErrorNotSupported;   // (the residual epilogue exists in the two-kernel path only)
   ug_march_args am;
   const int rc = ug_fill_march_args(p, am);
   if (rc) return rc;
@@ -602,7 +603,10 @@ extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *vie
     return 0;
   }
   if (p->mlp_width != 128 || p->mlp_in != p->k0_channels + 3 + 6 * p->viewbase_pe) return (int)hipErrorInvalidValue;
-  if (p->mlp_mode < UGRID_MLP_FP32 || p->mlp_mode > UGRID_MLP_FP16X2) return (int)hipErrorInvalidValue;
+  const int mlp_mode = p->mlp_mode & ~UGRID_MLP_RESIDUAL;
+  if (mlp_mode < UGRID_MLP_FP32 || mlp_mode > UGRID_MLP_FP16X2) return (int)hipErrorInvalidValue;
+  // residual colour: lane (h = 0) must hold channels 0..2 of its survivor, i.e. at least 3 channels per half-brick (C >= 9)
+  if ((p->mlp_mode & UGRID_MLP_RESIDUAL) && UG_CH(p->k0_channels) < 3) return (int)hipErrorInvalidValue;
   int32_t *counter = (int32_t *)ws_mem;  // first 256 B of the work list
 // the instantiated (F, C, PE) triples: Mip-NeRF-360 *_single.py (configs/default.py:104-124); tankstemple_unbounded/
 // truck_single.py:105; FourierGridModel's constructor default fourier_freq_num = 5 (FourierGrid_model.py:137); waymo-style
@@ -611,10 +615,10 @@ extern "C" int ugrid_render_shade(const ugrid_render_params *p, const float *vie
 // viewbase_pe = 8 (configs/waymo/waymo_base.py, configs/mega/*.py; rgbnet_dim 3 in mega/building_no_block.py); rgbnet_dim = 15
 // (configs/tankstemple_unbounded/train_single.py); rgbnet_dim = 9 (configs/free_dataset/*.py, whose rgbnet_width = 64 the host
 // pads to 128: fourier_render.pad_rgbnet_to_128)
-#define UG_SHADE_TRIPLES(X) X(3, 12, 4) X(4, 12, 4) X(5, 12, 4) X(2, 12, 4) X(1, 12, 4) X(0, 12, 4) X(2, 3, 2) X(3, 3, 2) X(3, 12, 8) X(3, 3, 8) X(3, 15, 4) X(3, 9, 4)
+#define UG_SHADE_TRIPLES(X) X(3, 12, 4) X(4, 12, 4) X(5, 12, 4) X(2, 12, 4) X(1, 12, 4) X(0, 12, 4) X(2, 3, 2) X(3, 3, 2) X(3, 12, 8) X(3, 3, 8) X(3, 15, 4) X(3, 9, 4) X(0, 9, 4)
 #define UG_SHADE_CASE(F_, C_, PE_)                                                          \
   if (p->freq_num == F_ && p->k0_channels == C_ && p->viewbase_pe == PE_)                   \
-    return ug_shade_launch<F_, C_, PE_>(a, viewdirs, k0_bricks, mlp_packed, ws, rgb_marched, counter, p->mlp_mode, ST(s));
+    return ug_shade_launch<F_, C_, PE_>(a, viewdirs, k0_bricks, mlp_packed, ws, rgb_marched, counter, mlp_mode, ST(s));
   UG_SHADE_TRIPLES(UG_SHADE_CASE)
 #undef UG_SHADE_CASE
   return (int)hipErrorNotSupported;

@@ -82,9 +82,16 @@ __device__ int g_pc_dbg;
 #define UG_PC_ADD(acc, t)
 #endif
 
-// A/B arm UG_PC_PRIO_PHASED=hi: the consumer raises its issue priority only while it feeds the matrix pipe (layers 1 and 2) and
-// drops back for the VALU-only layer 3 / accumulation, where the gather waves' address arithmetic should win
-#ifdef UG_PC_PRIO_PHASED
+// Issue priority of the consumer waves (round 4, profiles/r04/shade_priority_ab.txt): the SIMD's arbiter serves the wave with the
+// highest s_setprio first.  A consumer raises its priority to UG_PC_PRIO_PHASED (default 3, the maximum) while it feeds the
+// matrix pipe -- layers 1 and 2: an MFMA that waits behind the gather waves' address arithmetic leaves the pipe idle -- and drops
+// back to 0 for the VALU-only layer 3 / accumulation / slot wait, where the producers' work should win.  Measured on S1: 4.29-4.34
+// -> 4.05-4.11 ms (static priorities 1, 2, 3 for the whole consumer: 4.11-4.14).  Scheduling only: results are bit-identical.
+// -DUG_PC_PRIO_PHASED=0 builds the kernel without it.
+#ifndef UG_PC_PRIO_PHASED
+#define UG_PC_PRIO_PHASED 3
+#endif
+#if UG_PC_PRIO_PHASED > 0
 #define UG_PRIO_HI() __builtin_amdgcn_s_setprio(UG_PC_PRIO_PHASED)
 #define UG_PRIO_LO() __builtin_amdgcn_s_setprio(0)
 #else
@@ -242,6 +249,7 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
   l0 = (l0 + __shfl_xor(l0, 32)) + M.b3[0];
   l1 = (l1 + __shfl_xor(l1, 32)) + M.b3[1];
   l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
+  UG_RESIDUAL_ADD(M, x, l0, l1, l2)
   const float pr = ww * ug_sigmoid(l0), pg = ww * ug_sigmoid(l1), pb = ww * ug_sigmoid(l2);
   UG_PROF_MARK(prof, 5)
 #ifdef UG_ACC_DSADD

@@ -84,8 +84,8 @@ class DirectVoxGORenderer:
     def fused_supported(self):
         """the fused march (ugrid_render_march_dvgo) + shade kernels cover: the default HIP ops, fast_color_thres > 0, one
         resolution for both grids, and either no rgbnet (3-channel k0, rgb = sigmoid(k0)) or the DIRECT 3 x 128 rgbnet on
-        [k0 (12), view embedding] that ugrid_shade_supported(0, C, viewbase_pe) lists (rgbnet_direct = False, the diffuse +
-        residual colour of dvgo.py:411-414, stays on the composed forward)"""
+        [k0 (12), view embedding] that ugrid_shade_supported(0, C, viewbase_pe) lists -- rgbnet_direct, or the diffuse + residual
+        colour of dvgo.py:385-398 (rgbnet on [k0[3:], embedding], k0[:3] added to its output: the shade kernels' residual epilogue)"""
         if self._fused is False:
             return False
         s = self.s
@@ -97,8 +97,11 @@ class DirectVoxGORenderer:
         from . import _lib
         from .fourier_render import rgbnet_fits_fused
         w = s['rgbnet_weights']
-        return (bool(s['rgbnet_direct']) and rgbnet_fits_fused(w)
-                and w[0].shape[1] == C + 3 + 6 * int(s['viewbase_pe'])
+        # rgbnet_direct: the network reads all C channels; else (dvgo.py:385-398) channels 3.. and the first three are added to
+        # its output -- the shade kernels' residual epilogue (include/ugrid_hip.h: UGRID_MLP_RESIDUAL), C >= 9
+        c_in = C if bool(s['rgbnet_direct']) else C - 3
+        return (rgbnet_fits_fused(w) and (bool(s['rgbnet_direct']) or C >= 9)
+                and w[0].shape[1] == c_in + 3 + 6 * int(s['viewbase_pe'])
                 and bool(_lib.load().ugrid_shade_supported(0, C, int(s['viewbase_pe']))))
 
     @torch.no_grad()
@@ -121,6 +124,7 @@ class DirectVoxGORenderer:
                   'xyz_min': lo, 'xyz_max': hi, 'bg_len': 0.0, 'fourier_freq_num': 0, 'viewbase_pe': s['viewbase_pe'],
                   'act_shift': float(s['act_shift']), 'voxel_size_ratio': float(s['voxel_size_ratio']),
                   'fast_color_thres': float(s['fast_color_thres']), 'contracted_norm': 'inf', 'world_len': 0,
+                  'rgbnet_residual': (len(s['rgbnet_weights']) > 0 and not bool(s['rgbnet_direct'])),
                   'dvgo': {'mask': s['mask'], 'xyz2ijk_scale': s['xyz2ijk_scale'], 'xyz2ijk_shift': s['xyz2ijk_shift'],
                            'voxel_size': s['voxel_size']}}
             self._fused = FourierGridRenderer(st, self.device)

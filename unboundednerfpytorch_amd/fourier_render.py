@@ -151,6 +151,14 @@ class FourierGridRenderer:
                     raise RuntimeError("fused shade supports rgbnet_depth=3, rgbnet_width <= 128 "
                                        "(configs/default.py:104-105)")
                 ws_, bs_ = pad_rgbnet_to_128([x.to(dev, torch.float32) for x in ws_], [x.to(dev, torch.float32) for x in bs_])
+                # residual colour (DirectVoxGO with rgbnet_direct = False, dvgo.py:385-398): the network reads [k0[3:], embedding] and
+                # k0[:3] is added to its output.  The kernels gather all C channels anyway: the first layer gets ZERO columns for
+                # the three diffuse channels (so the matrix chain ignores them) and the shade epilogue adds them to the logits
+                self.residual = bool(state.get("rgbnet_residual", False))
+                if self.residual:
+                    if self.C < 9:
+                        raise RuntimeError("residual colour needs k0 channels >= 9 (3 diffuse + the rgbnet's features)")
+                    ws_[0] = torch.cat([ws_[0].new_zeros(ws_[0].shape[0], 3), ws_[0]], dim=1)
                 self.mlp_in = int(ws_[0].shape[1])
                 if self.mlp_in != self.C + 3 + 6 * self.pe:
                     raise RuntimeError("rgbnet input width must be C + 3 + 6*viewbase_pe")
@@ -212,7 +220,7 @@ class FourierGridRenderer:
                 getattr(p, k)[i] = self._vec[k][i]
         p.bg_len = self.bg_len
         p.act_shift, p.interval, p.thres = self.act_shift, self.interval(stepsize), self.thres
-        p.mlp_mode = self.mlp_mode
+        p.mlp_mode = self.mlp_mode | (_lib.MLP_RESIDUAL if getattr(self, "residual", False) else 0)
         return p
 
     def rays_per_chunk(self, S):
