@@ -521,6 +521,9 @@ def s3_train_step_block(device):
             r = bts.run(bts.parse(["--steps", "20", "--warmup", "4", "--first-step", str(first)]))
             out[phase] = {k: r[k] for k in ("ms_per_step", "phases_ms", "survivors_M", "samples", "rays_per_sec", "tv_phase", "loss", "psnr")}
             out["workload"] = r["workload"]
+            if phase == "dense_tv" and r.get("roofline_tv_adam_dense"):
+                # the path's one genuinely HBM-bound kernel, priced against the guide's 8 TB/s
+                out["roofline_tv_adam_dense"] = r["roofline_tv_adam_dense"]
             torch.cuda.empty_cache()
         return out
     except Exception as e:          # noqa: BLE001

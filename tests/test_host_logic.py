@@ -662,7 +662,14 @@ def test_pixel_tile_order_is_a_permutation_and_untile_inverts_it():
     blk = order[64 * 7: 64 * 8]
     rows, cols = blk // W, blk % W
     assert int(rows.max() - rows.min()) == 7 and int(cols.max() - cols.min()) == 7           # one 8 x 8 block
-    assert rows[:8].unique().numel() == 1 and cols[:8].tolist() == list(range(int(cols[0]), int(cols[0]) + 8))
+    from unboundednerfpytorch_amd import fourier_render as fr
+    if fr.TILE_MORTON:       # Z-order inside the block: every aligned run of 4 lanes is a 2 x 2 pixel quad, of 16 a 4 x 4 patch
+        for q in range(0, 64, 4):
+            assert int(rows[q:q + 4].max() - rows[q:q + 4].min()) == 1 and int(cols[q:q + 4].max() - cols[q:q + 4].min()) == 1
+        for q in range(0, 64, 16):
+            assert int(rows[q:q + 16].max() - rows[q:q + 16].min()) == 3 and int(cols[q:q + 16].max() - cols[q:q + 16].min()) == 3
+    else:
+        assert rows[:8].unique().numel() == 1 and cols[:8].tolist() == list(range(int(cols[0]), int(cols[0]) + 8))
     x = torch.arange(H * W * 3, dtype=torch.float32).view(H * W, 3)
     assert torch.equal(untile(x[order], H, W), x) and torch.equal(untile(x[order][:, 0].contiguous(), H, W), x[:, 0])
     assert pixel_tile_order(45, 77, "cpu") is None and pixel_tile_order(H, W, "cpu", tile=1) is None

@@ -17,6 +17,8 @@ Device data owned by the renderer:
 import ctypes
 import math
 
+import os
+
 import torch
 
 from . import _lib
@@ -618,19 +620,33 @@ _TILE_ORDER = {}
 RAY_TILE = 8      # a wave of the march kernel owns 64 rays: 8 x 8 pixels instead of a 64-pixel row segment
 
 
+TILE_MORTON = os.environ.get("UGRID_TILE_MORTON", "1") != "0"      # lanes inside an 8 x 8 block in Z-order (below)
+
+
+def _morton_ok(tile):
+    return TILE_MORTON and tile == 8
+
+
 def pixel_tile_order(H, W, device, tile=None):
-    """Flat pixel indices j*W+i of a view in tile-major order (tile x tile pixel blocks, row-major inside a block and
-    over the blocks), int64 [H*W] on `device`, cached -- or None when H or W is not a multiple of the tile.  Rendering a
-    frame's rays in this order gives every 64-ray wave of the march kernel an 8 x 8 pixel block: its rays end at similar
-    depths (the wave leaves the sample loop when its LAST ray is done) and share grid cells (5 % on the S1 frame).
-    Per-ray results do not depend on the order."""
+    """Flat pixel indices j*W+i of a view in tile-major order (tile x tile pixel blocks, row-major over the blocks), int64 [H*W]
+    on `device`, cached -- or None when H or W is not a multiple of the tile.  Rendering a frame's rays in this order gives every
+    64-ray wave of the march kernel an 8 x 8 pixel block: its rays end at similar depths (the wave leaves the sample loop when
+    its LAST ray is done) and share grid cells (5 % on the S1 frame).
+    Inside an 8 x 8 block the lanes follow the Z-order curve (lane bits y2 x2 y1 x1 y0 x0; TILE_MORTON, round 4): the vector
+    memory path serves a wave instruction four lanes at a time, and a 2 x 2 pixel quad spans fewer grid cells -- fewer tag
+    look-ups per instruction -- than four pixels of a row (profiles/r04/tile_morton_ab.txt).  Other tile sizes stay row-major
+    inside the block.  Per-ray results do not depend on the order."""
     tile = RAY_TILE if tile is None else int(tile)
     if tile <= 1 or H % tile or W % tile:
         return None
-    key = (H, W, tile, str(device))
+    key = (H, W, tile, str(device), _morton_ok(tile))
     p = _TILE_ORDER.get(key)
     if p is None:
-        p = torch.arange(H * W, device=device).view(H // tile, tile, W // tile, tile).permute(0, 2, 1, 3).reshape(-1).contiguous()
+        a = torch.arange(H * W, device=device)
+        if _morton_ok(tile):
+            p = a.view(H // 8, 2, 2, 2, W // 8, 2, 2, 2).permute(0, 4, 1, 5, 2, 6, 3, 7).reshape(-1).contiguous()
+        else:
+            p = a.view(H // tile, tile, W // tile, tile).permute(0, 2, 1, 3).reshape(-1).contiguous()
         if len(_TILE_ORDER) > 8:
             _TILE_ORDER.clear()
         _TILE_ORDER[key] = p
@@ -641,7 +657,10 @@ def untile(x, H, W, tile=None):
     """per-ray results [H*W, ...] in pixel_tile_order -> image order [H*W, ...]"""
     tile = RAY_TILE if tile is None else int(tile)
     rest = x.shape[1:]
-    return x.view(H // tile, W // tile, tile, tile, *rest).permute(0, 2, 1, 3, *range(4, 4 + len(rest))).reshape(H * W, *rest)
+    n = len(rest)
+    if _morton_ok(tile):      # [H/8, W/8, y2, x2, y1, x1, y0, x0, ...] -> [H/8, y2, y1, y0, W/8, x2, x1, x0, ...]
+        return x.view(H // 8, W // 8, 2, 2, 2, 2, 2, 2, *rest).permute(0, 2, 4, 6, 1, 3, 5, 7, *range(8, 8 + n)).reshape(H * W, *rest)
+    return x.view(H // tile, W // tile, tile, tile, *rest).permute(0, 2, 1, 3, *range(4, 4 + n)).reshape(H * W, *rest)
 
 
 def pixel_grid(H, W, device, flip_x=False, flip_y=False, mode="center"):
