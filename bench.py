@@ -832,11 +832,27 @@ def cpu_baseline(cpu_state, rays, gpu_out, stepsize, S, n_chunks, device=None, r
            "gpu_vs_oracle_linf_alphainv_last": stats["alphainv_last"]["linf_all"],
            "gpu_vs_oracle": stats}
     del model
+    rg = None
     if ref_gpu and device is not None and device.type == "cuda" and ref_model.available("kernels:fma"):
         try:
-            out["arbitration"] = _arbitration(cpu_state, device, ro, rd, vd, starts, chunk, stepsize, gpu_out, refs)
+            out["arbitration"], rg = _arbitration(cpu_state, device, ro, rd, vd, starts, chunk, stepsize, gpu_out, refs)
         except Exception as e:          # noqa: BLE001  (the checker's checker must never cost the measurement line)
             out["arbitration"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    if ref_gpu:
+        # GROUND TRUTH: the rays where the fused frame is further than 1e-4 from a reference, plus 256 random
+        # ones, re-evaluated in fp64 (tools/parity_fp64.py); the three distances to the truth and who is further from it how often
+        try:
+            sys.path.insert(0, ROOT)
+            from tools import parity_fp64
+            idx = torch.cat([torch.arange(b, b + chunk) for b in starts])
+            evals = {"fused": {k: gpu_out[k].cpu()[idx] for k in refs}, "ref_cpu": {k: torch.cat(v) for k, v in refs.items()}}
+            if rg is not None:
+                evals["ref_gpu"] = rg
+            gt = parity_fp64.ground_truth_study(cpu_state, (ro.cpu()[idx], rd.cpu()[idx], vd.cpu()[idx]), evals, stepsize, n_random=256, seed=0)
+            gt.pop("per_ray", None)
+            out["fp64_ground_truth"] = gt
+        except Exception as e:          # noqa: BLE001
+            out["fp64_ground_truth"] = {"error": "%s: %s" % (type(e).__name__, e)}
     return out
 
 
@@ -857,8 +873,8 @@ def _arbitration(cpu_state, device, ro, rd, vd, starts, chunk, stepsize, gpu_out
     for k in rg:
         g_ref, c_ref, fused = torch.cat(rg[k]), torch.cat(refs[k]), gpu_out[k].cpu()[idx]
         arb[k] = {"fused_vs_ref_on_gpu": lin(fused, g_ref), "ref_on_gpu_vs_ref_on_cpu": lin(g_ref, c_ref), "fused_vs_ref_on_cpu": lin(fused, c_ref)}
-    return {"note": "L-inf over the sampled rays; ref_on_gpu = the reference's own Python + its own compiled kernels (oracle/_ref/fma) + "
-                    "torch-ROCm grid_sample on this MI355X", "rays": int(idx.numel()), **arb}
+    return ({"note": "L-inf over the sampled rays; ref_on_gpu = the reference's own Python + its own compiled kernels (oracle/_ref/fma) + "
+                     "torch-ROCm grid_sample on this MI355X", "rays": int(idx.numel()), **arb}, {k: torch.cat(v) for k, v in rg.items()})
 
 
 def parity_stats(errs, margin, sq_rgb):
