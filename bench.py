@@ -420,7 +420,8 @@ def roofline_block(kern, M, R, S, shade_passes, frame_rays=None):
             os.path.relpath(ppath, ROOT), pmc.get("device_code_sha16"), code)
         pmc = {}
     scale = 1.0 if not frame_rays else R / float(frame_rays)     # counters are per whole-frame launch: a rank's share
-    l1m = _load_json(os.path.join(ROOT, "profiles", "r03", "microbench_l1_dwordx4.json")) or {}
+    l1m = (_load_json(os.path.join(PROFILE_DIR, "microbench_l1_dwordx4.json"))
+           or _load_json(os.path.join(ROOT, "profiles", "r03", "microbench_l1_dwordx4.json")) or {})     # (measured in round 3)
     l1_meas_bpc = l1m.get("quad64_B_per_clk_per_CU")             # the shade gather's access shape: 64 B per lane quad
     l1_meas_lin = l1m.get("linear_B_per_clk_per_CU")
     alg = {"render_march": R * S * 224 + R * 32,     # 8 coefficients x 7 levels x 4 B per sample + rays in / (depth, alphainv) out

@@ -1,4 +1,4 @@
-"""Time the experimental k0-gather variants (csrc/ugrid_gather_exp.hip, symbols ugx_*) on the real S1 work list.
+"""Time the experimental k0-gather variants (tools/experiments/ugrid_gather_exp.hip, symbols ugx_*) on the real S1 work list.
 GPU box only:  python tools/gpu_gather_variants.py [--grid 200] [--reps 3] > gpurun_out/gather_variants.txt
 
 For every variant: ms per launch (HIP events, best and mean of `reps`), bit-checksum of the produced features against

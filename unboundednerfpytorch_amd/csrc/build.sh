@@ -19,7 +19,7 @@ hipcc $FLAGS -fno-slp-vectorize ${UG_MARCH_FLAGS} -c ugrid_march.hip -o $O/ugrid
 pids+=($!)
 if [ "${UG_EXPERIMENTS:-0}" = "1" ]; then
   UG_SHADE_FLAGS="$UG_SHADE_FLAGS -DUG_EXPERIMENTS"
-  hipcc $FLAGS -fno-slp-vectorize -c ugrid_gather_exp.hip -o $O/ugrid_gather_exp.o "$@" &
+  hipcc $FLAGS -fno-slp-vectorize -I. -c ../../tools/experiments/ugrid_gather_exp.hip -o $O/ugrid_gather_exp.o "$@" &
   pids+=($!)
   OBJS="$OBJS $O/ugrid_gather_exp.o"
 fi
