@@ -1,7 +1,7 @@
 """Build the four pybind modules of binding/ (render_utils_cuda, total_variation_cuda, ub360_utils_cuda, adam_upd_cuda) against
 the C ABI of libugrid_hip.so -- INTEGRATION.md section B as code.  The reference's FourierGrid/cuda/setup.py:15-19 lists one
 CUDAExtension per module; here each module is ONE host-only C++ file (no device code: no hipcc needed for them) linked with
--lugrid_hip, with an rpath to the library's directory.  Output: binding/_build/<name>.so (git-ignored, shipped by gpurun).
+-lugrid_hip, with an rpath to the library's directory.  Output: binding/_build/ugrid_<name>.so (git-ignored, shipped by gpurun).
 
     python binding/build.py            # builds what is out of date (source hash stamp)
     import binding.build as b; mods = b.load()      # -> {name: module}, importable under the reference's names
@@ -19,6 +19,12 @@ OUT = os.path.join(HERE, "_build")
 LIBDIR = os.path.join(ROOT, "unboundednerfpytorch_amd")
 MODULES = {"render_utils_cuda": "render_utils.cpp", "total_variation_cuda": "total_variation.cpp", "ub360_utils_cuda": "ub360_utils.cpp",
            "adam_upd_cuda": "adam_upd.cpp"}
+# The extension modules are BUILT under a prefixed name (PyInit_ugrid_render_utils_cuda in ugrid_render_utils_cuda.so) and
+# REGISTERED under the reference's names by install().  Inside the reference tree a maintainer would build them under the plain
+# names (setup.py); here up to three same-named pybind modules live in one test process (oracle/_ref/{nofma,fma} = the reference's
+# own kernels, and these), and CPython's cache of single-phase-init extension modules re-populates whatever module sits in
+# sys.modules under a NAME when a cached .so of that name is loaded again -- the prefix keeps the families apart.
+PREFIX = "ugrid_"
 
 
 def _hash(paths):
@@ -48,12 +54,12 @@ def build(force=False, verbose=False):
     procs = []
     for name, src in MODULES.items():
         srcs = [os.path.join(HERE, src), os.path.join(HERE, "ugrid_binding_common.h"), os.path.join(ROOT, "include", "ugrid_hip.h")]
-        so = os.path.join(OUT, name + ".so")
+        so = os.path.join(OUT, PREFIX + name + ".so")
         stamp = so + ".srchash"
         want = _hash(srcs)
         if not force and os.path.exists(so) and os.path.exists(stamp) and open(stamp).read().strip() == want:
             continue
-        cmd = ["g++"] + cflags + ["-DTORCH_EXTENSION_NAME=" + name] + incs + [srcs[0], "-o", so] + libs
+        cmd = ["g++"] + cflags + ["-DTORCH_EXTENSION_NAME=" + PREFIX + name] + incs + [srcs[0], "-o", so] + libs
         if verbose:
             print(" ".join(cmd))
         procs.append((name, stamp, want, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -67,7 +73,7 @@ def build(force=False, verbose=False):
 
 
 def available():
-    return all(os.path.exists(os.path.join(OUT, n + ".so")) for n in MODULES)
+    return all(os.path.exists(os.path.join(OUT, PREFIX + n + ".so")) for n in MODULES)
 
 
 def load(names=None):
@@ -75,9 +81,13 @@ def load(names=None):
     import torch  # noqa: F401  (libtorch symbols)
     mods = {}
     for name in (names or MODULES):
-        spec = importlib.util.spec_from_file_location(name, os.path.join(OUT, name + ".so"))
+        if PREFIX + name in sys.modules:
+            mods[name] = sys.modules[PREFIX + name]
+            continue
+        spec = importlib.util.spec_from_file_location(PREFIX + name, os.path.join(OUT, PREFIX + name + ".so"))
         m = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(m)
+        sys.modules[PREFIX + name] = m
         mods[name] = m
     return mods
 

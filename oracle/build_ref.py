@@ -122,18 +122,37 @@ def reference_python_root():
     return d
 
 
+_LOADED = {}
+
+
 def load(variant="nofma"):
-    """Import the four prebuilt modules (needs a GPU at call time, not at import time).  Returns a dict."""
+    """Import the four prebuilt modules (needs a GPU at call time, not at import time).  Returns a dict, cached per variant.
+
+    Two precautions, both about CPython's cache of single-phase-init extension modules (pybind11 modules are such): loading a
+    cached .so AGAIN re-populates whatever module object sits in sys.modules under the module's NAME with the cached functions
+    (import.c: import_find_extension -> import_add_module(name) + dict update) -- and the product registers ITS drop-in modules
+    under exactly these names (compat.install_as_reference_extensions).  So (1) every variant is loaded once per process, and
+    (2) sys.modules' entries of these names are set aside while the loader runs and put back afterwards: the checker must
+    never be able to overwrite the thing it checks."""
     import importlib.util
     import torch  # noqa: F401  (the modules link against libtorch)
+    if variant in _LOADED:
+        return dict(_LOADED[variant])
     mods = {}
     for name, _ in MODULES:
         path = os.path.join(OUT, variant, name + ".so")
-        spec = importlib.util.spec_from_file_location(name, path)
-        m = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(m)
+        saved = sys.modules.pop(name, None)
+        try:
+            spec = importlib.util.spec_from_file_location(name, path)
+            m = importlib.util.module_from_spec(spec)
+            spec.loader.exec_module(m)
+        finally:
+            sys.modules.pop(name, None)
+            if saved is not None:
+                sys.modules[name] = saved
         mods[name] = m
-    return mods
+    _LOADED[variant] = mods
+    return dict(mods)
 
 
 if __name__ == "__main__":

@@ -47,3 +47,31 @@ def test_hip_ops_vs_live_reference_kernels_at_scale(variant):
     got = nc.run_all(hip_modules(), scale=8, device="cuda", chain_from=ref)
     assert_same(ref, got, "live " + variant)
     assert ref["sample_pts_on_rays"][0].shape[0] > 15000 and ref["alpha2weight"][0].numel() == 8 * nc.A2W_N
+
+
+def test_loading_the_reference_kernels_never_overwrites_the_drop_in_modules():
+    """The checker must not be able to replace the thing it checks.  CPython re-populates whatever module sits in sys.modules
+    under an extension module's NAME when a cached single-phase-init .so of that name is loaded again (import.c:
+    import_find_extension); the product registers its drop-in modules under exactly the reference's names
+    (compat.install_as_reference_extensions) and oracle/_ref holds same-named pybind modules.  oracle/build_ref.load therefore
+    loads every variant once and sets sys.modules' entries aside while it runs: after any number of loads the drop-in modules
+    are still this package's Python functions."""
+    import sys
+    import types
+    from oracle import build_ref
+    from unboundednerfpytorch_amd import adam_upd_cuda, compat, render_utils_cuda
+    if not build_ref.built("nofma"):
+        pytest.skip("oracle/_ref not built")
+    names = compat.install_as_reference_extensions()
+    try:
+        for variant in ("nofma", "fma", "nofma", "fma"):
+            if build_ref.built(variant):
+                mods = build_ref.load(variant)
+                assert mods["render_utils_cuda"] is not render_utils_cuda
+        assert sys.modules["render_utils_cuda"] is render_utils_cuda
+        for mod, fn in ((render_utils_cuda, "raw2alpha"), (render_utils_cuda, "alpha2weight"), (adam_upd_cuda, "masked_adam_upd")):
+            f = getattr(mod, fn)
+            assert isinstance(f, types.FunctionType) and f.__module__ == mod.__name__, (fn, f)
+    finally:
+        for n in names:
+            sys.modules.pop(n, None)

@@ -45,7 +45,7 @@ def regenerated(golden_dir, request):
         names = compat.install_as_reference_extensions(native=True)
         render_utils_cuda, total_variation_cuda, ub360_utils_cuda, adam_upd_cuda = [sys.modules[n] for n in (
             "render_utils_cuda", "total_variation_cuda", "ub360_utils_cuda", "adam_upd_cuda")]
-        assert render_utils_cuda.__file__.endswith(os.path.join("binding", "_build", "render_utils_cuda.so"))
+        assert render_utils_cuda.__file__.endswith(os.path.join("binding", "_build", "ugrid_render_utils_cuda.so"))
     else:
         names = compat.install_as_reference_extensions()
     assert sys.modules["render_utils_cuda"] is render_utils_cuda and len(names) == 4
