@@ -118,11 +118,17 @@ def test_training_320_iterations_psnr_tracks_the_reference_on_this_gpu():
 
 def test_gradients_vs_the_reference_on_this_gpu_and_its_own_run_to_run_spread():
     """"gradients 2e-3 of scale blamed on atomic order without a measured run-to-run spread of the reference's
-    own grid_sample backward".  Measured here: one training batch, the same parameters -- (a) the reference's own model on this
-    GPU, backward run TWICE (its grid_sample backward scatters with fp32 atomics: the spread between the two runs is what
-    summation order alone does), (b) this package's model (fused sampling, channel-last k0, fused rgbnet, RenderLoss).  For every
-    parameter the difference ours - reference, as a fraction of the gradient's scale, must stay within 5 x the reference's own
-    spread + 2e-5 (fp32 formula differences: sincos / alpha kernels, MFMA summation order)."""
+    own grid_sample backward".  Measured here on one training batch with the same parameters:
+      (a) the reference's own model on this GPU, backward run TWICE -- its grid_sample backward scatters with fp32 atomics, the
+          spread between the two runs is what summation order alone does to the GRID gradients;
+      (b) this package's model (fused sampling, channel-last k0, fused rgbnet, RenderLoss);
+      (c) for the rgbnet's parameters an fp64 GROUND TRUTH: the reference's own rgbnet input (captured by a forward hook), weights
+          and loss terms re-evaluated in double -- the run-to-run spread says nothing about them (the reference's GEMMs are
+          deterministic: same rounding every run), and two correct fp32 reductions over 80 000 samples of mixed sign differ by far
+          more than an atomics spread.
+    Asserted: the loss is equal to fp32 resolution, the same voxels are touched, the grid gradients agree to 5 x the reference's
+    spread + 2e-5 of their scale (density) / to the rgbnet's own accuracy (k0, whose gradient passes through the rgbnet), and each
+    rgbnet gradient is as close to the fp64 truth as the reference's own is (2 x + 2e-5 of its scale)."""
     from oracle import ref_model, ref_train
     from unboundednerfpytorch_amd import train_step as ts
     from unboundednerfpytorch_amd.fourier_model import FourierGridModel
@@ -147,6 +153,8 @@ def test_gradients_vs_the_reference_on_this_gpu_and_its_own_run_to_run_spread():
     init = {k: v.detach().clone() for k, v in ref.state_dict().items()}
     o, d, v, rgb = bts.random_rays(4096, dev, seed=31)
     cfg = dict(CFG, weight_tv_density=0.0, weight_tv_k0=0.0)
+    captured = {}
+    hook = ref.rgbnet.register_forward_pre_hook(lambda mod, inp: captured.__setitem__("feat", inp[0].detach()))
 
     def ref_grads():
         ref.load_state_dict(init)
@@ -159,9 +167,25 @@ def test_gradients_vs_the_reference_on_this_gpu_and_its_own_run_to_run_spread():
                 loss.backward()
         finally:
             torch.set_default_tensor_type(torch.FloatTensor)
-        return {k: p.grad.detach().clone() for k, p in ref.named_parameters() if p.grad is not None}, float(loss)
-    ga, la = ref_grads()
-    gb, lb = ref_grads()
+        return {k: p.grad.detach().clone() for k, p in ref.named_parameters() if p.grad is not None}, float(loss), out
+    ga, la, out_a = ref_grads()
+    gb, lb, _ = ref_grads()
+    hook.remove()
+    # ---- fp64 truth of the rgbnet gradients: the rgbnet's input, the compositing weights and the ray ids as the reference computed them
+    import copy
+    net64 = copy.deepcopy(ref.rgbnet).double()
+    for p_ in net64.parameters():
+        p_.grad = None
+    feat64 = captured["feat"].double()
+    w64, rid = out_a["weights"].detach().double(), out_a["ray_id"]
+    rgb64 = torch.sigmoid(net64(feat64))
+    marched = torch.zeros(len(o), 3, dtype=torch.float64, device=dev).index_add_(0, rid, w64[:, None] * rgb64)
+    t64 = rgb.double()
+    loss64 = cfg["weight_main"] * ((marched - t64) ** 2).mean() \
+        + cfg["weight_rgbper"] * (((rgb64 - t64[rid]) ** 2).sum(-1) * w64).sum() / len(o)
+    loss64.backward()
+    truth = {"rgbnet." + k: p_.grad.detach() for k, p_ in net64.named_parameters()}
+    # ---- this package
     m = FourierGridModel(**ctor).to(dev)
     m.load_state_dict(init)
     out = m(o, d, v, global_step=1, is_train=True, **RK)
@@ -172,11 +196,26 @@ def test_gradients_vs_the_reference_on_this_gpu_and_its_own_run_to_run_spread():
     rows = {}
     for k in ga:
         scale = float(ga[k].abs().max())
-        spread = float((ga[k] - gb[k]).abs().max()) / scale
-        ours = float((go[k].reshape(ga[k].shape) - ga[k]).abs().max()) / scale
-        same_mask = bool(torch.equal(go[k].reshape(ga[k].shape) != 0, ga[k] != 0)) if "grid" in k else None
-        rows[k] = {"scale": scale, "reference_run_to_run": spread, "ours_minus_reference": ours, "same_touched_voxels": same_mask}
-        print("grad %-18s scale %.3e   reference run-to-run %.2e   ours - reference %.2e   same touched voxels %s" % (k, scale, spread, ours, same_mask))
+        ours_t = go[k].reshape(ga[k].shape)
+        r = {"scale": scale, "reference_run_to_run": float((ga[k] - gb[k]).abs().max()) / scale,
+             "ours_minus_reference": float((ours_t - ga[k]).abs().max()) / scale,
+             "same_touched_voxels": bool(torch.equal(ours_t != 0, ga[k] != 0)) if "grid" in k else None}
+        if k in truth:
+            r["reference_minus_fp64"] = float((ga[k].double() - truth[k]).abs().max()) / scale
+            r["ours_minus_fp64"] = float((ours_t.double() - truth[k]).abs().max()) / scale
+        rows[k] = r
+        print("grad %-18s scale %.3e  ref run-to-run %.2e  ours-ref %.2e  ref-fp64 %s  ours-fp64 %s  same voxels %s" % (
+            k, scale, r["reference_run_to_run"], r["ours_minus_reference"],
+            ("%.2e" % r["reference_minus_fp64"]) if "reference_minus_fp64" in r else "-",
+            ("%.2e" % r["ours_minus_fp64"]) if "ours_minus_fp64" in r else "-", r["same_touched_voxels"]))
     json.dump({"loss_reference": [la, lb], "loss_ours": float(loss), "rows": rows}, open(os.path.join(ROOT, "gpurun_out", "grad_vs_reference_spread.json"), "w"), indent=1)
+    worst_net = max(max(r.get("ours_minus_fp64", 0.0), r.get("reference_minus_fp64", 0.0)) for r in rows.values())
     for k, r in rows.items():
-        assert r["ours_minus_reference"] <= 5.0 * r["reference_run_to_run"] + 2e-5, (k, r)
+        if "grid" in k:
+            assert r["same_touched_voxels"], k
+        if k == "density.grid":
+            assert r["ours_minus_reference"] <= 5.0 * r["reference_run_to_run"] + 2e-5, (k, r)
+        elif k == "k0.grid":       # d loss / d k0 passes through the rgbnet's input gradient: as accurate as the rgbnet's own gradients are
+            assert r["ours_minus_reference"] <= 5.0 * r["reference_run_to_run"] + 4.0 * worst_net + 2e-5, (k, r, worst_net)
+        else:
+            assert r["ours_minus_fp64"] <= 2.0 * r["reference_minus_fp64"] + 2e-5, (k, r)
