@@ -128,7 +128,10 @@ def test_gradients_vs_the_reference_on_this_gpu_and_its_own_run_to_run_spread():
           more than an atomics spread.
     Asserted: the loss is equal to fp32 resolution, the same voxels are touched, the grid gradients agree to 5 x the reference's
     spread + 2e-5 of their scale (density) / to the rgbnet's own accuracy (k0, whose gradient passes through the rgbnet), and each
-    rgbnet gradient is as close to the fp64 truth as the reference's own is (2 x + 2e-5 of its scale)."""
+    rgbnet gradient is as close to the fp64 truth as the reference's own is (2 x + 2e-5 of its scale) once the part that ReLU
+    flips can move is taken off: a pre-activation within fp32 rounding of zero lands on either side of the ReLU depending on the
+    summation order, and its whole gradient term comes or goes with it -- in ANY fp32 evaluation; the bound of that part is
+    computed from the fp64 quantities, element by element."""
     from oracle import ref_model, ref_train
     from unboundednerfpytorch_amd import train_step as ts
     from unboundednerfpytorch_amd.fourier_model import FourierGridModel
@@ -171,20 +174,41 @@ def test_gradients_vs_the_reference_on_this_gpu_and_its_own_run_to_run_spread():
     ga, la, out_a = ref_grads()
     gb, lb, _ = ref_grads()
     hook.remove()
-    # ---- fp64 truth of the rgbnet gradients: the rgbnet's input, the compositing weights and the ray ids as the reference computed them
-    import copy
-    net64 = copy.deepcopy(ref.rgbnet).double()
-    for p_ in net64.parameters():
-        p_.grad = None
+    # ---- fp64 truth of the rgbnet gradients: the rgbnet's input, the compositing weights and the ray ids as the reference computed
+    # them; the three layers written out so that the pre-activations are at hand
+    lin = [mm for mm in ref.rgbnet.modules() if isinstance(mm, torch.nn.Linear)]
+    W1, b1, W2, b2, W3, b3 = [t.detach().double().requires_grad_(True) for l_ in lin for t in (l_.weight, l_.bias)]
     feat64 = captured["feat"].double()
     w64, rid = out_a["weights"].detach().double(), out_a["ray_id"]
-    rgb64 = torch.sigmoid(net64(feat64))
+    z1 = feat64 @ W1.T + b1
+    h1 = torch.relu(z1)
+    z2 = h1 @ W2.T + b2
+    h2 = torch.relu(z2)
+    logits = h2 @ W3.T + b3
+    rgb64 = torch.sigmoid(logits)
     marched = torch.zeros(len(o), 3, dtype=torch.float64, device=dev).index_add_(0, rid, w64[:, None] * rgb64)
     t64 = rgb.double()
     loss64 = cfg["weight_main"] * ((marched - t64) ** 2).mean() \
         + cfg["weight_rgbper"] * (((rgb64 - t64[rid]) ** 2).sum(-1) * w64).sum() / len(o)
-    loss64.backward()
-    truth = {"rgbnet." + k: p_.grad.detach() for k, p_ in net64.named_parameters()}
+    g64 = torch.autograd.grad(loss64, [W1, b1, W2, b2, W3, b3, logits])
+    names = [k for k, _ in ref.rgbnet.named_parameters()]
+    truth = {"rgbnet." + k: g_ for k, g_ in zip(names, g64[:6])}
+    # A pre-activation within fp32 rounding of zero lands on either side of the ReLU depending on the summation order: that
+    # (sample, unit)'s gradient term is then present in one fp32 evaluation and absent in another -- both are correct fp32.  Bound
+    # of what such flips can move, per gradient element, from the fp64 quantities: |delta| x |input| summed over the (sample, unit)
+    # pairs whose |z| is below 5e-7 of the magnitude of its terms (layer 2), plus their propagation into layer 1.
+    with torch.no_grad():
+        d3 = g64[6]
+        d2pre = d3 @ W3                                          # [M,128] before the ReLU mask
+        d1pre = (d2pre * (z2 > 0)) @ W2
+        mag2 = h1 @ W2.abs().T + b2.abs()
+        mag1 = feat64.abs() @ W1.abs().T + b1.abs()
+        near2 = (z2.abs() < 5e-7 * mag2).double() * d2pre.abs()
+        near1 = (z1.abs() < 5e-7 * mag1).double() * d1pre.abs() + near2 @ W2.abs()
+        flip = {"rgbnet." + names[0]: near1.T @ feat64.abs(), "rgbnet." + names[1]: near1.sum(0),
+                "rgbnet." + names[2]: near2.T @ h1, "rgbnet." + names[3]: near2.sum(0),
+                "rgbnet." + names[4]: torch.zeros_like(W3), "rgbnet." + names[5]: torch.zeros_like(b3)}
+        n_near = int((z2.abs() < 5e-7 * mag2).sum()) + int((z1.abs() < 5e-7 * mag1).sum())
     # ---- this package
     m = FourierGridModel(**ctor).to(dev)
     m.load_state_dict(init)
@@ -203,13 +227,20 @@ def test_gradients_vs_the_reference_on_this_gpu_and_its_own_run_to_run_spread():
         if k in truth:
             r["reference_minus_fp64"] = float((ga[k].double() - truth[k]).abs().max()) / scale
             r["ours_minus_fp64"] = float((ours_t.double() - truth[k]).abs().max()) / scale
+            # the same distance with the movable (ReLU-flip) part of every element taken off
+            r["ours_minus_fp64_beyond_flips"] = float(((ours_t.double() - truth[k]).abs() - flip[k]).clamp_min(0).max()) / scale
+            r["flip_bound"] = float(flip[k].max()) / scale
         rows[k] = r
-        print("grad %-18s scale %.3e  ref run-to-run %.2e  ours-ref %.2e  ref-fp64 %s  ours-fp64 %s  same voxels %s" % (
+        print("grad %-18s scale %.3e  ref run-to-run %.2e  ours-ref %.2e  ref-fp64 %s  ours-fp64 %s (beyond ReLU flips %s, flip bound %s)  same voxels %s" % (
             k, scale, r["reference_run_to_run"], r["ours_minus_reference"],
             ("%.2e" % r["reference_minus_fp64"]) if "reference_minus_fp64" in r else "-",
-            ("%.2e" % r["ours_minus_fp64"]) if "ours_minus_fp64" in r else "-", r["same_touched_voxels"]))
-    json.dump({"loss_reference": [la, lb], "loss_ours": float(loss), "rows": rows}, open(os.path.join(ROOT, "gpurun_out", "grad_vs_reference_spread.json"), "w"), indent=1)
+            ("%.2e" % r["ours_minus_fp64"]) if "ours_minus_fp64" in r else "-",
+            ("%.2e" % r["ours_minus_fp64_beyond_flips"]) if "ours_minus_fp64" in r else "-",
+            ("%.2e" % r["flip_bound"]) if "flip_bound" in r else "-", r["same_touched_voxels"]))
+    print("(sample, unit) pairs within 5e-7 of a ReLU threshold: %d of %d" % (n_near, 2 * z1.numel()))
+    json.dump({"loss_reference": [la, lb], "loss_ours": float(loss), "pre_activations_within_rounding_of_zero": n_near, "rows": rows}, open(os.path.join(ROOT, "gpurun_out", "grad_vs_reference_spread.json"), "w"), indent=1)
     worst_net = max(max(r.get("ours_minus_fp64", 0.0), r.get("reference_minus_fp64", 0.0)) for r in rows.values())
+    assert n_near <= 40, n_near
     for k, r in rows.items():
         if "grid" in k:
             assert r["same_touched_voxels"], k
@@ -218,4 +249,4 @@ def test_gradients_vs_the_reference_on_this_gpu_and_its_own_run_to_run_spread():
         elif k == "k0.grid":       # d loss / d k0 passes through the rgbnet's input gradient: as accurate as the rgbnet's own gradients are
             assert r["ours_minus_reference"] <= 5.0 * r["reference_run_to_run"] + 4.0 * worst_net + 2e-5, (k, r, worst_net)
         else:
-            assert r["ours_minus_fp64"] <= 2.0 * r["reference_minus_fp64"] + 2e-5, (k, r)
+            assert r["ours_minus_fp64_beyond_flips"] <= 2.0 * r["reference_minus_fp64"] + 2e-5, (k, r)
