@@ -298,3 +298,33 @@ def test_native_ray_generation_matches_the_torch_chain(fr):
     part = fr.get_rays_of_pixel_index(H, W, K, c2w.cuda(), idx)
     for a, b in zip(part, full):
         assert torch.equal(a, b.reshape(-1, 3)[idx])
+
+
+def test_frame_render_is_capturable_in_a_hip_graph(fr):
+    """The fused render makes no host read and no allocation the caching allocator cannot serve from a graph pool: a whole
+    `FourierGridRenderer.forward(ray_order="coherent")` -- the march launch, the shade launch and their counter memsets, issued
+    through the C ABI on torch's current stream -- can be captured ONCE into a hipGraph (torch.cuda.CUDAGraph) and replayed on new
+    ray contents: same bits as the eager call.  (the boundary is ctypes, not a torch.library registration;
+    what a graph needs from a boundary -- stream-ordered launches, no syncs -- it has.)"""
+    state = make_state(seed=9, G=24, F=3, C=12, pe=4, norm="inf", thres=1e-4, dm=6.0, ds=12.0)
+    rend = fr.FourierGridRenderer(state, "cuda:0")
+    R = 4096
+    batches = [[torch.from_numpy(a).cuda() for a in synth.rays(70 + i, R)] for i in range(3)]
+    eager = [rend(o, d, v, stepsize=0.5, render_depth=True, ray_order="coherent") for o, d, v in batches]
+    eager = [{k: e[k].clone() for k in ("rgb_marched", "depth", "alphainv_last")} for e in eager]
+    so, sd, sv = [t.clone() for t in batches[0]]                       # static input buffers of the graph
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                      # warm-up on the capture stream (work list, tables, attributes)
+        rend(so, sd, sv, stepsize=0.5, render_depth=True, ray_order="coherent")
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = rend(so, sd, sv, stepsize=0.5, render_depth=True, ray_order="coherent")
+    for i in (1, 2, 0):
+        o, d, v = batches[i]
+        so.copy_(o); sd.copy_(d); sv.copy_(v)
+        graph.replay()
+        torch.cuda.synchronize()
+        for k in ("rgb_marched", "depth", "alphainv_last"):
+            assert torch.equal(out[k], eager[i][k]), (i, k)

@@ -253,6 +253,7 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         state_dict.  Code that reads `param.data` directly must call it (or torch.cuda.synchronize()) first."""
         world, rank = self._world()
         tv_terms = tv_terms or {}
+        self.last_exchange = {}          # (per step: parameters are replaced at every pg_scale event)
         scale = (1.0 / world) if (self.average and world > 1) else None
         side = None
         if overlap and world == 1:
