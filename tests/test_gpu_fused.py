@@ -305,7 +305,10 @@ def test_frame_render_is_capturable_in_a_hip_graph(fr):
     `FourierGridRenderer.forward(ray_order="coherent")` -- the march launch, the shade launch and their counter memsets, issued
     through the C ABI on torch's current stream -- can be captured ONCE into a hipGraph (torch.cuda.CUDAGraph) and replayed on new
     ray contents: same bits as the eager call.  (the boundary is ctypes, not a torch.library registration;
-    what a graph needs from a boundary -- stream-ordered launches, no syncs -- it has.)"""
+    what a graph needs from a boundary -- stream-ordered launches, no syncs -- it has.)  Writing this test found a real defect:
+    the shade kernels' tile counters were reset with hipMemsetAsync, and a memset NODE of a replayed graph does not reach the
+    L2-resident counters the kernels' device-scope atomics use -- from the second replay on three of four tiles kept the previous
+    frame's colours.  The counters are now zeroed by a one-block kernel (csrc/ugrid_render.h: UG_ZERO_WORDS)."""
     state = make_state(seed=9, G=24, F=3, C=12, pe=4, norm="inf", thres=1e-4, dm=6.0, ds=12.0)
     rend = fr.FourierGridRenderer(state, "cuda:0")
     R = 4096

@@ -1950,6 +1950,19 @@ static inline int ug_fill_march_args(const ugrid_render_params *p, ug_march_args
   return 0;
 }
 
+// Zero a few 32-bit words on the stream with a KERNEL instead of hipMemsetAsync: the shade kernels' tile counters are hit by
+// device-scope atomics and live in L2; a memset NODE of a captured hipGraph does not reach them coherently on replay (ROCm 7.2,
+// MI355X: from the second replay on every workgroup saw its counter exhausted and 3 of 4 tiles kept the previous frame's colours
+// -- tests/test_gpu_fused.py::test_frame_render_is_capturable_in_a_hip_graph), a kernel's stores do.  ~2 us per launch.
+static __global__ void ug_k_zero_u32(uint32_t *__restrict__ p, int n) {
+  if ((int)threadIdx.x < n) p[threadIdx.x] = 0u;
+}
+#define UG_ZERO_WORDS(ptr, n_words, st)                                                                      \
+  do {                                                                                                       \
+    hipLaunchKernelGGL(ug_k_zero_u32, dim3(1), dim3(64), 0, (st), (uint32_t *)(ptr), (int)(n_words));        \
+    UG_LAUNCH_CHECK();                                                                                       \
+  } while (0)
+
 static inline void ug_fill_shade_args(const ugrid_render_params *p, ug_shade_args &a) {
   a.n_rays = p->n_rays; a.X = p->grid_x; a.Y = p->grid_y; a.Z = p->grid_z;
   a.lox = p->xyz_min[0]; a.loy = p->xyz_min[1]; a.loz = p->xyz_min[2];

@@ -431,7 +431,7 @@ static int ug_fused_launch_nw(const ug_march_args &am, const ug_shade_args &as, 
   const int64_t n_tiles = (am.n_rays + UG_WAVE - 1) / UG_WAVE;
   const int64_t slots = (int64_t)UG_FUSED_MAX_WGS * NW, cap = (int64_t)UG_WAVE * am.S;
   char *base = (char *)ws_mem;
-  UG_HIP(hipMemsetAsync(base, 0, 256, st));  // 8 tile counters @0, survivor total @64
+  UG_ZERO_WORDS(base, 64, st);  // 8 tile counters @0, survivor total @64
   float4 *ent = (float4 *)(base + 256);
   uint8_t *slot = (uint8_t *)(base + 256 + ug_align256(slots * cap * 16));
   int64_t wgs = (n_tiles + NW - 1) / NW;
@@ -510,7 +510,7 @@ static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, con
                               ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
   const int lds_bytes = ug_shade_lds_bytes<C, PE, BF, NW>();
   UG_SET_DYN_LDS((k_shade_mlp<F, C, PE, NW, BF>), lds_bytes);
-  UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
+  UG_ZERO_WORDS(counter, 8, st);
   // persistent: one workgroup per CU (LDS holds the packed rgbnet image of the mode: 89 / 138 / 93 KB)
   int64_t wgs = (ws.n_tiles + NW - 1) / NW;
   if (wgs > 256) wgs = 256;
@@ -528,7 +528,7 @@ static int ug_shade_pc_launch(const ug_shade_args &a, const float *viewdirs, con
   const int lds_bytes = ug_pc_lds_bytes<PE, NPAIR, SLOTS>();
   if (lds_bytes > 160 * 1024) return (int)hipErrorInvalidValue;   // the CU's LDS
   UG_SET_DYN_LDS((k_shade_pc<F, PE, NPAIR, SLOTS, NBL, MODE>), lds_bytes);
-  UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
+  UG_ZERO_WORDS(counter, 8, st);
   // persistent, one workgroup per CU: NPAIR producer waves pull tiles, so a workgroup covers >= NPAIR tiles
   int64_t wgs = (ws.n_tiles + NPAIR - 1) / NPAIR;
   if (wgs > 256) wgs = 256;
@@ -545,7 +545,7 @@ static int ug_shade16_launch(const ug_shade_args &a, const float *viewdirs, cons
                              ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
   const int lds_bytes = (int)sizeof(float) * (ug_mlp16_lds_floats() + 16 * UG_ACC16_SCRATCH_FLOATS);
   UG_SET_DYN_LDS((k_shade_mlp16<F>), lds_bytes);
-  UG_HIP(hipMemsetAsync(counter, 0, 8 * sizeof(int32_t), st));
+  UG_ZERO_WORDS(counter, 8, st);
   int64_t wgs = (ws.n_tiles + 15) / 16;
   if (wgs > 256) wgs = 256;
   wgs = (wgs + 7) / 8 * 8;
@@ -635,7 +635,7 @@ extern "C" int ugrid_shade_supported(int32_t freq_num, int32_t k0_channels, int3
 
 extern "C" int ugrid_render_stats(void *ws_mem, int64_t n_rays, int32_t S, int64_t *d_stats, ugrid_stream_t s) {
   ug_ws_view ws = ug_ws_make(ws_mem, n_rays, S);
-  UG_HIP(hipMemsetAsync(d_stats, 0, sizeof(int64_t), ST(s)));
+  UG_ZERO_WORDS(d_stats, 2, ST(s));
   hipLaunchKernelGGL(k_ws_stats, dim3(64), dim3(256), 0, ST(s), ws.count, ws.n_tiles, d_stats);
   UG_LAUNCH_CHECK();
   return 0;
