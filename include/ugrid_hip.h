@@ -454,6 +454,39 @@ int ugrid_train_sample_backward(int64_t n_rays, float act_shift, float interval,
                                 const float *alphainv_last, const float *g_weights2, const float *g_alphainv_last,
                                 const float *g_density2, float *g_density1, ugrid_stream_t stream);
 
+/* ugrid_train_sample for the reference's two dense-grid models (NEW, round 4; same scratch / count / compact / backward
+ * contract as ugrid_train_sample, density_grid = the canonical [1,1,X,Y,Z] parameter):
+ *   ugrid_train_sample_dcvgo  DirectContractedVoxGO.forward's sampling (dcvgo.py:228-330): mid-point table, contraction
+ *       ((1 + bg_len) - bg_len / norm, dcvgo.py:258-262), cumdist_thres over the contracted samples (ub360_utils_kernel.cu:13-33;
+ *       dist_thres = (2 + 2 bg_len) / world_len * stepsize * 0.95, dcvgo.py:285), maskcache_lookup
+ *       (render_utils_kernel.cu:374-392; mask [mi,mj,mk] bytes on the device, mask_dims3 / xyz2ijk_* HOST pointers), dense
+ *       trilinear density, Raw2Alpha, alpha mask, Alphas2Weights, weight mask;
+ *   ugrid_train_sample_dvgo   DirectVoxGO.forward's (dvgo.py:306-375): sample_pts_on_rays (render_utils_kernel.cu:16-57,
+ *       100-260: per-ray t_min / t_max / step count; `far` as the caller passes it, the model passes 1e9), ~mask_outbbox, the mask
+ *       cache, then as above.  slots_per_ray = scratch slots per ray, >= the longest possible ray (the box diagonal / stepdist + 2).
+ *   ugrid_train_sample_compact_vox = ugrid_train_sample_compact + inner2 [M2] bytes (dcvgo.py:262 inner_mask of the surviving
+ *       samples; NULL: not wanted) and t_table == NULL allowed (DirectVoxGO has none: t2 receives float(step_id)). */
+int ugrid_train_sample_dcvgo(const float *density_grid, int X, int Y, int Z, const float *rays_o, const float *rays_d,
+                             int64_t n_rays, const float *t_table, int32_t n_samples, const float *scene_center3,
+                             const float *scene_radius3, const float *xyz_min, const float *xyz_max, double bg_len, int norm_l2,
+                             float dist_thres, const uint8_t *mask, const int32_t *mask_dims3, const float *xyz2ijk_scale3,
+                             const float *xyz2ijk_shift3, float act_shift, float interval, float thres, float *scratch_pts,
+                             float *scratch_density, int32_t *scratch_step, float *scratch_w, float *scratch_T, int32_t *count,
+                             int32_t *count2, float *alphainv_last, ugrid_stream_t stream);
+int ugrid_train_sample_dvgo(const float *density_grid, int X, int Y, int Z, const float *rays_o, const float *rays_d,
+                            int64_t n_rays, int32_t slots_per_ray, const float *xyz_min, const float *xyz_max, float near, float far,
+                            float stepdist, const uint8_t *mask, const int32_t *mask_dims3, const float *xyz2ijk_scale3,
+                            const float *xyz2ijk_shift3, float act_shift, float interval, float thres, float *scratch_pts,
+                            float *scratch_density, int32_t *scratch_step, float *scratch_w, float *scratch_T, int32_t *count,
+                            int32_t *count2, float *alphainv_last, ugrid_stream_t stream);
+int ugrid_train_sample_compact_vox(int64_t n_rays, int32_t slots_per_ray, float act_shift, float interval, float thres,
+                                   const float *scratch_pts, const float *scratch_density, const int32_t *scratch_step,
+                                   const float *scratch_w, const float *scratch_T, const int32_t *count, const int64_t *offset_end,
+                                   const int32_t *count2, const int64_t *offset_end2, const float *t_table, float *pts1,
+                                   float *density1, float *weights1, float *T1, int32_t *pos2, float *pts2, float *density2,
+                                   float *alpha2, float *weights2, int64_t *ray_id2, int64_t *step_id2, float *t2,
+                                   uint8_t *inner2, ugrid_stream_t stream);
+
 /* 1 when ugrid_render_shade / ugrid_render_fused have an rgbnet instantiation (depth 3, width 128) for this
  * (fourier_freq_num, k0 channels, viewbase_pe) triple, else 0 (they return hipErrorNotSupported for it). */
 int ugrid_shade_supported(int32_t freq_num, int32_t k0_channels, int32_t viewbase_pe);

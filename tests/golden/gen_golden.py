@@ -478,6 +478,87 @@ def gen_checkpoint_odd():
     print("odd checkpoint: density", tuple(model.density.grid.shape), "k0", tuple(model.k0.grid.shape), "M", out["weights"].numel())
 
 
+def _voxgo_reference_model(kind, case):
+    """the reference's own DirectVoxGO / DirectContractedVoxGO holding the synthetic parameters of a DVGO_CASES / DCVGO_CASES row"""
+    if kind == "dvgo":
+        dvgo = install_stubs.import_reference("dvgo")
+        name, seed, G, C, direct, R, dm, ds = case
+        xyz_min, xyz_max, nvox = dvgo_inputs(seed, G, C)
+        model = dvgo.DirectVoxGO(xyz_min=xyz_min, xyz_max=xyz_max, num_voxels=nvox, num_voxels_base=nvox, alpha_init=1e-2,
+                                 fast_color_thres=1e-4, rgbnet_dim=C, rgbnet_direct=direct, mask_cache_world_size=None)
+    else:
+        dcvgo = install_stubs.import_reference("dcvgo")
+        name, seed, G, Gb, C, norm, R, dm, ds = case
+        direct = True
+        model = dcvgo.DirectContractedVoxGO(xyz_min=synth.DCVGO_BOX[0], xyz_max=synth.DCVGO_BOX[1], num_voxels=G ** 3,
+                                            num_voxels_base=Gb ** 3, alpha_init=1e-2, fast_color_thres=1e-4,
+                                            contracted_norm=norm, rgbnet_dim=C)
+    ws = [int(x) for x in model.world_size]
+    sd = model.state_dict()
+    params = synth.dvgo_params(seed, ws, C, direct, dens_mean=dm, dens_std=ds)
+    with torch.no_grad():
+        for k, v in params.items():
+            assert tuple(sd[k].shape) == tuple(v.shape), (k, sd[k].shape, v.shape)
+            sd[k].copy_(torch.from_numpy(v))
+    return model.to(DEVICE), name, seed, R
+
+
+def gen_voxgo_train():
+    """One TRAINING forward + backward of the reference's own DirectVoxGO (all three DVGO_CASES: direct, residual colour, coarse)
+    and DirectContractedVoxGO (both DCVGO_CASES) -- loss = mse + 0.01 * entropy_last (run_train.py:254-261), + the
+    distortion-style use of weights / raw_density where the model returns them: outputs and the gradient of every parameter,
+    to pin unboundednerfpytorch_amd.voxgo_model (fused training forward, tests/test_gpu_voxgo_train.py).  Also the models'
+    parameter / buffer names and shapes, get_kwargs keys, update_occupancy_cache and scale_volume_grid."""
+    for kind, cases in (("dvgo", DVGO_CASES), ("dcvgo", synth.DCVGO_CASES)):
+        for case in cases:
+            model, name, seed, R = _voxgo_reference_model(kind, case)
+            if kind == "dvgo":
+                o, d, v = [torch.from_numpy(a) for a in synth.rays(seed, R, origin_scale=0.4)]
+                kw = dict(near=0.2, far=6.0, stepsize=0.5, bg=1, render_depth=True)
+            else:
+                o, d, v = [torch.from_numpy(a) for a in synth.rays(seed, R, origin_scale=0.5)]
+                o = o + torch.tensor(synth.DCVGO_BOX[0]) * 0.5 + torch.tensor(synth.DCVGO_BOX[1]) * 0.5
+                kw = dict(stepsize=0.5, bg=1, render_depth=True)
+            target = torch.from_numpy(synth.uniform(seed + 5, R * 3).reshape(R, 3))
+            out = model(o, d, v, global_step=1, is_train=True, **kw)
+            loss = torch.nn.functional.mse_loss(out["rgb_marched"], target)
+            pout = out["alphainv_last"].clamp(1e-6, 1 - 1e-6)
+            loss = loss + 0.01 * (-(pout * torch.log(pout) + (1 - pout) * torch.log(1 - pout))).mean()
+            loss = loss + 0.05 * (out["weights"] * out["weights"]).sum() / R
+            if "raw_density" in out:
+                loss = loss + 1e-4 * out["raw_density"].sum() / R
+            loss.backward()
+            res = {"loss": loss.detach().numpy(), "n_kept": np.int64(out["weights"].numel()), "target": target.numpy()}
+            for k in ("rgb_marched", "alphainv_last", "weights", "ray_id", "raw_rgb", "raw_alpha", "depth", "step_id", "wsum_mid"):
+                if k in out:
+                    res[k] = out[k].detach().numpy()
+            for k, p in model.named_parameters():
+                if p.grad is not None:
+                    res["grad." + k] = p.grad.numpy()
+            sd = model.state_dict()
+            res["sd_keys"] = np.array(sorted(sd.keys()))
+            res["sd_shapes"] = np.array([str(tuple(sd[k].shape)) for k in sorted(sd.keys())])
+            res["kwargs_keys"] = np.array(sorted(model.get_kwargs().keys()))
+            model.zero_grad()
+            model.update_occupancy_cache()
+            res["occ_mask"] = model.mask_cache.mask.numpy().copy()
+            G2 = int(model.world_size[0]) + 5
+            model.scale_volume_grid(G2 ** 3)
+            res["scaled_density"] = model.density.grid.detach().numpy().copy()
+            res["scaled_k0"] = model.k0.grid.detach().numpy().copy()
+            res["scaled_mask"] = model.mask_cache.mask.numpy().copy()
+            res["scaled_world_size"] = model.world_size.numpy().copy()
+            res["scaled_ratio"] = np.float32(float(model.voxel_size_ratio))
+            res["scaled_num_voxels"] = np.int64(G2 ** 3)
+            with torch.no_grad():
+                out2 = model(o, d, v, global_step=2, is_train=True, **kw)
+            res["scaled_rgb_marched"] = out2["rgb_marched"].numpy()
+            res["scaled_n_kept"] = np.int64(out2["weights"].numel())
+            np.savez_compressed(os.path.join(OUT, "voxgo_train_" + name + ".npz"), **res)
+            print("voxgo_train", name, "loss %.6f kept %d, after scaling to %s kept %d" % (
+                float(loss), int(res["n_kept"]), res["scaled_world_size"].tolist(), int(res["scaled_n_kept"])))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)  # deterministic reduction order in F.linear / grid_sample
     gen_fouriergrid()
@@ -493,3 +574,4 @@ if __name__ == "__main__":
     gen_dvgo_utils()
     gen_model_utils()
     gen_train_utils()
+    gen_voxgo_train()

@@ -1,0 +1,234 @@
+"""voxgo_model.DirectVoxGO / DirectContractedVoxGO -- the TRAINING counterparts of the reference's two dense-grid models
+(dvgo.py:26-425, dcvgo.py:27-384) -- against golden vectors produced by the reference's OWN model
+classes (tests/golden/gen_golden.py::gen_voxgo_train: one training forward + backward of every DVGO_CASES / DCVGO_CASES row,
+parameter names, update_occupancy_cache, scale_volume_grid):
+
+  * the FUSED training forward (grid.TrainSampleVox: ugrid_train_sample_dvgo / _dcvgo + the channel-last k0 lookup + the
+    fp32-MFMA rgbnet) reproduces the reference's sample lists, per-sample and per-ray outputs and the gradient of every parameter;
+  * it equals the op-by-op chain over the drop-in ops (fused_forward = False) bit for bit in everything the sampling decides;
+  * the state_dict / get_kwargs names and shapes are the reference's, checkpoints interchange;
+  * the coarse-to-fine step and the occupancy-cache update reproduce the reference's results;
+  * train_step.train_iteration drives both models (TV phases, masked Adam, pg_scale).
+CPU part (not gpu): names and shapes only -- the models have no CPU path."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+DVGO_CASES = [
+    # name, seed, G, C (0 = coarse stage), rgbnet_direct, R, dens_mean, dens_std   (tests/golden/gen_golden.py DVGO_CASES)
+    ("dvgo_fine_direct", 31, 22, 12, True, 150, 2.0, 4.0),
+    ("dvgo_fine_residual", 32, 18, 9, False, 120, 3.0, 5.0),
+    ("dvgo_coarse", 33, 20, 0, False, 120, 1.0, 4.0),
+]
+DVGO_BOX = ([-1.0, -0.8, -1.1], [1.0, 0.9, 1.0])
+ALL = [("dvgo", c) for c in DVGO_CASES] + [("dcvgo", c) for c in synth.DCVGO_CASES]
+IDS = [c[0] for _, c in ALL]
+
+
+def build(kind, case, device="cpu"):
+    from unboundednerfpytorch_amd import voxgo_model as vm
+    if kind == "dvgo":
+        name, seed, G, C, direct, R, dm, ds = case
+        m = vm.DirectVoxGO(xyz_min=DVGO_BOX[0], xyz_max=DVGO_BOX[1], num_voxels=G ** 3, num_voxels_base=G ** 3, alpha_init=1e-2,
+                           fast_color_thres=1e-4, rgbnet_dim=C, rgbnet_direct=direct, mask_cache_world_size=None)
+        o, d, v = [torch.from_numpy(a) for a in synth.rays(seed, R, origin_scale=0.4)]
+        kw = dict(near=0.2, far=6.0, stepsize=0.5, bg=1, render_depth=True)
+    else:
+        name, seed, G, Gb, C, norm, R, dm, ds = case
+        direct = True
+        m = vm.DirectContractedVoxGO(xyz_min=synth.DCVGO_BOX[0], xyz_max=synth.DCVGO_BOX[1], num_voxels=G ** 3,
+                                     num_voxels_base=Gb ** 3, alpha_init=1e-2, fast_color_thres=1e-4, contracted_norm=norm,
+                                     rgbnet_dim=C)
+        o, d, v = [torch.from_numpy(a) for a in synth.rays(seed, R, origin_scale=0.5)]
+        o = o + torch.tensor(synth.DCVGO_BOX[0]) * 0.5 + torch.tensor(synth.DCVGO_BOX[1]) * 0.5
+        kw = dict(stepsize=0.5, bg=1, render_depth=True)
+    ws = [int(x) for x in m.world_size]
+    params = synth.dvgo_params(seed, ws, C, direct, dens_mean=dm, dens_std=ds)
+    sd = m.state_dict()
+    with torch.no_grad():
+        for k, val in params.items():
+            assert tuple(sd[k].shape) == tuple(val.shape), (k, sd[k].shape, val.shape)
+            sd[k].copy_(torch.from_numpy(val))
+    m = m.to(device)
+    return m, name, [x.to(device) for x in (o, d, v)], kw, R, seed
+
+
+def golden_loss(out, target, R):
+    loss = torch.nn.functional.mse_loss(out["rgb_marched"], target)
+    p = out["alphainv_last"].clamp(1e-6, 1 - 1e-6)
+    loss = loss + 0.01 * (-(p * torch.log(p) + (1 - p) * torch.log(1 - p))).mean()
+    loss = loss + 0.05 * (out["weights"] * out["weights"]).sum() / R
+    if "raw_density" in out:
+        loss = loss + 1e-4 * out["raw_density"].sum() / R
+    return loss
+
+
+@pytest.mark.parametrize("kind,case", ALL, ids=IDS)
+def test_voxgo_models_have_the_reference_names_and_shapes(kind, case, golden_dir):
+    """state_dict keys / shapes and get_kwargs keys of the reference's classes (checkpoints interchange) -- runs on the CPU"""
+    m, name, _, _, _, _ = build(kind, case)
+    gold = np.load(os.path.join(golden_dir, "voxgo_train_" + name + ".npz"))
+    sd = m.state_dict()
+    assert sorted(sd.keys()) == gold["sd_keys"].tolist()
+    assert [str(tuple(sd[k].shape)) for k in sorted(sd.keys())] == gold["sd_shapes"].tolist()
+    assert sorted(m.get_kwargs().keys()) == gold["kwargs_keys"].tolist()
+    with pytest.raises(RuntimeError):          # no CPU path: the ops need the HIP library and a device tensor
+        o, d, v = [torch.from_numpy(a) for a in synth.rays(3, 4)]
+        m(o, d, v, near=0.2, far=6.0, stepsize=0.5, bg=1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,case", ALL, ids=IDS)
+def test_fused_training_forward_backward_matches_the_reference_model(kind, case, golden_dir):
+    dev = torch.device("cuda", 0)
+    m, name, (o, d, v), kw, R, seed = build(kind, case, dev)
+    gold = np.load(os.path.join(golden_dir, "voxgo_train_" + name + ".npz"))
+    target = torch.from_numpy(gold["target"]).to(dev)
+    assert m.fused_forward and m._can_fuse(o)
+    out = m(o, d, v, global_step=1, is_train=True, **kw)
+    loss = golden_loss(out, target, R)
+    loss.backward()
+    torch.cuda.synchronize()
+    # the sampling decisions (box, cumdist, mask cache, both thresholds) agree with the reference's unless a 1-ulp alpha or
+    # weight difference crosses a threshold
+    n, n_gold = int(out["weights"].numel()), int(gold["n_kept"])
+    assert abs(n - n_gold) <= 2, (n, n_gold)
+    if n == n_gold:
+        assert np.array_equal(out["ray_id"].cpu().numpy(), gold["ray_id"])
+        if "step_id" in gold.files:
+            assert np.array_equal(out["step_id"].cpu().numpy(), gold["step_id"])
+        for k in ("weights", "raw_alpha", "raw_rgb"):
+            np.testing.assert_allclose(out[k].detach().cpu().numpy(), gold[k], rtol=0, atol=2e-5, err_msg=k)
+    for k in ("rgb_marched", "alphainv_last", "depth", "wsum_mid"):
+        if k in gold.files:
+            np.testing.assert_allclose(out[k].detach().cpu().numpy(), gold[k], rtol=0, atol=1e-4, err_msg=k)
+    np.testing.assert_allclose(float(loss), float(gold["loss"]), rtol=2e-5)
+    for k, p in m.named_parameters():
+        g = gold["grad." + k]
+        assert p.grad is not None, k
+        scale = float(np.abs(g).max()) + 1e-20
+        err = float(np.abs(p.grad.cpu().numpy() - g).max())
+        assert err <= 5e-4 * scale, (k, err / scale)
+        if "grid" in k and n == n_gold:
+            assert np.array_equal(p.grad.cpu().numpy() != 0, g != 0), k          # the voxels MaskedAdam will update
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,case", ALL, ids=IDS)
+def test_fused_sampling_equals_the_op_by_op_chain(kind, case):
+    """fused (one march + one compaction) vs composed (sample_pts_on_rays / cumdist_thres / maskcache_lookup / grid query /
+    Raw2Alpha / Alphas2Weights as separate drop-in ops): the same samples, bit-equal weights, gradients equal up to the order
+    of the atomic sums"""
+    dev = torch.device("cuda", 0)
+    m, name, (o, d, v), kw, R, seed = build(kind, case, dev)
+    m.fused_rgbnet = False                 # library rgbnet on both sides: only the sampling differs
+    target = torch.from_numpy(synth.uniform(seed + 5, R * 3).reshape(R, 3)).to(dev)
+    o = o.clone()
+    o[:5] = o[:5] * 6.0                    # some rays from outside the box / far out in the contracted region
+    res = {}
+    for fused in (True, False):
+        m.fused_forward = fused
+        m.zero_grad(set_to_none=True)
+        out = m(o, d, v, global_step=1, is_train=True, **kw)
+        golden_loss(out, target, R).backward()
+        res[fused] = (out, {k: p.grad.clone() for k, p in m.named_parameters()})
+    a, b = res[True][0], res[False][0]
+    assert a["weights"].numel() > 500
+    for k in ("ray_id", "step_id", "t", "weights", "raw_alpha", "raw_density", "alphainv_last"):
+        if k in a and k in b:
+            assert torch.equal(a[k], b[k]), k
+    for k in ("rgb_marched", "depth", "wsum_mid"):
+        if k in a:
+            assert float((a[k] - b[k]).abs().max()) <= 1e-6, k
+    for k in res[True][1]:
+        ga, gb = res[True][1][k], res[False][1][k]
+        scale = float(gb.abs().max()) + 1e-20
+        assert float((ga - gb).abs().max()) <= 1e-4 * scale, (k, float((ga - gb).abs().max()) / scale)
+        if "grid" in k:
+            assert torch.equal(ga != 0, gb != 0), k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,case", ALL, ids=IDS)
+def test_occupancy_cache_and_coarse_to_fine_step_match_the_reference(kind, case, golden_dir):
+    dev = torch.device("cuda", 0)
+    m, name, (o, d, v), kw, R, seed = build(kind, case, dev)
+    gold = np.load(os.path.join(golden_dir, "voxgo_train_" + name + ".npz"))
+    m.update_occupancy_cache()
+    got = m.mask_cache.mask.cpu().numpy()
+    assert int((got != gold["occ_mask"]).sum()) <= 2            # (alpha > thres at a vertex: a 1-ulp flip at most)
+    m.scale_volume_grid(int(gold["scaled_num_voxels"]))
+    assert m.world_size.tolist() == gold["scaled_world_size"].tolist()
+    np.testing.assert_allclose(float(m.voxel_size_ratio), float(gold["scaled_ratio"]), rtol=1e-6)
+    np.testing.assert_allclose(m.density.grid.detach().cpu().numpy(), gold["scaled_density"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(m.k0.grid.detach().cpu().numpy(), gold["scaled_k0"], rtol=0, atol=2e-5)
+    assert float((m.mask_cache.mask.cpu().numpy() != gold["scaled_mask"]).mean()) <= 2e-3
+    with torch.no_grad():
+        out = m(o, d, v, global_step=2, is_train=True, **kw)       # the fused forward on the rescaled model (new mask, new ratio)
+    assert abs(int(out["weights"].numel()) - int(gold["scaled_n_kept"])) <= max(4, int(0.004 * int(gold["scaled_n_kept"])))
+    np.testing.assert_allclose(out["rgb_marched"].cpu().numpy(), gold["scaled_rgb_marched"], rtol=0, atol=2e-3)
+
+
+@pytest.mark.gpu
+def test_dvgo_voxel_count_views_matches_the_reference(golden_dir):
+    """DirectVoxGO.voxel_count_views (dvgo.py:250-276) on the three tiny views of tests/golden/dvgo_utils.npz"""
+    from unboundednerfpytorch_amd.fourier_render import get_rays_of_a_view
+    dev = torch.device("cuda", 0)
+    m, name, _, _, _, _ = build("dvgo", DVGO_CASES[0], dev)
+    gold = np.load(os.path.join(golden_dir, "dvgo_utils.npz"))
+    H, W, K, poses = synth.dvgo_views()
+    ro, rd = [], []
+    for c2w in poses:
+        o, d, _ = get_rays_of_a_view(H, W, torch.from_numpy(K).to(dev), torch.from_numpy(c2w).to(dev), inverse_y=False,
+                                     flip_x=False, flip_y=False)
+        ro.append(o.reshape(H, W, 3))
+        rd.append(d.reshape(H, W, 3))
+    count = m.voxel_count_views(rays_o_tr=torch.stack(ro), rays_d_tr=torch.stack(rd), imsz=1, near=0.2, far=6.0, stepsize=0.5,
+                                downrate=1, irregular_shape=False)
+    got, want = count.cpu().numpy(), gold["count"]
+    assert got.shape == want.shape
+    assert float((got != want).mean()) <= 1e-3            # `grad > 1` at a vertex: sums of trilinear weights in another order
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dvgo", "dcvgo"])
+def test_train_iteration_drives_the_voxgo_models(kind):
+    """train_step.train_iteration (run_train.py:185-296) on both models: a pg_scale step, the dense and the masked TV phase,
+    MaskedAdam with the touched-line bitmaps; the loss goes down on a fixed batch and the parameters stay finite"""
+    from unboundednerfpytorch_amd import train_step as ts
+    from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
+    dev = torch.device("cuda", 0)
+    case = DVGO_CASES[0] if kind == "dvgo" else synth.DCVGO_CASES[0]
+    m, name, (o, d, v), kw, R, seed = build(kind, case, dev)
+    with torch.no_grad():
+        m.mask_cache.mask.fill_(True)
+    target = torch.from_numpy(synth.uniform(seed + 5, R * 3).reshape(R, 3)).to(dev) * 0.5 + 0.25
+    cfg_train = dict(lrate_density=1e-1, lrate_k0=1e-1, lrate_rgbnet=1e-3, lrate_decay=20, pg_scale=[3], decay_after_scale=1.0,
+                     weight_main=1.0, weight_entropy_last=0.01, weight_rgbper=0.01, weight_nearclip=0.0, weight_distortion=0.0,
+                     tv_every=1, tv_after=0, tv_before=12, tv_dense_before=6, weight_tv_density=1e-5, weight_tv_k0=1e-6,
+                     skip_zero_grad_fields=['density', 'k0'])
+    nv = int(m.num_voxels)
+    cfg_model = dict(num_voxels=nv * 2)
+    with torch.no_grad():
+        m.scale_volume_grid(nv)          # (start from the low resolution of a 1-step pg_scale schedule)
+    opt = create_optimizer_or_freeze_model(m, cfg_train, global_step=0)
+    rk = {k: kw[k] for k in kw if k != "render_depth"}
+    losses = []
+    for step in range(1, 16):
+        opt = ts.maybe_scale_grids(m, opt, cfg_train, cfg_model, step)
+        loss, psnr = ts.train_iteration(m, opt, o, d, v, target, cfg_train, step, rk)
+        assert loss == loss and psnr == psnr
+        losses.append(loss)
+    torch.cuda.synchronize()
+    assert int(m.num_voxels) == nv * 2
+    assert losses[-1] < losses[3], losses
+    for k, p in m.named_parameters():
+        assert bool(torch.isfinite(p).all()), k

@@ -89,6 +89,10 @@ _SIGNATURES = {
                                  _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ugrid_train_sample_compact": (_I, [_L, _c.c_int32, _F, _F, _F] + [_P] * 23),
     "ugrid_train_sample_backward": (_I, [_L, _F, _F] + [_P] * 12),
+    "ugrid_train_sample_dcvgo": (_I, [_P, _I, _I, _I, _P, _P, _L, _P, _c.c_int32, _P, _P, _P, _P, _c.c_double, _I, _F, _P, _P, _P, _P,
+                                       _F, _F, _F] + [_P] * 9),
+    "ugrid_train_sample_dvgo": (_I, [_P, _I, _I, _I, _P, _P, _L, _c.c_int32, _P, _P, _F, _F, _F, _P, _P, _P, _P, _F, _F, _F] + [_P] * 9),
+    "ugrid_train_sample_compact_vox": (_I, [_L, _c.c_int32, _F, _F, _F] + [_P] * 24),
     "ugrid_grid_query_cl": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _L, _P, _P]),
     "ugrid_grid_query_backward_cl": (_I, [_P, _I, _I, _I, _I, _I, _P, _P, _P, _I, _L, _P, _P]),
     "ugrid_total_variation_add_grad_cl": (_I, [_P, _P, _F, _F, _F, _I, _L, _L, _L, _L, _L, _P]),

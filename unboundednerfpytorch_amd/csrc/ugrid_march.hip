@@ -257,6 +257,45 @@ struct ug_train_args {
   float shift, interval, thres;
 };
 
+// MODE 1 / 2 of k_train_march: the sampling rules of the reference's two non-Fourier models (single-level dense grids)
+//   1 = DirectContractedVoxGO (dcvgo.py:228-310): the FourierGrid point rule + of the contracted samples only those whose running
+//       inter-sample distance has just exceeded dist_thres (cumdist_thres, ub360_utils_kernel.cu:13-33: a serial recurrence
+//       along the ray -- here a readlane loop over the wave's 64 samples with a wave-uniform carry) + the mask cache
+//       (maskcache_lookup, render_utils_kernel.cu:374-392); the step id of a contracted sample is stored complemented
+//       (inner_mask of dcvgo.py:262 travels in the sign)
+//   2 = DirectVoxGO (dvgo.py:306-400): per-ray box clipping and step count (infer_t_minmax / infer_n_samples /
+//       sample_pts_on_rays, render_utils_kernel.cu:16-57,100-260), mask_outbbox, the mask cache; a.S = slots per ray (>= the
+//       longest possible ray: the host sizes it for the box diagonal), t_table unused
+struct ug_train_vox {
+  const uint8_t *mask;
+  int32_t mi, mj, mk;
+  float sx, sy, sz, hx, hy, hz;     // xyz2ijk_scale / xyz2ijk_shift
+  float dist_thres;                 // mode 1
+  float near, far, stepdist;        // mode 2
+};
+
+// mask cache: nearest voxel, C round(), NaN -> 0 like the device conversion (k_maskcache)
+__device__ __forceinline__ bool ug_train_maskcache(const ug_train_vox &v, float px, float py, float pz) {
+  float fi = roundf(px * v.sx + v.hx), fj = roundf(py * v.sy + v.hy), fk = roundf(pz * v.sz + v.hz);
+  fi = (fi != fi) ? 0.f : fi; fj = (fj != fj) ? 0.f : fj; fk = (fk != fk) ? 0.f : fk;
+  if (fi >= 0.f && fi < (float)v.mi && fj >= 0.f && fj < (float)v.mj && fk >= 0.f && fk < (float)v.mk)
+    return v.mask[((int64_t)fi * v.mj + (int64_t)fj) * v.mk + (int64_t)fk] != 0;
+  return false;
+}
+
+// sample t of a normalised ray, contracted outside the unit cube / ball (dcvgo.py:251-262, the arithmetic of k_train_march);
+// returns the norm before the contraction
+__device__ __forceinline__ float ug_train_point(const ug_train_args &a, float ox, float oy, float oz, float dx, float dy, float dz,
+                                                float t, float &px, float &py, float &pz) {
+  px = ox + dx * t; py = oy + dy * t; pz = oz + dz * t;
+  const float nrm = a.norm_l2 ? ug_norm3_torch(px, py, pz) : fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz)));
+  if (!(nrm <= 1.0f)) {
+    const float sc = a.B - a.A / nrm;
+    px = px / nrm * sc; py = py / nrm * sc; pz = pz / nrm * sc;
+  }
+  return nrm;
+}
+
 // alpha of a raw density exactly as k_raw2alpha forms it (e = expf(density + shift) is what its backward keeps)
 __device__ __forceinline__ float ug_train_alpha(float dens, float shift, float interval, float *e_out) {
   const float e = expf(dens + shift);
@@ -357,6 +396,127 @@ k_train_march(ug_train_args a, const float *__restrict__ grid, const float *__re
   }
 }
 
+// k_train_march<true> for the two dense-grid models (ug_train_vox above): MODE 1 = DirectContractedVoxGO, 2 = DirectVoxGO.
+// Same slot / scratch contract and the same stage-2 recurrence; P = 1, F = 0.
+template <int MODE>
+__global__ void __launch_bounds__(256)
+k_train_march_vox(ug_train_args a, ug_train_vox v, const float *__restrict__ grid, const float *__restrict__ rays_o,
+                  const float *__restrict__ rays_d, const float *__restrict__ t_table, const float *__restrict__ xyz_min,
+                  const float *__restrict__ xyz_max, float *__restrict__ s_pts, float *__restrict__ s_dens,
+                  int32_t *__restrict__ s_step, int32_t *__restrict__ count, float *__restrict__ s_w, float *__restrict__ s_T,
+                  int32_t *__restrict__ count2, float *__restrict__ alphainv_last) {
+  const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  if (ray >= a.n_rays) return;
+  const int lane = ug_lane();
+  const float lox = xyz_min[0], loy = xyz_min[1], loz = xyz_min[2], hix = xyz_max[0], hiy = xyz_max[1], hiz = xyz_max[2];
+  const float rox = rays_o[3 * ray], roy = rays_o[3 * ray + 1], roz = rays_o[3 * ray + 2];
+  const float rdx = rays_d[3 * ray], rdy = rays_d[3 * ray + 1], rdz = rays_d[3 * ray + 2];
+  float ox, oy, oz, dx, dy, dz;
+  int n = a.S;               // samples of this ray (wave-uniform)
+  if (MODE == 1) {
+    ox = (rox - a.cx) / a.rx; oy = (roy - a.cy) / a.ry; oz = (roz - a.cz) / a.rz;
+    const float dn = ug_norm3_torch(rdx, rdy, rdz);
+    dx = rdx / dn; dy = rdy / dn; dz = rdz / dn;
+  } else {
+    // ray / box slab test; a zero direction component is replaced by float(1e-6) (infer_t_minmax)
+    const float vx = (rdx == 0.f) ? (float)1e-6 : rdx, vy = (rdy == 0.f) ? (float)1e-6 : rdy, vz = (rdz == 0.f) ? (float)1e-6 : rdz;
+    const float ax = (hix - rox) / vx, ay = (hiy - roy) / vy, az = (hiz - roz) / vz;
+    const float bx = (lox - rox) / vx, by = (loy - roy) / vy, bz = (loz - roz) / vz;
+    const float tmin = fmaxf(fminf(fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz)), v.far), v.near);
+    const float tmax = fmaxf(fminf(fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz)), v.far), v.near);
+    const float rn = sqrtf(rdx * rdx + rdy * rdy + rdz * rdz);
+    const double c = (double)ceilf((tmax - tmin) * rn / v.stepdist);        // infer_n_samples
+    const double nn = c > 1. ? c : 1.;
+    n = nn > (double)a.S ? a.S : (int)nn;
+    ox = rox + rdx * tmin; oy = roy + rdy * tmin; oz = roz + rdz * tmin;     // rays_start
+    dx = rdx / rn; dy = rdy / rn; dz = rdz / rn;                             // rays_dir
+  }
+  const int64_t slot = ray * a.S;
+  int kept = 0, kept2 = 0;   // wave-uniform
+  float T_cum = 1.f;         // wave-uniform
+  float cum = 0.f;           // wave-uniform: the cumdist_thres carry (MODE 1)
+  bool stopped = false;
+  for (int j0 = 0; j0 < n && !stopped; j0 += UG_WAVE) {
+    const int j = j0 + lane;
+    bool keep = false, inner = true;
+    float px = 0.f, py = 0.f, pz = 0.f, dens = 0.f, alpha = 0.f;
+    if (MODE == 1) {
+      float dj = 0.f;
+      if (j < n) {
+        inner = ug_train_point(a, ox, oy, oz, dx, dy, dz, t_table[j], px, py, pz) <= 1.0f;
+        if (j > 0) {         // |p_j - p_{j-1}| over ALL consecutive samples (dcvgo.py:287)
+          float qx, qy, qz;
+          ug_train_point(a, ox, oy, oz, dx, dy, dz, t_table[j - 1], qx, qy, qz);
+          dj = ug_norm3_torch(px - qx, py - qy, pz - qz);
+        }
+      }
+      bool over = false;
+      const int cnt = (n - j0) < UG_WAVE ? (n - j0) : UG_WAVE;
+      for (int k = (j0 == 0 ? 1 : 0); k < cnt; ++k) {       // mask[:, 1:] |= cumdist_thres(dist): sample 0 has no distance
+        cum += ug_readlane_f(dj, k);
+        const bool ov = cum > v.dist_thres;
+        cum *= ov ? 0.f : 1.f;
+        if (lane == k) over = ov;
+      }
+      keep = j < n && (inner || over);
+    } else {
+      if (j < n) {
+        const float dist = v.stepdist * (float)j;
+        px = ox + dx * dist; py = oy + dy * dist; pz = oz + dz * dist;
+        keep = !((lox > px) | (loy > py) | (loz > pz) | (hix < px) | (hiy < py) | (hiz < pz));   // ~mask_outbbox
+      }
+    }
+    if (keep) keep = ug_train_maskcache(v, px, py, pz);
+    if (keep) {
+      const float ux = ug_unorm(px, lox, hix), uy = ug_unorm(py, loy, hiy), uz = ug_unorm(pz, loz, hiz);
+      const ug_taps tp = ug_tap_setup(a.X, a.Y, a.Z, ux, uy, uz);
+      float acc = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (tp.off[c] >= 0) acc += grid[tp.off[c]] * tp.w[c];
+      dens = acc;
+      float e;
+      alpha = ug_train_alpha(dens, a.shift, a.interval, &e);
+      keep = alpha > a.thres;
+    }
+    unsigned long long m = __ballot(keep);
+    float myT = 1.f, myW = 0.f;
+    unsigned long long mm = m;
+    while (mm != 0ull) {
+      const int k = __builtin_ctzll(mm);
+      mm &= mm - 1ull;
+      const float ak = ug_readlane_f(alpha, k);
+      if (lane == k) {
+        myT = T_cum;
+        myW = T_cum * ak;
+      }
+      T_cum = (float)((double)T_cum * (1. - (double)ak));
+      if ((double)T_cum < 1e-3) {          // the sample that crosses keeps its weight; the ray ends here
+        stopped = true;
+        m &= (2ull << k) - 1ull;
+        keep = keep && lane <= k;
+        break;
+      }
+    }
+    if (m != 0ull) {
+      if (keep) {
+        const int64_t idx = slot + kept + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        s_pts[3 * idx] = px; s_pts[3 * idx + 1] = py; s_pts[3 * idx + 2] = pz;
+        s_dens[idx] = dens;
+        s_step[idx] = (MODE == 1 && !inner) ? ~j : j;
+        s_w[idx] = myW; s_T[idx] = myT;
+      }
+      kept += __popcll(m);
+      kept2 += __popcll(__ballot(keep && myW > a.thres));
+    }
+  }
+  if (lane == 0) {
+    count[ray] = kept;
+    count2[ray] = kept2;
+    alphainv_last[ray] = T_cum;
+  }
+}
+
 // after the two cumsums: one wave per ray copies its slot to the ray-major arrays of stage 1 (M1 samples: what the backward
 // walks) and of stage 2 (M2 samples above the weight threshold: what the k0 lookup, the rgbnet and the loss consume);
 // pos2[i] = the stage-2 index of stage-1 sample i or -1
@@ -367,7 +527,8 @@ k_train_compact2(int64_t n_rays, int32_t S, float shift, float interval, float t
                  const int32_t *__restrict__ count2, const int64_t *__restrict__ end2, const float *__restrict__ t_table,
                  float *__restrict__ pts1, float *__restrict__ dens1, float *__restrict__ w1, float *__restrict__ T1,
                  int32_t *__restrict__ pos2, float *__restrict__ pts2, float *__restrict__ dens2, float *__restrict__ alpha2,
-                 float *__restrict__ w2, int64_t *__restrict__ ray_id2, int64_t *__restrict__ step_id2, float *__restrict__ tt2) {
+                 float *__restrict__ w2, int64_t *__restrict__ ray_id2, int64_t *__restrict__ step_id2, float *__restrict__ tt2,
+                 uint8_t *__restrict__ inner2) {
   const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (ray >= n_rays) return;
   const int lane = ug_lane();
@@ -379,9 +540,11 @@ k_train_compact2(int64_t n_rays, int32_t S, float shift, float interval, float t
     const bool on = i < n;
     float px = 0.f, py = 0.f, pz = 0.f, dn = 0.f, w = 0.f;
     int st = 0;
+    bool inr = true;
     if (on) {
       px = s_pts[3 * (src + i)]; py = s_pts[3 * (src + i) + 1]; pz = s_pts[3 * (src + i) + 2];
       dn = s_dens[src + i]; w = s_w[src + i]; st = s_step[src + i];
+      if (st < 0) { st = ~st; inr = false; }      // k_train_march_vox<1>: a contracted sample
       pts1[3 * (d1 + i)] = px; pts1[3 * (d1 + i) + 1] = py; pts1[3 * (d1 + i) + 2] = pz;
       dens1[d1 + i] = dn; w1[d1 + i] = w; T1[d1 + i] = s_T[src + i];
     }
@@ -397,7 +560,8 @@ k_train_compact2(int64_t n_rays, int32_t S, float shift, float interval, float t
       w2[o] = w;
       ray_id2[o] = ray;
       step_id2[o] = st;
-      tt2[o] = t_table[st];
+      tt2[o] = t_table ? t_table[st] : (float)st;
+      if (inner2) inner2[o] = inr ? 1 : 0;
     }
     d2 += __popcll(m);
   }
@@ -527,7 +691,87 @@ extern "C" int ugrid_train_sample_compact(int64_t n_rays, int32_t n_samples, flo
   if (n_rays <= 0) return 0;
   hipLaunchKernelGGL(k_train_compact2, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), n_rays, n_samples, act_shift, interval,
                      thres, scratch_pts, scratch_density, scratch_step, scratch_w, scratch_T, count, offset_end, count2, offset_end2,
-                     t_table, pts1, density1, weights1, T1, pos2, pts2, density2, alpha2, weights2, ray_id2, step_id2, t2);
+                     t_table, pts1, density1, weights1, T1, pos2, pts2, density2, alpha2, weights2, ray_id2, step_id2, t2,
+                     (uint8_t *)nullptr);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+static int ug_fill_train_vox(ug_train_vox *v, const uint8_t *mask, const int32_t *mask_dims3, const float *xyz2ijk_scale3,
+                             const float *xyz2ijk_shift3) {
+  if (!mask || !mask_dims3 || !xyz2ijk_scale3 || !xyz2ijk_shift3) return (int)hipErrorInvalidValue;
+  v->mask = mask;
+  v->mi = mask_dims3[0]; v->mj = mask_dims3[1]; v->mk = mask_dims3[2];
+  v->sx = xyz2ijk_scale3[0]; v->sy = xyz2ijk_scale3[1]; v->sz = xyz2ijk_scale3[2];
+  v->hx = xyz2ijk_shift3[0]; v->hy = xyz2ijk_shift3[1]; v->hz = xyz2ijk_shift3[2];
+  v->dist_thres = 0.f; v->near = 0.f; v->far = 0.f; v->stepdist = 1.f;
+  return 0;
+}
+
+extern "C" int ugrid_train_sample_dcvgo(const float *density_grid, int X, int Y, int Z, const float *rays_o, const float *rays_d,
+                                        int64_t n_rays, const float *t_table, int32_t n_samples, const float *scene_center3,
+                                        const float *scene_radius3, const float *xyz_min, const float *xyz_max, double bg_len,
+                                        int norm_l2, float dist_thres, const uint8_t *mask, const int32_t *mask_dims3,
+                                        const float *xyz2ijk_scale3, const float *xyz2ijk_shift3, float act_shift, float interval,
+                                        float thres, float *scratch_pts, float *scratch_density, int32_t *scratch_step,
+                                        float *scratch_w, float *scratch_T, int32_t *count, int32_t *count2, float *alphainv_last,
+                                        ugrid_stream_t s) {
+  if (n_rays <= 0) return 0;
+  if (n_samples <= 0 || !scratch_w || !scratch_T || !count2 || !alphainv_last || !t_table) return (int)hipErrorInvalidValue;
+  ug_train_vox v;
+  const int rc = ug_fill_train_vox(&v, mask, mask_dims3, xyz2ijk_scale3, xyz2ijk_shift3);
+  if (rc) return rc;
+  v.dist_thres = dist_thres;
+  ug_train_args a;
+  a.n_rays = n_rays; a.S = n_samples; a.P = 1; a.F = 0; a.X = X; a.Y = Y; a.Z = Z; a.norm_l2 = norm_l2;
+  a.cx = scene_center3[0]; a.cy = scene_center3[1]; a.cz = scene_center3[2];
+  a.rx = scene_radius3[0]; a.ry = scene_radius3[1]; a.rz = scene_radius3[2];
+  const double Bd = 1.0 + bg_len;
+  a.B = (float)Bd; a.A = (float)bg_len;       // dcvgo.py:261: (1 + bg_len) - bg_len / norm
+  a.shift = act_shift; a.interval = interval; a.thres = thres;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_train_march_vox<1>), dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), a, v, density_grid,
+                     rays_o, rays_d, t_table, xyz_min, xyz_max, scratch_pts, scratch_density, scratch_step, count, scratch_w, scratch_T,
+                     count2, alphainv_last);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ugrid_train_sample_dvgo(const float *density_grid, int X, int Y, int Z, const float *rays_o, const float *rays_d,
+                                       int64_t n_rays, int32_t slots_per_ray, const float *xyz_min, const float *xyz_max, float near,
+                                       float far, float stepdist, const uint8_t *mask, const int32_t *mask_dims3,
+                                       const float *xyz2ijk_scale3, const float *xyz2ijk_shift3, float act_shift, float interval,
+                                       float thres, float *scratch_pts, float *scratch_density, int32_t *scratch_step,
+                                       float *scratch_w, float *scratch_T, int32_t *count, int32_t *count2, float *alphainv_last,
+                                       ugrid_stream_t s) {
+  if (n_rays <= 0) return 0;
+  if (slots_per_ray <= 0 || !(stepdist > 0.f) || !scratch_w || !scratch_T || !count2 || !alphainv_last) return (int)hipErrorInvalidValue;
+  ug_train_vox v;
+  const int rc = ug_fill_train_vox(&v, mask, mask_dims3, xyz2ijk_scale3, xyz2ijk_shift3);
+  if (rc) return rc;
+  v.near = near; v.far = far; v.stepdist = stepdist;
+  ug_train_args a;
+  a.n_rays = n_rays; a.S = slots_per_ray; a.P = 1; a.F = 0; a.X = X; a.Y = Y; a.Z = Z; a.norm_l2 = 0;
+  a.cx = a.cy = a.cz = 0.f; a.rx = a.ry = a.rz = 1.f; a.B = 1.f; a.A = 0.f;
+  a.shift = act_shift; a.interval = interval; a.thres = thres;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_train_march_vox<2>), dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), a, v, density_grid,
+                     rays_o, rays_d, (const float *)nullptr, xyz_min, xyz_max, scratch_pts, scratch_density, scratch_step, count, scratch_w,
+                     scratch_T, count2, alphainv_last);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int ugrid_train_sample_compact_vox(int64_t n_rays, int32_t slots_per_ray, float act_shift, float interval, float thres,
+                                              const float *scratch_pts, const float *scratch_density, const int32_t *scratch_step,
+                                              const float *scratch_w, const float *scratch_T, const int32_t *count,
+                                              const int64_t *offset_end, const int32_t *count2, const int64_t *offset_end2,
+                                              const float *t_table, float *pts1, float *density1, float *weights1, float *T1,
+                                              int32_t *pos2, float *pts2, float *density2, float *alpha2, float *weights2,
+                                              int64_t *ray_id2, int64_t *step_id2, float *t2, uint8_t *inner2, ugrid_stream_t s) {
+  if (n_rays <= 0) return 0;
+  hipLaunchKernelGGL(k_train_compact2, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), n_rays, slots_per_ray, act_shift,
+                     interval, thres, scratch_pts, scratch_density, scratch_step, scratch_w, scratch_T, count, offset_end, count2,
+                     offset_end2, t_table, pts1, density1, weights1, T1, pos2, pts2, density2, alpha2, weights2, ray_id2, step_id2, t2,
+                     inner2);
   UG_LAUNCH_CHECK();
   return 0;
 }

@@ -238,6 +238,117 @@ class TrainSample(torch.autograd.Function):
         return (grad_grid,) + (None,) * 13
 
 
+class TrainSampleVox(torch.autograd.Function):
+    """TrainSample for the reference's two dense-grid models: the sampling of DirectContractedVoxGO.forward (dcvgo.py:228-330,
+    cfg['mode'] == 'dcvgo') and of DirectVoxGO.forward (dvgo.py:306-375, 'dvgo') as one march + one compaction
+    (include/ugrid_hip.h: ugrid_train_sample_dcvgo / _dvgo / _compact_vox), differentiable in the density grid through
+    `weights`, `alphainv_last` and the raw `density` output -- the backward is TrainSample's (ugrid_train_sample_backward +
+    the lookup's scatter).
+
+    forward(grid [1,1,X,Y,Z], rays_o [R,3], rays_d [R,3], t [S] or None, xyz_min, xyz_max, mask [mi,mj,mk] bool, cfg) ->
+        pts [M2,3], density [M2], alpha [M2], weights [M2], alphainv_last [R], ray_id [M2] i64, step_id [M2] i64, t [M2]
+        (dvgo: float(step_id)), inner [M2] bool (dvgo: all True)
+    cfg (host values): mode, act_shift, interval, thres, mask_scale[3], mask_shift[3] and
+        dcvgo: scene_center[3], scene_radius[3], bg_len, norm_l2, dist_thres;   dvgo: near, far, stepdist, slots"""
+    _scratch = {}
+
+    @staticmethod
+    def forward(ctx, grid, rays_o, rays_d, t, xyz_min, xyz_max, mask, cfg):
+        import ctypes
+        _lib.wait_pending(grid)
+        _lib.require_cuda(("grid", grid), ("rays_o", rays_o), ("rays_d", rays_d), ("xyz_min", xyz_min), ("xyz_max", xyz_max), ("mask", mask))
+        _lib.require_f32(("grid", grid), ("rays_o", rays_o), ("rays_d", rays_d))
+        if grid.dim() != 5 or grid.shape[0] != 1 or grid.shape[1] != 1 or not grid.is_contiguous():
+            raise RuntimeError("density grid must be a contiguous [1,1,X,Y,Z]")
+        if mask.dtype != torch.bool or mask.dim() != 3 or not mask.is_contiguous():
+            raise RuntimeError("mask must be a contiguous bool [mi,mj,mk]")
+        mode = cfg['mode']
+        _, _, X, Y, Z = grid.shape
+        R = rays_o.shape[0]
+        if mode == 'dcvgo':
+            _lib.require_cuda(("t", t))
+            _lib.require_f32(("t", t))
+            S = t.numel()
+        elif mode == 'dvgo':
+            S = int(cfg['slots'])
+        else:
+            raise ValueError(mode)
+        dev = grid.device
+        key = (dev, R * S)
+        sc = TrainSampleVox._scratch.get(key)
+        if sc is None:
+            TrainSampleVox._scratch.clear()          # one ray-batch shape at a time: 32 B per (ray, slot)
+            sc = (torch.empty(R * S, 3, device=dev), torch.empty(R * S, device=dev), torch.empty(R * S, dtype=torch.int32, device=dev),
+                  torch.empty(R * S, device=dev), torch.empty(R * S, device=dev))
+            TrainSampleVox._scratch[key] = sc
+        counts = torch.empty(2, R, dtype=torch.int32, device=dev)
+        ainv = torch.empty(R, device=dev)
+        f3 = lambda v: (ctypes.c_float * 3)(*[float(x) for x in v])
+        md = (ctypes.c_int32 * 3)(*[int(x) for x in mask.shape])
+        ms, mh = f3(cfg['mask_scale']), f3(cfg['mask_shift'])
+        vp = lambda a: ctypes.cast(a, ctypes.c_void_p)
+        shift, interval, thres = float(cfg['act_shift']), float(cfg['interval']), float(cfg['thres'])
+        with _lib.guard(dev):
+            st = _lib.stream_of(grid)
+            if mode == 'dcvgo':
+                c3, r3 = f3(cfg['scene_center']), f3(cfg['scene_radius'])
+                _lib.check(_L.ugrid_train_sample_dcvgo(
+                    _lib.ptr(grid), X, Y, Z, _lib.ptr(rays_o), _lib.ptr(rays_d), R, _lib.ptr(t), S, vp(c3), vp(r3), _lib.ptr(xyz_min),
+                    _lib.ptr(xyz_max), float(cfg['bg_len']), int(bool(cfg['norm_l2'])), float(cfg['dist_thres']), _lib.ptr(mask), vp(md),
+                    vp(ms), vp(mh), shift, interval, thres, *[_lib.ptr(x) for x in sc], _lib.ptr(counts[0]), _lib.ptr(counts[1]),
+                    _lib.ptr(ainv), st), "train_sample_dcvgo")
+            else:
+                _lib.check(_L.ugrid_train_sample_dvgo(
+                    _lib.ptr(grid), X, Y, Z, _lib.ptr(rays_o), _lib.ptr(rays_d), R, S, _lib.ptr(xyz_min), _lib.ptr(xyz_max),
+                    float(cfg['near']), float(cfg['far']), float(cfg['stepdist']), _lib.ptr(mask), vp(md), vp(ms), vp(mh), shift,
+                    interval, thres, *[_lib.ptr(x) for x in sc], _lib.ptr(counts[0]), _lib.ptr(counts[1]), _lib.ptr(ainv), st),
+                    "train_sample_dvgo")
+            off = torch.cumsum(counts, 1, dtype=torch.int64)            # [2,R] inclusive
+            M1, M2 = (int(x) for x in off[:, -1].tolist()) if R > 0 else (0, 0)     # the one host read
+            pts1, dens1, w1, T1 = torch.empty(M1, 3, device=dev), torch.empty(M1, device=dev), torch.empty(M1, device=dev), \
+                torch.empty(M1, device=dev)
+            pos2 = torch.empty(M1, dtype=torch.int32, device=dev)
+            pts2, dens2, alpha2, w2, tt2 = torch.empty(M2, 3, device=dev), torch.empty(M2, device=dev), torch.empty(M2, device=dev), \
+                torch.empty(M2, device=dev), torch.empty(M2, device=dev)
+            ray2, step2 = torch.empty(M2, dtype=torch.int64, device=dev), torch.empty(M2, dtype=torch.int64, device=dev)
+            inner2 = torch.ones(M2, dtype=torch.bool, device=dev)
+            if M1 > 0:
+                _lib.check(_L.ugrid_train_sample_compact_vox(
+                    R, S, shift, interval, thres, *[_lib.ptr(x) for x in sc], _lib.ptr(counts[0]), _lib.ptr(off[0]), _lib.ptr(counts[1]),
+                    _lib.ptr(off[1]), _lib.ptr(t) if mode == 'dcvgo' else None, _lib.ptr(pts1), _lib.ptr(dens1), _lib.ptr(w1),
+                    _lib.ptr(T1), _lib.ptr(pos2), _lib.ptr(pts2), _lib.ptr(dens2), _lib.ptr(alpha2), _lib.ptr(w2), _lib.ptr(ray2),
+                    _lib.ptr(step2), _lib.ptr(tt2), _lib.ptr(inner2) if mode == 'dcvgo' else None, st), "train_sample_compact_vox")
+        ctx.save_for_backward(pts1, dens1, w1, T1, pos2, counts, off, ainv, xyz_min, xyz_max)
+        ctx.shape, ctx.consts = tuple(grid.shape), (shift, interval)
+        ctx.pool_key, ctx.grid_stride = _gradpool.key_of(grid), tuple(grid.stride())
+        ctx.mark_non_differentiable(pts2, alpha2, ray2, step2, tt2, inner2)
+        return pts2, dens2, alpha2, w2, ainv, ray2, step2, tt2, inner2
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_pts, g_dens2, g_alpha, g_w2, g_ainv, g_ray, g_step, g_t, g_inner):
+        pts1, dens1, w1, T1, pos2, counts, off, ainv, xyz_min, xyz_max = ctx.saved_tensors
+        P, C, X, Y, Z = ctx.shape
+        dev = pts1.device
+        grad_grid = _gradpool.take(ctx.pool_key, ctx.shape, ctx.grid_stride, dev)
+        if grad_grid is None:
+            grad_grid = torch.zeros(ctx.shape, dtype=torch.float32, device=dev)
+        M1, R = pts1.shape[0], ainv.shape[0]
+        if M1 > 0:
+            f32 = lambda g: None if g is None else g.to(torch.float32).contiguous()
+            g_dens2, g_w2, g_ainv = f32(g_dens2), f32(g_w2), f32(g_ainv)
+            g1 = torch.empty(M1, 1, device=dev)
+            with _lib.guard(dev):
+                st = _lib.stream_of(pts1)
+                _lib.check(_L.ugrid_train_sample_backward(R, ctx.consts[0], ctx.consts[1], _lib.ptr(dens1), _lib.ptr(w1), _lib.ptr(T1),
+                                                          _lib.ptr(pos2), _lib.ptr(counts[0]), _lib.ptr(off[0]), _lib.ptr(ainv),
+                                                          _lib.ptr(g_w2), _lib.ptr(g_ainv), _lib.ptr(g_dens2), _lib.ptr(g1), st),
+                           "train_sample_backward")
+                _lib.check(_L.ugrid_grid_query_backward(_lib.ptr(g1), P, C, X, Y, Z, _lib.ptr(pts1), _lib.ptr(xyz_min), _lib.ptr(xyz_max),
+                                                        0, M1, _lib.ptr(grad_grid), st), "grid_query_backward")
+        return (grad_grid,) + (None,) * 7
+
+
 def create_grid(type, **kwargs):
     if type == 'DenseGrid':
         return FourierGrid(**kwargs)

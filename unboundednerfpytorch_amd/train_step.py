@@ -28,8 +28,11 @@ def maybe_scale_grids(model, optimizer, cfg_train, cfg_model, global_step, **opt
     if global_step not in pg:
         return optimizer
     rest = len(pg) - pg.index(global_step) - 1
-    model.scale_volume_grid(int(_get(cfg_model, 'num_voxels_density') / (2 ** rest)),
-                            int(_get(cfg_model, 'num_voxels_rgb') / (2 ** rest)))
+    if hasattr(model, 'num_voxels_density'):
+        model.scale_volume_grid(int(_get(cfg_model, 'num_voxels_density') / (2 ** rest)),
+                                int(_get(cfg_model, 'num_voxels_rgb') / (2 ** rest)))
+    else:       # voxgo_model.DirectVoxGO / DirectContractedVoxGO: one resolution for both grids (run_train.py:190-196)
+        model.scale_volume_grid(int(_get(cfg_model, 'num_voxels') / (2 ** rest)))
     optimizer = create_optimizer_or_freeze_model(model, cfg_train, global_step=0, **optimizer_kw)
     model.act_shift -= _get(cfg_train, 'decay_after_scale', 0.0)
     return optimizer
