@@ -290,7 +290,8 @@ __device__ __forceinline__ float ug_train_point(const ug_train_args &a, float ox
   px = ox + dx * t; py = oy + dy * t; pz = oz + dz * t;
   const float nrm = a.norm_l2 ? ug_norm3_torch(px, py, pz) : fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz)));
   if (!(nrm <= 1.0f)) {
-    const float sc = a.B - a.A / nrm;
+    // `bg_len / norm` with a Python number on the left is torch's Tensor.__rtruediv__ = reciprocal(norm) * bg_len: two roundings
+    const float sc = a.B - (1.0f / nrm) * a.A;
     px = px / nrm * sc; py = py / nrm * sc; pz = pz / nrm * sc;
   }
   return nrm;
@@ -337,7 +338,7 @@ k_train_march(ug_train_args a, const float *__restrict__ grid, const float *__re
       px = ox + dx * t; py = oy + dy * t; pz = oz + dz * t;
       const float nrm = a.norm_l2 ? ug_norm3_torch(px, py, pz) : fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz)));
       if (!(nrm <= 1.0f)) {
-        const float sc = a.B - a.A / nrm;
+        const float sc = a.B - (1.0f / nrm) * a.A;      // `A / norm` = reciprocal(norm) * A in torch (ug_contract)
         px = px / nrm * sc; py = py / nrm * sc; pz = pz / nrm * sc;
       }
       const float ux = ug_unorm(px, lox, hix), uy = ug_unorm(py, loy, hiy), uz = ug_unorm(pz, loz, hiz);

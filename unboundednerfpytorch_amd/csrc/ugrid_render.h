@@ -46,12 +46,13 @@ __device__ __forceinline__ float ug_norm3_torch(float x, float y, float z) {
   return sqrtf(fmaf(z, z, fmaf(y, y, x * x)));
 }
 
-// FourierGrid_model.py:534-548: p/|p| * ((1+bg) - bg/|p|) outside the unit cube (inf) / ball (l2)
+// FourierGrid_model.py:534-548: p/|p| * ((1+bg) - bg/|p|) outside the unit cube (inf) / ball (l2).  `A / norm` with a Python
+// number on the left is torch's Tensor.__rtruediv__ = reciprocal(norm) * A -- two roundings, formed the same way here
 template <bool L2>
 __device__ __forceinline__ ug_vec3 ug_contract(ug_vec3 p, float B, float A) {
   const float nrm = L2 ? ug_norm3_torch(p.x, p.y, p.z) : fmaxf(fabsf(p.x), fmaxf(fabsf(p.y), fabsf(p.z)));
   if (!(nrm <= 1.0f)) {
-    const float sc = B - A / nrm;
+    const float sc = B - (1.0f / nrm) * A;
     p.x = p.x / nrm * sc;
     p.y = p.y / nrm * sc;
     p.z = p.z / nrm * sc;
@@ -282,7 +283,7 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
       // UG_LIBM_SINCOS / UG_LIBM_ALPHA = the device libm instead of ugrid_math.h, UG_CORNER_SUM (ug_density_level)
 #ifdef UG_EXACT_DIV
       if (!(nrm <= 1.0f)) {
-        const float sc = a.B - a.A / nrm;
+        const float sc = a.B - (1.0f / nrm) * a.A;
         px = px / nrm * sc; py = py / nrm * sc; pz = pz / nrm * sc;
       }
       const float ux = ((px - a.lox) / a.ex) * 2.f - 1.f;
@@ -291,7 +292,7 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
 #else
       if (!(nrm <= 1.0f)) {
         const float rn = ug_rcp_refined(nrm);
-        const float sc = a.B - ug_div_r(a.A, nrm, rn);
+        const float sc = a.B - rn * a.A;       // reciprocal(norm) * A, as torch evaluates `A / norm` (ug_contract above)
         px = ug_div_r(px, nrm, rn) * sc;
         py = ug_div_r(py, nrm, rn) * sc;
         pz = ug_div_r(pz, nrm, rn) * sc;

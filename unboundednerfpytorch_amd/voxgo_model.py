@@ -142,7 +142,7 @@ class _VoxGOBase(nn.Module):
             return torch.sigmoid(k0)
         e = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
         emb = torch.cat([viewdirs, e.sin(), e.cos()], -1).flatten(0, -2)[ray_id]
-        k0_view = k0[:, 3:] if residual else k0
+        k0_view = k0[:, 3:].contiguous() if residual else k0
         lin = _ops.rgbnet_linears(self.rgbnet) if (self.fused_rgbnet and k0.is_cuda and torch.is_grad_enabled()) else None
         if lin is not None:
             logits = _ops.FusedRgbnet.apply(k0_view, emb, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight, lin[2].bias)
