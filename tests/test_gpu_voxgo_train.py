@@ -243,3 +243,35 @@ def test_train_iteration_drives_the_voxgo_models(kind):
     assert losses[-1] < losses[3], losses
     for k, p in m.named_parameters():
         assert bool(torch.isfinite(p).all()), k
+
+
+@pytest.mark.gpu
+def test_dcvgo_fused_loss_equals_the_composed_loss():
+    """DirectContractedVoxGO with the training tail as one op (ops.RenderLoss, what train_iteration selects) vs the torch chain of
+    train_step.training_loss on the model's return dict: the same loss and the same gradients -- distortion, entropy, rgbper and
+    the bg = 1 background included"""
+    from unboundednerfpytorch_amd import train_step as ts
+    from unboundednerfpytorch_amd.ops import loss_coefficients
+    dev = torch.device("cuda", 0)
+    m, name, (o, d, v), kw, R, seed = build("dcvgo", synth.DCVGO_CASES[0], dev)
+    target = torch.from_numpy(synth.uniform(seed + 5, R * 3).reshape(R, 3)).to(dev)
+    cfg = dict(weight_main=1.0, weight_entropy_last=0.01, weight_rgbper=0.02, weight_distortion=0.05, weight_nearclip=0.0)
+    rk = {k: kw[k] for k in kw if k != "render_depth"}
+    res = {}
+    for fused in (True, False):
+        m.zero_grad(set_to_none=True)
+        if fused:
+            coef = loss_coefficients(cfg, R, m.sample_table(rk["stepsize"], dev).numel(), None, 1)
+            out = m(o, d, v, global_step=1, is_train=True, fused_loss={'target': target, 'coef': coef}, **rk)
+            loss = out["loss"]
+        else:
+            out = m(o, d, v, global_step=1, is_train=True, **rk)
+            loss, _ = ts.training_loss(out, target, cfg, R)
+        loss.backward()
+        res[fused] = (float(loss), out["rgb_marched"].detach(), {k: p.grad.clone() for k, p in m.named_parameters()})
+    assert abs(res[True][0] - res[False][0]) <= 2e-6 * abs(res[False][0]), (res[True][0], res[False][0])
+    assert float((res[True][1] - res[False][1]).abs().max()) <= 2e-6
+    for k in res[True][2]:
+        ga, gb = res[True][2][k], res[False][2][k]
+        scale = float(gb.abs().max()) + 1e-20
+        assert float((ga - gb).abs().max()) <= 2e-4 * scale, (k, float((ga - gb).abs().max()) / scale)

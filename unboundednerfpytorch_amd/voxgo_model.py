@@ -136,19 +136,22 @@ class _VoxGOBase(nn.Module):
     def _can_fuse(self, rays_o):
         return self.fused_forward and self.fast_color_thres > 0 and rays_o.is_cuda
 
+    def _logits(self, k0_view, viewdirs, ray_id):
+        """rgbnet([k0, view embedding]) of the surviving samples: the fp32-MFMA kernels for the default 3-layer net while training"""
+        e = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
+        emb = torch.cat([viewdirs, e.sin(), e.cos()], -1).flatten(0, -2)[ray_id]
+        lin = _ops.rgbnet_linears(self.rgbnet) if (self.fused_rgbnet and k0_view.is_cuda and torch.is_grad_enabled()) else None
+        if lin is not None:
+            return _ops.FusedRgbnet.apply(k0_view, emb, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight, lin[2].bias)
+        return self.rgbnet(torch.cat([k0_view, emb], -1))
+
     def _colour(self, k0, viewdirs, ray_id, residual):
         """rgb of the surviving samples (dvgo.py:377-398, dcvgo.py:332-344)"""
         if self.rgbnet is None:
             return torch.sigmoid(k0)
-        e = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
-        emb = torch.cat([viewdirs, e.sin(), e.cos()], -1).flatten(0, -2)[ray_id]
-        k0_view = k0[:, 3:].contiguous() if residual else k0
-        lin = _ops.rgbnet_linears(self.rgbnet) if (self.fused_rgbnet and k0.is_cuda and torch.is_grad_enabled()) else None
-        if lin is not None:
-            logits = _ops.FusedRgbnet.apply(k0_view, emb, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight, lin[2].bias)
-        else:
-            logits = self.rgbnet(torch.cat([k0_view, emb], -1))
-        return torch.sigmoid(logits + k0[:, :3]) if residual else torch.sigmoid(logits)
+        if residual:
+            return torch.sigmoid(self._logits(k0[:, 3:].contiguous(), viewdirs, ray_id) + k0[:, :3])
+        return torch.sigmoid(self._logits(k0, viewdirs, ray_id))
 
 
 class DirectVoxGO(_VoxGOBase):
@@ -302,6 +305,7 @@ class DirectVoxGO(_VoxGOBase):
 
 class DirectContractedVoxGO(_VoxGOBase):
     """The contracted-unbounded model (dcvgo.py:27-384)."""
+    fused_loss = True           # train_step.train_iteration: compositing + loss as ops.RenderLoss (the losses of run_train.py:254-279)
 
     def __init__(self, xyz_min, xyz_max, num_voxels=0, num_voxels_base=0, alpha_init=None, mask_cache_world_size=None,
                  fast_color_thres=0, bg_len=0.2, contracted_norm='inf', density_type='DenseGrid', k0_type='DenseGrid',
@@ -427,6 +431,20 @@ class DirectContractedVoxGO(_VoxGOBase):
         k0 = self.k0(pts)
         if k0.dim() == 1:
             k0 = k0.unsqueeze(-1)
+        fused_loss = render_kwargs.get('fused_loss')
+        if fused_loss is not None and self.rgbnet is not None and k0.is_cuda:
+            # training tail as ONE op (ops.RenderLoss): sigmoid, compositing, background and the loss terms of run_train.py:254-279
+            # (train_step.train_iteration passes fused_loss = {'target': [N,3], 'coef': ops.loss_coefficients(...)})
+            logits = self._logits(k0, viewdirs, ray_id)
+            if render_kwargs.get('rand_bkgd', False) and is_train:
+                bg = torch.rand(N, 3, device=dev)
+            else:
+                bg = torch.full((N, 3), float(render_kwargs['bg']), device=dev) if float(render_kwargs['bg']) != 0.0 else None
+            loss, mse, rgb_marched = _ops.RenderLoss.apply(logits, weights, alphainv_last, density, ray_id, tt, None,
+                                                           fused_loss['target'], bg, fused_loss['coef'])
+            return {'alphainv_last': alphainv_last, 'weights': weights, 'rgb_marched': rgb_marched, 'raw_density': density,
+                    'raw_alpha': alpha, 'raw_logits': logits, 'ray_id': ray_id, 'step_id': step_id, 'n_max': n_max, 't': tt,
+                    'loss': loss, 'mse': mse}
         rgb = self._colour(k0, viewdirs, ray_id, residual=False)
         rgb_marched = torch.zeros(N, 3, device=dev).index_add_(0, ray_id, weights.unsqueeze(-1) * rgb)
         if render_kwargs.get('rand_bkgd', False) and is_train:
