@@ -196,7 +196,7 @@ def test_product_kernels_fit_their_register_budget_without_scratch(lib_path):
         ks = [k for k in meta if k.startswith(prefix)]
         assert ks, prefix
         return ks
-    budget = {"_Z7k_marchILi": 80, "_Z11k_shade_mlpILi": 256, "_Z10k_shade_pcILi": 256, "_Z14k_shade_direct": 128, "_Z13k_train_march": 128,
+    budget = {"_Z7k_marchILi": 80, "_Z11k_shade_mlpILi": 256, "_Z10k_shade_pcILi": 256, "_Z12k_shade_pc48ILi": 168, "_Z10k_view_embILi": 64, "_Z17k_train_march_voxILi": 128, "_Z14k_shade_direct": 128, "_Z13k_train_march": 128,
               "_Z15k_train_compact": 64, "_Z12k_grid_queryILb": 64, "_Z21k_grid_query_backwardILb": 64, "_Z12k_tv_cl_vec4ILb": 64,
               "_Z14k_tv_adam_vec4ILb": 64, "_Z9k_tv_vec4ILb": 64, "_Z11k_adam_vec4ILi": 64, "_Z17k_render_loss_fwd": 64,
               "_Z17k_render_loss_bwd": 64, "_Z14k_alpha2weight": 64, "_Z18k_alpha2weight_bwd": 64, "_Z16k_rays_of_a_view": 64,

@@ -147,7 +147,7 @@ def test_fused_sampling_equals_the_op_by_op_chain(kind, case):
             assert torch.equal(a[k], b[k]), k
     # DirectVoxGO: bit-equal.  DirectContractedVoxGO: the op-by-op chain normalises the ray directions (and takes the l2 norm of
     # the points) with torch-ROCm's `norm`, whose sqrt is NOT correctly rounded on this build (15 % of results one ulp away from
-    # torch's CPU / CUDA kernels, tools/scratch/diag_torch_ops.py); the kernel uses the correctly rounded one, like the goldens
+    # torch's CPU / CUDA kernels, tools/diag_torch_ops.py); the kernel uses the correctly rounded one, like the goldens
     # of the reference -- so a few samples' points differ by an ulp there and the values agree to ~1e-6 instead of bit for bit
     exact = kind == "dvgo"
     for k in ("weights", "raw_alpha", "raw_density", "alphainv_last"):

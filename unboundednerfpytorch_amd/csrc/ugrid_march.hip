@@ -851,7 +851,8 @@ k_march_dvgo(ug_march_args a, ug_dv_args dv, const float *__restrict__ rays_o, c
 // ----------------------------------------------------------------------------------------------
 extern "C" int64_t ugrid_render_ws_bytes(int64_t n_rays, int32_t S) {
   const int64_t n_tiles = (n_rays + UG_WAVE - 1) / UG_WAVE, cap = (int64_t)UG_WAVE * S;
-  return 256 + ug_align256(n_tiles * 4) + ug_align256(n_tiles * cap * 16) + ug_align256(n_tiles * cap);
+  return 256 + ug_align256(n_tiles * 4) + ug_align256(n_tiles * cap * 16) + ug_align256(n_tiles * cap) +
+         ug_align256(n_tiles * UG_WAVE * UG_EMB_ROW * (int64_t)sizeof(float));
 }
 
 static int ug_grid_query_any(bool cl, const float *grid, int P, int C, int X, int Y, int Z, const float *xyz,

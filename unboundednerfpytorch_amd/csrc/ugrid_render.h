@@ -139,8 +139,10 @@ struct ug_ws_view {
   int32_t *count;   // [n_tiles]
   float4 *ent;      // [n_tiles][64*S]  (px, py, pz, weight)
   uint8_t *slot;    // [n_tiles][64*S]  ray slot (0..63) inside the tile
+  float *emb;       // [n_tiles*64][32] view-direction embedding rows (k_view_emb; the 4 + 8 shade geometry reads them from here)
   int64_t n_tiles, cap;
 };
+#define UG_EMB_ROW 32      // floats per ray: two halves of 16 (14 used: v | sin | cos of FourierGrid_model.py:640-643, split like KL)
 #define UG_FEAT_STRIDE 12
 
 __host__ __device__ static inline int64_t ug_align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -155,6 +157,8 @@ static inline ug_ws_view ug_ws_make(void *ws, int64_t n_rays, int32_t S) {
   v.ent = (float4 *)b;
   b += ug_align256(v.n_tiles * v.cap * (int64_t)sizeof(float4));
   v.slot = (uint8_t *)b;
+  b += ug_align256(v.n_tiles * v.cap);
+  v.emb = (float *)b;
   return v;
 }
 

@@ -8,6 +8,9 @@ extern "C" int ugx_pc_dbg_set(int bits) { return (int)hipMemcpyToSymbol(HIP_SYMB
 
 extern "C" int ug_set_march_waves(int w);  // ugrid_march.hip
 extern "C" int ug_set_tv_xcd(int m);        // ugrid_ops.hip
+#ifndef UG_PC48_SLOTS
+#define UG_PC48_SLOTS 2      // ring slots per consumer of the 4 + 8 geometry
+#endif
 #ifndef UG_PC12_NBL
 #define UG_PC12_NBL 3        // gather items (x 6 dwordx4) in flight per producer wave of the 12-wave geometry (4 spills: A/B arm only)
 #endif
@@ -218,6 +221,71 @@ k_shade_pc(ug_shade_args a, const float *__restrict__ viewdirs, const float *__r
     float *scr = pairs + NPAIR * UG_PC_PAIR_FLOATS(SLOTS) + pair * ug_pc_consumer_scratch_floats<PE>();
     ug_pc_consumer<PE, SLOTS, MODE>(a, viewdirs, M, rgb_marched, ring, ctl, scr, pstat);
   }
+}
+
+// 4 + 8 geometry (round 4): waves 0-3 = producers (one per SIMD), waves 4-11 = consumers (two per SIMD), producer p feeds
+// consumers 2p and 2p + 1 (ug_pc_producer2).  Why: a consumer's rgbnet chain is latency-bound (12 k cycles per pass against 4.2 k
+// of matrix-pipe issue, profiles/r03/shade_pc12_phases.txt), the 6 + 6 geometry puts 1, 1, 2, 2 consumers on the four SIMDs, and
+// the gather side is bound by the CU's shared vector-memory path, not by the number of waves that issue the loads.
+template <int F, int PE, int SLOTS, int NBL>
+__global__ void __launch_bounds__(768, 1)
+k_shade_pc48(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
+             const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
+             int32_t *__restrict__ tile_counter) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int MLPF = ug_mlp_lds_floats<12, PE, 2>();
+  float *rings = lds + MLPF;
+  if (threadIdx.x < 32)             // head / tail counters of the eight rings
+    ((int *)(rings + (threadIdx.x >> 2) * UG_PC_PAIR_FLOATS(SLOTS) + SLOTS * UG_PC_SLOT_FLOATS))[threadIdx.x & 3] = 0;
+  const ug_mlp_lds M = ug_mlp_stage<12, PE, 2>(lds, mlp, a.residual);     // ends with __syncthreads()
+  const int wv = threadIdx.x >> 6;
+  if (wv < 4) {
+    float *r0 = rings + (2 * wv) * UG_PC_PAIR_FLOATS(SLOTS), *r1 = rings + (2 * wv + 1) * UG_PC_PAIR_FLOATS(SLOTS);
+    ug_pc_producer2<F, NBL, SLOTS>(a, k0b, ws, rgb_marched, tile_counter, r0, ug_lds_off(r0 + SLOTS * UG_PC_SLOT_FLOATS), r1,
+                                   ug_lds_off(r1 + SLOTS * UG_PC_SLOT_FLOATS));
+  } else {
+    // consumer c of producer p = c / 2 sits on SIMD (4 + c) % 4: the two consumers of a producer are on DIFFERENT SIMDs
+    const int c = wv - 4;
+    float *ring = rings + c * UG_PC_PAIR_FLOATS(SLOTS);
+    float *scr = rings + 8 * UG_PC_PAIR_FLOATS(SLOTS) + c * UG_ACC_SCRATCH_FLOATS;
+    ug_pc_consumer<PE, SLOTS, 2>(a, viewdirs, M, rgb_marched, ring, ug_lds_off(ring + SLOTS * UG_PC_SLOT_FLOATS), scr, nullptr, ws.emb);
+  }
+}
+
+// the view-direction embedding of every ray, once per frame: row = two halves of 16 floats, 14 used, split like the rgbnet's
+// first-layer inputs (ug_pc_consumer: emb[h * EH + e]); rays past the end repeat the last one (the consumers never publish them)
+template <int PE>
+__global__ void __launch_bounds__(256)
+k_view_emb(const float *__restrict__ viewdirs, int64_t n_rays, int64_t n_rows, float *__restrict__ emb_rows) {
+  constexpr int NEMB = 3 + 6 * PE, EH = (NEMB + 1) / 2;
+  static_assert(EH <= UG_EMB_ROW / 2, "row too small");
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= n_rows) return;
+  const int64_t ray = row < n_rays ? row : n_rays - 1;
+  const float vx = viewdirs[3 * ray], vy = viewdirs[3 * ray + 1], vz = viewdirs[3 * ray + 2];
+  float emb[UG_EMB_ROW];
+#pragma unroll
+  for (int e = 0; e < UG_EMB_ROW; ++e) emb[e] = 0.f;
+  float lin[2 * EH];
+  lin[0] = vx; lin[1] = vy; lin[2] = vz;
+#pragma unroll
+  for (int ax = 0; ax < 3; ++ax) {
+    const float v = ax == 0 ? vx : (ax == 1 ? vy : vz);
+#pragma unroll
+    for (int k = 0; k < PE; ++k) {
+      float s_, c_;
+      ug_sincos(v * (float)(1 << k), &s_, &c_);
+      lin[3 + ax * PE + k] = s_;
+      lin[3 + 3 * PE + ax * PE + k] = c_;
+    }
+  }
+#pragma unroll
+  for (int e = NEMB; e < 2 * EH; ++e) lin[e] = 0.f;
+#pragma unroll
+  for (int e = 0; e < 2 * EH; ++e) emb[(e / EH) * (UG_EMB_ROW / 2) + (e % EH)] = lin[e];
+  float4 *dst = (float4 *)(emb_rows + row * UG_EMB_ROW);
+#pragma unroll
+  for (int q = 0; q < UG_EMB_ROW / 4; ++q) dst[q] = make_float4(emb[4 * q], emb[4 * q + 1], emb[4 * q + 2], emb[4 * q + 3]);
 }
 
 #ifdef UG_EXPERIMENTS
@@ -497,7 +565,7 @@ extern "C" int ugrid_tune(const char *key, int value) {
   if (!key) return (int)hipErrorInvalidValue;
   if (!strcmp(key, "march_waves")) return ug_set_march_waves(value) ? (int)hipErrorInvalidValue : 0;
   if (!strcmp(key, "tv_xcd")) return ug_set_tv_xcd(value) ? (int)hipErrorInvalidValue : 0;
-  if (!strcmp(key, "shade_pc") && value >= 0 && value <= 2) { g_shade_pc = value; return 0; }
+  if (!strcmp(key, "shade_pc") && value >= 0 && value <= 3) { g_shade_pc = value; return 0; }
 #ifdef UG_EXPERIMENTS
   if (!strcmp(key, "shade16") && (value == 0 || value == 1)) { g_shade16 = value; return 0; }
   if (!strcmp(key, "shade_dbg") && value >= 0 && value < 4) { g_shade_dbg = value; return 0; }
@@ -539,6 +607,24 @@ static int ug_shade_pc_launch(const ug_shade_args &a, const float *viewdirs, con
   return 0;
 }
 
+template <int F, int PE, int SLOTS, int NBL>
+static int ug_shade_pc48_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
+                                ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
+  const int lds_bytes = ug_pc48_lds_bytes<PE, SLOTS>();
+  if (lds_bytes > 160 * 1024) return (int)hipErrorInvalidValue;
+  UG_SET_DYN_LDS((k_shade_pc48<F, PE, SLOTS, NBL>), lds_bytes);
+  UG_ZERO_WORDS(counter, 8, st);
+  const int64_t n_rows = ws.n_tiles * UG_WAVE;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_view_emb<PE>), dim3(ug_blocks(n_rows, 256)), dim3(256), 0, st, viewdirs, a.n_rays, n_rows, ws.emb);
+  int64_t wgs = (ws.n_tiles + 7) / 8;          // eight tile streams per workgroup
+  if (wgs > 256) wgs = 256;
+  wgs = (wgs + 7) / 8 * 8;
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_pc48<F, PE, SLOTS, NBL>), dim3((unsigned)wgs), dim3(768), lds_bytes, st,
+                     a, viewdirs, k0b, mlp, ws, rgb, counter);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
 #ifdef UG_EXPERIMENTS
 template <int F>
 static int ug_shade16_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
@@ -572,8 +658,12 @@ static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const 
     if (mlp_mode == UGRID_MLP_FP16X2) return (int)hipErrorInvalidValue;
   }
   if constexpr (C == 12 && PE <= 4) {
+    if constexpr (F <= 3 && PE == 4) {
+      if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc == 3)
+        return ug_shade_pc48_launch<F, PE, UG_PC48_SLOTS, UG_PC12_NBL>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+    }
     if constexpr (F <= 3) {      // the producers' set-up state grows with the level count: F >= 4 does not fit 168 VGPRs
-      if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc == 2)
+      if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc >= 2)
         return ug_shade_pc_launch<F, PE, 6, 2, UG_PC12_NBL, 1>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
     }
     if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc >= 1)

@@ -55,6 +55,12 @@ __host__ __device__ static inline int ug_pc_lds_bytes() {
   return (int)sizeof(float) * (ug_mlp_lds_floats<12, PE, 2>() + NPAIR * UG_PC_PAIR_FLOATS(SLOTS) + NPAIR * ug_pc_consumer_scratch_floats<PE>());
 }
 
+// 4 producers + 8 consumers: rgbnet image | 8 rings | 8 x (amask | aval) -- no embedding tables (consumer MODE 2)
+template <int PE, int SLOTS>
+__host__ __device__ static inline int ug_pc48_lds_bytes() {
+  return (int)sizeof(float) * (ug_mlp_lds_floats<12, PE, 2>() + 8 * UG_PC_PAIR_FLOATS(SLOTS) + 8 * UG_ACC_SCRATCH_FLOATS);
+}
+
 // ---- LDS counters: explicit ds_ instructions on the 32-bit LDS offset (no flat_ access may sneak in: flat operations
 // count on vmcnt AND lgkmcnt and would corrupt the producers' hand-counted vmcnt waits)
 typedef __attribute__((address_space(3))) const void *ug_lds_cptr;
@@ -386,15 +392,127 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// producer wave of the 4 + 8 geometry (k_shade_pc48): ONE producer feeds TWO consumers.  It walks two independent tile streams,
+// one pass of stream 0, one pass of stream 1, ... -- each stream has its own ring, its own consumer and its own position in its
+// tile's survivor list; a consumer therefore still sees whole tiles in order (per-ray sums in sample order, as before).  The pass
+// body is ug_pc_producer's.
+// ---------------------------------------------------------------------------------------------------------------------
+struct ug_pc_stream {
+  const float *ef;            // this tile's entries (px, py, pz, w)
+  const uint8_t *slot;
+  float *ring;
+  unsigned ctl;
+  int64_t tile;
+  int count, base;            // survivors of the tile, first survivor of the NEXT pass
+  int seq, tail_seen;
+  float w_n, pg0_n, pg1_n;    // inputs of the next pass (fetched one pass ahead)
+  int sl_n;
+  bool active;
+};
+
+// claim the next non-empty tile for a stream and prefetch its first pass (empty tiles are blacked out on the spot)
+__device__ __forceinline__ void ug_pc_stream_next_tile(ug_pc_stream &st, const ug_shade_args &a, const ug_ws_view &ws,
+                                                       float *__restrict__ rgb_marched, int32_t *__restrict__ tile_counter,
+                                                       int &victim, int lane, int qs, int comp) {
+  for (;;) {
+    const int64_t tile = ug_next_tile(tile_counter, ws.n_tiles, blockIdx.x & 7, victim);
+    if (tile < 0) { st.active = false; return; }
+    const int count = ws.count[tile];
+    if (count <= 0) {
+      const int64_t ray = tile * UG_WAVE + lane;
+      if (ray < a.n_rays) { rgb_marched[3 * ray] = 0.f; rgb_marched[3 * ray + 1] = 0.f; rgb_marched[3 * ray + 2] = 0.f; }
+      continue;
+    }
+    st.tile = tile; st.count = count; st.base = 0;
+    st.ef = (const float *)(ws.ent + tile * ws.cap);
+    st.slot = ws.slot + tile * ws.cap;
+    const int e0 = min(lane & 31, count - 1), q0 = min(qs, count - 1), q1 = min(16 + qs, count - 1);
+    st.sl_n = st.slot[e0]; st.w_n = st.ef[4 * e0 + 3];
+    st.pg0_n = st.ef[4 * q0 + comp]; st.pg1_n = st.ef[4 * q1 + comp];
+    st.active = true;
+    return;
+  }
+}
+
+template <int F, int NBL, int SLOTS>
+__device__ __forceinline__ void ug_pc_producer2(const ug_shade_args &a, const float *__restrict__ k0b, const ug_ws_view &ws,
+                                                float *__restrict__ rgb_marched, int32_t *__restrict__ tile_counter,
+                                                float *ring0, unsigned ctl0, float *ring1, unsigned ctl1) {
+  const int lane = ug_lane();
+  const int qs = lane >> 2, qg = lane & 3;
+  const ug_quad_axis qa = ug_quad_axis_of(a, qg);
+  const int comp = qg < 2 ? qg : 2;
+  int victim = 0;
+  ug_pc_stream st[2];
+  st[0].ring = ring0; st[0].ctl = ctl0; st[1].ring = ring1; st[1].ctl = ctl1;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    st[i].seq = 0; st[i].tail_seen = 0; st[i].active = false;
+    ug_pc_stream_next_tile(st[i], a, ws, rgb_marched, tile_counter, victim, lane, qs, comp);
+  }
+  while (st[0].active || st[1].active) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!st[i].active) continue;
+      ug_pc_stream &S = st[i];
+      const float ww = S.w_n, pg0 = S.pg0_n, pg1 = S.pg1_n;
+      const int sl = S.sl_n, base = S.base, count = S.count;
+      {     // the pass after this one (clamped indices past the end of the list: ug_pc_producer)
+        const int e2 = min(base + 32 + (lane & 31), count - 1), q0 = min(base + 32 + qs, count - 1), q1 = min(base + 48 + qs, count - 1);
+        S.sl_n = S.slot[e2]; S.w_n = S.ef[4 * e2 + 3];
+        S.pg0_n = S.ef[4 * q0 + comp]; S.pg1_n = S.ef[4 * q1 + comp];
+      }
+      float f3[2][3];
+      {
+        ug_gather_state<F, NBL, 2> gst;
+        const float pgs[2] = {pg0, pg1};
+        ug_k0_gather_begin<F, NBL, 2>(k0b, a, qa, pgs, gst);
+        ug_k0_gather_finish<F, NBL, 2>(k0b, a, gst, f3);
+      }
+      while (S.seq - S.tail_seen >= SLOTS) {
+        S.tail_seen = ug_lds_peek(S.ctl + 4);
+        if (S.seq - S.tail_seen >= SLOTS) __builtin_amdgcn_s_sleep(2);
+      }
+      float *sp = S.ring + (S.seq % SLOTS) * UG_PC_SLOT_FLOATS;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        float *fp = sp + UG_PC_FEAT + (16 * it + qs) * 12 + 3 * qg;
+        fp[0] = f3[it][0]; fp[1] = f3[it][1]; fp[2] = f3[it][2];
+      }
+      if (lane < 32) { sp[UG_PC_W + lane] = ww; ((int *)sp)[UG_PC_SL + lane] = sl; }
+      if (lane == 0) { ((int *)sp)[UG_PC_HDR] = (int)S.tile; ((int *)sp)[UG_PC_HDR + 1] = count; ((int *)sp)[UG_PC_HDR + 2] = base; }
+      ++S.seq;
+      ug_lds_publish(S.ctl, S.seq);
+      S.base = base + 32;
+      if (S.base >= count) ug_pc_stream_next_tile(S, a, ws, rgb_marched, tile_counter, victim, lane, qs, comp);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {       // end markers
+    ug_pc_stream &S = st[i];
+    while (S.seq - S.tail_seen >= SLOTS) {
+      S.tail_seen = ug_lds_peek(S.ctl + 4);
+      if (S.seq - S.tail_seen >= SLOTS) __builtin_amdgcn_s_sleep(2);
+    }
+    if (lane == 0) ((int *)(S.ring + (S.seq % SLOTS) * UG_PC_SLOT_FLOATS))[UG_PC_HDR] = -1;
+    ++S.seq;
+    ug_lds_publish(S.ctl, S.seq);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // consumer wave
 // ---------------------------------------------------------------------------------------------------------------------
 // MODE: 0 = hand-scheduled 4-tile pass (ug_rgbnet_pass_h2), 1 = lean pass.  (A third mode -- two passes of a tile per
 // consumer wave in lock step, every weight fragment feeding two MFMAs, layer 3 of a tile behind the next tile's MFMAs, 251
 // VGPRs -- was built, verified bit-identical and measured at 4.53-4.56 ms against 4.39 ms: profiles/r03/shade_dual_pass_ab.txt.)
+// MODE 2 = the lean pass with the view-direction embedding read per survivor from the global table k_view_emb wrote (ws.emb,
+// 64 B per lane and pass through the vector-memory path) instead of a per-consumer LDS table rebuilt at every tile change: the
+// 7 KB per consumer that frees are what lets EIGHT consumers share the CU's LDS (k_shade_pc48).
 template <int PE, int SLOTS, int MODE>
 __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const float *__restrict__ viewdirs, const ug_mlp_lds &M,
                                                float *__restrict__ rgb_marched, const float *ring, unsigned ctl, float *scr,
-                                               unsigned long long *pstat) {
+                                               unsigned long long *pstat, const float *__restrict__ emb_rows = nullptr) {
   constexpr int C = 12, CH = UG_CH(C), NEMB = 3 + 6 * PE, KL = (2 * CH + NEMB + 1) / 2, EH = KL - CH;
   const int lane = ug_lane();
   const int h = lane >> 5, sv = lane & 31;
@@ -449,6 +567,25 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
     ug_lds_publish(ctl + 4, seq);     // the slot's values are in registers: hand it back before the rgbnet starts
     const bool ok = base + sv < count;
     UG_PC_T0(tt_)
+    if constexpr (MODE == 2) {
+      // this lane's half of its survivor's embedding row: 14 floats = three 16-byte loads + one 8-byte load, issued before the
+      // tile bookkeeping so that their latency overlaps it
+      static_assert(EH <= 14 || MODE != 2, "UG_EMB_ROW holds 14 floats per half");
+      const float4 *er = (const float4 *)(emb_rows + ((int64_t)tile * UG_WAVE + sl) * UG_EMB_ROW + h * (UG_EMB_ROW / 2));
+      const float4 e0 = er[0], e1 = er[1], e2 = er[2];
+      const float2 e3 = *(const float2 *)(er + 3);
+      const float ev[14] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w, e3.x, e3.y};
+#pragma unroll
+      for (int s = CH; s < KL; ++s) x[s] = ev[s - CH];
+      if (tile != cur_tile) {
+        if (cur_tile >= 0) {
+          const int64_t ray = (int64_t)cur_tile * UG_WAVE + lane;
+          if (ray < a.n_rays) { rgb_marched[3 * ray] = accr; rgb_marched[3 * ray + 1] = accg; rgb_marched[3 * ray + 2] = accb; }
+        }
+        accr = accg = accb = 0.f;
+        cur_tile = tile;
+      }
+    } else
     if (tile != cur_tile) {
 #ifdef UG_ACC_DSADD
       if constexpr (MODE == 1) {        // the sums of the finished tile sit in LDS: fetch and clear (in order behind the adds)
@@ -487,7 +624,7 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
       for (int e = 0; e < 2 * EH; ++e) embt[lane * (2 * EH) + e] = emb[e];
       ug_wave_lds_sync();
     }
-    {
+    if constexpr (MODE != 2) {
       const float *er = embt + sl * (2 * EH) + h * EH;
 #pragma unroll
       for (int s = CH; s < KL; ++s) x[s] = er[s - CH];
@@ -499,7 +636,7 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
     if (dbg_nomlp) { if (ok && h == 0 && sl == lane) { accr += x[0] * ww; accg += x[1] * ww; accb += x[KL - 1] * ww; } } else
 #endif
     {
-      if constexpr (MODE == 1) {
+      if constexpr (MODE >= 1) {
         ug_rgbnet_pass_lean<C, PE>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, prof_unused);
       } else {
         ug_rgbnet_pass_h2<C, PE, true, true>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, h2st, prof_unused);
