@@ -12,7 +12,7 @@ cp $T/pmc_summary.json $P/pmc_summary.json
 cp $T/microbench_fetch_calib.json $P/microbench_fetch_calib.json
 cp $T/s1_kernel_stats.csv $P/bench_s1_kernel_stats.csv
 tail -1 $T/bench_line.json > $P/bench_s1_line.json
-for f in bench_2rank_shared_gpu.json dcvgo_1080p.json dvgo_lego_800.json train_step_s3.jsonl pytest_gpu.log smoke.log smi_trace.json smi_trace.csv; do
+for f in bench_2rank_shared_gpu.json dcvgo_1080p.json dvgo_lego_800.json voxgo_train.jsonl voxgo_train_composed.jsonl train_step_s3.jsonl pytest_gpu.log smoke.log smi_trace.json smi_trace.csv; do
   [ -s $T/$f ] && cp $T/$f $P/$f
 done
 for f in s1_fp64_ground_truth.json train_long_parity.json s1_arbitration_s1.json s1_arbitration_s1b.json; do

@@ -52,6 +52,8 @@ import json, sys
 for l in open(sys.argv[1]):
     d = json.loads(l); print(d['tv_phase'], '%.3f ms' % d['ms_per_step'], {k: round(v, 3) for k, v in d['phases_ms'].items()}, d['survivors_M'], d.get('k0_grad_lines_touched_frac'), d.get('roofline_tv_adam_dense'))
 PY
+timeout 600 python tools/bench_voxgo_train.py --model both > $OUT/voxgo_train.jsonl 2>/dev/null; cut -c1-300 $OUT/voxgo_train.jsonl
+timeout 300 python tools/bench_voxgo_train.py --model both --fused 0 --steps 10 > $OUT/voxgo_train_composed.jsonl 2>/dev/null
 # 6. smoke + the whole -m gpu suite
 timeout 600 python __graft_entry__.py smoke 2>&1 | tail -2 | tee $OUT/smoke.log
 timeout 2700 python -m pytest tests -m gpu -q -p no:warnings 2>&1 | tail -8 | tee $OUT/pytest_gpu.log
