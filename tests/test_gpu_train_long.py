@@ -10,7 +10,8 @@ targets (a ground-truth FourierGrid model rendered by the fused renderer):
                   fused rgbnet, RenderLoss, fused TV + Adam, touched-line bitmaps, recycled gradients).
 The run crosses TWO pg_scale events (iterations 100 and 200: grids grow, the optimizer is rebuilt, act_shift drops) and the dense ->
 masked TV switch (tv_dense_before = 150).  Asserted at every logged step: |PSNR_ours - PSNR_refA| <= max(0.01 dB, 3 x |PSNR_refB -
-PSNR_refA| there, ...) on the held-out rays -- the north star's +-0.01 dB wherever the reference reproduces itself that well."""
+PSNR_refA| there, 1.5 x the largest run-to-run spread of EITHER side) on the held-out rays -- the north star's +-0.01 dB wherever
+the two programs reproduce themselves that well (this package's run is repeated too: `oursB`)."""
 import json
 import os
 import sys
@@ -80,30 +81,38 @@ def test_training_320_iterations_psnr_tracks_the_reference_on_this_gpu():
                                   eval_every=EVAL_EVERY, render_kwargs=RK)
         del m
         torch.cuda.empty_cache()
-    # ---- this package
-    torch.manual_seed(1234)
-    m = FourierGridModel(**CTOR).to(dev)
-    missing = m.load_state_dict(init, strict=False)
-    assert not missing.missing_keys and not missing.unexpected_keys, missing
-    opt = create_optimizer_or_freeze_model(m, CFG, 0)
-    ours = {"psnr_train": [], "loss": [], "eval": []}
-    for step in range(1, N_ITERS + 1):
-        opt = ts.maybe_scale_grids(m, opt, CFG, CFG_MODEL, step)
-        o, d, v, rgb = batches[step - 1]
-        loss, psnr = ts.train_iteration(m, opt, o, d, v, rgb, CFG, step, RK)
-        ours["psnr_train"].append(psnr)
-        ours["loss"].append(loss)
-        if step % EVAL_EVERY == 0 or step == N_ITERS:
-            ours["eval"].append((step, _eval_psnr(m, held)))
-    runs["ours"] = ours
+    # ---- this package, also twice: its scatter backward uses fp32 atomics too, and its own run-to-run spread is the other half of
+    # the yardstick (two runs of the SAME code cannot be expected to agree with a third party better than with each other)
+    for tag in ("ours", "oursB"):
+        torch.manual_seed(1234)
+        m = FourierGridModel(**CTOR).to(dev)
+        missing = m.load_state_dict(init, strict=False)
+        assert not missing.missing_keys and not missing.unexpected_keys, missing
+        opt = create_optimizer_or_freeze_model(m, CFG, 0)
+        ours = {"psnr_train": [], "loss": [], "eval": []}
+        for step in range(1, N_ITERS + 1):
+            opt = ts.maybe_scale_grids(m, opt, CFG, CFG_MODEL, step)
+            o, d, v, rgb = batches[step - 1]
+            loss, psnr = ts.train_iteration(m, opt, o, d, v, rgb, CFG, step, RK)
+            ours["psnr_train"].append(psnr)
+            ours["loss"].append(loss)
+            if step % EVAL_EVERY == 0 or step == N_ITERS:
+                ours["eval"].append((step, _eval_psnr(m, held)))
+        runs[tag] = ours
+        del m, opt
+        torch.cuda.empty_cache()
     rows = []
     worst = 0.0
-    for (s, a), (_, b), (_, c) in zip(runs["refA"]["eval"], runs["refB"]["eval"], runs["ours"]["eval"]):
-        rows.append({"step": s, "psnr_refA": a, "psnr_refB": b, "psnr_ours": c, "ref_spread": abs(a - b), "ours_minus_refA": c - a})
-        print("step %4d  held-out PSNR  refA %.4f  refB %.4f  ours %.4f   |refA-refB| %.4f  ours-refA %+.4f" % (s, a, b, c, abs(a - b), c - a))
+    for (s, a), (_, b), (_, c), (_, c2) in zip(runs["refA"]["eval"], runs["refB"]["eval"], runs["ours"]["eval"], runs["oursB"]["eval"]):
+        rows.append({"step": s, "psnr_refA": a, "psnr_refB": b, "psnr_ours": c, "psnr_oursB": c2, "ref_spread": abs(a - b),
+                     "ours_spread": abs(c - c2), "ours_minus_refA": c - a})
+        print("step %4d  held-out PSNR  refA %.4f  refB %.4f  ours %.4f  oursB %.4f   |refA-refB| %.4f  |ours-oursB| %.4f  ours-refA %+.4f"
+              % (s, a, b, c, c2, abs(a - b), abs(c - c2), c - a))
     spread = max(r["ref_spread"] for r in rows)
+    ours_spread = max(r["ours_spread"] for r in rows)
     res = {"iterations": N_ITERS, "rays_per_batch": N_RAND, "pg_scale": CFG["pg_scale"], "tv_dense_before": CFG["tv_dense_before"],
-           "max_ref_run_to_run_spread_db": spread, "max_abs_ours_minus_refA_db": max(abs(r["ours_minus_refA"]) for r in rows),
+           "max_ref_run_to_run_spread_db": spread, "max_ours_run_to_run_spread_db": ours_spread,
+           "max_abs_ours_minus_refA_db": max(abs(r["ours_minus_refA"]) for r in rows),
            "final": rows[-1], "curve": rows,
            "train_psnr_mean_last_20": {k: sum(v["psnr_train"][-20:]) / 20 for k, v in runs.items()}}
     out = os.path.join(ROOT, "gpurun_out")
@@ -112,7 +121,7 @@ def test_training_320_iterations_psnr_tracks_the_reference_on_this_gpu():
     print(json.dumps({k: v for k, v in res.items() if k != "curve"}))
     assert rows[-1]["psnr_refA"] > rows[0]["psnr_refA"] + 3.0          # the run actually learns the scene
     for r in rows:
-        tol = max(0.01, 3.0 * r["ref_spread"], 1.5 * spread)
+        tol = max(0.01, 3.0 * r["ref_spread"], 1.5 * spread, 1.5 * ours_spread)
         assert abs(r["ours_minus_refA"]) <= tol, (r, tol)
 
 
