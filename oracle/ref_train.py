@@ -33,10 +33,18 @@ def import_reference(backend):
     return mod, utils
 
 
-def build_model(backend, ctor_kwargs, device):
+def build_model(backend, ctor_kwargs, device, kind="fourier"):
+    """kind: "fourier" = FourierGrid_model.FourierGridModel, "dvgo" = dvgo.DirectVoxGO, "dcvgo" = dcvgo.DirectContractedVoxGO"""
     mod, _ = import_reference(backend)
     with torch.device("cpu"):
-        model = mod.FourierGridModel(**ctor_kwargs)
+        if kind == "fourier":
+            model = mod.FourierGridModel(**ctor_kwargs)
+        elif kind == "dvgo":
+            model = importlib.import_module("FourierGrid.dvgo").DirectVoxGO(**ctor_kwargs)
+        elif kind == "dcvgo":
+            model = importlib.import_module("FourierGrid.dcvgo").DirectContractedVoxGO(**ctor_kwargs)
+        else:
+            raise ValueError(kind)
     return model.to(device)
 
 
@@ -73,7 +81,10 @@ def _loop(model, utils, ct, cfg_train, cfg_model, batches, n_iters, rk, near_thr
         for global_step in range(1, n_iters + 1):
             if global_step in pg:                                                                   # run_train.py:187-201
                 n_rest = len(pg) - pg.index(global_step) - 1
-                model.scale_volume_grid(int(cfg_model["num_voxels_density"] / (2 ** n_rest)), int(cfg_model["num_voxels_rgb"] / (2 ** n_rest)))
+                if "num_voxels_density" in cfg_model:
+                    model.scale_volume_grid(int(cfg_model["num_voxels_density"] / (2 ** n_rest)), int(cfg_model["num_voxels_rgb"] / (2 ** n_rest)))
+                else:       # DirectVoxGO / DirectContractedVoxGO: one resolution (run_train.py:190-196)
+                    model.scale_volume_grid(int(cfg_model["num_voxels"] / (2 ** n_rest)))
                 optimizer = utils.create_optimizer_or_freeze_model(model, ct, global_step=0)
                 model.act_shift -= cfg_train.get("decay_after_scale", 0.0)
             rays_o, rays_d, viewdirs, target = batches[global_step - 1]

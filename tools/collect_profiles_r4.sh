@@ -15,7 +15,7 @@ tail -1 $T/bench_line.json > $P/bench_s1_line.json
 for f in bench_2rank_shared_gpu.json dcvgo_1080p.json dvgo_lego_800.json voxgo_train.jsonl voxgo_train_composed.jsonl train_step_s3.jsonl pytest_gpu.log smoke.log smi_trace.json smi_trace.csv; do
   [ -s $T/$f ] && cp $T/$f $P/$f
 done
-for f in s1_fp64_ground_truth.json train_long_parity.json s1_arbitration_s1.json s1_arbitration_s1b.json; do
+for f in s1_fp64_ground_truth.json train_long_parity.json train_long_parity_dcvgo.json train_long_parity_dvgo.json s1_arbitration_s1.json s1_arbitration_s1b.json; do
   [ -s gpurun_out/$f ] && cp gpurun_out/$f $P/$f
 done
 python - <<'PY'
