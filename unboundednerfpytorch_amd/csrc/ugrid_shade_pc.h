@@ -94,6 +94,14 @@ __device__ int g_pc_dbg;
 // back to 0 for the VALU-only layer 3 / accumulation / slot wait, where the producers' work should win.  Measured on S1: 4.29-4.34
 // -> 4.05-4.11 ms (static priorities 1, 2, 3 for the whole consumer: 4.11-4.14).  Scheduling only: results are bit-identical.
 // -DUG_PC_PRIO_PHASED=0 builds the kernel without it.
+// polling intervals of the ring hand-off (s_sleep units of 64 clocks): a waiting producer polls the consumer's counter, a waiting
+// consumer the producer's; every poll is ~10 instructions on a SIMD it shares with working waves (A/B: profiles/r04/shade_poll_ab.txt)
+#ifndef UG_PC_PRODUCER_SLEEP
+#define UG_PC_PRODUCER_SLEEP 2
+#endif
+#ifndef UG_PC_CONSUMER_SLEEP
+#define UG_PC_CONSUMER_SLEEP 2
+#endif
 #ifndef UG_PC_PRIO_PHASED
 #define UG_PC_PRIO_PHASED 3
 #endif
@@ -359,7 +367,7 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
       UG_PC_T0(tw)
       while (seq - tail_seen >= SLOTS) {
         tail_seen = ug_lds_peek(ctl + 4);
-        if (seq - tail_seen >= SLOTS) __builtin_amdgcn_s_sleep(2);
+        if (seq - tail_seen >= SLOTS) __builtin_amdgcn_s_sleep(UG_PC_PRODUCER_SLEEP);
       }
       UG_PC_ADD(t_wait, tw)
       float *sp = ring + (seq % SLOTS) * UG_PC_SLOT_FLOATS;
@@ -547,7 +555,7 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
     UG_PC_T0(tw)
     while (head_seen <= seq) {
       head_seen = ug_lds_peek(ctl);
-      if (head_seen <= seq) __builtin_amdgcn_s_sleep(2);
+      if (head_seen <= seq) __builtin_amdgcn_s_sleep(UG_PC_CONSUMER_SLEEP);
     }
     UG_PC_ADD(t_wait, tw)
     const float *sp = ring + (seq % SLOTS) * UG_PC_SLOT_FLOATS;
