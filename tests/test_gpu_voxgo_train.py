@@ -207,6 +207,46 @@ def test_dvgo_voxel_count_views_matches_the_reference(golden_dir):
     got, want = count.cpu().numpy(), gold["count"]
     assert got.shape == want.shape
     assert float((got != want).mean()) <= 1e-3            # `grad > 1` at a vertex: sums of trilinear weights in another order
+    # hit_coarse_geo (dvgo.py:291-304) on the same views
+    hits = torch.stack([m.hit_coarse_geo(rays_o=o, rays_d=d, near=0.2, far=6.0, stepsize=0.5) for o, d in zip(ro, rd)]).cpu().numpy()
+    assert hits.shape == gold["hit"].shape and float((hits != gold["hit"]).mean()) <= 2e-3
+
+
+@pytest.mark.gpu
+def test_dvgo_maskout_near_cam_vox_and_dcvgo_lt_nviews():
+    """DirectVoxGO.maskout_near_cam_vox (dvgo.py:166-180): density = -100 exactly at the vertices within near_clip of a camera;
+    DirectContractedVoxGO.update_occupancy_cache_lt_nviews (dcvgo.py:194-214): the mask only loses voxels, keeps the ones the
+    views' samples touch, drops the ones no ray comes near"""
+    dev = torch.device("cuda", 0)
+    m, name, _, _, _, _ = build("dvgo", DVGO_CASES[0], dev)
+    before = m.density.grid.detach().clone()
+    cams = torch.tensor([[0.3, 0.1, -0.2], [-0.6, 0.5, 0.4]], device=dev)
+    m.maskout_near_cam_vox(cams, 0.35)
+    ws = m.world_size.tolist()
+    axes = [torch.linspace(float(m.xyz_min[a]), float(m.xyz_max[a]), ws[a], device=dev) for a in range(3)]
+    xyz = torch.stack(torch.meshgrid(*axes, indexing="ij"), -1)
+    near = ((xyz[..., None, :] - cams).norm(dim=-1).amin(-1) <= 0.35)[None, None]
+    assert int(near.sum()) > 50
+    assert bool((m.density.grid[near] == -100).all()) and torch.equal(m.density.grid[~near], before[~near])
+    # ---- lt_nviews
+    m2, name2, (o, d, v), kw, R, seed = build("dcvgo", synth.DCVGO_CASES[0], dev)
+    with torch.no_grad():
+        m2.mask_cache.mask.fill_(True)
+    o_tr = o.reshape(3, R // 3, 3)            # three "images" of R / 3 rays each
+    d_tr = d.reshape(3, R // 3, 3)
+    m2.update_occupancy_cache_lt_nviews(o_tr.flatten(0, 1), d_tr.flatten(0, 1), [R // 3] * 3, dict(stepsize=0.5), maskout_lt_nviews=1)
+    mask = m2.mask_cache.mask
+    frac = float(mask.float().mean())
+    assert 0.02 < frac < 0.98, frac                                    # some voxels seen, some never
+    pts = m2.sample_ray(ori_rays_o=o, ori_rays_d=d, stepsize=0.5)[0].reshape(-1, 3)
+    # every sample point lies in a cell with at least one kept corner ... most of them: `grad > 1` needs more than one unit of
+    # trilinear weight at a vertex, so isolated samples do not count; a vertex far from every sample is never kept
+    idx = ((pts - m2.xyz_min) / (m2.xyz_max - m2.xyz_min) * (torch.tensor(list(mask.shape), device=dev) - 1)).round().long()
+    idx = torch.minimum(torch.maximum(idx, torch.zeros_like(idx)), torch.tensor(list(mask.shape), device=dev) - 1)
+    touched = torch.zeros_like(mask)
+    touched[idx[:, 0], idx[:, 1], idx[:, 2]] = True
+    near_any = torch.nn.functional.max_pool3d(touched[None, None].float(), 3, 1, 1)[0, 0] > 0
+    assert not bool((mask & ~near_any).any())                          # nothing kept that no sample comes near
 
 
 @pytest.mark.gpu
