@@ -286,16 +286,18 @@ def test_train_iteration_drives_the_voxgo_models(kind):
 
 
 @pytest.mark.gpu
-def test_dcvgo_fused_loss_equals_the_composed_loss():
-    """DirectContractedVoxGO with the training tail as one op (ops.RenderLoss, what train_iteration selects) vs the torch chain of
-    train_step.training_loss on the model's return dict: the same loss and the same gradients -- distortion, entropy, rgbper and
-    the bg = 1 background included"""
+@pytest.mark.parametrize("kind,case", ALL, ids=IDS)
+def test_fused_loss_equals_the_composed_loss(kind, case):
+    """Both models with the training tail as one op (ops.RenderLoss, what train_iteration selects) vs the torch chain of
+    train_step.training_loss on the model's return dict: the same loss and the same gradients -- entropy, rgbper, the bg = 1
+    background, for the contracted model also the distortion term; fine (direct / residual rgbnet) and coarse (k0 = colour) stages"""
     from unboundednerfpytorch_amd import train_step as ts
     from unboundednerfpytorch_amd.ops import loss_coefficients
     dev = torch.device("cuda", 0)
-    m, name, (o, d, v), kw, R, seed = build("dcvgo", synth.DCVGO_CASES[0], dev)
+    m, name, (o, d, v), kw, R, seed = build(kind, case, dev)
     target = torch.from_numpy(synth.uniform(seed + 5, R * 3).reshape(R, 3)).to(dev)
-    cfg = dict(weight_main=1.0, weight_entropy_last=0.01, weight_rgbper=0.02, weight_distortion=0.05, weight_nearclip=0.0)
+    cfg = dict(weight_main=1.0, weight_entropy_last=0.01, weight_rgbper=0.02, weight_distortion=0.05 if kind == "dcvgo" else 0.0,
+               weight_nearclip=0.0)
     rk = {k: kw[k] for k in kw if k != "render_depth"}
     res = {}
     for fused in (True, False):
@@ -303,6 +305,7 @@ def test_dcvgo_fused_loss_equals_the_composed_loss():
         if fused:
             coef = loss_coefficients(cfg, R, m.sample_table(rk["stepsize"], dev).numel(), None, 1)
             out = m(o, d, v, global_step=1, is_train=True, fused_loss={'target': target, 'coef': coef}, **rk)
+            assert "loss" in out, name
             loss = out["loss"]
         else:
             out = m(o, d, v, global_step=1, is_train=True, **rk)

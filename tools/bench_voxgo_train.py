@@ -44,7 +44,7 @@ def make_model(kind, G, dev, fused):
                                      fast_color_thres=1e-4, rgbnet_dim=12).to(dev)
     m.fused_forward = bool(fused)
     m.fused_rgbnet = bool(fused)
-    m.fused_loss = bool(fused) and kind == "dcvgo"
+    m.fused_loss = bool(fused)
     Gd = int(m.world_size[0])
     st = bench.make_state_surfaces(Gd, dev, seed=0)
     with torch.no_grad():

@@ -145,6 +145,21 @@ class _VoxGOBase(nn.Module):
             return _ops.FusedRgbnet.apply(k0_view, emb, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight, lin[2].bias)
         return self.rgbnet(torch.cat([k0_view, emb], -1))
 
+    def _fused_tail(self, fused_loss, k0, viewdirs, ray_id, residual, weights, alphainv_last, density, tt, bg, N):
+        """Training tail as ONE op (ops.RenderLoss): sigmoid, compositing, background and the loss terms of run_train.py:254-279.
+        train_step.train_iteration passes fused_loss = {'target': [N,3], 'coef': ops.loss_coefficients(...)}.  The colour logits are
+        the rgbnet's output (+ the diffuse channels of the residual model) or, in the coarse stage, the 3-channel k0 itself."""
+        if self.rgbnet is None:
+            logits = k0
+        elif residual:
+            logits = self._logits(k0[:, 3:].contiguous(), viewdirs, ray_id) + k0[:, :3]
+        else:
+            logits = self._logits(k0, viewdirs, ray_id)
+        dens = density if density is not None else torch.zeros_like(weights)
+        loss, mse, rgb_marched = _ops.RenderLoss.apply(logits.contiguous(), weights, alphainv_last, dens, ray_id, tt, None,
+                                                       fused_loss['target'], bg, fused_loss['coef'])
+        return logits, loss, mse, rgb_marched
+
     def _colour(self, k0, viewdirs, ray_id, residual):
         """rgb of the surviving samples (dvgo.py:377-398, dcvgo.py:332-344)"""
         if self.rgbnet is None:
@@ -156,6 +171,11 @@ class _VoxGOBase(nn.Module):
 
 class DirectVoxGO(_VoxGOBase):
     """The bounded model (dvgo.py:26-425)."""
+    fused_loss = True           # train_step.train_iteration: compositing + loss as ops.RenderLoss (no distortion / nearclip term)
+
+    def sample_table(self, stepsize, device):
+        """train_iteration sizes the distortion term's interval from the sample table; the bounded model has neither: length 1"""
+        return torch.empty(1)
 
     def __init__(self, xyz_min, xyz_max, num_voxels=0, num_voxels_base=0, alpha_init=None, mask_cache_path=None,
                  mask_cache_thres=1e-3, mask_cache_world_size=None, fast_color_thres=0, density_type='DenseGrid',
@@ -272,9 +292,10 @@ class DirectVoxGO(_VoxGOBase):
             cfg = {'mode': 'dvgo', 'act_shift': hc['act_shift'], 'interval': interval_f, 'thres': float(self.fast_color_thres),
                    'mask_scale': hc['mask_scale'], 'mask_shift': hc['mask_shift'], 'near': float(render_kwargs['near']), 'far': 1e9,
                    'stepdist': stepdist, 'slots': int(math.ceil(hc['box_diag'] / stepdist)) + 2}
-            pts, density, alpha, weights, alphainv_last, ray_id, step_id, _, _ = _grid.TrainSampleVox.apply(
+            pts, density, alpha, weights, alphainv_last, ray_id, step_id, tt, _ = _grid.TrainSampleVox.apply(
                 self.density.grid, rays_o.contiguous(), rays_d.contiguous(), None, self.xyz_min, self.xyz_max, self.mask_cache.mask, cfg)
         else:
+            tt = None
             pts, ray_id, step_id = self.sample_ray(rays_o=rays_o, rays_d=rays_d, **render_kwargs)
             if self.mask_cache is not None:
                 m = self.mask_cache(pts)
@@ -291,8 +312,18 @@ class DirectVoxGO(_VoxGOBase):
         k0 = self.k0(pts)
         if k0.dim() == 1:
             k0 = k0.unsqueeze(-1)
-        rgb = self._colour(k0, viewdirs, ray_id, residual=self.rgbnet is not None and not self.rgbnet_direct)
+        residual = self.rgbnet is not None and not self.rgbnet_direct
         dev = rays_o.device
+        fused_loss = render_kwargs.get('fused_loss')
+        if fused_loss is not None and tt is not None and k0.is_cuda and float(fused_loss['coef'][2]) == 0.0 and float(fused_loss['coef'][4]) == 0.0:
+            # (the bounded model has no `s` / `t`: configurations with the distortion or nearclip terms take the composed tail and
+            # fail there exactly as they do with the reference's DirectVoxGO)
+            bg = torch.full((N, 3), float(render_kwargs['bg']), device=dev) if float(render_kwargs['bg']) != 0.0 else None
+            logits, loss, mse, rgb_marched = self._fused_tail(fused_loss, k0, viewdirs, ray_id, residual, weights, alphainv_last, density,
+                                                              tt, bg, N)
+            return {'alphainv_last': alphainv_last, 'weights': weights, 'rgb_marched': rgb_marched, 'raw_alpha': alpha,
+                    'raw_logits': logits, 'ray_id': ray_id, 'loss': loss, 'mse': mse}
+        rgb = self._colour(k0, viewdirs, ray_id, residual=residual)
         rgb_marched = torch.zeros(N, 3, device=dev).index_add_(0, ray_id, weights.unsqueeze(-1) * rgb)
         rgb_marched = rgb_marched + alphainv_last.unsqueeze(-1) * render_kwargs['bg']
         out = {'alphainv_last': alphainv_last, 'weights': weights, 'rgb_marched': rgb_marched, 'raw_alpha': alpha, 'raw_rgb': rgb,
@@ -432,16 +463,13 @@ class DirectContractedVoxGO(_VoxGOBase):
         if k0.dim() == 1:
             k0 = k0.unsqueeze(-1)
         fused_loss = render_kwargs.get('fused_loss')
-        if fused_loss is not None and self.rgbnet is not None and k0.is_cuda:
-            # training tail as ONE op (ops.RenderLoss): sigmoid, compositing, background and the loss terms of run_train.py:254-279
-            # (train_step.train_iteration passes fused_loss = {'target': [N,3], 'coef': ops.loss_coefficients(...)})
-            logits = self._logits(k0, viewdirs, ray_id)
+        if fused_loss is not None and k0.is_cuda:
             if render_kwargs.get('rand_bkgd', False) and is_train:
                 bg = torch.rand(N, 3, device=dev)
             else:
                 bg = torch.full((N, 3), float(render_kwargs['bg']), device=dev) if float(render_kwargs['bg']) != 0.0 else None
-            loss, mse, rgb_marched = _ops.RenderLoss.apply(logits, weights, alphainv_last, density, ray_id, tt, None,
-                                                           fused_loss['target'], bg, fused_loss['coef'])
+            logits, loss, mse, rgb_marched = self._fused_tail(fused_loss, k0, viewdirs, ray_id, False, weights, alphainv_last, density, tt,
+                                                              bg, N)
             return {'alphainv_last': alphainv_last, 'weights': weights, 'rgb_marched': rgb_marched, 'raw_density': density,
                     'raw_alpha': alpha, 'raw_logits': logits, 'ray_id': ray_id, 'step_id': step_id, 'n_max': n_max, 't': tt,
                     'loss': loss, 'mse': mse}
