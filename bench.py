@@ -531,6 +531,25 @@ def s3_train_step_block(device):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def voxgo_train_block():
+    """Row f4 of SURVEY section 8 under the driver's clock: one training step of voxgo_model.DirectVoxGO at the lego fine-stage
+    shape (the model of BASELINE.json configs[0]) and of DirectContractedVoxGO at the Mip-360 fine-stage shape (configs[1]'s model),
+    tools/bench_voxgo_train.run.  Secondary: a failure here never costs the headline line."""
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import argparse
+        import bench_voxgo_train as bvt
+        a = argparse.Namespace(steps=12, warmup=4, grid=0, fused=1, overlap=1)
+        out = {}
+        for kind, first, tag in (("dvgo", 1, "dvgo_lego_fine"), ("dcvgo", 1, "dcvgo_mip360_fine_dense_tv"), ("dcvgo", 10001, "dcvgo_mip360_fine_masked_tv")):
+            r = bvt.run(kind, a, first)
+            out[tag] = {k: r[k] for k in ("workload", "ms_per_step", "rays_per_sec", "survivors_M", "steps")}
+            torch.cuda.empty_cache()
+        return out
+    except Exception as e:          # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves through
     torch.distributed.run on 127.0.0.1 -- the command the driver uses for N > 1 -- and pass their exit code on.  On a box
@@ -772,6 +791,7 @@ def main():
         s3 = s3_train_step_block(device)
         if s3 is not None:
             res["secondary_s3_train_step"] = s3
+        res["secondary_voxgo_train_steps"] = voxgo_train_block()
     if rank == 0:
         print(json.dumps(res))
 
