@@ -221,7 +221,7 @@ def test_fused_render_deterministic_chunk_and_order_invariant(fr):
 
 def test_shade_kernel_geometries_are_bit_identical(fr, pe=4):
     """The shade kernels -- classic (0), 8-wave producer / consumer with the hand-scheduled pass (1), 12-wave 6 + 6 with the lean
-    pass (2), 12-wave 4 + 8 with the embedding rows in global memory (3) -- issue the same products and keep every summation order: their
+    pass (2), 12-wave 4 + 8 (3), 5 + 7 (4) and 6 + 6 (5) with the embedding rows in global memory -- issue the same products and keep every summation order: their
     rgb_marched must agree bit for bit on a frame with many partially filled passes and empty tiles."""
     G, F, C, R = 32, 3, 12, 50_000
     state = make_state(123, G, F, C, pe, "inf", 1e-4, 5.0, 12.0)
@@ -231,7 +231,7 @@ def test_shade_kernel_geometries_are_bit_identical(fr, pe=4):
     assert rend.mlp_mode == 2
     outs = {}
     try:
-        for pc in (0, 1, 2, 3):
+        for pc in (0, 1, 2, 3, 4, 5):
             fr.tune("shade_pc", pc)
             outs[pc] = rend(o, d, v, stepsize=0.5, render_depth=True, ray_order="coherent")["rgb_marched"].clone()
             again = rend(o, d, v, stepsize=0.5, render_depth=True, ray_order="coherent")["rgb_marched"]
@@ -239,7 +239,7 @@ def test_shade_kernel_geometries_are_bit_identical(fr, pe=4):
     finally:
         fr.tune("shade_pc", 2)
     assert float(outs[0].abs().max()) > 0.1
-    for pc in (1, 2, 3):
+    for pc in (1, 2, 3, 4, 5):
         assert torch.equal(outs[0], outs[pc]), (pc, float((outs[0] - outs[pc]).abs().max()))
 
 

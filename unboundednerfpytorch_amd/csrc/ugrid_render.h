@@ -836,6 +836,104 @@ __device__ __forceinline__ void ug_k0_gather_finish(const float *__restrict__ k0
     for (int c = 0; c < 3; ++c) feat[r][c] = ug_div_r(feat[r][c], (float)P, 1.0f / (float)P);
 }
 
+// ROLLING set-up variant of the same pipeline (round 4, k_shade_pc48): ug_gather_state keeps the cell set-up of ALL NR x P items
+// (4 registers each: 56 at F = 3) from begin to finish; here only the level coordinates of the lane's axis (NR x P registers) stay
+// alive and an item's cell offset / fractions are formed when the item is ISSUED, into a slot it shares with its load registers --
+// 4 registers per item IN FLIGHT.  The 40 registers that frees are a fourth item in flight inside the 168-register budget of the
+// 12-wave geometries.  Same arithmetic, same order of the polynomial sums: bit-identical features.
+template <int F, int NBL, int NR>
+struct ug_gather_roll {
+  static constexpr int P = 2 * F + 1, NI = NR * P;
+  float lc[NR][P];
+  unsigned off[NBL];
+  float tx[NBL], ty[NBL], tz[NBL];
+  ug_f4 v[NBL][6];
+};
+
+#define UG_ROLL_SETUP_ISSUE(st_, i_)                                                                                 \
+  {                                                                                                                    \
+    constexpr int s_ = (i_) % NBL;                                                                                     \
+    const float ix_ = fmaf(st_.lc[(i_) % NR][(i_) / NR], 0.5f, 0.5f) * qa.nm1;                                        \
+    const float cf_ = __builtin_amdgcn_fmed3f(floorf(ix_), 0.0f, qa.nm2);                                              \
+    const float wh_ = ix_ - cf_;                                                                                       \
+    const float cxf_ = ug_quad_bcast<0>(cf_), cyf_ = ug_quad_bcast<1>(cf_), czf_ = ug_quad_bcast<2>(cf_);               \
+    st_.tx[s_] = ug_quad_bcast<0>(wh_); st_.ty[s_] = ug_quad_bcast<1>(wh_); st_.tz[s_] = ug_quad_bcast<2>(wh_);         \
+    const unsigned row_ = (unsigned)fmaf(cxf_, (float)(a.Y - 1), cyf_);                                                \
+    const unsigned cell_ = __umul24(row_, (unsigned)(a.Z - 1)) + (unsigned)czf_;                                       \
+    if constexpr (F == 0) {                                                                                            \
+      st_.off[s_] = cell_;                                                                                             \
+      const char *pa = (const char *)k0b + (uint64_t)cell_ * 384ull + (uint64_t)((ug_lane() & 3) * 16);                \
+      st_.v[s_][0] = ug_gload4v<0>(pa);   st_.v[s_][1] = ug_gload4v<64>(pa);  st_.v[s_][2] = ug_gload4v<128>(pa);       \
+      st_.v[s_][3] = ug_gload4v<192>(pa); st_.v[s_][4] = ug_gload4v<256>(pa); st_.v[s_][5] = ug_gload4v<320>(pa);       \
+    } else {                                                                                                           \
+      st_.off[s_] = __umul24(cell_, 384u) + qa.goff;                                                                   \
+      const float *lb = k0b + (int64_t)((i_) / NR) * lvl_floats;                                                       \
+      st_.v[s_][0] = ug_gload4<0>(st_.off[s_], lb);   st_.v[s_][1] = ug_gload4<64>(st_.off[s_], lb);                    \
+      st_.v[s_][2] = ug_gload4<128>(st_.off[s_], lb); st_.v[s_][3] = ug_gload4<192>(st_.off[s_], lb);                   \
+      st_.v[s_][4] = ug_gload4<256>(st_.off[s_], lb); st_.v[s_][5] = ug_gload4<320>(st_.off[s_], lb);                   \
+    }                                                                                                                  \
+  }
+
+template <int F, int NBL, int NR, int I>
+__device__ __forceinline__ void ug_roll_issue(const float *__restrict__ k0b, const ug_shade_args &a, const ug_quad_axis &qa,
+                                              int64_t lvl_floats, ug_gather_roll<F, NBL, NR> &st) {
+  UG_ROLL_SETUP_ISSUE(st, I)
+}
+
+template <int F, int NBL, int NR, int I>
+__device__ __forceinline__ void ug_roll_step(const float *__restrict__ k0b, const ug_shade_args &a, const ug_quad_axis &qa,
+                                             int64_t lvl_floats, ug_gather_roll<F, NBL, NR> &st, float (&feat)[NR][3]) {
+  constexpr int NI = NR * (2 * F + 1);
+  if constexpr (I < NI) {
+    constexpr int after = (NI - 1 - I) < (NBL - 1) ? (NI - 1 - I) : (NBL - 1);   // items issued after item I
+    ug_vmwait6<6 * after>(st.v[I % NBL]);
+    ug_quad_poly(st.v[I % NBL], st.tx[I % NBL], st.ty[I % NBL], st.tz[I % NBL], I < NR, feat[I % NR]);
+    asm volatile("" :: "v"(feat[I % NR][0]), "v"(feat[I % NR][1]), "v"(feat[I % NR][2]));
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (I + NBL < NI) {
+      ug_roll_issue<F, NBL, NR, I + NBL>(k0b, a, qa, lvl_floats, st);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    ug_roll_step<F, NBL, NR, I + 1>(k0b, a, qa, lvl_floats, st, feat);
+  }
+}
+
+template <int F, int NBL, int NR, int I>
+__device__ __forceinline__ void ug_roll_prime(const float *__restrict__ k0b, const ug_shade_args &a, const ug_quad_axis &qa,
+                                              int64_t lvl_floats, ug_gather_roll<F, NBL, NR> &st) {
+  constexpr int NI = NR * (2 * F + 1);
+  if constexpr (I < NBL && I < NI) {
+    ug_roll_issue<F, NBL, NR, I>(k0b, a, qa, lvl_floats, st);
+    ug_roll_prime<F, NBL, NR, I + 1>(k0b, a, qa, lvl_floats, st);
+  }
+}
+
+template <int F, int NBL, int NR>
+__device__ __forceinline__ void ug_k0_gather_quad_roll(const float *__restrict__ k0b, const ug_shade_args &a,
+                                                       const ug_quad_axis &qa, const float (&p_g)[NR], float (&feat)[NR][3]) {
+  constexpr int P = 2 * F + 1;
+  ug_gather_roll<F, NBL, NR> st;
+#pragma unroll
+  for (int r = 0; r < NR; ++r) {
+    const float u = ug_div_r(p_g[r] - qa.lo, qa.ex, qa.ir) * 2.f - 1.f;
+    st.lc[r][0] = u;
+#pragma unroll
+    for (int k = 0; k < F; ++k) {
+      if (k == 0) ug_sincos_small(u, &st.lc[r][1], &st.lc[r][2]);
+      else ug_sincos((float)(1 << k) * u, &st.lc[r][2 * k + 1], &st.lc[r][2 * k + 2]);
+    }
+  }
+  const int64_t lvl_floats = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1) * 96;
+  __builtin_amdgcn_sched_barrier(0);
+  ug_roll_prime<F, NBL, NR, 0>(k0b, a, qa, lvl_floats, st);
+  __builtin_amdgcn_sched_barrier(0);
+  ug_roll_step<F, NBL, NR, 0>(k0b, a, qa, lvl_floats, st, feat);
+#pragma unroll
+  for (int r = 0; r < NR; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) feat[r][c] = ug_div_r(feat[r][c], (float)P, 1.0f / (float)P);
+}
+
 // k0 features (mean over the P levels) of the quad's NR survivors (one per gather round) at p_g[r]: this lane's 3
 // channels of each.
 template <int F, int NBL, int NR>

@@ -11,6 +11,12 @@ extern "C" int ug_set_tv_xcd(int m);        // ugrid_ops.hip
 #ifndef UG_PC48_SLOTS
 #define UG_PC48_SLOTS 2      // ring slots per consumer of the 4 + 8 geometry
 #endif
+#ifndef UG_PC57_EXTRA
+#define UG_PC57_EXTRA 0      // extra gather items in flight of a producer that feeds ONE consumer (it holds one stream's state less)
+#endif
+#ifndef UG_PC48_NBL
+#define UG_PC48_NBL 4        // gather items in flight per producer of the 4 + 8 geometry (rolling cell set-up: ug_k0_gather_quad_roll)
+#endif
 #ifndef UG_PC12_NBL
 #define UG_PC12_NBL 3        // gather items (x 6 dwordx4) in flight per producer wave of the 12-wave geometry (4 spills: A/B arm only)
 #endif
@@ -219,7 +225,7 @@ k_shade_pc(ug_shade_args a, const float *__restrict__ viewdirs, const float *__r
     ug_pc_producer<F, NBL, SLOTS>(a, k0b, ws, rgb_marched, tile_counter, ring, ctl, pstat);
   } else {
     float *scr = pairs + NPAIR * UG_PC_PAIR_FLOATS(SLOTS) + pair * ug_pc_consumer_scratch_floats<PE>();
-    ug_pc_consumer<PE, SLOTS, MODE>(a, viewdirs, M, rgb_marched, ring, ctl, scr, pstat);
+    ug_pc_consumer<PE, SLOTS, MODE>(a, viewdirs, M, rgb_marched, ring, ctl, scr, pstat, ws.emb);
   }
 }
 
@@ -227,27 +233,31 @@ k_shade_pc(ug_shade_args a, const float *__restrict__ viewdirs, const float *__r
 // consumers 2p and 2p + 1 (ug_pc_producer2).  Why: a consumer's rgbnet chain is latency-bound (12 k cycles per pass against 4.2 k
 // of matrix-pipe issue, profiles/r03/shade_pc12_phases.txt), the 6 + 6 geometry puts 1, 1, 2, 2 consumers on the four SIMDs, and
 // the gather side is bound by the CU's shared vector-memory path, not by the number of waves that issue the loads.
-template <int F, int PE, int SLOTS, int NBL>
+template <int F, int PE, int SLOTS, int NBL, int NP = 4, int NC = 8>
 __global__ void __launch_bounds__(768, 1)
 k_shade_pc48(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
              const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
              int32_t *__restrict__ tile_counter) {
+  static_assert(NP + NC == 12 && NC >= NP && NC <= 2 * NP, "12 waves; every producer feeds one or two consumers");
+  constexpr int ND = NC - NP;       // producers 0 .. ND-1 feed two consumers (2p, 2p + 1), the others one (ND + p)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int MLPF = ug_mlp_lds_floats<12, PE, 2>();
   float *rings = lds + MLPF;
-  if (threadIdx.x < 32)             // head / tail counters of the eight rings
+  if (threadIdx.x < 4 * NC)         // head / tail counters of the rings
     ((int *)(rings + (threadIdx.x >> 2) * UG_PC_PAIR_FLOATS(SLOTS) + SLOTS * UG_PC_SLOT_FLOATS))[threadIdx.x & 3] = 0;
   const ug_mlp_lds M = ug_mlp_stage<12, PE, 2>(lds, mlp, a.residual);     // ends with __syncthreads()
   const int wv = threadIdx.x >> 6;
-  if (wv < 4) {
-    float *r0 = rings + (2 * wv) * UG_PC_PAIR_FLOATS(SLOTS), *r1 = rings + (2 * wv + 1) * UG_PC_PAIR_FLOATS(SLOTS);
-    ug_pc_producer2<F, NBL, SLOTS>(a, k0b, ws, rgb_marched, tile_counter, r0, ug_lds_off(r0 + SLOTS * UG_PC_SLOT_FLOATS), r1,
-                                   ug_lds_off(r1 + SLOTS * UG_PC_SLOT_FLOATS));
+  if (wv < ND) {
+    float *r0 = rings + (2 * wv) * UG_PC_PAIR_FLOATS(SLOTS), *r1 = r0 + UG_PC_PAIR_FLOATS(SLOTS);
+    ug_pc_producer2<F, NBL, SLOTS, true>(a, k0b, ws, rgb_marched, tile_counter, r0, ug_lds_off(r0 + SLOTS * UG_PC_SLOT_FLOATS), r1,
+                                         ug_lds_off(r1 + SLOTS * UG_PC_SLOT_FLOATS));
+  } else if (wv < NP) {
+    float *r0 = rings + (ND + wv) * UG_PC_PAIR_FLOATS(SLOTS);
+    ug_pc_producer2<F, NBL + UG_PC57_EXTRA, SLOTS, false>(a, k0b, ws, rgb_marched, tile_counter, r0, ug_lds_off(r0 + SLOTS * UG_PC_SLOT_FLOATS), nullptr, 0u);
   } else {
-    // consumer c of producer p = c / 2 sits on SIMD (4 + c) % 4: the two consumers of a producer are on DIFFERENT SIMDs
-    const int c = wv - 4;
+    const int c = wv - NP;
     float *ring = rings + c * UG_PC_PAIR_FLOATS(SLOTS);
-    float *scr = rings + 8 * UG_PC_PAIR_FLOATS(SLOTS) + c * UG_ACC_SCRATCH_FLOATS;
+    float *scr = rings + NC * UG_PC_PAIR_FLOATS(SLOTS) + c * UG_ACC_SCRATCH_FLOATS;
     ug_pc_consumer<PE, SLOTS, 2>(a, viewdirs, M, rgb_marched, ring, ug_lds_off(ring + SLOTS * UG_PC_SLOT_FLOATS), scr, nullptr, ws.emb);
   }
 }
@@ -565,7 +575,7 @@ extern "C" int ugrid_tune(const char *key, int value) {
   if (!key) return (int)hipErrorInvalidValue;
   if (!strcmp(key, "march_waves")) return ug_set_march_waves(value) ? (int)hipErrorInvalidValue : 0;
   if (!strcmp(key, "tv_xcd")) return ug_set_tv_xcd(value) ? (int)hipErrorInvalidValue : 0;
-  if (!strcmp(key, "shade_pc") && value >= 0 && value <= 3) { g_shade_pc = value; return 0; }
+  if (!strcmp(key, "shade_pc") && value >= 0 && value <= 5) { g_shade_pc = value; return 0; }
 #ifdef UG_EXPERIMENTS
   if (!strcmp(key, "shade16") && (value == 0 || value == 1)) { g_shade16 = value; return 0; }
   if (!strcmp(key, "shade_dbg") && value >= 0 && value < 4) { g_shade_dbg = value; return 0; }
@@ -597,6 +607,10 @@ static int ug_shade_pc_launch(const ug_shade_args &a, const float *viewdirs, con
   if (lds_bytes > 160 * 1024) return (int)hipErrorInvalidValue;   // the CU's LDS
   UG_SET_DYN_LDS((k_shade_pc<F, PE, NPAIR, SLOTS, NBL, MODE>), lds_bytes);
   UG_ZERO_WORDS(counter, 8, st);
+  if constexpr (MODE == 2) {      // A/B arm: the 6 + 6 geometry with the consumers of the 4 + 8 / 5 + 7 ones (embedding rows from global memory)
+    const int64_t n_rows = ws.n_tiles * UG_WAVE;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_view_emb<PE>), dim3(ug_blocks(n_rows, 256)), dim3(256), 0, st, viewdirs, a.n_rays, n_rows, ws.emb);
+  }
   // persistent, one workgroup per CU: NPAIR producer waves pull tiles, so a workgroup covers >= NPAIR tiles
   int64_t wgs = (ws.n_tiles + NPAIR - 1) / NPAIR;
   if (wgs > 256) wgs = 256;
@@ -607,19 +621,19 @@ static int ug_shade_pc_launch(const ug_shade_args &a, const float *viewdirs, con
   return 0;
 }
 
-template <int F, int PE, int SLOTS, int NBL>
+template <int F, int PE, int SLOTS, int NBL, int NP, int NC>
 static int ug_shade_pc48_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
                                 ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
-  const int lds_bytes = ug_pc48_lds_bytes<PE, SLOTS>();
+  const int lds_bytes = ug_pc48_lds_bytes<PE, SLOTS, NC>();
   if (lds_bytes > 160 * 1024) return (int)hipErrorInvalidValue;
-  UG_SET_DYN_LDS((k_shade_pc48<F, PE, SLOTS, NBL>), lds_bytes);
+  UG_SET_DYN_LDS((k_shade_pc48<F, PE, SLOTS, NBL, NP, NC>), lds_bytes);
   UG_ZERO_WORDS(counter, 8, st);
   const int64_t n_rows = ws.n_tiles * UG_WAVE;
   hipLaunchKernelGGL(HIP_KERNEL_NAME(k_view_emb<PE>), dim3(ug_blocks(n_rows, 256)), dim3(256), 0, st, viewdirs, a.n_rays, n_rows, ws.emb);
-  int64_t wgs = (ws.n_tiles + 7) / 8;          // eight tile streams per workgroup
+  int64_t wgs = (ws.n_tiles + NC - 1) / NC;    // NC tile streams per workgroup
   if (wgs > 256) wgs = 256;
   wgs = (wgs + 7) / 8 * 8;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_pc48<F, PE, SLOTS, NBL>), dim3((unsigned)wgs), dim3(768), lds_bytes, st,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_pc48<F, PE, SLOTS, NBL, NP, NC>), dim3((unsigned)wgs), dim3(768), lds_bytes, st,
                      a, viewdirs, k0b, mlp, ws, rgb, counter);
   UG_LAUNCH_CHECK();
   return 0;
@@ -660,7 +674,11 @@ static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const 
   if constexpr (C == 12 && PE <= 4) {
     if constexpr (F <= 3 && PE == 4) {
       if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc == 3)
-        return ug_shade_pc48_launch<F, PE, UG_PC48_SLOTS, UG_PC12_NBL>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+        return ug_shade_pc48_launch<F, PE, UG_PC48_SLOTS, UG_PC48_NBL, 4, 8>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+      if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc == 5)
+        return ug_shade_pc_launch<F, PE, 6, 2, UG_PC12_NBL, 2>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+      if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc == 4)
+        return ug_shade_pc48_launch<F, PE, UG_PC48_SLOTS, UG_PC48_NBL, 5, 7>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
     }
     if constexpr (F <= 3) {      // the producers' set-up state grows with the level count: F >= 4 does not fit 168 VGPRs
       if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc >= 2)

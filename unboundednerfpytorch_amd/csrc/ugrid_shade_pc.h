@@ -55,10 +55,10 @@ __host__ __device__ static inline int ug_pc_lds_bytes() {
   return (int)sizeof(float) * (ug_mlp_lds_floats<12, PE, 2>() + NPAIR * UG_PC_PAIR_FLOATS(SLOTS) + NPAIR * ug_pc_consumer_scratch_floats<PE>());
 }
 
-// 4 producers + 8 consumers: rgbnet image | 8 rings | 8 x (amask | aval) -- no embedding tables (consumer MODE 2)
-template <int PE, int SLOTS>
+// NP producers + NC consumers (4 + 8, 5 + 7): rgbnet image | NC rings | NC x (amask | aval) -- no embedding tables (consumer MODE 2)
+template <int PE, int SLOTS, int NC = 8>
 __host__ __device__ static inline int ug_pc48_lds_bytes() {
-  return (int)sizeof(float) * (ug_mlp_lds_floats<12, PE, 2>() + 8 * UG_PC_PAIR_FLOATS(SLOTS) + 8 * UG_ACC_SCRATCH_FLOATS);
+  return (int)sizeof(float) * (ug_mlp_lds_floats<12, PE, 2>() + NC * UG_PC_PAIR_FLOATS(SLOTS) + NC * UG_ACC_SCRATCH_FLOATS);
 }
 
 // ---- LDS counters: explicit ds_ instructions on the 32-bit LDS offset (no flat_ access may sneak in: flat operations
@@ -357,10 +357,14 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
       } else
 #endif
       {
-        ug_gather_state<F, NBL, 2> gst;
         const float pgs[2] = {pg0, pg1};
+#ifdef UG_PC12_ROLL      // A/B arm: the rolling cell set-up (ug_k0_gather_quad_roll) in the 1 : 1 geometries as well
+        ug_k0_gather_quad_roll<F, NBL, 2>(k0b, a, qa, pgs, f3);
+#else
+        ug_gather_state<F, NBL, 2> gst;
         ug_k0_gather_begin<F, NBL, 2>(k0b, a, qa, pgs, gst);
         ug_k0_gather_finish<F, NBL, 2>(k0b, a, gst, f3);
+#endif
       }
       UG_PC_ADD(t_gather, tg)
       // a free slot: the consumer has taken pass seq - SLOTS (waited for AFTER the gather: the features sit in registers)
@@ -442,7 +446,7 @@ __device__ __forceinline__ void ug_pc_stream_next_tile(ug_pc_stream &st, const u
   }
 }
 
-template <int F, int NBL, int SLOTS>
+template <int F, int NBL, int SLOTS, bool TWO = true>
 __device__ __forceinline__ void ug_pc_producer2(const ug_shade_args &a, const float *__restrict__ k0b, const ug_ws_view &ws,
                                                 float *__restrict__ rgb_marched, int32_t *__restrict__ tile_counter,
                                                 float *ring0, unsigned ctl0, float *ring1, unsigned ctl1) {
@@ -453,14 +457,15 @@ __device__ __forceinline__ void ug_pc_producer2(const ug_shade_args &a, const fl
   int victim = 0;
   ug_pc_stream st[2];
   st[0].ring = ring0; st[0].ctl = ctl0; st[1].ring = ring1; st[1].ctl = ctl1;
+  constexpr int NS = TWO ? 2 : 1;             // TWO = false: a producer of the 5 + 7 geometry that feeds ONE consumer (ring1 unused)
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < NS; ++i) {
     st[i].seq = 0; st[i].tail_seen = 0; st[i].active = false;
     ug_pc_stream_next_tile(st[i], a, ws, rgb_marched, tile_counter, victim, lane, qs, comp);
   }
-  while (st[0].active || st[1].active) {
+  while (st[0].active || (TWO && st[1].active)) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NS; ++i) {
       if (!st[i].active) continue;
       ug_pc_stream &S = st[i];
       const float ww = S.w_n, pg0 = S.pg0_n, pg1 = S.pg1_n;
@@ -472,10 +477,8 @@ __device__ __forceinline__ void ug_pc_producer2(const ug_shade_args &a, const fl
       }
       float f3[2][3];
       {
-        ug_gather_state<F, NBL, 2> gst;
         const float pgs[2] = {pg0, pg1};
-        ug_k0_gather_begin<F, NBL, 2>(k0b, a, qa, pgs, gst);
-        ug_k0_gather_finish<F, NBL, 2>(k0b, a, gst, f3);
+        ug_k0_gather_quad_roll<F, NBL, 2>(k0b, a, qa, pgs, f3);      // rolling cell set-up: NBL = 4 items in flight fit 168 registers
       }
       while (S.seq - S.tail_seen >= SLOTS) {
         S.tail_seen = ug_lds_peek(S.ctl + 4);
@@ -496,7 +499,7 @@ __device__ __forceinline__ void ug_pc_producer2(const ug_shade_args &a, const fl
     }
   }
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {       // end markers
+  for (int i = 0; i < NS; ++i) {      // end markers
     ug_pc_stream &S = st[i];
     while (S.seq - S.tail_seen >= SLOTS) {
       S.tail_seen = ug_lds_peek(S.ctl + 4);
