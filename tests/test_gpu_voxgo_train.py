@@ -85,6 +85,22 @@ def test_voxgo_models_have_the_reference_names_and_shapes(kind, case, golden_dir
         m(o, d, v, near=0.2, far=6.0, stepsize=0.5, bg=1)
 
 
+@pytest.mark.parametrize("case", synth.DCVGO_CASES, ids=[c[0] for c in synth.DCVGO_CASES])
+def test_dcvgo_sample_table_and_derived_constants_match_the_reference(case, golden_dir):
+    """host side of the contracted model (CPU): the mid-point sample table the march kernel walks (dcvgo.py:243-250) reproduces the
+    `t` of every surviving sample of the reference's forward bit for bit, n_max, the world size and the kwargs the reference stores"""
+    m, name, _, kw, _, _ = build("dcvgo", case)
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))            # the reference's own forward (gen_golden.gen_dcvgo)
+    t = m.sample_table(kw["stepsize"], "cpu")
+    assert t.numel() == int(gold["n_max"])
+    assert np.array_equal(t.numpy()[gold["step_id"]], gold["t"])
+    assert [int(x) for x in m.world_size] == gold["world_size"].tolist()
+    k = m.get_kwargs()
+    assert k["num_voxels"] == m.num_voxels and k["mask_cache_world_size"] == list(m.mask_cache.mask.shape)
+    interval, stepdist = m._step_consts(kw["stepsize"])
+    assert interval == float(torch.tensor(kw["stepsize"]) * m.voxel_size_ratio) and stepdist == float(kw["stepsize"] * m.voxel_size)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,case", ALL, ids=IDS)
 def test_fused_training_forward_backward_matches_the_reference_model(kind, case, golden_dir):
