@@ -97,10 +97,11 @@ def main():
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1)
+    ap.add_argument("--phase", default="both", help="dcvgo: dense | masked | both TV phases")
     args = ap.parse_args()
     kinds = ["dvgo", "dcvgo"] if args.model == "both" else [args.model]
     for kind in kinds:
-        phases = [1] if CFG[kind]["weight_tv_k0"] == 0 else [1, 10001]
+        phases = [1] if CFG[kind]["weight_tv_k0"] == 0 else {"dense": [1], "masked": [10001]}.get(args.phase, [1, 10001])
         for first in phases:
             print(json.dumps(run(kind, args, first)), flush=True)
             torch.cuda.empty_cache()
