@@ -76,7 +76,8 @@ def run(kind, args, first_step):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
         o, d, v, rgb = batches[step - 1]
-        loss, psnr = ts.train_iteration(m, opt, o, d, v, rgb, cfg, first_step - 1 + step, rk, overlap_k0_update=bool(args.overlap))
+        loss, psnr = ts.train_iteration(m, opt, o, d, v, rgb, cfg, first_step - 1 + step, rk, overlap_k0_update=bool(args.overlap),
+                                        return_tensors=bool(args.lazy_loss))
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / args.steps
     with torch.no_grad():
@@ -85,7 +86,7 @@ def run(kind, args, first_step):
     return {"model": kind, "workload": "%s train step: G=%s, C=12, %d random rays, stepsize 0.5%s" % (
                 "DirectVoxGO (lego fine-stage shape)" if kind == "dvgo" else "DirectContractedVoxGO (mip-360 fine-stage shape)",
                 m.world_size.tolist(), n, "" if not tv_on else ", TV " + ("dense" if first_step < cfg["tv_dense_before"] else "masked")),
-            "fused": bool(args.fused), "ms_per_step": ms, "rays_per_sec": n / (ms * 1e-3), "survivors_M": int(out["weights"].numel()),
+            "fused": bool(args.fused), "lazy_loss": bool(args.lazy_loss), "ms_per_step": ms, "rays_per_sec": n / (ms * 1e-3), "survivors_M": int(out["weights"].numel()),
             "mask_cache_occupied_frac": float(m.mask_cache.mask.float().mean()), "steps": args.steps, "loss": float(loss), "psnr": float(psnr)}
 
 
@@ -98,6 +99,8 @@ def main():
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1)
     ap.add_argument("--phase", default="both", help="dcvgo: dense | masked | both TV phases")
+    ap.add_argument("--lazy-loss", type=int, default=0, help="train_iteration(return_tensors=True): no host read of loss / psnr per step "
+                    "(the reference reads psnr.item() every step; a caller that logs every N steps need not)")
     args = ap.parse_args()
     kinds = ["dvgo", "dcvgo"] if args.model == "both" else [args.model]
     for kind in kinds:
