@@ -334,3 +334,73 @@ def test_fused_loss_equals_the_composed_loss(kind, case):
         ga, gb = res[True][2][k], res[False][2][k]
         scale = float(gb.abs().max()) + 1e-20
         assert float((ga - gb).abs().max()) <= 2e-4 * scale, (k, float((ga - gb).abs().max()) / scale)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dvgo", "dcvgo"])
+def test_voxgo_edge_cases_empty_and_ragged(kind):
+    """Edge cases of the fused sampling march: (a) an all-False mask cache and (b) densities far below the alpha threshold -- no
+    stage-1 sample, M = 0 through the k0 lookup, the rgbnet kernels, the loss, backward and the optimizer; (c) bounded model: rays
+    that miss the box, rays with zero direction components (the 1e-6 replacement of infer_t_minmax), rays starting inside and
+    outside -- fused = op-by-op chain sample for sample; (d) a batch of ONE ray and a batch whose size is not a multiple of 64"""
+    from unboundednerfpytorch_amd import train_step as ts
+    from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
+    dev = torch.device("cuda", 0)
+    case = DVGO_CASES[0] if kind == "dvgo" else synth.DCVGO_CASES[0]
+    m, name, (o, d, v), kw, R, seed = build(kind, case, dev)
+    rk = {k: kw[k] for k in kw if k != "render_depth"}
+    target = torch.full((R, 3), 0.5, device=dev)
+    cfg = dict(lrate_density=1e-1, lrate_k0=1e-1, lrate_rgbnet=1e-3, lrate_decay=20, pg_scale=[], weight_main=1.0, weight_entropy_last=0.01,
+               weight_rgbper=0.01, weight_nearclip=0.0, weight_distortion=0.0, tv_every=1, tv_after=0, tv_before=100, tv_dense_before=2,
+               weight_tv_density=1e-5, weight_tv_k0=1e-6, skip_zero_grad_fields=['density', 'k0'])
+    # (a) nothing is known to be occupied
+    saved = m.mask_cache.mask.clone()
+    with torch.no_grad():
+        m.mask_cache.mask.fill_(False)
+    out = m(o, d, v, global_step=1, is_train=True, **kw)
+    assert out["weights"].numel() == 0 and out["ray_id"].numel() == 0
+    assert torch.equal(out["alphainv_last"], torch.ones(R, device=dev))
+    assert float((out["rgb_marched"].detach() - 1.0).abs().max()) == 0.0   # bg = 1
+    with torch.no_grad():
+        m.mask_cache.mask.copy_(saved)
+    # (b) empty space everywhere: the whole training iteration copes with M = 0, in both TV phases
+    dens_saved = m.density.grid.detach().clone()
+    with torch.no_grad():
+        m.density.grid.fill_(-60.0)
+    opt = create_optimizer_or_freeze_model(m, cfg, global_step=0)
+    before = {k: p.detach().clone() for k, p in m.named_parameters()}
+    for step in (1, 3):
+        loss, psnr = ts.train_iteration(m, opt, o, d, v, target, cfg, step, rk)
+        assert loss == loss and psnr == psnr
+    torch.cuda.synchronize()
+    for k, p in m.named_parameters():
+        assert bool(torch.isfinite(p).all()), k
+        if "rgbnet" in k:
+            assert torch.equal(p.detach(), before[k]), k                      # no sample: no colour gradient, no update (the grids move: TV)
+    with torch.no_grad():
+        m.density.grid.copy_(dens_saved)
+    # (c) + (d) ragged batches: fused = chain
+    g = torch.Generator().manual_seed(77)
+    for n in (1, 67):
+        oo = (torch.rand(n, 3, generator=g) * 2 - 1).to(dev) * (3.0 if kind == "dvgo" else 1.5)
+        dd = torch.randn(n, 3, generator=g).to(dev)
+        if n > 4:
+            dd[0] = torch.tensor([0.0, 0.0, 1.0], device=dev)                # axis-aligned: two zero components
+            dd[1] = torch.tensor([1.0, 0.0, 0.0], device=dev)
+            oo[2] = torch.tensor([5.0, 5.0, 5.0], device=dev); dd[2] = torch.tensor([1.0, 1.0, 1.0], device=dev)    # points away: misses
+            oo[3] = torch.zeros(3, device=dev)                                 # starts at the centre
+        vv = dd / dd.norm(dim=-1, keepdim=True)
+        res = {}
+        for fused in (True, False):
+            m.fused_forward = fused
+            with torch.no_grad():
+                res[fused] = m(oo, dd, vv, global_step=1, is_train=True, **kw)
+        m.fused_forward = True
+        a, b = res[True], res[False]
+        assert torch.equal(a["ray_id"], b["ray_id"]), n
+        if kind == "dvgo":
+            assert torch.equal(a["weights"], b["weights"]) and torch.equal(a["alphainv_last"], b["alphainv_last"])
+        else:
+            assert torch.equal(a["step_id"], b["step_id"])
+            assert float((a["weights"] - b["weights"]).abs().max() if a["weights"].numel() else 0.0) <= 2e-6
+        assert float((a["rgb_marched"] - b["rgb_marched"]).abs().max()) <= 5e-6
