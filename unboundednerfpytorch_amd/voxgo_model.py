@@ -209,8 +209,13 @@ class DirectVoxGO(_VoxGOBase):
         if mask_cache_world_size is None:
             mask_cache_world_size = self.world_size
         if mask_cache_path:
-            prior = _grid.MaskGrid(path=mask_cache_path, mask_cache_thres=mask_cache_thres).to(self.xyz_min.device)
-            mask = prior(self._vertices(mask_cache_world_size).to(prior.mask.device))
+            # the coarse stage's geometry, looked up at this model's mask vertices (dvgo.py:125-136).  The lookup is a HIP kernel:
+            # the model is usually built on the host and moved afterwards, so the prior is evaluated on the current HIP device
+            if not torch.cuda.is_available():
+                raise RuntimeError("mask_cache_path needs a HIP device (the mask-cache lookup has no CPU path)")
+            dev = torch.device("cuda", torch.cuda.current_device())
+            prior = _grid.MaskGrid(path=mask_cache_path, mask_cache_thres=mask_cache_thres).to(dev)
+            mask = prior(self._vertices(mask_cache_world_size).to(dev)).cpu()
         else:
             mask = torch.ones([int(x) for x in mask_cache_world_size], dtype=torch.bool)
         self.mask_cache = self._new_mask(mask)
