@@ -743,3 +743,41 @@ def test_sparse_touched_line_exchange_equals_the_dense_collectives_gloo():
                 assert e["mode"] == "sparse" and e["all_gather_bytes"] < e["dense_bytes_each_way"] // 3, e
             else:                                               # every element of the range moves: the gather stays dense
                 assert e["all_gather_bytes"] == e["dense_bytes_each_way"], e
+
+
+def test_maybe_scale_grids_serves_both_model_families():
+    """run_train.py:187-201: at a pg_scale step FourierGridModel.scale_volume_grid takes (density, rgb) voxel counts, DirectVoxGO /
+    DirectContractedVoxGO one count -- which the reference's configs carry as `num_voxels_rgb`; the optimizer is rebuilt and
+    act_shift lowered by decay_after_scale; any other step leaves everything alone"""
+    import torch
+    from unboundednerfpytorch_amd import train_step as ts
+
+    class Stub(torch.nn.Module):
+        def __init__(self, two):
+            super().__init__()
+            self.density = torch.nn.Linear(2, 2)
+            self.register_buffer("act_shift", torch.zeros(1))
+            self.calls = []
+            if two:
+                self.num_voxels_density = 1
+
+        def scale_volume_grid(self, *a):
+            self.calls.append(a)
+
+    cfg_train = dict(pg_scale=[10, 20, 30], decay_after_scale=0.5, lrate_density=1e-1, lrate_decay=20, skip_zero_grad_fields=[])
+    built = []
+    orig = ts.create_optimizer_or_freeze_model
+    ts.create_optimizer_or_freeze_model = lambda model, cfg, global_step, **kw: built.append(global_step) or "new-optimizer"
+    try:
+        for two, cfg_model, want in ((True, dict(num_voxels_density=8000, num_voxels_rgb=64000), [(2000, 16000), (4000, 32000), (8000, 64000)]),
+                                     (False, dict(num_voxels_rgb=64000, num_voxels_density=1), [(16000,), (32000,), (64000,)]),
+                                     (False, dict(num_voxels=64000), [(16000,), (32000,), (64000,)])):
+            m = Stub(two)
+            assert ts.maybe_scale_grids(m, "old", cfg_train, cfg_model, 11) == "old" and not m.calls
+            for step in (10, 20, 30):
+                assert ts.maybe_scale_grids(m, "old", cfg_train, cfg_model, step) == "new-optimizer"
+            assert m.calls == want, (m.calls, want)
+            assert float(m.act_shift) == -1.5
+    finally:
+        ts.create_optimizer_or_freeze_model = orig
+    assert built == [0] * 9

@@ -31,8 +31,12 @@ def maybe_scale_grids(model, optimizer, cfg_train, cfg_model, global_step, **opt
     if hasattr(model, 'num_voxels_density'):
         model.scale_volume_grid(int(_get(cfg_model, 'num_voxels_density') / (2 ** rest)),
                                 int(_get(cfg_model, 'num_voxels_rgb') / (2 ** rest)))
-    else:       # voxgo_model.DirectVoxGO / DirectContractedVoxGO: one resolution for both grids (run_train.py:190-196)
-        model.scale_volume_grid(int(_get(cfg_model, 'num_voxels') / (2 ** rest)))
+    else:       # voxgo_model.DirectVoxGO / DirectContractedVoxGO: one resolution for both grids.  The reference's configs carry it
+        # as `num_voxels_rgb` (run_train.py:190-194 scales these models with cur_voxels_rgb); a plain `num_voxels` is accepted too
+        nv = _get(cfg_model, 'num_voxels', None)
+        if nv is None:
+            nv = _get(cfg_model, 'num_voxels_rgb')
+        model.scale_volume_grid(int(nv / (2 ** rest)))
     optimizer = create_optimizer_or_freeze_model(model, cfg_train, global_step=0, **optimizer_kw)
     model.act_shift -= _get(cfg_train, 'decay_after_scale', 0.0)
     return optimizer
