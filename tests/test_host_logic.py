@@ -781,3 +781,37 @@ def test_maybe_scale_grids_serves_both_model_families():
     finally:
         ts.create_optimizer_or_freeze_model = orig
     assert built == [0] * 9
+
+
+def test_install_model_classes_rebinds_the_reference_classes():
+    """compat.install_model_classes: the reference's dvgo / dcvgo / FourierGrid_model modules then hand out this package's training
+    models (same constructor arguments: built here with the reference's own keyword names), and the originals come back"""
+    import sys
+    import pytest
+    from oracle import install_stubs
+    if not install_stubs.reference_available():
+        pytest.skip("reference tree not present")
+    from unboundednerfpytorch_amd import compat, fourier_model, voxgo_model
+    dvgo = install_stubs.import_reference("dvgo")
+    dcvgo = install_stubs.import_reference("dcvgo")
+    fgm = install_stubs.import_reference("FourierGrid_model")
+    orig = compat.install_model_classes()
+    try:
+        assert dvgo.DirectVoxGO is voxgo_model.DirectVoxGO and dcvgo.DirectContractedVoxGO is voxgo_model.DirectContractedVoxGO
+        assert fgm.FourierGridModel is fourier_model.FourierGridModel
+        # create_new_model's call shapes (run_train.py:32-50), incl. the extra keys its **model_kwargs carry
+        extra = dict(num_voxels_base_density=8 ** 3, num_voxels_base_rgb=8 ** 3, num_voxels_viewdir=-1, density_type='DenseGrid',
+                     k0_type='DenseGrid', density_config={}, k0_config={}, mpi_depth=128, nearest=False, pre_act_density=False,
+                     in_act_density=False, bbox_thres=1e-3, mask_cache_thres=1e-3, rgbnet_dim=12, rgbnet_full_implicit=False,
+                     rgbnet_direct=True, rgbnet_depth=3, rgbnet_width=128, alpha_init=1e-2, fast_color_thres=1e-4,
+                     maskout_near_cam_vox=False, world_bound_scale=1.05, stepsize=0.5, fourier_freq_num=3, sample_num=-1)
+        m1 = dvgo.DirectVoxGO(xyz_min=[-1, -1, -1], xyz_max=[1, 1, 1], num_voxels=8 ** 3, num_voxels_base=extra['num_voxels_base_rgb'],
+                              mask_cache_path=None, **extra)
+        m2 = dcvgo.DirectContractedVoxGO(xyz_min=[-1, -1, -1], xyz_max=[1, 1, 1], num_voxels=8 ** 3, num_voxels_base=extra['num_voxels_base_rgb'],
+                                         **extra)
+        assert isinstance(m1, dvgo.DirectVoxGO) and isinstance(m2, dcvgo.DirectContractedVoxGO)
+        assert set(m1.state_dict()) >= {"density.grid", "k0.grid", "mask_cache.mask", "rgbnet.0.weight"}
+        assert m2.get_kwargs()["contracted_norm"] == "inf"
+    finally:
+        dvgo.DirectVoxGO, dcvgo.DirectContractedVoxGO, fgm.FourierGridModel = orig
+    assert dvgo.DirectVoxGO is orig[0]
