@@ -815,3 +815,18 @@ def test_install_model_classes_rebinds_the_reference_classes():
     finally:
         dvgo.DirectVoxGO, dcvgo.DirectContractedVoxGO, fgm.FourierGridModel = orig
     assert dvgo.DirectVoxGO is orig[0]
+
+
+def test_fouriergrid_model_has_the_method_the_reference_program_calls():
+    """run_train.py:160-161 calls model.gather_training_rays(...) for the FourierGrid datasets: the method delegates to train_rays"""
+    from unboundednerfpytorch_amd import fourier_model, train_rays
+    seen = {}
+    orig = train_rays.gather_training_rays
+    train_rays.gather_training_rays = lambda model, *a: seen.setdefault("args", (model,) + a) and "seven-tuple"
+    try:
+        m = fourier_model.FourierGridModel([-1, -1, -1], [1, 1, 1], num_voxels_density=8 ** 3, num_voxels_base_density=8 ** 3,
+                                           num_voxels_rgb=8 ** 3, num_voxels_base_rgb=8 ** 3, alpha_init=1e-3, fourier_freq_num=1, rgbnet_dim=12)
+        assert m.gather_training_rays("dd", "im", "cfg", "it", "ct", "po", "hw", "ks", "rk") == "seven-tuple"
+        assert seen["args"] == (m, "dd", "im", "cfg", "it", "ct", "po", "hw", "ks", "rk")
+    finally:
+        train_rays.gather_training_rays = orig

@@ -205,6 +205,12 @@ class FourierGridModel(nn.Module):
                 count += (ones.grad > 1)
         return count
 
+    def gather_training_rays(self, data_dict, images, cfg, i_train, cfg_train, poses, HW, Ks, render_kwargs):
+        """The reference calls this as a METHOD of the model for its FourierGrid datasets (run_train.py:160-161,
+        FourierGrid_model.py:297-333); the implementation is train_rays.gather_training_rays."""
+        from .train_rays import gather_training_rays
+        return gather_training_rays(self, data_dict, images, cfg, i_train, cfg_train, poses, HW, Ks, render_kwargs)
+
     # -- forward ---------------------------------------------------------------------------------------------
     def sample_ray(self, ori_rays_o, ori_rays_d, stepsize, **unused):
         """Mid-point samples shared by all rays, contracted outside the unit cube / ball (:509-552)."""
