@@ -47,6 +47,13 @@ def test_python_binding_table_matches_header(lib_path):
     q16_img = (2 + 4) * 8 * 2 * 64 * 4 + 128 + 512 + 4 + 4          # 16x16x32 chain: A1 | A2 | bias2 | W3 | b3 | scales
     assert lib.ugrid_mlp_packed_bytes(12, 4) == 4 * (fp32_img + bf16_img + fp16_img + q16_img)
     assert lib.ugrid_render_ws_bytes(64, 256) >= 64 * 256 * 17
+    # the work list's layout (csrc/ugrid_render.h: ug_ws_make): tile counter | count | entries | ray slots | embedding rows (round 4:
+    # 32 floats per ray for the 4 + 8 / 5 + 7 shade geometries) -- the byte count must cover every region, for ragged ray counts too
+    a256 = lambda x: (x + 255) & ~255
+    for n_rays, S in ((64, 256), (1, 7), (65, 668), (1920 * 1080, 256), (1000003, 1068)):
+        nt = (n_rays + 63) // 64
+        cap = 64 * S
+        assert lib.ugrid_render_ws_bytes(n_rays, S) == 256 + a256(nt * 4) + a256(nt * cap * 16) + a256(nt * cap) + a256(nt * 64 * 32 * 4)
 
 
 def test_code_object_is_gfx950_only(lib_path):
