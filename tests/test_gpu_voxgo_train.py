@@ -101,6 +101,37 @@ def test_dcvgo_sample_table_and_derived_constants_match_the_reference(case, gold
     assert interval == float(torch.tensor(kw["stepsize"]) * m.voxel_size_ratio) and stepdist == float(kw["stepsize"] * m.voxel_size)
 
 
+def test_dvgo_march_slots_cover_the_longest_ray():
+    """DirectVoxGO.forward sizes the march's per-ray slots as ceil(box diagonal / stepdist) + 2 and the kernel clamps a ray's step
+    count to it ("never binding"): checked here on the CPU against the oracle's infer_t_minmax / infer_n_samples (the restatement of
+    render_utils_kernel.cu:16-57 the kernel follows) for rays from inside, outside, grazing, axis-aligned and missing the box,
+    several boxes, near planes and step sizes"""
+    import math
+    from oracle import ref_ops
+    g = torch.Generator().manual_seed(5)
+    worst = 0.0
+    for lo, hi in (([-1.0, -1.0, -1.0], [1.0, 1.0, 1.0]), ([-1.0, -0.8, -1.1], [1.0, 0.9, 1.0]), ([0.2, -3.0, 1.0], [0.9, 4.0, 1.5])):
+        lo_t, hi_t = torch.tensor(lo), torch.tensor(hi)
+        diag = float((hi_t - lo_t).norm())
+        n = 20000
+        o = lo_t + (hi_t - lo_t) * (torch.rand(n, 3, generator=g) * 3 - 1)          # inside and around the box
+        d = torch.randn(n, 3, generator=g) * torch.rand(n, 1, generator=g) * 3
+        d[:200, 1:] = 0.0                                                            # axis-aligned (the 1e-6 replacement)
+        d[200:400, 2] = 0.0
+        o[400:600] = lo_t - 5.0                                                      # far outside, mostly missing
+        # corner to corner: the longest chord
+        o[600] = lo_t - 1e-3 * (hi_t - lo_t); d[600] = hi_t - lo_t
+        o[601] = hi_t.clone(); d[601] = lo_t - hi_t
+        for near in (0.0, 0.05, 0.2, 2.0):
+            for stepdist in (0.004, 0.0131, 0.5):
+                t_min, t_max = ref_ops.infer_t_minmax(o.contiguous(), d.contiguous(), lo_t, hi_t, near, 1e9)
+                steps = ref_ops.infer_n_samples(d.contiguous(), t_min, t_max, stepdist)
+                slots = int(math.ceil(diag / stepdist)) + 2
+                assert int(steps.max()) <= slots, (lo, near, stepdist, int(steps.max()), slots)
+                worst = max(worst, int(steps.max()) / slots)
+    assert worst > 0.9            # the corner-to-corner rays do come close to the bound: the test exercises it
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,case", ALL, ids=IDS)
 def test_fused_training_forward_backward_matches_the_reference_model(kind, case, golden_dir):
