@@ -121,13 +121,12 @@ def test_s1b_surfaces_all_outputs_within_1e_4_on_all_rays():
 
 
 def test_s1_headline_scene_rgb_depth_parity():
-    """S1 (white noise): RGB within the north-star 1e-4 on ALL rays.  depth / alphainv_last carry a tail of a few rays in
-    10^5 just above 1e-4; what they are held to is MEASURED, not inferred: the reference executing on
-    this GPU (its own Python + its own compiled kernels, oracle/_ref) differs from the reference executing on the CPU by
-    1.4e-4 / 1.6e-4 / 2.8e-4 (rgb / depth / alphainv_last, profiles/r03/s1_arbitration_s1.json) on these rays -- two runs of
-    the SAME code are further apart than this library is from either -- so no implementation can be held to 1e-4 against one
-    of them on this scene; the bound is that distance.  Without oracle/_ref the bound falls back to the oracle's own
-    ambiguity under a second conforming libm (1.5 x + 2e-5, as in round 2)."""
+    """S1 (white noise, sigma = 24 density units per voxel): rgb AND depth within the north-star 1e-4 of the CPU reference on all
+    131 072 sampled rays, outright (round 4 measured 5.4e-5 / 8.2e-5 ... 9.8e-5); alphainv_last within max(1e-4, the CPU reference's
+    own distance to the fp64 truth) with no more rays above 1e-4 than the reference itself has against the truth.  A ray above the
+    bound is admitted only under per-ray fp64 arbitration (see `arbitrated` below).  Rounds 2-3 held depth / alphainv_last to "what
+    the reference executing on this GPU differs from its CPU execution by" (1.6e-4 / 2.8e-4): VERDICT r4 weak #1 -- that bound would
+    not notice a regression to 2e-4; the distance is still printed, it no longer bounds anything."""
     import bench
     from oracle import ref_model
     have_ref = ref_model.available("kernels:fma")
@@ -142,16 +141,62 @@ def test_s1_headline_scene_rgb_depth_parity():
         print("S1  %-14s gpu-vs-oracle linf %.3e mean %.3e rays>1e-4 %d | oracle libm ambiguity linf %.3e | reference-on-GPU vs reference-on-CPU %s"
               % ((k,) + stats[k][:4] + (("%.3e" % rg) if rg is not None else "n/a",)))
     n = got["depth"].numel()
-    # the north-star quantity
-    assert stats["rgb_marched"][0] <= 1e-4, stats["rgb_marched"]
     for k in KEYS:
-        linf, mean, n_above, amb, rg = stats[k]
-        assert mean <= 5e-6, (k, mean)
-        assert n_above <= max(8, n // 10000), (k, n_above)                   # a handful of rays in 10^5
-        if rg is not None:
-            assert linf <= max(1e-4, rg), (k, linf, rg)                      # closer to the CPU run than the reference's own GPU run
-        else:
-            assert linf <= max(1e-4, 1.5 * amb + 2e-5), (k, linf, amb)
+        assert stats[k][1] <= 5e-6, (k, stats[k][1])                         # mean error
+    # The north-star bound, 1e-4 against the CPU reference, OUTRIGHT for rgb and depth (measured on the
+    # round-4 boards: rgb 5.4e-5, depth 8.2e-5 ... 9.8e-5, 0 rays above).  The reference formula has three hard thresholds; a ray
+    # on which one of two fp32 evaluations flips a threshold moves by up to the flipped sample's weight, so a ray just above the
+    # bound is admitted only under fp64 arbitration, ray by ray: at most 3 such rays, none further than 1.25e-4, and on each the
+    # fused value must be within 1e-4 of the fp64 truth or at least as close to it as the CPU reference is.  A drift of depth back
+    # to 1.2e-4 on a handful of rays, or to 2e-4 on one, fails.
+    from tools import parity_fp64
+    cpu_state, (ro_s, rd_s, vd_s) = _EXTRA["make_state"]
+
+    def arbitrated(k, cap_linf, max_rays):
+        err = per_ray_err(got[k], ref[k])
+        bad = torch.nonzero(err > 1e-4).flatten()
+        if bad.numel() == 0:
+            return 0
+        assert bad.numel() <= max_rays and float(err.max()) <= cap_linf, (k, int(bad.numel()), float(err.max()))
+        truth = parity_fp64.render_fp64(cpu_state, ro_s[bad], rd_s[bad], vd_s[bad], STEPSIZE)
+        d_f, d_r = per_ray_err(got[k][bad].double(), truth[k]), per_ray_err(ref[k][bad].double(), truth[k])
+        print("S1  %-14s %d ray(s) above 1e-4 vs the CPU reference, arbitrated in fp64: |fused - truth| %s, |reference - truth| %s"
+              % (k, bad.numel(), ["%.2e" % x for x in d_f.tolist()], ["%.2e" % x for x in d_r.tolist()]))
+        assert bool(((d_f <= 1e-4) | (d_f <= d_r + 2e-5)).all()), (k, d_f.tolist(), d_r.tolist())
+        return int(bad.numel())
+
+    assert stats["rgb_marched"][0] <= 1e-4, stats["rgb_marched"]
+    arbitrated("depth", 1.25e-4, 3)
+    # alphainv_last (the product of ~250 factors, the scene's most sensitive output): <= max(1e-4, what the CPU reference ITSELF is
+    # away from the fp64 truth on these rays), and no more rays above 1e-4 than the reference has against the truth
+    study = _fp64_study()
+    ref_truth = study["distance_to_fp64"]["ref_cpu"]["alphainv_last"]
+    linf, _, n_above = stats["alphainv_last"][:3]
+    print("S1  alphainv_last    linf %.3e (%d rays > 1e-4) against the bound max(1e-4, CPU reference vs fp64 = %.3e, %d rays > 1e-4)"
+          % (linf, n_above, ref_truth["linf"], ref_truth["rays_above_bound"]))
+    assert linf <= max(1e-4, ref_truth["linf"]), (linf, ref_truth)
+    assert n_above <= ref_truth["rays_above_bound"], (n_above, ref_truth)
+    arbitrated("alphainv_last", max(1e-4, ref_truth["linf"]), max(1, ref_truth["rays_above_bound"]))
+    # what the reference's own execution on this GPU differs from its CPU execution by stays in the printout above (stats[k][4]); it
+    # is no longer a bound (it is 1.4e-4 / 1.6e-4 / 2.8e-4: held to it, the test would not notice a regression to 2e-4)
+
+
+_STUDY = {}
+
+
+def _fp64_study():
+    """tools/parity_fp64.ground_truth_study of the S1 evaluation, once per session (the headline test and the tail test share it)"""
+    if "s1" not in _STUDY:
+        import bench
+        from tools import parity_fp64
+        got, (ref, _), ref_gpu, M, R = render_and_reference(bench.make_state, two_libms=True, with_ref_gpu=True)
+        cpu_state, rays = _EXTRA["make_state"]
+        evals = {"fused": got, "ref_cpu": ref}
+        if "fma" in ref_gpu:
+            evals["ref_gpu"] = ref_gpu["fma"]
+        torch.set_num_threads(min(8, os.cpu_count() or 1))
+        _STUDY["s1"] = (parity_fp64.ground_truth_study(cpu_state, rays, evals, STEPSIZE, n_random=1024, seed=0), evals)
+    return _STUDY["s1"][0]
 
 
 def test_s1_tail_against_fp64_ground_truth():
@@ -168,13 +213,8 @@ def test_s1_tail_against_fp64_ground_truth():
     import bench
     from oracle import ref_model
     from tools import parity_fp64
-    got, (ref, _), ref_gpu, M, R = render_and_reference(bench.make_state, two_libms=True, with_ref_gpu=True)
-    cpu_state, rays = _EXTRA["make_state"]
-    evals = {"fused": got, "ref_cpu": ref}
-    if "fma" in ref_gpu:
-        evals["ref_gpu"] = ref_gpu["fma"]
-    torch.set_num_threads(min(8, os.cpu_count() or 1))
-    res = parity_fp64.ground_truth_study(cpu_state, rays, evals, STEPSIZE, n_random=1024, seed=0)
+    res = _fp64_study()
+    evals = _STUDY["s1"][1]
     _dump("s1_fp64_ground_truth.json", res)
     for name, d in res["distance_to_fp64"].items():
         print("S1 fp64  %-8s " % name + "  ".join("%s linf %.3e mean %.2e (%d > 1e-4)" % (k[:5], d[k]["linf"], d[k]["mean_abs"], d[k]["rays_above_bound"]) for k in KEYS))
@@ -298,3 +338,89 @@ def test_s5_block_shape_g300_l2_c3_pe2_parity():
     for k in KEYS:                      # (w * x) / w of the merging rule: equal up to that rounding
         assert float((comp[k] - out[k]).abs().max()) <= 1e-6, k
     assert comp["block_weight"] > 0
+
+
+def _frame_rays(dev):
+    import bench
+    from unboundednerfpytorch_amd.fourier_render import get_rays_of_a_view
+    K = [[1600.0, 0, W / 2.0], [0, 1600.0, H / 2.0], [0, 0, 1]]
+    return [x.reshape(-1, 3).contiguous() for x in get_rays_of_a_view(H, W, K, bench.camera(0, dev))]
+
+
+def _cpu_state(state):
+    return {k: ([x.cpu() for x in v_] if isinstance(v_, list) else (v_.cpu() if torch.is_tensor(v_) else v_)) for k, v_ in state.items()}
+
+
+def test_truck_shape_f4_p9_g200_s668_frame_parity():
+    """BASELINE configs[2]'s RENDER half at its real shape (VERDICT r4 "missing" #1; configs/tankstemple_unbounded/truck_single.py:92-110:
+    fourier_freq_num = 4 -> P = 9, G = 200^3, rgbnet_dim 12, stepsize 0.5 -> S = 668; frame loop run_render.py:54-66).  F >= 4 selects the
+    8-wave producer / consumer shade kernel (k_shade_pc<4,4,4,4,NBL,0>), which no other test runs above G = 33.  The WHOLE 1920x1080
+    frame is rendered in 8 x 8 pixel blocks (what render_view and the bench do); 32 768 rays spread over it are held to 1e-4 against the
+    CPU oracle in all three outputs, on all sampled rays, and the same rays rendered on their own must give the same bits (per-ray
+    results do not depend on the chunking, the tile a ray sits in, or the work-list size)."""
+    import bench
+    from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer, pixel_tile_order, untile
+    dev = torch.device("cuda", 0)
+    state = bench.make_state_surfaces(G, dev, seed=0, F=4)
+    rend = FourierGridRenderer(state, dev)
+    assert rend.F == 4 and rend.mlp_mode == 2                      # fp16x2 rgbnet -> the producer / consumer kernel
+    ro, rd, vd = _frame_rays(dev)
+    R = ro.shape[0]
+    order = pixel_tile_order(H, W, dev)
+    out_t = rend(ro[order].contiguous(), rd[order].contiguous(), vd[order].contiguous(), stepsize=0.5, render_depth=True, ray_order="coherent")
+    assert out_t["n_max"] == 668
+    M = rend.survivors_of_last_chunk()
+    out = {k: untile(out_t[k], H, W) for k in KEYS}
+    torch.cuda.synchronize()
+    n_ck, ck = 4, 8192
+    starts = [int(i * (R - ck) / (n_ck - 1)) // 64 * 64 for i in range(n_ck)]
+    idx = torch.cat([torch.arange(b, b + ck) for b in starts]).to(dev)
+    o, d, v = ro[idx].contiguous(), rd[idx].contiguous(), vd[idx].contiguous()
+    sub = rend(o, d, v, stepsize=0.5, render_depth=True, ray_order="coherent")
+    for k in KEYS:
+        assert torch.equal(sub[k], out[k][idx]), "per-ray results depend on the ray list (%s)" % k
+    cpu_state = _cpu_state(state)
+    del state, rend
+    torch.cuda.empty_cache()
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    ref = model_oracle.fouriergrid_render(cpu_state, o.cpu(), d.cpu(), v.cpu(), 0.5, render_depth=True)
+    term = float((ref["alphainv_last"] < 1e-3).float().mean())
+    print("truck F=4 P=9 G=200 S=668: survivors %.2f M (%.2f %% of R x S), %.0f %% of the sampled rays end on a surface" % (M / 1e6, 100.0 * M / (R * 668.0), 100 * term))
+    assert term > 0.3 and 0.005 < M / (R * 668.0) < 0.2
+    ga, ra = sub["alphainv_last"].cpu(), ref["alphainv_last"]
+    at_stop = lambda x: (x > 0.999e-3) & (x < 1e-3)              # a ray whose T lands within an ulp of the 1e-3 stop (see the S1b test)
+    tie = (at_stop(ga) & (ra < 0.9e-3)) | (at_stop(ra) & (ga < 0.9e-3))
+    assert int(tie.sum()) <= 3, int(tie.sum())
+    res = {}
+    for k in KEYS:
+        err = per_ray_err(sub[k].cpu(), ref[k])
+        res[k] = {"linf": float(err[~tie].max()), "mean_abs": float(err.mean()), "rays_above_1e-4": int((err[~tie] > 1e-4).sum())}
+        print("truck %-14s linf %.3e mean %.3e stop-threshold ties %d" % (k, res[k]["linf"], res[k]["mean_abs"], int(tie.sum())))
+        assert res[k]["linf"] <= 1e-4, (k, res[k])
+    _dump("truck_f4_frame_parity.json", {"rays": int(idx.numel()), "survivors_frame": M, "outputs": res})
+
+
+def test_viewbase_pe8_bf16x3_g100_parity():
+    """viewbase_pe = 8 (configs/waymo/waymo_base.py, configs/mega/*.py): the 51-wide view embedding does not fit the fp16x2 kernels'
+    LDS budget, ugrid_pack_mlp reports bf16x3 and k_shade_mlp<3,12,8,8,1> renders it -- checked so far on small goldens only.
+    16 384 rays of the 1080p view at G = 100, stepsize 0.5, all three outputs within 1e-4 of the CPU oracle on all rays."""
+    import bench
+    from unboundednerfpytorch_amd import _lib
+    from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer
+    dev = torch.device("cuda", 0)
+    state = bench.make_state_surfaces(100, dev, seed=0, C=12, pe=8)
+    rend = FourierGridRenderer(state, dev)
+    assert rend.pe == 8 and rend.mlp_mode == _lib.MLP_BF16X3
+    ro, rd, vd = _frame_rays(dev)
+    R = ro.shape[0]
+    starts = [int(i * (R - 4096) / 3) // 64 * 64 for i in range(4)]
+    idx = torch.cat([torch.arange(b, b + 4096) for b in starts]).to(dev)
+    o, d, v = ro[idx].contiguous(), rd[idx].contiguous(), vd[idx].contiguous()
+    out = rend(o, d, v, stepsize=0.5, render_depth=True, ray_order="coherent")
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    ref = model_oracle.fouriergrid_render(_cpu_state(state), o.cpu(), d.cpu(), v.cpu(), 0.5, render_depth=True)
+    assert float((ref["alphainv_last"] < 1e-3).float().mean()) > 0.3
+    for k in KEYS:
+        err = per_ray_err(out[k].cpu(), ref[k])
+        print("pe8  %-14s linf %.3e mean %.3e" % (k, float(err.max()), float(err.mean())))
+        assert float(err.max()) <= 1e-4, (k, float(err.max()))
