@@ -61,7 +61,6 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the S1b secondary scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--contiguous", action="store_true", help="N>1: contiguous ray bands instead of interleaved 64-ray tiles")
-    ap.add_argument("--single-launch", action="store_true", help="single persistent launch instead of march + shade")
     ap.add_argument("--mlp-mode", type=int, default=None, help="rgbnet arithmetic: 0 fp32 MFMA, 1 bf16x3, 2 fp16x2 (default: what ugrid_pack_mlp reports usable)")
     ap.add_argument("--pipeline", type=int, default=0, help="ray chunks software-pipelined over two streams (0 = off)")
     ap.add_argument("--tune", action="append", default=[], help="key=value speed knob (ugrid_tune), repeatable")
@@ -218,7 +217,7 @@ class FrameBench:
             self.stepsize = float(args.stepsize)      # e.g. 0.5: garden_single.py's own sampling (S = 668 at G = 200)
         if renderer is None:
             from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer
-            renderer = FourierGridRenderer(state, device, fused=args.single_launch, pipeline=args.pipeline, mlp_mode=args.mlp_mode)
+            renderer = FourierGridRenderer(state, device, pipeline=args.pipeline, mlp_mode=args.mlp_mode)
         self.rend = renderer
         # the frame's rays are in pixel-block (or row-segment) order by construction: no coherence check (= no host sync) in
         # the timed step; --shuffle-rays measures the raw kernels on incoherent tiles, so it opts out of the renderer's sort too
@@ -378,9 +377,7 @@ class FrameBench:
         return (ro, rd, vd), out, M
 
 
-def kernel_ms(timing, steps, single_launch):
-    if single_launch:
-        return {"render_fused": sum(ev[0].elapsed_time(ev[1]) for ev, _ in timing) / steps}
+def kernel_ms(timing, steps):
     # (pipelined frames carry 4 events per chunk; the kernels of neighbouring chunks overlap then)
     return {"render_march": sum(ev[0].elapsed_time(ev[1]) for ev, _ in timing) / steps,
             "render_shade": sum(ev[-2].elapsed_time(ev[-1]) for ev, _ in timing) / steps}
@@ -553,7 +550,7 @@ def truck_render_block(args, device, want_cpu):
         torch.cuda.empty_cache()
         steps = max(4, args.steps // 2)
         dt, timing = fb.timed(steps, 1)
-        kern = kernel_ms(timing, steps, False)
+        kern = kernel_ms(timing, steps)
         rays, out, M = fb.full_frame()
         R, S, P = fb.R, fb.S, 1 + 2 * F
         t = dt / steps
@@ -691,14 +688,14 @@ def main():
 
     dt, timing = fb.timed(args.steps, args.warmup)
     fb.check_exchange()
-    kern = kernel_ms(timing, args.steps, args.single_launch)
+    kern = kernel_ms(timing, args.steps)
     n_chunks = len(timing) // max(1, args.steps)
     rays_this_rank = sum(n for _, n in timing) // max(1, args.steps)
-    M_rank = fb.rend.survivors_of_last_chunk() if (not standin and n_chunks == 1 and not args.single_launch) else None
+    M_rank = fb.rend.survivors_of_last_chunk() if (not standin and n_chunks == 1) else None
     # per-rank kernel times (load imbalance of the strong-scaled frame)
     per_rank = None
     if use_dist:
-        mine = torch.tensor([kern.get("render_march", kern.get("render_fused", 0.0)), kern.get("render_shade", 0.0),
+        mine = torch.tensor([kern.get("render_march", 0.0), kern.get("render_shade", 0.0),
                              float(rays_this_rank)], device=device, dtype=torch.float64)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -769,7 +766,7 @@ def main():
             res["lib_sha16"] = lib_sha16()
             res["frame_sha16"] = frame_sha
             res["device_code_sha16"] = device_code_sha16()
-            if not args.single_launch and M_rank is not None:
+            if M_rank is not None:
                 # rank 0's own kernels: its share of the frame's rays and survivors (the whole frame at N = 1)
                 shade_passes = (M_rank + 31) // 32 + rays_this_rank // 64 // 2      # ~ sum over tiles of ceil(count / 32)
                 res["roofline"] = roofline_block(kern, M_rank, rays_this_rank, S, shade_passes, frame_rays=R, P=1 + 2 * args.freq,
@@ -803,7 +800,7 @@ def main():
         torch.cuda.empty_cache()
         steps2 = max(3, args.steps // 2)
         dt2, timing2 = fb2.timed(steps2, 1)
-        kern2 = kernel_ms(timing2, steps2, args.single_launch)
+        kern2 = kernel_ms(timing2, steps2)
         rays2, out2, M2 = fb2.full_frame()
         sec = {"workload": "S1b: same model shape, smooth fields with opaque surfaces (make_state_surfaces)",
                "value": fb2.R * fb2.S / (dt2 / steps2) / 1e6, "unit": "Msamples/s", "ms_per_step": dt2 / steps2 * 1e3, "steps": steps2,
@@ -818,7 +815,7 @@ def main():
             fb3 = FrameBench(g_args, None, device, 1, 0, None, renderer=fb2.rend)       # same packed bricks
             steps3 = max(4, args.steps // 2)
             dt3, timing3 = fb3.timed(steps3, 1)
-            kern3 = kernel_ms(timing3, steps3, args.single_launch)
+            kern3 = kernel_ms(timing3, steps3)
             _, out3, M3 = fb3.full_frame()
             res["secondary_garden_single_sampling"] = {
                 "workload": "S1b scene at garden_single.py's sampling: stepsize 0.5 -> S = %d samples per ray, fast_color_thres 1e-4" % fb3.S,

@@ -360,20 +360,6 @@ int ugrid_render_shade(const ugrid_render_params *h_params, const float *viewdir
                        const float *k0_bricks, const float *mlp_packed, void *ws,
                        float *rgb_marched, ugrid_stream_t stream);
 
-/* Single-launch render (march + shade fused in one persistent kernel; models with an rgbnet).  Every
- * persistent wave marches a 64-ray tile and immediately shades its survivors from a private scratch slot,
- * so the work list is only ugrid_render_fused_ws_bytes(S) (3072 wave slots x 64*S entries, independent of
- * the ray count) and the VALU-bound march of some waves overlaps the MFMA-bound rgbnet of others.
- * Same results, bit for bit, as ugrid_render_march + ugrid_render_shade. */
-int64_t ugrid_render_fused_ws_bytes(int32_t n_samples);
-int ugrid_render_fused(const ugrid_render_params *h_params, const float *rays_o, const float *rays_d,
-                       const float *viewdirs, const float *t_table, const float *s_table,
-                       const float *density_bricks, const float *k0_bricks, const float *mlp_packed,
-                       float *alphainv_last, float *depth, float *rgb_marched, void *ws,
-                       ugrid_stream_t stream);
-/* total survivors of the last ugrid_render_fused on this ws -> *d_stats (device int64) */
-int ugrid_render_fused_stats(const void *ws, int64_t *d_stats, ugrid_stream_t stream);
-
 /* rgbnet packing for the MFMA shade kernel: w0 [128, C+3+6pe], b0 [128], w1 [128,128], b1 [128],
  * w2 [3,128], b2 [3] (nn.Linear layout, FourierGrid_model.py:233-241) -> packed device array holding one
  * image per arithmetic mode.  k0_absmax: an upper bound on |k0 feature| (max |k0 grid value|: the feature is
@@ -487,7 +473,7 @@ int ugrid_train_sample_compact_vox(int64_t n_rays, int32_t slots_per_ray, float 
                                    float *alpha2, float *weights2, int64_t *ray_id2, int64_t *step_id2, float *t2,
                                    uint8_t *inner2, ugrid_stream_t stream);
 
-/* 1 when ugrid_render_shade / ugrid_render_fused have an rgbnet instantiation (depth 3, width 128) for this
+/* 1 when ugrid_render_shade has an rgbnet instantiation (depth 3, width 128) for this
  * (fourier_freq_num, k0 channels, viewbase_pe) triple, else 0 (they return hipErrorNotSupported for it). */
 int ugrid_shade_supported(int32_t freq_num, int32_t k0_channels, int32_t viewbase_pe);
 

@@ -44,16 +44,15 @@ def test_python_binding_table_matches_header(lib_path):
     fp32_img = 20 * 256 + 64 * 256 + 128 + 128 + 512 + 4
     bf16_img = (3 + 8) * 4 * 3 * 64 * 4 + 128 + 128 + 512 + 4
     fp16_img = (3 + 8) * 4 * 2 * 64 * 4 + 128 + 128 + 512 + 4 + 4
-    q16_img = (2 + 4) * 8 * 2 * 64 * 4 + 128 + 512 + 4 + 4          # 16x16x32 chain: A1 | A2 | bias2 | W3 | b3 | scales
-    assert lib.ugrid_mlp_packed_bytes(12, 4) == 4 * (fp32_img + bf16_img + fp16_img + q16_img)
+    assert lib.ugrid_mlp_packed_bytes(12, 4) == 4 * (fp32_img + bf16_img + fp16_img)
     assert lib.ugrid_render_ws_bytes(64, 256) >= 64 * 256 * 17
-    # the work list's layout (csrc/ugrid_render.h: ug_ws_make): tile counter | count | entries | ray slots | embedding rows (round 4:
-    # 32 floats per ray for the 4 + 8 / 5 + 7 shade geometries) -- the byte count must cover every region, for ragged ray counts too
+    # the work list's layout (csrc/ugrid_render.h: ug_ws_make): tile counter | count | entries | ray slots -- the byte count must
+    # cover every region, for ragged ray counts too
     a256 = lambda x: (x + 255) & ~255
     for n_rays, S in ((64, 256), (1, 7), (65, 668), (1920 * 1080, 256), (1000003, 1068)):
         nt = (n_rays + 63) // 64
         cap = 64 * S
-        assert lib.ugrid_render_ws_bytes(n_rays, S) == 256 + a256(nt * 4) + a256(nt * cap * 16) + a256(nt * cap) + a256(nt * 64 * 32 * 4)
+        assert lib.ugrid_render_ws_bytes(n_rays, S) == 256 + a256(nt * 4) + a256(nt * cap * 16) + a256(nt * cap)
 
 
 def test_code_object_is_gfx950_only(lib_path):
@@ -194,8 +193,7 @@ def _kernel_metadata(so):
 def test_product_kernels_fit_their_register_budget_without_scratch(lib_path):
     """Build-quality guard (no GPU needed): the kernels on the product path keep everything in registers -- no VGPR / SGPR
     spills, no scratch -- and stay inside the occupancy their design assumes: k_march <= 80 VGPR (6 waves / SIMD), the shade
-    kernel <= 256 (2 waves / SIMD with 8 waves per CU), streaming kernels <= 64.  (The measured-and-rejected A/B arms
-    k_shade_mlp16 / k_render_fused do spill; they are not checked.)"""
+    kernel <= 256 (2 waves / SIMD with 8 waves per CU), streaming kernels <= 64."""
     meta = _kernel_metadata(lib_path)
     assert len(meta) > 100
 
@@ -203,7 +201,7 @@ def test_product_kernels_fit_their_register_budget_without_scratch(lib_path):
         ks = [k for k in meta if k.startswith(prefix)]
         assert ks, prefix
         return ks
-    budget = {"_Z7k_marchILi": 80, "_Z11k_shade_mlpILi": 256, "_Z10k_shade_pcILi": 256, "_Z12k_shade_pc48ILi": 168, "_Z10k_view_embILi": 64, "_Z17k_train_march_voxILi": 128, "_Z14k_shade_direct": 128, "_Z13k_train_march": 128,
+    budget = {"_Z7k_marchILi": 80, "_Z11k_shade_mlpILi": 256, "_Z10k_shade_pcILi": 256, "_Z17k_train_march_voxILi": 128, "_Z14k_shade_direct": 128, "_Z13k_train_march": 128,
               "_Z15k_train_compact": 64, "_Z12k_grid_queryILb": 64, "_Z21k_grid_query_backwardILb": 64, "_Z12k_tv_cl_vec4ILb": 64,
               "_Z14k_tv_adam_vec4ILb": 64, "_Z9k_tv_vec4ILb": 64, "_Z11k_adam_vec4ILi": 64, "_Z17k_render_loss_fwd": 64,
               "_Z17k_render_loss_bwd": 64, "_Z14k_alpha2weight": 64, "_Z18k_alpha2weight_bwd": 64, "_Z16k_rays_of_a_view": 64,
@@ -216,8 +214,11 @@ def test_product_kernels_fit_their_register_budget_without_scratch(lib_path):
             w = re.match(r"_Z7k_marchILi\dELb[01]ELi(\d)EE", k)
             if w:                                           # k_march<F, L2, W>: W waves per SIMD -> 512 / W registers
                 limit = {4: 128, 5: 96, 6: 80}[int(w.group(1))]
+            lim = limit
+            if re.match(r"_Z10k_shade_pcILi\dELi\dELi6E", k):  # the 12-wave geometry (6 + 6): 3 waves per SIMD -> 168 registers
+                lim = 168
             assert m.get("vgpr_spill_count", 0) == 0 and m.get("sgpr_spill_count", 0) == 0 and m.get("private_segment_fixed_size", 0) == 0, (k, m)
-            assert m["vgpr_count"] <= limit, (k, m)
+            assert m["vgpr_count"] <= lim, (k, m)
 
 
 def _kernel_disassembly(so, name_prefix):
@@ -260,9 +261,11 @@ def test_shade_kernel_instruction_stream_regression(lib_path):
         MFMA issued right before it (the gfx950 dependent-MFMA observation, tools/microbench/mfma_dep_hazard.hip);
       * the hand-off polls sleep (s_sleep) instead of spinning."""
     import re
-    # (geometry, gather pattern): 8 waves = 6 items (36 loads) in flight, 12 waves = 3 items (18 loads)
+    # (geometry, gather pattern): 8 waves = 6 items (36 loads) in flight, 12 waves = 3 items (18 loads); F = 4 (truck_single.py,
+    # 18 items per pass) in the 12-wave geometry with the rolling cell set-up (round 5)
     for sym, want in (("_Z10k_shade_pcILi3ELi4ELi4ELi4ELi6ELi0E", "L" * 36 + ("<30>" + "L" * 6) * 8 + "<30><24><18><12><6><0>"),
-                      ("_Z10k_shade_pcILi3ELi4ELi6ELi2ELi3ELi1E", "L" * 18 + ("<12>" + "L" * 6) * 11 + "<12><6><0>")):
+                      ("_Z10k_shade_pcILi3ELi4ELi6ELi2ELi3ELi1E", "L" * 18 + ("<12>" + "L" * 6) * 11 + "<12><6><0>"),
+                      ("_Z10k_shade_pcILi4ELi4ELi6ELi2ELi3ELi1ELb1E", "L" * 18 + ("<12>" + "L" * 6) * 15 + "<12><6><0>")):
         asm = _kernel_disassembly(lib_path, sym)
         assert asm and len(asm) > 2000, sym
         ops = [l.split()[0] for l in asm]

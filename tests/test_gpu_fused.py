@@ -190,15 +190,9 @@ def test_fused_render_deterministic_chunk_and_order_invariant(fr):
         b2 = rend(o, d, v, stepsize=0.5, render_depth=True)
         assert torch.equal(a["rgb_marched"], b2["rgb_marched"])
     # two-kernel path (march -> work list -> shade) with a tiny work list, i.e. many chunks
-    small = fr.FourierGridRenderer(state, "cuda:0", max_ws_bytes=4 << 20, fused=False)
+    small = fr.FourierGridRenderer(state, "cuda:0", max_ws_bytes=4 << 20)
     assert small.rays_per_chunk(a["n_max"]) < R
     c = small(o, d, v, stepsize=0.5, render_depth=True)
-    # single persistent launch (instantiated for bf16x3 / fp32 rgbnet arithmetic only)
-    single = fr.FourierGridRenderer(state, "cuda:0", fused=True)
-    assert single.mlp_mode == 1
-    c2 = single(o, d, v, stepsize=0.5, render_depth=True)
-    a1 = fr.FourierGridRenderer(state, "cuda:0", mlp_mode=1)(o, d, v, stepsize=0.5, render_depth=True)
-    assert rend.survivors_of_last_chunk() == single.survivors_of_last_chunk()
     # software-pipelined chunks on two streams (march of chunk k+1 overlaps shade of chunk k), used twice so
     # the rotating work lists are re-used while the side streams still hold work
     piped = fr.FourierGridRenderer(state, "cuda:0", pipeline=5)
@@ -211,8 +205,7 @@ def test_fused_render_deterministic_chunk_and_order_invariant(fr):
     e2 = rend(o[perm].contiguous(), d[perm].contiguous(), v[perm].contiguous(), stepsize=0.5, render_depth=True, ray_order="sort")
     for k in ("rgb_marched", "depth", "alphainv_last"):
         assert torch.equal(a[k], b[k]), k
-        assert torch.equal(a[k], c[k]), k      # any chunking of the work list; single launch == two kernels
-        assert torch.equal(a1[k], c2[k]), k
+        assert torch.equal(a[k], c[k]), k      # any chunking of the work list
         assert torch.equal(a[k][perm], e[k]), k
         assert torch.equal(a[k][perm], e2[k]), k
     assert float(a["rgb_marched"].min()) >= 0 and float(a["rgb_marched"].max()) <= 1 + 1e-5

@@ -529,7 +529,7 @@ def _bench_worker(rank, world, port, q, contiguous, hw):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
     import bench
-    args = argparse.Namespace(height=hw[0], width=hw[1], grid=200, contiguous=contiguous, single_launch=False, pipeline=0, mlp_mode=None,
+    args = argparse.Namespace(height=hw[0], width=hw[1], grid=200, contiguous=contiguous, pipeline=0, mlp_mode=None,
                               ray_tile=8)
     fb = bench.FrameBench(args, None, torch.device("cpu"), world, rank, dist, renderer=_FakeRenderer())
     assert (fb.order is not None) == (hw[0] % 8 == 0 and hw[1] % 8 == 0)
@@ -556,7 +556,7 @@ def test_bench_strong_scaled_step_over_gloo(contiguous, hw):
     res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(timeout=60)
-    args = argparse.Namespace(height=hw[0], width=hw[1], grid=200, contiguous=contiguous, single_launch=False, pipeline=0, mlp_mode=None,
+    args = argparse.Namespace(height=hw[0], width=hw[1], grid=200, contiguous=contiguous, pipeline=0, mlp_mode=None,
                               ray_tile=0)
     fb = bench.FrameBench(args, None, torch.device("cpu"), 1, 0, None, renderer=_FakeRenderer())
     ro, rd, vd = fb.rays()                    # image order

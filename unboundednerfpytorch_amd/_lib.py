@@ -114,9 +114,6 @@ _SIGNATURES = {
     "ugrid_render_march_dcvgo": (_I, [_c.POINTER(RenderParams), _c.POINTER(DcvgoParams), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ugrid_render_march_dvgo": (_I, [_c.POINTER(RenderParams), _c.POINTER(DvgoParams), _P, _P, _P, _P, _P, _P, _P]),
     "ugrid_render_shade": (_I, [_c.POINTER(RenderParams), _P, _P, _P, _P, _P, _P]),
-    "ugrid_render_fused_ws_bytes": (_L, [_c.c_int32]),
-    "ugrid_render_fused": (_I, [_c.POINTER(RenderParams)] + [_P] * 13),
-    "ugrid_render_fused_stats": (_I, [_P, _P, _P]),
     "ugrid_mlp_packed_bytes": (_L, [_c.c_int32, _c.c_int32]),
     "ugrid_pack_mlp": (_I, [_P, _P, _P, _P, _P, _P, _c.c_int32, _c.c_int32, _c.c_int32, _c.c_float, _P,
                             _c.POINTER(_c.c_int32), _P]),

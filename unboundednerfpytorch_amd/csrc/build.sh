@@ -1,14 +1,12 @@
 #!/bin/bash
 # Build libugrid_hip.so for gfx950 (MI355X).  Usage: csrc/build.sh [extra hipcc flags]
 #   UG_OUT=path        alternative output (A/B builds); UG_OBJ=dir its object directory; UG_SHADE_FLAGS / UG_MARCH_FLAGS extra -D
-#   UG_EXPERIMENTS=1   also build the rejected A/B arms and the stand-alone gather variants (ugx_* symbols, the 16-wave
-#                      shade kernel, ugrid_tune("shade_dbg")): tools/ only, never the shipped library
 set -e
 cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include"
 O=${UG_OBJ:-../../build/obj}      # UG_OBJ: separate object directory (parallel A/B builds)
 mkdir -p $O
-rm -f $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_gather_exp.o $O/ugrid_train.o $O/ugrid_train_mlp.o   # a failed compile must not link a stale object
+rm -f $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_train.o $O/ugrid_train_mlp.o   # a failed compile must not link a stale object
 OBJS="$O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_train.o $O/ugrid_train_mlp.o"
 pids=()
 hipcc $FLAGS -c ugrid_ops.hip -o $O/ugrid_ops.o "$@" &
@@ -17,12 +15,6 @@ pids+=($!)
 # register pairs: the VALU-bound march kernel is 16 % faster without it, the shade kernel 1.3 %
 hipcc $FLAGS -fno-slp-vectorize ${UG_MARCH_FLAGS} -c ugrid_march.hip -o $O/ugrid_march.o "$@" &
 pids+=($!)
-if [ "${UG_EXPERIMENTS:-0}" = "1" ]; then
-  UG_SHADE_FLAGS="$UG_SHADE_FLAGS -DUG_EXPERIMENTS"
-  hipcc $FLAGS -fno-slp-vectorize -I. -c ../../tools/experiments/ugrid_gather_exp.hip -o $O/ugrid_gather_exp.o "$@" &
-  pids+=($!)
-  OBJS="$OBJS $O/ugrid_gather_exp.o"
-fi
 hipcc $FLAGS -fno-slp-vectorize ${UG_SHADE_FLAGS} -c ugrid_shade.hip -o $O/ugrid_shade.o "$@" &
 pids+=($!)
 hipcc $FLAGS -c ugrid_train.hip -o $O/ugrid_train.o "$@" &

@@ -851,8 +851,7 @@ k_march_dvgo(ug_march_args a, ug_dv_args dv, const float *__restrict__ rays_o, c
 // ----------------------------------------------------------------------------------------------
 extern "C" int64_t ugrid_render_ws_bytes(int64_t n_rays, int32_t S) {
   const int64_t n_tiles = (n_rays + UG_WAVE - 1) / UG_WAVE, cap = (int64_t)UG_WAVE * S;
-  return 256 + ug_align256(n_tiles * 4) + ug_align256(n_tiles * cap * 16) + ug_align256(n_tiles * cap) +
-         ug_align256(n_tiles * UG_WAVE * UG_EMB_ROW * (int64_t)sizeof(float));
+  return 256 + ug_align256(n_tiles * 4) + ug_align256(n_tiles * cap * 16) + ug_align256(n_tiles * cap);
 }
 
 static int ug_grid_query_any(bool cl, const float *grid, int P, int C, int X, int Y, int Z, const float *xyz,
@@ -953,9 +952,6 @@ extern "C" int ugrid_pack_bricks(const float *grid, int P, int C, int X, int Y, 
     return 0;
   }
   int coef = direct ? 0 : 1;
-#ifdef UG_CORNER_SUM
-  if (C == 1) coef = 0;   // A/B build: density bricks hold corner values (ug_density_level)
-#endif
   hipLaunchKernelGGL(k_pack_bricks, dim3((unsigned)blocks), dim3(256), 0, ST(s), grid, P, C, X, Y, Z, H, CH,
                      coef, bricks, total);
   UG_LAUNCH_CHECK();
@@ -1066,12 +1062,3 @@ extern "C" int ugrid_render_march_dvgo(const ugrid_render_params *p, const ugrid
 }
 
 
-#ifdef UG_MARCH_STATS
-// lane-efficiency study build only (-DUG_MARCH_STATS): {wave iterations, active lane-iterations, S per wave} since the last read
-extern "C" int ugx_march_stats_read(unsigned long long *host4) {
-  UG_HIP(hipMemcpyFromSymbol(host4, HIP_SYMBOL(g_march_stat), 32));
-  unsigned long long z[4] = {0, 0, 0, 0};
-  UG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_march_stat), z, 32));
-  return 0;
-}
-#endif

@@ -139,10 +139,8 @@ struct ug_ws_view {
   int32_t *count;   // [n_tiles]
   float4 *ent;      // [n_tiles][64*S]  (px, py, pz, weight)
   uint8_t *slot;    // [n_tiles][64*S]  ray slot (0..63) inside the tile
-  float *emb;       // [n_tiles*64][32] view-direction embedding rows (k_view_emb; the 4 + 8 shade geometry reads them from here)
   int64_t n_tiles, cap;
 };
-#define UG_EMB_ROW 32      // floats per ray: two halves of 16 (14 used: v | sin | cos of FourierGrid_model.py:640-643, split like KL)
 #define UG_FEAT_STRIDE 12
 
 __host__ __device__ static inline int64_t ug_align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
@@ -157,8 +155,6 @@ static inline ug_ws_view ug_ws_make(void *ws, int64_t n_rays, int32_t S) {
   v.ent = (float4 *)b;
   b += ug_align256(v.n_tiles * v.cap * (int64_t)sizeof(float4));
   v.slot = (uint8_t *)b;
-  b += ug_align256(v.n_tiles * v.cap);
-  v.emb = (float *)b;
   return v;
 }
 
@@ -187,33 +183,10 @@ __device__ __forceinline__ float ug_density_level(const char *__restrict__ lvl, 
   // byte offset of the cell record: the row index cx*(Y-1)+cy is exact in fp32 ((X-1)(Y-1) < 2^24), so it costs one
   // FMA + one convert; row * rowbytes is a full-rate 24-bit multiply (level < 4 GiB), then + cz*32.  The plain
   // integer form compiled to quarter-rate v_mad_u64_u32 pairs.
-#ifdef UG_MARCH_FCELL
-  // A/B arm (march diet, profiles/r04/march_ab.txt): the whole cell index in fp32 -- exact while (X-1)(Y-1)(Z-1) < 2^24
-  // (G <= 256; the host refuses the build's use otherwise) -- one convert and one shift instead of two converts, a shift and
-  // a 24-bit multiply-add
-  const unsigned off = (unsigned)fmaf(fmaf(ax.cellf, (float)(Y - 1), ay.cellf), (float)(Z - 1), az.cellf) << 5;
-#else
   const unsigned row = (unsigned)fmaf(ax.cellf, (float)(Y - 1), ay.cellf);
   const unsigned off = __umul24(row, (unsigned)(Z - 1) << 5) + ((unsigned)az.cell << 5);
-#endif
   const float4 *b = (const float4 *)(lvl + off);
   const float4 v0 = b[0], v1 = b[1];
-#ifdef UG_CORNER_SUM
-  // A/B build (tools/gpu_parity_ab.sh): bricks hold the 8 corner VALUES and the lookup is grid_sample's own weighted
-  // corner sum, weights (wz*wy)*wx, separate multiply and add in its accumulation order (tnw, tne, tsw, tse, bnw, ...)
-  {
-    const float zy00 = az.wlo * ay.wlo, zy10 = az.whi * ay.wlo, zy01 = az.wlo * ay.whi, zy11 = az.whi * ay.whi;
-    float r = v0.x * (zy00 * ax.wlo);
-    r = r + v0.y * (zy10 * ax.wlo);
-    r = r + v0.z * (zy01 * ax.wlo);
-    r = r + v0.w * (zy11 * ax.wlo);
-    r = r + v1.x * (zy00 * ax.whi);
-    r = r + v1.y * (zy10 * ax.whi);
-    r = r + v1.z * (zy01 * ax.whi);
-    r = r + v1.w * (zy11 * ax.whi);
-    return r;
-  }
-#endif
   // cell polynomial (k_pack_bricks): Horner in z, then y, then x -- 7 FMAs, no corner weights
   const float tz = az.whi, ty = ay.whi, tx = ax.whi;
   const float p00 = fmaf(v0.y, tz, v0.x), p01 = fmaf(v0.w, tz, v0.z);   // x^0: y^0, y^1
@@ -235,9 +208,6 @@ struct ug_dc_args {
 
 // March one 64-ray tile (lane = ray): writes alphainv_last / depth for the tile's rays, appends the
 // survivors to ent/slot (this wave's private list) and returns their count (wave-uniform).
-#ifdef UG_MARCH_STATS
-__device__ unsigned long long g_march_stat[4];
-#endif
 template <int F, bool L2, bool DC = false>
 __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float *__restrict__ rays_o,
                                              const float *__restrict__ rays_d, const float *__restrict__ t_table,
@@ -267,14 +237,8 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
   int nsurv = 0;  // wave-uniform
   [[maybe_unused]] float cum = 0.f, ppx = 0.f, ppy = 0.f, ppz = 0.f, wmid = 0.f;   // DC: cumdist recurrence, previous point
 
-#ifdef UG_MARCH_STATS
-  unsigned long long st_iter = 0, st_act = 0;   // lane-efficiency study (tools/gpu_march_stats.sh): iterations, active lanes
-#endif
   for (int j = 0; j < a.S; ++j) {
     if (__ballot(!done) == 0ull) break;  // every ray of this wave has terminated
-#ifdef UG_MARCH_STATS
-    st_iter += 1; st_act += __popcll(__ballot(!done));
-#endif
     bool surv = false;
     float w = 0.f;
     float px = 0.f, py = 0.f, pz = 0.f;
@@ -285,15 +249,6 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
       const float nrm = L2 ? ug_norm3_torch(px, py, pz) : fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz)));
       // A/B builds for the parity study (tools/gpu_parity_ab.sh): UG_EXACT_DIV = IEEE divisions instead of Markstein's,
       // UG_LIBM_SINCOS / UG_LIBM_ALPHA = the device libm instead of ugrid_math.h, UG_CORNER_SUM (ug_density_level)
-#ifdef UG_EXACT_DIV
-      if (!(nrm <= 1.0f)) {
-        const float sc = a.B - (1.0f / nrm) * a.A;
-        px = px / nrm * sc; py = py / nrm * sc; pz = pz / nrm * sc;
-      }
-      const float ux = ((px - a.lox) / a.ex) * 2.f - 1.f;
-      const float uy = ((py - a.loy) / a.ey) * 2.f - 1.f;
-      const float uz = ((pz - a.loz) / a.ez) * 2.f - 1.f;
-#else
       if (!(nrm <= 1.0f)) {
         const float rn = ug_rcp_refined(nrm);
         const float sc = a.B - rn * a.A;       // reciprocal(norm) * A, as torch evaluates `A / norm` (ug_contract above)
@@ -305,7 +260,6 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
       const float ux = ug_div_r(px - a.lox, a.ex, a.irx) * 2.f - 1.f;
       const float uy = ug_div_r(py - a.loy, a.ey, a.iry) * 2.f - 1.f;
       const float uz = ug_div_r(pz - a.loz, a.ez, a.irz) * 2.f - 1.f;
-#endif
       bool keep = true;
       [[maybe_unused]] bool inner = true;
       if constexpr (DC) {
@@ -328,51 +282,25 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
       }
       if (keep) {
         float dens = ug_density_level(bkb, ux, uy, uz, a.X, a.Y, a.Z);
-#ifdef UG_MARCH_DOUBLE_ANGLE
-        float pkx[2], pky[2], pkz[2];
-#endif
 #pragma unroll
         for (int k = 0; k < F; ++k) {
           const float f = (float)(1 << k);
           float sx, cx_, sy, cy_, sz, cz_;
-#ifdef UG_LIBM_SINCOS
-          sincosf(f * ux, &sx, &cx_);
-          sincosf(f * uy, &sy, &cy_);
-          sincosf(f * uz, &sz, &cz_);
-#else
           if (k == 0) {   // |u| <= 1 < pi/2: no range reduction needed, bit-identical (ug_sincos_small)
             ug_sincos_small(ux, &sx, &cx_);
             ug_sincos_small(uy, &sy, &cy_);
             ug_sincos_small(uz, &sz, &cz_);
-#ifdef UG_MARCH_DOUBLE_ANGLE
-            // A/B build only (priced in profiles/r03/march_ab.txt): the k >= 1 pairs by angle doubling
-            // from the k - 1 pair -- 3 VALU per pair instead of 19, but the error of the level coordinate doubles per level
-            pkx[0] = sx; pkx[1] = cx_; pky[0] = sy; pky[1] = cy_; pkz[0] = sz; pkz[1] = cz_;
-          } else if (true) {
-            { const float t2 = pkx[0] + pkx[0]; sx = t2 * pkx[1]; cx_ = fmaf(-t2, pkx[0], 1.0f); pkx[0] = sx; pkx[1] = cx_; }
-            { const float t2 = pky[0] + pky[0]; sy = t2 * pky[1]; cy_ = fmaf(-t2, pky[0], 1.0f); pky[0] = sy; pky[1] = cy_; }
-            { const float t2 = pkz[0] + pkz[0]; sz = t2 * pkz[1]; cz_ = fmaf(-t2, pkz[0], 1.0f); pkz[0] = sz; pkz[1] = cz_; }
-#endif
           } else {
             ug_sincos(f * ux, &sx, &cx_);
             ug_sincos(f * uy, &sy, &cy_);
             ug_sincos(f * uz, &sz, &cz_);
           }
-#endif
           dens += ug_density_level(bkb + (size_t)(2 * k + 1) * lvl_bytes, sx, sy, sz, a.X, a.Y, a.Z);
           dens += ug_density_level(bkb + (size_t)(2 * k + 2) * lvl_bytes, cx_, cy_, cz_, a.X, a.Y, a.Z);
         }
-#ifdef UG_EXACT_DIV
-        dens = dens / (float)P;
-#else
         dens = ug_div_r(dens, (float)P, 1.0f / (float)P);   // mean over levels: Markstein division, 3 VALU instead of 10
-#endif
         const float xs = dens + a.shift;
-#ifdef UG_LIBM_ALPHA
-        const float alpha = 1.0f - powf(1.0f + expf(xs), -a.interval);
-#else
         const float alpha = ug_alpha(xs, a.interval);
-#endif
         if (alpha > a.thres) {
           w = T * alpha;
           T = (float)((double)T * (1. - (double)alpha));
@@ -396,9 +324,6 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
       nsurv += __popcll(m);
     }
   }
-#ifdef UG_MARCH_STATS
-  if (lane == 0) { atomicAdd(&g_march_stat[0], st_iter); atomicAdd(&g_march_stat[1], st_act); atomicAdd(&g_march_stat[2], (unsigned long long)a.S); }
-#endif
   if (valid) {
     alphainv_last[ray] = T;
     depth[ray] = dsum;
@@ -518,8 +443,7 @@ __host__ __device__ static inline int ug_feat_of(int o, int r, int h) { return 3
 //   W3/(sW2*sX2) | b3 | {sX1, sX2/(sW1*sX1), 0, 0}
 struct ug_mlp_layout { int KL, offA1, offA2, offB1, offB2, offW3, offb3, total;
                        int KB1, bfA1, bfA2, bfB1, bfB2, bfW3, bfb3, total2;
-                       int hxA1, hxA2, hxB1, hxB2, hxW3, hxb3, hxS, total3;
-                       int qA1, qA2, qB2, qW3, qb3, qS, total4; };
+                       int hxA1, hxA2, hxB1, hxB2, hxW3, hxb3, hxS, total3; };
 // power-of-two scales of the fp16x2 image (ugrid_pack_mlp computes them on the host from the weights and the
 // caller's bound on |k0|)
 struct ug_mlp_scales { float sX1, sW1, sX2, sW2; };
@@ -550,37 +474,8 @@ __host__ __device__ static inline ug_mlp_layout ug_mlp_lay(int C, int n_emb) {
   L.hxb3 = L.hxW3 + 512;
   L.hxS = L.hxb3 + 4;
   L.total3 = L.hxS + 4;
-  // fourth image: fp16x2 operands for the 16x16x32 MFMA chain of k_shade_mlp16 (C = 12, PE = 4 only; see ug_shade_tile16):
-  //   qA1 [2 k-steps][8 tiles][2 parts][64 lanes][8 f16] | qA2 [4][8][2][64][8] | bias2 [4 groups][32] (x sW2 sX2) |
-  //   W3 [4 groups][32][4] (/ (sW2 sX2)) | b3 [4] | {sX1, sX2/(sW1 sX1), 0, 0}       (layer-1 bias rides in a K slot)
-  L.qA1 = L.total3;
-  L.qA2 = L.qA1 + 2 * 8 * 2 * 64 * 4;
-  L.qB2 = L.qA2 + 4 * 8 * 2 * 64 * 4;
-  L.qW3 = L.qB2 + 128;
-  L.qb3 = L.qW3 + 512;
-  L.qS = L.qb3 + 4;
-  L.total4 = L.qS + 4;
   return L;
 }
-
-// ---- K-slot maps of the 16x16x32 chain (C = 12, PE = 4): lane group jg = lane >> 4 supplies 16 layer-1 input slots
-//   0..2  k0 channels 3jg..3jg+2 (exactly what lane g = jg of a gather quad produces)
-//   3..8  (sin, cos) of the view-embedding pairs p = 3jg + (slot-3)/2, pair p = (axis p/4, frequency 2^(p%4))
-//   9     viewdir component jg (jg < 3) or the constant 1 whose weight column is the layer-1 bias (jg = 3)
-//   10..15 zero
-// returns the rgbnet input column, -1 for zero padding, -2 for the bias slot
-__host__ __device__ static inline int ug_q16_col(int slot, int jg) {
-  if (slot < 3) return 3 * jg + slot;
-  if (slot < 9) {
-    const int p = 3 * jg + ((slot - 3) >> 1), is_cos = (slot - 3) & 1;
-    return 12 + 3 + (is_cos ? 12 : 0) + p;      // sins: columns 15..26 ordered (axis, frequency) = p; cosines 27..38
-  }
-  if (slot == 9) return jg < 3 ? 12 + jg : -2;
-  return -1;
-}
-// layer-2 K slot (k-step ks, group jg, element e) = hidden feature 16 (2 ks + e/4) + 4 jg + e%4: the accumulator
-// registers [e%4] of tiles 2ks, 2ks+1 of the lane itself (C/D layout: rows 4 jg + r of a 16-row tile)
-__host__ __device__ static inline int ug_q16_feat(int ks, int jg, int e) { return 16 * (2 * ks + (e >> 2)) + 4 * jg + (e & 3); }
 
 // original rgbnet input column of (step s, half h); -1 = zero padding
 __host__ __device__ static inline int ug_in_col(int s, int h, int C, int n_emb, int KL) {
@@ -782,8 +677,10 @@ __device__ __forceinline__ void ug_k0_gather_begin(const float *__restrict__ k0b
     lc[0] = u;
 #pragma unroll
     for (int k = 0; k < F; ++k) {
-      if (k == 0) ug_sincos_small(u, &lc[1], &lc[2]);       // |u| <= 1: bit-identical without the range reduction
-      else ug_sincos((float)(1 << k) * u, &lc[2 * k + 1], &lc[2 * k + 2]);
+      if constexpr (F > 0) {      // (F = 0 has no Fourier levels: lc[1] would not exist)
+        if (k == 0) ug_sincos_small(u, &lc[1], &lc[2]);     // |u| <= 1: bit-identical without the range reduction
+        else ug_sincos((float)(1 << k) * u, &lc[2 * k + 1], &lc[2 * k + 2]);
+      }
     }
 #pragma unroll
     for (int l = 0; l < P; ++l) {
@@ -828,7 +725,7 @@ __device__ __forceinline__ void ug_k0_gather_finish(const float *__restrict__ k0
     // keep the item's math here: without the pin the scheduler hoists every later load above it (spills)
     asm volatile("" :: "v"(feat[i % NR][0]), "v"(feat[i % NR][1]), "v"(feat[i % NR][2]));
     __builtin_amdgcn_sched_barrier(0);
-    if (i + NBL < NI) UG_ISSUE_ITEM(st, i + NBL)
+    if (i + NBL < NI) { UG_ISSUE_ITEM(st, i + NBL) }
   }
 #pragma unroll
   for (int r = 0; r < NR; ++r)
@@ -919,8 +816,10 @@ __device__ __forceinline__ void ug_k0_gather_quad_roll(const float *__restrict__
     st.lc[r][0] = u;
 #pragma unroll
     for (int k = 0; k < F; ++k) {
-      if (k == 0) ug_sincos_small(u, &st.lc[r][1], &st.lc[r][2]);
-      else ug_sincos((float)(1 << k) * u, &st.lc[r][2 * k + 1], &st.lc[r][2 * k + 2]);
+      if constexpr (F > 0) {
+        if (k == 0) ug_sincos_small(u, &st.lc[r][1], &st.lc[r][2]);
+        else ug_sincos((float)(1 << k) * u, &st.lc[r][2 * k + 1], &st.lc[r][2 * k + 2]);
+      }
     }
   }
   const int64_t lvl_floats = (int64_t)(a.X - 1) * (a.Y - 1) * (a.Z - 1) * 96;
@@ -1183,13 +1082,8 @@ struct ug_kops { ug_hpart wl, wh; };
 // Optional phase profile (-DUG_SHADE_PROF, tools/gpu_shade_phases.sh): shader-clock ticks per phase of ug_shade_tile,
 // summed over all waves into g_shade_prof; phases: 0 tile set-up, 1 gather round 0, 2 gather round 1, 3 layer 1,
 // 4 layer 2, 5 layer 3 + sigmoid, 6 per-ray accumulation, 7 tile scheduling (outside this function)
-#ifdef UG_SHADE_PROF
-struct ug_prof { unsigned long long t, acc[8]; };
-#define UG_PROF_MARK(pr, i) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (pr).acc[i] += now_ - (pr).t; (pr).t = now_; }
-#else
 struct ug_prof { };
 #define UG_PROF_MARK(pr, i)
-#endif
 
 // One 32-survivor pass of the rgbnet + the ordered per-ray accumulation, shared by the classic shade tile loop
 // (ug_shade_tile) and the consumer waves of the producer / consumer kernel (ugrid_shade_pc.h).  Lane (h = lane >> 5,
@@ -1198,14 +1092,13 @@ struct ug_prof { };
 template <int C, int PE, int BF>
 __device__ __forceinline__ void ug_rgbnet_pass(const float (&x)[(2 * UG_CH(C) + 3 + 6 * PE + 1) / 2], float ww, int sl, bool ok,
                                                const ug_mlp_lds &M, unsigned *amask, float4 *aval, float &accr, float &accg,
-                                               float &accb, ug_prof &prof) {
+                                               float &accb) {
   constexpr int CH = UG_CH(C);
   constexpr int NEMB = 3 + 6 * PE;
   constexpr int KL = (2 * CH + NEMB + 1) / 2;
   const int lane = ug_lane();
   const int h = lane >> 5, sv = lane & 31;
   // ---- layers 1 and 2 on the matrix cores, transposed (H^T = W . X^T): accumulators feed the next layer
-  UG_PROF_MARK(prof, 2)
   f32x16 acc1[4], acc2[4];
   int bo = h * 64;
   asm volatile("" : "+v"(bo));  // keeps the 128 bias reads inside the pass (LICM would hoist + spill them)
@@ -1270,7 +1163,6 @@ __device__ __forceinline__ void ug_rgbnet_pass(const float (&x)[(2 * UG_CH(C) + 
       xs = xn;
     }
     ug_fence_results();
-    UG_PROF_MARK(prof, 3)
 #pragma unroll
     for (int o = 0; o < 4; ++o)
 #pragma unroll
@@ -1343,7 +1235,6 @@ __device__ __forceinline__ void ug_rgbnet_pass(const float (&x)[(2 * UG_CH(C) + 
     ug_fence_results();
   }
   // ---- layer 3 (3 outputs) on the VALU: each lane of the pair reduces its 64 features
-  UG_PROF_MARK(prof, 4)
   float l0 = 0.f, l1 = 0.f, l2 = 0.f;
   // W3 comes from LDS 16 rows at a time, all 16 reads issued before the first use: left to itself hipcc emits
   // read -> s_waitcnt -> 3 FMAs 64 times, one exposed LDS latency per hidden feature (phase profile: 3.3 k ticks)
@@ -1383,7 +1274,6 @@ __device__ __forceinline__ void ug_rgbnet_pass(const float (&x)[(2 * UG_CH(C) + 
   UG_RESIDUAL_ADD(M, x, l0, l1, l2)
   // weights.unsqueeze(-1) * rgb, then a per-ray sum in sample order (segment_coo semantics)
   const float pr = ww * ug_sigmoid(l0), pg = ww * ug_sigmoid(l1), pb = ww * ug_sigmoid(l2);
-  UG_PROF_MARK(prof, 5)
   {
     // per-ray sum in list (= sample) order through LDS: survivors publish their value and set their bit in the
     // owning ray's mask (ds_or: commutative, so deterministic); each ray lane then walks its bits upwards.
@@ -1406,7 +1296,6 @@ __device__ __forceinline__ void ug_rgbnet_pass(const float (&x)[(2 * UG_CH(C) + 
     }
     __builtin_amdgcn_wave_barrier();   // the next pass rewrites aval / amask
   }
-  UG_PROF_MARK(prof, 6)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1494,14 +1383,13 @@ __device__ __forceinline__ void ug_mfma3x4_v3(const f16x8 *__restrict__ Ap_next,
 template <int C, int PE, bool MASK_ZEROED, bool CARRY>
 __device__ __forceinline__ void ug_rgbnet_pass_h2(const float (&x)[(2 * UG_CH(C) + 3 + 6 * PE + 1) / 2], float ww, int sl, bool ok,
                                                   const ug_mlp_lds &M, unsigned *amask, float4 *aval, float &accr, float &accg,
-                                                  float &accb, ug_h2_state &st, ug_prof &prof) {
+                                                  float &accb, ug_h2_state &st) {
   constexpr int CH = UG_CH(C);
   constexpr int NEMB = 3 + 6 * PE;
   constexpr int KL = (2 * CH + NEMB + 1) / 2;
   constexpr int KB1 = (KL + 7) / 8;
   const int lane = ug_lane();
   const int h = lane >> 5, sv = lane & 31;
-  UG_PROF_MARK(prof, 2)
   int bo = h * 64;
   asm volatile("" : "+v"(bo));  // keeps the bias / W3 reads inside the pass (LICM would hoist + spill them)
   f32x16 acc2[4];
@@ -1535,7 +1423,6 @@ __device__ __forceinline__ void ug_rgbnet_pass_h2(const float (&x)[(2 * UG_CH(C)
     xs = xn;
   }
   ug_fence_results();
-  UG_PROF_MARK(prof, 3)
   {
     float v[8];
 #pragma unroll
@@ -1558,7 +1445,6 @@ __device__ __forceinline__ void ug_rgbnet_pass_h2(const float (&x)[(2 * UG_CH(C)
 #pragma unroll
   for (int i = 0; i < W3B / 4; ++i) w3[0][i] = ug_w3_load4(M, bo, 4 * i);
   ug_fence_results();
-  UG_PROF_MARK(prof, 4)
   // the NEXT pass's layer-1 biases into the (now dead) layer-1 accumulators: they land while layer 3 runs
   if constexpr (CARRY) ug_h2_preload(M, bo, st);
   // ---- layer 3 (3 outputs) on the VALU: each lane of the pair reduces its 64 hidden features
@@ -1585,7 +1471,6 @@ __device__ __forceinline__ void ug_rgbnet_pass_h2(const float (&x)[(2 * UG_CH(C)
   l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
   UG_RESIDUAL_ADD(M, x, l0, l1, l2)
   const float pr = ww * ug_sigmoid(l0), pg = ww * ug_sigmoid(l1), pb = ww * ug_sigmoid(l2);
-  UG_PROF_MARK(prof, 5)
   {
     // ordered per-ray sum through LDS, as in ug_rgbnet_pass
     if constexpr (!MASK_ZEROED) {
@@ -1607,7 +1492,6 @@ __device__ __forceinline__ void ug_rgbnet_pass_h2(const float (&x)[(2 * UG_CH(C)
     }
     __builtin_amdgcn_wave_barrier();   // the next pass rewrites aval / amask
   }
-  UG_PROF_MARK(prof, 6)
 }
 
 // Shade one tile's survivor list (32 survivors per pass, lanes l / l+32 pair up) and write the tile's
@@ -1619,7 +1503,7 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
                                               const float *__restrict__ k0b, const ug_mlp_lds &M, int64_t tile,
                                               int count, const float4 *__restrict__ ent,
                                               const uint8_t *__restrict__ slot,
-                                              float *__restrict__ scr, float *__restrict__ rgb_marched, ug_prof &prof) {
+                                              float *__restrict__ scr, float *__restrict__ rgb_marched) {
   constexpr int CH = UG_CH(C);
   constexpr int NEMB = 3 + 6 * PE;
   constexpr int KL = (2 * CH + NEMB + 1) / 2;
@@ -1658,7 +1542,6 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     ug_wave_lds_sync();
   }
 
-  UG_PROF_MARK(prof, 7)
   constexpr bool QUAD = (C == 12);
   const int qs = lane >> 2, qg = lane & 3;
   const ug_quad_axis qa = ug_quad_axis_of(a, qg);
@@ -1674,7 +1557,6 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
     if (16 + qs < count) pg1_n = ef[4 * (16 + qs) + (qg < 2 ? qg : 2)];
   }
   ug_gather_state<F, 4, 2> gst;
-  UG_PROF_MARK(prof, 0)
   for (int base = 0; base < count; base += 32) {
     const int e = base + sv;
     const bool ok = e < count;
@@ -1715,7 +1597,6 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
 #pragma unroll
           for (int k = 0; k < 6; ++k) { const float t = rp[k]; feat[k] = (it == 0 || mine) ? t : feat[k]; }
           ug_wave_lds_sync();
-          UG_PROF_MARK(prof, 1 + it)
         }
       } else {
         ug_k0_gather<F, CH>(k0b, h, en.x, en.y, en.z, a, feat);
@@ -1752,12 +1633,11 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
         }
       }
     }
-    UG_PROF_MARK(prof, 2)
     if constexpr (BF == 2 && UG_MLP_H2) {
       ug_h2_state h2st;
-      ug_rgbnet_pass_h2<C, PE, false, false>(x, en.w, sl, ok, M, amask, aval, accr, accg, accb, h2st, prof);
+      ug_rgbnet_pass_h2<C, PE, false, false>(x, en.w, sl, ok, M, amask, aval, accr, accg, accb, h2st);
     }
-    else ug_rgbnet_pass<C, PE, BF>(x, en.w, sl, ok, M, amask, aval, accr, accg, accb, prof);
+    else ug_rgbnet_pass<C, PE, BF>(x, en.w, sl, ok, M, amask, aval, accr, accg, accb);
   }
   const int64_t ray = tile * UG_WAVE + lane;
   if (ray < a.n_rays) {
@@ -1768,251 +1648,6 @@ __device__ __forceinline__ void ug_shade_tile(const ug_shade_args &a, const floa
 }
 
 
-#ifdef UG_EXPERIMENTS   // rejected A/B arm, built only by UG_EXPERIMENTS=1 csrc/build.sh
-// ================================================================================================================
-// 16x16x32 variant of the shade tile (C = 12, PE = 4, fp16x2 arithmetic): 16 survivors per pass, half the accumulator
-// registers of the 32x32 chain, so the kernel fits 128 VGPRs and runs 16 waves per CU (4 per SIMD) instead of 8.
-// Why: the phase profile of the 8-wave kernel (profiles/r02/shade_phases_8wave.txt) shows a wave spending ~23 k ticks
-// per 32 survivors in strictly serial phases (gather 10 k, layers 1+2 8.7 k, layer 3 3.3 k, accumulation 1 k) with
-// every pipe under 40 % busy: latency-bound at 2 waves per SIMD, not bound by any unit.
-//   * gather: one round of ug_k0_gather_quad (lane = 4 s + g), then 3 ds_bpermute move channels 3g..3g+2 of survivor s to
-//     lane (n = s, jg = g) = s + 16 g, the lane group that owns those K slots of the MFMA B operand
-//   * view embedding: no per-tile table (LDS is taken by 16 waves' worth of weights); lane group jg evaluates the three
-//     (axis, frequency) pairs of its K slots -- 3 sincos per pass
-//   * layer 1: K = 40 inputs (12 + 27 + the bias slot) in 2 k-steps of 32; layer 2: 4 k-steps; 8 output tiles of 16 rows;
-//     three fp16 products per k-step (Wl.xh, Wh.xl, Wh.xh); MFMAs round-robin over >= 4 tiles so that none reads the
-//     accumulator written right before it; A operands stream from LDS four tiles at a time, one group ahead
-//   * layer 3: each lane reduces its 32 hidden features, two cross-group shuffles finish the dot products
-// ================================================================================================================
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-struct ug_mlp16_lds { const f16x8 *A1, *A2; const float *B2, *b3; const float4 *W3; float sx1, c12; };
-
-__host__ __device__ static inline int ug_mlp16_lds_floats() {
-  const ug_mlp_layout ML = ug_mlp_lay(12, 27);
-  return ML.qS - ML.qA1;
-}
-#define UG_ACC16_SCRATCH_FLOATS 128   // per wave: [0,64) per-ray survivor bit masks + [64,128) 16 x {r,g,b,-}
-
-__device__ __forceinline__ ug_mlp16_lds ug_mlp16_stage(float *lds, const float *__restrict__ mlp) {
-  const ug_mlp_layout ML = ug_mlp_lay(12, 27);
-  const int n = ug_mlp16_lds_floats();
-  const float4 *src = (const float4 *)(mlp + ML.qA1);
-  float4 *dst = (float4 *)lds;
-  for (int i = threadIdx.x; i < n / 4; i += blockDim.x) dst[i] = src[i];
-  __syncthreads();
-  ug_mlp16_lds m;
-  m.A1 = (const f16x8 *)lds;
-  m.A2 = (const f16x8 *)(lds + (ML.qA2 - ML.qA1));
-  m.B2 = lds + (ML.qB2 - ML.qA1);
-  m.W3 = (const float4 *)(lds + (ML.qW3 - ML.qA1));
-  m.b3 = lds + (ML.qb3 - ML.qA1);
-  m.sx1 = mlp[ML.qS];
-  m.c12 = mlp[ML.qS + 1];
-  return m;
-}
-
-#define UG_MFMA16(acc, a, b)                                          \
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, acc, 0, 0, 0);   \
-  __builtin_amdgcn_sched_barrier(0)
-
-struct ug_a4 { f16x8 w[4]; };
-// A operands of tiles t0..t0+3 for (k-step block `ks_base` already folded into Ap, part): unit = 64 lanes x 16 B
-__device__ __forceinline__ ug_a4 ug_load_a4(const f16x8 *__restrict__ Ap, int t0, int part) {
-  ug_a4 r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r.w[i] = Ap[((t0 + i) * 2 + part) * 64];
-  return r;
-}
-
-// one k-step over the 8 output tiles: acc[t] += Wl.xh + Wh.xl + Wh.xh.  `cur` holds Wl of tiles 0..3 on entry (loaded by
-// the previous step); on exit it holds the next step's (Ap_next).
-__device__ __forceinline__ void ug_kstep16(const f16x8 *__restrict__ Ap, const f16x8 *__restrict__ Ap_next,
-                                           const ug_split2 &x, f32x4 (&acc)[8], ug_a4 &cur) {
-  ug_a4 nxt = ug_load_a4(Ap, 4, 1);          // Wl tiles 4..7
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { UG_MFMA16(acc[i], cur.w[i], x.h); }
-  cur = ug_load_a4(Ap, 0, 0);                // Wh tiles 0..3
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { UG_MFMA16(acc[4 + i], nxt.w[i], x.h); }
-  nxt = ug_load_a4(Ap, 4, 0);                // Wh tiles 4..7
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { UG_MFMA16(acc[i], cur.w[i], x.l); }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { UG_MFMA16(acc[i], cur.w[i], x.h); }
-  cur = ug_load_a4(Ap_next, 0, 1);           // next step's Wl tiles 0..3 (harmless re-read after the last step)
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { UG_MFMA16(acc[4 + i], nxt.w[i], x.l); }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) { UG_MFMA16(acc[4 + i], nxt.w[i], x.h); }
-}
-
-template <int F>
-__device__ __forceinline__ void ug_shade_tile16(const ug_shade_args &a, const float *__restrict__ viewdirs,
-                                                const float *__restrict__ k0b, const ug_mlp16_lds &M, int64_t tile,
-                                                int count, const float4 *__restrict__ ent,
-                                                const uint8_t *__restrict__ slot, float *__restrict__ scr,
-                                                float *__restrict__ rgb_marched, ug_prof &prof, int dbg) {
-  // dbg (experiments only, ugrid_tune("shade_dbg")): bit 0 = no k0 loads (features := position), bit 1 = no rgbnet
-  const int lane = ug_lane();
-  const int n = lane & 15, jg = lane >> 4;     // MFMA roles: survivor of the pass, K-slot group
-  const int qs = lane >> 2, qg = lane & 3;     // gather roles: survivor of the pass, channel group
-  const ug_quad_axis qa = ug_quad_axis_of(a, qg);
-  unsigned *amask = (unsigned *)scr;           // [64]
-  float4 *aval = (float4 *)(scr + 64);         // [16]
-  float accr = 0.f, accg = 0.f, accb = 0.f;    // lane = ray slot of this tile
-  // this lane's three embedding pairs p = 3 jg + i: axis p >> 2, frequency 2^(p & 3)
-  int ax_i[3];
-  float fr_i[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) { const int p = 3 * jg + i; ax_i[i] = p >> 2; fr_i[i] = (float)(1 << (p & 3)); }
-  const float *ef = (const float *)ent;
-  const int comp = qg < 2 ? qg : 2;
-  UG_PROF_MARK(prof, 7)
-  float w_n = 0.f, pg_n = 0.f;
-  int sl_n = 0;
-  if (n < count) { sl_n = slot[n]; w_n = ef[4 * n + 3]; }
-  if (qs < count) pg_n = ef[4 * qs + comp];
-  UG_PROF_MARK(prof, 0)
-  for (int base = 0; base < count; base += 16) {
-    const bool ok = base + n < count;
-    const float w = w_n, pg = pg_n;
-    const int sl = sl_n;
-    {
-      const int e2 = base + 16 + n, q2 = base + 16 + qs;
-      w_n = 0.f; pg_n = 0.f; sl_n = 0;
-      if (e2 < count) { sl_n = slot[e2]; w_n = ef[4 * e2 + 3]; }
-      if (q2 < count) pg_n = ef[4 * q2 + comp];
-    }
-    // view direction of the survivor's ray (L1-resident: 64 rays per tile)
-    int64_t ray = tile * UG_WAVE + sl;
-    if (ray >= a.n_rays) ray = a.n_rays - 1;
-    const float vx = viewdirs[3 * ray], vy = viewdirs[3 * ray + 1], vz = viewdirs[3 * ray + 2];
-    // ---- k0 features: quad gather, then to the MFMA lane of (survivor, channel group)
-    float x[16];
-    {
-      float f3[1][3];
-      if (dbg & 1) { f3[0][0] = pg; f3[0][1] = pg * 0.5f; f3[0][2] = pg * 0.25f; }
-      else {
-        const float pgs[1] = {pg};
-        ug_k0_gather_quad<F, 2, 1>(k0b, a, qa, pgs, f3);
-      }
-      const int src = (4 * n + jg) << 2;
-#pragma unroll
-      for (int c = 0; c < 3; ++c) x[c] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(f3[0][c])));
-    }
-    UG_PROF_MARK(prof, 1)
-    if (dbg & 2) {
-      if (ok && jg == 0) { accr += x[0] * w; accg += x[1] * w; accb += x[2] * w; }
-      continue;
-    }
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-      const float v = ax_i[i] == 0 ? vx : (ax_i[i] == 1 ? vy : vz);
-      ug_sincos(v * fr_i[i], &x[3 + 2 * i], &x[4 + 2 * i]);
-    }
-    x[9] = jg == 0 ? vx : (jg == 1 ? vy : (jg == 2 ? vz : 1.0f));
-    ug_split2 xs0, xs1;
-    {
-      float v8[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v8[e] = x[e];
-      xs0 = ug_split8h(v8, M.sx1);
-      v8[0] = x[8]; v8[1] = x[9];
-#pragma unroll
-      for (int e = 2; e < 8; ++e) v8[e] = 0.f;
-      xs1 = ug_split8h(v8, M.sx1);
-    }
-    UG_PROF_MARK(prof, 2)
-    // ---- layer 1: 2 k-steps
-    f32x4 acc1[8];
-#pragma unroll
-    for (int t = 0; t < 8; ++t) acc1[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    ug_a4 cur = ug_load_a4(M.A1 + lane, 0, 1);
-    ug_fence_operands();
-    ug_kstep16(M.A1 + lane, M.A1 + 16 * 64 + lane, xs0, acc1, cur);
-    ug_kstep16(M.A1 + 16 * 64 + lane, M.A2 + lane, xs1, acc1, cur);
-    ug_fence_results();
-    UG_PROF_MARK(prof, 3)
-    // ---- layer 2: relu, rescale + split (K slot e of k-step ks = register e%4 of tile 2ks + e/4), 4 k-steps
-    ug_split2 hs[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      float v8[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v8[e] = ug_relu(acc1[2 * ks + (e >> 2)][e & 3]);
-      hs[ks] = ug_split8h(v8, M.c12);
-    }
-    f32x4 acc2[8];
-    {
-      const float4 *b2p = (const float4 *)(M.B2 + jg * 32);
-#pragma unroll
-      for (int t = 0; t < 8; ++t) { const float4 b = b2p[t]; acc2[t] = (f32x4){b.x, b.y, b.z, b.w}; }
-    }
-    ug_fence_operands();
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-      ug_kstep16(M.A2 + ks * 16 * 64 + lane, M.A2 + (ks + 1 < 4 ? ks + 1 : ks) * 16 * 64 + lane, hs[ks], acc2, cur);
-    ug_fence_results();
-    UG_PROF_MARK(prof, 4)
-    // ---- layer 3: this lane's 32 hidden features, then the other three lane groups of the survivor
-    float l0 = 0.f, l1 = 0.f, l2 = 0.f;
-    {
-      const float4 *w3p = M.W3 + jg * 32;
-#pragma unroll
-      for (int sb = 0; sb < 32; sb += 16) {
-        float4 w3[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) w3[i] = w3p[sb + i];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const float hv = ug_relu(acc2[(sb + i) >> 2][(sb + i) & 3]);
-          l0 = fmaf(w3[i].x, hv, l0);
-          l1 = fmaf(w3[i].y, hv, l1);
-          l2 = fmaf(w3[i].z, hv, l2);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    l0 = l0 + __shfl_xor(l0, 16); l1 = l1 + __shfl_xor(l1, 16); l2 = l2 + __shfl_xor(l2, 16);
-    l0 = (l0 + __shfl_xor(l0, 32)) + M.b3[0];
-    l1 = (l1 + __shfl_xor(l1, 32)) + M.b3[1];
-    l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
-    const float pr = w * ug_sigmoid(l0), pgc = w * ug_sigmoid(l1), pb = w * ug_sigmoid(l2);
-    UG_PROF_MARK(prof, 5)
-    {
-      // ordered per-ray sum through LDS (see ug_shade_tile): 16 entries per pass, published by lane group 0
-      amask[lane] = 0u;
-      ug_wave_lds_sync();
-      if (ok && jg == 0) {
-        aval[n] = make_float4(pr, pgc, pb, 0.f);
-        atomicOr(&amask[sl], 1u << n);
-      }
-      ug_wave_lds_sync();
-      unsigned m = amask[lane];
-      while (m) {
-        const int k = __builtin_ctz(m);
-        const float4 t = aval[k];
-        accr += t.x; accg += t.y; accb += t.z;
-        m &= m - 1;
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    UG_PROF_MARK(prof, 6)
-  }
-  const int64_t ray = tile * UG_WAVE + lane;
-  if (ray < a.n_rays) {
-    rgb_marched[3 * ray] = accr;
-    rgb_marched[3 * ray + 1] = accg;
-    rgb_marched[3 * ray + 2] = accb;
-  }
-}
-
-#endif  // UG_EXPERIMENTS
 
 // dynamic tile scheduling with XCD affinity: the tile range is cut into 8 contiguous eighths, one atomic
 // counter each; a workgroup (XCD = blockIdx % 8) drains its own eighth first, then steals from the others.

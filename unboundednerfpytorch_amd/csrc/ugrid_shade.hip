@@ -2,31 +2,14 @@
 // single-launch variant and the rgbnet packing kernel.
 #include "ugrid_render.h"
 #include "ugrid_shade_pc.h"
-#ifdef UG_SHADE_PROF
-extern "C" int ugx_pc_dbg_set(int bits) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_pc_dbg), &bits, sizeof(int)); }
-#endif
 
 extern "C" int ug_set_march_waves(int w);  // ugrid_march.hip
 extern "C" int ug_set_tv_xcd(int m);        // ugrid_ops.hip
-#ifndef UG_PC48_SLOTS
-#define UG_PC48_SLOTS 2      // ring slots per consumer of the 4 + 8 geometry
-#endif
-#ifndef UG_PC57_EXTRA
-#define UG_PC57_EXTRA 0      // extra gather items in flight of a producer that feeds ONE consumer (it holds one stream's state less)
-#endif
-#ifndef UG_PC48_NBL
-#define UG_PC48_NBL 4        // gather items in flight per producer of the 4 + 8 geometry (rolling cell set-up: ug_k0_gather_quad_roll)
-#endif
-#ifndef UG_PC12_NBL
-#define UG_PC12_NBL 3        // gather items (x 6 dwordx4) in flight per producer wave of the 12-wave geometry (4 spills: A/B arm only)
-#endif
+#define UG_PC12_NBL 3        // gather items (x 6 dwordx4) in flight per producer wave of the 12-wave geometry (4 spill)
+#define UG_PC12_ROLL_FROM 3  // ugrid_tune("shade_pc") value from which F >= 4 takes the 12-wave geometry (rolling set-up)
 static int g_shade_pc = 2;   // ugrid_tune("shade_pc", 0|1|2): 2 = 12-wave producer / consumer shade kernel where it applies (default),
                              // 1 = its 8-wave form, 0 = the classic one-wave-does-everything kernel -- bit-identical results,
                              // A/B switch for measurements
-#ifdef UG_EXPERIMENTS        // csrc/build.sh with UG_EXPERIMENTS=1: the rejected A/B arms, never in the shipped library
-static int g_shade_dbg = 0;  // ugrid_tune("shade_dbg", bits) -- WRONG RESULTS by design (see ug_shade_tile16)
-static int g_shade16 = 0;    // ugrid_tune("shade16", 0|1): 16x16x32 / 16-wave kernel where it applies
-#endif
 
 __global__ void k_pack_mlp(const float *__restrict__ w0, const float *__restrict__ b0,
                            const float *__restrict__ w1, const float *__restrict__ b1,
@@ -55,45 +38,6 @@ __global__ void k_pack_mlp(const float *__restrict__ w0, const float *__restrict
   }
   if (blockIdx.x == 0 && threadIdx.x < 4)
     out[L.hxS + threadIdx.x] = threadIdx.x == 0 ? sc.sX1 : (threadIdx.x == 1 ? sc.sX2 / (sc.sW1 * sc.sX1) : 0.f);
-  // 16x16x32 fp16x2 image (k_shade_mlp16; C = 12, PE = 4): A operands lane (m = lane & 15, jg = lane >> 4) holds
-  // W[16 t + m][input of K slot (jg, 8 ks + e)]
-  if (C == 12 && n_emb == 27) {
-    unsigned short *qx = (unsigned short *)(out + L.qA1);
-    const int n_q = (L.qB2 - L.qA1) * 2;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n_q; i += gridDim.x * blockDim.x) {
-      const int e = i & 7, lane = (i >> 3) & 63, u = i >> 9;      // u = (ks * 8 + t) * 2 + part, layer 2 after layer 1
-      const int part = u & 1, t = (u >> 1) & 7, ksg = u >> 4;
-      const int m = lane & 15, jg = lane >> 4, f = 16 * t + m;
-      float w = 0.f;
-      if (ksg < 2) {
-        const int slot = 8 * ksg + e;
-        const int col = ug_q16_col(slot, jg);
-        if (col >= 0) w = w0[f * mlp_in + col] * sc.sW1;
-        else if (col == -2) w = b0[f] * sc.sW1;                 // the constant-one slot carries the layer-1 bias
-      } else {
-        const int ks = ksg - 2;
-        w = w1[f * 128 + ug_q16_feat(ks, jg, e)] * sc.sW2;
-      }
-      const _Float16 hh = (_Float16)w;
-      const _Float16 ll = (_Float16)(w - (float)hh);
-      qx[i] = __builtin_bit_cast(unsigned short, part == 0 ? hh : ll);
-    }
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 128 + 512 + 8; i += gridDim.x * blockDim.x) {
-      float v = 0.f;
-      if (i < 128) {                     // bias2 [jg][4 t + r] at the accumulator scale of layer 2
-        const int jg = i >> 5, t = (i >> 2) & 7, r = i & 3;
-        v = b1[16 * t + 4 * jg + r] * (sc.sW2 * sc.sX2);
-      } else if (i < 640) {              // W3 [jg][4 t + r][c]
-        const int q = i - 128, c = q & 3, tr = (q >> 2) & 31, jg = q >> 7;
-        if (c < 3) v = w2[c * 128 + 16 * (tr >> 2) + 4 * jg + (tr & 3)] / (sc.sW2 * sc.sX2);
-      } else if (i < 644) {
-        if (i - 640 < 3) v = b2[i - 640];
-      } else {
-        v = (i == 644) ? sc.sX1 : (i == 645 ? sc.sX2 / (sc.sW1 * sc.sX1) : 0.f);
-      }
-      out[L.qB2 + i] = v;
-    }
-  }
   // bf16x3 image: one thread per bf16 element
   unsigned short *bf = (unsigned short *)(out + L.bfA1);
   const int n_bf = (L.bfB1 - L.bfA1) * 2;
@@ -158,27 +102,6 @@ __global__ void k_pack_mlp(const float *__restrict__ w0, const float *__restrict
   }
 }
 
-#ifdef UG_SHADE_PROF
-__device__ unsigned long long g_shade_prof[16];   // [8..15]: rgbnet phases of the producer / consumer kernel
-extern "C" int ugx_shade_prof_read(unsigned long long *host8) {
-  UG_HIP(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_shade_prof), 64));
-  unsigned long long z[8] = {0};
-  UG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_shade_prof), z, 64));
-  return 0;
-}
-extern "C" int ugx_shade_prof2_read(unsigned long long *host8) {
-  UG_HIP(hipMemcpyFromSymbol(host8, HIP_SYMBOL(g_shade_prof), 64, 64));
-  unsigned long long z[8] = {0};
-  UG_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_shade_prof), z, 64, 64));
-  return 0;
-}
-#define UG_PROF_INIT(pr) ug_prof pr; pr.t = __builtin_amdgcn_s_memtime(); for (int i_ = 0; i_ < 8; ++i_) pr.acc[i_] = 0;
-#define UG_PROF_FLUSH(pr) if (ug_lane() == 0) for (int i_ = 0; i_ < 8; ++i_) atomicAdd(&g_shade_prof[i_], pr.acc[i_]);
-#else
-#define UG_PROF_INIT(pr) ug_prof pr;
-#define UG_PROF_FLUSH(pr)
-#endif
-
 // persistent shade kernel over a work list written by k_march (two-kernel path)
 template <int F, int C, int PE, int NW, int BF>
 __global__ void __launch_bounds__(NW * 64, NW / 4)
@@ -189,20 +112,18 @@ k_shade_mlp(ug_shade_args a, const float *__restrict__ viewdirs, const float *__
   const ug_mlp_lds M = ug_mlp_stage<C, PE, BF>(lds, mlp, a.residual);
   float *scr = lds + ug_mlp_lds_floats<C, PE, BF>() + (threadIdx.x >> 6) * ug_wave_scratch_floats<C, PE, BF>();
   int victim = 0;
-  UG_PROF_INIT(prof)
   for (;;) {
     const int64_t tile = ug_next_tile(tile_counter, ws.n_tiles, blockIdx.x & 7, victim);
     if (tile < 0) break;
     ug_shade_tile<F, C, PE, BF>(a, viewdirs, k0b, M, tile, ws.count[tile], ws.ent + tile * ws.cap,
-                                ws.slot + tile * ws.cap, scr, rgb_marched, prof);
+                                ws.slot + tile * ws.cap, scr, rgb_marched);
   }
-  UG_PROF_FLUSH(prof)
 }
 
 // producer / consumer shade kernels (ugrid_shade_pc.h): C = 12 quad bricks, fp16x2 rgbnet; NPAIR gather waves + NPAIR rgbnet
 // waves per workgroup, one workgroup per CU.  <4, 4 slots, 6 in flight, 4-tile pass> = 8 waves of 256 VGPRs;
-// <6, 2 slots, 3 in flight, lean pass> = 12 waves of <= 168 VGPRs
-template <int F, int PE, int NPAIR, int SLOTS, int NBL, int MODE>
+// <6, 2 slots, 3 in flight, lean pass> = 12 waves of <= 168 VGPRs (ROLL: the producers' rolling cell set-up, what F >= 4 needs there)
+template <int F, int PE, int NPAIR, int SLOTS, int NBL, int MODE, bool ROLL = false>
 __global__ void __launch_bounds__(NPAIR * 128, (NPAIR * 2 + 3) / 4)
 k_shade_pc(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
            const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
@@ -216,147 +137,12 @@ k_shade_pc(ug_shade_args a, const float *__restrict__ viewdirs, const float *__r
   const int wv = threadIdx.x >> 6, pair = wv % NPAIR;
   float *ring = pairs + pair * UG_PC_PAIR_FLOATS(SLOTS);
   const unsigned ctl = ug_lds_off(ring + SLOTS * UG_PC_SLOT_FLOATS);
-#ifdef UG_SHADE_PROF
-  unsigned long long *pstat = g_shade_prof;
-#else
-  unsigned long long *pstat = nullptr;
-#endif
   if (wv < NPAIR) {
-    ug_pc_producer<F, NBL, SLOTS>(a, k0b, ws, rgb_marched, tile_counter, ring, ctl, pstat);
+    ug_pc_producer<F, NBL, SLOTS, ROLL>(a, k0b, ws, rgb_marched, tile_counter, ring, ctl);
   } else {
     float *scr = pairs + NPAIR * UG_PC_PAIR_FLOATS(SLOTS) + pair * ug_pc_consumer_scratch_floats<PE>();
-    ug_pc_consumer<PE, SLOTS, MODE>(a, viewdirs, M, rgb_marched, ring, ctl, scr, pstat, ws.emb);
+    ug_pc_consumer<PE, SLOTS, MODE>(a, viewdirs, M, rgb_marched, ring, ctl, scr);
   }
-}
-
-// 4 + 8 geometry (round 4): waves 0-3 = producers (one per SIMD), waves 4-11 = consumers (two per SIMD), producer p feeds
-// consumers 2p and 2p + 1 (ug_pc_producer2).  Why: a consumer's rgbnet chain is latency-bound (12 k cycles per pass against 4.2 k
-// of matrix-pipe issue, profiles/r03/shade_pc12_phases.txt), the 6 + 6 geometry puts 1, 1, 2, 2 consumers on the four SIMDs, and
-// the gather side is bound by the CU's shared vector-memory path, not by the number of waves that issue the loads.
-template <int F, int PE, int SLOTS, int NBL, int NP = 4, int NC = 8>
-__global__ void __launch_bounds__(768, 1)
-k_shade_pc48(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
-             const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
-             int32_t *__restrict__ tile_counter) {
-  static_assert(NP + NC == 12 && NC >= NP && NC <= 2 * NP, "12 waves; every producer feeds one or two consumers");
-  constexpr int ND = NC - NP;       // producers 0 .. ND-1 feed two consumers (2p, 2p + 1), the others one (ND + p)
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int MLPF = ug_mlp_lds_floats<12, PE, 2>();
-  float *rings = lds + MLPF;
-  if (threadIdx.x < 4 * NC)         // head / tail counters of the rings
-    ((int *)(rings + (threadIdx.x >> 2) * UG_PC_PAIR_FLOATS(SLOTS) + SLOTS * UG_PC_SLOT_FLOATS))[threadIdx.x & 3] = 0;
-  const ug_mlp_lds M = ug_mlp_stage<12, PE, 2>(lds, mlp, a.residual);     // ends with __syncthreads()
-  const int wv = threadIdx.x >> 6;
-  if (wv < ND) {
-    float *r0 = rings + (2 * wv) * UG_PC_PAIR_FLOATS(SLOTS), *r1 = r0 + UG_PC_PAIR_FLOATS(SLOTS);
-    ug_pc_producer2<F, NBL, SLOTS, true>(a, k0b, ws, rgb_marched, tile_counter, r0, ug_lds_off(r0 + SLOTS * UG_PC_SLOT_FLOATS), r1,
-                                         ug_lds_off(r1 + SLOTS * UG_PC_SLOT_FLOATS));
-  } else if (wv < NP) {
-    float *r0 = rings + (ND + wv) * UG_PC_PAIR_FLOATS(SLOTS);
-    ug_pc_producer2<F, NBL + UG_PC57_EXTRA, SLOTS, false>(a, k0b, ws, rgb_marched, tile_counter, r0, ug_lds_off(r0 + SLOTS * UG_PC_SLOT_FLOATS), nullptr, 0u);
-  } else {
-    const int c = wv - NP;
-    float *ring = rings + c * UG_PC_PAIR_FLOATS(SLOTS);
-    float *scr = rings + NC * UG_PC_PAIR_FLOATS(SLOTS) + c * UG_ACC_SCRATCH_FLOATS;
-    ug_pc_consumer<PE, SLOTS, 2>(a, viewdirs, M, rgb_marched, ring, ug_lds_off(ring + SLOTS * UG_PC_SLOT_FLOATS), scr, nullptr, ws.emb);
-  }
-}
-
-// the view-direction embedding of every ray, once per frame: row = two halves of 16 floats, 14 used, split like the rgbnet's
-// first-layer inputs (ug_pc_consumer: emb[h * EH + e]); rays past the end repeat the last one (the consumers never publish them)
-template <int PE>
-__global__ void __launch_bounds__(256)
-k_view_emb(const float *__restrict__ viewdirs, int64_t n_rays, int64_t n_rows, float *__restrict__ emb_rows) {
-  constexpr int NEMB = 3 + 6 * PE, EH = (NEMB + 1) / 2;
-  static_assert(EH <= UG_EMB_ROW / 2, "row too small");
-  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= n_rows) return;
-  const int64_t ray = row < n_rays ? row : n_rays - 1;
-  const float vx = viewdirs[3 * ray], vy = viewdirs[3 * ray + 1], vz = viewdirs[3 * ray + 2];
-  float emb[UG_EMB_ROW];
-#pragma unroll
-  for (int e = 0; e < UG_EMB_ROW; ++e) emb[e] = 0.f;
-  float lin[2 * EH];
-  lin[0] = vx; lin[1] = vy; lin[2] = vz;
-#pragma unroll
-  for (int ax = 0; ax < 3; ++ax) {
-    const float v = ax == 0 ? vx : (ax == 1 ? vy : vz);
-#pragma unroll
-    for (int k = 0; k < PE; ++k) {
-      float s_, c_;
-      ug_sincos(v * (float)(1 << k), &s_, &c_);
-      lin[3 + ax * PE + k] = s_;
-      lin[3 + 3 * PE + ax * PE + k] = c_;
-    }
-  }
-#pragma unroll
-  for (int e = NEMB; e < 2 * EH; ++e) lin[e] = 0.f;
-#pragma unroll
-  for (int e = 0; e < 2 * EH; ++e) emb[(e / EH) * (UG_EMB_ROW / 2) + (e % EH)] = lin[e];
-  float4 *dst = (float4 *)(emb_rows + row * UG_EMB_ROW);
-#pragma unroll
-  for (int q = 0; q < UG_EMB_ROW / 4; ++q) dst[q] = make_float4(emb[4 * q], emb[4 * q + 1], emb[4 * q + 2], emb[4 * q + 3]);
-}
-
-#ifdef UG_EXPERIMENTS
-// 16-wave variant on 16x16x32 MFMA tiles (ug_shade_tile16): C = 12, PE = 4, fp16x2 arithmetic
-template <int F>
-__global__ void __launch_bounds__(1024, 1)
-k_shade_mlp16(ug_shade_args a, const float *__restrict__ viewdirs, const float *__restrict__ k0b,
-              const float *__restrict__ mlp, ug_ws_view ws, float *__restrict__ rgb_marched,
-              int32_t *__restrict__ tile_counter, int dbg) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const ug_mlp16_lds M = ug_mlp16_stage(lds, mlp);
-  float *scr = lds + ug_mlp16_lds_floats() + (threadIdx.x >> 6) * UG_ACC16_SCRATCH_FLOATS;
-  int victim = 0;
-  UG_PROF_INIT(prof)
-  for (;;) {
-    const int64_t tile = ug_next_tile(tile_counter, ws.n_tiles, blockIdx.x & 7, victim);
-    if (tile < 0) break;
-    ug_shade_tile16<F>(a, viewdirs, k0b, M, tile, ws.count[tile], ws.ent + tile * ws.cap, ws.slot + tile * ws.cap, scr,
-                       rgb_marched, prof, dbg);
-  }
-  UG_PROF_FLUSH(prof)
-}
-#endif
-
-// Single-launch render: every persistent wave marches a 64-ray tile and immediately shades the survivors
-// it found (its list lives in that wave's private scratch slot and is still L2-resident).  Waves of one CU
-// sit in different phases, so the VALU-bound march of some overlaps the MFMA-bound rgbnet of others.
-template <int F, bool L2, int C, int PE, int NW, int BF>
-__global__ void __launch_bounds__(NW * 64, NW / 4)
-k_render_fused(ug_march_args am, ug_shade_args as, const float *__restrict__ rays_o,
-               const float *__restrict__ rays_d, const float *__restrict__ viewdirs,
-               const float *__restrict__ t_table, const float *__restrict__ s_table,
-               const float *__restrict__ dens_bricks, const float *__restrict__ k0b,
-               const float *__restrict__ mlp, float *__restrict__ alphainv_last, float *__restrict__ depth,
-               float *__restrict__ rgb_marched, float4 *__restrict__ scratch_ent,
-               uint8_t *__restrict__ scratch_slot, unsigned long long *__restrict__ survivors_total,
-               int32_t *__restrict__ tile_counter, int64_t n_tiles) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const ug_mlp_lds M = ug_mlp_stage<C, PE, BF>(lds, mlp);
-  float *scr = lds + ug_mlp_lds_floats<C, PE, BF>() + (threadIdx.x >> 6) * ug_wave_scratch_floats<C, PE, BF>();
-  const int64_t cap = (int64_t)UG_WAVE * am.S;
-  const int64_t wslot = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
-  float4 *__restrict__ ent = scratch_ent + wslot * cap;
-  uint8_t *__restrict__ slot = scratch_slot + wslot * cap;
-  int victim = 0;
-  long long total = 0;
-  for (;;) {
-    const int64_t tile = ug_next_tile(tile_counter, n_tiles, blockIdx.x & 7, victim);
-    if (tile < 0) break;
-    const int count = ug_march_tile<F, L2>(am, rays_o, rays_d, t_table, s_table, dens_bricks, alphainv_last,
-                                           depth, tile, ent, slot);
-    // The list was written by this wave into a scratch slot it re-uses for every tile: its stores are
-    // write-through (they are in L2 once vmcnt drains), but this CU's vector L1 may still hold the slot's lines
-    // from the previous tile.  Drain the stores, then invalidate the L1 (agent-scope acquire = buffer_inv sc1).
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    ug_prof prof_unused;
-    ug_shade_tile<F, C, PE, BF>(as, viewdirs, k0b, M, tile, count, ent, slot, scr, rgb_marched, prof_unused);
-    total += count;
-  }
-  if (ug_lane() == 0 && total) atomicAdd(survivors_total, (unsigned long long)total);
 }
 
 // rgbnet == None: rgb = sigmoid(k0), k0 is a single-level 3-channel grid (bricks [8][4], ch 3 = 0)
@@ -417,7 +203,7 @@ __global__ void k_ws_stats(const int32_t *__restrict__ count, int64_t n_tiles, i
 // C ABI
 // ----------------------------------------------------------------------------------------------
 extern "C" int64_t ugrid_mlp_packed_bytes(int32_t k0_channels, int32_t viewbase_pe) {
-  return (int64_t)sizeof(float) * ug_mlp_lay(k0_channels, 3 + 6 * viewbase_pe).total4;
+  return (int64_t)sizeof(float) * ug_mlp_lay(k0_channels, 3 + 6 * viewbase_pe).total3;
 }
 
 // largest power of two <= v (v > 0, finite)
@@ -489,97 +275,11 @@ extern "C" int ugrid_pack_mlp(const float *w0, const float *b0, const float *w1,
   return 0;
 }
 
-// ---- single-launch fused render -----------------------------------------------------------------
-#define UG_FUSED_NW 12  // slots are sized for the largest variant
-#define UG_FUSED_MAX_WGS 256
-
-extern "C" int64_t ugrid_render_fused_ws_bytes(int32_t n_samples) {
-  const int64_t slots = (int64_t)UG_FUSED_MAX_WGS * UG_FUSED_NW, cap = (int64_t)UG_WAVE * n_samples;
-  return 256 + ug_align256(slots * cap * 16) + ug_align256(slots * cap);
-}
-
-
-template <int F, bool L2, int C, int PE, int NW, int BF>
-static int ug_fused_launch_nw(const ug_march_args &am, const ug_shade_args &as, const float *rays_o,
-                           const float *rays_d, const float *viewdirs, const float *t_table,
-                           const float *s_table, const float *dens_bricks, const float *k0b, const float *mlp,
-                           float *alphainv_last, float *depth, float *rgb, void *ws_mem, hipStream_t st) {
-  const int lds_bytes = ug_shade_lds_bytes<C, PE, BF, NW>();
-  UG_SET_DYN_LDS((k_render_fused<F, L2, C, PE, NW, BF>), lds_bytes);
-  const int64_t n_tiles = (am.n_rays + UG_WAVE - 1) / UG_WAVE;
-  const int64_t slots = (int64_t)UG_FUSED_MAX_WGS * NW, cap = (int64_t)UG_WAVE * am.S;
-  char *base = (char *)ws_mem;
-  UG_ZERO_WORDS(base, 64, st);  // 8 tile counters @0, survivor total @64
-  float4 *ent = (float4 *)(base + 256);
-  uint8_t *slot = (uint8_t *)(base + 256 + ug_align256(slots * cap * 16));
-  int64_t wgs = (n_tiles + NW - 1) / NW;
-  if (wgs > UG_FUSED_MAX_WGS) wgs = UG_FUSED_MAX_WGS;
-  wgs = (wgs + 7) / 8 * 8;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_render_fused<F, L2, C, PE, NW, BF>), dim3((unsigned)wgs), dim3(NW * 64), lds_bytes,
-                     st, am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks, k0b, mlp, alphainv_last,
-                     depth, rgb, ent, slot, (unsigned long long *)(base + 64), (int32_t *)base, n_tiles);
-  UG_LAUNCH_CHECK();
-  return 0;
-}
-
-template <int F, bool L2, int C, int PE>
-static int ug_fused_launch(const ug_march_args &am, const ug_shade_args &as, const float *rays_o,
-                           const float *rays_d, const float *viewdirs, const float *t_table,
-                           const float *s_table, const float *dens_bricks, const float *k0b, const float *mlp,
-                           float *alphainv_last, float *depth, float *rgb, void *ws_mem, int mlp_mode,
-                           hipStream_t st) {
-  // the single-launch variant is kept for experiments only (bf16x3 or fp32 MFMA; fp16x2 is not instantiated)
-  if (mlp_mode != UGRID_MLP_FP32)
-    return ug_fused_launch_nw<F, L2, C, PE, 8, 1>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks,
-                                                     k0b, mlp, alphainv_last, depth, rgb, ws_mem, st);
-  return ug_fused_launch_nw<F, L2, C, PE, 8, 0>(am, as, rays_o, rays_d, viewdirs, t_table, s_table, dens_bricks,
-                                                    k0b, mlp, alphainv_last, depth, rgb, ws_mem, st);
-}
-
-extern "C" int ugrid_render_fused(const ugrid_render_params *p, const float *rays_o, const float *rays_d,
-                                  const float *viewdirs, const float *t_table, const float *s_table,
-                                  const float *density_bricks, const float *k0_bricks, const float *mlp_packed,
-                                  float *alphainv_last, float *depth, float *rgb_marched, void *ws_mem,
-                                  ugrid_stream_t s) {
-  if (p->n_rays <= 0) return 0;
-  if (p->mlp_in == 0 || p->mlp_width != 128 || p->mlp_in != p->k0_channels + 3 + 6 * p->viewbase_pe)
-    return (int)hipErrorNotSupported;  // rgbnet-less models use the two-kernel path
-  if (p->mlp_mode & UGRID_MLP_RESIDUAL) return (int)hipErrorNotSupported;   // (the residual epilogue exists in the two-kernel path only)
-  ug_march_args am;
-  const int rc = ug_fill_march_args(p, am);
-  if (rc) return rc;
-  ug_shade_args as;
-  ug_fill_shade_args(p, as);
-#define UG_FUSED_CASE(F_, C_, PE_)                                                                        \
-  if (p->freq_num == F_ && p->k0_channels == C_ && p->viewbase_pe == PE_) {                               \
-    if (p->norm_l2)                                                                                       \
-      return ug_fused_launch<F_, true, C_, PE_>(am, as, rays_o, rays_d, viewdirs, t_table, s_table,       \
-                                                density_bricks, k0_bricks, mlp_packed, alphainv_last,     \
-                                                depth, rgb_marched, ws_mem, p->mlp_mode, ST(s));          \
-    return ug_fused_launch<F_, false, C_, PE_>(am, as, rays_o, rays_d, viewdirs, t_table, s_table,        \
-                                               density_bricks, k0_bricks, mlp_packed, alphainv_last,      \
-                                               depth, rgb_marched, ws_mem, p->mlp_mode, ST(s));           \
-  }
-  UG_FUSED_CASE(3, 12, 4)
-  UG_FUSED_CASE(4, 12, 4)
-#undef UG_FUSED_CASE
-  return (int)hipErrorNotSupported;
-}
-
-extern "C" int ugrid_render_fused_stats(const void *ws_mem, int64_t *d_stats, ugrid_stream_t s) {
-  return (int)hipMemcpyAsync(d_stats, (const char *)ws_mem + 64, sizeof(int64_t), hipMemcpyDeviceToDevice, ST(s));
-}
-
-
 extern "C" int ugrid_tune(const char *key, int value) {
   if (!key) return (int)hipErrorInvalidValue;
   if (!strcmp(key, "march_waves")) return ug_set_march_waves(value) ? (int)hipErrorInvalidValue : 0;
   if (!strcmp(key, "tv_xcd")) return ug_set_tv_xcd(value) ? (int)hipErrorInvalidValue : 0;
-  if (!strcmp(key, "shade_pc") && value >= 0 && value <= 5) { g_shade_pc = value; return 0; }
-#ifdef UG_EXPERIMENTS
-  if (!strcmp(key, "shade16") && (value == 0 || value == 1)) { g_shade16 = value; return 0; }
-  if (!strcmp(key, "shade_dbg") && value >= 0 && value < 4) { g_shade_dbg = value; return 0; }
-#endif
+  if (!strcmp(key, "shade_pc") && value >= 0 && value <= 3) { g_shade_pc = value; return 0; }
   return (int)hipErrorInvalidValue;
 }
 
@@ -600,71 +300,26 @@ static int ug_shade_launch_nw(const ug_shade_args &a, const float *viewdirs, con
 }
 
 
-template <int F, int PE, int NPAIR, int SLOTS, int NBL, int MODE>
+template <int F, int PE, int NPAIR, int SLOTS, int NBL, int MODE, bool ROLL = false>
 static int ug_shade_pc_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
                               ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
   const int lds_bytes = ug_pc_lds_bytes<PE, NPAIR, SLOTS>();
   if (lds_bytes > 160 * 1024) return (int)hipErrorInvalidValue;   // the CU's LDS
-  UG_SET_DYN_LDS((k_shade_pc<F, PE, NPAIR, SLOTS, NBL, MODE>), lds_bytes);
+  UG_SET_DYN_LDS((k_shade_pc<F, PE, NPAIR, SLOTS, NBL, MODE, ROLL>), lds_bytes);
   UG_ZERO_WORDS(counter, 8, st);
-  if constexpr (MODE == 2) {      // A/B arm: the 6 + 6 geometry with the consumers of the 4 + 8 / 5 + 7 ones (embedding rows from global memory)
-    const int64_t n_rows = ws.n_tiles * UG_WAVE;
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_view_emb<PE>), dim3(ug_blocks(n_rows, 256)), dim3(256), 0, st, viewdirs, a.n_rays, n_rows, ws.emb);
-  }
   // persistent, one workgroup per CU: NPAIR producer waves pull tiles, so a workgroup covers >= NPAIR tiles
   int64_t wgs = (ws.n_tiles + NPAIR - 1) / NPAIR;
   if (wgs > 256) wgs = 256;
   wgs = (wgs + 7) / 8 * 8;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_pc<F, PE, NPAIR, SLOTS, NBL, MODE>), dim3((unsigned)wgs), dim3(NPAIR * 128), lds_bytes, st,
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_pc<F, PE, NPAIR, SLOTS, NBL, MODE, ROLL>), dim3((unsigned)wgs), dim3(NPAIR * 128), lds_bytes, st,
                      a, viewdirs, k0b, mlp, ws, rgb, counter);
   UG_LAUNCH_CHECK();
   return 0;
 }
-
-template <int F, int PE, int SLOTS, int NBL, int NP, int NC>
-static int ug_shade_pc48_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
-                                ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
-  const int lds_bytes = ug_pc48_lds_bytes<PE, SLOTS, NC>();
-  if (lds_bytes > 160 * 1024) return (int)hipErrorInvalidValue;
-  UG_SET_DYN_LDS((k_shade_pc48<F, PE, SLOTS, NBL, NP, NC>), lds_bytes);
-  UG_ZERO_WORDS(counter, 8, st);
-  const int64_t n_rows = ws.n_tiles * UG_WAVE;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_view_emb<PE>), dim3(ug_blocks(n_rows, 256)), dim3(256), 0, st, viewdirs, a.n_rays, n_rows, ws.emb);
-  int64_t wgs = (ws.n_tiles + NC - 1) / NC;    // NC tile streams per workgroup
-  if (wgs > 256) wgs = 256;
-  wgs = (wgs + 7) / 8 * 8;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_pc48<F, PE, SLOTS, NBL, NP, NC>), dim3((unsigned)wgs), dim3(768), lds_bytes, st,
-                     a, viewdirs, k0b, mlp, ws, rgb, counter);
-  UG_LAUNCH_CHECK();
-  return 0;
-}
-
-#ifdef UG_EXPERIMENTS
-template <int F>
-static int ug_shade16_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
-                             ug_ws_view ws, float *rgb, int32_t *counter, hipStream_t st) {
-  const int lds_bytes = (int)sizeof(float) * (ug_mlp16_lds_floats() + 16 * UG_ACC16_SCRATCH_FLOATS);
-  UG_SET_DYN_LDS((k_shade_mlp16<F>), lds_bytes);
-  UG_ZERO_WORDS(counter, 8, st);
-  int64_t wgs = (ws.n_tiles + 15) / 16;
-  if (wgs > 256) wgs = 256;
-  wgs = (wgs + 7) / 8 * 8;
-  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_shade_mlp16<F>), dim3((unsigned)wgs), dim3(1024), lds_bytes, st, a, viewdirs, k0b,
-                     mlp, ws, rgb, counter, g_shade_dbg);
-  UG_LAUNCH_CHECK();
-  return 0;
-}
-
-#endif
 
 template <int F, int C, int PE>
 static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const float *k0b, const float *mlp,
                            ug_ws_view ws, float *rgb, int32_t *counter, int mlp_mode, hipStream_t st) {
-#ifdef UG_EXPERIMENTS
-  if constexpr (C == 12 && PE == 4) {
-    if (mlp_mode == UGRID_MLP_FP16X2 && g_shade16) return ug_shade16_launch<F>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-  }
-#endif
   // fp16x2 keeps a per-wave view-embedding table in LDS next to the rgbnet image: with viewbase_pe = 8 that is 14 KB per
   // consumer wave on top of a 99 KB image -- no 8-wave geometry fits the CU's 160 KB.  ugrid_pack_mlp reports bf16x3 as the
   // best mode for such networks and the fp16x2 kernels are not instantiated for them.
@@ -672,17 +327,14 @@ static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const 
     if (mlp_mode == UGRID_MLP_FP16X2) return (int)hipErrorInvalidValue;
   }
   if constexpr (C == 12 && PE <= 4) {
-    if constexpr (F <= 3 && PE == 4) {
-      if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc == 3)
-        return ug_shade_pc48_launch<F, PE, UG_PC48_SLOTS, UG_PC48_NBL, 4, 8>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-      if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc == 5)
-        return ug_shade_pc_launch<F, PE, 6, 2, UG_PC12_NBL, 2>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-      if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc == 4)
-        return ug_shade_pc48_launch<F, PE, UG_PC48_SLOTS, UG_PC48_NBL, 5, 7>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
-    }
-    if constexpr (F <= 3) {      // the producers' set-up state grows with the level count: F >= 4 does not fit 168 VGPRs
+    if constexpr (F <= 3) {
       if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc >= 2)
         return ug_shade_pc_launch<F, PE, 6, 2, UG_PC12_NBL, 1>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
+    } else {
+      // F >= 4 (P >= 9 levels): the producers' set-up state of a whole pass (4 registers per (round, level)) does not fit the
+      // 12-wave geometry's 168 VGPRs; the ROLLING set-up (4 registers per item in flight) does
+      if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc >= UG_PC12_ROLL_FROM)
+        return ug_shade_pc_launch<F, PE, 6, 2, UG_PC12_NBL, 1, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
     }
     if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc >= 1)
       return ug_shade_pc_launch<F, PE, 4, 4, UG_PC_NBL(F), 0>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);

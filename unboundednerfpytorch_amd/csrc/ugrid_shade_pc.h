@@ -28,15 +28,9 @@
 //                         pass (layer 2 two output tiles at a time, ug_rgbnet_pass_lean), 2-slot rings.  Why: the rgbnet chain
 //                         of ONE wave is latency-bound (9-11 k ticks per pass against 4.2 k of MFMA issue, phase profiles in
 //                         profiles/r03/); three waves per SIMD overlap each other's stalls, two cannot.
-#ifndef UG_PC_NBL
 // 8-wave geometry: gather items (x 6 dwordx4) in flight per producer wave: 6 at F <= 3; the set-up state grows with the level count
 // (4 registers per (round, level)), so F = 4 keeps 5 and F = 5 keeps 4 in flight to stay inside 256 VGPRs without scratch
-#ifdef UG_PC_NBL_FIXED            // A/B builds
-#define UG_PC_NBL(F) UG_PC_NBL_FIXED
-#else
 #define UG_PC_NBL(F) ((F) <= 3 ? 6 : ((F) == 4 ? 5 : 4))
-#endif
-#endif
 // ring slot (floats): feat [32][12] | w [32] | sl [32] (int) | hdr {tile, count, base, -} (int)
 #define UG_PC_FEAT 0
 #define UG_PC_W 384
@@ -55,12 +49,6 @@ __host__ __device__ static inline int ug_pc_lds_bytes() {
   return (int)sizeof(float) * (ug_mlp_lds_floats<12, PE, 2>() + NPAIR * UG_PC_PAIR_FLOATS(SLOTS) + NPAIR * ug_pc_consumer_scratch_floats<PE>());
 }
 
-// NP producers + NC consumers (4 + 8, 5 + 7): rgbnet image | NC rings | NC x (amask | aval) -- no embedding tables (consumer MODE 2)
-template <int PE, int SLOTS, int NC = 8>
-__host__ __device__ static inline int ug_pc48_lds_bytes() {
-  return (int)sizeof(float) * (ug_mlp_lds_floats<12, PE, 2>() + NC * UG_PC_PAIR_FLOATS(SLOTS) + NC * UG_ACC_SCRATCH_FLOATS);
-}
-
 // ---- LDS counters: explicit ds_ instructions on the 32-bit LDS offset (no flat_ access may sneak in: flat operations
 // count on vmcnt AND lgkmcnt and would corrupt the producers' hand-counted vmcnt waits)
 typedef __attribute__((address_space(3))) const void *ug_lds_cptr;
@@ -75,43 +63,18 @@ __device__ __forceinline__ void ug_lds_publish(unsigned off, int v) {
   asm volatile("s_waitcnt lgkmcnt(0)\n\tds_write_b32 %0, %1" :: "v"(off), "v"(v) : "memory");
 }
 
-#ifdef UG_SHADE_PROF
-// instrumented A/B builds only (tools/gpu_shade_pc_prof.py): g_pc_dbg bit 0 = producers skip the k0 loads (features :=
-// positions: WRONG RESULTS, shows the consumer-bound time), bit 1 = consumers skip the rgbnet (shows the producer-bound time)
-__device__ int g_pc_dbg;
-#define UG_PC_DBG(bit) (g_pc_dbg & (bit))
-#define UG_PC_T0(t) const unsigned long long t = __builtin_amdgcn_s_memtime();
-#define UG_PC_ADD(acc, t) acc += __builtin_amdgcn_s_memtime() - t;
-#else
-#define UG_PC_DBG(bit) 0
-#define UG_PC_T0(t)
-#define UG_PC_ADD(acc, t)
-#endif
 
 // Issue priority of the consumer waves (round 4, profiles/r04/shade_priority_ab.txt): the SIMD's arbiter serves the wave with the
 // highest s_setprio first.  A consumer raises its priority to UG_PC_PRIO_PHASED (default 3, the maximum) while it feeds the
 // matrix pipe -- layers 1 and 2: an MFMA that waits behind the gather waves' address arithmetic leaves the pipe idle -- and drops
 // back to 0 for the VALU-only layer 3 / accumulation / slot wait, where the producers' work should win.  Measured on S1: 4.29-4.34
 // -> 4.05-4.11 ms (static priorities 1, 2, 3 for the whole consumer: 4.11-4.14).  Scheduling only: results are bit-identical.
-// -DUG_PC_PRIO_PHASED=0 builds the kernel without it.
 // polling intervals of the ring hand-off (s_sleep units of 64 clocks): a waiting producer polls the consumer's counter, a waiting
 // consumer the producer's; every poll is ~10 instructions on a SIMD it shares with working waves (A/B: profiles/r04/shade_poll_ab.txt)
-#ifndef UG_PC_PRODUCER_SLEEP
 #define UG_PC_PRODUCER_SLEEP 2
-#endif
-#ifndef UG_PC_CONSUMER_SLEEP
 #define UG_PC_CONSUMER_SLEEP 2
-#endif
-#ifndef UG_PC_PRIO_PHASED
-#define UG_PC_PRIO_PHASED 3
-#endif
-#if UG_PC_PRIO_PHASED > 0
-#define UG_PRIO_HI() __builtin_amdgcn_s_setprio(UG_PC_PRIO_PHASED)
+#define UG_PRIO_HI() __builtin_amdgcn_s_setprio(3)
 #define UG_PRIO_LO() __builtin_amdgcn_s_setprio(0)
-#else
-#define UG_PRIO_HI()
-#define UG_PRIO_LO()
-#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // LEAN fp16x2 rgbnet pass for the 12-wave geometry (<= 168 VGPRs): same products, same accumulation order per output
@@ -136,14 +99,13 @@ __device__ __forceinline__ ug_hpair ug_load_hpair(const f16x8 *__restrict__ Ap, 
 template <int C, int PE>
 __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(C) + 3 + 6 * PE + 1) / 2], float ww, int sl, bool ok,
                                                     const ug_mlp_lds &M, unsigned *amask, float4 *aval, float &accr, float &accg,
-                                                    float &accb, ug_prof &prof) {
+                                                    float &accb) {
   constexpr int CH = UG_CH(C);
   constexpr int NEMB = 3 + 6 * PE;
   constexpr int KL = (2 * CH + NEMB + 1) / 2;
   constexpr int KB1 = (KL + 7) / 8;
   const int lane = ug_lane();
   const int h = lane >> 5, sv = lane & 31;
-  UG_PROF_MARK(prof, 2)
   UG_PRIO_HI();
   int bo = h * 64;
   asm volatile("" : "+v"(bo));
@@ -181,7 +143,6 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
       xs = xn;
     }
     ug_fence_results();
-    UG_PROF_MARK(prof, 3)
     // ---- hidden activations -> operand form: k-step 0 now, k-step st + 1 behind the MFMAs of k-step st of the first half
     {
       float v[8];
@@ -245,7 +206,6 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
     w3[0] = ug_w3_load4(M, bo, 32 * pr2);
     ug_fence_results();
     UG_PRIO_LO();
-    if (pr2 == 1) { UG_PROF_MARK(prof, 4) }
     // ---- layer 3, rows 32 pr2 .. 32 pr2 + 31 (same order as the 4-tile pass: rows ascending)
 #pragma unroll
     for (int sb = 0; sb < 32; sb += W3B) {
@@ -265,21 +225,6 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
   l2 = (l2 + __shfl_xor(l2, 32)) + M.b3[2];
   UG_RESIDUAL_ADD(M, x, l0, l1, l2)
   const float pr = ww * ug_sigmoid(l0), pg = ww * ug_sigmoid(l1), pb = ww * ug_sigmoid(l2);
-  UG_PROF_MARK(prof, 5)
-#ifdef UG_ACC_DSADD
-  {
-    // A/B arm (profiles/r04/shade_ab.txt): the per-ray sums live in LDS ([64 rays][3] floats in the wave's scratch) and every
-    // survivor adds its colour with three fire-and-forget ds_add_f32 -- no mask round trip, no wait.  LDS operations of a wave
-    // complete in program order, so passes are summed in order; WITHIN one instruction the order in which the LDS serialises
-    // lanes that hit the same ray is the hardware's (observed ascending = list order = bit-identical, but not architected).
-    if (ok && h == 0) {
-      const unsigned ra = ug_lds_off((const float *)amask + 3 * sl);
-      asm volatile("ds_add_f32 %0, %1\n\tds_add_f32 %0, %2 offset:4\n\tds_add_f32 %0, %3 offset:8"
-                   :: "v"(ra), "v"(pr), "v"(pg), "v"(pb) : "memory");
-    }
-    (void)aval; (void)accr; (void)accg; (void)accb;
-  }
-#else
   {
     // ordered per-ray sum through LDS (masks pre-cleared, see ug_rgbnet_pass_h2)
     if (ok && h == 0) {
@@ -297,17 +242,17 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
     }
     __builtin_amdgcn_wave_barrier();
   }
-#endif
-  UG_PROF_MARK(prof, 6)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // producer wave
 // ---------------------------------------------------------------------------------------------------------------------
-template <int F, int NBL, int SLOTS>
+// ROLL: the rolling cell set-up (ug_k0_gather_quad_roll: 4 registers per item IN FLIGHT instead of 4 per item of the pass) -- what
+// lets F >= 4 (P >= 9 levels: 72 set-up registers otherwise) into the 168-register budget of the 12-wave geometry
+template <int F, int NBL, int SLOTS, bool ROLL>
 __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const float *__restrict__ k0b, const ug_ws_view &ws,
                                                float *__restrict__ rgb_marched, int32_t *__restrict__ tile_counter,
-                                               float *ring, unsigned ctl, unsigned long long *pstat) {
+                                               float *ring, unsigned ctl) {
   const int lane = ug_lane();
   const int qs = lane >> 2, qg = lane & 3;
   const ug_quad_axis qa = ug_quad_axis_of(a, qg);
@@ -315,11 +260,6 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
   int seq = 0;            // passes published so far
   int tail_seen = 0;      // last value read from the consumer's counter
   int victim = 0;
-#ifdef UG_SHADE_PROF
-  unsigned long long t_wait = 0, t_gather = 0, n_pass = 0;
-  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-  const int dbg_nogather = UG_PC_DBG(1);
-#endif
   for (;;) {
     const int64_t tile = ug_next_tile(tile_counter, ws.n_tiles, blockIdx.x & 7, victim);
     if (tile < 0) break;
@@ -349,31 +289,22 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
         sl_n = slot[e2]; w_n = ef[4 * e2 + 3];
         pg0_n = ef[4 * q0 + comp]; pg1_n = ef[4 * q1 + comp];
       }
-      UG_PC_T0(tg)
       float f3[2][3];
-#ifdef UG_SHADE_PROF
-      if (dbg_nogather) {
-        f3[0][0] = pg0; f3[0][1] = pg0 * 0.5f; f3[0][2] = pg0 * 0.25f; f3[1][0] = pg1; f3[1][1] = pg1 * 0.5f; f3[1][2] = pg1 * 0.25f;
-      } else
-#endif
       {
         const float pgs[2] = {pg0, pg1};
-#ifdef UG_PC12_ROLL      // A/B arm: the rolling cell set-up (ug_k0_gather_quad_roll) in the 1 : 1 geometries as well
-        ug_k0_gather_quad_roll<F, NBL, 2>(k0b, a, qa, pgs, f3);
-#else
-        ug_gather_state<F, NBL, 2> gst;
-        ug_k0_gather_begin<F, NBL, 2>(k0b, a, qa, pgs, gst);
-        ug_k0_gather_finish<F, NBL, 2>(k0b, a, gst, f3);
-#endif
+        if constexpr (ROLL) {
+          ug_k0_gather_quad_roll<F, NBL, 2>(k0b, a, qa, pgs, f3);
+        } else {
+          ug_gather_state<F, NBL, 2> gst;
+          ug_k0_gather_begin<F, NBL, 2>(k0b, a, qa, pgs, gst);
+          ug_k0_gather_finish<F, NBL, 2>(k0b, a, gst, f3);
+        }
       }
-      UG_PC_ADD(t_gather, tg)
       // a free slot: the consumer has taken pass seq - SLOTS (waited for AFTER the gather: the features sit in registers)
-      UG_PC_T0(tw)
       while (seq - tail_seen >= SLOTS) {
         tail_seen = ug_lds_peek(ctl + 4);
         if (seq - tail_seen >= SLOTS) __builtin_amdgcn_s_sleep(UG_PC_PRODUCER_SLEEP);
       }
-      UG_PC_ADD(t_wait, tw)
       float *sp = ring + (seq % SLOTS) * UG_PC_SLOT_FLOATS;
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
@@ -384,9 +315,6 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
       if (lane == 0) { ((int *)sp)[UG_PC_HDR] = (int)tile; ((int *)sp)[UG_PC_HDR + 1] = count; ((int *)sp)[UG_PC_HDR + 2] = base; }
       ++seq;
       ug_lds_publish(ctl, seq);
-#ifdef UG_SHADE_PROF
-      ++n_pass;
-#endif
     }
   }
   // end marker
@@ -397,118 +325,6 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
   if (lane == 0) ((int *)(ring + (seq % SLOTS) * UG_PC_SLOT_FLOATS))[UG_PC_HDR] = -1;
   ++seq;
   ug_lds_publish(ctl, seq);
-#ifdef UG_SHADE_PROF
-  if (lane == 0) { atomicAdd(pstat + 0, t_gather); atomicAdd(pstat + 1, t_wait); atomicAdd(pstat + 2, n_pass);
-                   atomicAdd(pstat + 3, __builtin_amdgcn_s_memtime() - t_begin); }
-#endif
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// producer wave of the 4 + 8 geometry (k_shade_pc48): ONE producer feeds TWO consumers.  It walks two independent tile streams,
-// one pass of stream 0, one pass of stream 1, ... -- each stream has its own ring, its own consumer and its own position in its
-// tile's survivor list; a consumer therefore still sees whole tiles in order (per-ray sums in sample order, as before).  The pass
-// body is ug_pc_producer's.
-// ---------------------------------------------------------------------------------------------------------------------
-struct ug_pc_stream {
-  const float *ef;            // this tile's entries (px, py, pz, w)
-  const uint8_t *slot;
-  float *ring;
-  unsigned ctl;
-  int64_t tile;
-  int count, base;            // survivors of the tile, first survivor of the NEXT pass
-  int seq, tail_seen;
-  float w_n, pg0_n, pg1_n;    // inputs of the next pass (fetched one pass ahead)
-  int sl_n;
-  bool active;
-};
-
-// claim the next non-empty tile for a stream and prefetch its first pass (empty tiles are blacked out on the spot)
-__device__ __forceinline__ void ug_pc_stream_next_tile(ug_pc_stream &st, const ug_shade_args &a, const ug_ws_view &ws,
-                                                       float *__restrict__ rgb_marched, int32_t *__restrict__ tile_counter,
-                                                       int &victim, int lane, int qs, int comp) {
-  for (;;) {
-    const int64_t tile = ug_next_tile(tile_counter, ws.n_tiles, blockIdx.x & 7, victim);
-    if (tile < 0) { st.active = false; return; }
-    const int count = ws.count[tile];
-    if (count <= 0) {
-      const int64_t ray = tile * UG_WAVE + lane;
-      if (ray < a.n_rays) { rgb_marched[3 * ray] = 0.f; rgb_marched[3 * ray + 1] = 0.f; rgb_marched[3 * ray + 2] = 0.f; }
-      continue;
-    }
-    st.tile = tile; st.count = count; st.base = 0;
-    st.ef = (const float *)(ws.ent + tile * ws.cap);
-    st.slot = ws.slot + tile * ws.cap;
-    const int e0 = min(lane & 31, count - 1), q0 = min(qs, count - 1), q1 = min(16 + qs, count - 1);
-    st.sl_n = st.slot[e0]; st.w_n = st.ef[4 * e0 + 3];
-    st.pg0_n = st.ef[4 * q0 + comp]; st.pg1_n = st.ef[4 * q1 + comp];
-    st.active = true;
-    return;
-  }
-}
-
-template <int F, int NBL, int SLOTS, bool TWO = true>
-__device__ __forceinline__ void ug_pc_producer2(const ug_shade_args &a, const float *__restrict__ k0b, const ug_ws_view &ws,
-                                                float *__restrict__ rgb_marched, int32_t *__restrict__ tile_counter,
-                                                float *ring0, unsigned ctl0, float *ring1, unsigned ctl1) {
-  const int lane = ug_lane();
-  const int qs = lane >> 2, qg = lane & 3;
-  const ug_quad_axis qa = ug_quad_axis_of(a, qg);
-  const int comp = qg < 2 ? qg : 2;
-  int victim = 0;
-  ug_pc_stream st[2];
-  st[0].ring = ring0; st[0].ctl = ctl0; st[1].ring = ring1; st[1].ctl = ctl1;
-  constexpr int NS = TWO ? 2 : 1;             // TWO = false: a producer of the 5 + 7 geometry that feeds ONE consumer (ring1 unused)
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    st[i].seq = 0; st[i].tail_seen = 0; st[i].active = false;
-    ug_pc_stream_next_tile(st[i], a, ws, rgb_marched, tile_counter, victim, lane, qs, comp);
-  }
-  while (st[0].active || (TWO && st[1].active)) {
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-      if (!st[i].active) continue;
-      ug_pc_stream &S = st[i];
-      const float ww = S.w_n, pg0 = S.pg0_n, pg1 = S.pg1_n;
-      const int sl = S.sl_n, base = S.base, count = S.count;
-      {     // the pass after this one (clamped indices past the end of the list: ug_pc_producer)
-        const int e2 = min(base + 32 + (lane & 31), count - 1), q0 = min(base + 32 + qs, count - 1), q1 = min(base + 48 + qs, count - 1);
-        S.sl_n = S.slot[e2]; S.w_n = S.ef[4 * e2 + 3];
-        S.pg0_n = S.ef[4 * q0 + comp]; S.pg1_n = S.ef[4 * q1 + comp];
-      }
-      float f3[2][3];
-      {
-        const float pgs[2] = {pg0, pg1};
-        ug_k0_gather_quad_roll<F, NBL, 2>(k0b, a, qa, pgs, f3);      // rolling cell set-up: NBL = 4 items in flight fit 168 registers
-      }
-      while (S.seq - S.tail_seen >= SLOTS) {
-        S.tail_seen = ug_lds_peek(S.ctl + 4);
-        if (S.seq - S.tail_seen >= SLOTS) __builtin_amdgcn_s_sleep(2);
-      }
-      float *sp = S.ring + (S.seq % SLOTS) * UG_PC_SLOT_FLOATS;
-#pragma unroll
-      for (int it = 0; it < 2; ++it) {
-        float *fp = sp + UG_PC_FEAT + (16 * it + qs) * 12 + 3 * qg;
-        fp[0] = f3[it][0]; fp[1] = f3[it][1]; fp[2] = f3[it][2];
-      }
-      if (lane < 32) { sp[UG_PC_W + lane] = ww; ((int *)sp)[UG_PC_SL + lane] = sl; }
-      if (lane == 0) { ((int *)sp)[UG_PC_HDR] = (int)S.tile; ((int *)sp)[UG_PC_HDR + 1] = count; ((int *)sp)[UG_PC_HDR + 2] = base; }
-      ++S.seq;
-      ug_lds_publish(S.ctl, S.seq);
-      S.base = base + 32;
-      if (S.base >= count) ug_pc_stream_next_tile(S, a, ws, rgb_marched, tile_counter, victim, lane, qs, comp);
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {      // end markers
-    ug_pc_stream &S = st[i];
-    while (S.seq - S.tail_seen >= SLOTS) {
-      S.tail_seen = ug_lds_peek(S.ctl + 4);
-      if (S.seq - S.tail_seen >= SLOTS) __builtin_amdgcn_s_sleep(2);
-    }
-    if (lane == 0) ((int *)(S.ring + (S.seq % SLOTS) * UG_PC_SLOT_FLOATS))[UG_PC_HDR] = -1;
-    ++S.seq;
-    ug_lds_publish(S.ctl, S.seq);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -517,13 +333,11 @@ __device__ __forceinline__ void ug_pc_producer2(const ug_shade_args &a, const fl
 // MODE: 0 = hand-scheduled 4-tile pass (ug_rgbnet_pass_h2), 1 = lean pass.  (A third mode -- two passes of a tile per
 // consumer wave in lock step, every weight fragment feeding two MFMAs, layer 3 of a tile behind the next tile's MFMAs, 251
 // VGPRs -- was built, verified bit-identical and measured at 4.53-4.56 ms against 4.39 ms: profiles/r03/shade_dual_pass_ab.txt.)
-// MODE 2 = the lean pass with the view-direction embedding read per survivor from the global table k_view_emb wrote (ws.emb,
-// 64 B per lane and pass through the vector-memory path) instead of a per-consumer LDS table rebuilt at every tile change: the
-// 7 KB per consumer that frees are what lets EIGHT consumers share the CU's LDS (k_shade_pc48).
+// (Geometries with more consumers than producers -- 4 + 8, 5 + 7, the embedding table in global memory -- were built, verified
+// bit-identical and measured 3-5 % slower in round 4: profiles/r04/shade_geometry_48_ab.txt, tools/experiments/ARMS.md.)
 template <int PE, int SLOTS, int MODE>
 __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const float *__restrict__ viewdirs, const ug_mlp_lds &M,
-                                               float *__restrict__ rgb_marched, const float *ring, unsigned ctl, float *scr,
-                                               unsigned long long *pstat, const float *__restrict__ emb_rows = nullptr) {
+                                               float *__restrict__ rgb_marched, const float *ring, unsigned ctl, float *scr) {
   constexpr int C = 12, CH = UG_CH(C), NEMB = 3 + 6 * PE, KL = (2 * CH + NEMB + 1) / 2, EH = KL - CH;
   const int lane = ug_lane();
   const int h = lane >> 5, sv = lane & 31;
@@ -536,31 +350,12 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
   ug_h2_state h2st;
   if constexpr (MODE == 0) ug_h2_preload(M, h * 64, h2st);
   amask[lane] = 0u;                // the hand-scheduled passes keep the per-ray masks cleared between passes
-#ifdef UG_ACC_DSADD
-  amask[64 + lane] = 0u; amask[128 + lane] = 0u;     // (A/B arm: [64][3] per-ray sums in the same 192 floats)
-#endif
-#ifdef UG_PC_CONSUMER_PRIO
-  __builtin_amdgcn_s_setprio(UG_PC_CONSUMER_PRIO);   // A/B arm: the matrix-pipe waves win issue arbitration over the gather waves
-#endif
   ug_wave_lds_sync();
-#ifdef UG_SHADE_PROF
-  ug_prof prof_unused;          // phases of ug_rgbnet_pass: acc[3] layer 1, [4] layer 2, [5] layer 3 + sigmoid, [6] accumulation
-  for (int i_ = 0; i_ < 8; ++i_) prof_unused.acc[i_] = 0;
-#else
-  ug_prof prof_unused;
-#endif
-#ifdef UG_SHADE_PROF
-  unsigned long long t_wait = 0, t_mlp = 0, t_tile = 0;
-  const unsigned long long t_begin = __builtin_amdgcn_s_memtime();
-  const int dbg_nomlp = UG_PC_DBG(2);
-#endif
   for (;;) {
-    UG_PC_T0(tw)
     while (head_seen <= seq) {
       head_seen = ug_lds_peek(ctl);
       if (head_seen <= seq) __builtin_amdgcn_s_sleep(UG_PC_CONSUMER_SLEEP);
     }
-    UG_PC_ADD(t_wait, tw)
     const float *sp = ring + (seq % SLOTS) * UG_PC_SLOT_FLOATS;
     const int tile = __builtin_amdgcn_readfirstlane(((const int *)sp)[UG_PC_HDR]);
     if (tile < 0) break;
@@ -577,34 +372,7 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
     ++seq;
     ug_lds_publish(ctl + 4, seq);     // the slot's values are in registers: hand it back before the rgbnet starts
     const bool ok = base + sv < count;
-    UG_PC_T0(tt_)
-    if constexpr (MODE == 2) {
-      // this lane's half of its survivor's embedding row: 14 floats = three 16-byte loads + one 8-byte load, issued before the
-      // tile bookkeeping so that their latency overlaps it
-      static_assert(EH <= 14 || MODE != 2, "UG_EMB_ROW holds 14 floats per half");
-      const float4 *er = (const float4 *)(emb_rows + ((int64_t)tile * UG_WAVE + sl) * UG_EMB_ROW + h * (UG_EMB_ROW / 2));
-      const float4 e0 = er[0], e1 = er[1], e2 = er[2];
-      const float2 e3 = *(const float2 *)(er + 3);
-      const float ev[14] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w, e2.x, e2.y, e2.z, e2.w, e3.x, e3.y};
-#pragma unroll
-      for (int s = CH; s < KL; ++s) x[s] = ev[s - CH];
-      if (tile != cur_tile) {
-        if (cur_tile >= 0) {
-          const int64_t ray = (int64_t)cur_tile * UG_WAVE + lane;
-          if (ray < a.n_rays) { rgb_marched[3 * ray] = accr; rgb_marched[3 * ray + 1] = accg; rgb_marched[3 * ray + 2] = accb; }
-        }
-        accr = accg = accb = 0.f;
-        cur_tile = tile;
-      }
-    } else
     if (tile != cur_tile) {
-#ifdef UG_ACC_DSADD
-      if constexpr (MODE == 1) {        // the sums of the finished tile sit in LDS: fetch and clear (in order behind the adds)
-        float *ra = (float *)amask + 3 * lane;
-        accr = ra[0]; accg = ra[1]; accb = ra[2];
-        ra[0] = 0.f; ra[1] = 0.f; ra[2] = 0.f;
-      }
-#endif
       if (cur_tile >= 0) {
         const int64_t ray = (int64_t)cur_tile * UG_WAVE + lane;
         if (ray < a.n_rays) { rgb_marched[3 * ray] = accr; rgb_marched[3 * ray + 1] = accg; rgb_marched[3 * ray + 2] = accb; }
@@ -635,39 +403,19 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
       for (int e = 0; e < 2 * EH; ++e) embt[lane * (2 * EH) + e] = emb[e];
       ug_wave_lds_sync();
     }
-    if constexpr (MODE != 2) {
+    {
       const float *er = embt + sl * (2 * EH) + h * EH;
 #pragma unroll
       for (int s = CH; s < KL; ++s) x[s] = er[s - CH];
     }
-    UG_PC_ADD(t_tile, tt_)
-    UG_PC_T0(tm)
-#ifdef UG_SHADE_PROF
-    prof_unused.t = tm;
-    if (dbg_nomlp) { if (ok && h == 0 && sl == lane) { accr += x[0] * ww; accg += x[1] * ww; accb += x[KL - 1] * ww; } } else
-#endif
-    {
-      if constexpr (MODE >= 1) {
-        ug_rgbnet_pass_lean<C, PE>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, prof_unused);
-      } else {
-        ug_rgbnet_pass_h2<C, PE, true, true>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, h2st, prof_unused);
-      }
+    if constexpr (MODE == 1) {
+      ug_rgbnet_pass_lean<C, PE>(x, ww, sl, ok, M, amask, aval, accr, accg, accb);
+    } else {
+      ug_rgbnet_pass_h2<C, PE, true, true>(x, ww, sl, ok, M, amask, aval, accr, accg, accb, h2st);
     }
-    UG_PC_ADD(t_mlp, tm)
   }
-#ifdef UG_ACC_DSADD
-  if constexpr (MODE == 1) {
-    const float *ra = (const float *)amask + 3 * lane;
-    accr = ra[0]; accg = ra[1]; accb = ra[2];
-  }
-#endif
   if (cur_tile >= 0) {
     const int64_t ray = (int64_t)cur_tile * UG_WAVE + lane;
     if (ray < a.n_rays) { rgb_marched[3 * ray] = accr; rgb_marched[3 * ray + 1] = accg; rgb_marched[3 * ray + 2] = accb; }
   }
-#ifdef UG_SHADE_PROF
-  if (lane == 0) { atomicAdd(pstat + 4, t_mlp); atomicAdd(pstat + 5, t_wait); atomicAdd(pstat + 6, __builtin_amdgcn_s_memtime() - t_begin);
-                   atomicAdd(pstat + 7, t_tile);
-                   for (int i_ = 3; i_ < 7; ++i_) atomicAdd(pstat + 8 + i_, prof_unused.acc[i_]); }
-#endif
 }

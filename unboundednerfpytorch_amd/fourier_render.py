@@ -82,17 +82,16 @@ class FourierGridRenderer:
     `near` and `bg` as the reference, depth = sum w * step_id.  dvgo_render.DirectVoxGORenderer.render_rays builds it.
     """
 
-    def __init__(self, state, device, max_ws_bytes=48 << 30, fused=False, pipeline=0, mlp_mode=None):
+    def __init__(self, state, device, max_ws_bytes=48 << 30, pipeline=0, mlp_mode=None):
         dev = torch.device(device)
         if dev.type != "cuda":
             raise RuntimeError("FourierGridRenderer needs a HIP device (no CPU path)")
         self.device = dev
         self.max_ws_bytes = int(max_ws_bytes)
-        # fused=True: single persistent launch (march+shade per wave, 0.9 GB scratch), kept for experiments; False
-        # (default, measured faster on MI355X): march kernel -> work list -> shade kernel.
-        # pipeline=N>1: N ray chunks software-pipelined over two streams (measured slower: both kernels are
-        # issue-bound on the same SIMDs), also experimental.
-        self.use_fused = bool(fused)
+        # march kernel -> work list -> shade kernel.  (A single persistent launch that marched and shaded per wave was measured
+        # slower in rounds 1-3 and left the library in round 5: tools/experiments/ARMS.md.)
+        # pipeline=N>1: N ray chunks software-pipelined over two streams (measured slower: both kernels are bound by the same
+        # per-CU vector-memory path), experimental.
         self.mlp_mode = _lib.MLP_BF16X3   # rgbnet arithmetic; set from ugrid_pack_mlp's answer below
         self.pipeline = int(pipeline)
         dg = state["density_grid"].to(dev, torch.float32).contiguous()
@@ -174,8 +173,6 @@ class FourierGridRenderer:
                 self.mlp_mode = int(best.value) if mlp_mode is None else int(mlp_mode)
                 if self.mlp_mode == _lib.MLP_FP16X2 and best.value != _lib.MLP_FP16X2:
                     raise RuntimeError("fp16x2 rgbnet arithmetic is not usable for this network (operand range)")
-                if self.use_fused and mlp_mode is None:
-                    self.mlp_mode = min(self.mlp_mode, _lib.MLP_BF16X3)   # single-launch kernel: bf16x3 / fp32 only
             else:
                 if kg.shape[0] != 1 or self.C != 3:
                     raise RuntimeError("without an rgbnet k0 must be a single-level 3-channel grid")
@@ -226,7 +223,8 @@ class FourierGridRenderer:
         return p
 
     def rays_per_chunk(self, S):
-        per_ray = 17 * S + 8   # work-list entry {p, w} 16 B + ray slot 1 B per sample, worst case
+        per_ray = 17 * S + 8   # work-list entry {p, w} 16 B + ray slot 1 B per sample, worst case = ugrid_render_ws_bytes per ray
+                               # (+ 256-byte alignment of the three regions and the counters: covered by the 8)
         n = max(64, (self.max_ws_bytes // per_ray) // 64 * 64)
         return n
 
@@ -344,26 +342,9 @@ class FourierGridRenderer:
             dvp.near_clip, dvp.far_clip = float(render_kwargs["near"]), 1e9       # dvgo.py:318: the given far is ignored
             dvp.stepdist = self.stepdist(stepsize)
         timing = render_kwargs.get("timing")  # optional list collecting ([ev0, ev1, ev2], n_rays) per launch group
-        fused = self.use_fused and self.has_mlp and self.dc is None and (self.F, self.C, self.pe) in ((3, 12, 4), (4, 12, 4))
         with _lib.guard(dev):
             st = torch.cuda.current_stream(dev).cuda_stream
-            if fused:
-                need = _L.ugrid_render_fused_ws_bytes(S)
-                if self._ws is None or self._ws.numel() < need:
-                    self._ws = None
-                    self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
-                p = self._params(R, S, stepsize)
-                if timing is not None:
-                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-                    ev[0].record()
-                _lib.check(_L.ugrid_render_fused(p, _p(rays_o), _p(rays_d), _p(viewdirs), _p(t_tab), _p(s_tab),
-                                                 _p(self.density_bricks), _p(self.k0_bricks), _p(self.mlp_packed),
-                                                 _p(last), _p(depth), _p(rgb), _p(self._ws), st), "render_fused")
-                if timing is not None:
-                    ev[1].record()
-                    timing.append((ev, R))
-                self._last = ("fused", R, S)
-            elif self.pipeline > 1 and R >= 64 * 64 * self.pipeline and self.dc is None and self.dv is None:
+            if self.pipeline > 1 and R >= 64 * 64 * self.pipeline and self.dc is None and self.dv is None:
                 self._forward_pipelined(rays_o, rays_d, viewdirs, t_tab, s_tab, S, stepsize, last, depth, rgb, timing)
             else:
                 chunk = self.rays_per_chunk(S)
@@ -457,16 +438,12 @@ class FourierGridRenderer:
 
     @torch.no_grad()
     def survivors_of_last_chunk(self, n_rays=None, S=None):
-        """Number of surviving samples M counted by the most recent launch (whole call for the fused path, last
-        chunk for the two-kernel path).  Host sync."""
-        kind, n, S_ = self._last
+        """Number of surviving samples M counted by the most recent launch (the last chunk of the call).  Host sync."""
+        _, n, S_ = self._last
         out = torch.zeros(1, dtype=torch.int64, device=self.device)
         with _lib.guard(self.device):
             st = torch.cuda.current_stream(self.device).cuda_stream
-            if kind == "fused":
-                _lib.check(_L.ugrid_render_fused_stats(_p(self._ws), _p(out), st), "render_fused_stats")
-            else:
-                _lib.check(_L.ugrid_render_stats(_p(self._ws), n, S_, _p(out), st), "render_stats")
+            _lib.check(_L.ugrid_render_stats(_p(self._ws), n, S_, _p(out), st), "render_stats")
         return int(out.item())
 
     # -- constructors ------------------------------------------------------------------------------
