@@ -61,6 +61,10 @@ def parse():
     ap.add_argument("--no-secondary", action="store_true", help="skip the S1b secondary scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--contiguous", action="store_true", help="N>1: contiguous ray bands instead of interleaved 64-ray tiles")
+    ap.add_argument("--deal-group", type=int, default=0, help="N>1: deal the frame's 64-ray tiles (8x8 pixel blocks) round-robin in groups of "
+                    "this many consecutive tiles; 0 (default) = one block ROW of the image (W/8 tiles): the deal `scaling_proxy` measured "
+                    "best at N = 8 (balanced like single tiles, and a rank's rays keep their horizontal neighbours); 1 = single tiles")
+    ap.add_argument("--no-proxy", action="store_true", help="skip `scaling_proxy` (every rank's share of an N-way deal rendered ALONE on this GPU)")
     ap.add_argument("--mlp-mode", type=int, default=None, help="rgbnet arithmetic: 0 fp32 MFMA, 1 bf16x3, 2 fp16x2 (default: what ugrid_pack_mlp reports usable)")
     ap.add_argument("--pipeline", type=int, default=0, help="ray chunks software-pipelined over two streams (0 = off)")
     ap.add_argument("--tune", action="append", default=[], help="key=value speed knob (ugrid_tune), repeatable")
@@ -227,9 +231,12 @@ class FrameBench:
         self.S = self.rend.tables(self.stepsize)[2]
         self.c2w = camera(0, device)
         self.use_dist = dist is not None
+        # tiles dealt in groups (dist.tile_assignment): default one block row of the image
+        dg = int(getattr(args, "deal_group", 0) or 0)
+        self.deal_group = dg if dg > 0 else max(1, W // 8)
         if world > 1 and not args.contiguous:
-            self.idx = tile_assignment(self.R, world, rank).to(device)
-            self.per = tile_assignment(self.R, world, 0).numel()
+            self.idx = tile_assignment(self.R, world, rank, group=self.deal_group).to(device)
+            self.per = tile_assignment(self.R, world, 0, group=self.deal_group).numel()
             self.bounds = None
         else:
             self.idx = None
@@ -260,7 +267,7 @@ class FrameBench:
             pix_of_row = torch.full((world * self.per,), -1, dtype=torch.int64)
             for r in range(world):
                 if self.idx is not None:
-                    ir = tile_assignment(self.R, world, r)
+                    ir = tile_assignment(self.R, world, r, group=self.deal_group)
                 else:
                     b, e = shard_bounds(self.R, world, r)
                     ir = torch.arange(b, e, dtype=torch.int64)
@@ -530,6 +537,42 @@ def s3_train_step_block(device):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def scaling_proxy(args, rend, device, t1_ms, steps=4):
+    """What a 1-GPU box can say about N > 1: rank r's share of an N-way deal of THE frame rendered ALONE on this
+    device -- same kernels, same rays, same bricks as rank r of an N-GPU run (the tile exchange, 5.2 MB per rank at N = 8, is the only
+    thing missing) -- for every rank of N = 2, 4, 8 and three deals: single 64-ray tiles round-robin, block ROWS of the image
+    round-robin (W / 8 tiles), contiguous bands.  The slowest share is the frame time an N-GPU run cannot beat; t(1 GPU) / (N x slowest
+    share) is the efficiency it predicts.  Per-share HBM bytes come from a PMC pass over this function (tools/gpu_rank_share.sh ->
+    profiles/r05/scaling_proxy_pmc.json): a share whose time does not shrink like 1 / N while its HBM bytes do not either is
+    HBM-bound -- the deal destroyed the brick locality (single tiles: every rank touches the whole frame's bricks)."""
+    try:
+        out = {"t1_ms": t1_ms, "note": "share r of an N-way deal rendered alone on this GPU (no exchange); predicted_efficiency = t1 / (N * slowest share)"}
+        W = args.width
+        deals = (("tiles_round_robin", dict(contiguous=False, deal_group=1)), ("block_rows_round_robin", dict(contiguous=False, deal_group=max(1, W // 8))),
+                 ("contiguous_bands", dict(contiguous=True, deal_group=1)))
+        for N in (2, 4, 8):
+            row = {}
+            for name, kw in deals:
+                a = argparse.Namespace(**dict(vars(args), **kw))
+                ms, kms, rays = [], [], []
+                for r in range(N):
+                    fb = FrameBench(a, None, device, N, r, None, renderer=rend)
+                    dt, timing = fb.timed(steps, 1)
+                    k = kernel_ms(timing, steps)
+                    ms.append(dt / steps * 1e3)
+                    kms.append([k.get("render_march", 0.0), k.get("render_shade", 0.0)])
+                    rays.append(sum(n for _, n in timing) // steps)
+                    del fb
+                row[name] = {"share_ms": [round(x, 4) for x in ms], "share_march_shade_ms": [[round(x, 4) for x in p] for p in kms], "share_rays": rays,
+                             "slowest_share_ms": max(ms), "mean_share_ms": sum(ms) / N,
+                             "predicted_speedup": t1_ms / max(ms), "predicted_efficiency": t1_ms / (N * max(ms)),
+                             "imbalance_max_over_mean": max(ms) / (sum(ms) / N)}
+            out["N=%d" % N] = row
+        return out
+    except Exception as e:          # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
 def truck_render_block(args, device, want_cpu):
     """BASELINE.json configs[2]'s RENDER half at its real shape (VERDICT r4 "missing" #1): truck_single.py's model
     (configs/tankstemple_unbounded/truck_single.py:92-110: fourier_freq_num = 4 -> P = 9 levels, G = 200^3 for both grids, rgbnet_dim 12,
@@ -706,6 +749,9 @@ def main():
         wsteps = max(3, args.steps // 2)
         weak = {"value": world * fb.R * fb.S / (wdt / wsteps) / 1e6, "unit": "Msamples/s", "ms_per_step": wdt / wsteps * 1e3,
                 "note": "every rank renders its own full frame (own camera); no exchange"}
+    proxy = None
+    if world == 1 and not use_dist and not standin and not args.no_proxy and args.height % 8 == 0 and args.width % 8 == 0:
+        proxy = scaling_proxy(args, fb.rend, device, dt / args.steps * 1e3)
     # survivor statistics + parity inputs from one extra, untimed full frame on this rank
     rays_full, out_full, M = fb.full_frame()
     R, S = fb.R, fb.S
@@ -756,7 +802,8 @@ def main():
                            if fb.order is not None else "image order (64-pixel row segments per wave)"),
                        "parallelism": ("one frame over %d ranks, %s, 1 all-gather of [R/N,5] tiles per frame (async, overlaps "
                                        "the next frame)" % (world, "contiguous 64-aligned ray bands" if args.contiguous
-                                                            else "64-ray tiles dealt round-robin")) if world > 1 else "1 GPU"},
+                                                            else "64-ray tiles (8x8 pixel blocks) dealt round-robin in groups of %d" % fb.deal_group))
+                                       if world > 1 else "1 GPU"},
             "kernels": {k: {"ms": v} for k, v in kern.items()},
         }
         if standin:
@@ -773,6 +820,8 @@ def main():
                                                  ms_per_step=ms_step)
             else:
                 res["roofline"] = None
+        if proxy is not None:
+            res["scaling_proxy"] = proxy
         if per_rank is not None:
             res["per_rank"] = per_rank
         if frame_ok is not None:

@@ -479,7 +479,8 @@ int ugrid_shade_supported(int32_t freq_num, int32_t k0_channels, int32_t viewbas
 
 /* Tuning knobs (speed only, never results): "march_waves" 4..6 (waves per SIMD of the march kernel); "tv_xcd" 0|1|2
  * (dense TV / TV + Adam kernels: linear workgroup order | XCD-contiguous | + non-temporal streams, default 2);
- * "shade16" 0|1 and "shade_dbg" (A/B arms of the shade kernel). */
+ * "shade_pc" 0|1|2 (shade kernel geometry: classic | 8-wave producer / consumer | 12-wave where it applies, default 2 --
+ * bit-identical results).  Anything else returns hipErrorInvalidValue. */
 int ugrid_tune(const char *key, int value);
 
 /* Total survivors of the last march on this ws -> *d_stats (device int64). */

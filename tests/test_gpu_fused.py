@@ -212,11 +212,14 @@ def test_fused_render_deterministic_chunk_and_order_invariant(fr):
     assert float(a["alphainv_last"].min()) >= 0 and float(a["alphainv_last"].max()) <= 1
 
 
-def test_shade_kernel_geometries_are_bit_identical(fr, pe=4):
+@pytest.mark.parametrize("F", [3, 4])
+def test_shade_kernel_geometries_are_bit_identical(fr, F, pe=4):
     """The shade kernels -- classic (0), 8-wave producer / consumer with the hand-scheduled pass (1), 12-wave 6 + 6 with the lean
-    pass (2), 12-wave 4 + 8 (3), 5 + 7 (4) and 6 + 6 (5) with the embedding rows in global memory -- issue the same products and keep every summation order: their
-    rgb_marched must agree bit for bit on a frame with many partially filled passes and empty tiles."""
-    G, F, C, R = 32, 3, 12, 50_000
+    pass (2; at F = 4, truck_single.py's level count, its producers use the rolling cell set-up: round 5) -- issue the same products
+    and keep every summation order: their rgb_marched must agree bit for bit on a frame with many partially filled passes and empty
+    tiles.  (The 4 + 8 / 5 + 7 / global-table geometries of round 4 passed the same test before they were archived:
+    tools/experiments/ARMS.md.)"""
+    G, C, R = 32, 12, 50_000
     state = make_state(123, G, F, C, pe, "inf", 1e-4, 5.0, 12.0)
     o, d, v = [torch.from_numpy(a).cuda() for a in synth.rays(9, R)]
     o[:4096] = o[0]                              # a block of identical rays: full tiles next to sparse ones
@@ -224,7 +227,7 @@ def test_shade_kernel_geometries_are_bit_identical(fr, pe=4):
     assert rend.mlp_mode == 2
     outs = {}
     try:
-        for pc in (0, 1, 2, 3, 4, 5):
+        for pc in (0, 1, 2):
             fr.tune("shade_pc", pc)
             outs[pc] = rend(o, d, v, stepsize=0.5, render_depth=True, ray_order="coherent")["rgb_marched"].clone()
             again = rend(o, d, v, stepsize=0.5, render_depth=True, ray_order="coherent")["rgb_marched"]
@@ -232,7 +235,7 @@ def test_shade_kernel_geometries_are_bit_identical(fr, pe=4):
     finally:
         fr.tune("shade_pc", 2)
     assert float(outs[0].abs().max()) > 0.1
-    for pc in (1, 2, 3, 4, 5):
+    for pc in (1, 2):
         assert torch.equal(outs[0], outs[pc]), (pc, float((outs[0] - outs[pc]).abs().max()))
 
 

@@ -2,7 +2,8 @@
 devices and is SKIPPED on the 1-GPU boxes the builder's sessions get; the driver's 8-GPU node collects and runs them.  They
 exercise exactly what the gloo tests of tests/test_host_logic.py cover on the CPU, on the real kernels and the real
 collectives: dist.render_sharded (one all-gather of [R/N,5] tiles), dist.composite_blocks (one all-reduce),
-ShardedMaskedAdam with the touched-line exchange, and `python bench.py --gpus 2` as the driver launches it."""
+ShardedMaskedAdam with the touched-line exchange, and `python bench.py --gpus 2` as the driver launches it.  Round 5: every test
+runs at world = 2, 3 and 8 (RCCL: as many as the box has devices for; gloo: the ranks share the devices present)."""
 import json
 import os
 import subprocess
@@ -15,6 +16,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 N_DEV = torch.cuda.device_count() if torch.cuda.is_available() else 0
 need2 = pytest.mark.skipif(N_DEV < 2, reason="needs >= 2 GPUs (RCCL over xGMI); %d visible" % N_DEV)
+WORLDS = (2, 3, 8)      # an even, an odd and the node's full world size (VERDICT r4 "missing" #2)
+
+
+def need(world):
+    return pytest.mark.skipif(N_DEV < world, reason="needs >= %d GPUs (RCCL over xGMI); %d visible" % (world, N_DEV))
+
+
+RCCL_WORLDS = [pytest.param(w, marks=need(w)) for w in WORLDS]
 
 WORKER = r'''
 import json, os, sys
@@ -92,16 +101,18 @@ elif what == "sharded_adam":
                 gg = torch.Generator(device=dev).manual_seed(1000 * it + r)
                 gr = torch.zeros(p.numel() // 64, 64, device=dev)
                 hit = torch.randperm(gr.shape[0], device=dev, generator=gg)[:40 + 3 * r]
-                gr[hit] = torch.randn(hit.numel(), 64, device=dev, generator=gg)
+                # values on a 2^-8 lattice, |g| < 4: the sum over <= 8 ranks is exact in fp32, so neither the ring order of the
+                # collective nor the packing of the sparse exchange can show -- equality is asserted for EVERY world size
+                gr[hit] = (torch.randn(hit.numel(), 64, device=dev, generator=gg).clamp(-3.9, 3.9) * 256).round() / 256
                 grads.append(gr.reshape(-1))
             flat = lambda t: t.permute(0, 2, 3, 4, 1).reshape(-1)
             p.grad = torch.empty_like(p.data); flat(p.grad).copy_(grads[rank])
-            ref.grad = torch.empty_like(ref.data); flat(ref.grad).copy_(sum(grads) / world)
+            ref.grad = torch.empty_like(ref.data); flat(ref.grad).copy_(sum(grads) * (1.0 / world))   # exact sum, one rounding: the optimizer's own scale
             opt.step(); ropt.step()
             ex = dict(opt.last_exchange[id(p)])
         torch.cuda.synchronize()
-        res["sparse" if sparse else "dense"] = {"equal_to_single_process": bool(torch.equal(p.data, ref.data)) if world == 2 else
-                                                float((p.data - ref.data).abs().max()), "exchange": ex}
+        res["sparse" if sparse else "dense"] = {"equal_to_single_process": bool(torch.equal(p.data, ref.data)),
+                                                "linf_vs_single_process": float((p.data - ref.data).abs().max()), "exchange": ex}
     out.update(res)
 dist.barrier()
 if rank == 0:
@@ -126,26 +137,26 @@ def _run(what, n=2, timeout=600, backend="nccl"):
     return json.loads(line[len("RESULT "):])
 
 
-@need2
-def test_render_sharded_over_rccl_is_bitwise_the_single_device_render():
-    r = _run("render_sharded")
+@pytest.mark.parametrize("world", RCCL_WORLDS)
+def test_render_sharded_over_rccl_is_bitwise_the_single_device_render(world):
+    r = _run("render_sharded", n=world)
     print(json.dumps(r))
-    assert r["world"] == 2 and r["backend"] == "nccl" and r["bitwise_equal_to_single_device"] is True
+    assert r["world"] == world and r["backend"] == "nccl" and r["bitwise_equal_to_single_device"] is True
 
 
-@need2
-def test_composite_blocks_over_rccl_equals_the_single_process_rule():
-    r = _run("composite_blocks")
+@pytest.mark.parametrize("world", RCCL_WORLDS)
+def test_composite_blocks_over_rccl_equals_the_single_process_rule(world):
+    r = _run("composite_blocks", n=world)
     print(json.dumps(r))
-    assert r["linf_vs_single_process_rule"] <= 2e-6 and r["visible_blocks"] >= 1
+    assert r["world"] == world and r["linf_vs_single_process_rule"] <= 2e-6 and r["visible_blocks"] >= 1
 
 
-@need2
-def test_sharded_masked_adam_over_rccl_equals_the_single_process_optimizer():
-    r = _run("sharded_adam")
+@pytest.mark.parametrize("world", RCCL_WORLDS)
+def test_sharded_masked_adam_over_rccl_equals_the_single_process_optimizer(world):
+    r = _run("sharded_adam", n=world)
     print(json.dumps(r))
     for mode in ("sparse", "dense"):
-        assert r[mode]["equal_to_single_process"] is True, r[mode]
+        assert r["world"] == world and r[mode]["equal_to_single_process"] is True, r[mode]
     assert r["sparse"]["exchange"]["mode"] == "sparse"
     assert r["sparse"]["exchange"]["reduce_scatter_bytes"] < r["sparse"]["exchange"]["dense_bytes_each_way"] // 4
 
@@ -163,19 +174,21 @@ def test_bench_py_gpus_2_over_rccl():
     assert sum(r["rays"] for r in res["per_rank"]) == 1920 * 1080
 
 
+@pytest.mark.parametrize("world", WORLDS)
 @pytest.mark.parametrize("what", ["render_sharded", "composite_blocks", "sharded_adam"])
-def test_worker_code_on_two_gloo_ranks_sharing_this_gpu(what):
-    """the SAME worker scripts as the RCCL tests, two ranks over gloo on the device(s) present: the kernels, the tile dealing, the
-    merging rule and the touched-line exchange run on a 1-GPU box too (only the transport differs from the armed tests)"""
-    r = _run(what, backend="gloo")
+def test_worker_code_on_gloo_ranks_sharing_this_gpu(what, world):
+    """the SAME worker scripts as the RCCL tests, 2 / 3 / 8 ranks over gloo on the device(s) present: the kernels, the tile dealing
+    (ragged counts, ranks with short shares), the merging rule with `world` blocks and the touched-line exchange (owners whose range
+    nobody touched) run on a 1-GPU box too -- only the transport differs from the armed tests"""
+    r = _run(what, n=world, backend="gloo")
     print(json.dumps(r))
-    assert r["world"] == 2 and r["backend"] == "gloo"
+    assert r["world"] == world and r["backend"] == "gloo"
     if what == "render_sharded":
         assert r["bitwise_equal_to_single_device"] is True
     elif what == "composite_blocks":
         assert r["linf_vs_single_process_rule"] <= 2e-6 and r["visible_blocks"] >= 1
     else:
-        assert r["sparse"]["equal_to_single_process"] is True and r["dense"]["equal_to_single_process"] is True
+        assert r["sparse"]["equal_to_single_process"] is True and r["dense"]["equal_to_single_process"] is True, r
         assert r["sparse"]["exchange"]["mode"] == "sparse"
 
 

