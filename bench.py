@@ -537,16 +537,19 @@ def s3_train_step_block(device):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
-def scaling_proxy(args, rend, device, t1_ms, steps=4):
+def scaling_proxy(args, rend, device, t1_ms, steps=6):
     """What a 1-GPU box can say about N > 1: rank r's share of an N-way deal of THE frame rendered ALONE on this
     device -- same kernels, same rays, same bricks as rank r of an N-GPU run (the tile exchange, 5.2 MB per rank at N = 8, is the only
     thing missing) -- for every rank of N = 2, 4, 8 and three deals: single 64-ray tiles round-robin, block ROWS of the image
-    round-robin (W / 8 tiles), contiguous bands.  The slowest share is the frame time an N-GPU run cannot beat; t(1 GPU) / (N x slowest
-    share) is the efficiency it predicts.  Per-share HBM bytes come from a PMC pass over this function (tools/gpu_rank_share.sh ->
-    profiles/r05/scaling_proxy_pmc.json): a share whose time does not shrink like 1 / N while its HBM bytes do not either is
-    HBM-bound -- the deal destroyed the brick locality (single tiles: every rank touches the whole frame's bricks)."""
+    round-robin (W / 8 tiles, the default of --gpus N), contiguous bands.  A share's time is the GPU time of its step (ray generation
+    + march + shade) between two HIP events, median over `steps` back-to-back steps -- what a rank of a continuously fed N-GPU run
+    spends per frame.  (The host clock around single synchronised steps is NOT used: an idle -> busy transition of the queue
+    occasionally starts the first kernel 25-80 ms late on these boxes, profiles/r05/share_stall_diag.txt; back-to-back frames do
+    not idle.)  The slowest share is the frame time an N-GPU run cannot beat; t(1 GPU) / (N x slowest share) is the efficiency it
+    predicts.  Per-share HBM bytes come from a PMC pass (tools/gpu_rank_share.sh -> profiles/r05/rank_share_pmc.jsonl)."""
     try:
-        out = {"t1_ms": t1_ms, "note": "share r of an N-way deal rendered alone on this GPU (no exchange); predicted_efficiency = t1 / (N * slowest share)"}
+        out = {"t1_ms": t1_ms, "note": "share r of an N-way deal rendered alone on this GPU (no exchange); GPU time per step between HIP events, "
+                                       "median of %d back-to-back steps; predicted_efficiency = t1 / (N * slowest share)" % steps}
         W = args.width
         deals = (("tiles_round_robin", dict(contiguous=False, deal_group=1)), ("block_rows_round_robin", dict(contiguous=False, deal_group=max(1, W // 8))),
                  ("contiguous_bands", dict(contiguous=True, deal_group=1)))
@@ -557,9 +560,18 @@ def scaling_proxy(args, rend, device, t1_ms, steps=4):
                 ms, kms, rays = [], [], []
                 for r in range(N):
                     fb = FrameBench(a, None, device, N, r, None, renderer=rend)
-                    dt, timing = fb.timed(steps, 1)
+                    fb.step()
+                    evs, timing = [], []
+                    for _ in range(steps):
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
+                        fb.step(timing)
+                        e1.record()
+                        evs.append((e0, e1))
+                    torch.cuda.synchronize()
+                    per = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
                     k = kernel_ms(timing, steps)
-                    ms.append(dt / steps * 1e3)
+                    ms.append(per[len(per) // 2])
                     kms.append([k.get("render_march", 0.0), k.get("render_shade", 0.0)])
                     rays.append(sum(n for _, n in timing) // steps)
                     del fb

@@ -156,6 +156,21 @@ int ugrid_adam_upd(float *param, const float *grad, float *exp_avg, float *exp_a
                    const float *perlr, int64_t N, int step, float beta1, float beta2, float lr,
                    float eps, int mode, ugrid_stream_t stream);
 
+/* NEW (round 5, no reference counterpart): the reference's optimizer loops over the parameters with one extension call each
+ * (masked_adam.py:43-75); this applies adam_upd (mode 0) or masked_adam_upd (mode 1) to n_items SMALL tensors -- the rgbnet's
+ * six -- in one launch.  h_items is a HOST array; step / lr per tensor, betas / eps shared.  Element for element the arithmetic
+ * of ugrid_adam_upd: bit-identical results. */
+typedef struct {
+  float *param;
+  const float *grad;
+  float *exp_avg, *exp_avg_sq;
+  int64_t numel;
+  int32_t step;
+  float lr;
+} ugrid_adam_item;
+int ugrid_adam_upd_multi(const ugrid_adam_item *h_items, int32_t n_items, float beta1, float beta2, float eps, int32_t mode,
+                         ugrid_stream_t stream);
+
 /* ------------------------------------------------------------------ fused render path
  * New entry points (no native counterpart in the reference): they replace the torch-op chain of
  * FourierGridModel.forward (FourierGrid_model.py:554-672) and FourierGrid.forward

@@ -46,6 +46,25 @@ def masked_adam_upd_rezero(param, grad, exp_avg, exp_avg_sq, step, beta1, beta2,
                                                   _lib.ptr(touch), _lib.stream_of(param)), "masked_adam_upd_touch")
 
 
+def adam_upd_multi(items, beta1, beta2, eps, masked):
+    """NEW (not in the reference module): adam_upd (masked=False) or masked_adam_upd (masked=True) of several SMALL tensors in ONE
+    launch -- items = [(param, grad, exp_avg, exp_avg_sq, step, lr), ...], all contiguous fp32 on one device.  Bit-identical to the
+    per-tensor calls (include/ugrid_hip.h: ugrid_adam_upd_multi)."""
+    if not items:
+        return
+    arr = (_lib.AdamItem * len(items))()
+    for a, (param, grad, exp_avg, exp_avg_sq, step, lr) in zip(arr, items):
+        named = (("param", param), ("grad", grad), ("exp_avg", exp_avg), ("exp_avg_sq", exp_avg_sq))
+        _lib.require_cuda(*named)
+        _lib.require_f32(*named)
+        a.param, a.grad, a.exp_avg, a.exp_avg_sq = param.data_ptr(), grad.data_ptr(), exp_avg.data_ptr(), exp_avg_sq.data_ptr()
+        a.numel, a.step, a.lr = param.numel(), int(step), float(lr)
+    p0 = items[0][0]
+    with _lib.guard(p0.device):
+        _lib.check(_L.ugrid_adam_upd_multi(arr, len(items), float(beta1), float(beta2), float(eps), 1 if masked else 0, _lib.stream_of(p0)),
+                   "adam_upd_multi")
+
+
 def adam_upd_with_perlr(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps):
     _run(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps, 2, "adam_upd_with_perlr")
 

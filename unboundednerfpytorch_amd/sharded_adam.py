@@ -94,6 +94,7 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         return -(-per // align) * align
 
     LINE = 64      # floats per exchanged line (256 bytes: the touched-line bitmap's granule, include/ugrid_hip.h)
+    MULTI_MAX_NUMEL = 1 << 18      # single process: tensors up to this size (the rgbnet's) share ONE update launch (adam_upd_multi)
 
     def _shard_len(self, numel, world):
         """flat elements per rank for THIS optimizer: numel / world when that is a whole number of 256-byte lines (every large
@@ -259,7 +260,9 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         if overlap and world == 1:
             side = self._side = getattr(self, '_side', None) or _low_priority_stream()
         early, self._early = (getattr(self, '_early', None) or {}), {}
+        multi = getattr(self.ops, 'adam_upd_multi', None)
         for group in self.param_groups:
+            batch = []        # small tensors of this group, updated by ONE launch at the end of the group (HIP ops only)
             for param in group['params']:
                 ref = early.get(id(param))
                 if param.grad is None or (ref is not None and ref() is param):   # (updated already by step_param during the backward)
@@ -269,6 +272,16 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                 n = param.numel()
                 use_perlr = self.per_lr is not None and param.shape == self.per_lr.shape
                 sharded = world > 1 and n >= self.min_shard_numel
+                if (multi is not None and world == 1 and n <= self.MULTI_MAX_NUMEL and param not in tv_terms and not use_perlr
+                        and grad_hook is None and param.is_cuda and param.is_contiguous() and param.grad.is_contiguous()
+                        and param.dtype == torch.float32 and param.grad.dtype == torch.float32 and param.dim() != 5):
+                    if len(state) == 0:
+                        state['step'] = 0
+                        state['exp_avg'] = torch.zeros_like(param, memory_format=torch.preserve_format)
+                        state['exp_avg_sq'] = torch.zeros_like(param, memory_format=torch.preserve_format)
+                    state['step'] += 1
+                    batch.append((param.data, param.grad, state['exp_avg'], state['exp_avg_sq'], state['step'], group['lr']))
+                    continue
                 if not sharded:
                     # replicated: every rank applies the same (summed) gradient to its own full state
                     g = param.grad
@@ -362,6 +375,8 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                     full = torch.empty(total, dtype=flat_p.dtype, device=flat_p.device)
                     dist.all_gather_into_tensor(full, p_shard, group=self.group)
                     flat_p.copy_(full[:n])
+            if batch:
+                multi(batch, group['betas'][0], group['betas'][1], group['eps'], bool(group['skip_zero_grad']))
 
     # -- sparse (touched-line) exchange ----------------------------------------------------------------
     def _line_bits(self, param, flat_g, n):
