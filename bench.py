@@ -37,7 +37,7 @@ N_CU, N_SIMD, CLK_HZ = 256, 1024, 2.4e9
 L1_PEAK_GBS = N_CU * 64 * CLK_HZ / 1e9          # vector L1 / texture path, NOMINAL: 64 B per clock per CU = 39.3 TB/s
 # ... and as MEASURED on an MI355X by tools/microbench/l1_dwordx4.hip (pure L1-hit global_load_dwordx4 stream on every CU;
 # profiles/r03/microbench_l1_dwordx4.json); None until that file exists
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r04")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
 MFMA_F16_PEAK_TFLOPS = 2500.0       # dense f16/bf16 MFMA peak
 VALU_PEAK_GINST = N_SIMD * CLK_HZ / 2 / 1e9     # one wave64 VALU instruction per 2 cycles per SIMD
 
@@ -397,7 +397,7 @@ def _load_json(path):
         return None
 
 
-def roofline_block(kern, M, R, S, shade_passes, frame_rays=None, P=7, ms_per_step=None):
+def roofline_block(kern, M, R, S, shade_passes, frame_rays=None, P=7, ms_per_step=None, pmc_workload_ok=True):
     """Per-kernel utilisation of every candidate limit, and ONE summary entry: always the frame kernel with the LOWER fraction of
     its roof (no window, no tie rule: VERDICT r3 weak #4).
 
@@ -424,6 +424,9 @@ def roofline_block(kern, M, R, S, shade_passes, frame_rays=None, P=7, ms_per_ste
     if pmc and pmc.get("device_code_sha16") != code:
         pmc_refused = "counters of %s were taken on device code %s, this library is %s" % (
             os.path.relpath(ppath, ROOT), pmc.get("device_code_sha16"), code)
+        pmc = {}
+    elif pmc and not pmc_workload_ok:
+        pmc_refused = "counters of %s were taken on the default S1 frame, this run renders another workload" % os.path.relpath(ppath, ROOT)
         pmc = {}
     scale = 1.0 if not frame_rays else R / float(frame_rays)     # counters are per whole-frame launch: a rank's share
     l1m = (_load_json(os.path.join(PROFILE_DIR, "microbench_l1_dwordx4.json"))
@@ -467,11 +470,16 @@ def roofline_block(kern, M, R, S, shade_passes, frame_rays=None, P=7, ms_per_ste
         for k_src in ("sq_wait_any_of_wave_cycles", "sq_wait_inst_any_of_wave_cycles", "sq_active_inst_any_of_wave_cycles"):
             if k_src in c:
                 e[k_src] = c[k_src]
+        if "rocprofv3_avg_ms" in c:
+            # the average duration of this kernel in the committed `rocprofv3 --kernel-trace --stats` run of the same command
+            # (profiles/r05/bench_s1_kernel_stats.csv): the live HIP-event time above must agree with it
+            e["rocprofv3_avg_ms"] = c["rocprofv3_avg_ms"] * scale
+            e["hip_event_over_rocprofv3"] = ms / max(1e-9, c["rocprofv3_avg_ms"] * scale)
         if "gui_active_cycles" in c and scale == 1.0:
             # the chip runs these kernels at its power-limited clock, well below the 2.4 GHz the peaks assume: the same
             # counts against the cycles the kernel actually had (profiled launch) = how busy the units were
             cyc = c["gui_active_cycles"]
-            e["effective_clock_GHz_profiled"] = cyc / (c.get("profiled_ms", ms) * 1e-3) / 1e9
+            e["effective_clock_GHz_profiled"] = cyc / (c.get("pmc_pass_avg_ms", c.get("rocprofv3_avg_ms", ms)) * 1e-3) / 1e9
             if "valu_insts" in c:
                 e["valu_issue_busy"] = c["valu_insts"] * 2.0 / N_SIMD / cyc
             if "mfma_busy_cycles" in c:
@@ -507,13 +515,61 @@ def roofline_block(kern, M, R, S, shade_passes, frame_rays=None, P=7, ms_per_ste
                                                        "source": "profiles/r03/microbench_l1_dwordx4.json" if l1m else None},
                       "mfma_f16_TFLOPs": MFMA_F16_PEAK_TFLOPS,
                       "valu_Ginst_per_s": VALU_PEAK_GINST, "clock_GHz_assumed": CLK_HZ / 1e9},
-            "frame": {"algorithmic_bytes_formula": "R*S*224 + M*2688 + R*56 = %d" % (sum(alg.values())),
-                      "frac_of_hbm_algorithmic": sum(alg.values()) / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      "hbm_bytes_pmc": frame_hbm or None,
-                      "hbm_frac": (frame_hbm / (frame_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if frame_hbm else None},
+            "frame": frame_block(per, alg, mfma_flops, useful_flops, frame_ms, frame_hbm, ms_per_step, P),
             "pmc_source": src, "pmc_device_code_sha16": pmc.get("device_code_sha16"),
             "pmc_refused": pmc_refused, "pmc_scaled_to_rank_share": scale if scale != 1.0 else None,
             "per_kernel": per}
+
+
+def frame_block(per, alg, mfma_flops, useful_flops, kernels_ms, frame_hbm, ms_per_step, P):
+    """The whole frame against the two peaks MI355X_MICROARCH.md lists: every number one line of arithmetic from
+    the committed profiles (profiles/r05/pmc_summary.json, bench_s1_kernel_stats.csv) + the guide.  `ms` = the step time the line's
+    `value` is computed from (ray generation + march + shade + un-tiling) when given, else the two kernels' sum."""
+    ms = ms_per_step if ms_per_step else kernels_ms
+    t = ms * 1e-3
+    alg_total = sum(alg.values())
+    shade = per.get("render_shade", {})
+    out = {"ms": ms, "kernels_ms": kernels_ms,
+           "algorithmic_bytes": alg_total,
+           "algorithmic_bytes_formula": "R*S*32*P + M*384*P + R*56 with P = %d (SURVEY 8d: 224 B per sample, 2688 B per survivor at P = 7)" % P,
+           "frac_of_hbm_algorithmic": alg_total / t / 1e9 / HBM_PEAK_GBS,
+           "frac_of_hbm_algorithmic_note": "algorithmic gather bytes / step time / 8 TB/s: > 1 because the caches serve them (L1 hit rate 0.93) -- "
+                                           "NOT a roofline fraction; the north star's '>= 70 % of the HBM roofline' cannot describe a cache-blocked gather",
+           "hbm_bytes_pmc": frame_hbm or None,
+           "hbm_frac": (frame_hbm / t / 1e9 / HBM_PEAK_GBS) if frame_hbm else None,
+           "hbm_frac_note": "counter HBM bytes (TCC_EA0 request sizes + WRITE_SIZE) of march + shade / step time / 8 TB/s",
+           "mfma_executed_TFLOPs": sum(mfma_flops.values()) / t / 1e12,
+           "mfma_executed_frac_of_2.5PF": sum(mfma_flops.values()) / t / 1e12 / MFMA_F16_PEAK_TFLOPS,
+           "mfma_useful_TFLOPs": sum(useful_flops.values()) / t / 1e12,
+           "mfma_useful_frac_of_2.5PF": sum(useful_flops.values()) / t / 1e12 / MFMA_F16_PEAK_TFLOPS,
+           "mfma_note": "executed = 132 v_mfma_f32_32x32x16_f16 per 32-survivor pass (fp16x2: three products per useful one, K padded 39 -> 48); "
+                        "useful = 43 520 flop per survivor (SURVEY 8d); over the WHOLE step time -- over the shade kernel alone: "
+                        "%.3f executed / %.3f useful of 2.5 PFLOP/s" % (shade.get("mfma_frac", 0.0), shade.get("mfma_useful_TFLOPs", 0.0) / MFMA_F16_PEAK_TFLOPS),
+           "clock_GHz_profiled": {k: v.get("effective_clock_GHz_profiled") for k, v in per.items()},
+           "clock_note": "GRBM_GUI_ACTIVE / 8 XCDs / the launch's duration in the counter pass; the peaks above assume 2.4 GHz"}
+    return out
+
+
+def hbm_roofline_entry(r):
+    """The one kernel of the path the north star's "fraction of the HBM roofline" can be checked on: the fused
+    dense TV + Adam pass over S3's k0 grid streams seven 3.46 GB arrays, each byte once.  `achieved` = algorithmic bytes / the live
+    HIP-event time; `traffic` = the bytes the launch really moved (TCC_EA0 read / write request counters of a separate rocprofv3 --pmc
+    pass, profiles/r05/tv_adam_dense_pmc.json, merged only for the same device code)."""
+    out = {"kernel": r["kernel"], "bound": "hbm", "achieved": r["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": r["achieved"] / HBM_PEAK_GBS,
+           "ms": r["ms"], "algorithmic_bytes": r["algorithmic_bytes"], "traffic": None,
+           "note": "ugrid_tv_adam_dense_cl on the S3 k0 grid (P = 9, C = 12, 200^3, channel-last): 7 arrays x 3.456e9 B, each byte once; "
+                   "frac = algorithmic bytes / time / 8 TB/s (the guide's spec peak; ~6.3 TB/s is what it calls achievable: %.2f of that)"
+                   % (r["achieved"] / 6300.0)}
+    p = _load_json(os.path.join(PROFILE_DIR, "tv_adam_dense_pmc.json"))
+    if p and p.get("device_code_sha16") == device_code_sha16():
+        out["traffic"] = p.get("hbm_bytes")
+        out["traffic_read_bytes"], out["traffic_write_bytes"] = p.get("hbm_read_bytes"), p.get("hbm_write_bytes")
+        out["traffic_over_algorithmic"] = p.get("hbm_bytes") / float(r["algorithmic_bytes"]) if p.get("hbm_bytes") else None
+        out["traffic_GBps"] = p.get("hbm_bytes") / (r["ms"] * 1e-3) / 1e9 if p.get("hbm_bytes") else None
+        out["pmc_source"] = "profiles/r05/tv_adam_dense_pmc.json"
+    elif p:
+        out["pmc_refused"] = "counters were taken on device code %s" % p.get("device_code_sha16")
+    return out
 
 
 def s3_train_step_block(device):
@@ -828,8 +884,10 @@ def main():
             if M_rank is not None:
                 # rank 0's own kernels: its share of the frame's rays and survivors (the whole frame at N = 1)
                 shade_passes = (M_rank + 31) // 32 + rays_this_rank // 64 // 2      # ~ sum over tiles of ceil(count / 32)
+                default_s1 = (args.scene == "s1" and args.freq == 3 and not args.stepsize and G == 200 and (fb.H, fb.W) == (1080, 1920)
+                              and not args.shuffle_rays and args.ray_tile == 8)
                 res["roofline"] = roofline_block(kern, M_rank, rays_this_rank, S, shade_passes, frame_rays=R, P=1 + 2 * args.freq,
-                                                 ms_per_step=ms_step)
+                                                 ms_per_step=ms_step if world == 1 else None, pmc_workload_ok=default_s1)
             else:
                 res["roofline"] = None
         if proxy is not None:
@@ -901,6 +959,8 @@ def main():
         s3 = s3_train_step_block(device)
         if s3 is not None:
             res["secondary_s3_train_step"] = s3
+            if isinstance(s3.get("roofline_tv_adam_dense"), dict):
+                res["roofline_hbm"] = hbm_roofline_entry(s3["roofline_tv_adam_dense"])
         res["secondary_voxgo_train_steps"] = voxgo_train_block()
     if rank == 0:
         print(json.dumps(res))

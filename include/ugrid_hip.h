@@ -492,8 +492,9 @@ int ugrid_train_sample_compact_vox(int64_t n_rays, int32_t slots_per_ray, float 
  * (fourier_freq_num, k0 channels, viewbase_pe) triple, else 0 (they return hipErrorNotSupported for it). */
 int ugrid_shade_supported(int32_t freq_num, int32_t k0_channels, int32_t viewbase_pe);
 
-/* Tuning knobs (speed only, never results): "march_waves" 4..6 (waves per SIMD of the march kernel); "tv_xcd" 0|1|2
- * (dense TV / TV + Adam kernels: linear workgroup order | XCD-contiguous | + non-temporal streams, default 2);
+/* Tuning knobs (speed only, never results): "march_waves" 4..6 (waves per SIMD of the march kernel); "tv_xcd" 0|1|2|3
+ * (dense TV / TV + Adam kernels: linear workgroup order | XCD-contiguous | + non-temporal streams | + slab order (i-planes of a
+ * j-slab stay in L2) for the fused channel-last pass, default 3);
  * "shade_pc" 0|1|2 (shade kernel geometry: classic | 8-wave producer / consumer | 12-wave where it applies, default 2 --
  * bit-identical results).  Anything else returns hipErrorInvalidValue. */
 int ugrid_tune(const char *key, int value);

@@ -544,3 +544,42 @@ def test_fused_rgbnet_matches_torch_linear_layers(M, C, E, W):
         scale = float(b.abs().max()) + 1e-12
         tol = (3e-5 if flips == 0 else 1e-2) * scale + 1e-6
         assert float((a - b).abs().max()) <= tol, (n, float((a - b).abs().max()), scale, flips)
+
+
+@pytest.mark.parametrize("shape", [(1, 12, 8, 128, 96), (2, 4, 5, 300, 128), (3, 12, 24, 40, 40)])
+@pytest.mark.parametrize("skip_zero", [True, False])
+def test_slab_ordered_dense_tv_adam_is_bit_identical(shape, skip_zero):
+    """Round 5: the fused dense TV + Adam pass on channel-last grids visits the array in slabs of j-rows, i fastest over the slabs'
+    planes (k_tv_cl_slab, ugrid_tune tv_xcd = 3, the default), so that the i-1 / i+1 neighbour planes are found in L2 instead of
+    being fetched from memory three times.  Same loads, same expression per element: the result must equal the linear kernel's
+    (tv_xcd = 2) and the reference's two calls (total_variation_add_grad(dense) then (masked_)adam_upd) bit for bit -- three slabs
+    with a ragged last one (128 = 56 + 56 + 16 rows; 300 = 128 + 128 + 44, two levels), and a grid whose planes are too small for
+    the slab order (falls back to the linear kernel: same bits again)."""
+    from unboundednerfpytorch_amd import adam_upd_cuda as ad, total_variation_cuda as tv
+    from unboundednerfpytorch_amd.fourier_render import tune
+    g = torch.Generator(device="cuda").manual_seed(17)
+    cl = lambda t: t.contiguous(memory_format=torch.channels_last_3d)
+    p0 = cl(torch.randn(shape, device="cuda", generator=g))
+    gr = cl(torch.randn(shape, device="cuda", generator=g) * (torch.rand(shape, device="cuda", generator=g) < 0.1))
+    m0 = cl(torch.randn(shape, device="cuda", generator=g) * 0.01)
+    v0 = cl(torch.rand(shape, device="cuda", generator=g) * 0.01)
+    args = (5, 0.9, 0.99, 0.1, 1e-8)
+    outs = {}
+    try:
+        for mode in (2, 3):
+            tune("tv_xcd", mode)
+            m, v = m0.clone(memory_format=torch.preserve_format), v0.clone(memory_format=torch.preserve_format)
+            out = torch.empty_like(p0, memory_format=torch.preserve_format)
+            assert ad.tv_adam_dense(p0, out, gr, m, v, 0.3, 0.3, 0.3, *args, skip_zero)
+            outs[mode] = (out, m, v)
+    finally:
+        tune("tv_xcd", 3)
+    for a, b in zip(outs[2], outs[3]):
+        assert torch.equal(a, b)
+    # ... and the reference's two calls
+    pr, gr2 = p0.clone(memory_format=torch.preserve_format), gr.clone(memory_format=torch.preserve_format)
+    mr, vr = m0.clone(memory_format=torch.preserve_format), v0.clone(memory_format=torch.preserve_format)
+    tv.total_variation_add_grad(pr, gr2, 0.3, 0.3, 0.3, True)
+    (ad.masked_adam_upd if skip_zero else ad.adam_upd)(pr, gr2, mr, vr, *args)
+    assert torch.equal(outs[3][0], pr) and torch.equal(outs[3][1], mr) and torch.equal(outs[3][2], vr)
+    assert not torch.equal(pr, p0)

@@ -66,11 +66,13 @@ def main():
     opt = create_optimizer_or_freeze_model(m, cfg, 0, sharded=True)
     assert isinstance(opt, ShardedMaskedAdam) and not m.k0.grid.is_contiguous()
     steps = (1, 2, 10001)        # two dense-TV iterations and one in the masked-TV phase
+    exchanges = []
     for i, s in enumerate(steps):
         o, d, v, rgb = bts.random_rays(2048, dev, seed=40 + i)
         sl = slice(rank * 1024, (rank + 1) * 1024)
         ts.train_iteration(m, opt, o[sl].contiguous(), d[sl].contiguous(), v[sl].contiguous(), rgb[sl].contiguous(), cfg, s, rk,
                            near_thres=near, world_size=world)
+        exchanges.append({k: v for k, v in (opt.last_exchange.get(id(m.k0.grid)) or {}).items() if k in ("mode", "line_source", "lines_union", "lines_total")})
     sharded_state = opt.state[m.k0.grid]["exp_avg"].numel() < m.k0.grid.numel()
     sd = opt.state_dict()        # collective: full-shape moments on every rank
     res = None
@@ -92,7 +94,7 @@ def main():
         # relative to each tensor's own scale (the moments of the grids are ~1e-7): a layout mix-up must not hide in an absolute bound
         mom = max(float((sd["state"][i]["exp_avg"].cpu() - rsd["state"][i]["exp_avg"].cpu()).abs().max())
                   / (float(rsd["state"][i]["exp_avg"].abs().max()) + 1e-30) for i in rsd["state"])
-        res = {"world": world, "sharded_k0_state": bool(sharded_state), "k0_channels_last": True, "collectives": notes,
+        res = {"world": world, "sharded_k0_state": bool(sharded_state), "k0_channels_last": True, "collectives": notes, "k0_exchange_per_step": exchanges,
                "frac_elements_off_by_more_than_2pct_of_a_step": frac, "max_abs_param_diff": worst, "max_rel_exp_avg_diff": mom,
                "ok": bool(max(frac.values()) < 1e-4 and mom < 1e-2)}
     dist.barrier()

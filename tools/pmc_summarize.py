@@ -1,6 +1,6 @@
 """Turn the rocprofv3 --pmc passes of tools/gpu_pmc.sh (gpurun_out/<tag>/pmc_csv/pmc_pass_*.csv, or profiles/rNN/pmc/) into
 profiles/<round>/pmc_summary.json, the static per-launch counters bench.py's roofline block combines with its live times.
-usage: python tools/pmc_summarize.py <dir with pmc_pass_*.csv> <device_code_sha16> [out.json]
+usage: python tools/pmc_summarize.py <dir with pmc_pass_*.csv> <device_code_sha16> [out.json] [kernel_stats.csv of `rocprofv3 --stats`]
 
 HBM bytes per launch: FETCH_SIZE [KB] x 1024 x f + WRITE_SIZE [KB] x 1024, where f is the factor CALIBRATED for the kernel's
 access shape by tools/microbench/fetch_calib.hip (profiles/r04/microbench_fetch_calib.json): the guide's x 2 holds for wide
@@ -32,7 +32,14 @@ FETCH_SHAPE = {"render_march": "records_32B", "render_shade": "records_384B"}   
 def main():
     tag = sys.argv[1]
     code = sys.argv[2] if len(sys.argv) > 2 else None
-    dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r04", "pmc_summary.json")
+    dst = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r05", "pmc_summary.json")
+    stats_csv = sys.argv[4] if len(sys.argv) > 4 else None
+    avg_ms = {}
+    if stats_csv and os.path.exists(stats_csv):      # rocprofv3 --kernel-trace --stats of the same command: average duration per kernel
+        for r in csv.DictReader(open(stats_csv)):
+            for k, name in NAMES.items():
+                if k in r["Name"]:
+                    avg_ms[name] = float(r["AverageNs"]) / 1e6
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     files = sorted(glob.glob(os.path.join(tag, "**", "pmc_pass_*.csv"), recursive=True))
     for f in files:
@@ -52,6 +59,8 @@ def main():
     for name, d in agg.items():
         m = {c: sum(v) / len(v) for c, v in d.items()}
         e = {"counters": m, "launches": max(len(v) for v in d.values())}
+        if name in avg_ms:
+            e["rocprofv3_avg_ms"] = avg_ms[name]
         if "FETCH_SIZE" in m:
             f = 2.0
             if cal and FETCH_SHAPE.get(name) in cal.get("fetch_size_factor", {}):

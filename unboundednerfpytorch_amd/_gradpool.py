@@ -30,6 +30,7 @@ import torch
 _POOL = {}          # id(param) -> (weakref to param, buffer)
 _TOUCH = {}         # id(param) -> [data_ptr of the buffer, bitmap (int32 tensor), numel]
 _CERT = {}          # id(param) -> marking backward calls since certify() (the bitmap is valid only at exactly 1)
+_FINAL = set()      # ids of parameters that already carry the clean-up finalizer (ONE per parameter, not one per training step)
 enabled = True
 touch_enabled = True
 
@@ -60,10 +61,19 @@ def certify(params):
     for p in params:
         if isinstance(p, torch.nn.Parameter) and p.requires_grad:
             k = id(p)
-            if k not in _CERT:
-                weakref.finalize(p, _CERT.pop, k, None)
-                weakref.finalize(p, _TOUCH.pop, k, None)
+            if k not in _FINAL:
+                # decertify() pops the _CERT entry after every training step, so "k not in _CERT" held at every step: two new
+                # finalizers per certified grid per iteration, ~80 k objects over a 40 k-step run, all firing at pg_scale or exit
+                # (ADVICE r4).  One finalizer per parameter object, registered once, cleans all three tables.
+                _FINAL.add(k)
+                weakref.finalize(p, _forget, k)
             _CERT[k] = 0
+
+
+def _forget(k):
+    _CERT.pop(k, None)
+    _TOUCH.pop(k, None)
+    _FINAL.discard(k)
 
 
 def decertify(params):
@@ -112,6 +122,12 @@ def touch_of(param, g):
     if ent is None or g is not param.grad or ent[0] != g.data_ptr() or ent[2] != g.numel() or g.stride() != param.stride():
         return None
     return ent[1]
+
+
+def consume_touch(param):
+    """the bitmap of `param`'s gradient has been read AND cleared by a consumer that did not re-zero the buffer (the data-parallel
+    exchange, sharded_adam._line_bits): it no longer describes the gradient, so nobody else may be served it in this step"""
+    _TOUCH.pop(id(param), None)
 
 
 def clear():

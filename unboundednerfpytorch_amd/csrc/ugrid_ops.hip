@@ -843,6 +843,37 @@ k_tv_cl_vec4(const float *__restrict__ param, float *__restrict__ param_out, flo
                                  eps, rezero, ug_touched(touch, q));
 }
 
+// SLAB ORDER of the fused dense pass (round 5, tv_xcd = 3).  The linear walk fetches every i-plane of the parameter about THREE times
+// from memory: the i-1 / i+1 neighbours of a voxel are a whole plane away (Y x Z x C x 4 B = 1.9 MB at S3's k0 grid), a parameter
+// line would have to survive two plane-times in an XCD's 4 MB L2 beside four streaming arrays, and the request counters show it
+// does not -- 20.7 GB read per launch where 13.8 GB are needed, 31.0 GB moved in 4.31 ms = 7.2 TB/s of fabric traffic for 5.6 TB/s of
+// useful bytes (profiles/r05/tv_adam_dense_pmc.txt).  Here the SAME one-float4-per-lane kernel visits the array in slabs of JW rows
+// of j: workgroup b -> (level, slab, i, chunk of the slab's row run) with the chunk fastest, then i, then the slab -- three
+// consecutive i-planes of a slab are 3 x JW x Z x C x 4 B = 720 KB and stay in L2, a slab's two boundary rows are the only lines
+// read twice (8 %).  Same loads, same expression per element: bit-identical results.  (A variant that walked along i inside a
+// workgroup with the three centre values in registers cut the reads to 14.2 GB as well but ran 10 % SLOWER: every step of every
+// resident workgroup jumped 1.9 MB in seven arrays -- profiles/r05/tv_adam_dense_ab.txt.)
+struct ug_tv_slab { unsigned jw, n_slab, blocks_per_row_run, row4; };      // row4 = Z x C / 4 float4 per j-row
+
+template <int ADAM>
+__global__ void __launch_bounds__(256)
+k_tv_cl_slab(const float *__restrict__ param, float *__restrict__ param_out, float *__restrict__ grad,
+             float *__restrict__ exp_avg, float *__restrict__ exp_avg_sq, float wy, float wz, int sz_i, int sz_j,
+             int sz_k, int C, unsigned n4, ug_tv_slab sl, float step_size, float beta1, float beta2, float eps, int rezero,
+             const uint32_t *__restrict__ touch) {
+  const unsigned b = ug_xcd_block<1>();
+  const unsigned chunk = b % sl.blocks_per_row_run, r1 = b / sl.blocks_per_row_run;
+  const unsigned i = r1 % (unsigned)sz_i, r2 = r1 / (unsigned)sz_i;
+  const unsigned slab = r2 % sl.n_slab, level = r2 / sl.n_slab;
+  const unsigned j0 = slab * sl.jw, rows = min(sl.jw, (unsigned)sz_j - j0);
+  const unsigned within = chunk * 256u + threadIdx.x;
+  if (within >= rows * sl.row4) return;
+  const unsigned q = ((level * (unsigned)sz_i + i) * (unsigned)sz_j + j0) * sl.row4 + within;
+  if (q >= n4) return;
+  ug_tv_cl_one<true, ADAM, 2>(param, param_out, grad, exp_avg, exp_avg_sq, wy, wz, sz_i, sz_j, sz_k, C, q, step_size, beta1, beta2,
+                              eps, rezero, ug_touched(touch, q));
+}
+
 // masked TV gradient on the marked lines of a recycled gradient (UG_TOUCH_WALK)
 __global__ void __launch_bounds__(256)
 k_tv_cl_touch(const float *__restrict__ param, float *__restrict__ grad, float wy, float wz, int sz_i, int sz_j, int sz_k, int C,
@@ -851,8 +882,9 @@ k_tv_cl_touch(const float *__restrict__ param, float *__restrict__ grad, float w
                                                                (unsigned)q, 0.f, 0.f, 0.f, 0.f, 0, true));)
 }
 
-static int g_tv_xcd = 2;   // ugrid_tune("tv_xcd", 0|1|2): dense TV (+ Adam) kernels: linear block order | XCD-contiguous | + non-temporal streams
-extern "C" int ug_set_tv_xcd(int m) { if (m < 0 || m > 2) return 1; g_tv_xcd = m; return 0; }
+static int g_tv_xcd = 3;   // ugrid_tune("tv_xcd", 0|1|2|3): dense TV (+ Adam) kernels: linear block order | XCD-contiguous | + non-temporal
+                           // streams | + slab order of the fused channel-last pass (k_tv_cl_slab, default)
+extern "C" int ug_set_tv_xcd(int m) { if (m < 0 || m > 3) return 1; g_tv_xcd = m; return 0; }
 
 // ----------------------------------------------------------------------------------------------
 // C ABI
@@ -1129,8 +1161,31 @@ static int ug_tv_adam_dense_cl(const float *param, float *param_out, const float
   const unsigned n4 = (unsigned)(N / 4);
   float *g = const_cast<float *>(grad);   // ADAM != 0 never writes the gradient
   const dim3 gr((n4 + 255) / 256), bl(256);
+  // slab order (k_tv_cl_slab) when an i-plane is too large to stay in L2 across two plane-times: >= 512 KB per plane
+  const int64_t row4 = sz_k * C / 4, plane_bytes = sz_j * row4 * 16;
+  if (g_tv_xcd == 3 && sz_i >= 4 && sz_j >= 16 && plane_bytes >= (512 << 10) && N % (sz_i * sz_j * row4 * 4) == 0) {
+    ug_tv_slab sl;
+    sl.row4 = (unsigned)row4;
+    // rows per slab: three slab-planes (+ the streams' working set) well inside the 4 MB L2 -> about 256 KB per slab-plane
+    int64_t jw = (256 << 10) / (row4 * 16);
+    jw = jw < 4 ? 4 : (jw > sz_j ? sz_j : jw);
+    sl.jw = (unsigned)jw;
+    sl.n_slab = (unsigned)((sz_j + jw - 1) / jw);
+    sl.blocks_per_row_run = (unsigned)((jw * row4 + 255) / 256);
+    const int64_t levels = N / (sz_i * sz_j * row4 * 4);
+    const int64_t blocks = levels * sl.n_slab * sz_i * sl.blocks_per_row_run;
+    if (blocks < ((int64_t)1 << 31)) {
+#define UG_TV_SLAB_ARGS param, param_out, g, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, sl, step_size, beta1, beta2, eps, rezero, (const uint32_t *)touch
+      if (skip_zero_grad) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_slab<1>), dim3((unsigned)blocks), bl, 0, ST(s), UG_TV_SLAB_ARGS);
+      else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_slab<2>), dim3((unsigned)blocks), bl, 0, ST(s), UG_TV_SLAB_ARGS);
+#undef UG_TV_SLAB_ARGS
+      UG_LAUNCH_CHECK();
+      if (touch && rezero) UG_HIP(hipMemsetAsync(touch, 0, sizeof(uint32_t) * (size_t)ugrid_touch_words(N), ST(s)));
+      return 0;
+    }
+  }
 #define UG_TV_CL_ARGS param, param_out, g, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, step_size, beta1, beta2, eps, rezero, (const uint32_t *)touch
-  if (g_tv_xcd == 2) {
+  if (g_tv_xcd >= 2) {
     if (skip_zero_grad) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 1, 2>), gr, bl, 0, ST(s), UG_TV_CL_ARGS);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<true, 2, 2>), gr, bl, 0, ST(s), UG_TV_CL_ARGS);
   } else if (g_tv_xcd) {
@@ -1176,7 +1231,7 @@ extern "C" int ugrid_tv_adam_dense(const float *param, float *param_out, const f
   const unsigned n4 = (unsigned)(N / 4);
   const dim3 gr((n4 + 255) / 256), bl(256);
 #define UG_TV_ARGS param, param_out, grad, exp_avg, exp_avg_sq, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, n4, step_size, beta1, beta2, eps, rezero
-  if (g_tv_xcd == 2) {
+  if (g_tv_xcd >= 2) {      // (canonical layout, C = 1: an i-plane is Y x Z floats -- 160 KB at G = 200 -- and stays in L2: no sweep needed)
     if (skip_zero_grad) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_adam_vec4<true, 2>), gr, bl, 0, ST(s), UG_TV_ARGS);
     else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_adam_vec4<false, 2>), gr, bl, 0, ST(s), UG_TV_ARGS);
   } else if (g_tv_xcd) {

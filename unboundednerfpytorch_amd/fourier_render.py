@@ -28,7 +28,7 @@ _p = _lib.ptr
 
 
 def tune(key, value):
-    """Speed-only tuning knobs (ugrid_tune, include/ugrid_hip.h): 'march_waves' 4..6, 'tv_xcd' 0|1|2, 'shade_pc' 0|1|2."""
+    """Speed-only tuning knobs (ugrid_tune, include/ugrid_hip.h): 'march_waves' 4..6, 'tv_xcd' 0|1|2|3, 'shade_pc' 0|1|2."""
     _lib.check(_L.ugrid_tune(key.encode(), int(value)), "ugrid_tune(%s)" % key)
 
 

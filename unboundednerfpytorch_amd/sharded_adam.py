@@ -97,8 +97,9 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
     MULTI_MAX_NUMEL = 1 << 18      # single process: tensors up to this size (the rgbnet's) share ONE update launch (adam_upd_multi)
 
     def _shard_len(self, numel, world):
-        """flat elements per rank for THIS optimizer: numel / world when that is a whole number of 256-byte lines (every large
-        grid: the sparse exchange then applies), else the 4-voxel-aligned split with a padded tail (dense collectives)"""
+        """flat elements per rank for THIS optimizer: ceil(numel / world) rounded up to the update kernels' 4-voxel vectors.  The sparse
+        (touched-line) exchange applies when that split happens to be exact and a whole number of 256-byte lines per rank -- every
+        large grid at world 2 / 4 / 8 (_sparse_plan checks it) -- else the dense collectives run on a zero-padded copy"""
         return self.shard_len(numel, world, 4)
 
     def set_pervoxel_lr(self, count):
@@ -332,6 +333,7 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                     g_shard = self._sparse_reduce_scatter(plan, flat_g, per, world, rank)
                     self.last_exchange[id(param)] = {
                         "mode": "sparse reduce-scatter, dense all-gather", "lines_total": n // self.LINE, "lines_union": int(plan["lines"].numel()),
+                        "line_source": getattr(self, "_line_source", None),
                         "rows_per_rank_padded": plan["M"], "bitmap_bytes": plan["bitmap_bytes"],
                         "reduce_scatter_bytes": plan["M"] * world * self.LINE * 4, "all_gather_bytes": per * world * 4,
                         "dense_bytes_each_way": n * 4}
@@ -387,8 +389,13 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
         if t is not None and t.numel() * 32 >= nl:
             w = t.view(-1, 1)
             bits = ((w >> torch.arange(32, device=t.device, dtype=torch.int32)[None, :]) & 1).reshape(-1)[:nl].bool()
-            t.zero_()      # this gradient buffer is not recycled by the sharded step: its successor starts from a clean bitmap
+            # this gradient buffer is not recycled by the sharded step: its successor starts from a fresh bitmap, and the one just
+            # read is DROPPED rather than zeroed in place -- param.grad still holds data, and a zeroed bitmap served to a later
+            # touch_of consumer of the same step would claim "every line is zero" 
+            _gradpool.consume_touch(param)
+            self._line_source = "backward's touched-line bitmap"
             return bits
+        self._line_source = "scan of the gradient"
         return flat_g.view(nl, self.LINE).ne(0).any(dim=1)
 
     def _sparse_plan(self, param, flat_g, n, per, world, rank):

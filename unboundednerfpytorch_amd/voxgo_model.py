@@ -61,8 +61,11 @@ class _VoxGOBase(nn.Module):
         self.voxel_size_ratio = self.voxel_size / self.voxel_size_base
 
     def _vertices(self, shape):
-        axes = [torch.linspace(float(self.xyz_min[a]), float(self.xyz_max[a]), int(shape[a])) for a in range(3)]
-        return torch.stack(torch.meshgrid(*axes, indexing='ij'), -1).to(self.xyz_min.device)
+        # a DEVICE linspace between the fp32 buffers, as the reference forms it (dvgo.py:141-146, 187-192 under its CUDA default
+        # tensor type): torch's CPU and GPU linspace kernels can differ by an ulp, which moves a mask vertex at a cell boundary
+        dev = self.xyz_min.device
+        axes = [torch.linspace(self.xyz_min[a], self.xyz_max[a], int(shape[a]), device=dev) for a in range(3)]
+        return torch.stack(torch.meshgrid(*axes, indexing='ij'), -1)
 
     def _new_mask(self, mask):
         return _grid.MaskGrid(path=None, mask=mask, xyz_min=self.xyz_min, xyz_max=self.xyz_max)
@@ -99,6 +102,17 @@ class _VoxGOBase(nn.Module):
         alpha = self.activate_density(self.density(xyz)[None, None])
         alpha = F.max_pool3d(alpha, kernel_size=3, padding=1, stride=1)[0, 0]
         self.mask_cache.mask &= (alpha > self.fast_color_thres)
+
+    def __setattr__(self, name, value):
+        # a replaced mask cache (scale_volume_grid, a checkpoint loader, user code) may reuse the id and the storage address of the
+        # freed one: the host copies of its scale / shift are dropped whenever the attribute is assigned
+        if name == 'mask_cache':
+            object.__setattr__(self, '_hc_ver', None)
+        super().__setattr__(name, value)
+
+    def _apply(self, fn, *a, **k):
+        object.__setattr__(self, '_hc_ver', None)      # .to(device) / .float(): new storages under old versions
+        return super()._apply(fn, *a, **k)
 
     def _host_consts(self):
         """host copies of the small buffers the kernel takes by value, refreshed only when they change: no device-to-host read
