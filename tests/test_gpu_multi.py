@@ -202,7 +202,9 @@ def test_data_parallel_training_on_two_gloo_ranks_sharing_this_gpu():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29950 + os.getpid() % 40), os.path.join(ROOT, "tools", "dp_train_2rank_shared_gpu.py")]
+           "--master-port", str(29950 + os.getpid() % 40), os.path.join(ROOT, "tools", "dp_train_2rank_shared_gpu.py"), "--grid", "128", "--rays", "1024"]
+    # (G = 128: 3.5 M lines of 256 B in the k0 grid, a 1024-ray batch touches a few per cent of them -- at the tool's default G = 64
+    # a batch touches most lines and the optimizer rightly keeps the dense collectives)
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])

@@ -21,6 +21,11 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--grid", type=int, default=64)
+    ap.add_argument("--rays", type=int, default=2048, help="global batch (split over the ranks)")
+    a = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cuda", 0)
@@ -58,8 +63,9 @@ def main():
         dist.all_gather_into_tensor = ag
 
     cfg = dict(bts.TRUCK_CFG)
-    cfg.update(weight_nearclip=0.01, N_rand=2048)
-    G, F, near = 64, 4, 0.2
+    cfg.update(weight_nearclip=0.01, N_rand=a.rays)
+    G, F, near = a.grid, 4, 0.2
+    NR, per = a.rays, a.rays // world
     rk = dict(stepsize=0.5, rand_bkgd=False)
     torch.manual_seed(0)
     m = bts.make_model(G, F, dev, fused=True)
@@ -68,8 +74,8 @@ def main():
     steps = (1, 2, 10001)        # two dense-TV iterations and one in the masked-TV phase
     exchanges = []
     for i, s in enumerate(steps):
-        o, d, v, rgb = bts.random_rays(2048, dev, seed=40 + i)
-        sl = slice(rank * 1024, (rank + 1) * 1024)
+        o, d, v, rgb = bts.random_rays(NR, dev, seed=40 + i)
+        sl = slice(rank * per, (rank + 1) * per)
         ts.train_iteration(m, opt, o[sl].contiguous(), d[sl].contiguous(), v[sl].contiguous(), rgb[sl].contiguous(), cfg, s, rk,
                            near_thres=near, world_size=world)
         exchanges.append({k: v for k, v in (opt.last_exchange.get(id(m.k0.grid)) or {}).items() if k in ("mode", "line_source", "lines_union", "lines_total")})
@@ -81,7 +87,7 @@ def main():
         ref = bts.make_model(G, F, dev, fused=True)
         ropt = create_optimizer_or_freeze_model(ref, cfg, 0)
         for i, s in enumerate(steps):
-            o, d, v, rgb = bts.random_rays(2048, dev, seed=40 + i)
+            o, d, v, rgb = bts.random_rays(NR, dev, seed=40 + i)
             ts.train_iteration(ref, ropt, o, d, v, rgb, cfg, s, rk, near_thres=near, world_size=1)
         torch.cuda.synchronize()
         frac, worst = {}, {}
