@@ -10,8 +10,8 @@ scan) + shade (k0 query + rgbnet + weighted sum); grids and camera are resident 
   python bench.py [--gpus N --steps K --warmup W]          (N>1: launched by torch.distributed.run)
 
 Prints ONE JSON line on rank 0.  value = Msamples/s = R * S / t_step (all generated samples, before thresholding).
-Multi-GPU is STRONG-scaled: the N ranks render ONE frame -- rank r takes the 64-ray tiles r, r+N, ... (or a contiguous
-band with --contiguous) and the rendered tiles [R/N,5] are exchanged with one RCCL all-gather inside the timed step
+Multi-GPU is STRONG-scaled: the N ranks render ONE frame -- rank r takes a contiguous band of the frame's 64-ray tiles (--deal rows /
+tiles: block rows or single tiles dealt round-robin) and the rendered tiles [R/N,5] are exchanged with one RCCL all-gather inside the timed step
 (issued asynchronously: frame k's exchange overlaps frame k+1's render; the last one is waited for before the closing
 barrier).  A short weak-scaled loop (every rank its own full frame) is reported beside it as `weak_scaling`.
 A second scene (`secondary`, S1b: smooth density with surfaces, ~half of the rays terminate early) shows what wave-level
@@ -60,10 +60,14 @@ def parse():
     ap.add_argument("--no-truck", action="store_true", help="skip the truck-shaped secondary render (F = 4, P = 9, S = 668; 30 GB of bricks)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the S1b secondary scene")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--contiguous", action="store_true", help="N>1: contiguous ray bands instead of interleaved 64-ray tiles")
-    ap.add_argument("--deal-group", type=int, default=0, help="N>1: deal the frame's 64-ray tiles (8x8 pixel blocks) round-robin in groups of "
-                    "this many consecutive tiles; 0 (default) = one block ROW of the image (W/8 tiles): the deal `scaling_proxy` measured "
-                    "best at N = 8 (balanced like single tiles, and a rank's rays keep their horizontal neighbours); 1 = single tiles")
+    ap.add_argument("--deal", default="bands", choices=["bands", "rows", "tiles"],
+                    help="N>1: how the frame's 64-ray tiles (8x8 pixel blocks, in block-row order) are split over the ranks: contiguous "
+                    "BANDS (default: SURVEY 8e's partition; on the S1 frame the best of the three in `scaling_proxy`: 6.25 x predicted at "
+                    "N = 8 against 5.8 x, every rank keeps its neighbours' cells), whole block ROWS of the image dealt round-robin "
+                    "(balanced on scenes with sky, keeps horizontal neighbours) or single TILES dealt round-robin (finest balance, "
+                    "least sharing); --deal-group K deals groups of K tiles")
+    ap.add_argument("--contiguous", action="store_true", help="(= --deal bands; kept for older command lines)")
+    ap.add_argument("--deal-group", type=int, default=0, help="N>1: deal groups of this many consecutive tiles round-robin (overrides --deal)")
     ap.add_argument("--no-proxy", action="store_true", help="skip `scaling_proxy` (every rank's share of an N-way deal rendered ALONE on this GPU)")
     ap.add_argument("--mlp-mode", type=int, default=None, help="rgbnet arithmetic: 0 fp32 MFMA, 1 bf16x3, 2 fp16x2 (default: what ugrid_pack_mlp reports usable)")
     ap.add_argument("--pipeline", type=int, default=0, help="ray chunks software-pipelined over two streams (0 = off)")
@@ -231,10 +235,12 @@ class FrameBench:
         self.S = self.rend.tables(self.stepsize)[2]
         self.c2w = camera(0, device)
         self.use_dist = dist is not None
-        # tiles dealt in groups (dist.tile_assignment): default one block row of the image
+        # the deal (see --deal): contiguous bands unless tiles are dealt singly, by block rows of the image, or in groups of K
         dg = int(getattr(args, "deal_group", 0) or 0)
-        self.deal_group = dg if dg > 0 else max(1, W // 8)
-        if world > 1 and not args.contiguous:
+        deal = getattr(args, "deal", "bands")
+        self.deal_group = dg if dg > 0 else (max(1, W // 8) if deal == "rows" else 1)
+        self.contiguous = bool(getattr(args, "contiguous", False)) or (dg <= 0 and deal == "bands")
+        if world > 1 and not self.contiguous:
             self.idx = tile_assignment(self.R, world, rank, group=self.deal_group).to(device)
             self.per = tile_assignment(self.R, world, 0, group=self.deal_group).numel()
             self.bounds = None
@@ -597,7 +603,7 @@ def scaling_proxy(args, rend, device, t1_ms, steps=6):
     """What a 1-GPU box can say about N > 1: rank r's share of an N-way deal of THE frame rendered ALONE on this
     device -- same kernels, same rays, same bricks as rank r of an N-GPU run (the tile exchange, 5.2 MB per rank at N = 8, is the only
     thing missing) -- for every rank of N = 2, 4, 8 and three deals: single 64-ray tiles round-robin, block ROWS of the image
-    round-robin (W / 8 tiles, the default of --gpus N), contiguous bands.  A share's time is the GPU time of its step (ray generation
+    round-robin (W / 8 tiles), contiguous bands (the default of --gpus N).  A share's time is the GPU time of its step (ray generation
     + march + shade) between two HIP events, median over `steps` back-to-back steps -- what a rank of a continuously fed N-GPU run
     spends per frame.  (The host clock around single synchronised steps is NOT used: an idle -> busy transition of the queue
     occasionally starts the first kernel 25-80 ms late on these boxes, profiles/r05/share_stall_diag.txt; back-to-back frames do
@@ -607,8 +613,9 @@ def scaling_proxy(args, rend, device, t1_ms, steps=6):
         out = {"t1_ms": t1_ms, "note": "share r of an N-way deal rendered alone on this GPU (no exchange); GPU time per step between HIP events, "
                                        "median of %d back-to-back steps; predicted_efficiency = t1 / (N * slowest share)" % steps}
         W = args.width
-        deals = (("tiles_round_robin", dict(contiguous=False, deal_group=1)), ("block_rows_round_robin", dict(contiguous=False, deal_group=max(1, W // 8))),
-                 ("contiguous_bands", dict(contiguous=True, deal_group=1)))
+        deals = (("tiles_round_robin", dict(contiguous=False, deal="tiles", deal_group=0)),
+                 ("block_rows_round_robin", dict(contiguous=False, deal="rows", deal_group=0)),
+                 ("contiguous_bands", dict(contiguous=False, deal="bands", deal_group=0)))
         for N in (2, 4, 8):
             row = {}
             for name, kw in deals:
@@ -869,7 +876,7 @@ def main():
                            "%dx%d pixel blocks (one 8x8 block per 64-ray wave), results back in image order" % (args.ray_tile, args.ray_tile)
                            if fb.order is not None else "image order (64-pixel row segments per wave)"),
                        "parallelism": ("one frame over %d ranks, %s, 1 all-gather of [R/N,5] tiles per frame (async, overlaps "
-                                       "the next frame)" % (world, "contiguous 64-aligned ray bands" if args.contiguous
+                                       "the next frame)" % (world, "contiguous 64-aligned ray bands" if fb.contiguous
                                                             else "64-ray tiles (8x8 pixel blocks) dealt round-robin in groups of %d" % fb.deal_group))
                                        if world > 1 else "1 GPU"},
             "kernels": {k: {"ms": v} for k, v in kern.items()},

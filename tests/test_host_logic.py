@@ -578,7 +578,7 @@ def _bench_worker(rank, world, port, contiguous, hw, dg, q):
     sys.path.insert(0, ROOT)
     import bench
     args = argparse.Namespace(height=hw[0], width=hw[1], grid=200, contiguous=contiguous, pipeline=0, mlp_mode=None,
-                              ray_tile=8, deal_group=dg)
+                              ray_tile=8, deal="rows", deal_group=dg)       # dg = 0: block rows; > 0: groups of dg tiles
     fb = bench.FrameBench(args, None, torch.device("cpu"), world, rank, dist, renderer=_FakeRenderer())
     assert (fb.order is not None) == (hw[0] % 8 == 0 and hw[1] % 8 == 0)
     dt, timing = fb.timed(3, 1)
@@ -595,8 +595,8 @@ def _bench_worker(rank, world, port, contiguous, hw, dg, q):
 def test_bench_strong_scaled_step_over_gloo(world, contiguous, hw, dg):
     """the frame every rank assembles INSIDE the timed step (un-deal / un-band + un-tile of the 8 x 8 pixel-block ray order:
     one index_select) is the single-process frame in image order -- 2, 3 and 8 ranks, ragged shares, (16 x 24 pixels = 6 tiles
-    over 8 ranks) ranks that render nothing, tiles dealt singly (dg = 1), by block rows of the image (dg = 0, the default) and in
-    groups of 4"""
+    over 8 ranks) ranks that render nothing, tiles dealt singly (dg = 1), by block rows of the image (dg = 0) and in groups of 4;
+    contiguous = the bench's default bands"""
     import argparse
     import bench
     res = _spawn(_bench_worker, world, 37500 + (os.getpid() + 17 * world + (1 if contiguous else 0) + hw[0] + 3 * dg) % 2000, contiguous, hw, dg)

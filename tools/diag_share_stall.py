@@ -18,7 +18,7 @@ torch.cuda.empty_cache()
 fb0.timed(3, 1)
 res = []
 for N, deal_group, contiguous in ((8, 1, False), (8, 1, True)):
-    a = argparse.Namespace(**dict(vars(args), contiguous=contiguous, deal_group=deal_group))
+    a = argparse.Namespace(**dict(vars(args), contiguous=contiguous, deal="tiles", deal_group=deal_group))
     for r in range(N):
         fb = bench.FrameBench(a, None, dev, N, r, None, renderer=fb0.rend)
         ro, rd, vd = fb.get_rays_idx(fb.H, fb.W, fb.K, fb.c2w, fb.px)

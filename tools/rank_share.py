@@ -23,8 +23,7 @@ def main():
     dev = torch.device("cuda", 0)
     sys.argv = [sys.argv[0]]
     args = bench.parse()
-    args.contiguous = a.deal == "bands"
-    args.deal_group = 1 if a.deal != "rows" else max(1, args.width // 8)
+    args.contiguous, args.deal, args.deal_group = False, a.deal, 0
     state = bench.make_state(args.grid, dev, seed=0)
     fb0 = bench.FrameBench(args, state, dev, 1, 0, None)
     del state
