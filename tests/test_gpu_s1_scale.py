@@ -4,13 +4,15 @@ are compared with the CPU oracle, all rays, no margin carve-out.
 
 * S1b (smooth fields, opaque surfaces: trained-like statistics, every ray ends on a surface): rgb, depth and
   alphainv_last within 1e-4 of the oracle on ALL rays -- in practice ~1e-7.
-* S1 (white-noise grids, sigma = 24 density units per voxel): RGB within 1e-4 on all rays.  depth / alphainv_last carry
-  a tail of a few rays in 10^5 just above 1e-4 that is NOT produced by any arithmetic shortcut of the kernels
-  (profiles/r02/parity_ab_s1.txt: IEEE divisions, libm sincos / pow and grid_sample's own corner sum change the worst
-  rays by < 2e-6): it is the conditioning of the reference formula on this scene.  Round 3 arbitrates it against the
-  reference ITSELF executing on the MI355X (its own Python over its own compiled kernels, oracle/_ref): that run differs
-  from the CPU evaluation of the same code by 1.4e-4 / 1.6e-4 / 2.8e-4 -- more than the fused kernels do -- so the bound
-  the tail is held to is that measured distance; the tail must be a handful of rays, the mean error ~1e-6.
+* S1 (white-noise grids, sigma = 24 density units per voxel): rgb AND depth within 1e-4 of the CPU reference on all rays, outright
+  (round 5; measured 5.4e-5 / 8.2e-5 ... 9.8e-5); alphainv_last within max(1e-4, the reference's own distance to the fp64 truth).  A ray
+  above the bound is admitted only under per-ray fp64 arbitration.  The tail near the bound is NOT produced by any arithmetic shortcut of
+  the kernels (profiles/r02/parity_ab_s1.txt: IEEE divisions, libm sincos / pow and grid_sample's own corner sum change the worst rays
+  by < 2e-6): it is the conditioning of the reference formula on this scene -- the reference executing on the MI355X (its own Python
+  over its own compiled kernels, oracle/_ref) differs from its CPU evaluation by 1.4e-4 / 1.6e-4 / 2.8e-4, and against an fp64 ground
+  truth the fused render is the closest of the three (test_s1_tail_against_fp64_ground_truth).
+* truck_single.py's shape (F = 4 -> P = 9, S = 668) on the whole 1080p frame and viewbase_pe = 8 (bf16x3 kernel) at G = 100: 1e-4 on all
+  sampled rays (measured 4e-7).
 """
 import json
 import os
