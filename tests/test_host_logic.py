@@ -663,7 +663,7 @@ def test_device_code_hash_ignores_the_non_loaded_sections(tmp_path):
 
 
 def test_roofline_block_merges_counters_only_for_the_same_device_code(tmp_path, monkeypatch):
-    """bench.roofline_block: static PMC counters (profiles/r04/pmc_summary.json) are merged only when they were taken on
+    """bench.roofline_block: static PMC counters (profiles/r05/pmc_summary.json) are merged only when they were taken on
     the SAME device code (sha256 of .hip_fatbin); otherwise the block says so and carries live times + algorithmic rates
     only.  The algorithmic-bytes-over-HBM-peak figure is printed, labelled, and never chosen as the bound; the measured
     L1 peak of the micro-benchmark is used when its file is there; a rank's share scales the per-frame counters."""
@@ -704,6 +704,66 @@ def test_roofline_block_merges_counters_only_for_the_same_device_code(tmp_path, 
     (tmp_path / "pmc_summary.json").write_text(json.dumps(dict(pmc, device_code_sha16="0123456789abcdef")))
     r = bench.roofline_block(kern, M, R, S, M // 32)
     assert r["traffic"] is None and "0123456789abcdef" in r["pmc_refused"] and "hbm_frac" not in r["per_kernel"]["render_shade"]
+
+
+def test_roofline_frame_block_and_hbm_entry_are_one_line_of_arithmetic(tmp_path, monkeypatch):
+    """`roofline.frame` prices the step against the guide's two peaks from the committed counters -- every figure
+    must be reproducible by hand: algorithmic bytes / step time / 8 TB/s (> 1, labelled), counter HBM bytes / step time / 8 TB/s,
+    executed and useful MFMA flops / step time / 2.5 PFLOP/s, the rocprofv3 average beside the HIP-event time; counters of another
+    WORKLOAD are refused like counters of another build; `roofline_hbm` carries the dense TV + Adam pass with the bytes it moved."""
+    import json
+    import bench
+    code = bench.device_code_sha16()
+    R, S, M = 2073600, 256, 26065245
+    kern = {"render_march": 4.6, "render_shade": 4.0}
+    pmc = {"device_code_sha16": code,
+           "render_march": {"hbm_bytes": 5.7e9, "valu_insts": 3.64e9, "gui_active_cycles": 9.3e6, "rocprofv3_avg_ms": 4.7},
+           "render_shade": {"hbm_bytes": 6.4e9, "valu_insts": 1.2e9, "mfma_busy_cycles": 3.5e9, "gui_active_cycles": 7.4e6, "rocprofv3_avg_ms": 4.1}}
+    monkeypatch.setattr(bench, "PROFILE_DIR", str(tmp_path))
+    (tmp_path / "pmc_summary.json").write_text(json.dumps(pmc))
+    passes = M // 32
+    r = bench.roofline_block(kern, M, R, S, passes, ms_per_step=8.7)
+    fr = r["frame"]
+    alg = R * S * 224 + R * 32 + M * 2688 + R * 24
+    assert fr["algorithmic_bytes"] == alg and abs(fr["frac_of_hbm_algorithmic"] - alg / 8.7e-3 / 8e12) < 1e-9 and fr["frac_of_hbm_algorithmic"] > 2
+    assert abs(fr["hbm_frac"] - 12.1e9 / 8.7e-3 / 8e12) < 1e-9 and "NOT a roofline fraction" in fr["frac_of_hbm_algorithmic_note"]
+    assert abs(fr["mfma_executed_frac_of_2.5PF"] - passes * 132 * 32 * 32 * 16 * 2.0 / 8.7e-3 / 2.5e15) < 1e-9
+    assert abs(fr["mfma_useful_frac_of_2.5PF"] - M * 43520.0 / 8.7e-3 / 2.5e15) < 1e-9 and fr["mfma_useful_frac_of_2.5PF"] < fr["mfma_executed_frac_of_2.5PF"]
+    assert abs(fr["clock_GHz_profiled"]["render_march"] - 9.3e6 / 4.7e-3 / 1e9) < 1e-9
+    pk = r["per_kernel"]["render_shade"]
+    assert pk["rocprofv3_avg_ms"] == 4.1 and abs(pk["hip_event_over_rocprofv3"] - 4.0 / 4.1) < 1e-9
+    # another workload (e.g. --freq 4): the S1 counters are refused, times and algorithmic rates stay
+    r2 = bench.roofline_block(kern, M, R, S, passes, P=9, ms_per_step=8.7, pmc_workload_ok=False)
+    assert "another workload" in r2["pmc_refused"] and r2["frame"]["hbm_bytes_pmc"] is None
+    assert r2["frame"]["algorithmic_bytes"] == R * S * 288 + R * 32 + M * 3456 + R * 24
+    # the HBM-bound kernel's entry
+    tv = {"kernel": "ugrid_tv_adam_dense_cl", "ms": 4.3, "algorithmic_bytes": 24192000000, "achieved": 24192000000 / 4.3e-3 / 1e9}
+    e = bench.hbm_roofline_entry(tv)
+    assert e["bound"] == "hbm" and abs(e["frac"] - 24192000000 / 4.3e-3 / 8e12) < 1e-9 and e["traffic"] is None
+    (tmp_path / "tv_adam_dense_pmc.json").write_text(json.dumps({"device_code_sha16": code, "hbm_bytes": 24.4e9, "hbm_read_bytes": 14.1e9, "hbm_write_bytes": 10.3e9}))
+    e = bench.hbm_roofline_entry(tv)
+    assert e["traffic"] == 24.4e9 and abs(e["traffic_over_algorithmic"] - 24.4e9 / 24192000000) < 1e-9
+    (tmp_path / "tv_adam_dense_pmc.json").write_text(json.dumps({"device_code_sha16": "feedfeedfeedfeed", "hbm_bytes": 1.0}))
+    assert bench.hbm_roofline_entry(tv)["traffic"] is None and "feedfeedfeedfeed" in bench.hbm_roofline_entry(tv)["pmc_refused"]
+
+
+def test_tile_assignment_in_groups_partitions_the_rays():
+    """dist.tile_assignment(group = K): every ray exactly once over the ranks for any ray count / world / group (ranks beyond the last
+    group get none -- the world = 3 bug of round 5), consecutive tiles of a group stay together, rank 0 holds the largest share (the
+    all-gather's padded tile size)"""
+    from unboundednerfpytorch_amd.dist import tile_assignment
+    for n in (0, 1, 63, 64, 65, 1000, 64 * 37 + 11, 64 * 240 * 3):
+        for world in (1, 2, 3, 8):
+            for group in (1, 4, 240):
+                parts = [tile_assignment(n, world, r, group=group) for r in range(world)]
+                allidx = torch.cat(parts) if parts else torch.empty(0)
+                assert sorted(allidx.tolist()) == list(range(n)), (n, world, group)
+                assert parts[0].numel() == max(p.numel() for p in parts)
+                for p in parts:
+                    if p.numel() > 1:
+                        t = p // 64
+                        jumps = (t[1:] - t[:-1])
+                        assert bool(((jumps == 0) | (jumps == 1) | (jumps == (world - 1) * group + 1)).all()), (n, world, group)
 
 
 def test_pixel_tile_order_is_a_permutation_and_untile_inverts_it():
