@@ -927,15 +927,6 @@ extern "C" int64_t ugrid_brick_bytes(int P, int C, int X, int Y, int Z, int dire
   return (int64_t)P * (X - 1) * (Y - 1) * (Z - 1) * H * 8 * CH * (int64_t)sizeof(float);
 }
 
-// the round-1 pair layout for any C (the C == 12 product path packs quads; kept for tools/gpu_gather_variants.py)
-extern "C" int ug_pack_bricks_pair(const float *grid, int P, int C, int X, int Y, int Z, float *bricks, ugrid_stream_t s) {
-  int H, CH = ug_brick_ch(C, &H);
-  const int64_t total = (int64_t)P * (X - 1) * (Y - 1) * (Z - 1) * H * 8 * CH;
-  hipLaunchKernelGGL(k_pack_bricks, dim3(256 * 64), dim3(256), 0, ST(s), grid, P, C, X, Y, Z, H, CH, 1, bricks, total);
-  UG_LAUNCH_CHECK();
-  return 0;
-}
-
 extern "C" int ugrid_pack_bricks(const float *grid, int P, int C, int X, int Y, int Z, int direct,
                                  float *bricks, ugrid_stream_t s) {
   if (X < 2 || Y < 2 || Z < 2 || P < 1 || C < 1) return (int)hipErrorInvalidValue;

@@ -247,8 +247,8 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
       px = ox + dx * t; py = oy + dy * t; pz = oz + dz * t;
       // contraction p/|p| * (B - A/|p|) outside the unit cube / ball (FourierGrid_model.py:534-548)
       const float nrm = L2 ? ug_norm3_torch(px, py, pz) : fmaxf(fabsf(px), fmaxf(fabsf(py), fabsf(pz)));
-      // A/B builds for the parity study (tools/gpu_parity_ab.sh): UG_EXACT_DIV = IEEE divisions instead of Markstein's,
-      // UG_LIBM_SINCOS / UG_LIBM_ALPHA = the device libm instead of ugrid_math.h, UG_CORNER_SUM (ug_density_level)
+      // (Markstein divisions, ugrid_math.h sin / cos / alpha, the cell polynomial: each A/B-tested against IEEE division, the device libm
+      // and grid_sample's own corner sum on the S1 frame -- profiles/r02/parity_ab_s1.txt; the arms are archived, tools/experiments/ARMS.md)
       if (!(nrm <= 1.0f)) {
         const float rn = ug_rcp_refined(nrm);
         const float sc = a.B - rn * a.A;       // reciprocal(norm) * A, as torch evaluates `A / norm` (ug_contract above)
@@ -1078,12 +1078,6 @@ __device__ __forceinline__ void ug_mfma3x4(const f16x8 *__restrict__ Ap, const f
 
 // operands of one k-step of the hand-scheduled fp16x2 pass (both weight parts, loaded during the previous step)
 struct ug_kops { ug_hpart wl, wh; };
-
-// Optional phase profile (-DUG_SHADE_PROF, tools/gpu_shade_phases.sh): shader-clock ticks per phase of ug_shade_tile,
-// summed over all waves into g_shade_prof; phases: 0 tile set-up, 1 gather round 0, 2 gather round 1, 3 layer 1,
-// 4 layer 2, 5 layer 3 + sigmoid, 6 per-ray accumulation, 7 tile scheduling (outside this function)
-struct ug_prof { };
-#define UG_PROF_MARK(pr, i)
 
 // One 32-survivor pass of the rgbnet + the ordered per-ray accumulation, shared by the classic shade tile loop
 // (ug_shade_tile) and the consumer waves of the producer / consumer kernel (ugrid_shade_pc.h).  Lane (h = lane >> 5,
