@@ -192,24 +192,25 @@ def test_worker_code_on_gloo_ranks_sharing_this_gpu(what, world):
         assert r["sparse"]["exchange"]["mode"] == "sparse"
 
 
-def test_data_parallel_training_on_two_gloo_ranks_sharing_this_gpu():
-    """the touched-bitmap branch of the data-parallel exchange on the real kernels.  tools/dp_train_2rank_shared_gpu.py:
+@pytest.mark.parametrize("world", [2, 8])
+def test_data_parallel_training_on_gloo_ranks_sharing_this_gpu(world):
+    """the touched-bitmap branch of the data-parallel exchange on the real kernels, at 2 and at 8 ranks.  tools/dp_train_2rank_shared_gpu.py:
     fourier_model.FourierGridModel (channel-last k0) + train_iteration (certify -> marking backward) + ShardedMaskedAdam built by
-    create_optimizer_or_freeze_model(sharded=True) (recycled gradients, sparse exchange) on two ranks x half batches, three
+    create_optimizer_or_freeze_model(sharded=True) (recycled gradients, sparse exchange) on `world` ranks x 1 / world of the batch, three
     iterations over both TV phases, against the single-process run on the whole batch: the lines exchanged come from the backward's
     bitmap (not from a scan of the 3.5 GB-class gradient), the exchange is the sparse one, and the parameters agree with the
     single-process trajectory up to the atomics' summation order."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29950 + os.getpid() % 40), os.path.join(ROOT, "tools", "dp_train_2rank_shared_gpu.py"), "--grid", "128", "--rays", "1024"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(29950 + (os.getpid() + world) % 40), os.path.join(ROOT, "tools", "dp_train_2rank_shared_gpu.py"), "--grid", "128", "--rays", "1024"]
     # (G = 128: 3.5 M lines of 256 B in the k0 grid, a 1024-ray batch touches a few per cent of them -- at the tool's default G = 64
     # a batch touches most lines and the optimizer rightly keeps the dense collectives)
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     r = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
     print(json.dumps(r))
-    assert r["ok"] and r["sharded_k0_state"] and r["world"] == 2
+    assert r["ok"] and r["sharded_k0_state"] and r["world"] == world
     ex = r["k0_exchange_per_step"]
     assert all(e.get("line_source") == "backward's touched-line bitmap" for e in ex), ex
     assert ex[-1]["mode"] == "sparse" and ex[0]["mode"].startswith("sparse reduce-scatter")     # masked phase / dense-TV phase
