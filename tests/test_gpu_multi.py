@@ -121,6 +121,14 @@ dist.destroy_process_group()
 '''
 
 
+def _free_port():
+    """a rendezvous port the OS reports free right now (pid-derived ports can collide with a previous run's socket in TIME_WAIT)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def _run(what, n=2, timeout=600, backend="nccl"):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
@@ -130,7 +138,7 @@ def _run(what, n=2, timeout=600, backend="nccl"):
     with open(path, "w") as f:
         f.write(WORKER)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
-           "--master-port", str(29700 + os.getpid() % 200), path, ROOT, what]
+           "--master-port", str(_free_port()), path, ROOT, what]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     line = [l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1]
@@ -203,7 +211,7 @@ def test_data_parallel_training_on_gloo_ranks_sharing_this_gpu(world):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
-           "--master-port", str(29950 + (os.getpid() + world) % 40), os.path.join(ROOT, "tools", "dp_train_2rank_shared_gpu.py"), "--grid", "128", "--rays", "1024"]
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "dp_train_2rank_shared_gpu.py"), "--grid", "128", "--rays", "1024"]
     # (G = 128: 3.5 M lines of 256 B in the k0 grid, a 1024-ray batch touches a few per cent of them -- at the tool's default G = 64
     # a batch touches most lines and the optimizer rightly keeps the dense collectives)
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
