@@ -546,6 +546,60 @@ def test_fused_rgbnet_matches_torch_linear_layers(M, C, E, W):
         assert float((a - b).abs().max()) <= tol, (n, float((a - b).abs().max()), scale, flips)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,M,C,pe", [(8192, 100000, 12, 4), (77, 1000, 9, 4), (5, 0, 12, 4), (300, 4097, 3, 8), (64, 500, 0, 4),
+                                      (1, 1, 12, 0), (900, None, 12, 4)])
+def test_rgbnet_features_equals_the_torch_chain(N, M, C, pe):
+    """ops.rgbnet_features (one kernel) vs the reference's chain (FourierGrid_model.py:631-635): the k0 and viewdir columns are
+    copies (bit-equal); the sin / cos columns are sinf / cosf of the same fp32 product, within 1 ulp-of-one of torch's device
+    sin / cos (the two are built from different releases of the device math library, so the last bit may differ).  M = 0, no
+    k0 columns (embedding rows only), pe = 0 and ray_id = None (one row per ray) included; then the same rows fed to
+    FusedRgbnet as a ViewRows give the logits and gradients of the explicit-embedding call bit for bit."""
+    from unboundednerfpytorch_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(N + 3 * pe)
+    viewdirs = torch.nn.functional.normalize(torch.randn(N, 3, device="cuda", generator=g), dim=-1)
+    viewfreq = torch.tensor([float(2 ** i) for i in range(pe)], device="cuda")
+    if M is None:
+        ray_id, rows = None, N
+    else:
+        ray_id = torch.randint(0, N, (M,), device="cuda", generator=g).sort().values
+        rows = M
+    k0 = torch.randn(rows, C, device="cuda", generator=g) if C else None
+    got = ops.rgbnet_features(k0, viewdirs, viewfreq, ray_id)
+    e = (viewdirs.unsqueeze(-1) * viewfreq).flatten(-2)
+    emb = torch.cat([viewdirs, e.sin(), e.cos()], -1)
+    emb = emb if ray_id is None else emb[ray_id]
+    want = emb if k0 is None else torch.cat([k0, emb], -1)
+    assert got.shape == want.shape == (rows, C + 3 + 6 * pe)
+    assert torch.equal(got[:, :C + 3], want[:, :C + 3])
+    if rows and pe:
+        assert float((got - want).abs().max()) <= 1.2e-7, float((got - want).abs().max())
+    # [..., 3] view directions of an image (H, W, 3) flatten to rays
+    if M is not None and N % 4 == 0 and rows:
+        again = ops.rgbnet_features(k0, viewdirs.reshape(4, N // 4, 3), viewfreq, ray_id)
+        assert torch.equal(again, got)
+    if C and rows and pe == 4:
+        net = torch.nn.Sequential(torch.nn.Linear(C + 27, 128), torch.nn.ReLU(inplace=True),
+                                  torch.nn.Sequential(torch.nn.Linear(128, 128), torch.nn.ReLU(inplace=True)), torch.nn.Linear(128, 3)).cuda()
+        lin = ops.rgbnet_linears(net)
+        par = [p for l in lin for p in (l.weight, l.bias)]
+        go = torch.randn(rows, 3, device="cuda", generator=g)
+        res = []
+        for second in (got[:, C:].contiguous(), ops.ViewRows(viewdirs, viewfreq, ray_id)):
+            k = k0.clone().requires_grad_(True)
+            net.zero_grad(set_to_none=True)
+            out = ops.FusedRgbnet.apply(k, second, *par)
+            out.backward(go)
+            res.append([out.detach().clone(), k.grad.clone()] + [p.grad.clone() for p in par])
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+    with pytest.raises(TypeError):
+        ops.rgbnet_features(k0, viewdirs, viewfreq, torch.zeros(rows, dtype=torch.int32, device="cuda"))
+    if C:
+        with pytest.raises(ValueError):
+            ops.rgbnet_features(torch.zeros(rows + 1, C, device="cuda"), viewdirs, viewfreq, ray_id)
+
+
 @pytest.mark.parametrize("shape", [(1, 12, 8, 128, 96), (2, 4, 5, 300, 128), (3, 12, 24, 40, 40)])
 @pytest.mark.parametrize("skip_zero", [True, False])
 def test_slab_ordered_dense_tv_adam_is_bit_identical(shape, skip_zero):

@@ -296,6 +296,23 @@ def test_touched_line_bitmap_is_bound_to_buffer_and_backward():
         _gradpool.clear()
 
 
+def test_rgbnet_features_on_the_host_is_the_reference_chain():
+    """ops.rgbnet_features with CPU tensors (the models' CPU forward): the reference's expressions, FourierGrid_model.py:631-635"""
+    from unboundednerfpytorch_amd import ops
+    torch.manual_seed(3)
+    viewdirs = torch.nn.functional.normalize(torch.randn(6, 5, 3), dim=-1)
+    viewfreq = torch.tensor([1.0, 2.0, 4.0, 8.0])
+    ray_id = torch.tensor([0, 0, 3, 29, 29, 29])
+    k0 = torch.randn(6, 12)
+    e = (viewdirs.unsqueeze(-1) * viewfreq).flatten(-2)
+    emb = torch.cat([viewdirs, e.sin(), e.cos()], -1).flatten(0, -2)
+    assert torch.equal(ops.rgbnet_features(None, viewdirs, viewfreq, None), emb)
+    assert torch.equal(ops.rgbnet_features(None, viewdirs, viewfreq, ray_id), emb[ray_id])
+    assert torch.equal(ops.rgbnet_features(k0, viewdirs, viewfreq, ray_id), torch.cat([k0, emb[ray_id]], -1))
+    rows = ops.ViewRows(viewdirs, viewfreq, ray_id)
+    assert isinstance(rows, tuple) and rows[0] is viewdirs and rows[2] is ray_id
+
+
 def test_rgbnet_linears_recognises_only_the_default_network():
     from unboundednerfpytorch_amd import ops
     nn = torch.nn

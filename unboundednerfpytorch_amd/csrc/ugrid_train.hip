@@ -248,3 +248,45 @@ extern "C" int ugrid_render_loss_backward(const float *logits, const float *weig
   UG_LAUNCH_CHECK();
   return 0;
 }
+
+// Rows of the rgbnet's input, [k0 | viewdir | sin(viewdir 2^k) | cos(viewdir 2^k)] (FourierGrid_model.py:631-635: the view embedding
+// is formed per ray, indexed by ray_id and concatenated behind the k0 features -- six elementwise launches and two concatenations
+// there), one thread per output element so the stores coalesce.  Column order inside the sin / cos groups is torch's
+// (viewdirs.unsqueeze(-1) * viewfreq).flatten(-2): axis-major, frequency-minor.
+__global__ void __launch_bounds__(256)
+k_rgbnet_features(const float *__restrict__ k0, int C, const float *__restrict__ viewdirs, const float *__restrict__ freq, int pe,
+                  const int64_t *__restrict__ ray_id, int64_t total, float *__restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int K = C + 3 + 6 * pe;
+  const int64_t m = idx / K;
+  const int j = (int)(idx - m * K);
+  if (j < C) {
+    out[idx] = k0[m * C + j];
+    return;
+  }
+  const float *v = viewdirs + 3 * (ray_id ? ray_id[m] : m);
+  int e = j - C;
+  if (e < 3) {
+    out[idx] = v[e];
+    return;
+  }
+  e -= 3;
+  const bool is_cos = e >= 3 * pe;
+  if (is_cos) e -= 3 * pe;
+  const int a = e / pe;
+  const float x = v[a] * freq[e - a * pe];
+  out[idx] = is_cos ? cosf(x) : sinf(x);
+}
+
+extern "C" int ugrid_rgbnet_features(const float *k0, int32_t n_k0, const float *viewdirs, const float *viewfreq, int32_t pe,
+                                     const int64_t *ray_id, int64_t m, float *out, ugrid_stream_t st) {
+  if (n_k0 < 0 || pe < 0 || m < 0) return (int)hipErrorInvalidValue;
+  const int64_t total = m * (n_k0 + 3 + 6 * pe);
+  if (total == 0) return 0;                                  // (no samples: empty arrays have no address)
+  if ((n_k0 > 0 && !k0) || (pe > 0 && !viewfreq) || !viewdirs || !out) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_rgbnet_features, dim3(ug_blocks(total, 256)), dim3(256), 0, ST(st), k0, n_k0, viewdirs, viewfreq, pe, ray_id,
+                     total, out);
+  UG_LAUNCH_CHECK();
+  return 0;
+}

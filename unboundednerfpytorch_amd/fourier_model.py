@@ -315,15 +315,14 @@ class FourierGridModel(nn.Module):
         if self.rgbnet is None:
             rgb = torch.sigmoid(k0)
         else:
-            e = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
-            emb = torch.cat([viewdirs, e.sin(), e.cos()], -1).flatten(0, -2)[ray_id]
             lin = _ops.rgbnet_linears(self.rgbnet) if (self.fused_rgbnet and k0.is_cuda and torch.is_grad_enabled()) else None
             if lin is not None:
-                # the rgbnet and its derivative on the hand-written fp32-MFMA kernels (ops.FusedRgbnet): no library GEMMs
-                logits = _ops.FusedRgbnet.apply(k0, emb, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight,
-                                                lin[2].bias)
+                # the rgbnet and its derivative on the hand-written fp32-MFMA kernels (ops.FusedRgbnet): no library GEMMs; the
+                # view embedding rows are formed inside, together with the concatenation (ops.rgbnet_features)
+                logits = _ops.FusedRgbnet.apply(k0, _ops.ViewRows(viewdirs, self.viewfreq, ray_id), lin[0].weight, lin[0].bias,
+                                                lin[1].weight, lin[1].bias, lin[2].weight, lin[2].bias)
             else:
-                feat = torch.cat([k0, emb], -1)
+                feat = torch.cat([k0, _ops.rgbnet_features(None, viewdirs, self.viewfreq, ray_id)], -1)
                 if self.splitk_rgbnet and feat.is_cuda and torch.is_grad_enabled():
                     logits = _ops.sequential_splitk(self.rgbnet, feat)
                 else:

@@ -180,19 +180,68 @@ def rgbnet_linears(net):
     return lin
 
 
+class ViewRows(tuple):
+    """(viewdirs [N,3], viewfreq [pe], ray_id [M]): the view embedding of the M samples, not yet formed.  FusedRgbnet takes it in
+    place of the embedding rows and builds the rgbnet's input in one launch (rgbnet_features)."""
+
+    def __new__(cls, viewdirs, viewfreq, ray_id):
+        return super().__new__(cls, (viewdirs, viewfreq, ray_id))
+
+
+def rgbnet_features(k0, viewdirs, viewfreq, ray_id):
+    """cat([k0, emb], -1) with emb = cat([viewdirs, e.sin(), e.cos()], -1)[ray_id], e = (viewdirs[..., None] * viewfreq).flatten(-2)
+    (FourierGrid_model.py:631-635, dvgo.py:352-357) -- on the GPU one kernel (include/ugrid_hip.h: ugrid_rgbnet_features) in place
+    of that chain's six elementwise launches and two concatenations.  k0 [M,C] or None (the embedding rows alone); viewdirs
+    [..., 3] (flattened to rays); ray_id [M] or None.  No gradient flows (k0's derivative is FusedRgbnet's business)."""
+    viewdirs = viewdirs.reshape(-1, 3)
+    if not viewdirs.is_cuda:
+        e = (viewdirs.unsqueeze(-1) * viewfreq).flatten(-2)
+        emb = torch.cat([viewdirs, e.sin(), e.cos()], -1)
+        emb = emb if ray_id is None else emb[ray_id]
+        return emb if k0 is None else torch.cat([k0, emb], -1)
+    viewdirs, viewfreq = viewdirs.contiguous(), viewfreq.contiguous()
+    named = [("viewdirs", viewdirs), ("viewfreq", viewfreq)]
+    if k0 is not None:
+        k0 = k0.detach().contiguous()
+        named.append(("k0", k0))
+    _lib.require_cuda(*named, *([("ray_id", ray_id)] if ray_id is not None else []))
+    _lib.require_f32(*named)
+    if ray_id is not None:
+        if ray_id.dtype != torch.int64:
+            raise TypeError("rgbnet_features: ray_id must be int64, got %s" % ray_id.dtype)
+        ray_id = ray_id.contiguous()
+    M = viewdirs.shape[0] if ray_id is None else ray_id.shape[0]
+    C = 0 if k0 is None else k0.shape[1]
+    if k0 is not None and k0.shape[0] != M:
+        raise ValueError("rgbnet_features: k0 has %d rows, the samples are %d" % (k0.shape[0], M))
+    pe = viewfreq.numel()
+    out = torch.empty(M, C + 3 + 6 * pe, device=viewdirs.device)
+    with _lib.guard(out.device):
+        _lib.check(_L.ugrid_rgbnet_features(_lib.ptr(k0) if C else None, C, _lib.ptr(viewdirs), _lib.ptr(viewfreq) if pe else None, pe,
+                                            _lib.ptr(ray_id) if ray_id is not None else None, M, _lib.ptr(out), _lib.stream_of(out)),
+                   "rgbnet_features")
+    return out
+
+
 class FusedRgbnet(torch.autograd.Function):
     """logits = rgbnet(cat([k0, emb])) for the default 3 x 128 rgbnet, forward and backward on the hand-written fp32-MFMA
     kernels of csrc/ugrid_train_mlp.hip (include/ugrid_hip.h: ugrid_rgbnet_train_forward / _backward) instead of 13 library
-    GEMMs + elementwise kernels.  k0 [M,C] (gradient returned), emb [M,E] (view embedding rows, no gradient), then the three
+    GEMMs + elementwise kernels.  k0 [M,C] (gradient returned), emb [M,E] (view embedding rows, no gradient) or a ViewRows
+    (the rows are then formed together with the concatenation, one launch), then the three
     weights and biases in nn.Linear layout.  fp32; deterministic (the weight gradients are fixed-order sums of slab partials)."""
 
     @staticmethod
     def forward(ctx, k0, emb, w0, b0, w1, b1, w2, b2):
-        feat = torch.cat([k0, emb], -1).contiguous()
-        M, K = feat.shape
         ws = [t.contiguous() for t in (w0, b0, w1, b1, w2, b2)]
-        _lib.require_cuda(("k0", k0), ("emb", emb), *[("rgbnet", t) for t in ws])
-        _lib.require_f32(("k0", k0), ("emb", emb), *[("rgbnet", t) for t in ws])
+        if isinstance(emb, ViewRows):
+            _lib.require_cuda(("k0", k0), *[("rgbnet", t) for t in ws])
+            _lib.require_f32(("k0", k0), *[("rgbnet", t) for t in ws])
+            feat = rgbnet_features(k0, *emb)
+        else:
+            feat = torch.cat([k0, emb], -1).contiguous()
+            _lib.require_cuda(("k0", k0), ("emb", emb), *[("rgbnet", t) for t in ws])
+            _lib.require_f32(("k0", k0), ("emb", emb), *[("rgbnet", t) for t in ws])
+        M, K = feat.shape
         dev = feat.device
         W = ws[0].shape[0]
         h1 = torch.empty(M, W, device=dev)

@@ -152,11 +152,11 @@ class _VoxGOBase(nn.Module):
 
     def _logits(self, k0_view, viewdirs, ray_id):
         """rgbnet([k0, view embedding]) of the surviving samples: the fp32-MFMA kernels for the default 3-layer net while training"""
-        e = (viewdirs.unsqueeze(-1) * self.viewfreq).flatten(-2)
-        emb = torch.cat([viewdirs, e.sin(), e.cos()], -1).flatten(0, -2)[ray_id]
         lin = _ops.rgbnet_linears(self.rgbnet) if (self.fused_rgbnet and k0_view.is_cuda and torch.is_grad_enabled()) else None
         if lin is not None:
-            return _ops.FusedRgbnet.apply(k0_view, emb, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight, lin[2].bias)
+            rows = _ops.ViewRows(viewdirs, self.viewfreq, ray_id)      # the embedding is formed inside, with the concatenation
+            return _ops.FusedRgbnet.apply(k0_view, rows, lin[0].weight, lin[0].bias, lin[1].weight, lin[1].bias, lin[2].weight, lin[2].bias)
+        emb = _ops.rgbnet_features(None, viewdirs, self.viewfreq, ray_id)
         return self.rgbnet(torch.cat([k0_view, emb], -1))
 
     def _fused_tail(self, fused_loss, k0, viewdirs, ray_id, residual, weights, alphainv_last, density, tt, bg, N):
