@@ -496,6 +496,74 @@ int ugrid_train_sample_compact_vox(int64_t n_rays, int32_t slots_per_ray, float 
                                    float *alpha2, float *weights2, int64_t *ray_id2, int64_t *step_id2, float *t2,
                                    uint8_t *inner2, ugrid_stream_t stream);
 
+/* NEW (round 5; no reference counterpart): ONE training step's forward and backward of the reference's two dense-grid models
+ * issued natively -- DirectVoxGO.forward (dvgo.py:332-425) / DirectContractedVoxGO.forward (dcvgo.py:265-384) with the default
+ * 3 x `width` rgbnet (rgbnet_direct), the loss of run_train.py:254-279 and the whole backward, as three calls instead of the
+ * ~30 Python-issued launches of the op-by-op step (voxgo_model.py; a 1.2 ms step of which 0.8 ms is GPU time).  The calls run
+ * the SAME kernels on the SAME sizes in the same order as that step: results are bit-identical to it.
+ *
+ *   ugrid_voxgo_step_sample    ugrid_train_sample_dvgo / _dcvgo, the prefix sums of the two per-ray counts, and the step's ONE
+ *                              host read: M1 (stage-1 samples the backward walks) and M2 (samples that reach the rgbnet) are
+ *                              written into the struct.  Synchronises `stream`.
+ *   (the caller sizes the per-sample buffers: ws = ugrid_voxgo_step_ws_floats floats; the visible outputs below)
+ *   ugrid_voxgo_step_forward   ugrid_train_sample_compact_vox, the k0 lookup, ugrid_rgbnet_features,
+ *                              ugrid_rgbnet_train_forward, ugrid_render_loss -> out2 = {loss, mse}, rgb_marched, logits, ...
+ *   ugrid_voxgo_step_backward  ugrid_render_loss_backward, ugrid_rgbnet_train_backward (g_w0 .. g_b2 overwritten), the k0
+ *                              lookup's scatter into grad_k0_grid (+ touch bitmap when given: channel-last only), and
+ *                              ugrid_train_sample_backward + the density scatter into grad_density_grid.  Both grid gradients
+ *                              are ADDED to (the caller passes zeros for a fresh gradient).  ws_bwd: ugrid_voxgo_step_bwd_ws_floats.
+ * Device pointers unless marked HOST.  mode 0: DirectVoxGO (near / far / stepdist / slots used), 1: DirectContractedVoxGO
+ * (t_table[slots] / scene_center / scene_radius / bg_len / norm_l2 / dist_thres used).  bg: [n_rays,3] or NULL.  coef8: see
+ * ugrid_render_loss.  inner2 may be NULL.  ugrid_voxgo_step_sizeof = sizeof(ugrid_voxgo_step), for bindings to check their mirror. */
+typedef struct ugrid_voxgo_step {
+  int32_t mode;
+  int32_t k0_channels_last; /* k0_grid / grad_k0_grid stored [X][Y][Z][C] */
+  int32_t X, Y, Z;          /* density grid [1,1,X,Y,Z] (canonical) */
+  int32_t kX, kY, kZ, C;    /* k0 grid [1,C,kX,kY,kZ] */
+  int32_t pe, width;        /* viewbase_pe; rgbnet width (<= 128; C + 3 + 6 pe <= 128) */
+  int32_t slots;            /* scratch slots per ray (mode 0: >= the longest ray's step count; mode 1: the table length) */
+  int32_t norm_l2;
+  int32_t mask_dims[3];     /* HOST */
+  float mask_scale[3], mask_shift[3], scene_center[3], scene_radius[3]; /* HOST */
+  float act_shift, interval, thres, near_clip, far_clip, stepdist, dist_thres;
+  float coef8[8];           /* HOST */
+  double bg_len;
+  int64_t n_rays;
+  const float *density_grid, *k0_grid, *xyz_min, *xyz_max, *k0_xyz_min, *k0_xyz_max;
+  const uint8_t *mask;
+  const float *t_table, *viewfreq;
+  const float *w0, *b0, *w1, *b1, *w2, *b2;
+  const float *rays_o, *rays_d, *viewdirs, *target, *bg;
+  /* scratch of the sampling march: [n_rays * slots] (sc_pts: x 3) */
+  float *sc_pts, *sc_density;
+  int32_t *sc_step;
+  float *sc_w, *sc_T;
+  int32_t *counts;          /* [2, n_rays] */
+  int64_t *offsets;         /* [2, n_rays] inclusive prefix sums of counts */
+  int64_t *totals;          /* [2] */
+  float *alphainv_last;     /* [n_rays] */
+  int64_t *seg;             /* [2 n_rays] */
+  float *rgb_marched, *ray_tot, *partial, *out2; /* [n_rays,3], [n_rays,2], [n_rays,4], [2] */
+  int64_t M1, M2;           /* written by ugrid_voxgo_step_sample */
+  float *ws;
+  float *density2, *alpha2, *weights2, *t2; /* [M2] */
+  int64_t *ray_id2, *step_id2;              /* [M2] */
+  uint8_t *inner2;                          /* [M2] or NULL */
+  float *logits;                            /* [M2,3] */
+  /* backward */
+  const float *grad_loss;   /* the incoming scalar gradient */
+  float *ws_bwd;
+  float *g_w0, *g_b0, *g_w1, *g_b1, *g_w2, *g_b2;
+  float *grad_density_grid, *grad_k0_grid;
+  uint32_t *touch;          /* touched-line bitmap of grad_k0_grid, or NULL */
+} ugrid_voxgo_step;
+int64_t ugrid_voxgo_step_sizeof(void);
+int64_t ugrid_voxgo_step_ws_floats(const ugrid_voxgo_step *s);
+int64_t ugrid_voxgo_step_bwd_ws_floats(const ugrid_voxgo_step *s);
+int ugrid_voxgo_step_sample(ugrid_voxgo_step *s, ugrid_stream_t stream);
+int ugrid_voxgo_step_forward(const ugrid_voxgo_step *s, ugrid_stream_t stream);
+int ugrid_voxgo_step_backward(const ugrid_voxgo_step *s, ugrid_stream_t stream);
+
 /* 1 when ugrid_render_shade has an rgbnet instantiation (depth 3, width 128) for this
  * (fourier_freq_num, k0 channels, viewbase_pe) triple, else 0 (they return hipErrorNotSupported for it). */
 int ugrid_shade_supported(int32_t freq_num, int32_t k0_channels, int32_t viewbase_pe);

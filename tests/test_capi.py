@@ -55,6 +55,46 @@ def test_python_binding_table_matches_header(lib_path):
         assert lib.ugrid_render_ws_bytes(n_rays, S) == 256 + a256(nt * 4) + a256(nt * cap * 16) + a256(nt * cap)
 
 
+def test_voxgo_step_struct_mirror_matches_the_header(lib_path):
+    """_lib.VoxgoStep mirrors `ugrid_voxgo_step` field for field: names and order parsed from the header, C type -> ctypes type,
+    and the compiled sizeof; the workspace size helpers are host arithmetic over the struct's counts"""
+    from unboundednerfpytorch_amd import _lib
+    text = open(os.path.join(ROOT, "include", "ugrid_hip.h")).read()
+    body = re.search(r"typedef struct ugrid_voxgo_step \{(.*?)\} ugrid_voxgo_step;", text, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    ctype = {"int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64, "float": ctypes.c_float, "double": ctypes.c_double}
+    want = []
+    for decl in [d.strip() for d in body.split(";") if d.strip()]:
+        m = re.match(r"(const\s+)?(\w+)\s+(.*)", decl, flags=re.S)
+        base = m.group(2)
+        for item in [x.strip() for x in m.group(3).split(",")]:
+            ptr = item.startswith("*")
+            name = item.lstrip("*").strip()
+            arr = re.match(r"(\w+)\[(\d+)\]", name)
+            if ptr:
+                want.append((name, ctypes.c_void_p))
+            elif arr:
+                want.append((arr.group(1), ctype[base] * int(arr.group(2))))
+            else:
+                want.append((name, ctype[base]))
+    got = list(_lib.VoxgoStep._fields_)
+    assert [n for n, _ in got] == [n for n, _ in want]
+    for (n, a), (_, b) in zip(got, want):
+        assert ctypes.sizeof(a) == ctypes.sizeof(b) and (a is b or getattr(a, "_length_", None) == getattr(b, "_length_", None)), n
+    lib = _lib.load()
+    assert lib.ugrid_voxgo_step_sizeof() == ctypes.sizeof(_lib.VoxgoStep)
+    s = _lib.VoxgoStep()
+    s.C, s.pe, s.width, s.n_rays, s.M1, s.M2 = 12, 4, 128, 8192, 1000, 130
+    al = lambda n: (n + 63) & ~63
+    K = 12 + 27
+    assert lib.ugrid_voxgo_step_ws_floats(ctypes.addressof(s)) == al(3000) + 4 * al(1000) + al(390) + al(130 * 12) + al(130 * K) + 2 * al(130 * 128)
+    assert lib.ugrid_voxgo_step_bwd_ws_floats(ctypes.addressof(s)) == al(390) + 2 * al(130) + al(8192) + al(130 * 12) + al(1000) \
+        + al(lib.ugrid_rgbnet_train_scratch_floats(130))
+    # entry points refuse what they cannot run, before touching the device
+    bad = _lib.VoxgoStep()
+    assert lib.ugrid_voxgo_step_forward(ctypes.addressof(bad), None) != 0
+
+
 def test_code_object_is_gfx950_only(lib_path):
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-readelf", "--notes", lib_path], capture_output=True, text=True)
     # the fat binary is embedded; roc-obj-ls style check through strings

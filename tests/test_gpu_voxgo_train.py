@@ -333,6 +333,83 @@ def test_train_iteration_drives_the_voxgo_models(kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dvgo", "dcvgo"])
+def test_native_step_equals_the_op_by_op_step_bit_for_bit(kind):
+    """native_step.VoxGOStep (ONE autograd node, three C calls: include/ugrid_hip.h ugrid_voxgo_step_*) against the op-by-op step
+    over the drop-in ops (TrainSampleVox, GridQuery, FusedRgbnet, RenderLoss; native_step = False): the same kernels on the same
+    sizes in the same order, so the forward's arrays, the loss and the rgbnet's gradients must be bit-identical and the grid
+    gradients equal up to the order of the scatter's atomic adds; then 8 train_iteration steps -- dense TV, masked TV and no-TV
+    phases, touched-line bitmaps, random background for the contracted model -- stay on the same trajectory.
+    Configurations the native step does not take (residual rgbnet, coarse stage, no-grad forward, a frozen parameter) must select
+    the op path by themselves."""
+    import copy
+    from unboundednerfpytorch_amd import train_step as ts, native_step
+    from unboundednerfpytorch_amd.ops import loss_coefficients
+    from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
+    dev = torch.device("cuda", 0)
+    case = DVGO_CASES[0] if kind == "dvgo" else synth.DCVGO_CASES[0]
+    m_a, name, (o, d, v), kw, R, seed = build(kind, case, dev)
+    m_b = copy.deepcopy(m_a)
+    m_b.native_step = False
+    target = torch.from_numpy(synth.uniform(seed + 5, R * 3).reshape(R, 3)).to(dev) * 0.5 + 0.25
+    rk = {k: kw[k] for k in kw if k != "render_depth"}
+    if kind == "dcvgo":
+        rk["rand_bkgd"] = True
+    cfg = dict(lrate_density=1e-1, lrate_k0=1e-1, lrate_rgbnet=1e-3, lrate_decay=20, pg_scale=[], weight_main=1.0, weight_entropy_last=0.01,
+               weight_rgbper=0.01, weight_nearclip=0.0, weight_distortion=0.01 if kind == "dcvgo" else 0.0, tv_every=1, tv_after=0,
+               tv_before=7, tv_dense_before=4, weight_tv_density=1e-5, weight_tv_k0=1e-6, skip_zero_grad_fields=['density', 'k0'])
+    # one forward: the return dict
+    coef = loss_coefficients(cfg, R, m_a.sample_table(rk["stepsize"], dev).numel(), None, 1)
+    outs = []
+    for m in (m_a, m_b):
+        torch.manual_seed(5)
+        out = m(o, d, v, global_step=1, is_train=True, fused_loss={'target': target, 'coef': coef}, **rk)
+        out["loss"].backward()
+        outs.append((out, {k: p.grad.clone() for k, p in m.named_parameters()}))
+        m.zero_grad(set_to_none=True)
+    (oa, ga), (ob, gb) = outs
+    assert oa["loss"].grad_fn is not None and type(oa["loss"].grad_fn).__name__.startswith("VoxGOStep"), type(oa["loss"].grad_fn)
+    assert not type(ob["loss"].grad_fn).__name__.startswith("VoxGOStep")
+    assert set(oa) == set(ob), (sorted(oa), sorted(ob))
+    for k in oa:
+        if torch.is_tensor(oa[k]):
+            assert torch.equal(oa[k].detach(), ob[k].detach()), k
+        else:
+            assert oa[k] == ob[k], k
+    assert oa["weights"].numel() > 100
+    for k in ga:
+        if "grid" in k:      # the lookups' scatter adds with hardware atomics: the same terms in an order that varies run to run
+            scale = float(gb[k].abs().max())
+            assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * scale, (k, float((ga[k] - gb[k]).abs().max()), scale)
+        else:                # fixed-order sums: the same bits
+            assert torch.equal(ga[k], gb[k]), k
+    # eight training steps through the three TV phases
+    before = {k: p.detach().clone() for k, p in m_a.named_parameters()}
+    res = []
+    for m in (m_a, m_b):
+        torch.manual_seed(11)
+        opt = create_optimizer_or_freeze_model(m, cfg, global_step=0)
+        losses = [ts.train_iteration(m, opt, o, d, v, target, cfg, step, rk) for step in range(1, 9)]
+        torch.cuda.synchronize()
+        res.append((losses, {k: p.detach().clone() for k, p in m.named_parameters()}))
+    assert res[0][0][0] == res[1][0][0], (res[0][0][0], res[1][0][0])          # first step: identical parameters, identical loss
+    np.testing.assert_allclose(np.array(res[0][0]), np.array(res[1][0]), rtol=2e-4)
+    for k in res[0][1]:
+        pa, pb = res[0][1][k], res[1][1][k]
+        # Adam turns a rounding-level difference of a near-zero gradient into a difference of up to one learning-rate step
+        assert float((pa - pb).abs().max()) <= 0.05 * float((pb - before[k]).abs().max()) + 1e-7, (k, float((pa - pb).abs().max()))
+    assert res[0][0][-1][0] < res[0][0][0][0]
+    # not the native step's business: no gradient, a frozen grid
+    with torch.no_grad():
+        out = m_a(o, d, v, global_step=1, is_train=True, fused_loss={'target': target, 'coef': coef}, **rk)
+    assert out["loss"].grad_fn is None and out["ray_id"].numel() > 0
+    m_a.density.grid.requires_grad_(False)
+    assert m_a._native_params() is None
+    m_a.density.grid.requires_grad_(True)
+    assert m_a._native_params() is not None
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kind,case", ALL, ids=IDS)
 def test_fused_loss_equals_the_composed_loss(kind, case):
     """Both models with the training tail as one op (ops.RenderLoss, what train_iteration selects) vs the torch chain of

@@ -63,6 +63,36 @@ class AdamItem(_c.Structure):
                 ("numel", _c.c_int64), ("step", _c.c_int32), ("lr", _c.c_float)]
 
 
+class VoxgoStep(_c.Structure):
+    """Mirror of `ugrid_voxgo_step` (include/ugrid_hip.h); tests/test_capi.py compares the field list with the header's"""
+    _fields_ = [
+        ("mode", _c.c_int32), ("k0_channels_last", _c.c_int32),
+        ("X", _c.c_int32), ("Y", _c.c_int32), ("Z", _c.c_int32),
+        ("kX", _c.c_int32), ("kY", _c.c_int32), ("kZ", _c.c_int32), ("C", _c.c_int32),
+        ("pe", _c.c_int32), ("width", _c.c_int32), ("slots", _c.c_int32), ("norm_l2", _c.c_int32),
+        ("mask_dims", _c.c_int32 * 3),
+        ("mask_scale", _c.c_float * 3), ("mask_shift", _c.c_float * 3), ("scene_center", _c.c_float * 3), ("scene_radius", _c.c_float * 3),
+        ("act_shift", _c.c_float), ("interval", _c.c_float), ("thres", _c.c_float), ("near_clip", _c.c_float), ("far_clip", _c.c_float),
+        ("stepdist", _c.c_float), ("dist_thres", _c.c_float),
+        ("coef8", _c.c_float * 8),
+        ("bg_len", _c.c_double),
+        ("n_rays", _c.c_int64),
+        ("density_grid", _P), ("k0_grid", _P), ("xyz_min", _P), ("xyz_max", _P), ("k0_xyz_min", _P), ("k0_xyz_max", _P),
+        ("mask", _P), ("t_table", _P), ("viewfreq", _P),
+        ("w0", _P), ("b0", _P), ("w1", _P), ("b1", _P), ("w2", _P), ("b2", _P),
+        ("rays_o", _P), ("rays_d", _P), ("viewdirs", _P), ("target", _P), ("bg", _P),
+        ("sc_pts", _P), ("sc_density", _P), ("sc_step", _P), ("sc_w", _P), ("sc_T", _P),
+        ("counts", _P), ("offsets", _P), ("totals", _P), ("alphainv_last", _P), ("seg", _P),
+        ("rgb_marched", _P), ("ray_tot", _P), ("partial", _P), ("out2", _P),
+        ("M1", _c.c_int64), ("M2", _c.c_int64),
+        ("ws", _P),
+        ("density2", _P), ("alpha2", _P), ("weights2", _P), ("t2", _P), ("ray_id2", _P), ("step_id2", _P), ("inner2", _P), ("logits", _P),
+        ("grad_loss", _P), ("ws_bwd", _P),
+        ("g_w0", _P), ("g_b0", _P), ("g_w1", _P), ("g_b1", _P), ("g_w2", _P), ("g_b2", _P),
+        ("grad_density_grid", _P), ("grad_k0_grid", _P), ("touch", _P),
+    ]
+
+
 # name -> (restype, argtypes); every int-returning entry point returns a hipError_t
 _SIGNATURES = {
     "ugrid_abi_version": (_I, []),
@@ -113,6 +143,12 @@ _SIGNATURES = {
     "ugrid_masked_adam_upd_touch": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _P, _P]),
     "ugrid_tv_adam_dense_cl_touch": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _L, _L, _L, _L, _L, _I, _F, _F, _F, _F, _I, _P, _P]),
     "ugrid_rgbnet_features": (_I, [_P, _I, _P, _P, _I, _P, _L, _P, _P]),
+    "ugrid_voxgo_step_sizeof": (_L, []),
+    "ugrid_voxgo_step_ws_floats": (_L, [_P]),
+    "ugrid_voxgo_step_bwd_ws_floats": (_L, [_P]),
+    "ugrid_voxgo_step_sample": (_I, [_P, _P]),
+    "ugrid_voxgo_step_forward": (_I, [_P, _P]),
+    "ugrid_voxgo_step_backward": (_I, [_P, _P]),
     "ugrid_render_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P]),
     "ugrid_render_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ugrid_brick_bytes": (_L, [_I, _I, _I, _I, _I, _I]),

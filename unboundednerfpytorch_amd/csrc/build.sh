@@ -6,8 +6,8 @@ cd "$(dirname "$0")"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I../../include"
 O=${UG_OBJ:-../../build/obj}      # UG_OBJ: separate object directory (parallel A/B builds)
 mkdir -p $O
-rm -f $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_train.o $O/ugrid_train_mlp.o   # a failed compile must not link a stale object
-OBJS="$O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_train.o $O/ugrid_train_mlp.o"
+rm -f $O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_train.o $O/ugrid_train_mlp.o $O/ugrid_step.o   # a failed compile must not link a stale object
+OBJS="$O/ugrid_ops.o $O/ugrid_march.o $O/ugrid_shade.o $O/ugrid_train.o $O/ugrid_train_mlp.o $O/ugrid_step.o"
 pids=()
 hipcc $FLAGS -c ugrid_ops.hip -o $O/ugrid_ops.o "$@" &
 pids+=($!)
@@ -20,6 +20,8 @@ pids+=($!)
 hipcc $FLAGS -c ugrid_train.hip -o $O/ugrid_train.o "$@" &
 pids+=($!)
 hipcc $FLAGS -c ugrid_train_mlp.hip -o $O/ugrid_train_mlp.o "$@" &
+pids+=($!)
+hipcc $FLAGS -c ugrid_step.hip -o $O/ugrid_step.o "$@" &
 pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done   # a bare `wait` returns 0 even when a job failed
 hipcc --offload-arch=gfx950 -shared -fPIC -o ${UG_OUT:-../libugrid_hip.so} $OBJS

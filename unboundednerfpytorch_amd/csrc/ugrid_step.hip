@@ -1,0 +1,166 @@
+// One training step of the two dense-grid models issued natively (include/ugrid_hip.h: ugrid_voxgo_step).
+//
+// The op-by-op step (voxgo_model.py + train_step.py) is host-bound: ~30 launches through Python + ctypes + four autograd nodes
+// take ~0.9 ms to issue for 0.8 ms of GPU time.  Nothing here is a new algorithm: the three entry points call
+// the library's own launchers (the same kernels, sizes and order as the Python step -> bit-identical results) and add the two
+// things Python did in between -- the prefix sums of the per-ray counts (torch.cumsum) and the read of the two totals.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ugrid_common.h"
+#include "ugrid_hip.h"
+
+#define ST(s) ((hipStream_t)(s))
+
+// inclusive int64 prefix sums of the two int32 count rows [2, n] (block b = row b), totals[b] = the row's sum
+__global__ void __launch_bounds__(256)
+k_step_count_scan(const int32_t *__restrict__ counts, int64_t n, int64_t *__restrict__ offsets, int64_t *__restrict__ totals) {
+  __shared__ int64_t lds[256];
+  const int32_t *in = counts + (int64_t)blockIdx.x * n;
+  int64_t *out = offsets + (int64_t)blockIdx.x * n;
+  const int t = threadIdx.x;
+  const int64_t per = (n + 255) / 256, lo = (int64_t)t * per, hi = lo + per < n ? lo + per : n;
+  int64_t s = 0;
+  for (int64_t i = lo; i < hi; ++i) s += in[i];
+  lds[t] = s;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {
+    const int64_t add = (t >= off) ? lds[t - off] : 0;
+    __syncthreads();
+    lds[t] += add;
+    __syncthreads();
+  }
+  int64_t run = lds[t] - s;
+  for (int64_t i = lo; i < hi; ++i) {
+    run += in[i];
+    out[i] = run;
+  }
+  if (t == 255) totals[blockIdx.x] = lds[255];
+}
+
+static inline int64_t ug_al(int64_t floats) { return (floats + 63) & ~(int64_t)63; }      // 256-byte aligned sub-buffers
+
+struct ug_step_ws {      // forward workspace: what the backward needs again, and the rgbnet's input
+  float *pts1, *dens1, *w1, *T1;
+  int32_t *pos2;
+  float *pts2, *k0, *feat, *h1, *h2;
+  int64_t total;
+};
+struct ug_step_ws_bwd {
+  float *g_logits, *g_w, *g_dens, *g_ainv, *g_k0, *g1, *rg;
+  int64_t total;
+};
+
+static ug_step_ws ug_step_layout(const ugrid_voxgo_step *s) {
+  ug_step_ws w;
+  const int64_t M1 = s->M1, M2 = s->M2, K = s->C + 3 + 6 * s->pe;
+  int64_t o = 0;
+  auto take = [&](int64_t n) { float *p = s->ws ? s->ws + o : nullptr; o += ug_al(n); return p; };
+  w.pts1 = take(3 * M1); w.dens1 = take(M1); w.w1 = take(M1); w.T1 = take(M1);
+  w.pos2 = (int32_t *)take(M1);
+  w.pts2 = take(3 * M2); w.k0 = take(M2 * s->C); w.feat = take(M2 * K); w.h1 = take(M2 * s->width); w.h2 = take(M2 * s->width);
+  w.total = o;
+  return w;
+}
+
+static ug_step_ws_bwd ug_step_layout_bwd(const ugrid_voxgo_step *s) {
+  ug_step_ws_bwd w;
+  const int64_t M1 = s->M1, M2 = s->M2;
+  int64_t o = 0;
+  auto take = [&](int64_t n) { float *p = s->ws_bwd ? s->ws_bwd + o : nullptr; o += ug_al(n); return p; };
+  w.g_logits = take(3 * M2); w.g_w = take(M2); w.g_dens = take(M2); w.g_ainv = take(s->n_rays); w.g_k0 = take(M2 * s->C);
+  w.g1 = take(M1); w.rg = take(ugrid_rgbnet_train_scratch_floats(M2));
+  w.total = o;
+  return w;
+}
+
+extern "C" int64_t ugrid_voxgo_step_sizeof(void) { return (int64_t)sizeof(ugrid_voxgo_step); }
+extern "C" int64_t ugrid_voxgo_step_ws_floats(const ugrid_voxgo_step *s) { return ug_step_layout(s).total; }
+extern "C" int64_t ugrid_voxgo_step_bwd_ws_floats(const ugrid_voxgo_step *s) { return ug_step_layout_bwd(s).total; }
+
+static int ug_step_check(const ugrid_voxgo_step *s) {
+  if (!s || (s->mode != 0 && s->mode != 1) || s->n_rays <= 0 || s->slots <= 0 || s->C < 1 || s->pe < 0) return (int)hipErrorInvalidValue;
+  if (s->width < 1 || s->width > 128 || s->C + 3 + 6 * s->pe > 128) return (int)hipErrorNotSupported;
+  return 0;
+}
+
+extern "C" int ugrid_voxgo_step_sample(ugrid_voxgo_step *s, ugrid_stream_t st) {
+  int rc = ug_step_check(s);
+  if (rc) return rc;
+  const int64_t R = s->n_rays;
+  int32_t *c1 = s->counts, *c2 = s->counts + R;
+  if (s->mode == 1)
+    rc = ugrid_train_sample_dcvgo(s->density_grid, s->X, s->Y, s->Z, s->rays_o, s->rays_d, R, s->t_table, s->slots, s->scene_center,
+                                  s->scene_radius, s->xyz_min, s->xyz_max, s->bg_len, s->norm_l2, s->dist_thres, s->mask, s->mask_dims,
+                                  s->mask_scale, s->mask_shift, s->act_shift, s->interval, s->thres, s->sc_pts, s->sc_density, s->sc_step,
+                                  s->sc_w, s->sc_T, c1, c2, s->alphainv_last, st);
+  else
+    rc = ugrid_train_sample_dvgo(s->density_grid, s->X, s->Y, s->Z, s->rays_o, s->rays_d, R, s->slots, s->xyz_min, s->xyz_max, s->near_clip,
+                                 s->far_clip, s->stepdist, s->mask, s->mask_dims, s->mask_scale, s->mask_shift, s->act_shift, s->interval,
+                                 s->thres, s->sc_pts, s->sc_density, s->sc_step, s->sc_w, s->sc_T, c1, c2, s->alphainv_last, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_step_count_scan, dim3(2), dim3(256), 0, ST(st), s->counts, R, s->offsets, s->totals);
+  UG_LAUNCH_CHECK();
+  static thread_local int64_t *pinned = nullptr;      // the step's one host read lands in page-locked memory
+  if (!pinned) UG_HIP(hipHostMalloc((void **)&pinned, 2 * sizeof(int64_t), hipHostMallocDefault));
+  UG_HIP(hipMemcpyAsync(pinned, s->totals, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ST(st)));
+  UG_HIP(hipStreamSynchronize(ST(st)));
+  s->M1 = pinned[0];
+  s->M2 = pinned[1];
+  return 0;
+}
+
+extern "C" int ugrid_voxgo_step_forward(const ugrid_voxgo_step *s, ugrid_stream_t st) {
+  int rc = ug_step_check(s);
+  if (rc) return rc;
+  if (s->M1 < 0 || s->M2 < 0 || s->M2 > s->M1 || ((s->M1 | s->M2) && !s->ws)) return (int)hipErrorInvalidValue;
+  const ug_step_ws w = ug_step_layout(s);
+  const int64_t R = s->n_rays, M2 = s->M2;
+  const int K = s->C + 3 + 6 * s->pe;
+  if (s->M1 > 0) {
+    rc = ugrid_train_sample_compact_vox(R, s->slots, s->act_shift, s->interval, s->thres, s->sc_pts, s->sc_density, s->sc_step, s->sc_w,
+                                        s->sc_T, s->counts, s->offsets, s->counts + R, s->offsets + R, s->mode == 1 ? s->t_table : nullptr,
+                                        w.pts1, w.dens1, w.w1, w.T1, w.pos2, w.pts2, s->density2, s->alpha2, s->weights2, s->ray_id2,
+                                        s->step_id2, s->t2, s->mode == 1 ? s->inner2 : nullptr, st);
+    if (rc) return rc;
+  }
+  rc = (s->k0_channels_last ? ugrid_grid_query_cl : ugrid_grid_query)(s->k0_grid, 1, s->C, s->kX, s->kY, s->kZ, w.pts2, s->k0_xyz_min,
+                                                                     s->k0_xyz_max, 0, M2, w.k0, st);
+  if (rc) return rc;
+  rc = ugrid_rgbnet_features(w.k0, s->C, s->viewdirs, s->viewfreq, s->pe, s->ray_id2, M2, w.feat, st);
+  if (rc) return rc;
+  rc = ugrid_rgbnet_train_forward(w.feat, M2, K, s->w0, s->b0, s->w1, s->b1, s->w2, s->b2, s->width, w.h1, w.h2, s->logits, st);
+  if (rc) return rc;
+  return ugrid_render_loss(s->logits, s->weights2, nullptr, s->t2, s->alphainv_last, s->bg, s->target, s->ray_id2, M2, R, s->coef8, s->seg,
+                           s->rgb_marched, s->ray_tot, s->partial, s->out2, st);
+}
+
+extern "C" int ugrid_voxgo_step_backward(const ugrid_voxgo_step *s, ugrid_stream_t st) {
+  int rc = ug_step_check(s);
+  if (rc) return rc;
+  if (!s->grad_loss || !s->ws_bwd || !s->grad_density_grid || !s->grad_k0_grid) return (int)hipErrorInvalidValue;
+  const ug_step_ws w = ug_step_layout(s);
+  const ug_step_ws_bwd b = ug_step_layout_bwd(s);
+  const int64_t R = s->n_rays, M1 = s->M1, M2 = s->M2;
+  const int K = s->C + 3 + 6 * s->pe;
+  rc = ugrid_render_loss_backward(s->logits, s->weights2, nullptr, s->t2, s->alphainv_last, s->bg, s->target, s->ray_id2, M2, R, s->coef8,
+                                  s->seg, s->rgb_marched, s->ray_tot, s->grad_loss, b.g_logits, b.g_w, b.g_ainv, b.g_dens, st);
+  if (rc) return rc;
+  rc = ugrid_rgbnet_train_backward(b.g_logits, w.feat, w.h1, w.h2, M2, K, s->C, s->w0, s->w1, s->w2, s->width, b.g_k0, s->g_w0, s->g_b0,
+                                   s->g_w1, s->g_b1, s->g_w2, s->g_b2, b.rg, st);
+  if (rc) return rc;
+  if (s->k0_channels_last && s->touch)
+    rc = ugrid_grid_query_backward_cl_touch(b.g_k0, 1, s->C, s->kX, s->kY, s->kZ, w.pts2, s->k0_xyz_min, s->k0_xyz_max, 0, M2,
+                                            s->grad_k0_grid, s->touch, st);
+  else
+    rc = (s->k0_channels_last ? ugrid_grid_query_backward_cl : ugrid_grid_query_backward)(
+        b.g_k0, 1, s->C, s->kX, s->kY, s->kZ, w.pts2, s->k0_xyz_min, s->k0_xyz_max, 0, M2, s->grad_k0_grid, st);
+  if (rc) return rc;
+  if (M1 > 0) {
+    rc = ugrid_train_sample_backward(R, s->act_shift, s->interval, w.dens1, w.w1, w.T1, w.pos2, s->counts, s->offsets, s->alphainv_last,
+                                     b.g_w, b.g_ainv, b.g_dens, b.g1, st);
+    if (rc) return rc;
+    rc = ugrid_grid_query_backward(b.g1, 1, 1, s->X, s->Y, s->Z, w.pts1, s->xyz_min, s->xyz_max, 0, M1, s->grad_density_grid, st);
+  }
+  return rc;
+}

@@ -1,0 +1,163 @@
+"""The training step of the two dense-grid models issued natively: ONE autograd node whose forward is two C calls
+(include/ugrid_hip.h: ugrid_voxgo_step_sample / _forward) and whose backward is one (ugrid_voxgo_step_backward), in place of the
+op-by-op step's four nodes and ~30 launches issued from Python (voxgo_model.py: TrainSampleVox, the k0 GridQuery, FusedRgbnet,
+RenderLoss).  The C side runs the same kernels on the same sizes in the same order, so loss, outputs and every gradient are the
+op-by-op step's bit for bit (tests/test_gpu_native_step.py); what changes is the host time between launches.
+
+Only the tensors a training loop reads come back as autograd outputs (loss; mse without gradient); the per-sample arrays of the
+reference's return dict are handed out detached."""
+import ctypes
+
+import torch
+
+from . import _gradpool, _lib
+from . import grid as _grid
+
+_L = _lib.load()
+
+if int(_L.ugrid_voxgo_step_sizeof()) != ctypes.sizeof(_lib.VoxgoStep):
+    raise ImportError("native_step: _lib.VoxgoStep (%d bytes) does not mirror ugrid_voxgo_step (%d bytes) of the loaded library"
+                      % (ctypes.sizeof(_lib.VoxgoStep), int(_L.ugrid_voxgo_step_sizeof())))
+
+_WEIGHTS = ("w0", "b0", "w1", "b1", "w2", "b2")
+
+
+class VoxGOStep(torch.autograd.Function):
+    """forward(density_grid [1,1,X,Y,Z], k0_grid [1,C,X,Y,Z], w0, b0, w1, b1, w2, b2, pack) -> loss, mse
+    pack (dict, not differentiated): mode 'dvgo' | 'dcvgo', cfg (the dict TrainSampleVox takes), rays_o / rays_d / viewdirs [R,3],
+    viewfreq [pe], t (dcvgo: the sample table [S]), xyz_min / xyz_max, k0_xyz_min / k0_xyz_max, mask (bool [mi,mj,mk]),
+    target [R,3], bg [R,3] or None, coef (ops.loss_coefficients).  On return pack['out'] holds the detached per-sample / per-ray
+    arrays: alphainv_last, weights, rgb_marched, raw_alpha, raw_density, raw_logits, ray_id, step_id, t, inner."""
+
+    @staticmethod
+    def forward(ctx, density_grid, k0_grid, w0, b0, w1, b1, w2, b2, pack):
+        cfg, mode = pack['cfg'], pack['mode']
+        rays_o, rays_d, viewdirs = pack['rays_o'], pack['rays_d'], pack['viewdirs']
+        ws_ = [x.contiguous() for x in (w0, b0, w1, b1, w2, b2)]
+        f32 = [("density grid", density_grid), ("rays_o", rays_o), ("rays_d", rays_d), ("viewdirs", viewdirs),
+               ("target", pack['target']), ("viewfreq", pack['viewfreq'])] + [("rgbnet", x) for x in ws_]
+        if pack.get('bg') is not None:
+            f32.append(("bg", pack['bg']))
+        _lib.require_cuda(*f32, ("mask", pack['mask']))
+        _lib.require_f32(*f32, ("k0 grid", k0_grid))
+        for g in (density_grid, k0_grid):
+            _lib.wait_pending(g)     # an optimizer update of a grid may still run on a side stream (step(overlap=...))
+        if density_grid.dim() != 5 or tuple(density_grid.shape[:2]) != (1, 1) or not density_grid.is_contiguous():
+            raise RuntimeError("VoxGOStep: the density grid must be a contiguous [1,1,X,Y,Z]")
+        if k0_grid.dim() != 5 or k0_grid.shape[0] != 1:
+            raise RuntimeError("VoxGOStep: the k0 grid must be [1,C,X,Y,Z]")
+        k0_cl = bool(_lib.require_cuda_grid(("k0 grid", k0_grid)))
+        dev = density_grid.device
+        R = rays_o.shape[0]
+        t = pack.get('t')
+        S = int(cfg['slots']) if mode == 'dvgo' else t.numel()
+        mask = pack['mask']
+        C, W, pe = k0_grid.shape[1], ws_[0].shape[0], pack['viewfreq'].numel()
+        if tuple(ws_[0].shape) != (W, C + 3 + 6 * pe) or tuple(ws_[2].shape) != (W, W) or tuple(ws_[4].shape) != (3, W):
+            raise RuntimeError("VoxGOStep: rgbnet weights must be [W, C+3+6pe], [W,W], [3,W]")
+        if viewdirs.shape != (R, 3) or rays_d.shape != (R, 3) or pack['target'].shape != (R, 3):
+            raise RuntimeError("VoxGOStep: rays_o, rays_d, viewdirs, target must all be [R,3]")
+        key = (dev, R * S)
+        sc = _grid.TrainSampleVox._scratch.get(key)
+        if sc is None:
+            _grid.TrainSampleVox._scratch.clear()          # one ray-batch shape at a time: 32 B per (ray, slot)
+            sc = (torch.empty(R * S, 3, device=dev), torch.empty(R * S, device=dev), torch.empty(R * S, dtype=torch.int32, device=dev),
+                  torch.empty(R * S, device=dev), torch.empty(R * S, device=dev))
+            _grid.TrainSampleVox._scratch[key] = sc
+        counts = torch.empty(2, R, dtype=torch.int32, device=dev)
+        i64 = torch.empty(4 * R + 2, dtype=torch.int64, device=dev)        # offsets [2,R] | totals [2] | seg [2R]
+        perray = torch.empty(R, 6, device=dev)                             # ray_tot [R,2] | partial [R,4]
+        ainv = torch.empty(R, device=dev)
+        rgb_marched = torch.empty(R, 3, device=dev)
+        out2 = torch.empty(2, device=dev)
+        s = _lib.VoxgoStep()
+        s.mode = 0 if mode == 'dvgo' else 1
+        s.k0_channels_last = int(k0_cl)
+        s.X, s.Y, s.Z = density_grid.shape[2:]
+        s.kX, s.kY, s.kZ = k0_grid.shape[2:]
+        s.C, s.pe, s.width, s.slots = C, pe, W, S
+        s.mask_dims[:] = [int(x) for x in mask.shape]
+        s.mask_scale[:] = cfg['mask_scale']
+        s.mask_shift[:] = cfg['mask_shift']
+        s.act_shift, s.interval, s.thres = float(cfg['act_shift']), float(cfg['interval']), float(cfg['thres'])
+        if mode == 'dvgo':
+            s.near_clip, s.far_clip, s.stepdist = float(cfg['near']), float(cfg['far']), float(cfg['stepdist'])
+        else:
+            s.scene_center[:] = cfg['scene_center']
+            s.scene_radius[:] = cfg['scene_radius']
+            s.bg_len, s.norm_l2, s.dist_thres = float(cfg['bg_len']), int(bool(cfg['norm_l2'])), float(cfg['dist_thres'])
+            s.t_table = t.data_ptr()
+        s.coef8[:] = [float(x) for x in pack['coef']]
+        s.n_rays = R
+        rays_o, rays_d, viewdirs = rays_o.contiguous(), rays_d.contiguous(), viewdirs.contiguous()
+        target = pack['target'].contiguous()
+        bg = pack['bg'].contiguous() if pack.get('bg') is not None else None
+        viewfreq = pack['viewfreq'].contiguous()
+        s.density_grid, s.k0_grid = density_grid.data_ptr(), k0_grid.data_ptr()
+        s.xyz_min, s.xyz_max = pack['xyz_min'].data_ptr(), pack['xyz_max'].data_ptr()
+        s.k0_xyz_min, s.k0_xyz_max = pack['k0_xyz_min'].data_ptr(), pack['k0_xyz_max'].data_ptr()
+        s.mask, s.viewfreq = mask.data_ptr(), viewfreq.data_ptr()
+        for n, x in zip(_WEIGHTS, ws_):
+            setattr(s, n, x.data_ptr())
+        s.rays_o, s.rays_d, s.viewdirs, s.target = rays_o.data_ptr(), rays_d.data_ptr(), viewdirs.data_ptr(), target.data_ptr()
+        s.bg = bg.data_ptr() if bg is not None else None
+        s.sc_pts, s.sc_density, s.sc_step, s.sc_w, s.sc_T = (x.data_ptr() for x in sc)
+        s.counts, s.offsets = counts.data_ptr(), i64.data_ptr()
+        s.totals, s.seg = i64.data_ptr() + 16 * R, i64.data_ptr() + 16 * R + 16
+        s.alphainv_last, s.rgb_marched, s.out2 = ainv.data_ptr(), rgb_marched.data_ptr(), out2.data_ptr()
+        s.ray_tot, s.partial = perray.data_ptr(), perray.data_ptr() + 8 * R
+        ps = ctypes.addressof(s)
+        with _lib.guard(dev):
+            st = _lib.stream_of(density_grid)
+            _lib.check(_L.ugrid_voxgo_step_sample(ps, st), "voxgo_step_sample")          # the step's one host read: M1, M2
+            M2 = s.M2
+            ws = torch.empty(int(_L.ugrid_voxgo_step_ws_floats(ps)), device=dev)
+            f4 = torch.empty(4, M2, device=dev)                                # density2 | alpha2 | weights2 | t2
+            ids = torch.empty(2, M2, dtype=torch.int64, device=dev)            # ray_id2 | step_id2
+            logits = torch.empty(M2, 3, device=dev)
+            inner = torch.ones(M2, dtype=torch.bool, device=dev) if mode == 'dcvgo' else None
+            s.ws = ws.data_ptr()
+            s.density2, s.alpha2, s.weights2, s.t2 = (f4.data_ptr() + 4 * M2 * i for i in range(4))
+            s.ray_id2, s.step_id2 = ids.data_ptr(), ids.data_ptr() + 8 * M2
+            s.inner2 = inner.data_ptr() if inner is not None else None
+            s.logits = logits.data_ptr()
+            _lib.check(_L.ugrid_voxgo_step_forward(ps, st), "voxgo_step_forward")
+        ctx.step = s
+        # everything the struct points to stays alive until the backward has been issued
+        ctx.keep = (density_grid, k0_grid, ws_, rays_o, rays_d, viewdirs, target, bg, viewfreq, t, mask, pack['xyz_min'], pack['xyz_max'],
+                    pack['k0_xyz_min'], pack['k0_xyz_max'], sc, counts, i64, perray, ainv, rgb_marched, out2, ws, f4, ids, logits, inner)
+        ctx.shapes = (tuple(density_grid.shape), tuple(density_grid.stride()), tuple(k0_grid.shape), tuple(k0_grid.stride()), k0_cl)
+        ctx.keys = (_gradpool.key_of(density_grid), _gradpool.key_of(k0_grid))
+        ctx.wshapes = [tuple(x.shape) for x in ws_]
+        pack['out'] = {'alphainv_last': ainv, 'weights': f4[2], 'rgb_marched': rgb_marched, 'raw_alpha': f4[1], 'raw_density': f4[0],
+                       'raw_logits': logits, 'ray_id': ids[0], 'step_id': ids[1], 't': f4[3], 'inner': inner}
+        loss, mse = out2[0], out2[1]
+        ctx.mark_non_differentiable(mse)
+        return loss, mse
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_loss, g_mse):
+        s = ctx.step
+        (dshape, dstride, kshape, kstride, k0_cl), (dkey, kkey) = ctx.shapes, ctx.keys
+        dev = ctx.keep[0].device
+        g_loss = g_loss.to(torch.float32).reshape(1).contiguous()
+        gw = [torch.empty(sh, device=dev) for sh in ctx.wshapes]
+        g_density = _gradpool.take(dkey, dshape, dstride, dev)
+        if g_density is None:
+            g_density = torch.zeros(dshape, dtype=torch.float32, device=dev)
+        g_k0 = _gradpool.take(kkey, kshape, kstride, dev)                  # all zero, from the last step
+        if g_k0 is None:
+            g_k0 = _lib.empty_like_grid(kshape, k0_cl, dev, zero=True)
+        # channel-last: the scatter also marks the 256-byte lines it adds to (the optimizer's masked passes visit only those)
+        touch = _gradpool.touch_for_backward(kkey, g_k0, _L) if k0_cl else None
+        ps = ctypes.addressof(s)
+        ws_bwd = torch.empty(int(_L.ugrid_voxgo_step_bwd_ws_floats(ps)), device=dev)
+        s.grad_loss, s.ws_bwd = g_loss.data_ptr(), ws_bwd.data_ptr()
+        for n, x in zip(_WEIGHTS, gw):
+            setattr(s, "g_" + n, x.data_ptr())
+        s.grad_density_grid, s.grad_k0_grid = g_density.data_ptr(), g_k0.data_ptr()
+        s.touch = touch.data_ptr() if touch is not None else None
+        with _lib.guard(dev):
+            _lib.check(_L.ugrid_voxgo_step_backward(ps, _lib.stream_of(g_loss)), "voxgo_step_backward")
+        return (g_density, g_k0, *gw, None)

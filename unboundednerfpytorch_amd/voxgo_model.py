@@ -35,6 +35,8 @@ class _VoxGOBase(nn.Module):
     """What the two models share: one resolution for both grids, the mask cache, the coarse-to-fine step, the TV hooks."""
     fused_forward = True        # grid.TrainSampleVox (needs fast_color_thres > 0, like the reference's own masking branches)
     fused_rgbnet = True         # ops.FusedRgbnet for the default 3-layer rgbnet
+    native_step = True          # native_step.VoxGOStep: the fused training forward + loss as ONE autograd node issued from C
+                                # (same kernels, same bits; default rgbnet, rgbnet_direct, train_iteration's fused_loss)
 
     def _init_grids(self, density_type, k0_type, density_config, k0_config, k0_dim, channels_last):
         if density_type != 'DenseGrid' or k0_type != 'DenseGrid':
@@ -149,6 +151,35 @@ class _VoxGOBase(nn.Module):
 
     def _can_fuse(self, rays_o):
         return self.fused_forward and self.fast_color_thres > 0 and rays_o.is_cuda
+
+    def _native_params(self):
+        """The parameters of native_step.VoxGOStep (density grid, k0 grid, the rgbnet's three weights and biases), or None when this
+        configuration takes the op-by-op ops: the native step needs the default 3-layer rgbnet fed by all of k0 (rgbnet_direct),
+        gradients on, and every one of those parameters trainable."""
+        if not (self.native_step and self.fused_rgbnet and self.rgbnet is not None and torch.is_grad_enabled()
+                and getattr(self, 'rgbnet_direct', True)):
+            return None
+        lin = _ops.rgbnet_linears(self.rgbnet)
+        if lin is None:
+            return None
+        params = [self.density.grid, self.k0.grid] + [p for l in lin for p in (l.weight, l.bias)]
+        if not all(p.requires_grad for p in params) or self.density.query_fn is not None or self.k0.query_fn is not None \
+                or self.density.grid.shape[0] != 1 or self.k0.grid.shape[0] != 1:
+            return None
+        return params
+
+    def _native_forward(self, params, mode, cfg, t, rays_o, rays_d, viewdirs, fused_loss, bg):
+        """The training forward + loss as ONE autograd node issued from C (native_step.VoxGOStep): the reference's return dict with
+        loss / mse added, the per-sample arrays detached"""
+        from .native_step import VoxGOStep
+        pack = {'mode': mode, 'cfg': cfg, 't': t, 'rays_o': rays_o, 'rays_d': rays_d, 'viewdirs': viewdirs, 'viewfreq': self.viewfreq,
+                'xyz_min': self.xyz_min, 'xyz_max': self.xyz_max, 'k0_xyz_min': self.k0.xyz_min, 'k0_xyz_max': self.k0.xyz_max,
+                'mask': self.mask_cache.mask, 'target': fused_loss['target'], 'bg': bg, 'coef': fused_loss['coef']}
+        loss, mse = VoxGOStep.apply(*params, pack)
+        o = pack['out']
+        return {'alphainv_last': o['alphainv_last'], 'weights': o['weights'], 'rgb_marched': o['rgb_marched'], 'raw_alpha': o['raw_alpha'],
+                'raw_density': o['raw_density'], 'raw_logits': o['raw_logits'], 'ray_id': o['ray_id'], 'step_id': o['step_id'],
+                't': o['t'], 'loss': loss, 'mse': mse}
 
     def _logits(self, k0_view, viewdirs, ray_id):
         """rgbnet([k0, view embedding]) of the surviving samples: the fp32-MFMA kernels for the default 3-layer net while training"""
@@ -311,6 +342,14 @@ class DirectVoxGO(_VoxGOBase):
             cfg = {'mode': 'dvgo', 'act_shift': hc['act_shift'], 'interval': interval_f, 'thres': float(self.fast_color_thres),
                    'mask_scale': hc['mask_scale'], 'mask_shift': hc['mask_shift'], 'near': float(render_kwargs['near']), 'far': 1e9,
                    'stepdist': stepdist, 'slots': int(math.ceil(hc['box_diag'] / stepdist)) + 2}
+            fl = render_kwargs.get('fused_loss')
+            native = self._native_params() if (fl is not None and float(fl['coef'][2]) == 0.0 and float(fl['coef'][4]) == 0.0) else None
+            if native is not None:
+                bg = torch.full((N, 3), float(render_kwargs['bg']), device=rays_o.device) if float(render_kwargs['bg']) != 0.0 else None
+                out = self._native_forward(native, 'dvgo', cfg, None, rays_o.contiguous(), rays_d.contiguous(), viewdirs, fl, bg)
+                for k in ('raw_density', 'step_id', 't'):      # (not in DirectVoxGO's return dict, dvgo.py:405-417)
+                    out.pop(k)
+                return out
             pts, density, alpha, weights, alphainv_last, ray_id, step_id, tt, _ = _grid.TrainSampleVox.apply(
                 self.density.grid, rays_o.contiguous(), rays_d.contiguous(), None, self.xyz_min, self.xyz_max, self.mask_cache.mask, cfg)
         else:
@@ -454,6 +493,16 @@ class DirectContractedVoxGO(_VoxGOBase):
                    'mask_scale': hc['mask_scale'], 'mask_shift': hc['mask_shift'], 'scene_center': hc['scene_center'],
                    'scene_radius': hc['scene_radius'], 'bg_len': self.bg_len, 'norm_l2': self.contracted_norm == 'l2',
                    'dist_thres': dist_thres}
+            fl = render_kwargs.get('fused_loss')
+            native = self._native_params() if fl is not None else None
+            if native is not None:
+                if render_kwargs.get('rand_bkgd', False) and is_train:
+                    bg = torch.rand(N, 3, device=dev)
+                else:
+                    bg = torch.full((N, 3), float(render_kwargs['bg']), device=dev) if float(render_kwargs['bg']) != 0.0 else None
+                out = self._native_forward(native, 'dcvgo', cfg, t, rays_o.contiguous(), rays_d.contiguous(), viewdirs, fl, bg)
+                out['n_max'] = n_max
+                return out
             pts, density, alpha, weights, alphainv_last, ray_id, step_id, tt, inner = _grid.TrainSampleVox.apply(
                 self.density.grid, rays_o.contiguous(), rays_d.contiguous(), t, self.xyz_min, self.xyz_max, self.mask_cache.mask, cfg)
         else:
