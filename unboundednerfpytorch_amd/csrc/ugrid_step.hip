@@ -12,30 +12,48 @@
 
 #define ST(s) ((hipStream_t)(s))
 
-// inclusive int64 prefix sums of the two int32 count rows [2, n] (block b = row b), totals[b] = the row's sum
-__global__ void __launch_bounds__(256)
+// inclusive int64 prefix sums of the two int32 count rows [2, n] (block b = row b), totals[b] = the row's sum (torch.cumsum of the
+// op-by-op step).  Tiles of 1024 threads x 4 consecutive counts: the four loads of a thread are independent (one latency per
+// tile, not one per element), thread sums are scanned with wave shuffles + one LDS round over the 16 waves.
+#define UG_STEP_SCAN_THREADS 1024
+__global__ void __launch_bounds__(UG_STEP_SCAN_THREADS)
 k_step_count_scan(const int32_t *__restrict__ counts, int64_t n, int64_t *__restrict__ offsets, int64_t *__restrict__ totals) {
-  __shared__ int64_t lds[256];
+  __shared__ int64_t wave_sum[UG_STEP_SCAN_THREADS / UG_WAVE];
   const int32_t *in = counts + (int64_t)blockIdx.x * n;
   int64_t *out = offsets + (int64_t)blockIdx.x * n;
-  const int t = threadIdx.x;
-  const int64_t per = (n + 255) / 256, lo = (int64_t)t * per, hi = lo + per < n ? lo + per : n;
-  int64_t s = 0;
-  for (int64_t i = lo; i < hi; ++i) s += in[i];
-  lds[t] = s;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    const int64_t add = (t >= off) ? lds[t - off] : 0;
+  const int t = threadIdx.x, lane = t & (UG_WAVE - 1), w = t / UG_WAVE;
+  int64_t carry = 0;
+  for (int64_t base = 0; base < n; base += 4 * UG_STEP_SCAN_THREADS) {
+    const int64_t i0 = base + 4 * (int64_t)t;
+    int32_t v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (i0 + j < n) ? in[i0 + j] : 0;
+    const int64_t mine = (int64_t)v[0] + v[1] + v[2] + v[3];
+    int64_t inc = mine;                                   // inclusive scan of the thread sums within the wave
+#pragma unroll
+    for (int o = 1; o < UG_WAVE; o <<= 1) {
+      const int64_t up = __shfl_up(inc, o, UG_WAVE);
+      if (lane >= o) inc += up;
+    }
+    if (lane == UG_WAVE - 1) wave_sum[w] = inc;
     __syncthreads();
-    lds[t] += add;
+    int64_t before = carry, tile = 0;
+#pragma unroll
+    for (int k = 0; k < UG_STEP_SCAN_THREADS / UG_WAVE; ++k) {
+      const int64_t ws = wave_sum[k];
+      if (k < w) before += ws;
+      tile += ws;
+    }
+    int64_t run = before + inc - mine;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      run += v[j];
+      if (i0 + j < n) out[i0 + j] = run;
+    }
+    carry += tile;
     __syncthreads();
   }
-  int64_t run = lds[t] - s;
-  for (int64_t i = lo; i < hi; ++i) {
-    run += in[i];
-    out[i] = run;
-  }
-  if (t == 255) totals[blockIdx.x] = lds[255];
+  if (t == 0) totals[blockIdx.x] = carry;
 }
 
 static inline int64_t ug_al(int64_t floats) { return (floats + 63) & ~(int64_t)63; }      // 256-byte aligned sub-buffers
@@ -99,7 +117,7 @@ extern "C" int ugrid_voxgo_step_sample(ugrid_voxgo_step *s, ugrid_stream_t st) {
                                  s->far_clip, s->stepdist, s->mask, s->mask_dims, s->mask_scale, s->mask_shift, s->act_shift, s->interval,
                                  s->thres, s->sc_pts, s->sc_density, s->sc_step, s->sc_w, s->sc_T, c1, c2, s->alphainv_last, st);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_step_count_scan, dim3(2), dim3(256), 0, ST(st), s->counts, R, s->offsets, s->totals);
+  hipLaunchKernelGGL(k_step_count_scan, dim3(2), dim3(UG_STEP_SCAN_THREADS), 0, ST(st), s->counts, R, s->offsets, s->totals);
   UG_LAUNCH_CHECK();
   static thread_local int64_t *pinned = nullptr;      // the step's one host read lands in page-locked memory
   if (!pinned) UG_HIP(hipHostMalloc((void **)&pinned, 2 * sizeof(int64_t), hipHostMallocDefault));

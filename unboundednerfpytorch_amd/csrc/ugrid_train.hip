@@ -253,13 +253,14 @@ extern "C" int ugrid_render_loss_backward(const float *logits, const float *weig
 // is formed per ray, indexed by ray_id and concatenated behind the k0 features -- six elementwise launches and two concatenations
 // there), one thread per output element so the stores coalesce.  Column order inside the sin / cos groups is torch's
 // (viewdirs.unsqueeze(-1) * viewfreq).flatten(-2): axis-major, frequency-minor.
+template <typename IDX>      // uint32_t when the element count fits (a 64-bit division is ~100 VALU instructions, the kernel's largest cost)
 __global__ void __launch_bounds__(256)
 k_rgbnet_features(const float *__restrict__ k0, int C, const float *__restrict__ viewdirs, const float *__restrict__ freq, int pe,
                   const int64_t *__restrict__ ray_id, int64_t total, float *__restrict__ out) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int K = C + 3 + 6 * pe;
-  const int64_t m = idx / K;
+  const int64_t m = (int64_t)((IDX)idx / (IDX)K);
   const int j = (int)(idx - m * K);
   if (j < C) {
     out[idx] = k0[m * C + j];
@@ -285,8 +286,12 @@ extern "C" int ugrid_rgbnet_features(const float *k0, int32_t n_k0, const float 
   const int64_t total = m * (n_k0 + 3 + 6 * pe);
   if (total == 0) return 0;                                  // (no samples: empty arrays have no address)
   if ((n_k0 > 0 && !k0) || (pe > 0 && !viewfreq) || !viewdirs || !out) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_rgbnet_features, dim3(ug_blocks(total, 256)), dim3(256), 0, ST(st), k0, n_k0, viewdirs, viewfreq, pe, ray_id,
-                     total, out);
+  if (total < ((int64_t)1 << 32))
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rgbnet_features<uint32_t>), dim3(ug_blocks(total, 256)), dim3(256), 0, ST(st), k0, n_k0, viewdirs,
+                       viewfreq, pe, ray_id, total, out);
+  else
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rgbnet_features<uint64_t>), dim3(ug_blocks(total, 256)), dim3(256), 0, ST(st), k0, n_k0, viewdirs,
+                       viewfreq, pe, ray_id, total, out);
   UG_LAUNCH_CHECK();
   return 0;
 }

@@ -168,6 +168,18 @@ class _VoxGOBase(nn.Module):
             return None
         return params
 
+    def _const_bg(self, N, value, dev):
+        """the constant background colour as [N,3] rows (read-only; kept between steps: one fill launch less per iteration), or None
+        for a black background"""
+        if float(value) == 0.0:
+            return None
+        key = (int(N), float(value), str(dev))
+        cached = getattr(self, '_bg_rows', None)
+        if cached is None or cached[0] != key:
+            cached = (key, torch.full((N, 3), float(value), device=dev))
+            object.__setattr__(self, '_bg_rows', cached)
+        return cached[1]
+
     def _native_forward(self, params, mode, cfg, t, rays_o, rays_d, viewdirs, fused_loss, bg):
         """The training forward + loss as ONE autograd node issued from C (native_step.VoxGOStep): the reference's return dict with
         loss / mse added, the per-sample arrays detached"""
@@ -345,7 +357,7 @@ class DirectVoxGO(_VoxGOBase):
             fl = render_kwargs.get('fused_loss')
             native = self._native_params() if (fl is not None and float(fl['coef'][2]) == 0.0 and float(fl['coef'][4]) == 0.0) else None
             if native is not None:
-                bg = torch.full((N, 3), float(render_kwargs['bg']), device=rays_o.device) if float(render_kwargs['bg']) != 0.0 else None
+                bg = self._const_bg(N, render_kwargs['bg'], rays_o.device)
                 out = self._native_forward(native, 'dvgo', cfg, None, rays_o.contiguous(), rays_d.contiguous(), viewdirs, fl, bg)
                 for k in ('raw_density', 'step_id', 't'):      # (not in DirectVoxGO's return dict, dvgo.py:405-417)
                     out.pop(k)
@@ -499,7 +511,7 @@ class DirectContractedVoxGO(_VoxGOBase):
                 if render_kwargs.get('rand_bkgd', False) and is_train:
                     bg = torch.rand(N, 3, device=dev)
                 else:
-                    bg = torch.full((N, 3), float(render_kwargs['bg']), device=dev) if float(render_kwargs['bg']) != 0.0 else None
+                    bg = self._const_bg(N, render_kwargs['bg'], dev)
                 out = self._native_forward(native, 'dcvgo', cfg, t, rays_o.contiguous(), rays_d.contiguous(), viewdirs, fl, bg)
                 out['n_max'] = n_max
                 return out
