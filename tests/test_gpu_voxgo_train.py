@@ -370,6 +370,7 @@ def test_native_step_equals_the_op_by_op_step_bit_for_bit(kind):
     (oa, ga), (ob, gb) = outs
     assert oa["loss"].grad_fn is not None and type(oa["loss"].grad_fn).__name__.startswith("VoxGOStep"), type(oa["loss"].grad_fn)
     assert not type(ob["loss"].grad_fn).__name__.startswith("VoxGOStep")
+    assert torch.equal(oa.pop("loss_mse"), torch.stack([ob["loss"], ob["mse"]]).detach())    # {loss, mse} for a one-copy read
     assert set(oa) == set(ob), (sorted(oa), sorted(ob))
     for k in oa:
         if torch.is_tensor(oa[k]):
@@ -392,7 +393,8 @@ def test_native_step_equals_the_op_by_op_step_bit_for_bit(kind):
         losses = [ts.train_iteration(m, opt, o, d, v, target, cfg, step, rk) for step in range(1, 9)]
         torch.cuda.synchronize()
         res.append((losses, {k: p.detach().clone() for k, p in m.named_parameters()}))
-    assert res[0][0][0] == res[1][0][0], (res[0][0][0], res[1][0][0])          # first step: identical parameters, identical loss
+    assert res[0][0][0][0] == res[1][0][0][0], (res[0][0][0], res[1][0][0])    # first step: identical parameters, identical loss
+    assert abs(res[0][0][0][1] - res[1][0][0][1]) <= 1e-5                       # (psnr: host log10 of the same float32 mse)
     np.testing.assert_allclose(np.array(res[0][0]), np.array(res[1][0]), rtol=2e-4)
     for k in res[0][1]:
         pa, pb = res[0][1][k], res[1][1][k]

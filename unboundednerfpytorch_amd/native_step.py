@@ -27,7 +27,8 @@ class VoxGOStep(torch.autograd.Function):
     pack (dict, not differentiated): mode 'dvgo' | 'dcvgo', cfg (the dict TrainSampleVox takes), rays_o / rays_d / viewdirs [R,3],
     viewfreq [pe], t (dcvgo: the sample table [S]), xyz_min / xyz_max, k0_xyz_min / k0_xyz_max, mask (bool [mi,mj,mk]),
     target [R,3], bg [R,3] or None, coef (ops.loss_coefficients).  On return pack['out'] holds the detached per-sample / per-ray
-    arrays: alphainv_last, weights, rgb_marched, raw_alpha, raw_density, raw_logits, ray_id, step_id, t, inner."""
+    arrays: alphainv_last, weights, rgb_marched, raw_alpha, raw_density, raw_logits, ray_id, step_id, t, inner, and loss_mse
+    (the two scalars as one [2] tensor: a training loop that logs both reads them with one copy)."""
 
     @staticmethod
     def forward(ctx, density_grid, k0_grid, w0, b0, w1, b1, w2, b2, pack):
@@ -130,7 +131,7 @@ class VoxGOStep(torch.autograd.Function):
         ctx.keys = (_gradpool.key_of(density_grid), _gradpool.key_of(k0_grid))
         ctx.wshapes = [tuple(x.shape) for x in ws_]
         pack['out'] = {'alphainv_last': ainv, 'weights': f4[2], 'rgb_marched': rgb_marched, 'raw_alpha': f4[1], 'raw_density': f4[0],
-                       'raw_logits': logits, 'ray_id': ids[0], 'step_id': ids[1], 't': f4[3], 'inner': inner}
+                       'raw_logits': logits, 'ray_id': ids[0], 'step_id': ids[1], 't': f4[3], 'inner': inner, 'loss_mse': out2}
         loss, mse = out2[0], out2[1]
         ctx.mark_non_differentiable(mse)
         return loss, mse

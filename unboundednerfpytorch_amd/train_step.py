@@ -176,6 +176,12 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
         factor = 0.1 ** (1 / (_get(cfg_train, 'lrate_decay') * 1000))
         for g in optimizer.param_groups:
             g['lr'] = g['lr'] * factor
+    if not return_tensors and out.get('loss_mse') is not None:
+        # the native step hands out {loss, mse} as one [2] tensor: one device-to-host copy for both, the psnr formed on the host in
+        # float32 like the tensor expression below (no log10 / scale launches, no second synchronising read)
+        import numpy as np
+        loss_v, mse_v = out['loss_mse'].tolist()
+        return loss_v, float(np.float32(-10.0) * np.log10(np.float32(mse_v)))
     psnr = -10.0 * torch.log10(mse.detach())
     if return_tensors:
         return loss.detach(), psnr
