@@ -67,6 +67,7 @@ def run(kind, args, first_step):
     cfg = CFG[kind]
     G = args.grid or (160 if kind == "dvgo" else 320)
     m = make_model(kind, G, dev, args.fused)
+    m.native_step = bool(getattr(args, "native", 1))
     opt = create_optimizer_or_freeze_model(m, cfg, global_step=0)
     rk = dict(stepsize=0.5, bg=1, near=0.2, far=6.0) if kind == "dvgo" else dict(stepsize=0.5, bg=1, rand_bkgd=True)
     n = cfg["N_rand"]
@@ -86,7 +87,7 @@ def run(kind, args, first_step):
     return {"model": kind, "workload": "%s train step: G=%s, C=12, %d random rays, stepsize 0.5%s" % (
                 "DirectVoxGO (lego fine-stage shape)" if kind == "dvgo" else "DirectContractedVoxGO (mip-360 fine-stage shape)",
                 m.world_size.tolist(), n, "" if not tv_on else ", TV " + ("dense" if first_step < cfg["tv_dense_before"] else "masked")),
-            "fused": bool(args.fused), "lazy_loss": bool(args.lazy_loss), "ms_per_step": ms, "rays_per_sec": n / (ms * 1e-3), "survivors_M": int(out["weights"].numel()),
+            "fused": bool(args.fused), "native_step": bool(m.native_step and args.fused), "lazy_loss": bool(args.lazy_loss), "ms_per_step": ms, "rays_per_sec": n / (ms * 1e-3), "survivors_M": int(out["weights"].numel()),
             "mask_cache_occupied_frac": float(m.mask_cache.mask.float().mean()), "steps": args.steps, "loss": float(loss), "psnr": float(psnr)}
 
 
@@ -98,6 +99,8 @@ def main():
     ap.add_argument("--grid", type=int, default=0)
     ap.add_argument("--fused", type=int, default=1)
     ap.add_argument("--overlap", type=int, default=1)
+    ap.add_argument("--native", type=int, default=1, help="0: the op-by-op fused step (four autograd nodes issued from Python) instead of "
+                    "native_step.VoxGOStep (one node, three C calls) -- the same kernels and bits")
     ap.add_argument("--phase", default="both", help="dcvgo: dense | masked | both TV phases")
     ap.add_argument("--lazy-loss", type=int, default=0, help="train_iteration(return_tensors=True): no host read of loss / psnr per step "
                     "(the reference reads psnr.item() every step; a caller that logs every N steps need not)")
