@@ -259,12 +259,14 @@ int ugrid_rgbnet_train_backward(const float *g_logits, const float *feat, const 
                                 float *g_b2, float *scratch, ugrid_stream_t stream);
 
 /* NEW (no reference counterpart; replaces the elementwise chain of FourierGrid_model.py:631-635 / dvgo.py:352-357): the rgbnet's
- * input rows [k0 | viewdir | sin(viewdir * viewfreq) | cos(viewdir * viewfreq)] of the m surviving samples in ONE launch.
+ * input rows [k0 | viewdir | sin(viewdir * viewfreq) | cos(viewdir * viewfreq)] of the m surviving samples.
  * k0 [m, n_k0] (NULL with n_k0 = 0: only the view embedding rows), viewdirs [n_rays, 3], viewfreq [pe] (2^k), ray_id [m] (NULL:
  * row i uses viewdirs[i]), out [m, n_k0 + 3 + 6 pe].  Column order is torch's cat([viewdirs, e.sin(), e.cos()]) with
- * e = (viewdirs[..., None] * viewfreq).flatten(-2).  sinf / cosf of the same fp32 product torch forms. */
-int ugrid_rgbnet_features(const float *k0, int32_t n_k0, const float *viewdirs, const float *viewfreq, int32_t pe,
-                          const int64_t *ray_id, int64_t m, float *out, ugrid_stream_t stream);
+ * e = (viewdirs[..., None] * viewfreq).flatten(-2).  sinf / cosf of the same fp32 product torch forms.
+ * ray_rows: scratch [n_rays, 3 + 6 pe] or NULL.  With it (and ray_id, and m >= 2 n_rays) the embedding is formed once per ray and
+ * gathered (two launches, the same values); without it every output element evaluates its own sine / cosine (one launch). */
+int ugrid_rgbnet_features(const float *k0, int32_t n_k0, const float *viewdirs, int64_t n_rays, const float *viewfreq, int32_t pe,
+                          const int64_t *ray_id, int64_t m, float *ray_rows, float *out, ugrid_stream_t stream);
 
 /* NEW (no reference counterpart; training tail): sigmoid + per-ray compositing + the loss of run_train.py:254-279 in
  * one pass, and its derivative -- replaces FourierGrid_model.py:636-647 (sigmoid, weights * rgb, segment_coo, background)

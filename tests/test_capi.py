@@ -87,7 +87,8 @@ def test_voxgo_step_struct_mirror_matches_the_header(lib_path):
     s.C, s.pe, s.width, s.n_rays, s.M1, s.M2 = 12, 4, 128, 8192, 1000, 130
     al = lambda n: (n + 63) & ~63
     K = 12 + 27
-    assert lib.ugrid_voxgo_step_ws_floats(ctypes.addressof(s)) == al(3000) + 4 * al(1000) + al(390) + al(130 * 12) + al(130 * K) + 2 * al(130 * 128)
+    assert lib.ugrid_voxgo_step_ws_floats(ctypes.addressof(s)) == al(3000) + 4 * al(1000) + al(390) + al(130 * 12) + al(130 * K) + 2 * al(130 * 128) \
+        + al(8192 * 27)
     assert lib.ugrid_voxgo_step_bwd_ws_floats(ctypes.addressof(s)) == al(390) + 2 * al(130) + al(8192) + al(130 * 12) + al(1000) \
         + al(lib.ugrid_rgbnet_train_scratch_floats(130))
     # entry points refuse what they cannot run, before touching the device

@@ -548,13 +548,14 @@ def test_fused_rgbnet_matches_torch_linear_layers(M, C, E, W):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,M,C,pe", [(8192, 100000, 12, 4), (77, 1000, 9, 4), (5, 0, 12, 4), (300, 4097, 3, 8), (64, 500, 0, 4),
-                                      (1, 1, 12, 0), (900, None, 12, 4)])
+                                      (1, 1, 12, 0), (900, None, 12, 4), (900, 1000, 12, 4)])
 def test_rgbnet_features_equals_the_torch_chain(N, M, C, pe):
     """ops.rgbnet_features (one kernel) vs the reference's chain (FourierGrid_model.py:631-635): the k0 and viewdir columns are
     copies (bit-equal); the sin / cos columns are sinf / cosf of the same fp32 product, within 1 ulp-of-one of torch's device
     sin / cos (the two are built from different releases of the device math library, so the last bit may differ).  M = 0, no
     k0 columns (embedding rows only), pe = 0 and ray_id = None (one row per ray) included; then the same rows fed to
-    FusedRgbnet as a ViewRows give the logits and gradients of the explicit-embedding call bit for bit."""
+    FusedRgbnet as a ViewRows give the logits and gradients of the explicit-embedding call bit for bit.  Cases with at least two
+    samples per ray take the per-ray embedding + gather (two launches), the others the one-pass kernel: the same values."""
     from unboundednerfpytorch_amd import ops
     g = torch.Generator(device="cuda").manual_seed(N + 3 * pe)
     viewdirs = torch.nn.functional.normalize(torch.randn(N, 3, device="cuda", generator=g), dim=-1)

@@ -142,7 +142,7 @@ _SIGNATURES = {
     "ugrid_total_variation_add_grad_cl_touch": (_I, [_P, _P, _F, _F, _F, _L, _L, _L, _L, _L, _P, _P]),
     "ugrid_masked_adam_upd_touch": (_I, [_P, _P, _P, _P, _L, _I, _F, _F, _F, _F, _P, _P]),
     "ugrid_tv_adam_dense_cl_touch": (_I, [_P, _P, _P, _P, _P, _F, _F, _F, _L, _L, _L, _L, _L, _I, _F, _F, _F, _F, _I, _P, _P]),
-    "ugrid_rgbnet_features": (_I, [_P, _I, _P, _P, _I, _P, _L, _P, _P]),
+    "ugrid_rgbnet_features": (_I, [_P, _I, _P, _L, _P, _I, _P, _L, _P, _P, _P]),
     "ugrid_voxgo_step_sizeof": (_L, []),
     "ugrid_voxgo_step_ws_floats": (_L, [_P]),
     "ugrid_voxgo_step_bwd_ws_floats": (_L, [_P]),

@@ -61,7 +61,7 @@ static inline int64_t ug_al(int64_t floats) { return (floats + 63) & ~(int64_t)6
 struct ug_step_ws {      // forward workspace: what the backward needs again, and the rgbnet's input
   float *pts1, *dens1, *w1, *T1;
   int32_t *pos2;
-  float *pts2, *k0, *feat, *h1, *h2;
+  float *pts2, *k0, *feat, *h1, *h2, *ray_rows;
   int64_t total;
 };
 struct ug_step_ws_bwd {
@@ -77,6 +77,7 @@ static ug_step_ws ug_step_layout(const ugrid_voxgo_step *s) {
   w.pts1 = take(3 * M1); w.dens1 = take(M1); w.w1 = take(M1); w.T1 = take(M1);
   w.pos2 = (int32_t *)take(M1);
   w.pts2 = take(3 * M2); w.k0 = take(M2 * s->C); w.feat = take(M2 * K); w.h1 = take(M2 * s->width); w.h2 = take(M2 * s->width);
+  w.ray_rows = take(s->n_rays * (3 + 6 * s->pe));      // the view embedding per ray (ugrid_rgbnet_features' scratch)
   w.total = o;
   return w;
 }
@@ -145,7 +146,7 @@ extern "C" int ugrid_voxgo_step_forward(const ugrid_voxgo_step *s, ugrid_stream_
   rc = (s->k0_channels_last ? ugrid_grid_query_cl : ugrid_grid_query)(s->k0_grid, 1, s->C, s->kX, s->kY, s->kZ, w.pts2, s->k0_xyz_min,
                                                                      s->k0_xyz_max, 0, M2, w.k0, st);
   if (rc) return rc;
-  rc = ugrid_rgbnet_features(w.k0, s->C, s->viewdirs, s->viewfreq, s->pe, s->ray_id2, M2, w.feat, st);
+  rc = ugrid_rgbnet_features(w.k0, s->C, s->viewdirs, R, s->viewfreq, s->pe, s->ray_id2, M2, w.ray_rows, w.feat, st);
   if (rc) return rc;
   rc = ugrid_rgbnet_train_forward(w.feat, M2, K, s->w0, s->b0, s->w1, s->b1, s->w2, s->b2, s->width, w.h1, w.h2, s->logits, st);
   if (rc) return rc;

@@ -280,18 +280,40 @@ k_rgbnet_features(const float *__restrict__ k0, int C, const float *__restrict__
   out[idx] = is_cos ? cosf(x) : sinf(x);
 }
 
-extern "C" int ugrid_rgbnet_features(const float *k0, int32_t n_k0, const float *viewdirs, const float *viewfreq, int32_t pe,
-                                     const int64_t *ray_id, int64_t m, float *out, ugrid_stream_t st) {
-  if (n_k0 < 0 || pe < 0 || m < 0) return (int)hipErrorInvalidValue;
-  const int64_t total = m * (n_k0 + 3 + 6 * pe);
+// out[m] = [k0[m] | ray_rows[ray_id[m]]]: the view embedding formed once per RAY (k_rgbnet_features over the rays) and gathered --
+// a ray's ~15 surviving samples share its 24 sines and cosines, which were most of the one-pass kernel's time
+template <typename IDX>
+__global__ void __launch_bounds__(256)
+k_rgbnet_rows(const float *__restrict__ k0, int C, const float *__restrict__ ray_rows, int E, const int64_t *__restrict__ ray_id,
+              int64_t total, float *__restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int K = C + E;
+  const int64_t m = (int64_t)((IDX)idx / (IDX)K);
+  const int j = (int)(idx - m * K);
+  out[idx] = j < C ? k0[m * C + j] : ray_rows[ray_id[m] * E + (j - C)];
+}
+
+extern "C" int ugrid_rgbnet_features(const float *k0, int32_t n_k0, const float *viewdirs, int64_t n_rays, const float *viewfreq, int32_t pe,
+                                     const int64_t *ray_id, int64_t m, float *ray_rows, float *out, ugrid_stream_t st) {
+  if (n_k0 < 0 || pe < 0 || m < 0 || n_rays < 0) return (int)hipErrorInvalidValue;
+  const int E = 3 + 6 * pe;
+  const int64_t total = m * (n_k0 + E);
   if (total == 0) return 0;                                  // (no samples: empty arrays have no address)
   if ((n_k0 > 0 && !k0) || (pe > 0 && !viewfreq) || !viewdirs || !out) return (int)hipErrorInvalidValue;
-  if (total < ((int64_t)1 << 32))
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rgbnet_features<uint32_t>), dim3(ug_blocks(total, 256)), dim3(256), 0, ST(st), k0, n_k0, viewdirs,
-                       viewfreq, pe, ray_id, total, out);
-  else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_rgbnet_features<uint64_t>), dim3(ug_blocks(total, 256)), dim3(256), 0, ST(st), k0, n_k0, viewdirs,
-                       viewfreq, pe, ray_id, total, out);
+#define UG_FEAT(KERNEL, N, ...)                                                                                                     \
+  if ((N) < ((int64_t)1 << 32))                                                                                                     \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<uint32_t>), dim3(ug_blocks((N), 256)), dim3(256), 0, ST(st), __VA_ARGS__);            \
+  else                                                                                                                              \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<uint64_t>), dim3(ug_blocks((N), 256)), dim3(256), 0, ST(st), __VA_ARGS__);
+  if (ray_id && ray_rows && n_rays > 0 && m >= 2 * n_rays) {
+    const int64_t per_ray = n_rays * E;
+    UG_FEAT(k_rgbnet_features, per_ray, nullptr, 0, viewdirs, viewfreq, pe, nullptr, per_ray, ray_rows)
+    UG_FEAT(k_rgbnet_rows, total, k0, n_k0, ray_rows, E, ray_id, total, out)
+  } else {
+    UG_FEAT(k_rgbnet_features, total, k0, n_k0, viewdirs, viewfreq, pe, ray_id, total, out)
+  }
+#undef UG_FEAT
   UG_LAUNCH_CHECK();
   return 0;
 }

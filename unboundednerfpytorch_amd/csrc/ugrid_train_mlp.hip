@@ -194,29 +194,43 @@ k_wgrad(const float *__restrict__ dY, int ldd, int n_out, const float *__restric
   }
 }
 
-// out[e] = sum over slabs (ascending) of partial[slab][e]; 16 slabs are fetched per round (independent loads), then added
-// in order -- a fixed summation order, not a serial chain of load latencies
-// (weights and biases of a layer in ONE launch: elements [0, n_w) are the weight tile, [n_w, n_w + n_b) the bias -- each with its
-// own partial array and stride; at M ~ 1e5 the six separate reductions of a backward were 9 us of launch latency apiece)
-__global__ void __launch_bounds__(64)
+// out[e] = sum over slabs of partial[slab][e] in a FIXED two-level order: the slabs are cut into 16 consecutive groups, a thread
+// adds its group's slabs in ascending order (16 independent loads per round), then the 16 group sums are added in ascending order.
+// A workgroup = 16 elements x 16 groups: ~1000 workgroups for a 128 x 128 tile (one thread per element and a serial walk over 256
+// slabs left one wave per CU waiting out 16 dependent rounds of loads: 18 us per layer, three times per backward).
+// Weights and biases of a layer in ONE launch: elements [0, n_w) are the weight tile, [n_w, n_w + n_b) the bias -- each with its
+// own partial array and stride.
+__global__ void __launch_bounds__(256)
 k_wgrad_reduce(const float *__restrict__ partial_w, const float *__restrict__ partial_b, int n_slabs, int n_w, int n_b,
                float *__restrict__ out_w, float *__restrict__ out_b) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n_w + n_b) return;
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, grp = threadIdx.x >> 4;
+  int e = blockIdx.x * 16 + el;
+  const bool on = e < n_w + n_b;
   const bool is_b = e >= n_w;
   const float *__restrict__ partial = is_b ? partial_b : partial_w;
   float *__restrict__ out = is_b ? out_b : out_w;
   const int n = is_b ? n_b : n_w;
   if (is_b) e -= n_w;
+  const int per = (n_slabs + 15) >> 4, s_lo = grp * per, s_hi = s_lo + per < n_slabs ? s_lo + per : n_slabs;
   float acc = 0.f;
-  for (int b0 = 0; b0 < n_slabs; b0 += 16) {
-    float v[16];
+  if (on) {
+    for (int b0 = s_lo; b0 < s_hi; b0 += 16) {
+      float v[16];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) v[u] = (b0 + u < n_slabs) ? partial[(int64_t)(b0 + u) * n + e] : 0.f;
+      for (int u = 0; u < 16; ++u) v[u] = (b0 + u < s_hi) ? partial[(int64_t)(b0 + u) * n + e] : 0.f;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc += v[u];
+      for (int u = 0; u < 16; ++u) acc += v[u];
+    }
   }
-  out[e] = acc;
+  red[grp][el] = acc;
+  __syncthreads();
+  if (grp == 0 && on) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][el];
+    out[e] = t;
+  }
 }
 
 // Y[s][c] = (G[s][c] > 0) ? sum_{j < K} X[s][j] * W[j][c] : 0 for K <= 4 (the gradient of the 3-channel logits pushed through the
@@ -304,7 +318,153 @@ static inline int ug_wgrad_launch(const float *dY, int ldd, int n_out, const flo
   else if (K <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<2>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<4>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs);
   const int n_w = n_out * K, n_b = db ? n_out : 0;
-  hipLaunchKernelGGL(k_wgrad_reduce, dim3((n_w + n_b + 63) / 64), dim3(64), 0, st, pw, pb, n_slabs, n_w, n_b, dW, db);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((n_w + n_b + 15) / 16), dim3(256), 0, st, pw, pb, n_slabs, n_w, n_b, dW, db);
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ----------------------------------------------------------------------------------------------
+// The 3-channel last layer without the matrix pipe.  Its three passes through k_lin / k_wgrad pad the 3 logits to a 32-wide MFMA
+// tile (10 x the arithmetic) and read the [M,W] activations h2 three times; as VALU kernels they are streams over h2:
+//   k_l3_fwd   logits[s][c] = sum_k h2[s][k] W3[c][k] + b3[c]                              reads h2 once
+//   k_l3_bwd   dW3[c][k] = sum_s g[s][c] h2[s][k],  db3[c] = sum_s g[s][c],
+//              g_h2[s][k] = h2[s][k] > 0 ? g[s][0] W3[0][k] + g[s][1] W3[1][k] + g[s][2] W3[2][k] : 0   (k_lin_smallk's expression)
+//                                                                                          reads h2 once, writes g_h2
+// Both need W % 4 == 0 (float4 columns); the weight gradient is a fixed-order sum of per-block partials (k_wgrad_reduce).
+// ----------------------------------------------------------------------------------------------
+#define UG_L3_MAX_BLOCKS 1024
+template <int LPR>      // lanes per row: the power of two >= W / 4
+__global__ void __launch_bounds__(256)
+k_l3_fwd(const float *__restrict__ h2, int64_t M, int W, const float *__restrict__ w3, const float *__restrict__ b3,
+         float *__restrict__ logits) {
+  constexpr int RPW = UG_WAVE / LPR;                 // rows per wave and iteration
+  const int lane = ug_lane(), sub = lane % LPR, rw = lane / LPR;
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const bool col_ok = 4 * sub < W;
+  float4 wv[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) wv[c] = col_ok ? *(const float4 *)(w3 + (int64_t)c * W + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float bias[3] = {b3[0], b3[1], b3[2]};
+  for (int64_t s0 = wave * RPW; s0 < M; s0 += n_waves * RPW) {
+    const int64_t s = s0 + rw;
+    const bool on = s < M && col_ok;
+    const float4 h = on ? *(const float4 *)(h2 + s * W + 4 * sub) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float r[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      r[c] = h.x * wv[c].x;
+      r[c] += h.y * wv[c].y;
+      r[c] += h.z * wv[c].z;
+      r[c] += h.w * wv[c].w;
+    }
+#pragma unroll
+    for (int o = LPR >> 1; o > 0; o >>= 1)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) r[c] += __shfl_xor(r[c], o, UG_WAVE);
+    if (sub == 0 && s < M) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) logits[3 * s + c] = r[c] + bias[c];
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+k_l3_bwd(const float *__restrict__ g, const float *__restrict__ h2, int64_t M, int W, const float *__restrict__ w3,
+         float *__restrict__ g_h2, float *__restrict__ partial_w, float *__restrict__ partial_b, int rows_per_block) {
+  __shared__ float red[3840];                        // [row groups][3 W + 3]: (1024 / W) * (3 W + 3) <= 3840 floats
+  const int W4 = W >> 2, RPI = 256 / W4;             // float4 columns per row; rows per iteration
+  const int t = threadIdx.x, col4 = t % W4, grp = t / W4;
+  const bool live = grp < RPI;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+  float4 wv[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) wv[c] = *(const float4 *)(w3 + (int64_t)c * W + 4 * col4);
+  float acc[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  float bs[3] = {0.f, 0.f, 0.f};
+  if (live) {
+    for (int64_t s = r0 + grp; s < r1; s += RPI) {
+      const float g0 = g[3 * s], g1 = g[3 * s + 1], g2 = g[3 * s + 2];
+      const float4 h = *(const float4 *)(h2 + s * W + 4 * col4);
+      const float hv[4] = {h.x, h.y, h.z, h.w};
+      const float w0[4] = {wv[0].x, wv[0].y, wv[0].z, wv[0].w}, w1[4] = {wv[1].x, wv[1].y, wv[1].z, wv[1].w},
+                  w2[4] = {wv[2].x, wv[2].y, wv[2].z, wv[2].w};
+      float o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc[0][q] += g0 * hv[q];
+        acc[1][q] += g1 * hv[q];
+        acc[2][q] += g2 * hv[q];
+        float r = 0.f;
+        r += g0 * w0[q];
+        r += g1 * w1[q];
+        r += g2 * w2[q];
+        o[q] = hv[q] > 0.f ? r : 0.f;
+      }
+      *(float4 *)(g_h2 + s * W + 4 * col4) = make_float4(o[0], o[1], o[2], o[3]);
+      if (col4 == 0) {
+        bs[0] += g0;
+        bs[1] += g1;
+        bs[2] += g2;
+      }
+    }
+    const int stride = 3 * W + 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) red[grp * stride + c * W + 4 * col4 + q] = acc[c][q];
+      if (col4 == 0) red[grp * stride + 3 * W + c] = bs[c];
+    }
+  }
+  __syncthreads();
+  const int stride = 3 * W + 3;
+  for (int e = t; e < stride; e += 256) {
+    float v = 0.f;
+    for (int gq = 0; gq < RPI; ++gq) v += red[gq * stride + e];      // fixed order over the row groups
+    if (e < 3 * W) partial_w[(int64_t)blockIdx.x * 3 * W + e] = v;
+    else partial_b[(int64_t)blockIdx.x * 3 + (e - 3 * W)] = v;
+  }
+}
+
+static inline bool ug_l3_ok(int W, const void *a, const void *b) {
+  return W >= 4 && W <= 128 && (W & 3) == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+}
+
+static int ug_l3_forward(const float *h2, int64_t M, int W, const float *w3, const float *b3, float *logits, hipStream_t st) {
+  if (M <= 0) return 0;
+  const int w4 = W >> 2;
+  const int lpr = w4 <= 1 ? 1 : w4 <= 2 ? 2 : w4 <= 4 ? 4 : w4 <= 8 ? 8 : w4 <= 16 ? 16 : 32;
+  const int64_t waves = (M + (UG_WAVE / lpr) - 1) / (UG_WAVE / lpr);
+  int64_t blocks = (waves + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+#define UG_L3F(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_l3_fwd<L>), dim3((unsigned)blocks), dim3(256), 0, st, h2, M, W, w3, b3, logits)
+  switch (lpr) {
+    case 1: UG_L3F(1); break;
+    case 2: UG_L3F(2); break;
+    case 4: UG_L3F(4); break;
+    case 8: UG_L3F(8); break;
+    case 16: UG_L3F(16); break;
+    default: UG_L3F(32); break;
+  }
+#undef UG_L3F
+  UG_LAUNCH_CHECK();
+  return 0;
+}
+
+// partial: UG_L3_MAX_BLOCKS * (3 W + 3) floats of scratch
+static int ug_l3_backward(const float *g, const float *h2, int64_t M, int W, const float *w3, float *g_h2, float *dW, float *db,
+                          float *partial, hipStream_t st) {
+  if (M <= 0) {
+    UG_HIP(hipMemsetAsync(dW, 0, sizeof(float) * 3 * (size_t)W, st));
+    UG_HIP(hipMemsetAsync(db, 0, sizeof(float) * 3, st));
+    return 0;
+  }
+  const int rpi = 256 / (W >> 2);
+  int64_t rows = 8 * (int64_t)rpi;                                       // >= 8 iterations per block
+  if ((M + rows - 1) / rows > UG_L3_MAX_BLOCKS) rows = ((M + UG_L3_MAX_BLOCKS - 1) / UG_L3_MAX_BLOCKS + rpi - 1) / rpi * rpi;
+  const int nb = (int)((M + rows - 1) / rows);
+  float *pw = partial, *pb = partial + (size_t)UG_L3_MAX_BLOCKS * 3 * W;
+  hipLaunchKernelGGL(k_l3_bwd, dim3((unsigned)nb), dim3(256), 0, st, g, h2, M, W, w3, g_h2, pw, pb, (int)rows);
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((3 * W + 3 + 15) / 16), dim3(256), 0, st, pw, pb, nb, 3 * W, 3, dW, db);
   UG_LAUNCH_CHECK();
   return 0;
 }
@@ -325,6 +485,7 @@ extern "C" int ugrid_rgbnet_train_forward(const float *feat, int64_t M, int32_t 
   if (rc) return rc;
   rc = ug_lin_launch(h1, M, W, W, w1, W, W, 0, b1, 1, nullptr, 0, h2, W, ST(s));
   if (rc) return rc;
+  if (ug_l3_ok(W, h2, w2)) return ug_l3_forward(h2, M, W, w2, b2, logits, ST(s));
   return ug_lin_launch(h2, M, W, W, w2, W, 3, 0, b2, 0, nullptr, 0, logits, 3, ST(s));
 }
 
@@ -336,10 +497,16 @@ extern "C" int ugrid_rgbnet_train_backward(const float *g_logits, const float *f
   const int W = width;
   float *g_h2 = scratch, *g_h1 = scratch + (size_t)M * 128;         // [M,W] each (room for W = 128)
   float *part = scratch + (size_t)2 * M * 128;                      // slab partials of the weight gradients
-  int rc = ug_wgrad_launch(g_logits, 3, 3, h2, W, W, M, g_w2, g_b2, part, ST(s));                            // dW3, db3
-  if (rc) return rc;
-  rc = ug_lin_launch(g_logits, M, 3, 3, w2, W, W, 1, nullptr, 0, h2, W, g_h2, W, ST(s));                      // dH2 = dL . W3, ReLU mask
-  if (rc) return rc;
+  int rc;
+  if (ug_l3_ok(W, h2, w2) && ((uintptr_t)g_h2 & 15) == 0) {
+    rc = ug_l3_backward(g_logits, h2, M, W, w2, g_h2, g_w2, g_b2, part, ST(s));                               // dW3, db3, dH2: one pass over h2
+    if (rc) return rc;
+  } else {
+    rc = ug_wgrad_launch(g_logits, 3, 3, h2, W, W, M, g_w2, g_b2, part, ST(s));                              // dW3, db3
+    if (rc) return rc;
+    rc = ug_lin_launch(g_logits, M, 3, 3, w2, W, W, 1, nullptr, 0, h2, W, g_h2, W, ST(s));                    // dH2 = dL . W3, ReLU mask
+    if (rc) return rc;
+  }
   rc = ug_wgrad_launch(g_h2, W, W, h1, W, W, M, g_w1, g_b1, part, ST(s));                                     // dW2, db2
   if (rc) return rc;
   rc = ug_lin_launch(g_h2, M, W, W, w1, W, W, 1, nullptr, 0, h1, W, g_h1, W, ST(s));                          // dH1 = dH2 . W2, ReLU mask

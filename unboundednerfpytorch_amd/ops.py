@@ -216,10 +216,13 @@ def rgbnet_features(k0, viewdirs, viewfreq, ray_id):
         raise ValueError("rgbnet_features: k0 has %d rows, the samples are %d" % (k0.shape[0], M))
     pe = viewfreq.numel()
     out = torch.empty(M, C + 3 + 6 * pe, device=viewdirs.device)
+    N = viewdirs.shape[0]
+    # many samples per ray: the embedding is formed once per ray and gathered (the library decides; same values either way)
+    ray_rows = torch.empty(N, 3 + 6 * pe, device=viewdirs.device) if (ray_id is not None and M >= 2 * N) else None
     with _lib.guard(out.device):
-        _lib.check(_L.ugrid_rgbnet_features(_lib.ptr(k0) if C else None, C, _lib.ptr(viewdirs), _lib.ptr(viewfreq) if pe else None, pe,
-                                            _lib.ptr(ray_id) if ray_id is not None else None, M, _lib.ptr(out), _lib.stream_of(out)),
-                   "rgbnet_features")
+        _lib.check(_L.ugrid_rgbnet_features(_lib.ptr(k0) if C else None, C, _lib.ptr(viewdirs), N, _lib.ptr(viewfreq) if pe else None, pe,
+                                            _lib.ptr(ray_id) if ray_id is not None else None, M, _lib.ptr(ray_rows), _lib.ptr(out),
+                                            _lib.stream_of(out)), "rgbnet_features")
     return out
 
 
