@@ -499,29 +499,34 @@ int ugrid_train_sample_compact_vox(int64_t n_rays, int32_t slots_per_ray, float 
                                    uint8_t *inner2, ugrid_stream_t stream);
 
 /* NEW (round 5; no reference counterpart): ONE training step's forward and backward of the reference's two dense-grid models
- * issued natively -- DirectVoxGO.forward (dvgo.py:332-425) / DirectContractedVoxGO.forward (dcvgo.py:265-384) with the default
+ * issued natively -- DirectVoxGO.forward (dvgo.py:332-425) / DirectContractedVoxGO.forward (dcvgo.py:265-384) /
+ * FourierGridModel.forward (FourierGrid_model.py:554-672) with the default
  * 3 x `width` rgbnet (rgbnet_direct), the loss of run_train.py:254-279 and the whole backward, as three calls instead of the
  * ~30 Python-issued launches of the op-by-op step (voxgo_model.py; a 1.2 ms step of which 0.8 ms is GPU time).  The calls run
  * the SAME kernels on the SAME sizes in the same order as that step: results are bit-identical to it.
  *
- *   ugrid_voxgo_step_sample    ugrid_train_sample_dvgo / _dcvgo, the prefix sums of the two per-ray counts, and the step's ONE
+ *   ugrid_voxgo_step_sample    ugrid_train_sample_dvgo / _dcvgo / ugrid_train_sample, the prefix sums of the two per-ray counts, and the step's ONE
  *                              host read: M1 (stage-1 samples the backward walks) and M2 (samples that reach the rgbnet) are
  *                              written into the struct.  Synchronises `stream`.
  *   (the caller sizes the per-sample buffers: ws = ugrid_voxgo_step_ws_floats floats; the visible outputs below)
- *   ugrid_voxgo_step_forward   ugrid_train_sample_compact_vox, the k0 lookup, ugrid_rgbnet_features,
+ *   ugrid_voxgo_step_forward   ugrid_train_sample_compact(_vox), the k0 lookup, ugrid_rgbnet_features,
  *                              ugrid_rgbnet_train_forward, ugrid_render_loss -> out2 = {loss, mse}, rgb_marched, logits, ...
  *   ugrid_voxgo_step_backward  ugrid_render_loss_backward, ugrid_rgbnet_train_backward (g_w0 .. g_b2 overwritten), the k0
  *                              lookup's scatter into grad_k0_grid (+ touch bitmap when given: channel-last only), and
  *                              ugrid_train_sample_backward + the density scatter into grad_density_grid.  Both grid gradients
  *                              are ADDED to (the caller passes zeros for a fresh gradient).  ws_bwd: ugrid_voxgo_step_bwd_ws_floats.
  * Device pointers unless marked HOST.  mode 0: DirectVoxGO (near / far / stepdist / slots used), 1: DirectContractedVoxGO
- * (t_table[slots] / scene_center / scene_radius / bg_len / norm_l2 / dist_thres used).  bg: [n_rays,3] or NULL.  coef8: see
+ * (t_table[slots] / scene_center / scene_radius / bg_len / norm_l2 / dist_thres used), 2: FourierGridModel
+ * (FourierGrid_model.py:509-672: ugrid_train_sample over the Fourier density grid, no mask cache; t_table / scene_center /
+ * scene_radius / bg_len / norm_l2 and the two grids' levels used).  bg: [n_rays,3] or NULL.  coef8: see
  * ugrid_render_loss.  inner2 may be NULL.  ugrid_voxgo_step_sizeof = sizeof(ugrid_voxgo_step), for bindings to check their mirror. */
 typedef struct ugrid_voxgo_step {
   int32_t mode;
-  int32_t k0_channels_last; /* k0_grid / grad_k0_grid stored [X][Y][Z][C] */
-  int32_t X, Y, Z;          /* density grid [1,1,X,Y,Z] (canonical) */
-  int32_t kX, kY, kZ, C;    /* k0 grid [1,C,kX,kY,kZ] */
+  int32_t k0_channels_last; /* k0_grid / grad_k0_grid stored [P][X][Y][Z][C] */
+  int32_t P, freq_num;      /* density grid levels and its fourier_freq_num (mode 2: P = 1 + 2 freq_num; modes 0, 1: 1 and 0) */
+  int32_t kP, k0_freq_num;  /* the same for the k0 grid */
+  int32_t X, Y, Z;          /* density grid [P,1,X,Y,Z] (canonical) */
+  int32_t kX, kY, kZ, C;    /* k0 grid [kP,C,kX,kY,kZ] */
   int32_t pe, width;        /* viewbase_pe; rgbnet width (<= 128; C + 3 + 6 pe <= 128) */
   int32_t slots;            /* scratch slots per ray (mode 0: >= the longest ray's step count; mode 1: the table length) */
   int32_t norm_l2;
@@ -565,6 +570,11 @@ int64_t ugrid_voxgo_step_bwd_ws_floats(const ugrid_voxgo_step *s);
 int ugrid_voxgo_step_sample(ugrid_voxgo_step *s, ugrid_stream_t stream);
 int ugrid_voxgo_step_forward(const ugrid_voxgo_step *s, ugrid_stream_t stream);
 int ugrid_voxgo_step_backward(const ugrid_voxgo_step *s, ugrid_stream_t stream);
+/* ugrid_voxgo_step_backward in two halves, for a caller that starts the k0 grid's update (the step's largest pass) beside the
+ * rest of the backward: _k0 = loss, rgbnet and the k0 scatter (grad_k0_grid complete on the stream; grad_density_grid not needed
+ * yet), _density = the sampling's backward + the density scatter.  _backward = the one after the other. */
+int ugrid_voxgo_step_backward_k0(const ugrid_voxgo_step *s, ugrid_stream_t stream);
+int ugrid_voxgo_step_backward_density(const ugrid_voxgo_step *s, ugrid_stream_t stream);
 
 /* 1 when ugrid_render_shade has an rgbnet instantiation (depth 3, width 128) for this
  * (fourier_freq_num, k0 channels, viewbase_pe) triple, else 0 (they return hipErrorNotSupported for it). */

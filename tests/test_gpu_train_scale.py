@@ -323,6 +323,69 @@ def test_fused_render_loss_equals_the_composed_tail(rand_bkgd):
             assert int(odd.sum()) <= 1024, (k, int(odd.sum()))
 
 
+@pytest.mark.parametrize("rand_bkgd", [False, True])
+def test_native_step_equals_the_op_by_op_step(rand_bkgd):
+    """FourierGridModel's training forward + loss as native_step.VoxGOStep (mode 'fourier': ONE autograd node, the C entry points
+    ugrid_voxgo_step_*) against the op-by-op ops of the same module (TrainSample, GridQuery, FusedRgbnet, RenderLoss; native_step =
+    False) at P = 9, G = 100: the same kernels, sizes and order -- the forward's arrays, loss, mse and the rgbnet's gradients bit for
+    bit, the grid gradients up to the order of the scatters' atomic adds; then four train_iteration steps with the k0 update started
+    from INSIDE the node's backward (pack['k0_grad_ready']) against the hook-driven op-by-op steps."""
+    import copy
+    import bench_train_step as bts
+    from unboundednerfpytorch_amd import ops, train_step as ts
+    from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
+    dev = torch.device("cuda", 0)
+    m_a = build(dev)
+    m_b = copy.deepcopy(m_a)
+    m_b.native_step = False
+    cfg = dict(bts.TRUCK_CFG)
+    cfg.update(weight_nearclip=0.3, weight_distortion=0.01, weight_rgbper=0.01, weight_entropy_last=0.001)
+    o, d, v, rgb = bts.random_rays(3000, dev, seed=8)
+    kw = dict(stepsize=0.5, rand_bkgd=rand_bkgd)
+    coef = ops.loss_coefficients(cfg, len(o), m_a.sample_table(0.5, dev).numel(), 0.2, 1)
+    outs = []
+    for m in (m_a, m_b):
+        torch.manual_seed(5)
+        out = m(o, d, v, global_step=1, is_train=True, fused_loss={"target": rgb, "coef": coef}, **kw)
+        out["loss"].backward()
+        outs.append((out, {k: p.grad.clone() for k, p in m.named_parameters()}))
+        m.zero_grad(set_to_none=True)
+    (oa, ga), (ob, gb) = outs
+    assert type(oa["loss"].grad_fn).__name__.startswith("VoxGOStep") and not type(ob["loss"].grad_fn).__name__.startswith("VoxGOStep")
+    assert torch.equal(oa.pop("loss_mse"), torch.stack([ob["loss"], ob["mse"]]).detach())
+    oa.pop("native")
+    assert set(oa) == set(ob), (sorted(oa), sorted(ob))
+    assert oa["weights"].numel() > 1000
+    for k in oa:
+        if torch.is_tensor(oa[k]):
+            assert torch.equal(oa[k].detach(), ob[k].detach()), k
+        else:
+            assert oa[k] == ob[k], k
+    for k in ga:
+        if "grid" in k:
+            scale = float(gb[k].abs().max())
+            assert float((ga[k] - gb[k]).abs().max()) <= 2e-6 * scale, (k, float((ga[k] - gb[k]).abs().max()), scale)
+        else:
+            assert torch.equal(ga[k], gb[k]), k
+    res = []
+    for m in (m_a, m_b):
+        torch.manual_seed(11)
+        opt = create_optimizer_or_freeze_model(m, bts.TRUCK_CFG, global_step=0)
+        losses = []
+        for s in (1, 2, 3, 4):
+            oo, dd, vv, tt = bts.random_rays(2048, dev, seed=30 + s)
+            losses.append(ts.train_iteration(m, opt, oo, dd, vv, tt, bts.TRUCK_CFG, s, kw, overlap_k0_update=True))
+            assert getattr(m.k0.grid, "_ug_pending", None) is not None       # the k0 update went to the side stream in both
+        sd = m.state_dict()
+        res.append((losses, {k: x.detach().clone() for k, x in sd.items() if x.dtype == torch.float32}))
+    assert res[0][0][0][0] == res[1][0][0][0]
+    np.testing.assert_allclose(np.array(res[0][0]), np.array(res[1][0]), rtol=2e-4)
+    for k in res[0][1]:
+        diff = (res[0][1][k] - res[1][1][k]).abs()
+        lr = 0.1 if "grid" in k else 1e-3
+        assert int((diff > 0.02 * lr).sum()) <= max(2, int(1e-4 * diff.numel())), (k, float(diff.max()))
+
+
 def test_k0_update_on_the_side_stream_gives_the_same_training():
     """train_iteration(overlap_k0_update=True): the k0 TV + Adam pass runs on a second stream beside the next forward's
     density march; parameters read through state_dict() (which waits for the pending update) after four steps equal those

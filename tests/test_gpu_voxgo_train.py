@@ -371,6 +371,7 @@ def test_native_step_equals_the_op_by_op_step_bit_for_bit(kind):
     assert oa["loss"].grad_fn is not None and type(oa["loss"].grad_fn).__name__.startswith("VoxGOStep"), type(oa["loss"].grad_fn)
     assert not type(ob["loss"].grad_fn).__name__.startswith("VoxGOStep")
     assert torch.equal(oa.pop("loss_mse"), torch.stack([ob["loss"], ob["mse"]]).detach())    # {loss, mse} for a one-copy read
+    oa.pop("native")
     assert set(oa) == set(ob), (sorted(oa), sorted(ob))
     for k in oa:
         if torch.is_tensor(oa[k]):

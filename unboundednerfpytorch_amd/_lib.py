@@ -67,6 +67,7 @@ class VoxgoStep(_c.Structure):
     """Mirror of `ugrid_voxgo_step` (include/ugrid_hip.h); tests/test_capi.py compares the field list with the header's"""
     _fields_ = [
         ("mode", _c.c_int32), ("k0_channels_last", _c.c_int32),
+        ("P", _c.c_int32), ("freq_num", _c.c_int32), ("kP", _c.c_int32), ("k0_freq_num", _c.c_int32),
         ("X", _c.c_int32), ("Y", _c.c_int32), ("Z", _c.c_int32),
         ("kX", _c.c_int32), ("kY", _c.c_int32), ("kZ", _c.c_int32), ("C", _c.c_int32),
         ("pe", _c.c_int32), ("width", _c.c_int32), ("slots", _c.c_int32), ("norm_l2", _c.c_int32),
@@ -149,6 +150,8 @@ _SIGNATURES = {
     "ugrid_voxgo_step_sample": (_I, [_P, _P]),
     "ugrid_voxgo_step_forward": (_I, [_P, _P]),
     "ugrid_voxgo_step_backward": (_I, [_P, _P]),
+    "ugrid_voxgo_step_backward_k0": (_I, [_P, _P]),
+    "ugrid_voxgo_step_backward_density": (_I, [_P, _P]),
     "ugrid_render_loss": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P]),
     "ugrid_render_loss_backward": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "ugrid_brick_bytes": (_L, [_I, _I, _I, _I, _I, _I]),

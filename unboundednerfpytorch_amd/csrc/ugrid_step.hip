@@ -98,7 +98,12 @@ extern "C" int64_t ugrid_voxgo_step_ws_floats(const ugrid_voxgo_step *s) { retur
 extern "C" int64_t ugrid_voxgo_step_bwd_ws_floats(const ugrid_voxgo_step *s) { return ug_step_layout_bwd(s).total; }
 
 static int ug_step_check(const ugrid_voxgo_step *s) {
-  if (!s || (s->mode != 0 && s->mode != 1) || s->n_rays <= 0 || s->slots <= 0 || s->C < 1 || s->pe < 0) return (int)hipErrorInvalidValue;
+  if (!s || s->mode < 0 || s->mode > 2 || s->n_rays <= 0 || s->slots <= 0 || s->C < 1 || s->pe < 0 || s->P < 1 || s->kP < 1 ||
+      s->freq_num < 0 || s->k0_freq_num < 0)
+    return (int)hipErrorInvalidValue;
+  if (s->mode != 2 && (s->P != 1 || s->freq_num != 0)) return (int)hipErrorInvalidValue;       // the dense-grid models' density grid
+  if (s->P != 1 + 2 * s->freq_num && !(s->P == 1 && s->freq_num == 0)) return (int)hipErrorInvalidValue;
+  if (s->kP != 1 + 2 * s->k0_freq_num && !(s->kP == 1 && s->k0_freq_num == 0)) return (int)hipErrorInvalidValue;
   if (s->width < 1 || s->width > 128 || s->C + 3 + 6 * s->pe > 128) return (int)hipErrorNotSupported;
   return 0;
 }
@@ -108,7 +113,11 @@ extern "C" int ugrid_voxgo_step_sample(ugrid_voxgo_step *s, ugrid_stream_t st) {
   if (rc) return rc;
   const int64_t R = s->n_rays;
   int32_t *c1 = s->counts, *c2 = s->counts + R;
-  if (s->mode == 1)
+  if (s->mode == 2)
+    rc = ugrid_train_sample(s->density_grid, s->P, s->X, s->Y, s->Z, s->freq_num, s->rays_o, s->rays_d, R, s->t_table, s->slots,
+                            s->scene_center, s->scene_radius, s->xyz_min, s->xyz_max, s->bg_len, s->norm_l2, s->act_shift, s->interval,
+                            s->thres, s->sc_pts, s->sc_density, s->sc_step, s->sc_w, s->sc_T, c1, c2, s->alphainv_last, st);
+  else if (s->mode == 1)
     rc = ugrid_train_sample_dcvgo(s->density_grid, s->X, s->Y, s->Z, s->rays_o, s->rays_d, R, s->t_table, s->slots, s->scene_center,
                                   s->scene_radius, s->xyz_min, s->xyz_max, s->bg_len, s->norm_l2, s->dist_thres, s->mask, s->mask_dims,
                                   s->mask_scale, s->mask_shift, s->act_shift, s->interval, s->thres, s->sc_pts, s->sc_density, s->sc_step,
@@ -136,15 +145,20 @@ extern "C" int ugrid_voxgo_step_forward(const ugrid_voxgo_step *s, ugrid_stream_
   const ug_step_ws w = ug_step_layout(s);
   const int64_t R = s->n_rays, M2 = s->M2;
   const int K = s->C + 3 + 6 * s->pe;
-  if (s->M1 > 0) {
+  if (s->M1 > 0 && s->mode == 2) {
+    rc = ugrid_train_sample_compact(R, s->slots, s->act_shift, s->interval, s->thres, s->sc_pts, s->sc_density, s->sc_step, s->sc_w, s->sc_T,
+                                    s->counts, s->offsets, s->counts + R, s->offsets + R, s->t_table, w.pts1, w.dens1, w.w1, w.T1, w.pos2,
+                                    w.pts2, s->density2, s->alpha2, s->weights2, s->ray_id2, s->step_id2, s->t2, st);
+    if (rc) return rc;
+  } else if (s->M1 > 0) {
     rc = ugrid_train_sample_compact_vox(R, s->slots, s->act_shift, s->interval, s->thres, s->sc_pts, s->sc_density, s->sc_step, s->sc_w,
                                         s->sc_T, s->counts, s->offsets, s->counts + R, s->offsets + R, s->mode == 1 ? s->t_table : nullptr,
                                         w.pts1, w.dens1, w.w1, w.T1, w.pos2, w.pts2, s->density2, s->alpha2, s->weights2, s->ray_id2,
                                         s->step_id2, s->t2, s->mode == 1 ? s->inner2 : nullptr, st);
     if (rc) return rc;
   }
-  rc = (s->k0_channels_last ? ugrid_grid_query_cl : ugrid_grid_query)(s->k0_grid, 1, s->C, s->kX, s->kY, s->kZ, w.pts2, s->k0_xyz_min,
-                                                                     s->k0_xyz_max, 0, M2, w.k0, st);
+  rc = (s->k0_channels_last ? ugrid_grid_query_cl : ugrid_grid_query)(s->k0_grid, s->kP, s->C, s->kX, s->kY, s->kZ, w.pts2, s->k0_xyz_min,
+                                                                     s->k0_xyz_max, s->k0_freq_num, M2, w.k0, st);
   if (rc) return rc;
   rc = ugrid_rgbnet_features(w.k0, s->C, s->viewdirs, R, s->viewfreq, s->pe, s->ray_id2, M2, w.ray_rows, w.feat, st);
   if (rc) return rc;
@@ -154,13 +168,14 @@ extern "C" int ugrid_voxgo_step_forward(const ugrid_voxgo_step *s, ugrid_stream_
                            s->rgb_marched, s->ray_tot, s->partial, s->out2, st);
 }
 
-extern "C" int ugrid_voxgo_step_backward(const ugrid_voxgo_step *s, ugrid_stream_t st) {
+// first half of the backward: everything up to the k0 grid's gradient (complete when this returns to the stream)
+extern "C" int ugrid_voxgo_step_backward_k0(const ugrid_voxgo_step *s, ugrid_stream_t st) {
   int rc = ug_step_check(s);
   if (rc) return rc;
-  if (!s->grad_loss || !s->ws_bwd || !s->grad_density_grid || !s->grad_k0_grid) return (int)hipErrorInvalidValue;
+  if (!s->grad_loss || !s->ws_bwd || !s->grad_k0_grid) return (int)hipErrorInvalidValue;
   const ug_step_ws w = ug_step_layout(s);
   const ug_step_ws_bwd b = ug_step_layout_bwd(s);
-  const int64_t R = s->n_rays, M1 = s->M1, M2 = s->M2;
+  const int64_t R = s->n_rays, M2 = s->M2;
   const int K = s->C + 3 + 6 * s->pe;
   rc = ugrid_render_loss_backward(s->logits, s->weights2, nullptr, s->t2, s->alphainv_last, s->bg, s->target, s->ray_id2, M2, R, s->coef8,
                                   s->seg, s->rgb_marched, s->ray_tot, s->grad_loss, b.g_logits, b.g_w, b.g_ainv, b.g_dens, st);
@@ -169,17 +184,28 @@ extern "C" int ugrid_voxgo_step_backward(const ugrid_voxgo_step *s, ugrid_stream
                                    s->g_w1, s->g_b1, s->g_w2, s->g_b2, b.rg, st);
   if (rc) return rc;
   if (s->k0_channels_last && s->touch)
-    rc = ugrid_grid_query_backward_cl_touch(b.g_k0, 1, s->C, s->kX, s->kY, s->kZ, w.pts2, s->k0_xyz_min, s->k0_xyz_max, 0, M2,
-                                            s->grad_k0_grid, s->touch, st);
-  else
-    rc = (s->k0_channels_last ? ugrid_grid_query_backward_cl : ugrid_grid_query_backward)(
-        b.g_k0, 1, s->C, s->kX, s->kY, s->kZ, w.pts2, s->k0_xyz_min, s->k0_xyz_max, 0, M2, s->grad_k0_grid, st);
+    return ugrid_grid_query_backward_cl_touch(b.g_k0, s->kP, s->C, s->kX, s->kY, s->kZ, w.pts2, s->k0_xyz_min, s->k0_xyz_max, s->k0_freq_num,
+                                              M2, s->grad_k0_grid, s->touch, st);
+  return (s->k0_channels_last ? ugrid_grid_query_backward_cl : ugrid_grid_query_backward)(
+      b.g_k0, s->kP, s->C, s->kX, s->kY, s->kZ, w.pts2, s->k0_xyz_min, s->k0_xyz_max, s->k0_freq_num, M2, s->grad_k0_grid, st);
+}
+
+// second half: the sampling's backward and the density grid's gradient (reads what the first half left in ws_bwd)
+extern "C" int ugrid_voxgo_step_backward_density(const ugrid_voxgo_step *s, ugrid_stream_t st) {
+  int rc = ug_step_check(s);
   if (rc) return rc;
-  if (M1 > 0) {
-    rc = ugrid_train_sample_backward(R, s->act_shift, s->interval, w.dens1, w.w1, w.T1, w.pos2, s->counts, s->offsets, s->alphainv_last,
-                                     b.g_w, b.g_ainv, b.g_dens, b.g1, st);
-    if (rc) return rc;
-    rc = ugrid_grid_query_backward(b.g1, 1, 1, s->X, s->Y, s->Z, w.pts1, s->xyz_min, s->xyz_max, 0, M1, s->grad_density_grid, st);
-  }
-  return rc;
+  if (!s->ws_bwd || !s->grad_density_grid) return (int)hipErrorInvalidValue;
+  if (s->M1 <= 0) return 0;
+  const ug_step_ws w = ug_step_layout(s);
+  const ug_step_ws_bwd b = ug_step_layout_bwd(s);
+  rc = ugrid_train_sample_backward(s->n_rays, s->act_shift, s->interval, w.dens1, w.w1, w.T1, w.pos2, s->counts, s->offsets, s->alphainv_last,
+                                   b.g_w, b.g_ainv, b.g_dens, b.g1, st);
+  if (rc) return rc;
+  return ugrid_grid_query_backward(b.g1, s->P, 1, s->X, s->Y, s->Z, w.pts1, s->xyz_min, s->xyz_max, s->freq_num, s->M1, s->grad_density_grid,
+                                   st);
+}
+
+extern "C" int ugrid_voxgo_step_backward(const ugrid_voxgo_step *s, ugrid_stream_t st) {
+  const int rc = ugrid_voxgo_step_backward_k0(s, st);
+  return rc ? rc : ugrid_voxgo_step_backward_density(s, st);
 }

@@ -47,6 +47,7 @@ class FourierGridModel(nn.Module):
         self.splitk_rgbnet = backend is None       # ops.SplitKLinear weight gradients (training on the GPU only)
         self.fused_rgbnet = backend is None        # ops.FusedRgbnet: the default 3 x 128 rgbnet fwd / bwd on the MFMA kernels
         self.fused_loss = backend is None          # train_step.train_iteration: compositing + loss as ops.RenderLoss
+        self.native_step = backend is None         # native_step.VoxGOStep: training forward + loss as ONE autograd node issued from C
         lo_s, hi_s = torch.Tensor(xyz_min), torch.Tensor(xyz_max)
         self.register_buffer('scene_center', (lo_s + hi_s) * 0.5)
         self.register_buffer('scene_radius', (hi_s - lo_s) * 0.5)
@@ -258,6 +259,22 @@ class FourierGridModel(nn.Module):
         edge_out = 1.5 / torch.linspace(1, 1 / 128, n_inner + 1)
         return torch.cat([(edge_in[1:] + edge_in[:-1]) * 0.5, (edge_out[1:] + edge_out[:-1]) * 0.5])
 
+    def _native_params(self):
+        """The parameters of native_step.VoxGOStep (density grid, k0 grid, the rgbnet's three weights and biases), or None when this
+        configuration takes the op-by-op ops: default 3-layer rgbnet, gradients on, every one of those parameters trainable, both
+        grids looked up by the HIP kernels (no injected query function)"""
+        if not (self.native_step and self.fused_rgbnet and self.rgbnet is not None and torch.is_grad_enabled()):
+            return None
+        lin = _ops.rgbnet_linears(self.rgbnet)
+        if lin is None:
+            return None
+        params = [self.density.grid, self.k0.grid] + [p for l in lin for p in (l.weight, l.bias)]
+        if not all(p.requires_grad for p in params) or self.density.query_fn is not None or self.k0.query_fn is not None \
+                or self.density.grid.shape[0] != 1 + 2 * max(self.fourier_freq_num, 0) \
+                or self.k0.grid.shape[0] != 1 + 2 * max(self.k0.nerf_pos_num_freq, 0):
+            return None
+        return params
+
     def forward(self, rays_o, rays_d, viewdirs, global_step=None, is_train=False, **render_kwargs):
         assert rays_o.dim() == 2 and rays_o.shape[-1] == 3, 'Only support point queries in [N, 3] format'
         if self._fast_color_thres is not None and global_step in self._fast_color_thres:
@@ -272,6 +289,26 @@ class FourierGridModel(nn.Module):
             t = self.sample_table(render_kwargs['stepsize'], dev)
             S = t.numel()
             hc = self._host_consts()
+            fl = render_kwargs.get('fused_loss')
+            native = self._native_params() if (fl is not None and self.splitk_rgbnet) else None
+            if native is not None:
+                # the whole forward + loss as ONE autograd node issued from C (native_step.VoxGOStep, mode 'fourier'): the same
+                # kernels, sizes and order as the ops below
+                from .native_step import VoxGOStep
+                cfg = {'act_shift': hc[2], 'interval': float(interval), 'thres': float(self.fast_color_thres), 'scene_center': hc[0],
+                       'scene_radius': hc[1], 'bg_len': self.bg_len, 'norm_l2': self.contracted_norm == 'l2',
+                       'freq_num': self.fourier_freq_num, 'k0_freq_num': self.k0.nerf_pos_num_freq}
+                bg = torch.rand(R, 3, device=dev) if render_kwargs.get('rand_bkgd', False) else None
+                pack = {'mode': 'fourier', 'cfg': cfg, 't': t, 'rays_o': rays_o.contiguous(), 'rays_d': rays_d.contiguous(),
+                        'viewdirs': viewdirs, 'viewfreq': self.viewfreq, 'xyz_min': self.xyz_min, 'xyz_max': self.xyz_max,
+                        'k0_xyz_min': self.k0.xyz_min, 'k0_xyz_max': self.k0.xyz_max, 'mask': None, 'target': fl['target'], 'bg': bg,
+                        'coef': fl['coef']}
+                loss, mse = VoxGOStep.apply(*native, pack)
+                o = pack['out']
+                return {'alphainv_last': o['alphainv_last'], 'weights': o['weights'], 'rgb_marched': o['rgb_marched'],
+                        'raw_density': o['raw_density'], 'raw_alpha': o['raw_alpha'], 'raw_logits': o['raw_logits'], 'ray_id': o['ray_id'],
+                        'step_id': o['step_id'], 'n_max': S, 't': o['t'], 'loss': loss, 'mse': mse, 'loss_mse': o['loss_mse'],
+                        'native': pack}
             pts, density, alpha, weights, alphainv_last, ray_id, step_id, tt = _grid.TrainSample.apply(
                 self.density.grid, rays_o.contiguous(), rays_d.contiguous(), t, hc[0], hc[1], self.xyz_min, self.xyz_max,
                 self.bg_len, self.contracted_norm == 'l2', hc[2], float(interval), float(self.fast_color_thres),

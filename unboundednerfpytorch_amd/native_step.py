@@ -1,8 +1,8 @@
-"""The training step of the two dense-grid models issued natively: ONE autograd node whose forward is two C calls
+"""The training step of the dense-grid models and of FourierGridModel issued natively: ONE autograd node whose forward is two C calls
 (include/ugrid_hip.h: ugrid_voxgo_step_sample / _forward) and whose backward is one (ugrid_voxgo_step_backward), in place of the
-op-by-op step's four nodes and ~30 launches issued from Python (voxgo_model.py: TrainSampleVox, the k0 GridQuery, FusedRgbnet,
-RenderLoss).  The C side runs the same kernels on the same sizes in the same order, so loss, outputs and every gradient are the
-op-by-op step's bit for bit (tests/test_gpu_native_step.py); what changes is the host time between launches.
+op-by-op step's four nodes and ~30 launches issued from Python (voxgo_model.py / fourier_model.py: TrainSampleVox / TrainSample, the
+k0 GridQuery, FusedRgbnet, RenderLoss).  The C side runs the same kernels on the same sizes in the same order, so loss, outputs and every gradient are the
+op-by-op step's (tests/test_gpu_voxgo_train.py, tests/test_gpu_train_step.py: bit for bit where sums have a fixed order); what changes is the host time between launches.
 
 Only the tensors a training loop reads come back as autograd outputs (loss; mse without gradient); the per-sample arrays of the
 reference's return dict are handed out detached."""
@@ -23,10 +23,14 @@ _WEIGHTS = ("w0", "b0", "w1", "b1", "w2", "b2")
 
 
 class VoxGOStep(torch.autograd.Function):
-    """forward(density_grid [1,1,X,Y,Z], k0_grid [1,C,X,Y,Z], w0, b0, w1, b1, w2, b2, pack) -> loss, mse
-    pack (dict, not differentiated): mode 'dvgo' | 'dcvgo', cfg (the dict TrainSampleVox takes), rays_o / rays_d / viewdirs [R,3],
-    viewfreq [pe], t (dcvgo: the sample table [S]), xyz_min / xyz_max, k0_xyz_min / k0_xyz_max, mask (bool [mi,mj,mk]),
-    target [R,3], bg [R,3] or None, coef (ops.loss_coefficients).  On return pack['out'] holds the detached per-sample / per-ray
+    """forward(density_grid [P,1,X,Y,Z], k0_grid [P,C,X,Y,Z], w0, b0, w1, b1, w2, b2, pack) -> loss, mse
+    pack (dict, not differentiated): mode 'dvgo' | 'dcvgo' | 'fourier', cfg (the dict TrainSampleVox takes; 'fourier': act_shift,
+    interval, thres, scene_center, scene_radius, bg_len, norm_l2, freq_num, k0_freq_num), rays_o / rays_d / viewdirs [R,3],
+    viewfreq [pe], t (dcvgo, fourier: the sample table [S]), xyz_min / xyz_max, k0_xyz_min / k0_xyz_max, mask (bool [mi,mj,mk];
+    none for 'fourier'), target [R,3], bg [R,3] or None, coef (ops.loss_coefficients).
+    pack['k0_grad_ready'] (optional, may be set any time before the backward): callable(k0_parameter) invoked in the middle of the
+    backward, as soon as the k0 grid's gradient is complete and assigned to .grad -- train_step.train_iteration starts the k0
+    update there, beside the density half of the backward; the node then reports no gradient for the k0 grid.  On return pack['out'] holds the detached per-sample / per-ray
     arrays: alphainv_last, weights, rgb_marched, raw_alpha, raw_density, raw_logits, ray_id, step_id, t, inner, and loss_mse
     (the two scalars as one [2] tensor: a training loop that logs both reads them with one copy)."""
 
@@ -39,20 +43,22 @@ class VoxGOStep(torch.autograd.Function):
                ("target", pack['target']), ("viewfreq", pack['viewfreq'])] + [("rgbnet", x) for x in ws_]
         if pack.get('bg') is not None:
             f32.append(("bg", pack['bg']))
-        _lib.require_cuda(*f32, ("mask", pack['mask']))
+        mask = pack.get('mask')
+        _lib.require_cuda(*f32, *([("mask", mask)] if mask is not None else []))
         _lib.require_f32(*f32, ("k0 grid", k0_grid))
-        for g in (density_grid, k0_grid):
-            _lib.wait_pending(g)     # an optimizer update of a grid may still run on a side stream (step(overlap=...))
-        if density_grid.dim() != 5 or tuple(density_grid.shape[:2]) != (1, 1) or not density_grid.is_contiguous():
-            raise RuntimeError("VoxGOStep: the density grid must be a contiguous [1,1,X,Y,Z]")
-        if k0_grid.dim() != 5 or k0_grid.shape[0] != 1:
-            raise RuntimeError("VoxGOStep: the k0 grid must be [1,C,X,Y,Z]")
+        _lib.wait_pending(density_grid)     # an optimizer update of a grid may still run on a side stream (step(overlap=...)); the
+                                            # k0 grid's is waited for AFTER the sampling march, which does not read it
+        if density_grid.dim() != 5 or density_grid.shape[1] != 1 or not density_grid.is_contiguous():
+            raise RuntimeError("VoxGOStep: the density grid must be a contiguous [P,1,X,Y,Z]")
+        if k0_grid.dim() != 5:
+            raise RuntimeError("VoxGOStep: the k0 grid must be [P,C,X,Y,Z]")
+        if mode != 'fourier' and (density_grid.shape[0] != 1 or k0_grid.shape[0] != 1):
+            raise RuntimeError("VoxGOStep: the dense-grid models' grids have one level")
         k0_cl = bool(_lib.require_cuda_grid(("k0 grid", k0_grid)))
         dev = density_grid.device
         R = rays_o.shape[0]
         t = pack.get('t')
         S = int(cfg['slots']) if mode == 'dvgo' else t.numel()
-        mask = pack['mask']
         C, W, pe = k0_grid.shape[1], ws_[0].shape[0], pack['viewfreq'].numel()
         if tuple(ws_[0].shape) != (W, C + 3 + 6 * pe) or tuple(ws_[2].shape) != (W, W) or tuple(ws_[4].shape) != (3, W):
             raise RuntimeError("VoxGOStep: rgbnet weights must be [W, C+3+6pe], [W,W], [3,W]")
@@ -72,21 +78,25 @@ class VoxGOStep(torch.autograd.Function):
         rgb_marched = torch.empty(R, 3, device=dev)
         out2 = torch.empty(2, device=dev)
         s = _lib.VoxgoStep()
-        s.mode = 0 if mode == 'dvgo' else 1
+        s.mode = {'dvgo': 0, 'dcvgo': 1, 'fourier': 2}[mode]
         s.k0_channels_last = int(k0_cl)
+        s.P, s.kP = density_grid.shape[0], k0_grid.shape[0]
+        s.freq_num, s.k0_freq_num = (max(int(cfg['freq_num']), 0), max(int(cfg['k0_freq_num']), 0)) if mode == 'fourier' else (0, 0)
         s.X, s.Y, s.Z = density_grid.shape[2:]
         s.kX, s.kY, s.kZ = k0_grid.shape[2:]
         s.C, s.pe, s.width, s.slots = C, pe, W, S
-        s.mask_dims[:] = [int(x) for x in mask.shape]
-        s.mask_scale[:] = cfg['mask_scale']
-        s.mask_shift[:] = cfg['mask_shift']
+        if mask is not None:
+            s.mask_dims[:] = [int(x) for x in mask.shape]
+            s.mask_scale[:] = cfg['mask_scale']
+            s.mask_shift[:] = cfg['mask_shift']
+            s.mask = mask.data_ptr()
         s.act_shift, s.interval, s.thres = float(cfg['act_shift']), float(cfg['interval']), float(cfg['thres'])
         if mode == 'dvgo':
             s.near_clip, s.far_clip, s.stepdist = float(cfg['near']), float(cfg['far']), float(cfg['stepdist'])
         else:
             s.scene_center[:] = cfg['scene_center']
             s.scene_radius[:] = cfg['scene_radius']
-            s.bg_len, s.norm_l2, s.dist_thres = float(cfg['bg_len']), int(bool(cfg['norm_l2'])), float(cfg['dist_thres'])
+            s.bg_len, s.norm_l2, s.dist_thres = float(cfg['bg_len']), int(bool(cfg['norm_l2'])), float(cfg.get('dist_thres', 0.0))
             s.t_table = t.data_ptr()
         s.coef8[:] = [float(x) for x in pack['coef']]
         s.n_rays = R
@@ -97,7 +107,7 @@ class VoxGOStep(torch.autograd.Function):
         s.density_grid, s.k0_grid = density_grid.data_ptr(), k0_grid.data_ptr()
         s.xyz_min, s.xyz_max = pack['xyz_min'].data_ptr(), pack['xyz_max'].data_ptr()
         s.k0_xyz_min, s.k0_xyz_max = pack['k0_xyz_min'].data_ptr(), pack['k0_xyz_max'].data_ptr()
-        s.mask, s.viewfreq = mask.data_ptr(), viewfreq.data_ptr()
+        s.viewfreq = viewfreq.data_ptr()
         for n, x in zip(_WEIGHTS, ws_):
             setattr(s, n, x.data_ptr())
         s.rays_o, s.rays_d, s.viewdirs, s.target = rays_o.data_ptr(), rays_d.data_ptr(), viewdirs.data_ptr(), target.data_ptr()
@@ -111,6 +121,7 @@ class VoxGOStep(torch.autograd.Function):
         with _lib.guard(dev):
             st = _lib.stream_of(density_grid)
             _lib.check(_L.ugrid_voxgo_step_sample(ps, st), "voxgo_step_sample")          # the step's one host read: M1, M2
+            _lib.wait_pending(k0_grid)
             M2 = s.M2
             ws = torch.empty(int(_L.ugrid_voxgo_step_ws_floats(ps)), device=dev)
             f4 = torch.empty(4, M2, device=dev)                                # density2 | alpha2 | weights2 | t2
@@ -130,6 +141,7 @@ class VoxGOStep(torch.autograd.Function):
         ctx.shapes = (tuple(density_grid.shape), tuple(density_grid.stride()), tuple(k0_grid.shape), tuple(k0_grid.stride()), k0_cl)
         ctx.keys = (_gradpool.key_of(density_grid), _gradpool.key_of(k0_grid))
         ctx.wshapes = [tuple(x.shape) for x in ws_]
+        ctx.pack = pack
         pack['out'] = {'alphainv_last': ainv, 'weights': f4[2], 'rgb_marched': rgb_marched, 'raw_alpha': f4[1], 'raw_density': f4[0],
                        'raw_logits': logits, 'ray_id': ids[0], 'step_id': ids[1], 't': f4[3], 'inner': inner, 'loss_mse': out2}
         loss, mse = out2[0], out2[1]
@@ -159,6 +171,18 @@ class VoxGOStep(torch.autograd.Function):
             setattr(s, "g_" + n, x.data_ptr())
         s.grad_density_grid, s.grad_k0_grid = g_density.data_ptr(), g_k0.data_ptr()
         s.touch = touch.data_ptr() if touch is not None else None
+        ready = ctx.pack.get('k0_grad_ready')
         with _lib.guard(dev):
-            _lib.check(_L.ugrid_voxgo_step_backward(ps, _lib.stream_of(g_loss)), "voxgo_step_backward")
-        return (g_density, g_k0, *gw, None)
+            st = _lib.stream_of(g_loss)
+            if ready is None:
+                _lib.check(_L.ugrid_voxgo_step_backward(ps, st), "voxgo_step_backward")
+                return (g_density, g_k0, *gw, None)
+            # the k0 gradient first; its consumer (the optimizer's early k0 update, on a side stream) is started before the density
+            # half of the backward is issued, and owns the gradient from here on
+            _lib.check(_L.ugrid_voxgo_step_backward_k0(ps, st), "voxgo_step_backward_k0")
+            k0_param = ctx.keep[1]
+            k0_param.grad = g_k0
+            del g_k0
+            ready(k0_param)
+            _lib.check(_L.ugrid_voxgo_step_backward_density(ps, st), "voxgo_step_backward_density")
+        return (g_density, None, *gw, None)

@@ -143,7 +143,11 @@ def train_iteration(model, optimizer, rays_o, rays_d, viewdirs, target, cfg_trai
 
         def _early_k0_update(p):          # (an autograd hook must return None)
             optimizer.step_param(p, k0_term, overlap=True)
-        hook = model.k0.grid.register_post_accumulate_grad_hook(_early_k0_update)
+        if out.get('native') is not None:
+            # the native step is ONE autograd node: its backward calls back between its two halves (native_step.VoxGOStep)
+            out['native']['k0_grad_ready'] = _early_k0_update
+        else:
+            hook = model.k0.grid.register_post_accumulate_grad_hook(_early_k0_update)
     # Touched-line bitmaps (_gradpool): in THIS loss graph the feature grid receives gradient from exactly one lookup (the
     # model's k0 query; every loss term reaches the grid through it), which is what the bitmap's validity rests on -- so the
     # step certifies it for its own backward only.  A caller-supplied loss that regularises k0.grid directly must not use

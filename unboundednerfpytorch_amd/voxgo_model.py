@@ -191,7 +191,7 @@ class _VoxGOBase(nn.Module):
         o = pack['out']
         return {'alphainv_last': o['alphainv_last'], 'weights': o['weights'], 'rgb_marched': o['rgb_marched'], 'raw_alpha': o['raw_alpha'],
                 'raw_density': o['raw_density'], 'raw_logits': o['raw_logits'], 'ray_id': o['ray_id'], 'step_id': o['step_id'],
-                't': o['t'], 'loss': loss, 'mse': mse, 'loss_mse': o['loss_mse']}
+                't': o['t'], 'loss': loss, 'mse': mse, 'loss_mse': o['loss_mse'], 'native': pack}
 
     def _logits(self, k0_view, viewdirs, ray_id):
         """rgbnet([k0, view embedding]) of the surviving samples: the fp32-MFMA kernels for the default 3-layer net while training"""
