@@ -13,7 +13,9 @@ cp $T/tv_adam_dense_pmc.json $P/tv_adam_dense_pmc.json
 cp $T/s1_kernel_stats.csv $P/bench_s1_kernel_stats.csv
 cp $T/truck_kernel_stats.csv $P/bench_truck_kernel_stats.csv
 tail -1 $T/bench_line.json > $P/bench_s1_line.json
-for f in bench_2rank_shared_gpu.json bench_8rank_shared_gpu.json dcvgo_1080p.json dvgo_lego_800.json voxgo_train.jsonl train_step_s3.jsonl pytest_gpu.log smoke.log \
+for f in bench_2rank_shared_gpu.json bench_8rank_shared_gpu.json dcvgo_1080p.json dvgo_lego_800.json voxgo_train.jsonl voxgo_train_lazy_loss.jsonl voxgo_train_op_by_op.jsonl \
+         voxgo_train_dvgo_kernel_stats.csv voxgo_train_dcvgo_kernel_stats.csv train_step_s3_masked_kernel_stats.csv voxgo_train_host_profile_dvgo.txt \
+         train_step_s3.jsonl pytest_gpu.log smoke.log \
          smi_trace.json smi_trace.csv tv_adam_dense.jsonl rank_share_pmc.jsonl; do
   [ -s $T/$f ] && cp $T/$f $P/$f
 done

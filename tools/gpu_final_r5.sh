@@ -82,7 +82,19 @@ import json, sys
 for l in open(sys.argv[1]):
     d = json.loads(l); print(d['tv_phase'], '%.3f ms' % d['ms_per_step'], {k: round(v, 3) for k, v in d['phases_ms'].items()}, d['survivors_M'], d.get('k0_grad_lines_touched_frac'))
 PY
-timeout 600 python tools/bench_voxgo_train.py --model both > $OUT/voxgo_train.jsonl 2>/dev/null; cut -c1-260 $OUT/voxgo_train.jsonl
+timeout 600 python tools/bench_voxgo_train.py --model both --steps 100 --warmup 10 > $OUT/voxgo_train.jsonl 2>/dev/null; cut -c1-260 $OUT/voxgo_train.jsonl
+timeout 600 python tools/bench_voxgo_train.py --model both --steps 100 --warmup 10 --lazy-loss 1 > $OUT/voxgo_train_lazy_loss.jsonl 2>/dev/null
+timeout 600 python tools/bench_voxgo_train.py --model both --steps 100 --warmup 10 --native 0 > $OUT/voxgo_train_op_by_op.jsonl 2>/dev/null
+python - $OUT <<'PY'
+import json, sys
+for f in ("voxgo_train_lazy_loss.jsonl", "voxgo_train_op_by_op.jsonl"):
+    for l in open(sys.argv[1] + "/" + f):
+        d = json.loads(l); print(f, d["model"], d["workload"][-14:], "native" if d["native_step"] else "op-by-op", round(d["ms_per_step"], 4))
+PY
+# kernel traces of the native training steps (DVGO, DCVGO masked, S3 masked) and the host profile of the DVGO step
+bash tools/gpu_r5r.sh > $OUT/voxgo_trace_print.txt 2>&1; cp gpurun_out/r5r/voxgo_train_*_kernel_stats.csv $OUT/ 2>/dev/null
+bash tools/gpu_r5t.sh > $OUT/s3_trace_print.txt 2>&1; cp gpurun_out/r5t/train_step_s3_masked_kernel_stats.csv $OUT/ 2>/dev/null
+bash tools/gpu_r5o.sh $TAG-host > /dev/null 2>&1; cp gpurun_out/$TAG-host/voxgo_train_host_profile_dvgo.txt $OUT/ 2>/dev/null
 # 7. smoke + the whole -m gpu suite
 timeout 600 python __graft_entry__.py smoke 2>&1 | tail -2 | tee $OUT/smoke.log
 timeout 3000 python -m pytest tests -m gpu -q -p no:warnings --durations=15 2>&1 | tail -30 | tee $OUT/pytest_gpu.log
