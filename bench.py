@@ -681,7 +681,7 @@ def truck_render_block(args, device, want_cpu):
                "chunks_per_frame": len(timing) // steps,
                "kernels": {k: {"ms": v, "algorithmic_bytes": alg.get(k), "algorithmic_GBps": (alg[k] / (v * 1e-3) / 1e9) if k in alg and v > 0 else None}
                            for k, v in kern.items()},
-               "shade_kernel": "k_shade_pc<4,4,4,4,NBL,0> (8 waves: 4 gather + 4 rgbnet; F >= 4 does not fit the 12-wave geometry's 168 VGPRs)"}
+               "shade_kernel": "k_shade_pc<4,4,6,2,3,1,true> (12 waves: 6 gather + 6 rgbnet; F >= 4 enters the 12-wave geometry through the rolling cell set-up)"}
         if cpu_state is not None:
             cb = cpu_baseline(cpu_state, rays, out, fb.stepsize, S, 4, device, ref_gpu=False)
             res["cpu_baseline_Msamples"] = cb["value"]
