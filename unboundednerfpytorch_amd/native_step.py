@@ -172,6 +172,8 @@ class VoxGOStep(torch.autograd.Function):
         s.grad_density_grid, s.grad_k0_grid = g_density.data_ptr(), g_k0.data_ptr()
         s.touch = touch.data_ptr() if touch is not None else None
         ready = ctx.pack.get('k0_grad_ready')
+        if ready is not None and ctx.keep[1].grad is not None:
+            ready = None       # a gradient is already accumulated on the k0 grid: this one has to be ADDED by autograd, not consumed here
         with _lib.guard(dev):
             st = _lib.stream_of(g_loss)
             if ready is None:
