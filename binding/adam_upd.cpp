@@ -4,11 +4,14 @@
 static void run(torch::Tensor &param, torch::Tensor &grad, torch::Tensor &exp_avg, torch::Tensor &exp_avg_sq, const torch::Tensor *perlr,
                 int step, float beta1, float beta2, float lr, float eps, int mode, const char *what) {
   CHECK_INPUT(param); CHECK_INPUT(grad); CHECK_INPUT(exp_avg); CHECK_INPUT(exp_avg_sq);
-  CHECK_F32(param); CHECK_F32(grad); CHECK_F32(exp_avg); CHECK_F32(exp_avg_sq);
-  if (perlr) { CHECK_CUDA((*perlr)); CHECK_CONTIGUOUS((*perlr)); CHECK_F32((*perlr)); }
+  CHECK_REAL(param); CHECK_SAME(grad, param); CHECK_SAME(exp_avg, param); CHECK_SAME(exp_avg_sq, param);
+  if (perlr) { CHECK_CUDA((*perlr)); CHECK_CONTIGUOUS((*perlr)); CHECK_SAME((*perlr), param); }
   UG_GUARD(param);
-  ug_check(ugrid_adam_upd(fpm(param), fp(grad), fpm(exp_avg), fpm(exp_avg_sq), perlr ? fp(*perlr) : nullptr, param.numel(), step, beta1, beta2,
-                          lr, eps, mode, ug_stream()), what);
+  ug_check(is64(param) ? ugrid_adam_upd_f64(dpm(param), dp(grad), dpm(exp_avg), dpm(exp_avg_sq), perlr ? dp(*perlr) : nullptr, param.numel(), step,
+                                            beta1, beta2, lr, eps, mode, ug_stream())
+                       : ugrid_adam_upd(fpm(param), fp(grad), fpm(exp_avg), fpm(exp_avg_sq), perlr ? fp(*perlr) : nullptr, param.numel(), step,
+                                        beta1, beta2, lr, eps, mode, ug_stream()),
+           what);
 }
 
 void adam_upd(torch::Tensor param, torch::Tensor grad, torch::Tensor exp_avg, torch::Tensor exp_avg_sq, int step, float beta1, float beta2,

@@ -43,7 +43,7 @@ def _flags():
     incs = ["-I" + os.path.join(ROOT, "include"), "-I" + sysconfig.get_paths()["include"]] + ["-isystem" + p for p in inc]
     tl = os.path.join(os.path.dirname(torch.__file__), "lib")
     libs = ["-L" + tl, "-Wl,-rpath," + tl, "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch", "-ltorch_python",
-            "-L" + LIBDIR, "-Wl,-rpath,$ORIGIN/../../unboundednerfpytorch_amd", "-Wl,-rpath," + LIBDIR, "-lugrid_hip", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"]
+            "-L" + LIBDIR, "-Wl,-rpath,$ORIGIN/../../unboundednerfpytorch_amd", "-Wl,-rpath," + LIBDIR, "-lugrid_hip", "-lugrid_hip_f64", "-L/opt/rocm/lib", "-Wl,-rpath,/opt/rocm/lib", "-lamdhip64"]
     return cflags, incs, libs
 
 
@@ -53,7 +53,8 @@ def build(force=False, verbose=False):
     built = []
     procs = []
     for name, src in MODULES.items():
-        srcs = [os.path.join(HERE, src), os.path.join(HERE, "ugrid_binding_common.h"), os.path.join(ROOT, "include", "ugrid_hip.h")]
+        srcs = [os.path.join(HERE, src), os.path.join(HERE, "ugrid_binding_common.h"), os.path.join(ROOT, "include", "ugrid_hip.h"),
+                os.path.join(ROOT, "include", "ugrid_hip_f64.h")]
         so = os.path.join(OUT, PREFIX + name + ".so")
         stamp = so + ".srchash"
         want = _hash(srcs)

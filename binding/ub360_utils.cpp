@@ -3,11 +3,11 @@
 #include "ugrid_binding_common.h"
 
 torch::Tensor cumdist_thres(torch::Tensor dist, float thres) {
-  CHECK_INPUT(dist); CHECK_F32(dist);
+  CHECK_INPUT(dist); CHECK_REAL(dist);
   TORCH_CHECK(dist.dim() == 2, "dist must be [n_rays, n_pts]");
   UG_GUARD(dist);
   auto mask = torch::empty({dist.size(0), dist.size(1)}, dist.options().dtype(at::kBool));
-  ug_check(ugrid_cumdist_thres(fp(dist), thres, dist.size(0), dist.size(1), (uint8_t *)mask.data_ptr<bool>(), ug_stream()), "cumdist_thres");
+  ug_check((is64(dist) ? ugrid_cumdist_thres_f64(dp(dist), thres, dist.size(0), dist.size(1), (uint8_t *)mask.data_ptr<bool>(), ug_stream()) : ugrid_cumdist_thres(fp(dist), thres, dist.size(0), dist.size(1), (uint8_t *)mask.data_ptr<bool>(), ug_stream())), "cumdist_thres");
   return mask;
 }
 

@@ -194,11 +194,13 @@ EXPORTED = {RU: 13, TV: 1, UB: 1, AD: 3}   # m.def counts of the four reference 
 TRANSCENDENTAL = {"raw2alpha", "raw2alpha_backward", "raw2alpha_nonuni", "raw2alpha_nonuni_backward"}
 
 
-def run_case(mods, case, scale, prev, device=None):
+def run_case(mods, case, scale, prev, device=None, dtype=None):
     """Call one case on `mods` (dict module name -> module with the reference's function signatures).  Returns the list
     of result tensors on the CPU: the op's return value(s), or the mutated arguments for in-place ops."""
     name, mod, fn, make, mutated = case
     args = make(scale, prev)
+    if dtype is not None:       # the reference dispatches float and double: the same seeded values in the other floating type
+        args = [a.to(dtype) if (torch.is_tensor(a) and a.is_floating_point()) else a for a in args]
     if device is not None:
         args = [a.to(device) if torch.is_tensor(a) else a for a in args]
     ret = getattr(mods[mod], fn)(*args)
@@ -211,13 +213,14 @@ def run_case(mods, case, scale, prev, device=None):
     return [o.detach().cpu() for o in outs]
 
 
-def run_all(mods, scale=1, device=None, chain_from=None):
+def run_all(mods, scale=1, device=None, chain_from=None, dtype=None):
     """All cases in table order.  chain_from: dict name -> outputs to feed dependent cases from (the golden file), so
-    that every implementation sees the same inputs; default: its own outputs."""
+    that every implementation sees the same inputs; default: its own outputs.  dtype: cast the floating inputs (float64:
+    the reference's other dispatch type)."""
     results = {}
     for case in CASES:
         prev = chain_from if chain_from is not None else results
-        results[case[0]] = run_case(mods, case, scale, prev, device)
+        results[case[0]] = run_case(mods, case, scale, prev, device, dtype)
     return results
 
 

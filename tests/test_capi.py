@@ -55,6 +55,37 @@ def test_python_binding_table_matches_header(lib_path):
         assert lib.ugrid_render_ws_bytes(n_rays, S) == 256 + a256(nt * 4) + a256(nt * cap * 16) + a256(nt * cap)
 
 
+def test_float64_twin_library_exports_its_header(lib_path):
+    """include/ugrid_hip_f64.h (the double instantiations of the ops the reference dispatches on the tensor type) = the exports of
+    libugrid_hip_f64.so = the ctypes table; every twin has the argument list of its float entry point (the count half of
+    sample_pts_on_rays without the scan workspace); the library carries gfx950 code only and the product library does not depend on it"""
+    from unboundednerfpytorch_amd import _lib
+    text = open(os.path.join(ROOT, "include", "ugrid_hip_f64.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = sorted(set(re.findall(r"\b(ugrid_[a-z0-9_]+)\s*\(", text)))
+    assert names == sorted(_lib.EXPORTED_SYMBOLS_F64) and len(names) == 15
+    so = os.path.join(ROOT, "unboundednerfpytorch_amd", "libugrid_hip_f64.so")
+    lib = ctypes.CDLL(so)
+    assert not [n for n in names if not hasattr(lib, n)]
+    base = open(os.path.join(ROOT, "include", "ugrid_hip.h")).read()
+    base = re.sub(r"/\*.*?\*/", "", base, flags=re.S)
+    def params(src, name):
+        m = re.search(r"\b%s\s*\((.*?)\)\s*;" % name, src, flags=re.S)
+        return [re.sub(r"\s+", " ", a.strip()) for a in m.group(1).split(",")]
+    for n in names:
+        a32, a64 = params(base, n[:-4]), params(text, n)
+        if n == "ugrid_sample_pts_on_rays_count_f64":
+            a32 = [a for a in a32 if "scan_ws" not in a]
+        assert len(a32) == len(a64), n
+        for x, y in zip(a32, a64):
+            assert x.replace("const float *", "const double *").replace("float *", "double *").split()[:-1] == y.split()[:-1] \
+                or x.split()[:-1] == y.split()[:-1], (n, x, y)
+    assert _lib.load_f64() is _lib.load_f64()
+    out = subprocess.run(["ldd", lib_path], capture_output=True, text=True).stdout
+    assert "ugrid_hip_f64" not in out
+    assert b"gfx950" in open(so, "rb").read() and b"gfx942" not in open(so, "rb").read()
+
+
 def test_voxgo_step_struct_mirror_matches_the_header(lib_path):
     """_lib.VoxgoStep mirrors `ugrid_voxgo_step` field for field: names and order parsed from the header, C type -> ctypes type,
     and the compiled sizeof; the workspace size helpers are host arithmetic over the struct's counts"""

@@ -49,6 +49,60 @@ def test_hip_ops_vs_live_reference_kernels_at_scale(variant):
     assert ref["sample_pts_on_rays"][0].shape[0] > 15000 and ref["alpha2weight"][0].numel() == 8 * nc.A2W_N
 
 
+def test_float64_twins_reproduce_reference_kernel_outputs_bit_for_bit(golden_dir):
+    """tests/golden/native_ops_f64.npz: outputs of the reference's own kernels called with double tensors on an MI355X
+    (tests/golden/gen_native_golden_f64.py).  The fp64 twins must reproduce every one of them exactly, with or without
+    oracle/_ref on the box."""
+    gold, _ = nc.load_golden(os.path.join(golden_dir, "native_ops_f64.npz"))
+    assert gold["raw2alpha"][0].dtype == torch.float64
+    got = nc.run_all(hip_modules(), scale=1, device="cuda", chain_from=gold, dtype=torch.float64)
+    assert_same(gold, got, "golden float64")
+
+
+def pybind_modules():
+    from binding import build as bb
+    if not bb.available():
+        pytest.skip("binding/_build not built")
+    return bb.load()
+
+
+@pytest.mark.parametrize("binding", ["ctypes", "pybind"])
+@pytest.mark.parametrize("variant", ["nofma", "fma"])
+@pytest.mark.parametrize("scale", [1, 8])
+def test_float64_twins_vs_live_reference_kernels(variant, scale, binding):
+    """The reference's modules dispatch float AND double (AT_DISPATCH_FLOATING_TYPES).  The double instantiations of the drop-in ops
+    (include/ugrid_hip_f64.h, libugrid_hip_f64.so) against the reference's own kernels called with double tensors: all 18
+    functions, bit for bit -- the reference keeps many intermediates in float whatever the tensor type is (slab distances,
+    sample positions, the transmittance, the TV accumulator, the running distance), so "compute in double" would NOT reproduce
+    it.  The chained cases (infer_n_samples, raw2alpha_backward, alpha2weight_backward) take the reference's outputs as inputs."""
+    from oracle import build_ref
+    if not build_ref.built(variant):
+        pytest.skip("oracle/_ref/%s not built (python oracle/build_ref.py in the build container)" % variant)
+    ref = nc.run_all(build_ref.load(variant), scale=scale, device="cuda", dtype=torch.float64)
+    mods = hip_modules() if binding == "ctypes" else pybind_modules()      # both bindings of the C ABI (INTEGRATION.md A / B)
+    got = nc.run_all(mods, scale=scale, device="cuda", chain_from=ref, dtype=torch.float64)
+    for name in ref:
+        for t in ref[name]:
+            assert t.dtype in (torch.float64, torch.int64, torch.bool), (name, t.dtype)
+    assert_same(ref, got, "live float64 " + variant)
+    assert ref["sample_pts_on_rays"][0].dtype == torch.float64 and ref["sample_pts_on_rays"][0].shape[0] > 1000 * scale
+
+
+def test_float64_and_mixed_type_errors():
+    """one floating type per call; anything but float32 / float64 is refused, as is a double tensor for the ops that have no
+    reference counterpart"""
+    from unboundednerfpytorch_amd import adam_upd_cuda, render_utils_cuda
+    d32 = torch.randn(100, device="cuda")
+    with pytest.raises(RuntimeError):
+        render_utils_cuda.raw2alpha(d32.half(), -9.0, 0.5)
+    with pytest.raises(RuntimeError):
+        render_utils_cuda.raw2alpha_nonuni(d32.double(), -9.0, torch.full_like(d32, 0.5))
+    with pytest.raises(RuntimeError):
+        adam_upd_cuda.masked_adam_upd_rezero(d32.double(), d32.double(), d32.double(), d32.double(), 1, 0.9, 0.99, 0.1, 1e-8)
+    e, a = render_utils_cuda.raw2alpha(d32.double(), -9.0, 0.5)
+    assert e.dtype == a.dtype == torch.float64
+
+
 def test_loading_the_reference_kernels_never_overwrites_the_drop_in_modules():
     """The checker must not be able to replace the thing it checks.  CPython re-populates whatever module sits in sys.modules
     under an extension module's NAME when a cached single-phase-init .so of that name is loaded again (import.c:

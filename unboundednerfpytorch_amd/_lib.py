@@ -171,7 +171,57 @@ _SIGNATURES = {
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
+# the entry points the reference dispatches on the tensor type (AT_DISPATCH_FLOATING_TYPES): their double instantiations live in a
+# library of their own, include/ugrid_hip_f64.h -> libugrid_hip_f64.so (same signatures, array pointers double; the scan of
+# sample_pts_on_rays_count needs no workspace there)
+LIB_F64_PATH = os.path.join(_HERE, "libugrid_hip_f64.so")
+_F64_TWINS = ("ugrid_infer_t_minmax", "ugrid_infer_n_samples", "ugrid_infer_ray_start_dir", "ugrid_sample_pts_on_rays_count",
+              "ugrid_sample_pts_on_rays_fill", "ugrid_sample_ndc_pts_on_rays", "ugrid_sample_bg_pts_on_rays", "ugrid_maskcache_lookup",
+              "ugrid_raw2alpha", "ugrid_raw2alpha_backward", "ugrid_alpha2weight", "ugrid_alpha2weight_backward",
+              "ugrid_total_variation_add_grad", "ugrid_cumdist_thres", "ugrid_adam_upd")
+_SIGNATURES_F64 = {n + "_f64": _SIGNATURES[n] for n in _F64_TWINS}
+_SIGNATURES_F64["ugrid_sample_pts_on_rays_count_f64"] = (_I, [_P, _P, _P, _P, _F, _F, _F, _L, _P, _P, _P, _P, _P, _P])
+EXPORTED_SYMBOLS_F64 = tuple(_SIGNATURES_F64)
+
 _lib = None
+_lib_f64 = None
+
+
+def load_f64():
+    """The fp64 twins (loaded on first use: nothing on the rendering / training path needs them).  Raises if the library is absent."""
+    global _lib_f64
+    if _lib_f64 is not None:
+        return _lib_f64
+    if not os.path.exists(LIB_F64_PATH):
+        raise ImportError("libugrid_hip_f64.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'`.  "
+                          "There is no CPU fallback." % LIB_F64_PATH)
+    lib = ctypes.CDLL(LIB_F64_PATH)
+    for name, (res, args) in _SIGNATURES_F64.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib_f64 = lib
+    return lib
+
+
+def real_dtype(*named):
+    """The common floating type of the tensors of a reference-dispatched op: torch.float32 or torch.float64 (the two types of the
+    reference's AT_DISPATCH_FLOATING_TYPES).  RuntimeError for anything else, or for a mix (the reference reinterprets every array
+    with the first tensor's type: a mix is a caller's bug there too)."""
+    dt = named[0][1].dtype
+    if dt not in (torch.float32, torch.float64):
+        raise RuntimeError("%s: float32 or float64 expected (got %s)" % (named[0][0], dt))
+    for name, t in named[1:]:
+        if t.dtype != dt:
+            raise RuntimeError("%s is %s, %s is %s: one floating type per call" % (named[0][0], dt, name, t.dtype))
+    return dt
+
+
+def entry(name, dtype):
+    """the C entry point `name` for tensors of `dtype`: libugrid_hip.so's, or its `_f64` twin of libugrid_hip_f64.so"""
+    if dtype == torch.float64:
+        return getattr(load_f64(), name + "_f64")
+    return getattr(load(), name)
 
 
 def load():

@@ -14,9 +14,11 @@ def _run(param, grad, exp_avg, exp_avg_sq, perlr, step, beta1, beta2, lr, eps, m
     # elementwise over the storage: any dense layout works as long as all operands share it (canonical, or the
     # channel-last training layout of grid.FourierGrid)
     _lib.require_cuda_grid(*named) if param.dim() == 5 else _lib.require_cuda(*named)
-    _lib.require_f32(*named)
+    dt = _lib.real_dtype(*named)
+    if dt == torch.float64 and mode == 3:
+        raise RuntimeError("masked_adam_upd_rezero: float32 only (no reference counterpart)")
     with _lib.guard(param.device):
-        _lib.check(_L.ugrid_adam_upd(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
+        _lib.check(_lib.entry("ugrid_adam_upd", dt)(_lib.ptr(param), _lib.ptr(grad), _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
                                      _lib.ptr(perlr), param.numel(), int(step), float(beta1), float(beta2),
                                      float(lr), float(eps), mode, _lib.stream_of(param)), what)
 

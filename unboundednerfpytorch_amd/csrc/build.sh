@@ -25,3 +25,6 @@ hipcc $FLAGS -c ugrid_step.hip -o $O/ugrid_step.o "$@" &
 pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done   # a bare `wait` returns 0 even when a job failed
 hipcc --offload-arch=gfx950 -shared -fPIC -o ${UG_OUT:-../libugrid_hip.so} $OBJS
+# the fp64 twins of the drop-in ops: a library of its own (nothing on the rendering / training path loads it)
+hipcc $FLAGS -c ugrid_ops_f64.hip -o $O/ugrid_ops_f64.o "$@"
+hipcc --offload-arch=gfx950 -shared -fPIC -o ${UG_OUT_F64:-../libugrid_hip_f64.so} $O/ugrid_ops_f64.o

@@ -21,9 +21,17 @@ def total_variation_add_grad(param, grad, wx, wy, wz, dense_mode):
 
 def _tv(param, grad, wx, wy, wz, dense_mode, touch):
     cl = _lib.require_cuda_grid(("param", param), ("grad", grad))
-    _lib.require_f32(("param", param), ("grad", grad))
+    dt = _lib.real_dtype(("param", param), ("grad", grad))
     if param.dim() != 5 or param.shape != grad.shape:
         raise RuntimeError("param/grad must be 5-D tensors of equal shape")
+    if dt == torch.float64:      # the reference's double instantiation (total_variation_kernel.cu:50,59): canonical layout only
+        if cl or touch is not None:
+            raise RuntimeError("float64 total_variation_add_grad: canonical (contiguous) layout, no touched-line bitmap")
+        with _lib.guard(param.device):
+            _lib.check(_lib.entry("ugrid_total_variation_add_grad", dt)(
+                _lib.ptr(param), _lib.ptr(grad), float(wx), float(wy), float(wz), 1 if dense_mode else 0, param.size(2), param.size(3),
+                param.size(4), param.numel(), _lib.stream_of(param)), "total_variation_add_grad (float64)")
+        return
     if touch is not None and (not cl or dense_mode):
         raise RuntimeError("the touched-line bitmap serves the masked mode on channel-last storage only")
     if cl and touch is not None:

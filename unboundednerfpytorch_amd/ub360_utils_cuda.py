@@ -9,12 +9,12 @@ _L = _lib.load()
 
 def cumdist_thres(dist, thres):
     _lib.require_cuda(("dist", dist))
-    _lib.require_f32(("dist", dist))
+    dt = _lib.real_dtype(("dist", dist))
     if dist.dim() != 2:
         raise RuntimeError("dist must be [n_rays, n_pts]")
     mask = torch.empty(dist.size(0), dist.size(1), dtype=torch.bool, device=dist.device)
     with _lib.guard(dist.device):
-        _lib.check(_L.ugrid_cumdist_thres(_lib.ptr(dist), float(thres), dist.size(0), dist.size(1), _lib.ptr(mask),
+        _lib.check(_lib.entry("ugrid_cumdist_thres", dt)(_lib.ptr(dist), float(thres), dist.size(0), dist.size(1), _lib.ptr(mask),
                                           _lib.stream_of(dist)), "cumdist_thres")
     return mask
 
