@@ -286,8 +286,10 @@ def test_error_behaviour(mods):
     x = torch.zeros(8, 3, device="cuda")[:, :2]
     with pytest.raises(RuntimeError, match="must be contiguous"):
         ru.infer_ray_start_dir(x, x, torch.zeros(8, device="cuda"))
-    with pytest.raises(RuntimeError, match="float32"):
-        ru.raw2alpha(torch.zeros(4, dtype=torch.float64, device="cuda"), 0.0, 0.5)
+    with pytest.raises(RuntimeError, match="float32 or float64"):      # the two types of the reference's AT_DISPATCH_FLOATING_TYPES
+        ru.raw2alpha(torch.zeros(4, dtype=torch.float16, device="cuda"), 0.0, 0.5)
+    e, a = ru.raw2alpha(torch.zeros(4, dtype=torch.float64, device="cuda"), 0.0, 0.5)      # (round 5: the double twins)
+    assert e.dtype == a.dtype == torch.float64 and torch.equal(e, torch.ones_like(e))
 
 
 def test_autograd_and_masked_adam_match_reference_golden(mods, golden_dir):

@@ -335,5 +335,5 @@ def empty_like_grid(shape, channels_last, device, zero=False):
 def require_f32(*named):
     for name, t in named:
         if t.dtype != torch.float32:
-            raise RuntimeError("%s: only float32 is implemented by the MI355X path (got %s); the reference "
-                               "also dispatches double, which its hot path never uses" % (name, t.dtype))
+            raise RuntimeError("%s: float32 expected (got %s) -- this op has no reference counterpart and exists in fp32 only; the ops "
+                               "the reference dispatches on the tensor type also take float64" % (name, t.dtype))
