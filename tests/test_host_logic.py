@@ -313,6 +313,38 @@ def test_rgbnet_features_on_the_host_is_the_reference_chain():
     assert isinstance(rows, tuple) and rows[0] is viewdirs and rows[2] is ray_id
 
 
+def test_native_step_selection_is_host_logic():
+    """Which configurations take native_step.VoxGOStep is decided on the host from the module's own state (no device needed): the
+    default 3-layer rgbnet fed by all of k0, every parameter trainable, gradients on, the HIP lookups (no injected query function);
+    residual-colour and coarse-stage models, frozen parameters, no_grad and injected back-ends select the op-by-op ops."""
+    from unboundednerfpytorch_amd import voxgo_model as vm
+    from unboundednerfpytorch_amd.fourier_model import FourierGridModel
+    kw = dict(xyz_min=[-1, -1, -1], xyz_max=[1, 1, 1], num_voxels=12 ** 3, num_voxels_base=12 ** 3, alpha_init=1e-2, fast_color_thres=1e-4)
+    direct = vm.DirectVoxGO(rgbnet_dim=12, rgbnet_direct=True, **kw)
+    p = direct._native_params()
+    assert p is not None and len(p) == 8 and p[0] is direct.density.grid and p[1] is direct.k0.grid
+    assert vm.DirectVoxGO(rgbnet_dim=9, rgbnet_direct=False, **kw)._native_params() is None            # residual colour
+    assert vm.DirectVoxGO(rgbnet_dim=0, **kw)._native_params() is None                                 # coarse stage: no rgbnet
+    assert vm.DirectVoxGO(rgbnet_dim=12, rgbnet_direct=True, rgbnet_depth=4, **kw)._native_params() is None      # not the default network
+    with torch.no_grad():
+        assert direct._native_params() is None
+    direct.k0.grid.requires_grad_(False)
+    assert direct._native_params() is None
+    direct.k0.grid.requires_grad_(True)
+    direct.native_step = False
+    assert direct._native_params() is None
+    dc = vm.DirectContractedVoxGO(rgbnet_dim=12, **kw)
+    assert dc._native_params() is not None
+    fg = dict(xyz_min=[-1, -1, -1], xyz_max=[1, 1, 1], num_voxels_density=10 ** 3, num_voxels_base_density=10 ** 3, num_voxels_rgb=10 ** 3,
+              num_voxels_base_rgb=10 ** 3, num_voxels_viewdir=-1, alpha_init=1e-4, fast_color_thres=1e-4, fourier_freq_num=2, rgbnet_dim=12)
+    m = FourierGridModel(**fg)
+    p = m._native_params()
+    assert p is not None and p[0].shape[0] == 5 and p[1].shape[0] == 5
+    import types
+    be = types.SimpleNamespace(Raw2Alpha=None, Alphas2Weights=None, grid_query=lambda *a: None, total_variation_cuda=None, render_utils_cuda=None)
+    assert FourierGridModel(backend=be, **fg)._native_params() is None                                   # injected back-end: op-by-op
+
+
 def test_rgbnet_linears_recognises_only_the_default_network():
     from unboundednerfpytorch_amd import ops
     nn = torch.nn
