@@ -228,3 +228,46 @@ def test_c_oracle_pinned_on_reference_kernels(golden_dir):
     import json
     fma = json.loads(bytes(z["report_json"]).decode())
     assert fma and all(v == 0 for v in fma.values())
+
+
+def test_c_oracle_f64_pinned_on_reference_kernels(golden_dir):
+    """oracle/ref_ops_f64.c -- the DOUBLE instantiation (the reference dispatches AT_DISPATCH_FLOATING_TYPES) -- against outputs of
+    the reference's own kernels called with double tensors on an MI355X (tests/golden/gen_native_golden_f64.py ->
+    native_ops_f64.npz): all 18 functions.  Bit-exact for everything but the raw2alpha family -- which shows that the restatement
+    has the reference's float intermediates in the right places (a version that computed "everything in double" differs in
+    every function that has one) -- and for that family exp / pow of glibc against the device libm: exp and the gradients within
+    4 ulp of a double, alpha = 1 - pow(1 + e, -interval) within 1e-15 absolute."""
+    import json
+    import native_cases as nc
+    gold, z = nc.load_golden(os.path.join(golden_dir, "native_ops_f64.npz"))
+    orc = {nc.RU: ref_ops.render_utils_cuda, nc.TV: ref_ops.total_variation_cuda, nc.UB: ref_ops.ub360_utils_cuda,
+           nc.AD: ref_ops.adam_upd_cuda}
+    got = nc.run_all(orc, scale=1, chain_from=gold, dtype=torch.float64)
+    n_f64 = 0
+    for name in gold:
+        assert len(got[name]) == len(gold[name]) > 0, name
+        for k, (a, b) in enumerate(zip(gold[name], got[name])):
+            key = "%s[%d]" % (name, k)
+            assert a.shape == b.shape and a.dtype == b.dtype and a.dtype in (torch.float64, torch.int64, torch.bool), key
+            n_f64 += a.dtype == torch.float64
+            if name not in nc.TRANSCENDENTAL:
+                assert np.array_equal(a.numpy(), b.numpy(), equal_nan=True), key
+                continue
+            an, bn = a.numpy(), b.numpy()
+            assert np.array_equal(np.isfinite(an), np.isfinite(bn)), key
+            fin = np.isfinite(an)
+            assert np.array_equal(an[~fin], bn[~fin]), key
+            if name in ("raw2alpha", "raw2alpha_nonuni") and k == 1:
+                np.testing.assert_allclose(bn[fin], an[fin], rtol=0, atol=1e-15, err_msg=key)
+            else:
+                ai, bi = an[fin].view(np.int64), bn[fin].view(np.int64)        # (same sign: exp > 0; gradients compared where both finite)
+                same_sign = np.signbit(an[fin]) == np.signbit(bn[fin])
+                assert same_sign.all() and np.abs(ai - bi).max() <= 4, key
+    assert n_f64 >= 25
+    fma = json.loads(bytes(z["report_json"]).decode())
+    assert fma and all(v == 0 for v in fma.values())      # the reference's two contraction builds agree on every output
+    # the float32 entry points are refused doubles mixed with floats, and the ops without a reference counterpart stay fp32
+    with pytest.raises(AssertionError):
+        ref_ops.raw2alpha_nonuni(torch.zeros(4, dtype=torch.float64), 0.0, torch.zeros(4))
+    with pytest.raises(AssertionError):
+        ref_ops.segment_cumsum(torch.zeros(4, dtype=torch.float64), torch.zeros(4, dtype=torch.float64), torch.zeros(4, dtype=torch.int64))
