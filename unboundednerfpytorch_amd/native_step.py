@@ -37,12 +37,15 @@ class VoxGOStep(torch.autograd.Function):
     @staticmethod
     def forward(ctx, density_grid, k0_grid, w0, b0, w1, b1, w2, b2, pack):
         cfg, mode = pack['cfg'], pack['mode']
-        rays_o, rays_d, viewdirs = pack['rays_o'], pack['rays_d'], pack['viewdirs']
+        # (dense copies where a caller hands in views: the op-by-op ops do the same)
+        rays_o, rays_d, viewdirs = (pack[k].contiguous() for k in ('rays_o', 'rays_d', 'viewdirs'))
+        target, viewfreq = pack['target'].contiguous(), pack['viewfreq'].contiguous()
+        bg = pack['bg'].contiguous() if pack.get('bg') is not None else None
         ws_ = [x.contiguous() for x in (w0, b0, w1, b1, w2, b2)]
         f32 = [("density grid", density_grid), ("rays_o", rays_o), ("rays_d", rays_d), ("viewdirs", viewdirs),
-               ("target", pack['target']), ("viewfreq", pack['viewfreq'])] + [("rgbnet", x) for x in ws_]
-        if pack.get('bg') is not None:
-            f32.append(("bg", pack['bg']))
+               ("target", target), ("viewfreq", viewfreq)] + [("rgbnet", x) for x in ws_]
+        if bg is not None:
+            f32.append(("bg", bg))
         mask = pack.get('mask')
         _lib.require_cuda(*f32, *([("mask", mask)] if mask is not None else []))
         _lib.require_f32(*f32, ("k0 grid", k0_grid))
@@ -59,10 +62,10 @@ class VoxGOStep(torch.autograd.Function):
         R = rays_o.shape[0]
         t = pack.get('t')
         S = int(cfg['slots']) if mode == 'dvgo' else t.numel()
-        C, W, pe = k0_grid.shape[1], ws_[0].shape[0], pack['viewfreq'].numel()
+        C, W, pe = k0_grid.shape[1], ws_[0].shape[0], viewfreq.numel()
         if tuple(ws_[0].shape) != (W, C + 3 + 6 * pe) or tuple(ws_[2].shape) != (W, W) or tuple(ws_[4].shape) != (3, W):
             raise RuntimeError("VoxGOStep: rgbnet weights must be [W, C+3+6pe], [W,W], [3,W]")
-        if viewdirs.shape != (R, 3) or rays_d.shape != (R, 3) or pack['target'].shape != (R, 3):
+        if viewdirs.shape != (R, 3) or rays_d.shape != (R, 3) or target.shape != (R, 3) or (bg is not None and bg.shape != (R, 3)):
             raise RuntimeError("VoxGOStep: rays_o, rays_d, viewdirs, target must all be [R,3]")
         key = (dev, R * S)
         sc = _grid.TrainSampleVox._scratch.get(key)
@@ -100,10 +103,6 @@ class VoxGOStep(torch.autograd.Function):
             s.t_table = t.data_ptr()
         s.coef8[:] = [float(x) for x in pack['coef']]
         s.n_rays = R
-        rays_o, rays_d, viewdirs = rays_o.contiguous(), rays_d.contiguous(), viewdirs.contiguous()
-        target = pack['target'].contiguous()
-        bg = pack['bg'].contiguous() if pack.get('bg') is not None else None
-        viewfreq = pack['viewfreq'].contiguous()
         s.density_grid, s.k0_grid = density_grid.data_ptr(), k0_grid.data_ptr()
         s.xyz_min, s.xyz_max = pack['xyz_min'].data_ptr(), pack['xyz_max'].data_ptr()
         s.k0_xyz_min, s.k0_xyz_max = pack['k0_xyz_min'].data_ptr(), pack['k0_xyz_max'].data_ptr()
