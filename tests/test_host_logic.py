@@ -313,6 +313,106 @@ def test_rgbnet_features_on_the_host_is_the_reference_chain():
     assert isinstance(rows, tuple) and rows[0] is viewdirs and rows[2] is ray_id
 
 
+@pytest.mark.parametrize("mode", ["fourier", "dvgo", "dcvgo"])
+def test_native_step_host_side_runs_over_a_stand_in_library(mode, monkeypatch):
+    """native_step.VoxGOStep's host side -- input checks, struct fill for the three modes, buffer sizing after the one host read,
+    the returned arrays' shapes, and BOTH backward routes (all gradients returned; or the k0 gradient assigned and handed to the
+    `k0_grad_ready` callback between the two halves, the node then reporting none for k0) -- with the C entry points replaced by a
+    stand-in that only fills M1 / M2, on CPU tensors, incl. strided views as ray inputs.  The kernels' results are the GPU tests'
+    business (test_gpu_voxgo_train.py, test_gpu_train_scale.py)."""
+    import ctypes
+    from unboundednerfpytorch_amd import _lib, native_step, voxgo_model as vm
+    from unboundednerfpytorch_amd.fourier_model import FourierGridModel
+    calls = []
+
+    class StandIn:
+        def ugrid_voxgo_step_sample(self, ps, st):
+            s = ctypes.cast(ps, ctypes.POINTER(_lib.VoxgoStep)).contents
+            assert s.mode == {"dvgo": 0, "dcvgo": 1, "fourier": 2}[mode] and s.n_rays == 8 and s.C == 12 and s.pe == 4 and s.width == 128
+            assert (s.P, s.kP, s.freq_num) == ((5, 5, 2) if mode == "fourier" else (1, 1, 0))
+            assert bool(s.mask) == (mode != "fourier") and bool(s.t_table) == (mode != "dvgo") and s.slots == (20 if mode == "dvgo" else 16)
+            s.M1, s.M2 = 40, 17
+            calls.append("sample")
+            return 0
+
+        def ugrid_voxgo_step_ws_floats(self, ps):
+            return 1000
+
+        def ugrid_voxgo_step_bwd_ws_floats(self, ps):
+            return 1000
+
+        def __getattr__(self, name):
+            if name.startswith("ugrid_voxgo_step_"):
+                def f(ps, st, _n=name[len("ugrid_voxgo_step_"):]):
+                    s = ctypes.cast(ps, ctypes.POINTER(_lib.VoxgoStep)).contents
+                    assert s.ws and s.logits and s.weights2 and (_n == "forward" or (s.grad_loss and s.ws_bwd and s.grad_k0_grid and s.g_w2))
+                    calls.append(_n)
+                    return 0
+                return f
+            if name == "ugrid_touch_words":
+                return lambda n: (n + 2047) // 2048
+            raise AttributeError(name)
+
+    monkeypatch.setattr(native_step, "_L", StandIn())
+    monkeypatch.setattr(_lib, "require_cuda", lambda *a: None)
+    monkeypatch.setattr(_lib, "require_cuda_grid", lambda *a: _lib.is_channels_last(a[0][1]))
+    monkeypatch.setattr(_lib, "stream_of", lambda t: None)
+    monkeypatch.setattr(_lib, "guard", lambda d: _lib._NO_GUARD)
+    monkeypatch.setattr(_lib, "empty_like_grid", lambda shape, cl, dev, zero=False: torch.zeros(shape).contiguous(
+        memory_format=torch.channels_last_3d if cl else torch.contiguous_format))
+    R = 8
+    if mode == "fourier":
+        m = FourierGridModel(xyz_min=[-1, -1, -1], xyz_max=[1, 1, 1], num_voxels_density=10 ** 3, num_voxels_base_density=10 ** 3,
+                             num_voxels_rgb=10 ** 3, num_voxels_base_rgb=10 ** 3, num_voxels_viewdir=-1, alpha_init=1e-4, fast_color_thres=1e-4,
+                             fourier_freq_num=2, rgbnet_dim=12)
+        cfg = {"act_shift": 0.0, "interval": 0.5, "thres": 1e-4, "scene_center": [0., 0., 0.], "scene_radius": [1., 1., 1.], "bg_len": 0.2,
+               "norm_l2": False, "freq_num": 2, "k0_freq_num": 2}
+        t, bg, mask = torch.linspace(0, 1, 16), None, None
+    else:
+        kw = dict(xyz_min=[-1, -1, -1], xyz_max=[1, 1, 1], num_voxels=12 ** 3, num_voxels_base=12 ** 3, alpha_init=1e-2, fast_color_thres=1e-4,
+                  rgbnet_dim=12)
+        m = vm.DirectVoxGO(rgbnet_direct=True, **kw) if mode == "dvgo" else vm.DirectContractedVoxGO(**kw)
+        cfg = {"act_shift": 0.0, "interval": 0.5, "thres": 1e-4, "mask_scale": [1., 1., 1.], "mask_shift": [0., 0., 0.]}
+        cfg.update({"near": 0.2, "far": 1e9, "stepdist": 0.1, "slots": 20} if mode == "dvgo" else
+                   {"scene_center": [0., 0., 0.], "scene_radius": [1., 1., 1.], "bg_len": 0.2, "norm_l2": False, "dist_thres": 0.01})
+        t, bg, mask = (None if mode == "dvgo" else torch.linspace(0, 1, 16)), torch.rand(R, 3), m.mask_cache.mask
+    params = m._native_params()
+
+    def pack():
+        return {"mode": mode, "cfg": cfg, "t": t, "rays_o": torch.zeros(R, 3), "rays_d": torch.ones(R, 6)[:, ::2], "viewdirs": torch.ones(3, R).t(),
+                "viewfreq": m.viewfreq, "xyz_min": m.xyz_min, "xyz_max": m.xyz_max, "k0_xyz_min": m.k0.xyz_min, "k0_xyz_max": m.k0.xyz_max,
+                "mask": mask, "target": torch.zeros(R, 3), "bg": bg, "coef": (1, 0, 0, 0, 0, 0, 0.1, R)}
+    pk = pack()
+    loss, mse = native_step.VoxGOStep.apply(*params, pk)
+    assert loss.requires_grad and not mse.requires_grad and loss.shape == mse.shape == ()
+    out = pk["out"]
+    assert out["weights"].shape == out["ray_id"].shape == (17,) and out["raw_logits"].shape == (17, 3) and out["loss_mse"].shape == (2,)
+    assert out["alphainv_last"].shape == (R,) and out["rgb_marched"].shape == (R, 3) and (out["inner"] is None) == (mode != "dcvgo")
+    loss.backward()
+    assert all(p.grad is not None and p.grad.shape == p.shape for p in params)
+    assert calls == ["sample", "forward", "backward"]
+    # the mid-backward route: the callback sees the k0 gradient assigned, the node returns none for k0
+    del calls[:]
+    for p in params:
+        p.grad = None
+    pk = pack()
+    seen = []
+    pk["k0_grad_ready"] = lambda prm: seen.append((prm is m.k0.grid, prm.grad is not None))
+    native_step.VoxGOStep.apply(*params, pk)[0].backward()
+    assert seen == [(True, True)] and calls == ["sample", "forward", "backward_k0", "backward_density"]
+    assert m.k0.grid.grad is not None and m.density.grid.grad is not None
+    # ... and not over a gradient that is already accumulated (it has to be ADDED by autograd then)
+    del calls[:], seen[:]
+    pk = pack()
+    pk["k0_grad_ready"] = lambda prm: seen.append(1)
+    native_step.VoxGOStep.apply(*params, pk)[0].backward()
+    assert seen == [] and calls[-1] == "backward"
+    with pytest.raises(RuntimeError, match=r"\[R,3\]"):
+        bad = pack()
+        bad["target"] = torch.zeros(R + 1, 3)
+        native_step.VoxGOStep.apply(*params, bad)
+
+
 def test_native_step_selection_is_host_logic():
     """Which configurations take native_step.VoxGOStep is decided on the host from the module's own state (no device needed): the
     default 3-layer rgbnet fed by all of k0, every parameter trainable, gradients on, the HIP lookups (no injected query function);
