@@ -37,7 +37,8 @@ N_CU, N_SIMD, CLK_HZ = 256, 1024, 2.4e9
 L1_PEAK_GBS = N_CU * 64 * CLK_HZ / 1e9          # vector L1 / texture path, NOMINAL: 64 B per clock per CU = 39.3 TB/s
 # ... and as MEASURED on an MI355X by tools/microbench/l1_dwordx4.hip (pure L1-hit global_load_dwordx4 stream on every CU;
 # profiles/r03/microbench_l1_dwordx4.json); None until that file exists
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r05")
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r06")        # this round's counters; older rounds' files are used only when they were
+PROFILE_FALLBACK = ("r05",)                                # taken on the SAME device code (the hash check below decides)
 MFMA_F16_PEAK_TFLOPS = 2500.0       # dense f16/bf16 MFMA peak
 VALU_PEAK_GINST = N_SIMD * CLK_HZ / 2 / 1e9     # one wave64 VALU instruction per 2 cycles per SIMD
 
@@ -396,6 +397,18 @@ def kernel_ms(timing, steps):
             "render_shade": sum(ev[-2].elapsed_time(ev[-1]) for ev, _ in timing) / steps}
 
 
+def _profile_path(name, code=None):
+    """profiles/<this round>/<name>; if it is absent (or holds counters of another device code) and an earlier round's file of
+    that name was taken on `code`, that one -- static counters stay valid exactly as long as the kernels' binary does"""
+    first = os.path.join(PROFILE_DIR, name)
+    cands = [first] + [os.path.join(os.path.dirname(PROFILE_DIR), r, name) for r in PROFILE_FALLBACK]
+    for c in cands:
+        j = _load_json(c)
+        if j is not None and (code is None or j.get("device_code_sha16") == code):
+            return c
+    return first
+
+
 def _load_json(path):
     try:
         return json.load(open(path))
@@ -423,9 +436,9 @@ def roofline_block(kern, M, R, S, shade_passes, frame_rays=None, P=7, ms_per_ste
     64 B) + WRITE_SIZE.  VALU: instruction counts x 2 clocks per SIMD.  Matrix pipe: SQ_VALU_MFMA_BUSY_CYCLES.
     Static counters are merged ONLY when taken on the same device code (`device_code_sha16` = sha256 of .hip_fatbin); times are
     live HIP events of this run."""
-    ppath = os.path.join(PROFILE_DIR, "pmc_summary.json")
-    pmc = _load_json(ppath) or {}
     code = device_code_sha16()
+    ppath = _profile_path("pmc_summary.json", code)
+    pmc = _load_json(ppath) or {}
     pmc_refused = None
     if pmc and pmc.get("device_code_sha16") != code:
         pmc_refused = "counters of %s were taken on device code %s, this library is %s" % (
@@ -566,13 +579,14 @@ def hbm_roofline_entry(r):
            "note": "ugrid_tv_adam_dense_cl on the S3 k0 grid (P = 9, C = 12, 200^3, channel-last): 7 arrays x 3.456e9 B, each byte once; "
                    "frac = algorithmic bytes / time / 8 TB/s (the guide's spec peak; ~6.3 TB/s is what it calls achievable: %.2f of that)"
                    % (r["achieved"] / 6300.0)}
-    p = _load_json(os.path.join(PROFILE_DIR, "tv_adam_dense_pmc.json"))
+    tpath = _profile_path("tv_adam_dense_pmc.json", device_code_sha16())
+    p = _load_json(tpath)
     if p and p.get("device_code_sha16") == device_code_sha16():
         out["traffic"] = p.get("hbm_bytes")
         out["traffic_read_bytes"], out["traffic_write_bytes"] = p.get("hbm_read_bytes"), p.get("hbm_write_bytes")
         out["traffic_over_algorithmic"] = p.get("hbm_bytes") / float(r["algorithmic_bytes"]) if p.get("hbm_bytes") else None
         out["traffic_GBps"] = p.get("hbm_bytes") / (r["ms"] * 1e-3) / 1e9 if p.get("hbm_bytes") else None
-        out["pmc_source"] = "profiles/r05/tv_adam_dense_pmc.json"
+        out["pmc_source"] = os.path.relpath(tpath, ROOT)
     elif p:
         out["pmc_refused"] = "counters were taken on device code %s" % p.get("device_code_sha16")
     return out
@@ -865,9 +879,12 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rays_per_sec": R / (dt / args.steps),
-            "config": {"workload": "%s: FourierGridModel render, R=%dx%d rays x S=%d samples, G=%d^3, F=%d (P=%d), C=12, "
-                                   "rgbnet 39-128-128-3, stepsize %.3g, thres 1e-4, %s"
-                                   % (args.scene.upper(), fb.W, fb.H, S, G, args.freq, 1 + 2 * args.freq, fb.stepsize, scene_desc[args.scene]),
+            "config": {"workload": "%s %dx%dx%d G%d F%d(P%d) C12 rgbnet 39-128-128-3 f32 stepsize %.3g thres 1e-4 %s"
+                                   % (args.scene.upper(), fb.W, fb.H, S, G, args.freq, 1 + 2 * args.freq, fb.stepsize,
+                                      {"s1": "white-noise grids", "s1b": "trained-like fields"}[args.scene]),
+                       "workload_long": "%s: FourierGridModel render, R=%dx%d rays x S=%d samples, G=%d^3, F=%d (P=%d), C=12, "
+                                        "rgbnet 39-128-128-3, stepsize %.3g, thres 1e-4, %s"
+                                        % (args.scene.upper(), fb.W, fb.H, S, G, args.freq, 1 + 2 * args.freq, fb.stepsize, scene_desc[args.scene]),
                        "rays": R, "samples_per_ray": S, "survivors_M": M, "survivor_frac": M / float(R * S),
                        "terminated_ray_frac": term_frac, "chunks_per_frame": n_chunks,
                        "step": "ray generation + march + shade + %s" % (
@@ -970,7 +987,126 @@ def main():
                 res["roofline_hbm"] = hbm_roofline_entry(s3["roofline_tv_adam_dense"])
         res["secondary_voxgo_train_steps"] = voxgo_train_block()
     if rank == 0:
-        print(json.dumps(res))
+        line = compact_line(res)
+        print(json.dumps(line, separators=(",", ":")))
+
+
+LINE_BUDGET = 4096          # bytes: the driver parses the LAST stdout line; a 22 KB line (round 5) did not parse
+
+
+def _num(x, nd=4):
+    """a float rounded to nd significant digits (the detail file keeps full precision); everything else unchanged"""
+    if isinstance(x, float) and math.isfinite(x) and x != 0.0:
+        return float("%.*g" % (nd, x))
+    return x
+
+
+def _pick(d, keys, nd=4):
+    return {k: _num(d.get(k), nd) for k in keys if isinstance(d, dict) and k in d}
+
+
+def write_detail(res, path=None):
+    """Everything bench.py measured (per-kernel blocks, fp64 ground truth, arbitration, scaling_proxy, per-output parity statistics of
+    the secondaries) goes to bench_detail.json next to this file -- and, on a gpurun box, to gpurun_out/ so that it travels back.
+    Returns (path relative to the repo, sha16 of the bytes)."""
+    blob = json.dumps(res, indent=1, sort_keys=True).encode()
+    path = path or os.environ.get("UGRID_BENCH_DETAIL") or os.path.join(ROOT, "bench_detail.json")
+    try:
+        with open(path, "wb") as f:
+            f.write(blob)
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out_dir) and os.path.dirname(os.path.abspath(path)) == ROOT:
+            with open(os.path.join(out_dir, os.path.basename(path)), "wb") as f:
+                f.write(blob)
+    except OSError as e:            # a read-only tree must not cost the line
+        return {"path": None, "error": str(e), "sha16": hashlib.sha256(blob).hexdigest()[:16], "bytes": len(blob)}
+    return {"path": os.path.relpath(path, ROOT), "sha16": hashlib.sha256(blob).hexdigest()[:16], "bytes": len(blob)}
+
+
+def compact_line(res, detail_path=None):
+    """The ONE line the driver parses: the contract's keys, `roofline` / `roofline_hbm` / `cpu_baseline` as numbers only, one
+    number (ms per step) per secondary, and where the rest went (`detail`: bench_detail.json + its sha16).  Always < LINE_BUDGET
+    bytes (tests/test_host_logic.py::test_bench_line_fits_the_driver)."""
+    line = {k: _num(res.get(k), 6) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                             "scaling", "vs_baseline", "dtype", "data", "rays_per_sec")}
+    cfg = res.get("config") or {}
+    line["config"] = {"workload": str(cfg.get("workload", ""))[:119]}
+    line["config"].update(_pick(cfg, ("rays", "samples_per_ray", "survivors_M", "survivor_frac", "chunks_per_frame")))
+    line["config"]["parallelism"] = str(cfg.get("parallelism", ""))[:60]
+    line["config"]["step"] = str(cfg.get("step", ""))[:100]
+    line["kernels"] = {k: _num(v.get("ms")) for k, v in (res.get("kernels") or {}).items()}
+    for k in ("renderer", "lib_sha16", "device_code_sha16", "frame_sha16", "assembled_frame_equals_single_rank_frame"):
+        if k in res:
+            line[k] = res[k]
+    rf = res.get("roofline")
+    if isinstance(rf, dict):
+        line["roofline"] = _pick(rf, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ta_busy_measured", "hbm_frac_measured",
+                                      "frac_of_hbm_algorithmic"))
+        pk = rf.get("per_kernel") or {}
+        line["roofline"]["per_kernel"] = {k: _pick(v, ("ms", "l1_frac", "hbm_frac", "mfma_frac", "ta_busy_measured", "mfma_pipe_busy", "valu_issue_busy",
+                                                       "rocprofv3_avg_ms"), 3) for k, v in pk.items()}
+    else:
+        line["roofline"] = None
+    rh = res.get("roofline_hbm")
+    if isinstance(rh, dict):
+        line["roofline_hbm"] = _pick(rh, ("kernel", "bound", "achieved", "peak", "unit", "frac", "ms", "algorithmic_bytes", "traffic"))
+    cb = res.get("cpu_baseline")
+    if isinstance(cb, dict):
+        if "error" in cb:
+            line["cpu_baseline"] = {"error": str(cb["error"])[:200]}
+        else:
+            c = _pick(cb, ("value", "unit", "cores", "host_cores", "kind"))
+            c["sample"] = str(cb.get("sample", ""))[:60]
+            c["linf"] = {"rgb": _num(cb.get("gpu_vs_oracle_linf_rgb"), 3), "depth": _num(cb.get("gpu_vs_oracle_linf_depth"), 3),
+                         "alphainv_last": _num(cb.get("gpu_vs_oracle_linf_alphainv_last"), 3)}
+            line["cpu_baseline"] = c
+    if isinstance(res.get("weak_scaling"), dict):
+        line["weak_scaling"] = _pick(res["weak_scaling"], ("value", "unit", "ms_per_step"))
+    # one number per secondary: ms per step (a frame or a training step); the workloads are named in DESIGN.md / the detail file
+    sec = {}
+
+    def put(name, d, *path):
+        for k in path:
+            d = d.get(k) if isinstance(d, dict) else None
+        if isinstance(d, dict) and "error" in d:
+            sec[name] = "error"
+        elif isinstance(d, dict) and "ms_per_step" in d:
+            sec[name] = _num(d["ms_per_step"])
+    put("s1b_render", res.get("secondary"))
+    put("s1b_s668_render", res.get("secondary_garden_single_sampling"))
+    put("truck_render", res.get("secondary_truck_render"))
+    tr = res.get("secondary_truck_render")
+    if isinstance(tr, dict) and isinstance(tr.get("kernels"), dict):
+        for k, v in tr["kernels"].items():
+            sec["truck_" + k.replace("render_", "")] = _num(v.get("ms"))
+        g = tr.get("gpu_vs_oracle") or {}
+        if g:
+            sec["truck_linf_rgb"] = _num((g.get("rgb_marched") or {}).get("linf_all"), 3)
+    s1b = res.get("secondary")
+    if isinstance(s1b, dict) and isinstance(s1b.get("kernels"), dict):
+        sec["s1b_shade"] = _num((s1b["kernels"].get("render_shade") or {}).get("ms"))
+    put("s3_train_dense_tv", res.get("secondary_s3_train_step"), "dense_tv")
+    put("s3_train_masked_tv", res.get("secondary_s3_train_step"), "masked_tv")
+    vg = res.get("secondary_voxgo_train_steps")
+    if isinstance(vg, dict):
+        if "error" in vg:
+            sec["voxgo_train"] = "error"
+        for k in vg:
+            put(k, vg, k)
+    if sec:
+        line["secondary_ms"] = sec
+    px = res.get("scaling_proxy")
+    if isinstance(px, dict) and isinstance(px.get("N=8"), dict):
+        b = px["N=8"].get("contiguous_bands") or {}
+        line["scaling_proxy_N8"] = _pick(b, ("slowest_share_ms", "predicted_speedup"))
+    line["detail"] = write_detail(res, detail_path)
+    n = len(json.dumps(line, separators=(",", ":")))
+    if n >= LINE_BUDGET:            # never print an unparseable line: drop the optional blocks, largest first
+        for k in ("secondary_ms", "scaling_proxy_N8", "weak_scaling", "roofline_hbm"):
+            line.pop(k, None)
+            if len(json.dumps(line, separators=(",", ":"))) < LINE_BUDGET:
+                break
+    return line
 
 
 def cpu_baseline(cpu_state, rays, gpu_out, stepsize, S, n_chunks, device=None, ref_gpu=True):
@@ -1023,10 +1159,11 @@ def cpu_baseline(cpu_state, rays, gpu_out, stepsize, S, n_chunks, device=None, r
     errs = {k: torch.cat(v) for k, v in errs.items()}
     stats = parity_stats(errs, torch.cat(margins), sq)
     out = {"value": n_samples / t_total / 1e6, "unit": "Msamples/s", "cores": cores, "host_cores": os.cpu_count(), "kind": kind,
-           "sample": "%d chunks x 8192 rays x %d samples of the same frame (%s, torch CPU grid_sample path, %d threads: the "
-                     "fastest setting on this host), 1 warm-up chunk"
-                     % (n_chunks, S, "the reference's own FourierGridModel.forward over the C restatement of its extension modules"
-                        if kind == "reference" else "oracle/model_oracle.py", cores),
+           "sample": "%dx8192 rays x %d samples of the same frame, %d threads" % (n_chunks, S, cores),
+           "sample_long": "%d chunks x 8192 rays x %d samples of the same frame (%s, torch CPU grid_sample path, %d threads: the "
+                          "fastest setting on this host), 1 warm-up chunk"
+                          % (n_chunks, S, "the reference's own FourierGridModel.forward over the C restatement of its extension modules"
+                             if kind == "reference" else "oracle/model_oracle.py", cores),
            "rays_per_sec": n_chunks * chunk / t_total,
            "gpu_vs_oracle_linf_rgb": stats["rgb_marched"]["linf_all"], "gpu_vs_oracle_linf_depth": stats["depth"]["linf_all"],
            "gpu_vs_oracle_linf_alphainv_last": stats["alphainv_last"]["linf_all"],

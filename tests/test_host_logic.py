@@ -768,7 +768,7 @@ def test_bench_strong_scaled_step_over_gloo(world, contiguous, hw, dg):
         assert max(shares) - min(shares) <= 8 * hw[1]           # dealt block rows: balanced to one 8-pixel-high row of the image
 
 
-def test_bench_launches_itself_for_n_gt_1():
+def test_bench_launches_itself_for_n_gt_1(tmp_path):
     """`python bench.py --gpus 2` with no launcher in the environment (how the driver starts the N = 1 line, with N = 2):
     bench.py re-executes itself through torch.distributed.run on 127.0.0.1 and rank 0 prints the ONE JSON line.  CI runs it
     with the CPU stand-in renderer over gloo (UGRID_BENCH_STANDIN); on a GPU box the same path runs the HIP renderer."""
@@ -777,20 +777,61 @@ def test_bench_launches_itself_for_n_gt_1():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["UGRID_BENCH_STANDIN"] = "bench_standin:Renderer"
     env["OMP_NUM_THREADS"] = "1"
+    detail = str(tmp_path / "bench_detail.json")
+    env["UGRID_BENCH_DETAIL"] = detail
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--height", "40",
                         "--width", "104"], env=env, capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
+    assert len(lines[0]) < 4096                 # the driver parses this line: round 5's 22 KB line was recorded as unparsed
     res = json.loads(lines[0])
     assert res["n_gpus"] == 2 and res["steps"] == 2 and res["scaling"] == "strong"
-    assert res["assembled_frame_equals_single_rank_frame"] is True
-    assert sum(r["rays"] for r in res["per_rank"]) == 40 * 104 and "stand-in" in res["renderer"]
+    assert res["assembled_frame_equals_single_rank_frame"] is True and "stand-in" in res["renderer"]
     assert "frame assembly" in res["config"]["step"] and res["weak_scaling"]["value"] > 0
+    # everything else is in the detail file the line names (path relative to the repo root + sha16 of its bytes)
+    import hashlib
+    blob = open(detail, "rb").read()
+    assert res["detail"]["sha16"] == hashlib.sha256(blob).hexdigest()[:16] and res["detail"]["bytes"] == len(blob)
+    full = json.loads(blob)
+    assert sum(r["rays"] for r in full["per_rank"]) == 40 * 104 and full["value"] == pytest.approx(res["value"], rel=1e-4)
     # a wrong launcher environment is refused, not silently run at another size
     env2 = dict(env, WORLD_SIZE="3", RANK="0")
     p2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=120)
     assert p2.returncode != 0 and "WORLD_SIZE=3" in (p2.stderr + p2.stdout)
+
+
+def test_bench_line_fits_the_driver(tmp_path):
+    """the ONE line stays under 4 KB whatever the run measured -- checked on the largest result bench.py has ever
+    produced (round 5's 22 KB line, profiles/r05/bench_s1_line.json) -- carries every key of the contract plus `roofline` and
+    `cpu_baseline` as numbers (no prose), one number per secondary, and names the detail file that holds the rest."""
+    import json
+    import bench
+    full = json.load(open(os.path.join(ROOT, "profiles", "r05", "bench_s1_line.json")))
+    assert len(json.dumps(full)) > 20000
+    line = bench.compact_line(full, str(tmp_path / "d.json"))
+    text = json.dumps(line, separators=(",", ":"))
+    assert len(text) < bench.LINE_BUDGET == 4096 and "\n" not in text
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline", "kernels", "detail"):
+        assert k in line, k
+    assert len(line["config"]["workload"]) < 120 and set(line["kernels"]) == {"render_march", "render_shade"}
+    rf = line["roofline"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ta_busy_measured", "hbm_frac_measured", "frac_of_hbm_algorithmic"):
+        assert k in rf, k
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3 and rf["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-3)
+    assert not any(isinstance(v, str) and len(v) > 24 for v in rf.values())            # numbers and names only
+    assert line["roofline_hbm"]["frac"] == pytest.approx(full["roofline_hbm"]["frac"], rel=1e-3)
+    cb = line["cpu_baseline"]
+    assert cb["kind"] in ("reference", "port") and cb["cores"] == 8 and cb["value"] > 0 and set(cb["linf"]) == {"rgb", "depth", "alphainv_last"}
+    sec = line["secondary_ms"]
+    assert sec["truck_render"] == pytest.approx(full["secondary_truck_render"]["ms_per_step"], rel=1e-3)
+    assert sec["dvgo_lego_fine"] > 0 and sec["s3_train_masked_tv"] > 0 and sec["s1b_s668_render"] > 0
+    assert json.load(open(tmp_path / "d.json")) == full
+    # a result bloated far past anything real still prints a parseable line: optional blocks are dropped, the contract's keys never
+    fat = dict(full, secondary_voxgo_train_steps={("leg%03d" % i): {"ms_per_step": 1.0 + i} for i in range(400)})
+    line2 = bench.compact_line(fat, str(tmp_path / "d2.json"))
+    assert len(json.dumps(line2, separators=(",", ":"))) < 4096 and "roofline" in line2 and "cpu_baseline" in line2 and "secondary_ms" not in line2
 
 
 def test_device_code_hash_ignores_the_non_loaded_sections(tmp_path):

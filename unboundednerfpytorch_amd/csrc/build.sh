@@ -26,5 +26,7 @@ pids+=($!)
 for p in "${pids[@]}"; do wait "$p"; done   # a bare `wait` returns 0 even when a job failed
 hipcc --offload-arch=gfx950 -shared -fPIC -o ${UG_OUT:-../libugrid_hip.so} $OBJS
 # the fp64 twins of the drop-in ops: a library of its own (nothing on the rendering / training path loads it)
+# (an A/B build -- UG_OUT set -- gets its own f64 output beside it, so that parallel A/B builds never rewrite the shipped library)
+F64_OUT=${UG_OUT_F64:-${UG_OUT:+${UG_OUT%.so}_f64.so}}
 hipcc $FLAGS -c ugrid_ops_f64.hip -o $O/ugrid_ops_f64.o "$@"
-hipcc --offload-arch=gfx950 -shared -fPIC -o ${UG_OUT_F64:-../libugrid_hip_f64.so} $O/ugrid_ops_f64.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o ${F64_OUT:-../libugrid_hip_f64.so} $O/ugrid_ops_f64.o
