@@ -274,19 +274,20 @@ int ugrid_rgbnet_features(const float *k0, int32_t n_k0, const float *viewdirs, 
  * composed chain.  ray_id ascending (the model's compaction is ray-major); logits [n,3] are the rgbnet outputs before the
  * sigmoid; bg [n_rays,3] the rand_bkgd draw or NULL; target [n_rays,3]; s may be NULL: s_i = 1 - 1/(1 + t_i) then
  * (FourierGrid_model.py:649).
- * h_coef8 (HOST floats): weight_main, weight_entropy_last, weight_distortion, weight_rgbper, weight_nearclip (times the
- * data-parallel world size), near_thres, interval (= 1/n_max), n_rays (the rgbper denominator).  A weight of 0 disables
- * its term.  seg_scratch: 2*n_rays int64 (filled by the forward, read by the backward); rgb_marched [n_rays,3];
- * ray_tot [n_rays,2] (per-ray sums of w and w*s); partial [n_rays,4]; out2 = {loss, mse} on the device.
+ * h_coef9 (9 HOST floats): weight_main, weight_entropy_last, weight_distortion, weight_rgbper, weight_nearclip (times the
+ * data-parallel world size), near_thres, interval (= 1/n_max), n_rays (the rgbper denominator), weight_freq (the image-space
+ * Fourier MSE of run_train.py:255 / FourierGrid_model.py:112-129: MSE between the real parts of the 3-point FFTs over the
+ * colour axis).  A weight of 0 disables its term.  seg_scratch: 2*n_rays int64 (filled by the forward, read by the backward);
+ * rgb_marched [n_rays,3]; ray_tot [n_rays,2] (per-ray sums of w and w*s); partial [n_rays,5]; out2 = {loss, mse} on the device.
  * backward: grad_loss = the incoming scalar gradient (device); writes g_logits [n,3], g_weights [n], g_alphainv_last
  * [n_rays], g_density [n] (the nearclip term's only effect). */
 int ugrid_render_loss(const float *logits, const float *weights, const float *s, const float *t, const float *alphainv_last,
                       const float *bg, const float *target, const int64_t *ray_id, int64_t n, int64_t n_rays,
-                      const float *h_coef8, int64_t *seg_scratch, float *rgb_marched, float *ray_tot, float *partial,
+                      const float *h_coef9, int64_t *seg_scratch, float *rgb_marched, float *ray_tot, float *partial,
                       float *out2, ugrid_stream_t stream);
 int ugrid_render_loss_backward(const float *logits, const float *weights, const float *s, const float *t,
                                const float *alphainv_last, const float *bg, const float *target, const int64_t *ray_id,
-                               int64_t n, int64_t n_rays, const float *h_coef8, const int64_t *seg_scratch,
+                               int64_t n, int64_t n_rays, const float *h_coef9, const int64_t *seg_scratch,
                                const float *rgb_marched, const float *ray_tot, const float *grad_loss, float *g_logits,
                                float *g_weights, float *g_alphainv_last, float *g_density, ugrid_stream_t stream);
 
@@ -518,7 +519,7 @@ int ugrid_train_sample_compact_vox(int64_t n_rays, int32_t slots_per_ray, float 
  * Device pointers unless marked HOST.  mode 0: DirectVoxGO (near / far / stepdist / slots used), 1: DirectContractedVoxGO
  * (t_table[slots] / scene_center / scene_radius / bg_len / norm_l2 / dist_thres used), 2: FourierGridModel
  * (FourierGrid_model.py:509-672: ugrid_train_sample over the Fourier density grid, no mask cache; t_table / scene_center /
- * scene_radius / bg_len / norm_l2 and the two grids' levels used).  bg: [n_rays,3] or NULL.  coef8: see
+ * scene_radius / bg_len / norm_l2 and the two grids' levels used).  bg: [n_rays,3] or NULL.  coef9: see
  * ugrid_render_loss.  inner2 may be NULL.  ugrid_voxgo_step_sizeof = sizeof(ugrid_voxgo_step), for bindings to check their mirror. */
 typedef struct ugrid_voxgo_step {
   int32_t mode;
@@ -533,7 +534,7 @@ typedef struct ugrid_voxgo_step {
   int32_t mask_dims[3];     /* HOST */
   float mask_scale[3], mask_shift[3], scene_center[3], scene_radius[3]; /* HOST */
   float act_shift, interval, thres, near_clip, far_clip, stepdist, dist_thres;
-  float coef8[8];           /* HOST */
+  float coef9[9];           /* HOST */
   double bg_len;
   int64_t n_rays;
   const float *density_grid, *k0_grid, *xyz_min, *xyz_max, *k0_xyz_min, *k0_xyz_max;
@@ -550,7 +551,7 @@ typedef struct ugrid_voxgo_step {
   int64_t *totals;          /* [2] */
   float *alphainv_last;     /* [n_rays] */
   int64_t *seg;             /* [2 n_rays] */
-  float *rgb_marched, *ray_tot, *partial, *out2; /* [n_rays,3], [n_rays,2], [n_rays,4], [2] */
+  float *rgb_marched, *ray_tot, *partial, *out2; /* [n_rays,3], [n_rays,2], [n_rays,5], [2] */
   int64_t M1, M2;           /* written by ugrid_voxgo_step_sample */
   float *ws;
   float *density2, *alpha2, *weights2, *t2; /* [M2] */

@@ -559,6 +559,49 @@ def gen_voxgo_train():
                 float(loss), int(res["n_kept"]), res["scaled_world_size"].tolist(), int(res["scaled_n_kept"])))
 
 
+def gen_fourier_loss():
+    """The image-space Fourier loss (`weight_freq`; bicycle_single.py:57 and stump_single.py:55 use 5.0):
+    (a) the reference's own FourierMSELoss module (FourierGrid_model.py:112-129) on seeded [R,3] colours: value and gradient;
+    (b) one training forward + backward of the reference FourierGridModel on synth.TRAIN_CASE with the loss run_train.py:254-265 forms
+        under bicycle_single.py's weights that need no third-party package (weight_main 1.0, weight_freq 5.0, weight_entropy_last 0.001,
+        weight_nearclip 1.0 with near_thres = FREQ_NEAR; weight_distortion calls torch_efficient_distloss, absent from the image):
+        loss, mse, freq term and the gradient of every parameter."""
+    mod = install_stubs.import_reference("FourierGrid_model")
+    crit = mod.FourierMSELoss()
+    R = 257
+    pred = torch.from_numpy(synth.uniform(901, R * 3).reshape(R, 3)).requires_grad_(True)
+    gt = torch.from_numpy(synth.uniform(902, R * 3).reshape(R, 3))
+    val = crit(pred, gt)
+    val.backward()
+    res = {"a_loss": val.detach().numpy(), "a_grad": pred.grad.numpy().copy()}
+    c = synth.TRAIN_CASE
+    params = synth.fouriergrid_params(c["seed"], c["G"], c["F"], c["C"], viewbase_pe=c["pe"], dens_mean=c["dm"], dens_std=c["ds"])
+    model = build_reference_model(mod, c["G"], c["F"], c["C"], c["pe"], c["norm"], c["thres"], params)
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(c["seed"], c["R"])]
+    target = torch.from_numpy(synth.uniform(c["seed"] + 5, c["R"] * 3).reshape(c["R"], 3))
+    out = model(o, d, v, global_step=1, is_train=True, stepsize=c["stepsize"], render_depth=True)
+    w = synth.FREQ_WEIGHTS
+    mse = torch.nn.functional.mse_loss(out["rgb_marched"], target)                       # run_train.py:254
+    freq = crit(out["rgb_marched"], target)                                              # :255
+    loss = w["weight_main"] * mse + w["weight_freq"] * freq                              # :257
+    pout = out["alphainv_last"].clamp(1e-6, 1 - 1e-6)                                    # :258-261
+    loss = loss + w["weight_entropy_last"] * (-(pout * torch.log(pout) + (1 - pout) * torch.log(1 - pout))).mean()
+    near_mask = out["t"] < synth.FREQ_NEAR                                               # :262-268
+    density = out["raw_density"][near_mask]
+    assert len(density) > 0
+    loss = loss + w["weight_nearclip"] * (density - density.detach()).sum()
+    loss.backward()
+    res.update({"b_loss": loss.detach().numpy(), "b_mse": mse.detach().numpy(), "b_freq": freq.detach().numpy(),
+                "b_n_kept": np.int64(out["weights"].numel()), "b_n_near": np.int64(int(near_mask.sum())),
+                "b_rgb_marched": out["rgb_marched"].detach().numpy()})
+    for k, p in model.named_parameters():
+        if p.grad is not None:
+            res["b_grad." + k] = p.grad.numpy()
+    np.savez_compressed(os.path.join(OUT, "fourier_loss.npz"), **res)
+    print("fourier_loss (a) %.6f (b) loss %.6f mse %.6f freq %.6f kept %d near %d" % (
+        float(val), float(loss), float(mse), float(freq), int(res["b_n_kept"]), int(res["b_n_near"])))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)  # deterministic reduction order in F.linear / grid_sample
     gen_fouriergrid()
@@ -575,3 +618,4 @@ if __name__ == "__main__":
     gen_model_utils()
     gen_train_utils()
     gen_voxgo_train()
+    gen_fourier_loss()

@@ -204,7 +204,7 @@ def test_fp16x2_scale_derivation_is_host_arithmetic(lib_path):
 def test_shade_shape_dispatch_table_and_loss_coefficients():
     """host-only entry points: ugrid_shade_supported mirrors the (F, C, PE) instantiations of ugrid_shade.hip, and
     fourier_render.fused_shape_supported routes a reference checkpoint to the fused or the composed renderer;
-    ops.loss_coefficients packs cfg_train for ugrid_render_loss (None when a term the fused op lacks is on)."""
+    ops.loss_coefficients packs cfg_train for ugrid_render_loss (None when nearclip is on without its threshold)."""
     import os
     import types
 
@@ -223,9 +223,9 @@ def test_shade_shape_dispatch_table_and_loss_coefficients():
     assert fused_shape_supported(small) and not fused_shape_supported(odd)
     cfg = dict(weight_main=1.0, weight_entropy_last=1e-3, weight_distortion=0.01, weight_rgbper=0.02, weight_nearclip=0.5)
     c = ops.loss_coefficients(cfg, 4096, 668, near_thres=0.2, world_size=2)
-    assert c == (1.0, 1e-3, 0.01, 0.02, 1.0, 0.2, 1.0 / 668, 4096.0)
+    assert c == (1.0, 1e-3, 0.01, 0.02, 1.0, 0.2, 1.0 / 668, 4096.0, 0.0)
     assert ops.loss_coefficients(types.SimpleNamespace(**cfg), 4096, 668, near_thres=0.2, world_size=2) == c
-    assert ops.loss_coefficients(dict(cfg, weight_freq=0.1), 4096, 668, 0.2) is None          # image-space Fourier loss: composed path
+    assert ops.loss_coefficients(dict(cfg, weight_freq=5.0), 4096, 668, 0.2)[8] == 5.0         # image-space Fourier loss (bicycle_single.py:57): 9th entry
     assert ops.loss_coefficients(cfg, 4096, 668, near_thres=None) is None                     # nearclip needs its threshold
     assert ops.loss_coefficients(dict(cfg, weight_nearclip=0.0), 4096, 668)[4:6] == (0.0, 0.0)
 
@@ -362,3 +362,14 @@ def test_shade_kernel_instruction_stream_regression(lib_path):
     ops2 = [l.split()[0] for l in asm2]
     assert not [o for o in ops2 if o.startswith(("flat_", "scratch_"))]
     assert len([l for l in asm2 if l.startswith("v_mfma")]) == 132
+
+
+def test_env_tune_is_parsed_defensively():
+    """UGRID_TUNE="key=value,..." is applied at import (fourier_render): a malformed or rejected entry is warned about and skipped,
+    it must not make the package unimportable."""
+    import warnings
+    from unboundednerfpytorch_amd import fourier_render as fr
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        assert fr._apply_env_tune("tv_xcd, a=b=c ,no_such_knob=1,,tv_xcd=3") == ["tv_xcd"]
+    assert len(w) == 3 and all("UGRID_TUNE" in str(x.message) for x in w)

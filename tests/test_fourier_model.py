@@ -61,6 +61,44 @@ def test_training_forward_backward_matches_the_reference_model(golden_dir):
         assert np.array_equal(p.grad.numpy() == 0, g == 0), name
 
 
+def test_fourier_loss_matches_the_reference_class_and_its_closed_form(golden_dir):
+    """weight_freq (bicycle_single.py:57, stump_single.py:55): tests/golden/fourier_loss.npz holds the reference's own FourierMSELoss
+    (FourierGrid_model.py:112-129) on seeded colours (a) and one training step of the reference model under bicycle_single's loss
+    weights (b).  train_step.fourier_mse_loss is that loss; the closed form the HIP kernels evaluate (csrc/ugrid_train.hip: with
+    e = pred - gt, f0 = e0 + e1 + e2, f1 = e0 - (e1 + e2) / 2: mean (f0^2 + 2 f1^2) / 3, gradient 2 / (3 R) [f0 + 2 f1, f0 - f1, f0 - f1])
+    reproduces its value and gradient; training_loss with those weights reproduces the step's loss and every parameter gradient."""
+    from unboundednerfpytorch_amd import train_step as ts
+    gold = np.load(os.path.join(golden_dir, "fourier_loss.npz"))
+    R = 257
+    pred = torch.from_numpy(synth.uniform(901, R * 3).reshape(R, 3)).requires_grad_(True)
+    gt = torch.from_numpy(synth.uniform(902, R * 3).reshape(R, 3))
+    val = ts.fourier_mse_loss(pred, gt)
+    val.backward()
+    np.testing.assert_allclose(float(val), float(gold["a_loss"]), rtol=1e-6)
+    np.testing.assert_allclose(pred.grad.numpy(), gold["a_grad"], rtol=1e-5, atol=1e-9)
+    e = (pred.detach() - gt).numpy().astype(np.float64)
+    f0, f1 = e.sum(1), e[:, 0] - 0.5 * (e[:, 1] + e[:, 2])
+    np.testing.assert_allclose((f0 ** 2 + 2 * f1 ** 2).sum() / (3 * R), float(gold["a_loss"]), rtol=1e-6)
+    g = 2.0 / (3 * R) * np.stack([f0 + 2 * f1, f0 - f1, f0 - f1], 1)
+    np.testing.assert_allclose(g, gold["a_grad"], rtol=1e-5, atol=1e-9)
+    # (b) the whole step on the CPU model over the oracle back-end
+    c = synth.TRAIN_CASE
+    torch.set_num_threads(1)
+    m = build(c)
+    o, d, v = [torch.from_numpy(a) for a in synth.rays(c["seed"], c["R"])]
+    target = torch.from_numpy(synth.uniform(c["seed"] + 5, c["R"] * 3).reshape(c["R"], 3))
+    out = m(o, d, v, global_step=1, is_train=True, stepsize=c["stepsize"], render_depth=True)
+    cfg = dict(synth.FREQ_WEIGHTS, weight_distortion=0.0, weight_rgbper=0.0)
+    loss, mse = ts.training_loss(out, target, cfg, c["R"], near_thres=synth.FREQ_NEAR)
+    loss.backward()
+    assert out["weights"].numel() == int(gold["b_n_kept"]) and int((out["t"] < synth.FREQ_NEAR).sum()) == int(gold["b_n_near"])
+    np.testing.assert_allclose(float(mse), float(gold["b_mse"]), rtol=2e-6)
+    np.testing.assert_allclose(float(loss), float(gold["b_loss"]), rtol=2e-6)
+    for name, p in m.named_parameters():
+        gg = gold["b_grad." + name]
+        assert np.abs(p.grad.numpy() - gg).max() <= 2e-6 * np.abs(gg).max() + 1e-12, name
+
+
 def test_model_utilities_match_the_reference_model(golden_dir):
     c = synth.MODEL_UTILS_CASE
     gold = np.load(os.path.join(golden_dir, "fg_model_utils.npz"))

@@ -334,12 +334,14 @@ def test_train_iteration_drives_the_voxgo_models(kind):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["dvgo", "dcvgo"])
-def test_native_step_equals_the_op_by_op_step_bit_for_bit(kind):
+def test_native_step_equals_the_op_by_op_step(kind):
     """native_step.VoxGOStep (ONE autograd node, three C calls: include/ugrid_hip.h ugrid_voxgo_step_*) against the op-by-op step
     over the drop-in ops (TrainSampleVox, GridQuery, FusedRgbnet, RenderLoss; native_step = False): the same kernels on the same
-    sizes in the same order, so the forward's arrays, the loss and the rgbnet's gradients must be bit-identical and the grid
-    gradients equal up to the order of the scatter's atomic adds; then 8 train_iteration steps -- dense TV, masked TV and no-TV
-    phases, touched-line bitmaps, random background for the contracted model -- stay on the same trajectory.
+    sizes in the same order, so the forward's arrays, the loss and the rgbnet's gradients must be bit-identical (torch.equal) and the
+    grid gradients equal up to the order of the scatter's atomic adds; then 8 train_iteration steps -- dense TV, masked TV and no-TV
+    phases, touched-line bitmaps, random background for the contracted model -- stay on the same trajectory.  The non-bitwise bounds
+    are synth.NATIVE_* (profiles/r06/native_step_spread.json: <= 4 x the largest difference of 100 repetitions; two op-by-op runs
+    differ from each other by the same amounts).
     Configurations the native step does not take (residual rgbnet, coarse stage, no-grad forward, a frozen parameter) must select
     the op path by themselves."""
     import copy
@@ -382,8 +384,8 @@ def test_native_step_equals_the_op_by_op_step_bit_for_bit(kind):
     for k in ga:
         if "grid" in k:      # the lookups' scatter adds with hardware atomics: the same terms in an order that varies run to run
             scale = float(gb[k].abs().max())
-            # (a voxel's sum of n atomic adds in two different orders differs by up to ~n eps of its magnitude: n reaches tens)
-            assert float((ga[k] - gb[k]).abs().max()) <= 1e-4 * scale, (k, float((ga[k] - gb[k]).abs().max()), scale)
+            # (a voxel's sum of n atomic adds in two different orders: observed <= 1.1e-7 of the largest gradient at this size)
+            assert float((ga[k] - gb[k]).abs().max()) <= synth.NATIVE_GRID_GRAD_BOUND * scale, (k, float((ga[k] - gb[k]).abs().max()), scale)
         else:                # fixed-order sums: the same bits
             assert torch.equal(ga[k], gb[k]), k
     # eight training steps through the three TV phases
@@ -397,15 +399,9 @@ def test_native_step_equals_the_op_by_op_step_bit_for_bit(kind):
         res.append((losses, {k: p.detach().clone() for k, p in m.named_parameters()}))
     assert res[0][0][0][0] == res[1][0][0][0], (res[0][0][0], res[1][0][0])    # first step: identical parameters, identical loss
     assert abs(res[0][0][0][1] - res[1][0][0][1]) <= 1e-5                       # (psnr: host log10 of the same float32 mse)
-    np.testing.assert_allclose(np.array(res[0][0]), np.array(res[1][0]), rtol=2e-3)      # (Adam's sign-like first steps amplify the atomics' rounding)
-    for k in res[0][1]:
-        pa, pb = res[0][1][k], res[1][1][k]
-        # Adam's first steps are sign-like: an entry whose gradient is within rounding of zero moves by +-lr in either run, and the
-        # scatters' atomics make that rounding run-dependent -- allow a 1e-4 fraction of such entries (2 of a small tensor); every
-        # other entry stays within 2 % of a learning-rate step
-        diff = (pa - pb).abs()
-        lr = 0.1 if "grid" in k else 1e-3
-        assert int((diff > 0.02 * lr).sum()) <= max(2, int(1e-4 * diff.numel())), (k, float(diff.max()), int((diff > 0.02 * lr).sum()))
+    # losses: loss exactly as the tool compares it; psnr = -10 log10(mse) amplifies nothing (observed <= 1.2e-7 relative)
+    np.testing.assert_allclose(np.array(res[0][0]), np.array(res[1][0]), rtol=synth.NATIVE_LOSS_RTOL)
+    synth.assert_same_trajectory(res[0][1], res[1][1])
     assert res[0][0][-1][0] < res[0][0][0][0]
     # not the native step's business: no gradient, a frozen grid
     with torch.no_grad():

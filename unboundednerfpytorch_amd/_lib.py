@@ -75,7 +75,7 @@ class VoxgoStep(_c.Structure):
         ("mask_scale", _c.c_float * 3), ("mask_shift", _c.c_float * 3), ("scene_center", _c.c_float * 3), ("scene_radius", _c.c_float * 3),
         ("act_shift", _c.c_float), ("interval", _c.c_float), ("thres", _c.c_float), ("near_clip", _c.c_float), ("far_clip", _c.c_float),
         ("stepdist", _c.c_float), ("dist_thres", _c.c_float),
-        ("coef8", _c.c_float * 8),
+        ("coef9", _c.c_float * 9),
         ("bg_len", _c.c_double),
         ("n_rays", _c.c_int64),
         ("density_grid", _P), ("k0_grid", _P), ("xyz_min", _P), ("xyz_max", _P), ("k0_xyz_min", _P), ("k0_xyz_max", _P),

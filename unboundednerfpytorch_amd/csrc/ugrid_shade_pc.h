@@ -73,6 +73,13 @@ __device__ __forceinline__ void ug_lds_publish(unsigned off, int v) {
 // consumer the producer's; every poll is ~10 instructions on a SIMD it shares with working waves (A/B: profiles/r04/shade_poll_ab.txt)
 #define UG_PC_PRODUCER_SLEEP 2
 #define UG_PC_CONSUMER_SLEEP 2
+// TIMING-ONLY ablation arms (tools/experiments/ARMS.md "round 6"; never defined in the shipped build -- results are WRONG with any of
+// them): each removes one piece of a pass so that its cost on the whole kernel can be measured instead of priced.
+//   UG_ABL_NO_EMB_KSTEPS  layer 1 runs its first k-step only (12 of its 36 MFMAs) and the per-pass embedding-table read is skipped:
+//                         an UPPER bound of what hoisting the per-ray half of layer 1 can return (the hoist's own table reads excluded)
+//   UG_ABL_NO_L3          no layer-3 VALU work (64 relu + 192 FMA + 66 W3 reads): upper bound of "layer 3 off the VALU"
+//   UG_ABL_NO_CONSUME     the consumer hands every slot straight back: the producers' (gather) side alone
+//   UG_ABL_NO_GATHER      the producer publishes passes without loading a brick: the consumers' (rgbnet) side alone
 #define UG_PRIO_HI() __builtin_amdgcn_s_setprio(3)
 #define UG_PRIO_LO() __builtin_amdgcn_s_setprio(0)
 
@@ -134,12 +141,17 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
       xs = ug_split8h(v, M.sx1);
     }
     ug_fence_operands();
+#ifdef UG_ABL_NO_EMB_KSTEPS
+    constexpr int KB1_RUN = 1;
+#else
+    constexpr int KB1_RUN = KB1;
+#endif
 #pragma unroll
-    for (int s = 0; s < KB1; ++s) {
+    for (int s = 0; s < KB1_RUN; ++s) {
       float vn[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) vn[e] = (8 * (s + 1) + e < KL) ? x[(8 * (s + 1) + e < KL) ? 8 * (s + 1) + e : 0] : 0.f;
-      ug_mfma3x4(A1h + (s * 8) * 64 + lane, (s + 1 < KB1 ? A1h + ((s + 1) * 8) * 64 : A2h) + lane, xs, vn, M.sx1, xn, acc1, wl);
+      ug_mfma3x4(A1h + (s * 8) * 64 + lane, (s + 1 < KB1_RUN ? A1h + ((s + 1) * 8) * 64 : A2h) + lane, xs, vn, M.sx1, xn, acc1, wl);
       xs = xn;
     }
     ug_fence_results();
@@ -207,8 +219,14 @@ __device__ __forceinline__ void ug_rgbnet_pass_lean(const float (&x)[(2 * UG_CH(
     ug_fence_results();
     UG_PRIO_LO();
     // ---- layer 3, rows 32 pr2 .. 32 pr2 + 31 (same order as the 4-tile pass: rows ascending)
+#ifdef UG_ABL_NO_L3
+    l0 += acc2[0][0]; l1 += acc2[0][1]; l2 += acc2[1][0];
+    constexpr int L3_FIRST = 32;
+#else
+    constexpr int L3_FIRST = 0;
+#endif
 #pragma unroll
-    for (int sb = 0; sb < 32; sb += W3B) {
+    for (int sb = L3_FIRST; sb < 32; sb += W3B) {
       const int cur = (sb / W3B) & 1;
       if (sb + W3B < 32) w3[cur ^ 1] = ug_w3_load4(M, bo, 32 * pr2 + sb + W3B);
       __builtin_amdgcn_sched_barrier(0);
@@ -292,7 +310,12 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
       float f3[2][3];
       {
         const float pgs[2] = {pg0, pg1};
+#ifdef UG_ABL_NO_GATHER
+        f3[0][0] = pg0; f3[0][1] = pg1; f3[0][2] = ww; f3[1][0] = pg1; f3[1][1] = pg0; f3[1][2] = ww;
+        if constexpr (false) {
+#else
         if constexpr (ROLL) {
+#endif
           ug_k0_gather_quad_roll<F, NBL, 2>(k0b, a, qa, pgs, f3);
         } else {
           ug_gather_state<F, NBL, 2> gst;
@@ -403,11 +426,20 @@ __device__ __forceinline__ void ug_pc_consumer(const ug_shade_args &a, const flo
       for (int e = 0; e < 2 * EH; ++e) embt[lane * (2 * EH) + e] = emb[e];
       ug_wave_lds_sync();
     }
+#ifdef UG_ABL_NO_EMB_KSTEPS
+#pragma unroll
+    for (int s = CH; s < KL; ++s) x[s] = 0.f;
+#else
     {
       const float *er = embt + sl * (2 * EH) + h * EH;
 #pragma unroll
       for (int s = CH; s < KL; ++s) x[s] = er[s - CH];
     }
+#endif
+#ifdef UG_ABL_NO_CONSUME
+    accr += x[0] + ww; accg += x[1]; accb += (float)sl + (ok ? 1.f : 0.f);
+    continue;
+#endif
     if constexpr (MODE == 1) {
       ug_rgbnet_pass_lean<C, PE>(x, ww, sl, ok, M, amask, aval, accr, accg, accb);
     } else {

@@ -164,7 +164,7 @@ extern "C" int ugrid_voxgo_step_forward(const ugrid_voxgo_step *s, ugrid_stream_
   if (rc) return rc;
   rc = ugrid_rgbnet_train_forward(w.feat, M2, K, s->w0, s->b0, s->w1, s->b1, s->w2, s->b2, s->width, w.h1, w.h2, s->logits, st);
   if (rc) return rc;
-  return ugrid_render_loss(s->logits, s->weights2, nullptr, s->t2, s->alphainv_last, s->bg, s->target, s->ray_id2, M2, R, s->coef8, s->seg,
+  return ugrid_render_loss(s->logits, s->weights2, nullptr, s->t2, s->alphainv_last, s->bg, s->target, s->ray_id2, M2, R, s->coef9, s->seg,
                            s->rgb_marched, s->ray_tot, s->partial, s->out2, st);
 }
 
@@ -177,7 +177,7 @@ extern "C" int ugrid_voxgo_step_backward_k0(const ugrid_voxgo_step *s, ugrid_str
   const ug_step_ws_bwd b = ug_step_layout_bwd(s);
   const int64_t R = s->n_rays, M2 = s->M2;
   const int K = s->C + 3 + 6 * s->pe;
-  rc = ugrid_render_loss_backward(s->logits, s->weights2, nullptr, s->t2, s->alphainv_last, s->bg, s->target, s->ray_id2, M2, R, s->coef8,
+  rc = ugrid_render_loss_backward(s->logits, s->weights2, nullptr, s->t2, s->alphainv_last, s->bg, s->target, s->ray_id2, M2, R, s->coef9,
                                   s->seg, s->rgb_marched, s->ray_tot, s->grad_loss, b.g_logits, b.g_w, b.g_ainv, b.g_dens, st);
   if (rc) return rc;
   rc = ugrid_rgbnet_train_backward(b.g_logits, w.feat, w.h1, w.h2, M2, K, s->C, s->w0, s->w1, s->w2, s->width, b.g_k0, s->g_w0, s->g_b0,

@@ -1,5 +1,5 @@
 // Training tail in two kernels per direction: sigmoid + per-ray compositing + the loss terms of run_train.py:254-279
-// (main MSE, entropy_last, nearclip, flatten_eff_distloss, rgbper) and their hand-written derivatives.
+// (main MSE, the image-space Fourier MSE, entropy_last, nearclip, flatten_eff_distloss, rgbper) and their hand-written derivatives.
 //
 // The composed torch chain this replaces (FourierGrid_model.py:636-672 after the rgbnet, run_train.py:254-279) is ~45
 // launches forward and ~90 backward on [M] / [M,3] / [R,3] arrays that together hold a few MB: launch-bound.  Here one
@@ -8,13 +8,17 @@
 //   per sample i of ray r :  rgb_i = sigmoid(logit_i)                                   (FourierGrid_model.py:636)
 //   rgb_marched[r]        =  sum_i w_i rgb_i + alphainv_last[r] * bg[r]                 (:638-647, bg = rand_bkgd draw or none)
 //   mse                   =  mean_{r,c} (rgb_marched - target)^2                        (run_train.py:254)
+//   freq                  =  mean_{r,k} (Re FFT_3(rgb_marched)_k - Re FFT_3(target)_k)^2   (run_train.py:255, FourierMSELoss
+//                            FourierGrid_model.py:112-129: the FFT runs over the COLOUR axis, n = 3, only the real part is used).
+//                            Re FFT_3 is linear: with e = rgb_marched - target its three outputs are f0 = e0 + e1 + e2 and, twice,
+//                            f1 = e0 - (e1 + e2) / 2  (cos(2 pi / 3) = cos(4 pi / 3) = -1/2)  ->  freq = mean_r (f0^2 + 2 f1^2) / 3
 //   entropy_last          =  mean_r -(p log p + (1-p) log(1-p)),  p = clamp(alphainv_last, 1e-6, 1-1e-6)   (:258-261)
 //   nearclip              =  sum_{i: t_i < near} (density_i - stop_grad(density_i))      (:262-265; value 0, gradient 1)
 //   distortion            =  1/n_d sum_i [ 2 w_i (s_i W_<i - WS_<i) + w_i^2 interval / 3 ],  n_d = ray_id.max() + 1   (:274)
 //   rgbper                =  1/n_rays sum_i stop_grad(w_i) sum_c (rgb_i - target[r])^2    (:276-278)
-//   loss = w_main mse + w_ent entropy_last + w_near nearclip + w_dist distortion + w_per rgbper
+//   loss = w_main mse + w_freq freq + w_ent entropy_last + w_near nearclip + w_dist distortion + w_per rgbper
 //
-// Per-ray partial sums go to a [R,4] array that ONE block reduces in a fixed order (deterministic loss value); the
+// Per-ray partial sums go to a [R,5] array that ONE block reduces in a fixed order (deterministic loss value); the
 // exclusive running sums W_<i, WS_<i are formed sequentially along the ray exactly as k_segment_cumsum forms them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -25,8 +29,9 @@
 #define ST(s) ((hipStream_t)(s))
 
 struct ug_loss_coef {
-  float w_main, w_ent, w_dist, w_per, w_near, near_thres, interval, n_rays;
+  float w_main, w_ent, w_dist, w_per, w_near, near_thres, interval, n_rays, w_freq;
 };
+#define UG_LOSS_PARTIALS 5
 
 __device__ __forceinline__ float ug_wave_sum(float v) {
 #pragma unroll
@@ -99,35 +104,41 @@ k_render_loss_fwd(const float *__restrict__ logits, const float *__restrict__ we
     ray_tot[2 * r + 1] = cws;
     const float e0 = a0 - t0, e1 = a1 - t1, e2 = a2 - t2;
     const float p = fminf(fmaxf(av, 1e-6f), 1.f - 1e-6f);
-    partial[4 * r] = e0 * e0 + e1 * e1 + e2 * e2;
-    partial[4 * r + 1] = -(p * logf(p) + (1.f - p) * logf(1.f - p));
-    partial[4 * r + 2] = per;
-    partial[4 * r + 3] = dist;
+    const float f0 = (e0 + e1) + e2, f1 = e0 - 0.5f * (e1 + e2);
+    partial[UG_LOSS_PARTIALS * r] = e0 * e0 + e1 * e1 + e2 * e2;
+    partial[UG_LOSS_PARTIALS * r + 1] = -(p * logf(p) + (1.f - p) * logf(1.f - p));
+    partial[UG_LOSS_PARTIALS * r + 2] = per;
+    partial[UG_LOSS_PARTIALS * r + 3] = dist;
+    partial[UG_LOSS_PARTIALS * r + 4] = f0 * f0 + 2.f * (f1 * f1);
   }
 }
 
-// one block: fixed-order reduction of the [R,4] partials, then the weighted sum.  out = {loss, mse}
+// one block: fixed-order reduction of the [R,5] partials, then the weighted sum.  out = {loss, mse}
 __global__ void __launch_bounds__(256)
 k_render_loss_final(const float *__restrict__ partial, int64_t n_rays, const int64_t *__restrict__ ray_id, int64_t n,
                     ug_loss_coef c, float *__restrict__ out) {
-  __shared__ float red[4][256];
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  constexpr int NP = UG_LOSS_PARTIALS;
+  __shared__ float red[NP][256];
+  float acc[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) acc[k] = 0.f;
   for (int64_t r = threadIdx.x; r < n_rays; r += 256)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] += partial[4 * r + k];
+    for (int k = 0; k < NP; ++k) acc[k] += partial[NP * r + k];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) red[k][threadIdx.x] = acc[k];
+  for (int k = 0; k < NP; ++k) red[k][threadIdx.x] = acc[k];
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+      for (int k = 0; k < NP; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
     __syncthreads();
   }
   if (threadIdx.x == 0) {
     const float R = (float)n_rays;
     const float mse = red[0][0] / (3.f * R);
     float loss = c.w_main * mse;
+    if (c.w_freq != 0.f) loss += c.w_freq * (red[4][0] / (3.f * R));
     if (c.w_ent > 0.f) loss += c.w_ent * (red[1][0] / R);
     if (c.w_dist > 0.f && n > 0) loss += c.w_dist * (red[3][0] / (float)(ray_id[n - 1] + 1));
     if (c.w_per > 0.f) loss += c.w_per * (red[2][0] / c.n_rays);
@@ -152,8 +163,16 @@ k_render_loss_bwd(const float *__restrict__ logits, const float *__restrict__ we
   const float R = (float)n_rays;
   const float t0 = target[3 * r], t1 = target[3 * r + 1], t2 = target[3 * r + 2];
   const float k_mse = g * c.w_main * 2.f / (3.f * R);
-  const float m0 = k_mse * (rgb_marched[3 * r] - t0), m1 = k_mse * (rgb_marched[3 * r + 1] - t1),
-              m2 = k_mse * (rgb_marched[3 * r + 2] - t2);
+  float m0 = k_mse * (rgb_marched[3 * r] - t0), m1 = k_mse * (rgb_marched[3 * r + 1] - t1), m2 = k_mse * (rgb_marched[3 * r + 2] - t2);
+  if (c.w_freq != 0.f) {
+    // d freq / d e = 2 / (3 R) [ f0 (1,1,1) + 2 f1 (1,-1/2,-1/2) ]: the transposed 3 x 3 map applied to (f0, f1, f1)
+    const float e0 = rgb_marched[3 * r] - t0, e1 = rgb_marched[3 * r + 1] - t1, e2 = rgb_marched[3 * r + 2] - t2;
+    const float f0 = (e0 + e1) + e2, f1 = e0 - 0.5f * (e1 + e2);
+    const float k_freq = g * c.w_freq * 2.f / (3.f * R);
+    m0 += k_freq * (f0 + 2.f * f1);
+    m1 += k_freq * (f0 - f1);
+    m2 += k_freq * (f0 - f1);
+  }
   const float k_per = c.w_per > 0.f ? g * c.w_per * 2.f / c.n_rays : 0.f;
   const float k_dist = (c.w_dist > 0.f && n > 0) ? g * c.w_dist / (float)(ray_id[n - 1] + 1) : 0.f;
   const float k_near = g * c.w_near;
@@ -199,6 +218,7 @@ static ug_loss_coef ug_coef(const float *h) {
   ug_loss_coef c;
   c.w_main = h[0]; c.w_ent = h[1]; c.w_dist = h[2]; c.w_per = h[3]; c.w_near = h[4]; c.near_thres = h[5]; c.interval = h[6];
   c.n_rays = h[7];
+  c.w_freq = h[8];
   return c;
 }
 
@@ -220,13 +240,13 @@ __global__ void k_loss_segments(const int64_t *__restrict__ ray_id, int64_t n, i
 
 extern "C" int ugrid_render_loss(const float *logits, const float *weights, const float *s, const float *t, const float *alphainv_last,
                                  const float *bg, const float *target, const int64_t *ray_id, int64_t n, int64_t n_rays,
-                                 const float *h_coef8, int64_t *seg_scratch, float *rgb_marched, float *ray_tot,
+                                 const float *h_coef9, int64_t *seg_scratch, float *rgb_marched, float *ray_tot,
                                  float *partial, float *out2, ugrid_stream_t st) {
   if (n_rays <= 0 || (n > 0 && !s && !t)) return (int)hipErrorInvalidValue;      // (no samples: empty arrays have no address)
   int64_t *i_start = seg_scratch, *i_end = seg_scratch + n_rays;
   UG_HIP(hipMemsetAsync(seg_scratch, 0, sizeof(int64_t) * 2 * n_rays, ST(st)));
   if (n > 0) hipLaunchKernelGGL(k_loss_segments, dim3(ug_blocks(n, 256)), dim3(256), 0, ST(st), ray_id, n, i_start, i_end);
-  const ug_loss_coef c = ug_coef(h_coef8);
+  const ug_loss_coef c = ug_coef(h_coef9);
   hipLaunchKernelGGL(k_render_loss_fwd, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(st), logits, weights, s, t,
                      alphainv_last, bg, target, i_start, i_end, n_rays, c, rgb_marched, ray_tot, partial);
   hipLaunchKernelGGL(k_render_loss_final, dim3(1), dim3(256), 0, ST(st), partial, n_rays, ray_id, n, c, out2);
@@ -236,12 +256,12 @@ extern "C" int ugrid_render_loss(const float *logits, const float *weights, cons
 
 extern "C" int ugrid_render_loss_backward(const float *logits, const float *weights, const float *s, const float *t,
                                           const float *alphainv_last, const float *bg, const float *target,
-                                          const int64_t *ray_id, int64_t n, int64_t n_rays, const float *h_coef8,
+                                          const int64_t *ray_id, int64_t n, int64_t n_rays, const float *h_coef9,
                                           const int64_t *seg_scratch, const float *rgb_marched, const float *ray_tot,
                                           const float *grad_loss, float *g_logits, float *g_weights, float *g_alphainv_last,
                                           float *g_density, ugrid_stream_t st) {
   if (n_rays <= 0) return (int)hipErrorInvalidValue;
-  const ug_loss_coef c = ug_coef(h_coef8);
+  const ug_loss_coef c = ug_coef(h_coef9);
   hipLaunchKernelGGL(k_render_loss_bwd, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(st), logits, weights, s, t,
                      alphainv_last, bg, target, ray_id, n, seg_scratch, seg_scratch + n_rays, n_rays, c, rgb_marched, ray_tot,
                      grad_loss, g_logits, g_weights, g_alphainv_last, g_density);

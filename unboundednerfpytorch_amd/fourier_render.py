@@ -33,8 +33,23 @@ def tune(key, value):
 
 
 # UGRID_TUNE="key=value,key=value": speed knobs applied when the module is imported (A/B runs of tests / tools without code changes)
-for _kv in filter(None, os.environ.get("UGRID_TUNE", "").split(",")):
-    tune(_kv.split("=")[0].strip(), int(_kv.split("=")[1]))
+# A malformed or rejected entry is reported and skipped: an environment variable must not make the package unimportable.
+def _apply_env_tune(spec):
+    import warnings
+    applied = []
+    for kv in filter(None, (x.strip() for x in spec.split(","))):
+        key, sep, val = kv.partition("=")
+        try:
+            if not sep:
+                raise ValueError("expected key=value")
+            tune(key.strip(), int(val))
+            applied.append(key.strip())
+        except (ValueError, RuntimeError) as e:
+            warnings.warn("UGRID_TUNE entry %r ignored: %s" % (kv, e))
+    return applied
+
+
+_apply_env_tune(os.environ.get("UGRID_TUNE", ""))
 
 
 def sample_table(world_len, stepsize, bg_len, t_boundary=1.5):  # noqa: E302  (dcvgo.py:243-250 uses t_boundary = 2)

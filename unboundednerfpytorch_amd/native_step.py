@@ -22,6 +22,14 @@ if int(_L.ugrid_voxgo_step_sizeof()) != ctypes.sizeof(_lib.VoxgoStep):
 _WEIGHTS = ("w0", "b0", "w1", "b1", "w2", "b2")
 
 
+def _coef9(coef):
+    """ops.loss_coefficients' tuple as the 9 floats of ugrid_render_loss (an 8-tuple of an older caller: weight_freq = 0)"""
+    c = [float(x) for x in coef]
+    if len(c) not in (8, 9):
+        raise RuntimeError("loss coefficients: 8 or 9 numbers (ops.loss_coefficients), got %d" % len(c))
+    return c + [0.0] * (9 - len(c))
+
+
 class VoxGOStep(torch.autograd.Function):
     """forward(density_grid [P,1,X,Y,Z], k0_grid [P,C,X,Y,Z], w0, b0, w1, b1, w2, b2, pack) -> loss, mse
     pack (dict, not differentiated): mode 'dvgo' | 'dcvgo' | 'fourier', cfg (the dict TrainSampleVox takes; 'fourier': act_shift,
@@ -47,8 +55,22 @@ class VoxGOStep(torch.autograd.Function):
         if bg is not None:
             f32.append(("bg", bg))
         mask = pack.get('mask')
+        # the buffers handed to C as raw pointers get the checks grid.TrainSampleVox makes: the sample table and the four
+        # box corners float32 / dense / on the device (dense copies are kept alive by `pack` below), the mask a dense bool [mi,mj,mk]
+        box = {}
+        for k in ('xyz_min', 'xyz_max', 'k0_xyz_min', 'k0_xyz_max'):
+            box[k] = pack[k].contiguous()
+            f32.append((k, box[k]))
+        t_tab = pack.get('t')
+        if t_tab is not None:
+            t_tab = t_tab.contiguous()
+            f32.append(("t", t_tab))
+        if mask is not None and (mask.dtype != torch.bool or mask.dim() != 3):
+            raise RuntimeError("VoxGOStep: mask must be a bool tensor [mi,mj,mk] (got %s, %d-D)" % (mask.dtype, mask.dim()))
         _lib.require_cuda(*f32, *([("mask", mask)] if mask is not None else []))
         _lib.require_f32(*f32, ("k0 grid", k0_grid))
+        if any(x.device != density_grid.device for _, x in f32) or k0_grid.device != density_grid.device:
+            raise RuntimeError("VoxGOStep: every tensor of the step must be on the density grid's device")
         _lib.wait_pending(density_grid)     # an optimizer update of a grid may still run on a side stream (step(overlap=...)); the
                                             # k0 grid's is waited for AFTER the sampling march, which does not read it
         if density_grid.dim() != 5 or density_grid.shape[1] != 1 or not density_grid.is_contiguous():
@@ -60,7 +82,7 @@ class VoxGOStep(torch.autograd.Function):
         k0_cl = bool(_lib.require_cuda_grid(("k0 grid", k0_grid)))
         dev = density_grid.device
         R = rays_o.shape[0]
-        t = pack.get('t')
+        t = t_tab
         S = int(cfg['slots']) if mode == 'dvgo' else t.numel()
         C, W, pe = k0_grid.shape[1], ws_[0].shape[0], viewfreq.numel()
         if tuple(ws_[0].shape) != (W, C + 3 + 6 * pe) or tuple(ws_[2].shape) != (W, W) or tuple(ws_[4].shape) != (3, W):
@@ -76,7 +98,7 @@ class VoxGOStep(torch.autograd.Function):
             _grid.TrainSampleVox._scratch[key] = sc
         counts = torch.empty(2, R, dtype=torch.int32, device=dev)
         i64 = torch.empty(4 * R + 2, dtype=torch.int64, device=dev)        # offsets [2,R] | totals [2] | seg [2R]
-        perray = torch.empty(R, 6, device=dev)                             # ray_tot [R,2] | partial [R,4]
+        perray = torch.empty(R, 7, device=dev)                             # ray_tot [R,2] | partial [R,5]
         ainv = torch.empty(R, device=dev)
         rgb_marched = torch.empty(R, 3, device=dev)
         out2 = torch.empty(2, device=dev)
@@ -101,11 +123,11 @@ class VoxGOStep(torch.autograd.Function):
             s.scene_radius[:] = cfg['scene_radius']
             s.bg_len, s.norm_l2, s.dist_thres = float(cfg['bg_len']), int(bool(cfg['norm_l2'])), float(cfg.get('dist_thres', 0.0))
             s.t_table = t.data_ptr()
-        s.coef8[:] = [float(x) for x in pack['coef']]
+        s.coef9[:] = _coef9(pack['coef'])
         s.n_rays = R
         s.density_grid, s.k0_grid = density_grid.data_ptr(), k0_grid.data_ptr()
-        s.xyz_min, s.xyz_max = pack['xyz_min'].data_ptr(), pack['xyz_max'].data_ptr()
-        s.k0_xyz_min, s.k0_xyz_max = pack['k0_xyz_min'].data_ptr(), pack['k0_xyz_max'].data_ptr()
+        s.xyz_min, s.xyz_max = box['xyz_min'].data_ptr(), box['xyz_max'].data_ptr()
+        s.k0_xyz_min, s.k0_xyz_max = box['k0_xyz_min'].data_ptr(), box['k0_xyz_max'].data_ptr()
         s.viewfreq = viewfreq.data_ptr()
         for n, x in zip(_WEIGHTS, ws_):
             setattr(s, n, x.data_ptr())
@@ -135,8 +157,7 @@ class VoxGOStep(torch.autograd.Function):
             _lib.check(_L.ugrid_voxgo_step_forward(ps, st), "voxgo_step_forward")
         ctx.step = s
         # everything the struct points to stays alive until the backward has been issued
-        ctx.keep = (density_grid, k0_grid, ws_, rays_o, rays_d, viewdirs, target, bg, viewfreq, t, mask, pack['xyz_min'], pack['xyz_max'],
-                    pack['k0_xyz_min'], pack['k0_xyz_max'], sc, counts, i64, perray, ainv, rgb_marched, out2, ws, f4, ids, logits, inner)
+        ctx.keep = (density_grid, k0_grid, ws_, rays_o, rays_d, viewdirs, target, bg, viewfreq, t, mask, box, sc, counts, i64, perray, ainv, rgb_marched, out2, ws, f4, ids, logits, inner)
         ctx.shapes = (tuple(density_grid.shape), tuple(density_grid.stride()), tuple(k0_grid.shape), tuple(k0_grid.stride()), k0_cl)
         ctx.keys = (_gradpool.key_of(density_grid), _gradpool.key_of(k0_grid))
         ctx.wshapes = [tuple(x.shape) for x in ws_]

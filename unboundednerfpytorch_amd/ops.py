@@ -295,14 +295,14 @@ def sequential_splitk(net, x):
 
 class RenderLoss(torch.autograd.Function):
     """Training tail in one op (include/ugrid_hip.h: ugrid_render_loss): rgb = sigmoid(logits), rgb_marched = per-ray
-    sum of weights * rgb + alphainv_last * bg, and the loss of run_train.py:254-279 (main MSE, entropy_last, nearclip,
-    flatten_eff_distloss with interval = 1 / n_max, rgbper) -- what fourier_model.FourierGridModel.forward's tail and
+    sum of weights * rgb + alphainv_last * bg, and the loss of run_train.py:254-279 (main MSE, the image-space Fourier MSE of
+    FourierGrid_model.py:112-129, entropy_last, nearclip, flatten_eff_distloss with interval = 1 / n_max, rgbper) -- what fourier_model.FourierGridModel.forward's tail and
     train_step.training_loss compute with ~45 torch launches (and ~90 in the backward).  ray_id must be ascending.
 
     forward(logits [M,3], weights [M], alphainv_last [R], raw_density [M], ray_id [M], t [M], s [M] or None (then
             s = 1 - 1/(1+t)), target [R,3], bg [R,3] or None, coef) -> loss (scalar), mse (scalar, no gradient), rgb_marched [R,3] (no gradient)
     coef = (weight_main, weight_entropy_last, weight_distortion, weight_rgbper, weight_nearclip * world_size, near_thres,
-            interval, n_rays); gradients flow to logits, weights, alphainv_last and raw_density."""
+            interval, n_rays, weight_freq); gradients flow to logits, weights, alphainv_last and raw_density."""
 
     @staticmethod
     def forward(ctx, logits, weights, alphainv_last, raw_density, ray_id, t, s, target, bg, coef):
@@ -320,11 +320,14 @@ class RenderLoss(torch.autograd.Function):
         s = s.contiguous() if s is not None else None
         bg = bg.contiguous() if bg is not None else None
         ray_id = ray_id.contiguous()
-        h = (ctypes.c_float * 8)(*[float(x) for x in coef])
+        c9 = [float(x) for x in coef]
+        if len(c9) not in (8, 9):
+            raise RuntimeError("RenderLoss: coef holds 8 or 9 numbers (ops.loss_coefficients)")
+        h = (ctypes.c_float * 9)(*(c9 + [0.0] * (9 - len(c9))))
         seg = torch.empty(2 * R, dtype=torch.int64, device=dev)
         rgb_marched = torch.empty(R, 3, device=dev)
         ray_tot = torch.empty(R, 2, device=dev)
-        partial = torch.empty(R, 4, device=dev)
+        partial = torch.empty(R, 5, device=dev)
         out2 = torch.empty(2, device=dev)
         with _lib.guard(dev):
             _lib.check(_L.ugrid_render_loss(_lib.ptr(logits), _lib.ptr(weights), _lib.ptr(s) if s is not None else None, _lib.ptr(t),
@@ -359,13 +362,12 @@ class RenderLoss(torch.autograd.Function):
 
 def loss_coefficients(cfg_train, n_rays, n_max, near_thres=None, world_size=1):
     """the coef tuple of RenderLoss from a cfg_train (dict or attribute object, run_train.py:254-279), or None when the
-    configuration uses a term the fused op does not implement (weight_freq: the image-space Fourier loss)"""
+    configuration cannot be evaluated by the fused op (nearclip without its threshold).  weight_freq -- the image-space Fourier
+    loss of bicycle_single.py:57 / stump_single.py:55 (5.0), barn / caterpillar (0.3), waymo_no_block (1.0) -- is the 9th entry."""
     get = (lambda k, d=0.0: cfg_train.get(k, d)) if isinstance(cfg_train, dict) else (lambda k, d=0.0: getattr(cfg_train, k, d))
-    if get('weight_freq', 0.0):
-        return None
     w_near = get('weight_nearclip', 0.0)
     if w_near > 0 and near_thres is None:
         return None
     return (get('weight_main', 1.0), max(get('weight_entropy_last', 0.0), 0.0), max(get('weight_distortion', 0.0), 0.0),
             max(get('weight_rgbper', 0.0), 0.0), (w_near * world_size) if w_near > 0 else 0.0,
-            near_thres if near_thres is not None else 0.0, 1.0 / n_max, float(n_rays))
+            near_thres if near_thres is not None else 0.0, 1.0 / n_max, float(n_rays), float(get('weight_freq', 0.0) or 0.0))

@@ -275,7 +275,8 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                 sharded = world > 1 and n >= self.min_shard_numel
                 if (multi is not None and world == 1 and n <= self.MULTI_MAX_NUMEL and param not in tv_terms and not use_perlr
                         and grad_hook is None and param.is_cuda and param.is_contiguous() and param.grad.is_contiguous()
-                        and param.dtype == torch.float32 and param.grad.dtype == torch.float32 and param.dim() != 5):
+                        and param.dtype == torch.float32 and param.grad.dtype == torch.float32 and param.dim() != 5
+                        and param.grad.device == param.device):
                     if len(state) == 0:
                         state['step'] = 0
                         state['exp_avg'] = torch.zeros_like(param, memory_format=torch.preserve_format)
@@ -377,8 +378,13 @@ class ShardedMaskedAdam(torch.optim.Optimizer):
                     full = torch.empty(total, dtype=flat_p.dtype, device=flat_p.device)
                     dist.all_gather_into_tensor(full, p_shard, group=self.group)
                     flat_p.copy_(full[:n])
-            if batch:
-                multi(batch, group['betas'][0], group['betas'][1], group['eps'], bool(group['skip_zero_grad']))
+            # one launch per DEVICE: the multi-tensor kernel runs on its first item's device and stream (a group that spans
+            # devices must not hand it foreign pointers -- ADVICE r5)
+            by_dev = {}
+            for item in batch:
+                by_dev.setdefault(item[0].device, []).append(item)
+            for items in by_dev.values():
+                multi(items, group['betas'][0], group['betas'][1], group['eps'], bool(group['skip_zero_grad']))
 
     # -- sparse (touched-line) exchange ----------------------------------------------------------------
     def _line_bits(self, param, flat_g, n):
