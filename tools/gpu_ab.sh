@@ -10,12 +10,13 @@ mkdir -p $OUT
 STEPS=${AB_STEPS:-12}
 for lib in "$@"; do
   for rep in $(seq 1 ${AB_REPS:-1}); do
-    UGRID_LIB=$PWD/$lib timeout 300 python bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-secondary $BENCH_FLAGS 2>$OUT/err_$(basename $lib).log | tail -1 > $OUT/line_$(basename $lib).json
-    python - "$lib" $OUT/line_$(basename $lib).json <<'PY' | tee -a $OUT/ab.txt
+    LINE=$OUT/line_${AB_NAME:-ab}_$(basename $lib)_$rep.json
+    UGRID_LIB=$PWD/$lib timeout 300 python bench.py --steps $STEPS --warmup 3 --no-cpu-baseline --no-secondary $BENCH_FLAGS 2>$OUT/err_$(basename $lib).log | tail -1 > $LINE
+    python - "$lib" $LINE <<'PY' | tee -a $OUT/ab.txt
 import json, sys
 try:
     d = json.load(open(sys.argv[2]))
-    k = {n: round(v["ms"], 3) for n, v in d["kernels"].items()}
+    k = {n: round(v["ms"] if isinstance(v, dict) else v, 3) for n, v in d["kernels"].items()}      # (round 6: the compact line holds plain numbers)
     print("%-34s step %.3f ms  %s  frame %s  code %s" % (sys.argv[1].split("/")[-1], d["ms_per_step"], k, d.get("frame_sha16"), d.get("device_code_sha16")))
 except Exception as e:
     print("%-34s FAILED (%s)" % (sys.argv[1], e))

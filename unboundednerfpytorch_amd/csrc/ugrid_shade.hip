@@ -5,6 +5,7 @@
 
 extern "C" int ug_set_march_waves(int w);  // ugrid_march.hip
 extern "C" int ug_set_tv_xcd(int m);        // ugrid_ops.hip
+extern "C" int ug_set_train_mlp(int m);     // ugrid_train_mlp.hip
 #define UG_PC12_NBL 3        // gather items (x 6 dwordx4) in flight per producer wave of the 12-wave geometry (4 spill)
 static int g_shade_pc = 2;   // ugrid_tune("shade_pc", 0|1|2): 2 = 12-wave producer / consumer shade kernel where it applies (default),
                              // 1 = its 8-wave form, 0 = the classic one-wave-does-everything kernel -- bit-identical results,
@@ -278,6 +279,7 @@ extern "C" int ugrid_tune(const char *key, int value) {
   if (!key) return (int)hipErrorInvalidValue;
   if (!strcmp(key, "march_waves")) return ug_set_march_waves(value) ? (int)hipErrorInvalidValue : 0;
   if (!strcmp(key, "tv_xcd")) return ug_set_tv_xcd(value) ? (int)hipErrorInvalidValue : 0;
+  if (!strcmp(key, "train_mlp")) return ug_set_train_mlp(value) ? (int)hipErrorInvalidValue : 0;
   if (!strcmp(key, "shade_pc") && value >= 0 && value <= 2) { g_shade_pc = value; return 0; }
   return (int)hipErrorInvalidValue;
 }

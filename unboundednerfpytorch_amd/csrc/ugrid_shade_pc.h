@@ -312,16 +312,15 @@ __device__ __forceinline__ void ug_pc_producer(const ug_shade_args &a, const flo
         const float pgs[2] = {pg0, pg1};
 #ifdef UG_ABL_NO_GATHER
         f3[0][0] = pg0; f3[0][1] = pg1; f3[0][2] = ww; f3[1][0] = pg1; f3[1][1] = pg0; f3[1][2] = ww;
-        if constexpr (false) {
 #else
         if constexpr (ROLL) {
-#endif
           ug_k0_gather_quad_roll<F, NBL, 2>(k0b, a, qa, pgs, f3);
         } else {
           ug_gather_state<F, NBL, 2> gst;
           ug_k0_gather_begin<F, NBL, 2>(k0b, a, qa, pgs, gst);
           ug_k0_gather_finish<F, NBL, 2>(k0b, a, gst, f3);
         }
+#endif
       }
       // a free slot: the consumer has taken pass seq - SLOTS (waited for AFTER the gather: the features sit in registers)
       while (seq - tail_seen >= SLOTS) {

@@ -233,6 +233,238 @@ k_wgrad_reduce(const float *__restrict__ partial_w, const float *__restrict__ pa
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// bf16x3 twins of k_lin / k_wgrad (round 6; ugrid_tune("train_mlp", 1), the default).
+//
+// v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate: the 128-wide layers of a DVGO step (M ~ 1.2e5) are 25 us of matrix-pipe
+// time per launch, and the fp32 kernels reach a third of that rate (profiles/r05/voxgo_train_dvgo_pmc.txt: matrix pipe busy 0.34).
+// Every fp32 operand is split into three bf16 parts x = h + m + l (|x - (h + m + l)| <= 2^-24 |x|: the split the render side's
+// BF16X3 rgbnet uses, csrc/ugrid_render.h ug_split8) and a product keeps the six part products above 2^-24 of |a||b|
+// (m m, l h, h l, m h, h m, h h -- smallest first), accumulated in fp32 by v_mfma_f32_32x32x16_bf16: 6 MFMAs of 32 cycles per 16
+// reduction steps against 8 of 64 -- 2.7 x less matrix time at fp32 accuracy, no range guard needed (bf16 has fp32's exponent).
+// Operand mapping of v_mfma_f32_32x32x16_bf16 (lane l, h = l >> 5):  a: A[m = l & 31][k = 8 h + e],  b: B[k = 8 h + e][n = l & 31],
+// e = 0..7;  d[i]: D[m = 8 (i >> 2) + 4 h + (i & 3)][n = l & 31].
+// ----------------------------------------------------------------------------------------------
+typedef __bf16 mlp_bf16x8 __attribute__((ext_vector_type(8)));
+struct mlp_split3 { mlp_bf16x8 h, m, l; };
+__device__ __forceinline__ mlp_split3 mlp_split8(const float (&x)[8]) {
+  mlp_split3 s;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 hh = (__bf16)x[i];
+    const float r1 = x[i] - (float)hh;
+    const __bf16 mm = (__bf16)r1;
+    const float r2 = r1 - (float)mm;
+    s.h[i] = hh; s.m[i] = mm; s.l[i] = (__bf16)r2;
+  }
+  return s;
+}
+// (the pinned issue order + scheduling barrier of the render side's bf16 chain: an MFMA never reads as SrcC the accumulator the MFMA issued
+// right before it wrote -- csrc/ugrid_render.h UG_MFMA_BF16)
+#define MLP_MFMA_BF16(acc, a, b)                                      \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);  \
+  __builtin_amdgcn_sched_barrier(0)
+
+// Y^T tile = W . X^T: D[m = output][n = sample] -- the weights are the A operands (LDS image, 16-byte records of 8 bf16), the lane's own
+// sample row the B operand, and a lane ends up with FOUR CONSECUTIVE outputs of its sample per accumulator quad: 16 float4 stores per
+// tile and lane instead of 64 scalar ones.  KS = k-steps of 16 (the reduction runs over 2 x 8 KS padded inputs: lane half h streams
+// elements [8 KS h, 8 KS (h + 1)) of its row, as k_lin does); n_out in (32, 128], a multiple of 4.
+// LDS image: rec[((ks * 3 + part) * 2 + h) * 128 + n] = parts of W[n][8 KS h + 8 ks + e], e = 0..7 (zero beyond K / n_out).
+#define UG_LINB_THREADS 512
+template <int KS, bool VEC>
+__global__ void __launch_bounds__(UG_LINB_THREADS)
+k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__restrict__ W, int ldw, int n_out, int w_in_major,
+         const float *__restrict__ bias, int relu, const float *__restrict__ G, int ldg, float *__restrict__ Y, int ldy) {
+  extern __shared__ float lds[];
+  mlp_bf16x8 *img = (mlp_bf16x8 *)lds;
+  constexpr int KH = 8 * KS, N_REC = 2 * KS * 128;
+  for (int r = threadIdx.x; r < N_REC; r += UG_LINB_THREADS) {
+    int n, kq;                                     // kq = h * KS + ks: the record's first input is 8 kq
+    if (w_in_major) { n = r & 127; kq = r >> 7; } else { kq = r % (2 * KS); n = r / (2 * KS); }
+    const int k0 = 8 * kq, h = kq / KS, ks = kq - h * KS;
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      v[e] = (k0 + e < K && n < n_out) ? (w_in_major ? W[(int64_t)(k0 + e) * ldw + n] : W[(int64_t)n * ldw + k0 + e]) : 0.f;
+    const mlp_split3 sp = mlp_split8(v);
+    img[((ks * 3 + 0) * 2 + h) * 128 + n] = sp.h;
+    img[((ks * 3 + 1) * 2 + h) * 128 + n] = sp.m;
+    img[((ks * 3 + 2) * 2 + h) * 128 + n] = sp.l;
+  }
+  __syncthreads();
+  const int lane = ug_lane(), h = lane >> 5, col = lane & 31;
+  const int64_t n_tiles = (M + 31) >> 5;
+  constexpr int WAVES = UG_LINB_THREADS / 64;
+  const mlp_bf16x8 *__restrict__ wl = img + h * 128 + col;
+  const int k_base = h * KH;
+  const int nt_live = (n_out + 31) >> 5;          // output tiles that hold anything (wave-uniform)
+  for (int64_t tile = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6); tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
+    const int64_t s = tile * 32 + col;
+    const bool row_ok = s < M;
+    const float *__restrict__ xr = X + (row_ok ? s : 0) * ldx + k_base;
+    struct f8 { float v[8]; };
+    auto load8 = [&](int ks) -> f8 {               // elements 8 ks .. 8 ks + 7 of the lane's half row
+      f8 r;
+      if (VEC) {
+        const float4 a = row_ok ? *(const float4 *)(xr + 8 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 b = row_ok ? *(const float4 *)(xr + 8 * ks + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) r.v[e] = (row_ok && k_base + 8 * ks + e < K) ? xr[8 * ks + e] : 0.f;
+      }
+      return r;
+    };
+    mlp_f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    constexpr int AHEAD = KS < 4 ? KS : 4;         // row pieces in flight
+    f8 xq[AHEAD];
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) xq[a] = load8(a);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const mlp_split3 xs = mlp_split8(xq[ks % AHEAD].v);
+      if (ks + AHEAD < KS) xq[ks % AHEAD] = load8(ks + AHEAD);
+      const mlp_bf16x8 *wp = wl + (ks * 3) * 2 * 128;
+      mlp_bf16x8 wm[4], wlo[4], wh[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wm[t] = wp[(1 * 2) * 128 + 32 * t];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wlo[t] = wp[(2 * 2) * 128 + 32 * t];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wm[t], xs.m); }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) wh[t] = wp[(0 * 2) * 128 + 32 * t];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wlo[t], xs.h); }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wh[t], xs.l); }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wm[t], xs.h); }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wh[t], xs.m); }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wh[t], xs.h); }
+    }
+    if (row_ok) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t >= nt_live) continue;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c0 = 32 * t + 8 * q + 4 * h;   // outputs c0 .. c0 + 3 of sample s (n_out % 4 == 0: all four or none)
+          if (c0 >= n_out) continue;
+          float r[4] = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+          if (bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = r[j] + bias[c0 + j];
+          }
+          if (relu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = fmaxf(r[j], 0.f);
+          }
+          if (G) {
+            const float4 g = *(const float4 *)(G + s * ldg + c0);
+            if (!(g.x > 0.f)) r[0] = 0.f;
+            if (!(g.y > 0.f)) r[1] = 0.f;
+            if (!(g.z > 0.f)) r[2] = 0.f;
+            if (!(g.w > 0.f)) r[3] = 0.f;
+          }
+          *(float4 *)(Y + s * ldy + c0) = make_float4(r[0], r[1], r[2], r[3]);
+        }
+      }
+    }
+  }
+}
+
+// dW[c][k] partials with the SAMPLES as the reduction, bf16x3: one wave = 32 output features c x 64 input features k (two column
+// tiles) over the sample chunks of its slab -- A[m = c][kk = sample 8 h + e] = dY, B[kk][n = k] = X, 16 samples per MFMA group.
+// Eight dword loads per operand column and step (lanes = consecutive features: coalesced), fetched one step ahead.
+template <int NT>      // column tiles per wave (>= 2: see the MFMA order below)
+__global__ void __launch_bounds__(256)
+k_wgrad_b3(const float *__restrict__ dY, int ldd, int n_out, const float *__restrict__ X, int ldx, int K, int64_t M,
+           float *__restrict__ partial_w, float *__restrict__ partial_b, int mt_count, int kt_count, int n_slabs) {
+  const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int mt = (int)(wave % mt_count);
+  const int kt = (int)((wave / mt_count) % kt_count);
+  const int slab = (int)(wave / ((int64_t)mt_count * kt_count));
+  if (slab >= n_slabs) return;
+  const int lane = ug_lane(), h = lane >> 5, col = lane & 31;
+  const int c = 32 * mt + col;
+  const bool c_ok = c < n_out;
+  const int kcol0 = 32 * NT * kt + col;
+  mlp_f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float bsum = 0.f;
+  bool k_ok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) k_ok[t] = kcol0 + 32 * t < K;
+  struct opnd { float a[8], b[NT][8]; };
+  auto fetch = [&](int64_t sb, int64_t s1) -> opnd {
+    opnd o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int64_t s = sb + 8 * h + e;
+      const bool on = s < s1;
+      o.a[e] = (on && c_ok) ? dY[s * ldd + c] : 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) o.b[t][e] = (on && k_ok[t]) ? X[s * ldx + kcol0 + 32 * t] : 0.f;
+    }
+    return o;
+  };
+  for (int64_t s0 = (int64_t)slab * UG_WG_CHUNK; s0 < M; s0 += (int64_t)n_slabs * UG_WG_CHUNK) {
+    const int64_t s1 = (s0 + UG_WG_CHUNK < M) ? s0 + UG_WG_CHUNK : M;
+    opnd cur = fetch(s0, s1);
+    for (int64_t sb = s0; sb < s1; sb += 16) {                 // rows >= s1 contribute zeros
+      const opnd nxt = fetch(sb + 16, s1);                     // (past the chunk: all zeros, no loads issued)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) bsum += cur.a[e];
+      const mlp_split3 as = mlp_split8(cur.a);
+      mlp_split3 bs[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) bs[t] = mlp_split8(cur.b[t]);
+      __builtin_amdgcn_sched_barrier(0);
+      // products outer, column tiles inner: consecutive MFMAs never share an accumulator (NT >= 2)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.m, bs[t].m); }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.l, bs[t].h); }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.h, bs[t].l); }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.m, bs[t].h); }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.h, bs[t].m); }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.h, bs[t].h); }
+      cur = nxt;
+    }
+  }
+  float *__restrict__ pw = partial_w + (int64_t)slab * n_out * K;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int k = kcol0 + 32 * t;
+    if (k >= K) continue;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int cc = 32 * mt + 8 * (i >> 2) + 4 * h + (i & 3);
+      if (cc < n_out) pw[(int64_t)cc * K + k] = acc[t][i];
+    }
+  }
+  if (partial_b && kt == 0) {
+    bsum += __shfl_xor(bsum, 32, UG_WAVE);
+    if (h == 0 && c_ok) partial_b[(int64_t)slab * n_out + c] = bsum;
+  }
+}
+
 // Y[s][c] = (G[s][c] > 0) ? sum_{j < K} X[s][j] * W[j][c] : 0 for K <= 4 (the gradient of the 3-channel logits pushed through the
 // last layer): three FMAs per element, one float4 of outputs per lane -- no matrix pipe needed
 __global__ void __launch_bounds__(256)
@@ -259,6 +491,11 @@ k_lin_smallk(const float *__restrict__ X, int64_t M, int K, const float *__restr
   *(float4 *)(Y + s * n_out + c) = make_float4(r[0], r[1], r[2], r[3]);
 }
 
+// ugrid_tune("train_mlp", 0 | 1): arithmetic of the 33..128-wide products of the training rgbnet -- 0 = fp32 MFMA (k_lin / k_wgrad),
+// 1 = bf16x3 (k_lin_b3 / k_wgrad_b3, default).  Both are fp32-accurate; the results differ in the last bits (another rounding of the products).
+static int g_train_mlp = 1;
+extern "C" int ug_set_train_mlp(int m) { if (m < 0 || m > 1) return 1; g_train_mlp = m; return 0; }
+
 static inline int ug_lin_launch(const float *X, int64_t M, int K, int ldx, const float *W, int ldw, int n_out, int w_in_major, const float *bias,
                                 int relu, const float *G, int ldg, float *Y, int ldy, hipStream_t st) {
   if (M <= 0) return 0;
@@ -279,6 +516,28 @@ static inline int ug_lin_launch(const float *X, int64_t M, int K, int ldx, const
   if (K <= 4 && w_in_major && !bias && !relu && ldx == K && ldw == n_out && ldy == n_out && (!G || ldg == n_out) && (n_out & 3) == 0 &&
       ((((uintptr_t)W) | ((uintptr_t)Y) | ((uintptr_t)G)) & 15) == 0) {
     hipLaunchKernelGGL(k_lin_smallk, dim3((unsigned)((M * (n_out >> 2) + 255) / 256)), dim3(256), 0, st, X, M, K, W, n_out, G, Y);
+    UG_LAUNCH_CHECK();
+    return 0;
+  }
+  if (g_train_mlp == 1 && nt == 4 && (n_out & 3) == 0 && (ldy & 3) == 0 && ((uintptr_t)Y & 15) == 0 &&
+      (!G || ((ldg & 3) == 0 && ((uintptr_t)G & 15) == 0))) {
+    constexpr int WB = UG_LINB_THREADS / 64;
+    int64_t wgb = (tiles + WB - 1) / WB;
+    if (wgb > 256) wgb = 256;                      // one persistent 8-wave workgroup per CU (the image is 12 KB per k-step)
+#define UG_LINB_GO(KS_, VEC_)                                                                                                    \
+  {                                                                                                                              \
+    constexpr int lds = KS_ * 2 * 128 * 3 * 16;                                                                                  \
+    UG_SET_DYN_LDS((k_lin_b3<KS_, VEC_>), lds);                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lin_b3<KS_, VEC_>), dim3((unsigned)wgb), dim3(UG_LINB_THREADS), lds, st, X, M, K, ldx, W, ldw,  \
+                       n_out, w_in_major, bias, relu, G, ldg, Y, ldy);                                                           \
+  }
+    const bool al = (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0;
+    if (kh <= 16) { if (al && K == 32) UG_LINB_GO(2, true) else UG_LINB_GO(2, false) }
+    else if (kh <= 24) UG_LINB_GO(3, false)
+    else if (kh <= 32) { if (al && K == 64) UG_LINB_GO(4, true) else UG_LINB_GO(4, false) }
+    else if (kh <= 48) UG_LINB_GO(6, false)
+    else { if (al && K == 128) UG_LINB_GO(8, true) else UG_LINB_GO(8, false) }
+#undef UG_LINB_GO
     UG_LAUNCH_CHECK();
     return 0;
   }
@@ -314,7 +573,12 @@ static inline int ug_wgrad_launch(const float *dY, int ldd, int n_out, const flo
   float *pw = partial, *pb = db ? partial + (size_t)UG_WG_MAX_SLABS * n_out * K : nullptr;
   const int64_t waves = (int64_t)n_slabs * mt_count;
   const dim3 gr((unsigned)((waves + 3) / 4)), bl(256);
-  if (K <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<1>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs);
+  if (g_train_mlp == 1 && K > 32) {                // bf16x3: one wave = 32 output features x 64 input features
+    const int kt_count = (K + 63) / 64;
+    const int64_t wv = (int64_t)n_slabs * mt_count * kt_count;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_b3<2>), dim3((unsigned)((wv + 3) / 4)), bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count,
+                       kt_count, n_slabs);
+  } else if (K <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<1>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs);
   else if (K <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<2>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs);
   else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<4>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs);
   const int n_w = n_out * K, n_b = db ? n_out : 0;
