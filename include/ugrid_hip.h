@@ -246,8 +246,8 @@ int ugrid_tv_adam_dense_cl_touch(const float *param, float *param_out, const flo
  * w2 [3,128] (128 = `width`); feat [M, mlp_in] row-major.  forward: h1, h2 [M,128] (post-ReLU activations, kept for the backward),
  * logits [M,3].
  * backward: g_w*, g_b* (overwritten, not accumulated), g_feat [M, n_feat_grad] = the gradient of the first n_feat_grad input
- * columns (the k0 features; 0 / NULL = none); scratch: ugrid_rgbnet_train_scratch_floats(M) floats.  fp32 products and
- * accumulation; the weight gradients are sums of <= 256 slab partials added in a fixed order (deterministic).  width <= 128
+ * columns (the k0 features; 0 / NULL = none); scratch: ugrid_rgbnet_train_scratch_floats(M) floats.  fp32-accurate products
+ * (bf16x3 or fp32 MFMA: ugrid_tune "train_mlp"), fp32 accumulation; the weight gradients are sums of <= 256 slab partials added in a fixed order (deterministic).  width <= 128
  * (h1 / h2 are [M, width], w0 [width, mlp_in], w1 [width, width], w2 [3, width]), mlp_in <= 128. */
 int64_t ugrid_rgbnet_train_scratch_floats(int64_t M);
 int ugrid_rgbnet_train_forward(const float *feat, int64_t M, int32_t mlp_in, const float *w0, const float *b0, const float *w1,
@@ -508,7 +508,7 @@ int ugrid_train_sample_compact_vox(int64_t n_rays, int32_t slots_per_ray, float 
  *
  *   ugrid_voxgo_step_sample    ugrid_train_sample_dvgo / _dcvgo / ugrid_train_sample, the prefix sums of the two per-ray counts, and the step's ONE
  *                              host read: M1 (stage-1 samples the backward walks) and M2 (samples that reach the rgbnet) are
- *                              written into the struct.  Synchronises `stream`.
+ *                              written into the struct.  Synchronises `stream` (not with sync_free, below).
  *   (the caller sizes the per-sample buffers: ws = ugrid_voxgo_step_ws_floats floats; the visible outputs below)
  *   ugrid_voxgo_step_forward   ugrid_train_sample_compact(_vox), the k0 lookup, ugrid_rgbnet_features,
  *                              ugrid_rgbnet_train_forward, ugrid_render_loss -> out2 = {loss, mse}, rgb_marched, logits, ...
@@ -516,6 +516,14 @@ int ugrid_train_sample_compact_vox(int64_t n_rays, int32_t slots_per_ray, float 
  *                              lookup's scatter into grad_k0_grid (+ touch bitmap when given: channel-last only), and
  *                              ugrid_train_sample_backward + the density scatter into grad_density_grid.  Both grid gradients
  *                              are ADDED to (the caller passes zeros for a fresh gradient).  ws_bwd: ugrid_voxgo_step_bwd_ws_floats.
+ * sync_free = 1 (round 6): the step makes NO host read and synchronises nothing -- every call only enqueues work on `stream`, so
+ *   a whole step can run ahead of the host or be captured in a hipGraph.  The caller sets M1 / M2 to the CAPACITY of the per-sample
+ *   arrays before ugrid_voxgo_step_sample (M1 >= n_rays * slots: the stage-1 arrays cannot overflow; M2 <= M1: stage-2 samples
+ *   beyond it are dropped by the compaction -- memory-safe -- and the caller finds totals[1] > M2 when it next looks); the true
+ *   counts stay in `totals` on the device, every per-sample kernel of the step processes min(capacity, count) rows in grid-stride
+ *   loops whose grids follow hint1 / hint2.  Rows of the per-sample outputs beyond the count are not written.  Forward arrays are
+ *   bit-identical to the host-counted step's; the rgbnet's weight gradients are the same sums cut into slabs by the capacity
+ *   instead of the count (they differ by rounding when the count is below 32 768).
  * Device pointers unless marked HOST.  mode 0: DirectVoxGO (near / far / stepdist / slots used), 1: DirectContractedVoxGO
  * (t_table[slots] / scene_center / scene_radius / bg_len / norm_l2 / dist_thres used), 2: FourierGridModel
  * (FourierGrid_model.py:509-672: ugrid_train_sample over the Fourier density grid, no mask cache; t_table / scene_center /
@@ -552,7 +560,10 @@ typedef struct ugrid_voxgo_step {
   float *alphainv_last;     /* [n_rays] */
   int64_t *seg;             /* [2 n_rays] */
   float *rgb_marched, *ray_tot, *partial, *out2; /* [n_rays,3], [n_rays,2], [n_rays,5], [2] */
-  int64_t M1, M2;           /* written by ugrid_voxgo_step_sample */
+  int64_t M1, M2;           /* written by ugrid_voxgo_step_sample; sync_free: set by the CALLER -- the rows the per-sample arrays hold */
+  int64_t hint1, hint2;     /* sync_free: expected counts (e.g. the previous step's), size the launch grids only; 0 = M1 / M2 */
+  int32_t sync_free;        /* 1: no host read anywhere in the step (below) */
+  int32_t reserved_;
   float *ws;
   float *density2, *alpha2, *weights2, *t2; /* [M2] */
   int64_t *ray_id2, *step_id2;              /* [M2] */
@@ -585,7 +596,10 @@ int ugrid_shade_supported(int32_t freq_num, int32_t k0_channels, int32_t viewbas
  * (dense TV / TV + Adam kernels: linear workgroup order | XCD-contiguous | + non-temporal streams | + slab order (i-planes of a
  * j-slab stay in L2) for the fused channel-last pass, default 3);
  * "shade_pc" 0|1|2 (shade kernel geometry: classic | 8-wave producer / consumer | 12-wave where it applies, default 2 --
- * bit-identical results).  Anything else returns hipErrorInvalidValue. */
+ * bit-identical results).  One knob selects an arithmetic, not only a speed: "train_mlp" 0|1 -- the 33..128-wide products of
+ * ugrid_rgbnet_train_forward / _backward on fp32 MFMAs | on bf16x3 (three-way bf16 split, the six part products above 2^-24,
+ * fp32 accumulation: fp32-accurate, 2.7 x less matrix time; default 1); results of the two differ in the last bits.
+ * Anything else returns hipErrorInvalidValue. */
 int ugrid_tune(const char *key, int value);
 
 /* Total survivors of the last march on this ws -> *d_stats (device int64). */

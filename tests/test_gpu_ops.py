@@ -549,6 +549,48 @@ def test_fused_rgbnet_matches_torch_linear_layers(M, C, E, W):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("M,C,E,W", [(70000, 12, 27, 128), (4097, 15, 27, 128), (3000, 9, 27, 64), (777, 9, 27, 40), (31, 12, 51, 128)])
+def test_fused_rgbnet_bf16x3_kernels_against_the_fp32_mfma_kernels(M, C, E, W):
+    """ugrid_tune('train_mlp', 1) (k_lin_b3 / k_wgrad_b3: every fp32 operand split into three bf16 parts, the six part products above
+    2^-24, fp32 accumulation -- the default since round 6) against ugrid_tune('train_mlp', 0) (v_mfma_f32_32x32x2_f32: exact fp32
+    products) on the same inputs: logits and every gradient to 1e-6 of the tensor's largest magnitude -- two orders below the suite's
+    1e-4 bound for fp32 gradients -- apart from the samples whose pre-activation sits within rounding of zero and lands on the other
+    side of the ReLU (at most M / 20000 + 1 rows; they carry a whole term into the weight gradients).  Inputs at trained-like scales
+    AND at 1e-6 / 1e+4 (the gradient's and a saturated feature's range: bf16 keeps fp32's exponent, no range guard)."""
+    from unboundednerfpytorch_amd import ops, fourier_render as fr
+    torch.manual_seed(M + W)
+    net = torch.nn.Sequential(torch.nn.Linear(C + E, W), torch.nn.ReLU(inplace=True),
+                              torch.nn.Sequential(torch.nn.Linear(W, W), torch.nn.ReLU(inplace=True)), torch.nn.Linear(W, 3)).cuda()
+    lin = ops.rgbnet_linears(net)
+    par = [p for l in lin for p in (l.weight, l.bias)]
+    for scale_in, scale_go in ((1.0, 1.0), (1e4, 1e-6)):
+        k0 = (torch.randn(M, C, device="cuda") * scale_in).requires_grad_(True)
+        emb = torch.randn(M, E, device="cuda")
+        go = torch.randn(M, 3, device="cuda") * scale_go
+        res = []
+        try:
+            for mode in (0, 1):
+                fr.tune("train_mlp", mode)
+                k0.grad = None
+                net.zero_grad(set_to_none=True)
+                out = ops.FusedRgbnet.apply(k0, emb, *par)
+                out.backward(go)
+                res.append([out.detach().clone(), k0.grad.clone()] + [p.grad.clone() for p in par])
+        finally:
+            fr.tune("train_mlp", 1)
+        a, b = res
+        assert not torch.equal(a[0], b[0]) or M < 64            # (the two arithmetics are different roundings: the knob did something)
+        assert float((a[0] - b[0]).abs().max()) <= 1e-6 * float(a[0].abs().max()) + 1e-30
+        row_err = (a[1] - b[1]).abs().amax(dim=1)
+        flips = int((row_err > 1e-6 * float(a[1].abs().max()) + 1e-30).sum())
+        assert flips <= M // 20000 + 1, flips
+        for n, x, y in zip(["w0", "b0", "w1", "b1", "w2", "b2"], a[2:], b[2:]):
+            scale = float(x.abs().max()) + 1e-30
+            tol = (1e-6 if flips == 0 else 1e-2) * scale
+            assert float((x - y).abs().max()) <= tol, (n, float((x - y).abs().max()), scale, flips, scale_in)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("N,M,C,pe", [(8192, 100000, 12, 4), (77, 1000, 9, 4), (5, 0, 12, 4), (300, 4097, 3, 8), (64, 500, 0, 4),
                                       (1, 1, 12, 0), (900, None, 12, 4), (900, 1000, 12, 4)])
 def test_rgbnet_features_equals_the_torch_chain(N, M, C, pe):

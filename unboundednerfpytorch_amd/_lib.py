@@ -85,7 +85,7 @@ class VoxgoStep(_c.Structure):
         ("sc_pts", _P), ("sc_density", _P), ("sc_step", _P), ("sc_w", _P), ("sc_T", _P),
         ("counts", _P), ("offsets", _P), ("totals", _P), ("alphainv_last", _P), ("seg", _P),
         ("rgb_marched", _P), ("ray_tot", _P), ("partial", _P), ("out2", _P),
-        ("M1", _c.c_int64), ("M2", _c.c_int64),
+        ("M1", _c.c_int64), ("M2", _c.c_int64), ("hint1", _c.c_int64), ("hint2", _c.c_int64), ("sync_free", _c.c_int32), ("reserved_", _c.c_int32),
         ("ws", _P),
         ("density2", _P), ("alpha2", _P), ("weights2", _P), ("t2", _P), ("ray_id2", _P), ("step_id2", _P), ("inner2", _P), ("logits", _P),
         ("grad_loss", _P), ("ws_bwd", _P),

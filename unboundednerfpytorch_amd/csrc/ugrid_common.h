@@ -35,6 +35,31 @@
     }                                                                                                         \
   } while (0)
 
+// ---- device-resident row counts (the sync-free training step, ugrid_step.hip) -------------------------------------------------
+// A training step's per-sample arrays have M1 / M2 rows, numbers that exist only on the device until somebody reads them.  While
+// a ug_devn_scope is alive on the calling thread, the launchers of the per-sample training kernels (grid query fwd / bwd, rgbnet
+// features, k_lin*, k_wgrad*, k_l3_*, the loss kernels) hand `ptr` to their kernels, which then process min(n, *ptr) rows in
+// grid-stride loops: the host's `n` is only the CAPACITY of the arrays, and `hint` (> 0: e.g. the previous step's count) sizes the
+// grids.  Without a scope the kernels get a null pointer and behave exactly as before.
+struct ug_devn { const int64_t *ptr; int64_t hint; int64_t cap; };      // cap (> 0): rows the stage-2 arrays hold (compaction drops what exceeds it)
+extern thread_local ug_devn ug_tl_devn;               // defined in ugrid_step.hip
+struct ug_devn_scope {
+  ug_devn saved;
+  ug_devn_scope(const int64_t *p, int64_t hint, int64_t cap = 0) : saved(ug_tl_devn) { ug_tl_devn.ptr = p; ug_tl_devn.hint = hint; ug_tl_devn.cap = cap; }
+  ~ug_devn_scope() { ug_tl_devn = saved; }
+};
+// rows the grid of a launch is sized for: the capacity, or the hint where a device count will stop the kernel anyway
+static inline int64_t ug_launch_rows(int64_t n) {
+  return (ug_tl_devn.ptr && ug_tl_devn.hint > 0 && ug_tl_devn.hint < n) ? ug_tl_devn.hint : n;
+}
+#define UG_DEVN_CLAMP(n, n_dev)                 \
+  do {                                          \
+    if (n_dev) {                                \
+      const int64_t nd_ = *(n_dev);             \
+      if (nd_ < (n)) (n) = nd_ < 0 ? 0 : nd_;   \
+    }                                           \
+  } while (0)
+
 static inline unsigned ug_blocks(int64_t n, int threads) {
   return (unsigned)((n + threads - 1) / threads);
 }

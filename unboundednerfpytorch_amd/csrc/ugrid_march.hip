@@ -126,12 +126,11 @@ __device__ __forceinline__ void ug_level_coords(int l, float ux, float uy, float
 // channels of a voxel are one contiguous run -- the training layout of multi-channel grids, section 4.4 of DESIGN.md);
 // the arithmetic and its order are the same in both layouts.
 template <bool CL>
-__global__ void k_grid_query(const float *__restrict__ grid, int P, int C, int X, int Y, int Z,
-                             const float *__restrict__ xyz, const float *__restrict__ xyz_min,
-                             const float *__restrict__ xyz_max, int F, int64_t n, float *__restrict__ out) {
+__device__ __forceinline__ void ug_grid_query_one(int64_t tid, const float *__restrict__ grid, int P, int C, int X, int Y, int Z,
+                                                  const float *__restrict__ xyz, const float *__restrict__ xyz_min,
+                                                  const float *__restrict__ xyz_max, int F, int64_t n, float *__restrict__ out) {
   // canonical layout: one lane per point, levels and channels in loops.  channel-last: one lane per (point, channel),
   // channel fastest -- the C lanes of a point read one 4C-byte voxel record per corner; same per-channel operation order
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t p = CL ? tid / C : tid;
   if (p >= n) return;
   const float ux = ug_unorm(xyz[3 * p], xyz_min[0], xyz_max[0]);
@@ -172,6 +171,17 @@ __global__ void k_grid_query(const float *__restrict__ grid, int P, int C, int X
   if (F > 0)
     for (int ch = 0; ch < C; ++ch) row[ch] = row[ch] / (float)P;
 }
+// n_dev (may be null): the row count on the device (ug_devn, ugrid_common.h); grid-stride, so that a grid sized by a hint covers any count
+template <bool CL>
+__global__ void k_grid_query(const float *__restrict__ grid, int P, int C, int X, int Y, int Z,
+                             const float *__restrict__ xyz, const float *__restrict__ xyz_min,
+                             const float *__restrict__ xyz_max, int F, int64_t n, float *__restrict__ out,
+                             const int64_t *__restrict__ n_dev) {
+  UG_DEVN_CLAMP(n, n_dev);
+  const int64_t total = CL ? n * C : n;
+  for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (int64_t)gridDim.x * blockDim.x)
+    ug_grid_query_one<CL>(tid, grid, P, C, X, Y, Z, xyz, xyz_min, xyz_max, F, n, out);
+}
 
 // backward w.r.t. the grid: 1 lane per (point, level); grad_grid[l, ch, corner] += w * grad_out[p, ch] / P with
 // hardware fp32 atomics (global_atomic_add_f32).  Like torch's grid_sample backward the accumulation order is
@@ -182,14 +192,13 @@ __global__ void k_grid_query(const float *__restrict__ grid, int P, int C, int X
 // non-zeros (ugrid_touch_words; the marking happens before the lane's own zero test, so that a record any channel of which
 // receives a gradient is always marked).
 template <bool CL>
-__global__ void k_grid_query_backward(const float *__restrict__ grad_out, int P, int C, int X, int Y, int Z,
-                                      const float *__restrict__ xyz, const float *__restrict__ xyz_min,
-                                      const float *__restrict__ xyz_max, int F, int64_t n,
-                                      float *__restrict__ grad_grid, uint32_t *__restrict__ touch) {
+__device__ __forceinline__ void ug_grid_query_backward_one(int64_t tid, const float *__restrict__ grad_out, int P, int C, int X, int Y, int Z,
+                                                           const float *__restrict__ xyz, const float *__restrict__ xyz_min,
+                                                           const float *__restrict__ xyz_max, int F, int64_t n,
+                                                           float *__restrict__ grad_grid, uint32_t *__restrict__ touch) {
   // canonical layout: one lane per (point, level), channels in a loop (each channel is its own volume).
   // channel-last layout: one lane per (point, level, channel), channel fastest -- the C lanes of one (point, level) hit
   // C consecutive floats of one voxel record, so each atomic instruction touches ~64/C records instead of 64 lines.
-  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t q = CL ? tid / C : tid;
   const int chl = CL ? (int)(tid - q * C) : 0;
   if (q >= n * P) return;
@@ -236,6 +245,16 @@ __global__ void k_grid_query_backward(const float *__restrict__ grad_out, int P,
     for (int c = 0; c < 8; ++c)
       if (t.off[c] >= 0) unsafeAtomicAdd(gg + t.off[c], g * t.w[c]);
   }
+}
+template <bool CL>
+__global__ void k_grid_query_backward(const float *__restrict__ grad_out, int P, int C, int X, int Y, int Z,
+                                      const float *__restrict__ xyz, const float *__restrict__ xyz_min,
+                                      const float *__restrict__ xyz_max, int F, int64_t n,
+                                      float *__restrict__ grad_grid, uint32_t *__restrict__ touch, const int64_t *__restrict__ n_dev) {
+  UG_DEVN_CLAMP(n, n_dev);
+  const int64_t total = (CL ? n * C : n) * P;
+  for (int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; tid < total; tid += (int64_t)gridDim.x * blockDim.x)
+    ug_grid_query_backward_one<CL>(tid, grad_out, P, C, X, Y, Z, xyz, xyz_min, xyz_max, F, n, grad_grid, touch);
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -529,7 +548,7 @@ k_train_compact2(int64_t n_rays, int32_t S, float shift, float interval, float t
                  float *__restrict__ pts1, float *__restrict__ dens1, float *__restrict__ w1, float *__restrict__ T1,
                  int32_t *__restrict__ pos2, float *__restrict__ pts2, float *__restrict__ dens2, float *__restrict__ alpha2,
                  float *__restrict__ w2, int64_t *__restrict__ ray_id2, int64_t *__restrict__ step_id2, float *__restrict__ tt2,
-                 uint8_t *__restrict__ inner2) {
+                 uint8_t *__restrict__ inner2, int64_t cap2) {
   const int64_t ray = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (ray >= n_rays) return;
   const int lane = ug_lane();
@@ -552,8 +571,10 @@ k_train_compact2(int64_t n_rays, int32_t S, float shift, float interval, float t
     const bool k2 = on && w > thres;
     const unsigned long long m = __ballot(k2);
     const int64_t o = d2 + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-    if (on) pos2[d1 + i] = k2 ? (int32_t)o : -1;
-    if (k2) {
+    // cap2: rows the stage-2 arrays hold (sync-free step with a caller-chosen capacity: what exceeds it is dropped, memory-safe, and
+    // the caller finds totals[1] > capacity when it next looks; everywhere else cap2 = INT64_MAX)
+    if (on) pos2[d1 + i] = (k2 && o < cap2) ? (int32_t)o : -1;
+    if (k2 && o < cap2) {
       float e;
       pts2[3 * o] = px; pts2[3 * o + 1] = py; pts2[3 * o + 2] = pz;
       dens2[o] = dn;
@@ -693,7 +714,7 @@ extern "C" int ugrid_train_sample_compact(int64_t n_rays, int32_t n_samples, flo
   hipLaunchKernelGGL(k_train_compact2, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), n_rays, n_samples, act_shift, interval,
                      thres, scratch_pts, scratch_density, scratch_step, scratch_w, scratch_T, count, offset_end, count2, offset_end2,
                      t_table, pts1, density1, weights1, T1, pos2, pts2, density2, alpha2, weights2, ray_id2, step_id2, t2,
-                     (uint8_t *)nullptr);
+                     (uint8_t *)nullptr, ug_tl_devn.cap > 0 ? ug_tl_devn.cap : INT64_MAX);
   UG_LAUNCH_CHECK();
   return 0;
 }
@@ -772,7 +793,7 @@ extern "C" int ugrid_train_sample_compact_vox(int64_t n_rays, int32_t slots_per_
   hipLaunchKernelGGL(k_train_compact2, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(s), n_rays, slots_per_ray, act_shift,
                      interval, thres, scratch_pts, scratch_density, scratch_step, scratch_w, scratch_T, count, offset_end, count2,
                      offset_end2, t_table, pts1, density1, weights1, T1, pos2, pts2, density2, alpha2, weights2, ray_id2, step_id2, t2,
-                     inner2);
+                     inner2, ug_tl_devn.cap > 0 ? ug_tl_devn.cap : INT64_MAX);
   UG_LAUNCH_CHECK();
   return 0;
 }
@@ -858,12 +879,13 @@ static int ug_grid_query_any(bool cl, const float *grid, int P, int C, int X, in
                              const float *xyz_min, const float *xyz_max, int freq_num, int64_t n, float *out, hipStream_t st) {
   if (n <= 0) return 0;
   if (P != (freq_num > 0 ? 2 * freq_num + 1 : 1)) return (int)hipErrorInvalidValue;
+  const int64_t nl = ug_launch_rows(n);          // (a device count in force: the grid follows the hint, the kernel the count)
   if (cl)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query<true>), dim3(ug_blocks(n * C, 256)), dim3(256), 0, st, grid, P, C, X, Y, Z, xyz,
-                       xyz_min, xyz_max, freq_num, n, out);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query<true>), dim3(ug_blocks(nl * C, 256)), dim3(256), 0, st, grid, P, C, X, Y, Z, xyz,
+                       xyz_min, xyz_max, freq_num, n, out, ug_tl_devn.ptr);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query<false>), dim3(ug_blocks(n, 256)), dim3(256), 0, st, grid, P, C, X, Y, Z, xyz,
-                       xyz_min, xyz_max, freq_num, n, out);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query<false>), dim3(ug_blocks(nl, 256)), dim3(256), 0, st, grid, P, C, X, Y, Z, xyz,
+                       xyz_min, xyz_max, freq_num, n, out, ug_tl_devn.ptr);
   UG_LAUNCH_CHECK();
   return 0;
 }
@@ -885,12 +907,13 @@ static int ug_grid_query_backward_any(bool cl, const float *grad_out, int P, int
                                       float *grad_grid, hipStream_t st, uint32_t *touch = nullptr) {
   if (n <= 0) return 0;
   if (P != (freq_num > 0 ? 2 * freq_num + 1 : 1)) return (int)hipErrorInvalidValue;
+  const int64_t nl = ug_launch_rows(n);
   if (cl)
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query_backward<true>), dim3(ug_blocks(n * P * C, 256)), dim3(256), 0, st, grad_out, P, C,
-                       X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid, touch);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query_backward<true>), dim3(ug_blocks(nl * P * C, 256)), dim3(256), 0, st, grad_out, P, C,
+                       X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid, touch, ug_tl_devn.ptr);
   else
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query_backward<false>), dim3(ug_blocks(n * P, 256)), dim3(256), 0, st, grad_out, P, C,
-                       X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid, (uint32_t *)nullptr);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_grid_query_backward<false>), dim3(ug_blocks(nl * P, 256)), dim3(256), 0, st, grad_out, P, C,
+                       X, Y, Z, xyz, xyz_min, xyz_max, freq_num, n, grad_grid, (uint32_t *)nullptr, ug_tl_devn.ptr);
   UG_LAUNCH_CHECK();
   return 0;
 }

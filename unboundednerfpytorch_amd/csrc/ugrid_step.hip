@@ -12,6 +12,8 @@
 
 #define ST(s) ((hipStream_t)(s))
 
+thread_local ug_devn ug_tl_devn = {nullptr, 0, 0};      // (ugrid_common.h: the device-resident row count of the sync-free step)
+
 // inclusive int64 prefix sums of the two int32 count rows [2, n] (block b = row b), totals[b] = the row's sum (torch.cumsum of the
 // op-by-op step).  Tiles of 1024 threads x 4 consecutive counts: the four loads of a thread are independent (one latency per
 // tile, not one per element), thread sums are scanned with wave shuffles + one LDS round over the 16 waves.
@@ -105,8 +107,13 @@ static int ug_step_check(const ugrid_voxgo_step *s) {
   if (s->P != 1 + 2 * s->freq_num && !(s->P == 1 && s->freq_num == 0)) return (int)hipErrorInvalidValue;
   if (s->kP != 1 + 2 * s->k0_freq_num && !(s->kP == 1 && s->k0_freq_num == 0)) return (int)hipErrorInvalidValue;
   if (s->width < 1 || s->width > 128 || s->C + 3 + 6 * s->pe > 128) return (int)hipErrorNotSupported;
+  if (s->sync_free && (s->M1 < s->n_rays * (int64_t)s->slots || s->M2 < 1 || s->M2 > s->M1 || s->hint1 < 0 || s->hint2 < 0))
+    return (int)hipErrorInvalidValue;                    // capacities: stage 1 cannot overflow, stage 2 is clamped by the compaction
   return 0;
 }
+// the count of the step's stage-1 / stage-2 arrays as the kernels see it: on the device (sync_free) or the host's number
+#define UG_STEP_ROWS1(s) ug_devn_scope rows_scope_((s)->sync_free ? (s)->totals : nullptr, (s)->hint1, 0)
+#define UG_STEP_ROWS2(s) ug_devn_scope rows_scope_((s)->sync_free ? (s)->totals + 1 : nullptr, (s)->hint2, (s)->sync_free ? (s)->M2 : 0)
 
 extern "C" int ugrid_voxgo_step_sample(ugrid_voxgo_step *s, ugrid_stream_t st) {
   int rc = ug_step_check(s);
@@ -129,6 +136,7 @@ extern "C" int ugrid_voxgo_step_sample(ugrid_voxgo_step *s, ugrid_stream_t st) {
   if (rc) return rc;
   hipLaunchKernelGGL(k_step_count_scan, dim3(2), dim3(UG_STEP_SCAN_THREADS), 0, ST(st), s->counts, R, s->offsets, s->totals);
   UG_LAUNCH_CHECK();
+  if (s->sync_free) return 0;                          // M1 / M2 stay the caller's capacities; the counts stay in s->totals
   static thread_local int64_t *pinned = nullptr;      // the step's one host read lands in page-locked memory
   if (!pinned) UG_HIP(hipHostMalloc((void **)&pinned, 2 * sizeof(int64_t), hipHostMallocDefault));
   UG_HIP(hipMemcpyAsync(pinned, s->totals, 2 * sizeof(int64_t), hipMemcpyDeviceToHost, ST(st)));
@@ -145,6 +153,7 @@ extern "C" int ugrid_voxgo_step_forward(const ugrid_voxgo_step *s, ugrid_stream_
   const ug_step_ws w = ug_step_layout(s);
   const int64_t R = s->n_rays, M2 = s->M2;
   const int K = s->C + 3 + 6 * s->pe;
+  UG_STEP_ROWS2(s);
   if (s->M1 > 0 && s->mode == 2) {
     rc = ugrid_train_sample_compact(R, s->slots, s->act_shift, s->interval, s->thres, s->sc_pts, s->sc_density, s->sc_step, s->sc_w, s->sc_T,
                                     s->counts, s->offsets, s->counts + R, s->offsets + R, s->t_table, w.pts1, w.dens1, w.w1, w.T1, w.pos2,
@@ -177,6 +186,7 @@ extern "C" int ugrid_voxgo_step_backward_k0(const ugrid_voxgo_step *s, ugrid_str
   const ug_step_ws_bwd b = ug_step_layout_bwd(s);
   const int64_t R = s->n_rays, M2 = s->M2;
   const int K = s->C + 3 + 6 * s->pe;
+  UG_STEP_ROWS2(s);
   rc = ugrid_render_loss_backward(s->logits, s->weights2, nullptr, s->t2, s->alphainv_last, s->bg, s->target, s->ray_id2, M2, R, s->coef9,
                                   s->seg, s->rgb_marched, s->ray_tot, s->grad_loss, b.g_logits, b.g_w, b.g_ainv, b.g_dens, st);
   if (rc) return rc;
@@ -198,6 +208,7 @@ extern "C" int ugrid_voxgo_step_backward_density(const ugrid_voxgo_step *s, ugri
   if (s->M1 <= 0) return 0;
   const ug_step_ws w = ug_step_layout(s);
   const ug_step_ws_bwd b = ug_step_layout_bwd(s);
+  UG_STEP_ROWS1(s);
   rc = ugrid_train_sample_backward(s->n_rays, s->act_shift, s->interval, w.dens1, w.w1, w.T1, w.pos2, s->counts, s->offsets, s->alphainv_last,
                                    b.g_w, b.g_ainv, b.g_dens, b.g1, st);
   if (rc) return rc;

@@ -116,7 +116,8 @@ k_render_loss_fwd(const float *__restrict__ logits, const float *__restrict__ we
 // one block: fixed-order reduction of the [R,5] partials, then the weighted sum.  out = {loss, mse}
 __global__ void __launch_bounds__(256)
 k_render_loss_final(const float *__restrict__ partial, int64_t n_rays, const int64_t *__restrict__ ray_id, int64_t n,
-                    ug_loss_coef c, float *__restrict__ out) {
+                    ug_loss_coef c, float *__restrict__ out, const int64_t *__restrict__ n_dev) {
+  UG_DEVN_CLAMP(n, n_dev);
   constexpr int NP = UG_LOSS_PARTIALS;
   __shared__ float red[NP][256];
   float acc[NP];
@@ -154,9 +155,10 @@ k_render_loss_bwd(const float *__restrict__ logits, const float *__restrict__ we
                   const int64_t *__restrict__ i_start, const int64_t *__restrict__ i_end, int64_t n_rays, ug_loss_coef c,
                   const float *__restrict__ rgb_marched, const float *__restrict__ ray_tot,
                   const float *__restrict__ grad_loss, float *__restrict__ g_logits, float *__restrict__ g_weights,
-                  float *__restrict__ g_ainv, float *__restrict__ g_density) {
+                  float *__restrict__ g_ainv, float *__restrict__ g_density, const int64_t *__restrict__ n_dev) {
   const int64_t r = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   if (r >= n_rays) return;
+  UG_DEVN_CLAMP(n, n_dev);
   const int lane = ug_lane();
   const int64_t i_s = i_start[r], i_e = i_end[r];
   const float g = grad_loss[0];
@@ -223,19 +225,21 @@ static ug_loss_coef ug_coef(const float *h) {
 }
 
 // k_segments of ugrid_ops.hip (ray_id ascending -> [i_start, i_end) per ray, empty rays 0,0)
+// (n_dev: the sample count on the device, ug_devn in ugrid_common.h; null = n)
 __global__ void k_loss_segments(const int64_t *__restrict__ ray_id, int64_t n, int64_t *__restrict__ i_start,
-                                int64_t *__restrict__ i_end) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int64_t r = ray_id[i];
-  if (i > 0) {
-    const int64_t rp = ray_id[i - 1];
-    if (r != rp) {
-      i_start[r] = i;
-      i_end[rp] = i;
+                                int64_t *__restrict__ i_end, const int64_t *__restrict__ n_dev) {
+  UG_DEVN_CLAMP(n, n_dev);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = ray_id[i];
+    if (i > 0) {
+      const int64_t rp = ray_id[i - 1];
+      if (r != rp) {
+        i_start[r] = i;
+        i_end[rp] = i;
+      }
     }
+    if (i == n - 1) i_end[r] = n;
   }
-  if (i == n - 1) i_end[r] = n;
 }
 
 extern "C" int ugrid_render_loss(const float *logits, const float *weights, const float *s, const float *t, const float *alphainv_last,
@@ -245,11 +249,11 @@ extern "C" int ugrid_render_loss(const float *logits, const float *weights, cons
   if (n_rays <= 0 || (n > 0 && !s && !t)) return (int)hipErrorInvalidValue;      // (no samples: empty arrays have no address)
   int64_t *i_start = seg_scratch, *i_end = seg_scratch + n_rays;
   UG_HIP(hipMemsetAsync(seg_scratch, 0, sizeof(int64_t) * 2 * n_rays, ST(st)));
-  if (n > 0) hipLaunchKernelGGL(k_loss_segments, dim3(ug_blocks(n, 256)), dim3(256), 0, ST(st), ray_id, n, i_start, i_end);
+  if (n > 0) hipLaunchKernelGGL(k_loss_segments, dim3(ug_blocks(ug_launch_rows(n), 256)), dim3(256), 0, ST(st), ray_id, n, i_start, i_end, ug_tl_devn.ptr);
   const ug_loss_coef c = ug_coef(h_coef9);
   hipLaunchKernelGGL(k_render_loss_fwd, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(st), logits, weights, s, t,
                      alphainv_last, bg, target, i_start, i_end, n_rays, c, rgb_marched, ray_tot, partial);
-  hipLaunchKernelGGL(k_render_loss_final, dim3(1), dim3(256), 0, ST(st), partial, n_rays, ray_id, n, c, out2);
+  hipLaunchKernelGGL(k_render_loss_final, dim3(1), dim3(256), 0, ST(st), partial, n_rays, ray_id, n, c, out2, ug_tl_devn.ptr);
   UG_LAUNCH_CHECK();
   return 0;
 }
@@ -264,7 +268,7 @@ extern "C" int ugrid_render_loss_backward(const float *logits, const float *weig
   const ug_loss_coef c = ug_coef(h_coef9);
   hipLaunchKernelGGL(k_render_loss_bwd, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(st), logits, weights, s, t,
                      alphainv_last, bg, target, ray_id, n, seg_scratch, seg_scratch + n_rays, n_rays, c, rgb_marched, ray_tot,
-                     grad_loss, g_logits, g_weights, g_alphainv_last, g_density);
+                     grad_loss, g_logits, g_weights, g_alphainv_last, g_density, ug_tl_devn.ptr);
   UG_LAUNCH_CHECK();
   return 0;
 }
@@ -276,28 +280,32 @@ extern "C" int ugrid_render_loss_backward(const float *logits, const float *weig
 template <typename IDX>      // uint32_t when the element count fits (a 64-bit division is ~100 VALU instructions, the kernel's largest cost)
 __global__ void __launch_bounds__(256)
 k_rgbnet_features(const float *__restrict__ k0, int C, const float *__restrict__ viewdirs, const float *__restrict__ freq, int pe,
-                  const int64_t *__restrict__ ray_id, int64_t total, float *__restrict__ out) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
+                  const int64_t *__restrict__ ray_id, int64_t total, float *__restrict__ out, const int64_t *__restrict__ n_dev) {
   const int K = C + 3 + 6 * pe;
-  const int64_t m = (int64_t)((IDX)idx / (IDX)K);
-  const int j = (int)(idx - m * K);
-  if (j < C) {
-    out[idx] = k0[m * C + j];
-    return;
+  if (n_dev) {                                   // rows on the device (ug_devn): total = rows * K
+    const int64_t td = *n_dev * K;
+    if (td < total) total = td;
   }
-  const float *v = viewdirs + 3 * (ray_id ? ray_id[m] : m);
-  int e = j - C;
-  if (e < 3) {
-    out[idx] = v[e];
-    return;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = (int64_t)((IDX)idx / (IDX)K);
+    const int j = (int)(idx - m * K);
+    if (j < C) {
+      out[idx] = k0[m * C + j];
+      continue;
+    }
+    const float *v = viewdirs + 3 * (ray_id ? ray_id[m] : m);
+    int e = j - C;
+    if (e < 3) {
+      out[idx] = v[e];
+      continue;
+    }
+    e -= 3;
+    const bool is_cos = e >= 3 * pe;
+    if (is_cos) e -= 3 * pe;
+    const int a = e / pe;
+    const float x = v[a] * freq[e - a * pe];
+    out[idx] = is_cos ? cosf(x) : sinf(x);
   }
-  e -= 3;
-  const bool is_cos = e >= 3 * pe;
-  if (is_cos) e -= 3 * pe;
-  const int a = e / pe;
-  const float x = v[a] * freq[e - a * pe];
-  out[idx] = is_cos ? cosf(x) : sinf(x);
 }
 
 // out[m] = [k0[m] | ray_rows[ray_id[m]]]: the view embedding formed once per RAY (k_rgbnet_features over the rays) and gathered --
@@ -305,13 +313,17 @@ k_rgbnet_features(const float *__restrict__ k0, int C, const float *__restrict__
 template <typename IDX>
 __global__ void __launch_bounds__(256)
 k_rgbnet_rows(const float *__restrict__ k0, int C, const float *__restrict__ ray_rows, int E, const int64_t *__restrict__ ray_id,
-              int64_t total, float *__restrict__ out) {
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= total) return;
+              int64_t total, float *__restrict__ out, const int64_t *__restrict__ n_dev) {
   const int K = C + E;
-  const int64_t m = (int64_t)((IDX)idx / (IDX)K);
-  const int j = (int)(idx - m * K);
-  out[idx] = j < C ? k0[m * C + j] : ray_rows[ray_id[m] * E + (j - C)];
+  if (n_dev) {
+    const int64_t td = *n_dev * K;
+    if (td < total) total = td;
+  }
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = (int64_t)((IDX)idx / (IDX)K);
+    const int j = (int)(idx - m * K);
+    out[idx] = j < C ? k0[m * C + j] : ray_rows[ray_id[m] * E + (j - C)];
+  }
 }
 
 extern "C" int ugrid_rgbnet_features(const float *k0, int32_t n_k0, const float *viewdirs, int64_t n_rays, const float *viewfreq, int32_t pe,
@@ -321,17 +333,19 @@ extern "C" int ugrid_rgbnet_features(const float *k0, int32_t n_k0, const float 
   const int64_t total = m * (n_k0 + E);
   if (total == 0) return 0;                                  // (no samples: empty arrays have no address)
   if ((n_k0 > 0 && !k0) || (pe > 0 && !viewfreq) || !viewdirs || !out) return (int)hipErrorInvalidValue;
-#define UG_FEAT(KERNEL, N, ...)                                                                                                     \
-  if ((N) < ((int64_t)1 << 32))                                                                                                     \
+#define UG_FEAT(KERNEL, N, NMAX, ...)      /* N: elements the grid is sized for; NMAX: the largest element index + 1 */           \
+  if ((NMAX) < ((int64_t)1 << 32))                                                                                                  \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<uint32_t>), dim3(ug_blocks((N), 256)), dim3(256), 0, ST(st), __VA_ARGS__);            \
   else                                                                                                                              \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(KERNEL<uint64_t>), dim3(ug_blocks((N), 256)), dim3(256), 0, ST(st), __VA_ARGS__);
   if (ray_id && ray_rows && n_rays > 0 && m >= 2 * n_rays) {
     const int64_t per_ray = n_rays * E;
-    UG_FEAT(k_rgbnet_features, per_ray, nullptr, 0, viewdirs, viewfreq, pe, nullptr, per_ray, ray_rows)
-    UG_FEAT(k_rgbnet_rows, total, k0, n_k0, ray_rows, E, ray_id, total, out)
+    const int64_t total_l = ug_launch_rows(m) * (n_k0 + E);
+    UG_FEAT(k_rgbnet_features, per_ray, per_ray, nullptr, 0, viewdirs, viewfreq, pe, nullptr, per_ray, ray_rows, (const int64_t *)nullptr)
+    UG_FEAT(k_rgbnet_rows, total_l, total, k0, n_k0, ray_rows, E, ray_id, total, out, ug_tl_devn.ptr)
   } else {
-    UG_FEAT(k_rgbnet_features, total, k0, n_k0, viewdirs, viewfreq, pe, ray_id, total, out)
+    const int64_t total_l = ug_launch_rows(m) * (n_k0 + E);
+    UG_FEAT(k_rgbnet_features, total_l, total, k0, n_k0, viewdirs, viewfreq, pe, ray_id, total, out, ug_tl_devn.ptr)
   }
 #undef UG_FEAT
   UG_LAUNCH_CHECK();

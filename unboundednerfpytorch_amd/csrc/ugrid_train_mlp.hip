@@ -42,7 +42,9 @@ typedef float mlp_f32x16 __attribute__((ext_vector_type(16)));
 template <int KH, int NT, bool VEC>
 __global__ void __launch_bounds__(UG_LIN_THREADS)
 k_lin(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__restrict__ W, int ldw, int n_out, int w_in_major,
-      const float *__restrict__ bias, int relu, const float *__restrict__ G, int ldg, float *__restrict__ Y, int ldy) {
+      const float *__restrict__ bias, int relu, const float *__restrict__ G, int ldg, float *__restrict__ Y, int ldy,
+      const int64_t *__restrict__ n_dev) {
+  UG_DEVN_CLAMP(M, n_dev);                        // (rows on the device: ug_devn, ugrid_common.h)
   extern __shared__ float lds[];                  // weight image Ws[k][c], rows of NP + 1 floats (zero padded)
   constexpr int NP = NT * 32, NPP = NP + 1, K2 = 2 * KH;
   static_assert(KH % 4 == 0, "k-steps come in rounds of four");
@@ -139,11 +141,12 @@ k_lin(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__res
 template <int NT>
 __global__ void __launch_bounds__(256)
 k_wgrad(const float *__restrict__ dY, int ldd, int n_out, const float *__restrict__ X, int ldx, int K, int64_t M,
-        float *__restrict__ partial_w, float *__restrict__ partial_b, int mt_count, int n_slabs) {
+        float *__restrict__ partial_w, float *__restrict__ partial_b, int mt_count, int n_slabs, const int64_t *__restrict__ n_dev) {
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int mt = (int)(wave % mt_count);
   const int slab = (int)(wave / mt_count);
   if (slab >= n_slabs) return;
+  UG_DEVN_CLAMP(M, n_dev);
   const int lane = ug_lane(), h = lane >> 5, col = lane & 31;
   const int c = 32 * mt + col;
   const bool c_ok = c < n_out;
@@ -274,7 +277,9 @@ __device__ __forceinline__ mlp_split3 mlp_split8(const float (&x)[8]) {
 template <int KS, bool VEC>
 __global__ void __launch_bounds__(UG_LINB_THREADS)
 k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__restrict__ W, int ldw, int n_out, int w_in_major,
-         const float *__restrict__ bias, int relu, const float *__restrict__ G, int ldg, float *__restrict__ Y, int ldy) {
+         const float *__restrict__ bias, int relu, const float *__restrict__ G, int ldg, float *__restrict__ Y, int ldy,
+         const int64_t *__restrict__ n_dev) {
+  UG_DEVN_CLAMP(M, n_dev);
   extern __shared__ float lds[];
   mlp_bf16x8 *img = (mlp_bf16x8 *)lds;
   constexpr int KH = 8 * KS, N_REC = 2 * KS * 128;
@@ -388,7 +393,9 @@ k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__
 template <int NT>      // column tiles per wave (>= 2: see the MFMA order below)
 __global__ void __launch_bounds__(256)
 k_wgrad_b3(const float *__restrict__ dY, int ldd, int n_out, const float *__restrict__ X, int ldx, int K, int64_t M,
-           float *__restrict__ partial_w, float *__restrict__ partial_b, int mt_count, int kt_count, int n_slabs) {
+           float *__restrict__ partial_w, float *__restrict__ partial_b, int mt_count, int kt_count, int n_slabs,
+           const int64_t *__restrict__ n_dev) {
+  UG_DEVN_CLAMP(M, n_dev);
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int mt = (int)(wave % mt_count);
   const int kt = (int)((wave / mt_count) % kt_count);
@@ -469,10 +476,10 @@ k_wgrad_b3(const float *__restrict__ dY, int ldd, int n_out, const float *__rest
 // last layer): three FMAs per element, one float4 of outputs per lane -- no matrix pipe needed
 __global__ void __launch_bounds__(256)
 k_lin_smallk(const float *__restrict__ X, int64_t M, int K, const float *__restrict__ W, int n_out, const float *__restrict__ G,
-             float *__restrict__ Y) {
+             float *__restrict__ Y, const int64_t *__restrict__ n_dev) {
+  UG_DEVN_CLAMP(M, n_dev);
   const int q4 = n_out >> 2;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= M * q4) return;
+  for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < M * q4; idx += (int64_t)gridDim.x * blockDim.x) {
   const int64_t s = idx / q4;
   const int c = (int)(idx - s * q4) * 4;
   float r[4] = {0.f, 0.f, 0.f, 0.f};
@@ -489,6 +496,7 @@ k_lin_smallk(const float *__restrict__ X, int64_t M, int K, const float *__restr
     if (!(g.w > 0.f)) r[3] = 0.f;
   }
   *(float4 *)(Y + s * n_out + c) = make_float4(r[0], r[1], r[2], r[3]);
+  }
 }
 
 // ugrid_tune("train_mlp", 0 | 1): arithmetic of the 33..128-wide products of the training rgbnet -- 0 = fp32 MFMA (k_lin / k_wgrad),
@@ -501,7 +509,7 @@ static inline int ug_lin_launch(const float *X, int64_t M, int K, int ldx, const
   if (M <= 0) return 0;
   if (K < 1 || K > 128 || n_out < 1 || n_out > 128) return (int)hipErrorNotSupported;
   const int kh = (K + 1) / 2, nt = n_out <= 32 ? 1 : 4;
-  const int64_t tiles = (M + 31) / 32;
+  const int64_t tiles = (ug_launch_rows(M) + 31) / 32;      // (grid only: the kernels loop over the tiles of the rows they find)
   constexpr int WAVES = UG_LIN_THREADS / 64;
   int64_t wgs = (tiles + WAVES - 1) / WAVES;
   if (wgs > 256) wgs = 256;                        // one persistent 16-wave workgroup per CU: the weights are staged once
@@ -510,12 +518,13 @@ static inline int ug_lin_launch(const float *X, int64_t M, int K, int ldx, const
     constexpr int lds = 2 * KH * (NT_ * 32 + 1) * 4;                                                                             \
     UG_SET_DYN_LDS((k_lin<KH, NT_, VEC_>), lds);   /* per device */                                                   \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lin<KH, NT_, VEC_>), dim3((unsigned)wgs), dim3(UG_LIN_THREADS), lds, st, X, M, K, ldx, W, ldw, \
-                       n_out, w_in_major, bias, relu, G, ldg, Y, ldy);                                                           \
+                       n_out, w_in_major, bias, relu, G, ldg, Y, ldy, ug_tl_devn.ptr);                                           \
   }
   const bool vec = K == 128 && (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0;
   if (K <= 4 && w_in_major && !bias && !relu && ldx == K && ldw == n_out && ldy == n_out && (!G || ldg == n_out) && (n_out & 3) == 0 &&
       ((((uintptr_t)W) | ((uintptr_t)Y) | ((uintptr_t)G)) & 15) == 0) {
-    hipLaunchKernelGGL(k_lin_smallk, dim3((unsigned)((M * (n_out >> 2) + 255) / 256)), dim3(256), 0, st, X, M, K, W, n_out, G, Y);
+    hipLaunchKernelGGL(k_lin_smallk, dim3((unsigned)((ug_launch_rows(M) * (n_out >> 2) + 255) / 256)), dim3(256), 0, st, X, M, K, W, n_out, G, Y,
+                       ug_tl_devn.ptr);
     UG_LAUNCH_CHECK();
     return 0;
   }
@@ -529,7 +538,7 @@ static inline int ug_lin_launch(const float *X, int64_t M, int K, int ldx, const
     constexpr int lds = KS_ * 2 * 128 * 3 * 16;                                                                                  \
     UG_SET_DYN_LDS((k_lin_b3<KS_, VEC_>), lds);                                                                                  \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lin_b3<KS_, VEC_>), dim3((unsigned)wgb), dim3(UG_LINB_THREADS), lds, st, X, M, K, ldx, W, ldw,  \
-                       n_out, w_in_major, bias, relu, G, ldg, Y, ldy);                                                           \
+                       n_out, w_in_major, bias, relu, G, ldg, Y, ldy, ug_tl_devn.ptr);                                           \
   }
     const bool al = (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0;
     if (kh <= 16) { if (al && K == 32) UG_LINB_GO(2, true) else UG_LINB_GO(2, false) }
@@ -577,10 +586,10 @@ static inline int ug_wgrad_launch(const float *dY, int ldd, int n_out, const flo
     const int kt_count = (K + 63) / 64;
     const int64_t wv = (int64_t)n_slabs * mt_count * kt_count;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad_b3<2>), dim3((unsigned)((wv + 3) / 4)), bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count,
-                       kt_count, n_slabs);
-  } else if (K <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<1>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs);
-  else if (K <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<2>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs);
-  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<4>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs);
+                       kt_count, n_slabs, ug_tl_devn.ptr);
+  } else if (K <= 32) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<1>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs, ug_tl_devn.ptr);
+  else if (K <= 64) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<2>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs, ug_tl_devn.ptr);
+  else hipLaunchKernelGGL(HIP_KERNEL_NAME(k_wgrad<4>), gr, bl, 0, st, dY, ldd, n_out, X, ldx, K, M, pw, pb, mt_count, n_slabs, ug_tl_devn.ptr);
   const int n_w = n_out * K, n_b = db ? n_out : 0;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((n_w + n_b + 15) / 16), dim3(256), 0, st, pw, pb, n_slabs, n_w, n_b, dW, db);
   UG_LAUNCH_CHECK();
@@ -600,7 +609,8 @@ static inline int ug_wgrad_launch(const float *dY, int ldd, int n_out, const flo
 template <int LPR>      // lanes per row: the power of two >= W / 4
 __global__ void __launch_bounds__(256)
 k_l3_fwd(const float *__restrict__ h2, int64_t M, int W, const float *__restrict__ w3, const float *__restrict__ b3,
-         float *__restrict__ logits) {
+         float *__restrict__ logits, const int64_t *__restrict__ n_dev) {
+  UG_DEVN_CLAMP(M, n_dev);
   constexpr int RPW = UG_WAVE / LPR;                 // rows per wave and iteration
   const int lane = ug_lane(), sub = lane % LPR, rw = lane / LPR;
   const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, n_waves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -634,18 +644,22 @@ k_l3_fwd(const float *__restrict__ h2, int64_t M, int W, const float *__restrict
 
 __global__ void __launch_bounds__(256)
 k_l3_bwd(const float *__restrict__ g, const float *__restrict__ h2, int64_t M, int W, const float *__restrict__ w3,
-         float *__restrict__ g_h2, float *__restrict__ partial_w, float *__restrict__ partial_b, int rows_per_block) {
+         float *__restrict__ g_h2, float *__restrict__ partial_w, float *__restrict__ partial_b, int rows_per_block,
+         const int64_t *__restrict__ n_dev) {
+  UG_DEVN_CLAMP(M, n_dev);
   __shared__ float red[3840];                        // [row groups][3 W + 3]: (1024 / W) * (3 W + 3) <= 3840 floats
   const int W4 = W >> 2, RPI = 256 / W4;             // float4 columns per row; rows per iteration
   const int t = threadIdx.x, col4 = t % W4, grp = t / W4;
   const bool live = grp < RPI;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
   float4 wv[3];
 #pragma unroll
   for (int c = 0; c < 3; ++c) wv[c] = *(const float4 *)(w3 + (int64_t)c * W + 4 * col4);
   float acc[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   float bs[3] = {0.f, 0.f, 0.f};
   if (live) {
+    // the block's row chunks: one when the grid covers the rows (the host-counted case), more when a device count exceeds the hint
+    for (int64_t r0 = (int64_t)blockIdx.x * rows_per_block; r0 < M; r0 += (int64_t)gridDim.x * rows_per_block) {
+    const int64_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
     for (int64_t s = r0 + grp; s < r1; s += RPI) {
       const float g0 = g[3 * s], g1 = g[3 * s + 1], g2 = g[3 * s + 2];
       const float4 h = *(const float4 *)(h2 + s * W + 4 * col4);
@@ -670,6 +684,7 @@ k_l3_bwd(const float *__restrict__ g, const float *__restrict__ h2, int64_t M, i
         bs[1] += g1;
         bs[2] += g2;
       }
+    }
     }
     const int stride = 3 * W + 3;
 #pragma unroll
@@ -697,10 +712,10 @@ static int ug_l3_forward(const float *h2, int64_t M, int W, const float *w3, con
   if (M <= 0) return 0;
   const int w4 = W >> 2;
   const int lpr = w4 <= 1 ? 1 : w4 <= 2 ? 2 : w4 <= 4 ? 4 : w4 <= 8 ? 8 : w4 <= 16 ? 16 : 32;
-  const int64_t waves = (M + (UG_WAVE / lpr) - 1) / (UG_WAVE / lpr);
+  const int64_t waves = (ug_launch_rows(M) + (UG_WAVE / lpr) - 1) / (UG_WAVE / lpr);
   int64_t blocks = (waves + 3) / 4;
   if (blocks > 4096) blocks = 4096;
-#define UG_L3F(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_l3_fwd<L>), dim3((unsigned)blocks), dim3(256), 0, st, h2, M, W, w3, b3, logits)
+#define UG_L3F(L) hipLaunchKernelGGL(HIP_KERNEL_NAME(k_l3_fwd<L>), dim3((unsigned)blocks), dim3(256), 0, st, h2, M, W, w3, b3, logits, ug_tl_devn.ptr)
   switch (lpr) {
     case 1: UG_L3F(1); break;
     case 2: UG_L3F(2); break;
@@ -723,11 +738,12 @@ static int ug_l3_backward(const float *g, const float *h2, int64_t M, int W, con
     return 0;
   }
   const int rpi = 256 / (W >> 2);
+  const int64_t Ml = ug_launch_rows(M);                                  // (a device count in force: chunks and grid follow the hint)
   int64_t rows = 8 * (int64_t)rpi;                                       // >= 8 iterations per block
-  if ((M + rows - 1) / rows > UG_L3_MAX_BLOCKS) rows = ((M + UG_L3_MAX_BLOCKS - 1) / UG_L3_MAX_BLOCKS + rpi - 1) / rpi * rpi;
-  const int nb = (int)((M + rows - 1) / rows);
+  if ((Ml + rows - 1) / rows > UG_L3_MAX_BLOCKS) rows = ((Ml + UG_L3_MAX_BLOCKS - 1) / UG_L3_MAX_BLOCKS + rpi - 1) / rpi * rpi;
+  const int nb = (int)((Ml + rows - 1) / rows);
   float *pw = partial, *pb = partial + (size_t)UG_L3_MAX_BLOCKS * 3 * W;
-  hipLaunchKernelGGL(k_l3_bwd, dim3((unsigned)nb), dim3(256), 0, st, g, h2, M, W, w3, g_h2, pw, pb, (int)rows);
+  hipLaunchKernelGGL(k_l3_bwd, dim3((unsigned)nb), dim3(256), 0, st, g, h2, M, W, w3, g_h2, pw, pb, (int)rows, ug_tl_devn.ptr);
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((3 * W + 3 + 15) / 16), dim3(256), 0, st, pw, pb, nb, 3 * W, 3, dW, db);
   UG_LAUNCH_CHECK();
   return 0;

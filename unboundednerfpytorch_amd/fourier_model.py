@@ -48,6 +48,8 @@ class FourierGridModel(nn.Module):
         self.fused_rgbnet = backend is None        # ops.FusedRgbnet: the default 3 x 128 rgbnet fwd / bwd on the MFMA kernels
         self.fused_loss = backend is None          # train_step.train_iteration: compositing + loss as ops.RenderLoss
         self.native_step = backend is None         # native_step.VoxGOStep: training forward + loss as ONE autograd node issued from C
+        self.native_sync_free = False              # True / {'capacity': rows}: that node without its host read (capacity-sized per-sample
+                                                   # arrays, counts on the device; native_step.VoxGOStep pack['sync_free'])
         lo_s, hi_s = torch.Tensor(xyz_min), torch.Tensor(xyz_max)
         self.register_buffer('scene_center', (lo_s + hi_s) * 0.5)
         self.register_buffer('scene_radius', (hi_s - lo_s) * 0.5)
@@ -302,7 +304,7 @@ class FourierGridModel(nn.Module):
                 pack = {'mode': 'fourier', 'cfg': cfg, 't': t, 'rays_o': rays_o.contiguous(), 'rays_d': rays_d.contiguous(),
                         'viewdirs': viewdirs, 'viewfreq': self.viewfreq, 'xyz_min': self.xyz_min, 'xyz_max': self.xyz_max,
                         'k0_xyz_min': self.k0.xyz_min, 'k0_xyz_max': self.k0.xyz_max, 'mask': None, 'target': fl['target'], 'bg': bg,
-                        'coef': fl['coef']}
+                        'coef': fl['coef'], 'sync_free': self.native_sync_free}
                 loss, mse = VoxGOStep.apply(*native, pack)
                 o = pack['out']
                 return {'alphainv_last': o['alphainv_last'], 'weights': o['weights'], 'rgb_marched': o['rgb_marched'],

@@ -28,7 +28,8 @@ _p = _lib.ptr
 
 
 def tune(key, value):
-    """Speed-only tuning knobs (ugrid_tune, include/ugrid_hip.h): 'march_waves' 4..6, 'tv_xcd' 0|1|2|3, 'shade_pc' 0|1|2."""
+    """Tuning knobs (ugrid_tune, include/ugrid_hip.h): speed only -- 'march_waves' 4..6, 'tv_xcd' 0|1|2|3, 'shade_pc' 0|1|2; and one choice of
+    arithmetic -- 'train_mlp' 0|1 (training rgbnet products on fp32 MFMAs | bf16x3, both fp32-accurate)."""
     _lib.check(_L.ugrid_tune(key.encode(), int(value)), "ugrid_tune(%s)" % key)
 
 

@@ -22,6 +22,38 @@ if int(_L.ugrid_voxgo_step_sizeof()) != ctypes.sizeof(_lib.VoxgoStep):
 _WEIGHTS = ("w0", "b0", "w1", "b1", "w2", "b2")
 
 
+class _CountTracker:
+    """The sync-free step's only knowledge of its sample counts on the host: totals [2] of an EARLIER step, copied to page-locked memory
+    behind that step's scan kernel and looked at (event query, never a wait) when a later step is issued.  They size launch grids
+    (ugrid_voxgo_step.hint1 / hint2 -- the kernels themselves read the live counts on the device and loop over whatever they find) and
+    reveal, one step late, a stage-2 count beyond a caller-chosen capacity."""
+
+    def __init__(self):
+        self.host, self.event, self.last, self.cap2 = None, None, (0, 0), None
+
+    def poll(self):
+        if self.event is not None and self.event.query():
+            self.last = (int(self.host[0]), int(self.host[1]))
+            self.event = None
+            if self.cap2 is not None and self.last[1] > self.cap2:
+                raise RuntimeError("sync-free training step: %d samples reached the rgbnet in an earlier step, the per-sample arrays hold %d "
+                                   "(pack['sync_free']['capacity']); the samples beyond it were dropped -- raise the capacity" % (self.last[1], self.cap2))
+        return self.last
+
+    def track(self, totals, cap2):
+        if self.event is not None or torch.cuda.is_current_stream_capturing():
+            return
+        if self.host is None:
+            self.host = torch.empty(2, dtype=torch.int64).pin_memory()
+        self.host.copy_(totals, non_blocking=True)
+        self.cap2 = cap2
+        self.event = torch.cuda.Event()
+        self.event.record()
+
+
+_TRACKERS = {}
+
+
 def _coef9(coef):
     """ops.loss_coefficients' tuple as the 9 floats of ugrid_render_loss (an 8-tuple of an older caller: weight_freq = 0)"""
     c = [float(x) for x in coef]
@@ -36,6 +68,10 @@ class VoxGOStep(torch.autograd.Function):
     interval, thres, scene_center, scene_radius, bg_len, norm_l2, freq_num, k0_freq_num), rays_o / rays_d / viewdirs [R,3],
     viewfreq [pe], t (dcvgo, fourier: the sample table [S]), xyz_min / xyz_max, k0_xyz_min / k0_xyz_max, mask (bool [mi,mj,mk];
     none for 'fourier'), target [R,3], bg [R,3] or None, coef (ops.loss_coefficients).
+    pack['sync_free'] (optional: True or {'capacity': rows of the stage-2 arrays (default rays x slots: cannot overflow), 'hints': (M1, M2)
+    expected counts}): the step makes no host read and synchronises nothing -- forward and backward only enqueue work, the whole step can
+    run ahead of the host or be captured in a hipGraph (include/ugrid_hip.h ugrid_voxgo_step.sync_free).  The per-sample outputs then
+    have the capacity's length with pack['out']['n_valid'] (device int64 [2]) rows written.
     pack['k0_grad_ready'] (optional, may be set any time before the backward): callable(k0_parameter) invoked in the middle of the
     backward, as soon as the k0 grid's gradient is complete and assigned to .grad -- train_step.train_iteration starts the k0
     update there, beside the density half of the backward; the node then reports no gradient for the k0 grid.  On return pack['out'] holds the detached per-sample / per-ray
@@ -139,9 +175,24 @@ class VoxGOStep(torch.autograd.Function):
         s.alphainv_last, s.rgb_marched, s.out2 = ainv.data_ptr(), rgb_marched.data_ptr(), out2.data_ptr()
         s.ray_tot, s.partial = perray.data_ptr(), perray.data_ptr() + 8 * R
         ps = ctypes.addressof(s)
+        sf = pack.get('sync_free')
+        tracker = None
+        if sf:
+            # no host read: the per-sample arrays are sized by CAPACITY (stage 1: every slot of every ray; stage 2: the same unless the
+            # caller bounds it), the counts stay on the device (include/ugrid_hip.h, sync_free); grids follow an earlier step's counts
+            sf = sf if isinstance(sf, dict) else {}
+            cap2 = int(sf.get('capacity') or R * S)
+            if not (1 <= cap2 <= R * S):
+                raise RuntimeError("VoxGOStep: sync_free capacity must be in [1, rays x slots = %d], got %d" % (R * S, cap2))
+            tracker = _TRACKERS.setdefault((dev, mode, R, S), _CountTracker())
+            h1, h2 = sf['hints'] if sf.get('hints') is not None else tracker.poll()
+            s.sync_free, s.M1, s.M2 = 1, R * S, cap2
+            s.hint1, s.hint2 = (min(R * S, h1 + h1 // 4 + 1024) if h1 > 0 else 0), (min(cap2, h2 + h2 // 4 + 1024) if h2 > 0 else 0)
         with _lib.guard(dev):
             st = _lib.stream_of(density_grid)
-            _lib.check(_L.ugrid_voxgo_step_sample(ps, st), "voxgo_step_sample")          # the step's one host read: M1, M2
+            _lib.check(_L.ugrid_voxgo_step_sample(ps, st), "voxgo_step_sample")          # the step's one host read: M1, M2 (none: sync_free)
+            if tracker is not None:
+                tracker.track(i64[2 * R:2 * R + 2], s.M2 if s.M2 < R * S else None)
             _lib.wait_pending(k0_grid)
             M2 = s.M2
             ws = torch.empty(int(_L.ugrid_voxgo_step_ws_floats(ps)), device=dev)
@@ -164,6 +215,9 @@ class VoxGOStep(torch.autograd.Function):
         ctx.pack = pack
         pack['out'] = {'alphainv_last': ainv, 'weights': f4[2], 'rgb_marched': rgb_marched, 'raw_alpha': f4[1], 'raw_density': f4[0],
                        'raw_logits': logits, 'ray_id': ids[0], 'step_id': ids[1], 't': f4[3], 'inner': inner, 'loss_mse': out2}
+        if s.sync_free:
+            # the per-sample arrays have the capacity's length; rows [0, n_valid[1]) are written (n_valid: stage-1 / stage-2 counts, on the device)
+            pack['out']['n_valid'] = i64[2 * R:2 * R + 2]
         loss, mse = out2[0], out2[1]
         ctx.mark_non_differentiable(mse)
         return loss, mse

@@ -36,6 +36,8 @@ class _VoxGOBase(nn.Module):
     fused_forward = True        # grid.TrainSampleVox (needs fast_color_thres > 0, like the reference's own masking branches)
     fused_rgbnet = True         # ops.FusedRgbnet for the default 3-layer rgbnet
     native_step = True          # native_step.VoxGOStep: the fused training forward + loss as ONE autograd node issued from C
+    native_sync_free = False    # True / {'capacity': rows}: that node without its host read (capacity-sized per-sample arrays, counts
+                                # on the device; native_step.VoxGOStep pack['sync_free'])
                                 # (same kernels, same bits; default rgbnet, rgbnet_direct, train_iteration's fused_loss)
 
     def _init_grids(self, density_type, k0_type, density_config, k0_config, k0_dim, channels_last):
@@ -186,7 +188,8 @@ class _VoxGOBase(nn.Module):
         from .native_step import VoxGOStep
         pack = {'mode': mode, 'cfg': cfg, 't': t, 'rays_o': rays_o, 'rays_d': rays_d, 'viewdirs': viewdirs, 'viewfreq': self.viewfreq,
                 'xyz_min': self.xyz_min, 'xyz_max': self.xyz_max, 'k0_xyz_min': self.k0.xyz_min, 'k0_xyz_max': self.k0.xyz_max,
-                'mask': self.mask_cache.mask, 'target': fused_loss['target'], 'bg': bg, 'coef': fused_loss['coef']}
+                'mask': self.mask_cache.mask, 'target': fused_loss['target'], 'bg': bg, 'coef': fused_loss['coef'],
+                'sync_free': self.native_sync_free}
         loss, mse = VoxGOStep.apply(*params, pack)
         o = pack['out']
         return {'alphainv_last': o['alphainv_last'], 'weights': o['weights'], 'rgb_marched': o['rgb_marched'], 'raw_alpha': o['raw_alpha'],
