@@ -72,6 +72,9 @@ def parse():
     ap.add_argument("--no-proxy", action="store_true", help="skip `scaling_proxy` (every rank's share of an N-way deal rendered ALONE on this GPU)")
     ap.add_argument("--mlp-mode", type=int, default=None, help="rgbnet arithmetic: 0 fp32 MFMA, 1 bf16x3, 2 fp16x2 (default: what ugrid_pack_mlp reports usable)")
     ap.add_argument("--pipeline", type=int, default=0, help="ray chunks software-pipelined over two streams (0 = off)")
+    ap.add_argument("--frame-pair", type=int, default=-1, help="consecutive frames alternate between two streams, each with a work list of its own: "
+                    "the march of frame k+1 runs beside the shade of frame k (a 1/N share alone fills 0.66 of a wave per slot and stages 93 KB "
+                    "of weights per shade launch).  -1 = on for --gpus N > 1, off for 1 GPU (a whole frame fills the chip; measured no gain)")
     ap.add_argument("--tune", action="append", default=[], help="key=value speed knob (ugrid_tune), repeatable")
     ap.add_argument("--shuffle-rays", action="store_true", help="render the frame's rays in a random order (incoherent 64-ray tiles, "
                     "like a training batch): shows what the kernels owe to neighbouring pixels sharing cells")
@@ -265,6 +268,11 @@ class FrameBench:
             self.px = self.order[self.px].contiguous()
         self.gathered = [torch.empty(world * self.per, 5, device=device) for _ in range(2)] if self.use_dist else None
         self.inflight = {"work": None, "n": 0, "tile": None}
+        fp = int(getattr(args, "frame_pair", -1))
+        self.pair = None
+        if (fp == 1 or (fp < 0 and world > 1)) and device.type == "cuda" and hasattr(self.rend, "use_workspace_slot"):
+            self.pair = [torch.cuda.Stream(device), torch.cuda.Stream(device)]      # frames alternate between them (step)
+        self.n_step = 0
         self.last_out = None
         self.frame = None
         # row of the gathered [world*per,5] buffer that holds image pixel i: undoes the tile dealing (or the bands) and the
@@ -302,7 +310,20 @@ class FrameBench:
         return ro[b:e].contiguous(), rd[b:e].contiguous(), vd[b:e].contiguous()
 
     def step(self, timing=None, weak=False):
-        """strong (default): this rank's shard of THE frame; weak: a whole frame of its own camera."""
+        """strong (default): this rank's shard of THE frame; weak: a whole frame of its own camera.  With a stream pair (--frame-pair) the
+        whole step -- ray generation, march, shade, exchange -- is issued on stream k & 1 with work list k & 1: two frames are in flight,
+        nothing of frame k + 1 waits for frame k except the exchange's own hand-over (the frames of a view list are independent)."""
+        if self.pair is None:
+            return self._step(timing, weak)
+        k = self.n_step & 1
+        self.n_step += 1
+        if self.n_step <= 2:
+            self.pair[k].wait_stream(torch.cuda.current_stream(self.device))      # (what set up the inputs ran on the caller's stream)
+        self.rend.use_workspace_slot(k)
+        with torch.cuda.stream(self.pair[k]):
+            return self._step(timing, weak)
+
+    def _step(self, timing=None, weak=False):
         # ray generation is inside the step: the whole frame (weak / 1 GPU) or this rank's pixels of it (strong)
         if self.order is not None and (weak or self.world == 1):
             ro, rd, vd = self.get_rays_idx(self.H, self.W, self.K, camera(self.rank, self.device) if weak else self.c2w, self.order)
@@ -608,6 +629,11 @@ def s3_train_step_block(device):
                 # the path's one genuinely HBM-bound kernel, priced against the guide's 8 TB/s
                 out["roofline_tv_adam_dense"] = r["roofline_tv_adam_dense"]
             torch.cuda.empty_cache()
+        # round 6: the same masked-TV step with NO host read in the loop -- the sync-free native step (counts stay on the device) and the
+        # loss handed back as a tensor (train_iteration(return_tensors=True): a caller that logs every N steps)
+        r = bts.run(bts.parse(["--steps", "20", "--warmup", "4", "--first-step", "10001", "--sync-free", "1", "--lazy-loss", "1"]))
+        out["masked_tv_sync_free"] = {k: r[k] for k in ("ms_per_step", "survivors_M", "rays_per_sec", "tv_phase")}
+        torch.cuda.empty_cache()
         return out
     except Exception as e:          # noqa: BLE001
         return {"error": "%s: %s" % (type(e).__name__, e)}
@@ -635,8 +661,9 @@ def scaling_proxy(args, rend, device, t1_ms, steps=6):
             for name, kw in deals:
                 a = argparse.Namespace(**dict(vars(args), **kw))
                 ms, kms, rays = [], [], []
+                ms_pair = []
                 for r in range(N):
-                    fb = FrameBench(a, None, device, N, r, None, renderer=rend)
+                    fb = FrameBench(argparse.Namespace(**dict(vars(a), frame_pair=0)), None, device, N, r, None, renderer=rend)
                     fb.step()
                     evs, timing = [], []
                     for _ in range(steps):
@@ -652,10 +679,37 @@ def scaling_proxy(args, rend, device, t1_ms, steps=6):
                     kms.append([k.get("render_march", 0.0), k.get("render_shade", 0.0)])
                     rays.append(sum(n for _, n in timing) // steps)
                     del fb
+                    # the same share with consecutive frames on two streams / two work lists (--frame-pair): frames per second of a
+                    # continuously fed rank, GPU time of 2 x steps back-to-back frames between two events that bracket BOTH streams
+                    fbp = FrameBench(argparse.Namespace(**dict(vars(a), frame_pair=1)), None, device, N, r, None, renderer=rend)
+                    if fbp.pair is not None:
+                        fbp.step(); fbp.step()
+                        torch.cuda.synchronize()
+                        main = torch.cuda.current_stream(device)
+                        batches = []
+                        for _ in range(3):             # median of three batches (an idle -> busy start-up glitch of 25-80 ms hits ~5 % of batches)
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record(main)
+                            for st in fbp.pair:
+                                st.wait_event(e0)
+                            for _ in range(2 * steps):
+                                fbp.step()
+                            for st in fbp.pair:
+                                main.wait_stream(st)
+                            e1.record(main)
+                            torch.cuda.synchronize()
+                            batches.append(e0.elapsed_time(e1) / (2 * steps))
+                        ms_pair.append(sorted(batches)[1])
+                    rend.use_workspace_slot(0)
+                    del fbp
                 row[name] = {"share_ms": [round(x, 4) for x in ms], "share_march_shade_ms": [[round(x, 4) for x in p] for p in kms], "share_rays": rays,
                              "slowest_share_ms": max(ms), "mean_share_ms": sum(ms) / N,
                              "predicted_speedup": t1_ms / max(ms), "predicted_efficiency": t1_ms / (N * max(ms)),
                              "imbalance_max_over_mean": max(ms) / (sum(ms) / N)}
+                if len(ms_pair) == N:
+                    row[name].update({"frame_pair_share_ms": [round(x, 4) for x in ms_pair], "frame_pair_slowest_share_ms": max(ms_pair),
+                                      "frame_pair_predicted_speedup": t1_ms / max(ms_pair),
+                                      "frame_pair_predicted_efficiency": t1_ms / (N * max(ms_pair))})
             out["N=%d" % N] = row
         return out
     except Exception as e:          # noqa: BLE001
@@ -722,6 +776,12 @@ def voxgo_train_block():
         for kind, first, tag in (("dvgo", 1, "dvgo_lego_fine"), ("dcvgo", 1, "dcvgo_mip360_fine_dense_tv"), ("dcvgo", 10001, "dcvgo_mip360_fine_masked_tv")):
             r = bvt.run(kind, a, first)
             out[tag] = {k: r[k] for k in ("workload", "native_step", "ms_per_step", "rays_per_sec", "survivors_M", "steps")}
+            torch.cuda.empty_cache()
+        # round 6: no host read in the loop (sync-free native step + the loss as a tensor), the two steps VERDICT r5 item 5 / 6 name
+        b = argparse.Namespace(**dict(vars(a), lazy_loss=1, sync_free=1))
+        for kind, first, tag in (("dvgo", 1, "dvgo_lego_fine_sync_free"), ("dcvgo", 10001, "dcvgo_mip360_fine_masked_tv_sync_free")):
+            r = bvt.run(kind, b, first)
+            out[tag] = {k: r[k] for k in ("workload", "native_step", "sync_free", "lazy_loss", "ms_per_step", "rays_per_sec", "survivors_M", "steps")}
             torch.cuda.empty_cache()
         return out
     except Exception as e:          # noqa: BLE001
@@ -1087,6 +1147,7 @@ def compact_line(res, detail_path=None):
         sec["s1b_shade"] = _num((s1b["kernels"].get("render_shade") or {}).get("ms"))
     put("s3_train_dense_tv", res.get("secondary_s3_train_step"), "dense_tv")
     put("s3_train_masked_tv", res.get("secondary_s3_train_step"), "masked_tv")
+    put("s3_train_masked_tv_sync_free", res.get("secondary_s3_train_step"), "masked_tv_sync_free")
     vg = res.get("secondary_voxgo_train_steps")
     if isinstance(vg, dict):
         if "error" in vg:
@@ -1098,7 +1159,7 @@ def compact_line(res, detail_path=None):
     px = res.get("scaling_proxy")
     if isinstance(px, dict) and isinstance(px.get("N=8"), dict):
         b = px["N=8"].get("contiguous_bands") or {}
-        line["scaling_proxy_N8"] = _pick(b, ("slowest_share_ms", "predicted_speedup"))
+        line["scaling_proxy_N8"] = _pick(b, ("slowest_share_ms", "predicted_speedup", "frame_pair_slowest_share_ms", "frame_pair_predicted_speedup"))
     line["detail"] = write_detail(res, detail_path)
     n = len(json.dumps(line, separators=(",", ":")))
     if n >= LINE_BUDGET:            # never print an unparseable line: drop the optional blocks, largest first

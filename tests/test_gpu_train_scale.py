@@ -486,6 +486,58 @@ def test_native_step_equals_the_op_by_op_step(rand_bkgd):
     synth.assert_same_trajectory(res[0][1], res[1][1])
 
 
+def test_sync_free_fourier_step_equals_the_host_counted_step():
+    """FourierGridModel at P = 9, G = 100 with native_sync_free = True (mode 'fourier' of ugrid_voxgo_step, sync_free = 1: no host read,
+    capacity-sized per-sample arrays, counts on the device) against the host-counted native step: per-ray arrays and the written rows of
+    the per-sample arrays bit-equal, loss and mse equal, grid gradients within the atomics' bound, the rgbnet's to 1e-5; then four
+    train_iteration steps with return_tensors=True (no host read anywhere in the loop) stay on the host-counted trajectory."""
+    import copy
+    import bench_train_step as bts
+    from unboundednerfpytorch_amd import ops, train_step as ts
+    from unboundednerfpytorch_amd.train_utils import create_optimizer_or_freeze_model
+    dev = torch.device("cuda", 0)
+    m = build(dev)
+    cfg = dict(bts.TRUCK_CFG)
+    cfg.update(weight_freq=5.0, weight_nearclip=1.0, weight_distortion=0.05)
+    o, d, v, rgb = bts.random_rays(3000, dev, seed=8)
+    near, kw = 0.2, dict(stepsize=0.5)
+    coef = ops.loss_coefficients(cfg, len(o), m.sample_table(0.5, dev).numel(), near, 1)
+    res = []
+    for sf in (False, True, {'hints': (64, 64)}, True):
+        m.native_sync_free = sf
+        m.zero_grad(set_to_none=True)
+        out = m(o, d, v, global_step=1, is_train=True, fused_loss={"target": rgb, "coef": coef}, **kw)
+        assert type(out["loss"].grad_fn).__name__.startswith("VoxGOStep")
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        res.append((out, {k: p.grad.clone() for k, p in m.named_parameters()}))
+    oa, ga = res[0]
+    n = oa["weights"].numel()
+    assert n > 1000
+    for ob, gb in res[1:]:
+        assert ob["native"]["out"]["n_valid"].tolist()[1] == n and ob["weights"].numel() > n
+        assert torch.equal(ob["loss_mse"], oa["loss_mse"])
+        for k in ("alphainv_last", "rgb_marched"):
+            assert torch.equal(ob[k], oa[k]), k
+        for k in ("weights", "raw_alpha", "raw_density", "raw_logits", "ray_id", "step_id", "t"):
+            assert torch.equal(ob[k][:n], oa[k]), k
+        for k in ga:
+            scale = float(ga[k].abs().max()) + 1e-30
+            bound = synth.NATIVE_GRID_GRAD_BOUND if "grid" in k else 1e-5
+            assert float((ga[k] - gb[k]).abs().max()) <= bound * scale, (k, float((ga[k] - gb[k]).abs().max()), scale)
+    traj = []
+    for sf in (False, True):
+        mm = copy.deepcopy(m)
+        mm.native_sync_free = sf
+        mm.zero_grad(set_to_none=True)
+        opt = create_optimizer_or_freeze_model(mm, cfg, global_step=0)
+        losses = [ts.train_iteration(mm, opt, o, d, v, rgb, cfg, s, kw, near_thres=near, return_tensors=True)[0] for s in range(1, 5)]
+        traj.append(([float(x) for x in losses], {k: x.detach().clone() for k, x in mm.state_dict().items() if x.dtype == torch.float32}))
+    assert traj[0][0][0] == traj[1][0][0]
+    np.testing.assert_allclose(np.array(traj[0][0]), np.array(traj[1][0]), rtol=2e-5)       # (rgbnet gradients: slabs cut by capacity, rounding)
+    synth.assert_same_trajectory(traj[0][1], traj[1][1])
+
+
 def test_k0_update_on_the_side_stream_gives_the_same_training():
     """train_iteration(overlap_k0_update=True): the k0 TV + Adam pass runs on a second stream beside the next forward's
     density march; parameters read through state_dict() (which waits for the pending update) after four steps equal those

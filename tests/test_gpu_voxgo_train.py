@@ -413,6 +413,148 @@ def test_native_step_equals_the_op_by_op_step(kind):
     assert m_a._native_params() is not None
 
 
+def _sync_free_pair(kind, dev):
+    """a model, its inputs and the fused-loss kwargs of the native step (both dense-grid models; weights as test_native_step_equals...)"""
+    from unboundednerfpytorch_amd.ops import loss_coefficients
+    case = DVGO_CASES[0] if kind == "dvgo" else synth.DCVGO_CASES[0]
+    m, name, (o, d, v), kw, R, seed = build(kind, case, dev)
+    target = torch.from_numpy(synth.uniform(seed + 5, R * 3).reshape(R, 3)).to(dev) * 0.5 + 0.25
+    rk = {k: kw[k] for k in kw if k != "render_depth"}
+    cfg = dict(weight_main=1.0, weight_entropy_last=0.01, weight_rgbper=0.01, weight_nearclip=0.0, weight_distortion=0.01 if kind == "dcvgo" else 0.0)
+    coef = loss_coefficients(cfg, R, m.sample_table(rk["stepsize"], dev).numel(), None, 1)
+    return m, (o, d, v), dict(rk, fused_loss={'target': target, 'coef': coef}), R
+
+
+PER_SAMPLE = ("weights", "raw_alpha", "raw_density", "raw_logits", "ray_id", "step_id", "t")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dvgo", "dcvgo"])
+def test_sync_free_step_equals_the_host_counted_step(kind):
+    """native_sync_free = True (ugrid_voxgo_step.sync_free: no host read, capacity-sized per-sample arrays, the counts
+    on the device, every per-sample kernel running min(capacity, count) rows in grid-stride loops) against the host-counted native step
+    on the same inputs -- with no hint (grids sized by the capacity), with hints far BELOW the counts (the kernels must loop) and with the
+    tracker's own hints (second call): the per-ray arrays and the first n_valid rows of the per-sample arrays bit-equal, loss and mse
+    equal, grid gradients within the scatter's atomic-order bound, the rgbnet's gradients to 1e-5 of their largest entry (the same sums
+    cut into slabs by the capacity instead of the count)."""
+    from unboundednerfpytorch_amd import native_step
+    dev = torch.device("cuda", 0)
+    m, (o, d, v), kw, R = _sync_free_pair(kind, dev)
+    res = []
+    for sf in (False, True, {'hints': (100, 50)}, True):
+        m.native_sync_free = sf
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(5)
+        out = m(o, d, v, global_step=1, is_train=True, **kw)
+        assert type(out["loss"].grad_fn).__name__.startswith("VoxGOStep")
+        out["loss"].backward()
+        torch.cuda.synchronize()
+        res.append((out, {k: p.grad.clone() for k, p in m.named_parameters()}))
+    (oa, ga) = res[0]
+    n = oa["weights"].numel()
+    assert n > 100
+    for ob, gb in res[1:]:
+        nv = ob["native"]["out"]["n_valid"].tolist()
+        assert nv[1] == n and nv[0] >= n, (nv, n)
+        assert ob["weights"].numel() >= n and ob["weights"].numel() > n          # capacity-sized
+        assert torch.equal(ob["loss_mse"], oa["loss_mse"])
+        for k in ("alphainv_last", "rgb_marched"):
+            assert torch.equal(ob[k], oa[k]), k
+        for k in PER_SAMPLE:
+            if k in oa:             # (DirectVoxGO's return dict has no raw_density / t, like the reference's)
+                assert torch.equal(ob[k][:n], oa[k]), k
+        for k in ga:
+            scale = float(ga[k].abs().max()) + 1e-30
+            bound = synth.NATIVE_GRID_GRAD_BOUND if "grid" in k else 1e-5
+            assert float((ga[k] - gb[k]).abs().max()) <= bound * scale, (k, float((ga[k] - gb[k]).abs().max()), scale)
+    # the tracker learnt the counts from the second call: the last call's grids followed them
+    tr = [t for key, t in native_step._TRACKERS.items() if key[1] == kind]
+    assert tr and tr[-1].poll()[1] == n
+
+
+@pytest.mark.gpu
+def test_sync_free_step_with_a_small_capacity_drops_memory_safely_and_reports_it():
+    """A caller-chosen stage-2 capacity below the count: the compaction drops what exceeds it (no out-of-bounds write: the arrays behind
+    the capacity-sized ones are untouched), the step runs on the truncated list, and the NEXT step that looks at the counts raises."""
+    from unboundednerfpytorch_amd import native_step
+    dev = torch.device("cuda", 0)
+    m, (o, d, v), kw, R = _sync_free_pair("dcvgo", dev)
+    m.native_sync_free = False
+    n = m(o, d, v, global_step=1, is_train=True, **kw)["weights"].numel()
+    cap = n // 2
+    native_step._TRACKERS.clear()
+    m.native_sync_free = {'capacity': cap}
+    out = m(o, d, v, global_step=1, is_train=True, **kw)
+    out["loss"].backward()
+    torch.cuda.synchronize()
+    assert out["weights"].numel() == cap and int(out["native"]["out"]["n_valid"][1]) == n
+    assert bool(torch.isfinite(out["loss"])) and all(bool(torch.isfinite(p.grad).all()) for p in m.parameters())
+    assert bool((out["ray_id"][1:] >= out["ray_id"][:-1]).all())                # the kept prefix is still ray-major
+    with pytest.raises(RuntimeError, match="raise the capacity"):
+        m(o, d, v, global_step=1, is_train=True, **kw)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["dvgo", "dcvgo"])
+def test_train_step_is_capturable_in_a_hip_graph(kind):
+    """The sync-free step -- forward, loss and the whole backward -- captured ONCE in a hipGraph and replayed on new ray contents (same
+    buffers): loss, the per-ray arrays and the written rows of the per-sample arrays bit-equal to the eager host-counted step on those
+    rays; gradients within the atomics' bound.  (The host-counted step cannot be captured: it reads M1 / M2 in the middle.)"""
+    dev = torch.device("cuda", 0)
+    m, (o, d, v), kw, R = _sync_free_pair(kind, dev)
+    o2, d2, v2 = o.flip(0).contiguous(), d.flip(0).contiguous(), v.flip(0).contiguous()
+    t2 = kw["fused_loss"]["target"].flip(0).contiguous()
+    # eager references on both ray sets
+    ref = []
+    for rays, tg in (((o, d, v), kw["fused_loss"]["target"]), ((o2, d2, v2), t2)):
+        m.native_sync_free = False
+        m.zero_grad(set_to_none=True)
+        torch.manual_seed(5)
+        out = m(*rays, global_step=1, is_train=True, **dict(kw, fused_loss=dict(kw["fused_loss"], target=tg)))
+        out["loss"].backward()
+        ref.append((out, {k: p.grad.clone() for k, p in m.named_parameters()}))
+    # static inputs of the graph
+    so, sd, sv, stg = o.clone(), d.clone(), v.clone(), kw["fused_loss"]["target"].clone()
+    m.native_sync_free = {'hints': (0, 0)}
+    m.zero_grad(set_to_none=True)
+    kwg = dict(kw, fused_loss=dict(kw["fused_loss"], target=stg))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                      # warm-up on a side stream (allocator pools, lazy module loads)
+        for _ in range(2):
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(5)
+            w = m(so, sd, sv, global_step=1, is_train=True, **kwg)
+            w["loss"].backward()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    m.zero_grad(set_to_none=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        torch.manual_seed(5)
+        gout = m(so, sd, sv, global_step=1, is_train=True, **kwg)
+        gout["loss"].backward()
+        ggrads = {k: p.grad for k, p in m.named_parameters()}
+    for (rays, tg), (oref, gref) in zip((((o, d, v), kw["fused_loss"]["target"]), ((o2, d2, v2), t2)), ref):
+        so.copy_(rays[0]); sd.copy_(rays[1]); sv.copy_(rays[2]); stg.copy_(tg)
+        for p in ggrads.values():
+            p.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        n = oref["weights"].numel()
+        assert int(gout["native"]["out"]["n_valid"][1]) == n
+        assert torch.equal(gout["loss_mse"], oref["loss_mse"])
+        for k in ("alphainv_last", "rgb_marched"):
+            assert torch.equal(gout[k], oref[k]), k
+        for k in PER_SAMPLE:
+            if k in oref:
+                assert torch.equal(gout[k][:n], oref[k]), k
+        for k in gref:
+            scale = float(gref[k].abs().max()) + 1e-30
+            bound = synth.NATIVE_GRID_GRAD_BOUND if "grid" in k else 1e-5
+            assert float((gref[k] - ggrads[k]).abs().max()) <= bound * scale, (k, float((gref[k] - ggrads[k]).abs().max()), scale)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind,case", ALL, ids=IDS)
 def test_fused_loss_equals_the_composed_loss(kind, case):

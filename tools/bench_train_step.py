@@ -78,6 +78,7 @@ def parse(argv=None):
                     "the masked TV / Adam passes visit only the lines the backward marked; 0 = the scanning kernels")
     ap.add_argument("--lazy-loss", type=int, default=0, help="train_iteration(return_tensors=True): no host read of loss / psnr per step")
     ap.add_argument("--tune", action="append", default=[], help="key=value for ugrid_tune (A/B switches), repeatable")
+    ap.add_argument("--sync-free", type=int, default=0, help="1: the native step without its mid-forward host read (ugrid_voxgo_step.sync_free)")
     ap.add_argument("--channels-last", type=int, default=1, help="k0 stored [P][X][Y][Z][C] (the training layout) or row-major")
     return ap.parse_args(argv)
 
@@ -94,6 +95,7 @@ def run(args):
     dev = torch.device("cuda", 0)
     model = make_model(args.grid, args.freq, dev, args.fused, args.channels_last)
     model.fused_loss = bool(args.fused_loss)
+    model.native_sync_free = bool(getattr(args, "sync_free", 0))
     opt = create_optimizer_or_freeze_model(model, TRUCK_CFG, global_step=0)
     rk = dict(stepsize=0.5, rand_bkgd=True)
     timers = None
@@ -148,7 +150,7 @@ def run(args):
            "fused_forward": bool(getattr(model, "fused_forward", False)),
            "k0_channels_last": not model.k0.grid.is_contiguous(), "fused_loss": bool(args.fused_loss), "overlap_k0_update": bool(args.overlap),
            "tv_phase": "dense" if args.first_step + args.warmup + args.steps - 1 < TRUCK_CFG["tv_dense_before"] else "masked",
-           "touch_bitmap": bool(_gradpool.touch_enabled), "lazy_loss": bool(getattr(args, "lazy_loss", 0)), "k0_grad_lines_touched_frac": touched,
+           "touch_bitmap": bool(_gradpool.touch_enabled), "lazy_loss": bool(getattr(args, "lazy_loss", 0)), "sync_free": bool(getattr(args, "sync_free", 0)), "k0_grad_lines_touched_frac": touched,
            "ms_per_step": total, "phases_ms": ms, "steps": args.steps, "survivors_M": M, "samples": args.rays * S,
            "rays_per_sec": args.rays / (total * 1e-3), "k0_voxels": n_k0,
            "k0_streaming_floor_ms": {"note": "compulsory HBM passes over the 3.46 GB k0-sized arrays per step at 6.3 TB/s achievable: "

@@ -68,6 +68,7 @@ def run(kind, args, first_step):
     G = args.grid or (160 if kind == "dvgo" else 320)
     m = make_model(kind, G, dev, args.fused)
     m.native_step = bool(getattr(args, "native", 1))
+    m.native_sync_free = bool(getattr(args, "sync_free", 0))
     opt = create_optimizer_or_freeze_model(m, cfg, global_step=0)
     rk = dict(stepsize=0.5, bg=1, near=0.2, far=6.0) if kind == "dvgo" else dict(stepsize=0.5, bg=1, rand_bkgd=True)
     n = cfg["N_rand"]
@@ -87,7 +88,7 @@ def run(kind, args, first_step):
     return {"model": kind, "workload": "%s train step: G=%s, C=12, %d random rays, stepsize 0.5%s" % (
                 "DirectVoxGO (lego fine-stage shape)" if kind == "dvgo" else "DirectContractedVoxGO (mip-360 fine-stage shape)",
                 m.world_size.tolist(), n, "" if not tv_on else ", TV " + ("dense" if first_step < cfg["tv_dense_before"] else "masked")),
-            "fused": bool(args.fused), "native_step": bool(m.native_step and args.fused), "lazy_loss": bool(args.lazy_loss), "ms_per_step": ms, "rays_per_sec": n / (ms * 1e-3), "survivors_M": int(out["weights"].numel()),
+            "fused": bool(args.fused), "native_step": bool(m.native_step and args.fused), "sync_free": bool(m.native_sync_free), "lazy_loss": bool(args.lazy_loss), "ms_per_step": ms, "rays_per_sec": n / (ms * 1e-3), "survivors_M": int(out["weights"].numel()),
             "mask_cache_occupied_frac": float(m.mask_cache.mask.float().mean()), "steps": args.steps, "loss": float(loss), "psnr": float(psnr)}
 
 
@@ -104,6 +105,8 @@ def main():
     ap.add_argument("--phase", default="both", help="dcvgo: dense | masked | both TV phases")
     ap.add_argument("--lazy-loss", type=int, default=0, help="train_iteration(return_tensors=True): no host read of loss / psnr per step "
                     "(the reference reads psnr.item() every step; a caller that logs every N steps need not)")
+    ap.add_argument("--sync-free", type=int, default=0, help="1: the native step without its mid-forward host read (capacity-sized per-sample arrays, counts on "
+                    "the device: include/ugrid_hip.h ugrid_voxgo_step.sync_free); with --lazy-loss 1 the loop makes no host read at all")
     args = ap.parse_args()
     kinds = ["dvgo", "dcvgo"] if args.model == "both" else [args.model]
     for kind in kinds:

@@ -1,0 +1,54 @@
+"""Bisect of the hipGraph capture of the sync-free training step (round 6, visit H): each stage in its own process (a crash in
+hipStreamEndCapture must not take the other stages with it).   python tools/dbg_graph_step.py [stage kind]"""
+import faulthandler
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def stage(name, kind):
+    import torch
+    import test_gpu_voxgo_train as T
+    faulthandler.enable()
+    dev = torch.device("cuda", 0)
+    m, (o, d, v), kw, R = T._sync_free_pair(kind, dev)
+    m.native_sync_free = {'hints': (0, 0)}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(2):
+            m.zero_grad(set_to_none=True)
+            w = m(o, d, v, global_step=1, is_train=True, **kw)
+            w["loss"].backward()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    m.zero_grad(set_to_none=True)
+    print(name, kind, "warm-up done", flush=True)
+    g = torch.cuda.CUDAGraph()
+    mode = "thread_local" if "tl" in name else "global"
+    with torch.cuda.graph(g, capture_error_mode=mode):
+        out = m(o, d, v, global_step=1, is_train=True, **kw)
+        print(name, "forward captured", flush=True)
+        if "bwd" in name:
+            out["loss"].backward()
+            print(name, "backward captured", flush=True)
+    print(name, "capture ended", flush=True)
+    g.replay()
+    torch.cuda.synchronize()
+    print(name, kind, "replayed: loss", float(out["loss"]), "n_valid", out["native"]["out"]["n_valid"].tolist(), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        stage(sys.argv[1], sys.argv[2])
+    else:
+        for kind in ("dvgo", "dcvgo"):
+            for name in ("fwd", "fwd_bwd", "fwd_bwd_tl"):
+                r = subprocess.run([sys.executable, __file__, name, kind], capture_output=True, text=True, timeout=300)
+                tail = [l for l in (r.stdout + r.stderr).splitlines() if "Warning" not in l and "amdgpu.ids" not in l]
+                print("==", kind, name, "rc", r.returncode)
+                print("\n".join(tail[:14]))

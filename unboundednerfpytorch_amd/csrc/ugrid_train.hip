@@ -224,6 +224,10 @@ static ug_loss_coef ug_coef(const float *h) {
   return c;
 }
 
+__global__ void k_zero_i64(int64_t *__restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0;
+}
+
 // k_segments of ugrid_ops.hip (ray_id ascending -> [i_start, i_end) per ray, empty rays 0,0)
 // (n_dev: the sample count on the device, ug_devn in ugrid_common.h; null = n)
 __global__ void k_loss_segments(const int64_t *__restrict__ ray_id, int64_t n, int64_t *__restrict__ i_start,
@@ -248,7 +252,10 @@ extern "C" int ugrid_render_loss(const float *logits, const float *weights, cons
                                  float *partial, float *out2, ugrid_stream_t st) {
   if (n_rays <= 0 || (n > 0 && !s && !t)) return (int)hipErrorInvalidValue;      // (no samples: empty arrays have no address)
   int64_t *i_start = seg_scratch, *i_end = seg_scratch + n_rays;
-  UG_HIP(hipMemsetAsync(seg_scratch, 0, sizeof(int64_t) * 2 * n_rays, ST(st)));
+  // (a kernel, not hipMemsetAsync: the memset NODE of a replayed hipGraph does not invalidate what the previous replay's kernels left in
+  // L2 -- DESIGN.md 4.2, the render path's tile counters -- and the sync-free training step is captured with this call inside)
+  hipLaunchKernelGGL(k_zero_i64, dim3(ug_blocks(2 * n_rays, 256) < 1024 ? ug_blocks(2 * n_rays, 256) : 1024), dim3(256), 0, ST(st), seg_scratch,
+                     2 * n_rays);
   if (n > 0) hipLaunchKernelGGL(k_loss_segments, dim3(ug_blocks(ug_launch_rows(n), 256)), dim3(256), 0, ST(st), ray_id, n, i_start, i_end, ug_tl_devn.ptr);
   const ug_loss_coef c = ug_coef(h_coef9);
   hipLaunchKernelGGL(k_render_loss_fwd, dim3(ug_blocks(n_rays * UG_WAVE, 256)), dim3(256), 0, ST(st), logits, weights, s, t,

@@ -249,6 +249,16 @@ class FourierGridRenderer:
         n = max(64, (self.max_ws_bytes // per_ray) // 64 * 64)
         return n
 
+    def use_workspace_slot(self, k):
+        """Frames in flight on different streams need work lists of their own -- the march of one fills its list while the shade of the
+        other drains its (bench.py --frame-pair; run_render's views are independent frames): slot k's workspace becomes the current one."""
+        slots = self.__dict__.setdefault("_ws_slots", {})
+        cur = self.__dict__.get("_ws_slot", 0)
+        if k != cur:
+            slots[cur] = self._ws
+            self._ws = slots.get(k)
+            self._ws_slot = k
+
     def _workspace(self, n_rays, S):
         need = _L.ugrid_render_ws_bytes(n_rays, S)
         if self._ws is None or self._ws.numel() < need:
