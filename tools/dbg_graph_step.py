@@ -16,6 +16,18 @@ def stage(name, kind):
     faulthandler.enable()
     dev = torch.device("cuda", 0)
     m, (o, d, v), kw, R = T._sync_free_pair(kind, dev)
+    if "ref" in name:                 # what the test does first: eager host-counted reference runs on the same model
+        for _ in range(2):
+            m.native_sync_free = False
+            m.zero_grad(set_to_none=True)
+            torch.manual_seed(5)
+            r = m(o, d, v, global_step=1, is_train=True, **kw)
+            r["loss"].backward()
+        m.zero_grad(set_to_none=True)
+        print(name, kind, "eager host-counted references done", flush=True)
+    if "clone" in name:               # static clones as the graph's inputs
+        o, d, v = o.clone(), d.clone(), v.clone()
+        kw = dict(kw, fused_loss=dict(kw["fused_loss"], target=kw["fused_loss"]["target"].clone()))
     m.native_sync_free = {'hints': (0, 0)}
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -36,6 +48,7 @@ def stage(name, kind):
         if "bwd" in name:
             out["loss"].backward()
             print(name, "backward captured", flush=True)
+            grads = {k: p.grad for k, p in m.named_parameters()}
     print(name, "capture ended", flush=True)
     g.replay()
     torch.cuda.synchronize()
@@ -47,7 +60,7 @@ if __name__ == "__main__":
         stage(sys.argv[1], sys.argv[2])
     else:
         for kind in ("dvgo", "dcvgo"):
-            for name in ("fwd", "fwd_bwd", "fwd_bwd_tl"):
+            for name in ("fwd_bwd", "clone_fwd_bwd", "ref_fwd_bwd", "ref_clone_fwd_bwd"):
                 r = subprocess.run([sys.executable, __file__, name, kind], capture_output=True, text=True, timeout=300)
                 tail = [l for l in (r.stdout + r.stderr).splitlines() if "Warning" not in l and "amdgpu.ids" not in l]
                 print("==", kind, name, "rc", r.returncode)

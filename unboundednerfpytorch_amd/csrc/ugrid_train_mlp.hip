@@ -283,56 +283,67 @@ k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__
   extern __shared__ float lds[];
   mlp_bf16x8 *img = (mlp_bf16x8 *)lds;
   constexpr int KH = 8 * KS, N_REC = 2 * KS * 128;
+  const int lane = ug_lane(), h = lane >> 5, col = lane & 31;
+  const int64_t n_tiles = (M + 31) >> 5;
+  constexpr int WAVES = UG_LINB_THREADS / 64;
+  const int k_base = h * KH;
+  struct f8 { float v[8]; };
+  struct rowctx { const float *xr; int64_t s; bool ok; };
+  auto ctx_of = [&](int64_t tile) -> rowctx {
+    rowctx r;
+    r.s = tile * 32 + col;
+    r.ok = tile < n_tiles && r.s < M;
+    r.xr = X + (r.ok ? r.s : 0) * ldx + k_base;
+    return r;
+  };
+  auto load8 = [&](const rowctx &rc, int ks) -> f8 {   // elements 8 ks .. 8 ks + 7 of the lane's half row
+    f8 r;
+    if (VEC) {
+      const float4 a = rc.ok ? *(const float4 *)(rc.xr + 8 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 b = rc.ok ? *(const float4 *)(rc.xr + 8 * ks + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r.v[e] = (rc.ok && k_base + 8 * ks + e < K) ? rc.xr[8 * ks + e] : 0.f;
+    }
+    return r;
+  };
+  constexpr int AHEAD = KS < 4 ? KS : 4;           // row pieces in flight
+  // the first tile's row pieces are requested BEFORE the weights are staged (an HBM round trip beside the 96 KB of split + LDS writes),
+  // every later tile's before the previous tile's stores
+  int64_t tile = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  rowctx rc = ctx_of(tile);
+  f8 xq[AHEAD];
+#pragma unroll
+  for (int a = 0; a < AHEAD; ++a) xq[a] = load8(rc, a);
   for (int r = threadIdx.x; r < N_REC; r += UG_LINB_THREADS) {
     int n, kq;                                     // kq = h * KS + ks: the record's first input is 8 kq
     if (w_in_major) { n = r & 127; kq = r >> 7; } else { kq = r % (2 * KS); n = r / (2 * KS); }
-    const int k0 = 8 * kq, h = kq / KS, ks = kq - h * KS;
+    const int k0 = 8 * kq, hh = kq / KS, ks = kq - hh * KS;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e)
       v[e] = (k0 + e < K && n < n_out) ? (w_in_major ? W[(int64_t)(k0 + e) * ldw + n] : W[(int64_t)n * ldw + k0 + e]) : 0.f;
     const mlp_split3 sp = mlp_split8(v);
-    img[((ks * 3 + 0) * 2 + h) * 128 + n] = sp.h;
-    img[((ks * 3 + 1) * 2 + h) * 128 + n] = sp.m;
-    img[((ks * 3 + 2) * 2 + h) * 128 + n] = sp.l;
+    img[((ks * 3 + 0) * 2 + hh) * 128 + n] = sp.h;
+    img[((ks * 3 + 1) * 2 + hh) * 128 + n] = sp.m;
+    img[((ks * 3 + 2) * 2 + hh) * 128 + n] = sp.l;
   }
   __syncthreads();
-  const int lane = ug_lane(), h = lane >> 5, col = lane & 31;
-  const int64_t n_tiles = (M + 31) >> 5;
-  constexpr int WAVES = UG_LINB_THREADS / 64;
   const mlp_bf16x8 *__restrict__ wl = img + h * 128 + col;
-  const int k_base = h * KH;
   const int nt_live = (n_out + 31) >> 5;          // output tiles that hold anything (wave-uniform)
-  for (int64_t tile = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6); tile < n_tiles; tile += (int64_t)gridDim.x * WAVES) {
-    const int64_t s = tile * 32 + col;
-    const bool row_ok = s < M;
-    const float *__restrict__ xr = X + (row_ok ? s : 0) * ldx + k_base;
-    struct f8 { float v[8]; };
-    auto load8 = [&](int ks) -> f8 {               // elements 8 ks .. 8 ks + 7 of the lane's half row
-      f8 r;
-      if (VEC) {
-        const float4 a = row_ok ? *(const float4 *)(xr + 8 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 b = row_ok ? *(const float4 *)(xr + 8 * ks + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-      } else {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) r.v[e] = (row_ok && k_base + 8 * ks + e < K) ? xr[8 * ks + e] : 0.f;
-      }
-      return r;
-    };
+  for (; tile < n_tiles; ) {
+    const int64_t s = rc.s;
+    const bool row_ok = rc.ok;
     mlp_f32x16 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    constexpr int AHEAD = KS < 4 ? KS : 4;         // row pieces in flight
-    f8 xq[AHEAD];
-#pragma unroll
-    for (int a = 0; a < AHEAD; ++a) xq[a] = load8(a);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const mlp_split3 xs = mlp_split8(xq[ks % AHEAD].v);
-      if (ks + AHEAD < KS) xq[ks % AHEAD] = load8(ks + AHEAD);
+      if (ks + AHEAD < KS) xq[ks % AHEAD] = load8(rc, ks + AHEAD);
       const mlp_bf16x8 *wp = wl + (ks * 3) * 2 * 128;
       mlp_bf16x8 wm[4], wlo[4], wh[4];
 #pragma unroll
@@ -356,6 +367,10 @@ k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__
 #pragma unroll
       for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wh[t], xs.h); }
     }
+    tile += (int64_t)gridDim.x * WAVES;
+    rc = ctx_of(tile);
+#pragma unroll
+    for (int a = 0; a < AHEAD; ++a) xq[a] = load8(rc, a);      // (past the last tile: rc.ok is false, no loads)
     if (row_ok) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -389,7 +404,7 @@ k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__
 
 // dW[c][k] partials with the SAMPLES as the reduction, bf16x3: one wave = 32 output features c x 64 input features k (two column
 // tiles) over the sample chunks of its slab -- A[m = c][kk = sample 8 h + e] = dY, B[kk][n = k] = X, 16 samples per MFMA group.
-// Eight dword loads per operand column and step (lanes = consecutive features: coalesced), fetched one step ahead.
+// Eight dword loads per operand column and step (lanes = consecutive features: coalesced), fetched four steps ahead.
 template <int NT>      // column tiles per wave (>= 2: see the MFMA order below)
 __global__ void __launch_bounds__(256)
 k_wgrad_b3(const float *__restrict__ dY, int ldd, int n_out, const float *__restrict__ X, int ldx, int K, int64_t M,
@@ -415,45 +430,72 @@ k_wgrad_b3(const float *__restrict__ dY, int ldd, int n_out, const float *__rest
 #pragma unroll
   for (int t = 0; t < NT; ++t) k_ok[t] = kcol0 + 32 * t < K;
   struct opnd { float a[8], b[NT][8]; };
-  auto fetch = [&](int64_t sb, int64_t s1) -> opnd {
+  // The wave's work as ONE sequence of 16-sample steps: step t = rows 16 (t & 7) .. + 15 of chunk (t >> 3) of its slab (chunks slab,
+  // slab + n_slabs, ...).  Operands are fetched FOUR steps ahead (a ring of four register sets): with two waves per SIMD a step's
+  // split + 12 MFMAs are ~900 cycles, an HBM round trip 2-4 k -- one step of look-ahead left the wave waiting most of the time (59 us at
+  // M = 1.2e5, round 6 visit I).
+  const int64_t n_chunks = (M + UG_WG_CHUNK - 1) / UG_WG_CHUNK;
+  const int64_t T = slab < n_chunks ? ((n_chunks - slab + n_slabs - 1) / n_slabs) * (UG_WG_CHUNK / 16) : 0;
+  auto fetch = [&](int64_t t) -> opnd {
     opnd o;
+    if (t >= T) {                                   // (wave-uniform) past the end: zeros, no loads
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int64_t s = sb + 8 * h + e;
-      const bool on = s < s1;
-      o.a[e] = (on && c_ok) ? dY[s * ldd + c] : 0.f;
+      for (int e = 0; e < 8; ++e) {
+        o.a[e] = 0.f;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) o.b[t][e] = (on && k_ok[t]) ? X[s * ldx + kcol0 + 32 * t] : 0.f;
+        for (int q = 0; q < NT; ++q) o.b[q][e] = 0.f;
+      }
+      return o;
+    }
+    const int64_t sb = ((int64_t)slab + (t >> 3) * n_slabs) * UG_WG_CHUNK + 16 * (t & 7) + 8 * h;
+    const float *__restrict__ pa = dY + sb * ldd + c;
+    const float *__restrict__ pb = X + sb * ldx + kcol0;
+    if (sb - 8 * h + 16 <= M) {                     // (wave-uniform) every row of the step exists: no row predicates
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o.a[e] = c_ok ? pa[(int64_t)e * ldd] : 0.f;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) o.b[q][e] = k_ok[q] ? pb[(int64_t)e * ldx + 32 * q] : 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const bool on = sb + e < M;
+        o.a[e] = (on && c_ok) ? pa[(int64_t)e * ldd] : 0.f;
+#pragma unroll
+        for (int q = 0; q < NT; ++q) o.b[q][e] = (on && k_ok[q]) ? pb[(int64_t)e * ldx + 32 * q] : 0.f;
+      }
     }
     return o;
   };
-  for (int64_t s0 = (int64_t)slab * UG_WG_CHUNK; s0 < M; s0 += (int64_t)n_slabs * UG_WG_CHUNK) {
-    const int64_t s1 = (s0 + UG_WG_CHUNK < M) ? s0 + UG_WG_CHUNK : M;
-    opnd cur = fetch(s0, s1);
-    for (int64_t sb = s0; sb < s1; sb += 16) {                 // rows >= s1 contribute zeros
-      const opnd nxt = fetch(sb + 16, s1);                     // (past the chunk: all zeros, no loads issued)
+  auto consume = [&](const opnd &cur) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bsum += cur.a[e];
-      const mlp_split3 as = mlp_split8(cur.a);
-      mlp_split3 bs[NT];
+    for (int e = 0; e < 8; ++e) bsum += cur.a[e];
+    const mlp_split3 as = mlp_split8(cur.a);
+    mlp_split3 bs[NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) bs[t] = mlp_split8(cur.b[t]);
-      __builtin_amdgcn_sched_barrier(0);
-      // products outer, column tiles inner: consecutive MFMAs never share an accumulator (NT >= 2)
+    for (int t = 0; t < NT; ++t) bs[t] = mlp_split8(cur.b[t]);
+    __builtin_amdgcn_sched_barrier(0);
+    // products outer, column tiles inner: consecutive MFMAs never share an accumulator (NT >= 2)
 #pragma unroll
-      for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.m, bs[t].m); }
+    for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.m, bs[t].m); }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.l, bs[t].h); }
+    for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.l, bs[t].h); }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.h, bs[t].l); }
+    for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.h, bs[t].l); }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.m, bs[t].h); }
+    for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.m, bs[t].h); }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.h, bs[t].m); }
+    for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.h, bs[t].m); }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.h, bs[t].h); }
-      cur = nxt;
-    }
+    for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.h, bs[t].h); }
+  };
+  opnd q0 = fetch(0), q1 = fetch(1), q2 = fetch(2), q3 = fetch(3);
+  for (int64_t t = 0; t < T; t += 4) {              // (T is a multiple of 8)
+    consume(q0); q0 = fetch(t + 4);
+    consume(q1); q1 = fetch(t + 5);
+    consume(q2); q2 = fetch(t + 6);
+    consume(q3); q3 = fetch(t + 7);
   }
   float *__restrict__ pw = partial_w + (int64_t)slab * n_out * K;
 #pragma unroll
