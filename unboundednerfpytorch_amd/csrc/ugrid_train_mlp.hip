@@ -270,10 +270,16 @@ __device__ __forceinline__ mlp_split3 mlp_split8(const float (&x)[8]) {
 
 // Y^T tile = W . X^T: D[m = output][n = sample] -- the weights are the A operands (LDS image, 16-byte records of 8 bf16), the lane's own
 // sample row the B operand, and a lane ends up with FOUR CONSECUTIVE outputs of its sample per accumulator quad: 16 float4 stores per
-// tile and lane instead of 64 scalar ones.  KS = k-steps of 16 (the reduction runs over 2 x 8 KS padded inputs: lane half h streams
-// elements [8 KS h, 8 KS (h + 1)) of its row, as k_lin does); n_out in (32, 128], a multiple of 4.
-// LDS image: rec[((ks * 3 + part) * 2 + h) * 128 + n] = parts of W[n][8 KS h + 8 ks + e], e = 0..7 (zero beyond K / n_out).
+// tile and lane instead of 64 scalar ones.  KS = k-steps of 16 inputs (zero padded); in k-step ks lane half h multiplies inputs
+// 16 ks + 8 h .. + 7 of its sample.  n_out in (32, 128], a multiple of 4.
+// LDS image: rec[((ks * 3 + part) * 2 + h) * 128 + n] = parts of W[n][16 ks + 8 h + e], e = 0..7 (zero beyond K / n_out).
+// VEC (K = 16 KS, 16-byte aligned rows): the sample rows reach their lanes THROUGH LDS.  A lane reading its own row makes every load
+// instruction touch 64 different cache lines -- 66 tag look-ups per instruction and the vector-memory path busy for 29 of the kernel's
+// 50 us (profiles/r06/klin_b3_pmc.txt); here a k-step's 32 x 64 bytes are fetched by two COALESCED dwordx4 per lane (four lanes per
+// 64-byte piece: 16 pieces per instruction), written to the wave's own 2.5 KB staging tile (rows padded to 80 bytes: the transposed
+// reads are conflict-free) and read back in operand order.
 #define UG_LINB_THREADS 512
+#define UG_LINB_XT_FLOATS (2 * 32 * 20)      /* per wave: two staging tiles of 32 rows x 20 floats */
 template <int KS, bool VEC>
 __global__ void __launch_bounds__(UG_LINB_THREADS)
 k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__restrict__ W, int ldw, int n_out, int w_in_major,
@@ -282,34 +288,45 @@ k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__
   UG_DEVN_CLAMP(M, n_dev);
   extern __shared__ float lds[];
   mlp_bf16x8 *img = (mlp_bf16x8 *)lds;
-  constexpr int KH = 8 * KS, N_REC = 2 * KS * 128;
+  constexpr int N_REC = 2 * KS * 128;
   const int lane = ug_lane(), h = lane >> 5, col = lane & 31;
   const int64_t n_tiles = (M + 31) >> 5;
   constexpr int WAVES = UG_LINB_THREADS / 64;
-  const int k_base = h * KH;
+  float *xt = lds + N_REC * 3 * 4 + (threadIdx.x >> 6) * UG_LINB_XT_FLOATS;      // (VEC) this wave's staging tiles
   struct f8 { float v[8]; };
-  struct rowctx { const float *xr; int64_t s; bool ok; };
+  // what a lane fetches per k-step: VEC -- 16 bytes of row (lane >> 2) and of row 16 + (lane >> 2) of the tile, piece lane & 3;
+  // otherwise its own 8 inputs
+  struct rowctx { const float *p0, *p1; int64_t s; bool ok, ok0, ok1; };
   auto ctx_of = [&](int64_t tile) -> rowctx {
     rowctx r;
     r.s = tile * 32 + col;
     r.ok = tile < n_tiles && r.s < M;
-    r.xr = X + (r.ok ? r.s : 0) * ldx + k_base;
-    return r;
-  };
-  auto load8 = [&](const rowctx &rc, int ks) -> f8 {   // elements 8 ks .. 8 ks + 7 of the lane's half row
-    f8 r;
     if (VEC) {
-      const float4 a = rc.ok ? *(const float4 *)(rc.xr + 8 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 b = rc.ok ? *(const float4 *)(rc.xr + 8 * ks + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+      const int64_t r0 = tile * 32 + (lane >> 2);
+      r.ok0 = tile < n_tiles && r0 < M;
+      r.ok1 = tile < n_tiles && r0 + 16 < M;
+      r.p0 = X + (r.ok0 ? r0 : 0) * ldx + 4 * (lane & 3);
+      r.p1 = X + (r.ok1 ? r0 + 16 : 0) * ldx + 4 * (lane & 3);
     } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) r.v[e] = (rc.ok && k_base + 8 * ks + e < K) ? rc.xr[8 * ks + e] : 0.f;
+      r.ok0 = r.ok1 = r.ok;
+      r.p0 = r.p1 = X + (r.ok ? r.s : 0) * ldx + 8 * h;
     }
     return r;
   };
-  constexpr int AHEAD = KS < 4 ? KS : 4;           // row pieces in flight
-  // the first tile's row pieces are requested BEFORE the weights are staged (an HBM round trip beside the 96 KB of split + LDS writes),
+  auto load8 = [&](const rowctx &rc, int ks) -> f8 {
+    f8 r;
+    if (VEC) {
+      const float4 a = rc.ok0 ? *(const float4 *)(rc.p0 + 16 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 b = rc.ok1 ? *(const float4 *)(rc.p1 + 16 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
+      r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r.v[e] = (rc.ok && 16 * ks + 8 * h + e < K) ? rc.p0[16 * ks + e] : 0.f;
+    }
+    return r;
+  };
+  constexpr int AHEAD = KS < 4 ? KS : 4;           // k-steps in flight
+  // the first tile's rows are requested BEFORE the weights are staged (an HBM round trip beside the 96 KB of split + LDS writes),
   // every later tile's before the previous tile's stores
   int64_t tile = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
   rowctx rc = ctx_of(tile);
@@ -317,9 +334,9 @@ k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__
 #pragma unroll
   for (int a = 0; a < AHEAD; ++a) xq[a] = load8(rc, a);
   for (int r = threadIdx.x; r < N_REC; r += UG_LINB_THREADS) {
-    int n, kq;                                     // kq = h * KS + ks: the record's first input is 8 kq
+    int n, kq;                                     // kq = 2 ks + h: the record's first input is 8 kq
     if (w_in_major) { n = r & 127; kq = r >> 7; } else { kq = r % (2 * KS); n = r / (2 * KS); }
-    const int k0 = 8 * kq, hh = kq / KS, ks = kq - hh * KS;
+    const int k0 = 8 * kq, ks = kq >> 1, hh = kq & 1;
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e)
@@ -342,8 +359,18 @@ k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const mlp_split3 xs = mlp_split8(xq[ks % AHEAD].v);
+      f8 xv = xq[ks % AHEAD];
       if (ks + AHEAD < KS) xq[ks % AHEAD] = load8(rc, ks + AHEAD);
+      if (VEC) {                                   // coalesced pieces -> staging tile -> the lane's own 8 inputs
+        float *buf = xt + (ks & 1) * (32 * 20);
+        *(float4 *)(buf + (lane >> 2) * 20 + 4 * (lane & 3)) = make_float4(xv.v[0], xv.v[1], xv.v[2], xv.v[3]);
+        *(float4 *)(buf + (16 + (lane >> 2)) * 20 + 4 * (lane & 3)) = make_float4(xv.v[4], xv.v[5], xv.v[6], xv.v[7]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        const float4 a = *(const float4 *)(buf + col * 20 + 8 * h), b = *(const float4 *)(buf + col * 20 + 8 * h + 4);
+        xv.v[0] = a.x; xv.v[1] = a.y; xv.v[2] = a.z; xv.v[3] = a.w; xv.v[4] = b.x; xv.v[5] = b.y; xv.v[6] = b.z; xv.v[7] = b.w;
+      }
+      const mlp_split3 xs = mlp_split8(xv.v);
       const mlp_bf16x8 *wp = wl + (ks * 3) * 2 * 128;
       mlp_bf16x8 wm[4], wlo[4], wh[4];
 #pragma unroll
@@ -370,7 +397,7 @@ k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__
     tile += (int64_t)gridDim.x * WAVES;
     rc = ctx_of(tile);
 #pragma unroll
-    for (int a = 0; a < AHEAD; ++a) xq[a] = load8(rc, a);      // (past the last tile: rc.ok is false, no loads)
+    for (int a = 0; a < AHEAD; ++a) xq[a] = load8(rc, a);      // (past the last tile: nothing is loaded)
     if (row_ok) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -577,7 +604,7 @@ static inline int ug_lin_launch(const float *X, int64_t M, int K, int ldx, const
     if (wgb > 256) wgb = 256;                      // one persistent 8-wave workgroup per CU (the image is 12 KB per k-step)
 #define UG_LINB_GO(KS_, VEC_)                                                                                                    \
   {                                                                                                                              \
-    constexpr int lds = KS_ * 2 * 128 * 3 * 16;                                                                                  \
+    constexpr int lds = KS_ * 2 * 128 * 3 * 16 + (UG_LINB_THREADS / 64) * UG_LINB_XT_FLOATS * 4;                                 \
     UG_SET_DYN_LDS((k_lin_b3<KS_, VEC_>), lds);                                                                                  \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lin_b3<KS_, VEC_>), dim3((unsigned)wgb), dim3(UG_LINB_THREADS), lds, st, X, M, K, ldx, W, ldw,  \
                        n_out, w_in_major, bias, relu, G, ldg, Y, ldy, ug_tl_devn.ptr);                                           \
