@@ -185,104 +185,14 @@ __device__ __forceinline__ float ug_density_level(const char *__restrict__ lvl, 
   // integer form compiled to quarter-rate v_mad_u64_u32 pairs.
   const unsigned row = (unsigned)fmaf(ax.cellf, (float)(Y - 1), ay.cellf);
   const unsigned off = __umul24(row, (unsigned)(Z - 1) << 5) + ((unsigned)az.cell << 5);
-  const float tz = az.whi, ty = ay.whi, tx = ax.whi;
   const float4 *b = (const float4 *)(lvl + off);
   const float4 v0 = b[0], v1 = b[1];
   // cell polynomial (k_pack_bricks): Horner in z, then y, then x -- 7 FMAs, no corner weights
+  const float tz = az.whi, ty = ay.whi, tx = ax.whi;
   const float p00 = fmaf(v0.y, tz, v0.x), p01 = fmaf(v0.w, tz, v0.z);   // x^0: y^0, y^1
   const float p10 = fmaf(v1.y, tz, v1.x), p11 = fmaf(v1.w, tz, v1.z);   // x^1
   return fmaf(fmaf(p11, ty, p10), tx, fmaf(p01, ty, p00));
 }
-
-#ifdef UG_MARCH_SCALAR_UNIFORM
-// A/B arm (round 6, tools/experiments/ARMS.md).  When every active lane of the wave reads the SAME record (26 % of the (wave, sample, level)
-// triples on S1, profiles/r05/cell_sharing_s1.json wave_uniform_frac) ONE scalar load through the constant cache serves the wave and the
-// vector-memory path -- the march's binding unit, 16 clocks per dwordx4 whatever the number of distinct records -- is not touched.
-// Version 1 branched inside ug_density_level: load and use in one block per level, every level's latency exposed in turn: 4 % SLOWER
-// (profiles/r06/march_scalar_uniform_ab_v1.txt).  Version 2 separates ISSUE (cell set-up, uniformity test, the load) from FINISH (the
-// polynomial): a group of levels is issued back to back, other work runs under the loads, then the group is finished in level order --
-// same floats, same FMAs, same summation order: bit-identical results.
-typedef float ug_f8 __attribute__((ext_vector_type(8)));
-struct ug_lvl_req {
-  float tx, ty, tz;
-  bool uni;            // wave-uniform
-  ug_f8 sc;            // the record in scalar registers (uni)
-  float4 v0, v1;       // or in vector registers
-};
-__device__ __forceinline__ void ug_level_issue(const char *__restrict__ lvl, float cx, float cy, float cz, int X, int Y, int Z,
-                                               ug_lvl_req &r) {
-  const ug_axis_fast ax = ug_axis_inrange(cx, X), ay = ug_axis_inrange(cy, Y), az = ug_axis_inrange(cz, Z);
-  const unsigned row = (unsigned)fmaf(ax.cellf, (float)(Y - 1), ay.cellf);
-  const unsigned off = __umul24(row, (unsigned)(Z - 1) << 5) + ((unsigned)az.cell << 5);
-  r.tz = az.whi; r.ty = ay.whi; r.tx = ax.whi;
-  const unsigned uoff = (unsigned)__builtin_amdgcn_readfirstlane((int)off);
-  r.uni = __builtin_amdgcn_ballot_w64(off != uoff) == 0ull;
-  if (r.uni) {
-    typedef __attribute__((address_space(4))) const ug_f8 *ug_cptr;      // constant address space + uniform address = s_load_dwordx8
-    r.sc = *(ug_cptr)(uintptr_t)(lvl + uoff);
-  } else {
-    const float4 *b = (const float4 *)(lvl + off);
-    r.v0 = b[0]; r.v1 = b[1];
-  }
-}
-__device__ __forceinline__ float ug_level_finish(const ug_lvl_req &r) {
-  // the opaque pass of tz pins the polynomial HERE: without it the compiler merges this branch with ug_level_issue's (same condition) and
-  // sinks the polynomial behind the loads of the issue block -- load, wait, use per level, version 1 again
-  float tz = r.tz;
-  asm volatile("" : "+v"(tz));
-  if (r.uni) {
-    const float p00 = fmaf(r.sc[1], tz, r.sc[0]), p01 = fmaf(r.sc[3], tz, r.sc[2]);
-    const float p10 = fmaf(r.sc[5], tz, r.sc[4]), p11 = fmaf(r.sc[7], tz, r.sc[6]);
-    return fmaf(fmaf(p11, r.ty, p10), r.tx, fmaf(p01, r.ty, p00));
-  }
-  const float p00 = fmaf(r.v0.y, tz, r.v0.x), p01 = fmaf(r.v0.w, tz, r.v0.z);
-  const float p10 = fmaf(r.v1.y, tz, r.v1.x), p11 = fmaf(r.v1.w, tz, r.v1.z);
-  return fmaf(fmaf(p11, r.ty, p10), r.tx, fmaf(p01, r.ty, p00));
-}
-// all P levels of a sample, groups of UG_SU_GROUP Fourier frequencies issued together
-#ifndef UG_SU_GROUP
-#define UG_SU_GROUP 1
-#endif
-template <int F>
-__device__ __forceinline__ float ug_density_levels_su(const char *__restrict__ bkb, size_t lvl_bytes, float ux, float uy, float uz,
-                                                      int X, int Y, int Z) {
-  ug_lvl_req q0;
-  ug_level_issue(bkb, ux, uy, uz, X, Y, Z, q0);
-  float dens = 0.f;
-  bool have0 = true;
-#pragma unroll
-  for (int k0 = 0; k0 < F; k0 += UG_SU_GROUP) {
-    ug_lvl_req qs[UG_SU_GROUP], qc[UG_SU_GROUP];
-#pragma unroll
-    for (int g = 0; g < UG_SU_GROUP; ++g) {
-      const int k = k0 + g;
-      if (k >= F) continue;
-      const float f = (float)(1 << k);
-      float sx, cx_, sy, cy_, sz, cz_;
-      if (k == 0) {
-        ug_sincos_small(ux, &sx, &cx_);
-        ug_sincos_small(uy, &sy, &cy_);
-        ug_sincos_small(uz, &sz, &cz_);
-      } else {
-        ug_sincos(f * ux, &sx, &cx_);
-        ug_sincos(f * uy, &sy, &cy_);
-        ug_sincos(f * uz, &sz, &cz_);
-      }
-      ug_level_issue(bkb + (size_t)(2 * k + 1) * lvl_bytes, sx, sy, sz, X, Y, Z, qs[g]);
-      ug_level_issue(bkb + (size_t)(2 * k + 2) * lvl_bytes, cx_, cy_, cz_, X, Y, Z, qc[g]);
-    }
-    if (have0) { dens = ug_level_finish(q0); have0 = false; }      // level 0 is finished under the first group's loads
-#pragma unroll
-    for (int g = 0; g < UG_SU_GROUP; ++g) {
-      if (k0 + g >= F) continue;
-      dens += ug_level_finish(qs[g]);
-      dens += ug_level_finish(qc[g]);
-    }
-  }
-  if (have0) dens = ug_level_finish(q0);
-  return dens;
-}
-#endif
 
 // DirectContractedVoxGO additions to the march (dcvgo.py:228-310; DC = true, single-level grids, F = 0): of the contracted
 // samples only those are evaluated whose running inter-sample distance has just exceeded dist_thres (cumdist_thres,
@@ -371,9 +281,6 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
         }
       }
       if (keep) {
-#ifdef UG_MARCH_SCALAR_UNIFORM
-        float dens = ug_density_levels_su<F>(bkb, lvl_bytes, ux, uy, uz, a.X, a.Y, a.Z);
-#else
         float dens = ug_density_level(bkb, ux, uy, uz, a.X, a.Y, a.Z);
 #pragma unroll
         for (int k = 0; k < F; ++k) {
@@ -391,7 +298,6 @@ __device__ __forceinline__ int ug_march_tile(const ug_march_args &a, const float
           dens += ug_density_level(bkb + (size_t)(2 * k + 1) * lvl_bytes, sx, sy, sz, a.X, a.Y, a.Z);
           dens += ug_density_level(bkb + (size_t)(2 * k + 2) * lvl_bytes, cx_, cy_, cz_, a.X, a.Y, a.Z);
         }
-#endif
         dens = ug_div_r(dens, (float)P, 1.0f / (float)P);   // mean over levels: Markstein division, 3 VALU instead of 10
         const float xs = dens + a.shift;
         const float alpha = ug_alpha(xs, a.interval);
