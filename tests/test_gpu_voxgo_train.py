@@ -504,27 +504,36 @@ def test_train_step_is_capturable_in_a_hip_graph(kind):
     m, (o, d, v), kw, R = _sync_free_pair(kind, dev)
     o2, d2, v2 = o.flip(0).contiguous(), d.flip(0).contiguous(), v.flip(0).contiguous()
     t2 = kw["fused_loss"]["target"].flip(0).contiguous()
-    # eager references on both ray sets
+    # eager references on both ray sets.  On a SIDE stream, and only detached copies are kept: an autograd graph that is still alive keeps
+    # the parameters' AccumulateGrad nodes alive, bound to the stream they were created on -- had that been the default (null) stream, the
+    # captured backward would pull the null stream into the capture and hipStreamEndCapture takes the process down (profiles/r06/NOTES.md,
+    # visits M-O: any eager run on the default stream whose result is still referenced does it; torch's own advice is a side-stream warm-up)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
     ref = []
-    for rays, tg in (((o, d, v), kw["fused_loss"]["target"]), ((o2, d2, v2), t2)):
-        m.native_sync_free = False
-        m.zero_grad(set_to_none=True)
-        torch.manual_seed(5)
-        out = m(*rays, global_step=1, is_train=True, **dict(kw, fused_loss=dict(kw["fused_loss"], target=tg)))
-        out["loss"].backward()
-        ref.append((out, {k: p.grad.clone() for k, p in m.named_parameters()}))
+    keep = ("loss_mse", "alphainv_last", "rgb_marched") + PER_SAMPLE
+    with torch.cuda.stream(side):
+        for rays, tg in (((o, d, v), kw["fused_loss"]["target"]), ((o2, d2, v2), t2)):
+            m.native_sync_free = False
+            m.zero_grad(set_to_none=True)
+            out = m(*rays, global_step=1, is_train=True, **dict(kw, fused_loss=dict(kw["fused_loss"], target=tg)))
+            out["loss"].backward()
+            ref.append(({k: out[k].detach().clone() for k in keep if k in out}, {k: p.grad.clone() for k, p in m.named_parameters()}))
+            del out
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
     # static inputs of the graph
     so, sd, sv, stg = o.clone(), d.clone(), v.clone(), kw["fused_loss"]["target"].clone()
     m.native_sync_free = {'hints': (0, 0)}
     m.zero_grad(set_to_none=True)
     kwg = dict(kw, fused_loss=dict(kw["fused_loss"], target=stg))
-    side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
-    with torch.cuda.stream(side):                      # warm-up on a side stream (allocator pools, lazy module loads)
+    with torch.cuda.stream(side):                      # warm-up on the side stream (allocator pools, lazy module loads)
         for _ in range(2):
             m.zero_grad(set_to_none=True)
             w = m(so, sd, sv, global_step=1, is_train=True, **kwg)
             w["loss"].backward()
+            del w
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     m.zero_grad(set_to_none=True)

@@ -104,6 +104,34 @@ __device__ __forceinline__ ug_taps ug_tap_setup(int X, int Y, int Z, float cx, f
   return t;
 }
 
+// The same taps for kernels that LOAD the corners: every offset is valid (a corner outside the grid is clamped, per axis, onto the cell's
+// in-range corner) and its weight is 0 -- `acc += g[off] * w` then runs without a branch and adds an exact zero where grid_sample pads.
+// With `if (off >= 0) acc += g[off] * w` every load sat under its own exec branch and hipcc put s_waitcnt vmcnt(0) behind each: the eight
+// corners of a level fetched ONE AFTER THE OTHER (round 6, visit P; S3's sampling march 0.64 ms).  Bit-identical: x + 0 = x, and the
+// clamped corner is one the sample reads anyway (a NaN there reaches the result in both forms).
+__device__ __forceinline__ ug_taps ug_tap_setup_ld(int X, int Y, int Z, float cx, float cy, float cz) {
+  const float ix = ((cx + 1.f) / 2.f) * (float)(X - 1);
+  const float iy = ((cy + 1.f) / 2.f) * (float)(Y - 1);
+  const float iz = ((cz + 1.f) / 2.f) * (float)(Z - 1);
+  const float fx = floorf(ix), fy = floorf(iy), fz = floorf(iz);
+  const float wx0 = (fx + 1.f) - ix, wx1 = ix - fx;
+  const float wy0 = (fy + 1.f) - iy, wy1 = iy - fy;
+  const float wz0 = (fz + 1.f) - iz, wz1 = iz - fz;
+  const int x0 = (int)fminf(fmaxf(fx, -2.f), (float)X), y0 = (int)fminf(fmaxf(fy, -2.f), (float)Y),
+            z0 = (int)fminf(fmaxf(fz, -2.f), (float)Z);
+  ug_taps t;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int xi = x0 + (c >> 2), yi = y0 + ((c >> 1) & 1), zi = z0 + (c & 1);
+    const bool in = xi >= 0 && xi < X && yi >= 0 && yi < Y && zi >= 0 && zi < Z;
+    const int xc = min(max(xi, 0), X - 1), yc = min(max(yi, 0), Y - 1), zc = min(max(zi, 0), Z - 1);
+    t.off[c] = ((int64_t)xc * Y + yc) * Z + zc;
+    const float w = ((c & 1) ? wz1 : wz0) * (((c >> 1) & 1) ? wy1 : wy0) * ((c >> 2) ? wx1 : wx0);
+    t.w[c] = in ? w : 0.f;
+  }
+  return t;
+}
+
 // level coordinates of the Fourier grid: l = 0 plain, odd l = sin(2^k u), even l = cos(2^k u), k = (l-1)/2
 __device__ __forceinline__ void ug_level_coords(int l, float ux, float uy, float uz, float &cx, float &cy, float &cz) {
   cx = ux; cy = uy; cz = uz;
@@ -143,12 +171,11 @@ __device__ __forceinline__ void ug_grid_query_one(int64_t tid, const float *__re
     for (int l = 0; l < P; ++l) {
       float cx, cy, cz;
       ug_level_coords(l, ux, uy, uz, cx, cy, cz);
-      const ug_taps t = ug_tap_setup(X, Y, Z, cx, cy, cz);
+      const ug_taps t = ug_tap_setup_ld(X, Y, Z, cx, cy, cz);
       const float *__restrict__ g = grid + (int64_t)l * vol * C + ch;
       float acc = 0.f;
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (t.off[c] >= 0) acc += g[t.off[c] * C] * t.w[c];
+      for (int c = 0; c < 8; ++c) acc += g[t.off[c] * C] * t.w[c];
       sum = (l == 0) ? acc : sum + acc;
     }
     out[tid] = (F > 0) ? sum / (float)P : sum;
@@ -158,13 +185,12 @@ __device__ __forceinline__ void ug_grid_query_one(int64_t tid, const float *__re
   for (int l = 0; l < P; ++l) {
     float cx, cy, cz;
     ug_level_coords(l, ux, uy, uz, cx, cy, cz);
-    const ug_taps t = ug_tap_setup(X, Y, Z, cx, cy, cz);
+    const ug_taps t = ug_tap_setup_ld(X, Y, Z, cx, cy, cz);
     for (int ch = 0; ch < C; ++ch) {
       const float *__restrict__ g = grid + ((int64_t)l * C + ch) * vol;
       float acc = 0.f;
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (t.off[c] >= 0) acc += g[t.off[c]] * t.w[c];
+      for (int c = 0; c < 8; ++c) acc += g[t.off[c]] * t.w[c];
       row[ch] = (l == 0) ? acc : row[ch] + acc;
     }
   }
@@ -364,12 +390,11 @@ k_train_march(ug_train_args a, const float *__restrict__ grid, const float *__re
       for (int l = 0; l < a.P; ++l) {
         float cx, cy, cz;
         ug_level_coords(l, ux, uy, uz, cx, cy, cz);
-        const ug_taps tp = ug_tap_setup(a.X, a.Y, a.Z, cx, cy, cz);
+        const ug_taps tp = ug_tap_setup_ld(a.X, a.Y, a.Z, cx, cy, cz);
         const float *__restrict__ g = grid + (int64_t)l * vol;
         float acc = 0.f;
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
-          if (tp.off[c] >= 0) acc += g[tp.off[c]] * tp.w[c];
+        for (int c = 0; c < 8; ++c) acc += g[tp.off[c]] * tp.w[c];
         dens = (l == 0) ? acc : dens + acc;
       }
       if (a.F > 0) dens = dens / (float)a.P;
@@ -489,11 +514,10 @@ k_train_march_vox(ug_train_args a, ug_train_vox v, const float *__restrict__ gri
     if (keep) keep = ug_train_maskcache(v, px, py, pz);
     if (keep) {
       const float ux = ug_unorm(px, lox, hix), uy = ug_unorm(py, loy, hiy), uz = ug_unorm(pz, loz, hiz);
-      const ug_taps tp = ug_tap_setup(a.X, a.Y, a.Z, ux, uy, uz);
+      const ug_taps tp = ug_tap_setup_ld(a.X, a.Y, a.Z, ux, uy, uz);
       float acc = 0.f;
 #pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (tp.off[c] >= 0) acc += grid[tp.off[c]] * tp.w[c];
+      for (int c = 0; c < 8; ++c) acc += grid[tp.off[c]] * tp.w[c];
       dens = acc;
       float e;
       alpha = ug_train_alpha(dens, a.shift, a.interval, &e);

@@ -471,13 +471,17 @@ k_tv_vec4(const float *__restrict__ param, float *__restrict__ grad, float wy, f
   const unsigned sj = (unsigned)sz_k, si = (unsigned)sz_k * (unsigned)sz_j;
   const float4 p = *(const float4 *)(param + idx);
   const bool k_first = kq == 0, k_last = kq == k4 - 1;
-  const float pm = k_first ? 0.f : param[idx - 1];
-  const float pp = k_last ? 0.f : param[idx + 4];
-  float4 nj0 = p, nj1 = p, ni0 = p, ni1 = p;
-  if (j != 0) nj0 = *(const float4 *)(param + idx - sj);
-  if (j != (unsigned)sz_j - 1) nj1 = *(const float4 *)(param + idx + sj);
-  if (i != 0) ni0 = *(const float4 *)(param + idx - si);
-  if (i != (unsigned)sz_i - 1) ni1 = *(const float4 *)(param + idx + si);
+  // unconditional neighbour loads (a missing neighbour re-reads a value of the element itself), the missing terms switched off by a
+  // zero weight: loads under their own exec branches are waited for one by one (see ug_tv_cl_one); bit-identical
+  const float pm = param[idx - (k_first ? 0u : 1u)];
+  const float pp = param[idx + (k_last ? 3u : 4u)];
+  const float wkm = k_first ? 0.f : wz, wkp = k_last ? 0.f : wz;
+  const float wj0 = j != 0 ? wy : 0.f, wj1 = j != (unsigned)sz_j - 1 ? wy : 0.f;
+  const float wi0 = i != 0 ? wz : 0.f, wi1 = i != (unsigned)sz_i - 1 ? wz : 0.f;
+  const float4 nj0 = *(const float4 *)(param + idx - (j != 0 ? sj : 0u));
+  const float4 nj1 = *(const float4 *)(param + idx + (j != (unsigned)sz_j - 1 ? sj : 0u));
+  const float4 ni0 = *(const float4 *)(param + idx - (i != 0 ? si : 0u));
+  const float4 ni1 = *(const float4 *)(param + idx + (i != (unsigned)sz_i - 1 ? si : 0u));
   const float pv[4] = {p.x, p.y, p.z, p.w}, gv[4] = {g0.x, g0.y, g0.z, g0.w};
   const float km[4] = {pm, p.x, p.y, p.z}, kp[4] = {p.y, p.z, p.w, pp};
   const float a0[4] = {nj0.x, nj0.y, nj0.z, nj0.w}, a1[4] = {nj1.x, nj1.y, nj1.z, nj1.w};
@@ -486,12 +490,12 @@ k_tv_vec4(const float *__restrict__ param, float *__restrict__ grad, float wy, f
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float g = 0;
-    g += ((k_first && e == 0) ? 0.f : wz * ug_clamp1(pv[e] - km[e]));
-    g += ((k_last && e == 3) ? 0.f : wz * ug_clamp1(pv[e] - kp[e]));
-    g += (j == 0 ? 0.f : wy * ug_clamp1(pv[e] - a0[e]));
-    g += (j == (unsigned)sz_j - 1 ? 0.f : wy * ug_clamp1(pv[e] - a1[e]));
-    g += (i == 0 ? 0.f : wz * ug_clamp1(pv[e] - b0[e]));
-    g += (i == (unsigned)sz_i - 1 ? 0.f : wz * ug_clamp1(pv[e] - b1[e]));
+    g += (e == 0 ? wkm : wz) * ug_clamp1(pv[e] - km[e]);
+    g += (e == 3 ? wkp : wz) * ug_clamp1(pv[e] - kp[e]);
+    g += wj0 * ug_clamp1(pv[e] - a0[e]);
+    g += wj1 * ug_clamp1(pv[e] - a1[e]);
+    g += wi0 * ug_clamp1(pv[e] - b0[e]);
+    g += wi1 * ug_clamp1(pv[e] - b1[e]);
     out[e] = (DENSE || gv[e] != 0.f) ? gv[e] + g : gv[e];
   }
   *(float4 *)(grad + idx) = make_float4(out[0], out[1], out[2], out[3]);
@@ -696,13 +700,17 @@ k_tv_adam_vec4(const float *__restrict__ param, float *__restrict__ param_out, c
   const unsigned sj = (unsigned)sz_k, si = (unsigned)sz_k * (unsigned)sz_j;
   const float4 p = *(const float4 *)(param + idx);
   const bool k_first = kq == 0, k_last = kq == k4 - 1;
-  const float pm = k_first ? 0.f : param[idx - 1];
-  const float pp = k_last ? 0.f : param[idx + 4];
-  float4 nj0 = p, nj1 = p, ni0 = p, ni1 = p;
-  if (j != 0) nj0 = *(const float4 *)(param + idx - sj);
-  if (j != (unsigned)sz_j - 1) nj1 = *(const float4 *)(param + idx + sj);
-  if (i != 0) ni0 = *(const float4 *)(param + idx - si);
-  if (i != (unsigned)sz_i - 1) ni1 = *(const float4 *)(param + idx + si);
+  // unconditional neighbour loads (a missing neighbour re-reads a value of the element itself), the missing terms switched off by a
+  // zero weight: loads under their own exec branches are waited for one by one (see ug_tv_cl_one); bit-identical
+  const float pm = param[idx - (k_first ? 0u : 1u)];
+  const float pp = param[idx + (k_last ? 3u : 4u)];
+  const float wkm = k_first ? 0.f : wz, wkp = k_last ? 0.f : wz;
+  const float wj0 = j != 0 ? wy : 0.f, wj1 = j != (unsigned)sz_j - 1 ? wy : 0.f;
+  const float wi0 = i != 0 ? wz : 0.f, wi1 = i != (unsigned)sz_i - 1 ? wz : 0.f;
+  const float4 nj0 = *(const float4 *)(param + idx - (j != 0 ? sj : 0u));
+  const float4 nj1 = *(const float4 *)(param + idx + (j != (unsigned)sz_j - 1 ? sj : 0u));
+  const float4 ni0 = *(const float4 *)(param + idx - (i != 0 ? si : 0u));
+  const float4 ni1 = *(const float4 *)(param + idx + (i != (unsigned)sz_i - 1 ? si : 0u));
   const float4 m4 = ug_ld4<XCD == 2>(exp_avg + idx), v4 = ug_ld4<XCD == 2>(exp_avg_sq + idx);
   float pv[4] = {p.x, p.y, p.z, p.w}, mv[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w};
   const float pold[4] = {p.x, p.y, p.z, p.w}, gv[4] = {g0.x, g0.y, g0.z, g0.w};
@@ -712,12 +720,12 @@ k_tv_adam_vec4(const float *__restrict__ param, float *__restrict__ param_out, c
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float g = 0;
-    g += ((k_first && e == 0) ? 0.f : wz * ug_clamp1(pold[e] - km[e]));
-    g += ((k_last && e == 3) ? 0.f : wz * ug_clamp1(pold[e] - kp[e]));
-    g += (j == 0 ? 0.f : wy * ug_clamp1(pold[e] - a0[e]));
-    g += (j == (unsigned)sz_j - 1 ? 0.f : wy * ug_clamp1(pold[e] - a1[e]));
-    g += (i == 0 ? 0.f : wz * ug_clamp1(pold[e] - b0[e]));
-    g += (i == (unsigned)sz_i - 1 ? 0.f : wz * ug_clamp1(pold[e] - b1[e]));
+    g += (e == 0 ? wkm : wz) * ug_clamp1(pold[e] - km[e]);
+    g += (e == 3 ? wkp : wz) * ug_clamp1(pold[e] - kp[e]);
+    g += wj0 * ug_clamp1(pold[e] - a0[e]);
+    g += wj1 * ug_clamp1(pold[e] - a1[e]);
+    g += wi0 * ug_clamp1(pold[e] - b0[e]);
+    g += wi1 * ug_clamp1(pold[e] - b1[e]);
     const float gt = gv[e] + g;
     if (!MASKED || gt != 0.f) ug_adam_one<0>(pv[e], gt, mv[e], vv[e], 1.f, step_size, beta1, beta2, eps);
   }
@@ -787,13 +795,18 @@ __device__ __forceinline__ void ug_tv_cl_one(const float *__restrict__ param, fl
                  i = (vox / ((unsigned)sz_k * (unsigned)sz_j)) % (unsigned)sz_i;
   const unsigned sk = (unsigned)C, sj = (unsigned)sz_k * sk, si = (unsigned)sz_j * sj;
   const float4 p = *(const float4 *)(param + idx);
-  float4 nk0 = p, nk1 = p, nj0 = p, nj1 = p, ni0 = p, ni1 = p;
-  if (k != 0) nk0 = *(const float4 *)(param + idx - sk);
-  if (k != (unsigned)sz_k - 1) nk1 = *(const float4 *)(param + idx + sk);
-  if (j != 0) nj0 = *(const float4 *)(param + idx - sj);
-  if (j != (unsigned)sz_j - 1) nj1 = *(const float4 *)(param + idx + sj);
-  if (i != 0) ni0 = *(const float4 *)(param + idx - si);
-  if (i != (unsigned)sz_i - 1) ni1 = *(const float4 *)(param + idx + si);
+  // the six neighbours by UNCONDITIONAL loads (a missing neighbour re-reads the element itself) and their terms switched off by a zero
+  // WEIGHT below: with `if (k != 0) nk0 = load` every load sat under its own exec branch and hipcc waited vmcnt(0) behind each -- seven
+  // round trips per element one after the other (round 6).  Bit-identical: a switched-off term is 0 * clamp(p - p) = 0, as before.
+  const float wk0 = k != 0 ? wz : 0.f, wk1 = k != (unsigned)sz_k - 1 ? wz : 0.f;
+  const float wj0 = j != 0 ? wy : 0.f, wj1 = j != (unsigned)sz_j - 1 ? wy : 0.f;
+  const float wi0 = i != 0 ? wz : 0.f, wi1 = i != (unsigned)sz_i - 1 ? wz : 0.f;
+  const float4 nk0 = *(const float4 *)(param + idx - (k != 0 ? sk : 0u));
+  const float4 nk1 = *(const float4 *)(param + idx + (k != (unsigned)sz_k - 1 ? sk : 0u));
+  const float4 nj0 = *(const float4 *)(param + idx - (j != 0 ? sj : 0u));
+  const float4 nj1 = *(const float4 *)(param + idx + (j != (unsigned)sz_j - 1 ? sj : 0u));
+  const float4 ni0 = *(const float4 *)(param + idx - (i != 0 ? si : 0u));
+  const float4 ni1 = *(const float4 *)(param + idx + (i != (unsigned)sz_i - 1 ? si : 0u));
   float pv[4] = {p.x, p.y, p.z, p.w};
   const float pold[4] = {p.x, p.y, p.z, p.w}, gv[4] = {g0.x, g0.y, g0.z, g0.w};
   const float k0[4] = {nk0.x, nk0.y, nk0.z, nk0.w}, k1[4] = {nk1.x, nk1.y, nk1.z, nk1.w};
@@ -809,12 +822,12 @@ __device__ __forceinline__ void ug_tv_cl_one(const float *__restrict__ param, fl
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     float g = 0;
-    g += (k == 0 ? 0.f : wz * ug_clamp1(pold[e] - k0[e]));
-    g += (k == (unsigned)sz_k - 1 ? 0.f : wz * ug_clamp1(pold[e] - k1[e]));
-    g += (j == 0 ? 0.f : wy * ug_clamp1(pold[e] - a0[e]));
-    g += (j == (unsigned)sz_j - 1 ? 0.f : wy * ug_clamp1(pold[e] - a1[e]));
-    g += (i == 0 ? 0.f : wz * ug_clamp1(pold[e] - b0[e]));
-    g += (i == (unsigned)sz_i - 1 ? 0.f : wz * ug_clamp1(pold[e] - b1[e]));
+    g += wk0 * ug_clamp1(pold[e] - k0[e]);
+    g += wk1 * ug_clamp1(pold[e] - k1[e]);
+    g += wj0 * ug_clamp1(pold[e] - a0[e]);
+    g += wj1 * ug_clamp1(pold[e] - a1[e]);
+    g += wi0 * ug_clamp1(pold[e] - b0[e]);
+    g += wi1 * ug_clamp1(pold[e] - b1[e]);
     out[e] = (DENSE || gv[e] != 0.f) ? gv[e] + g : gv[e];
     if (ADAM) {
       if (ADAM == 2 || out[e] != 0.f) ug_adam_one<0>(pv[e], out[e], mv[e], vv[e], 1.f, step_size, beta1, beta2, eps);

@@ -268,61 +268,148 @@ __device__ __forceinline__ mlp_split3 mlp_split8(const float (&x)[8]) {
   acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);  \
   __builtin_amdgcn_sched_barrier(0)
 
-// Y^T tile = W . X^T: D[m = output][n = sample] -- the weights are the A operands (LDS image, 16-byte records of 8 bf16), the lane's own
-// sample row the B operand, and a lane ends up with FOUR CONSECUTIVE outputs of its sample per accumulator quad: 16 float4 stores per
-// tile and lane instead of 64 scalar ones.  KS = k-steps of 16 inputs (zero padded); in k-step ks lane half h multiplies inputs
+// one k-step of a 32-sample x 128-output tile: the sample's 8 inputs (B operand) against the three weight parts of 4 output tiles
+// (A operands from the LDS image, wl = image + h * 128 + col), six products per tile, smallest first; consecutive MFMAs never share an
+// accumulator
+__device__ __forceinline__ void mlp_b3_kstep(mlp_f32x16 (&acc)[4], const mlp_bf16x8 *__restrict__ wl, int ks, const float (&xv)[8]) {
+  const mlp_split3 xs = mlp_split8(xv);
+  const mlp_bf16x8 *wp = wl + (ks * 3) * 2 * 128;
+  mlp_bf16x8 wm[4], wlo[4], wh[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) wm[t] = wp[(1 * 2) * 128 + 32 * t];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) wlo[t] = wp[(2 * 2) * 128 + 32 * t];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wm[t], xs.m); }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) wh[t] = wp[(0 * 2) * 128 + 32 * t];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wlo[t], xs.h); }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wh[t], xs.l); }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wm[t], xs.h); }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wh[t], xs.m); }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wh[t], xs.h); }
+}
+
+// the weight image of k_lin_b3 / k_lin_b3_dense: rec[((ks * 3 + part) * 2 + h) * 128 + n] = parts of W[n][16 ks + 8 h + e], e = 0..7
+// (zero beyond K / n_out); unconditional loads on clamped indices, zeros by a mask product (see k_wgrad_b3)
+template <int KS, int THREADS>
+__device__ __forceinline__ void mlp_b3_stage_weights(mlp_bf16x8 *img, const float *__restrict__ W, int ldw, int K, int n_out, int w_in_major) {
+  constexpr int N_REC = 2 * KS * 128;
+  for (int r = threadIdx.x; r < N_REC; r += THREADS) {
+    int n, kq;                                     // kq = 2 ks + h: the record's first input is 8 kq
+    if (w_in_major) { n = r & 127; kq = r >> 7; } else { kq = r % (2 * KS); n = r / (2 * KS); }
+    const int k0 = 8 * kq, ks = kq >> 1, hh = kq & 1;
+    float v[8];
+    const int nc = n < n_out ? n : n_out - 1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int kc = k0 + e < K ? k0 + e : K - 1;
+      v[e] = (w_in_major ? W[(int64_t)kc * ldw + nc] : W[(int64_t)nc * ldw + kc]) * ((k0 + e < K && n < n_out) ? 1.f : 0.f);
+    }
+    const mlp_split3 sp = mlp_split8(v);
+    img[((ks * 3 + 0) * 2 + hh) * 128 + n] = sp.h;
+    img[((ks * 3 + 1) * 2 + hh) * 128 + n] = sp.m;
+    img[((ks * 3 + 2) * 2 + hh) * 128 + n] = sp.l;
+  }
+}
+
+// bias, ReLU, the ReLU mask of the layer below, 16 float4 stores: D[m = output][n = sample] of one tile -> Y[s][..]
+__device__ __forceinline__ void mlp_b3_store(const mlp_f32x16 (&acc)[4], int64_t s, int h, int n_out, const float *__restrict__ bias, int relu,
+                                             const float *__restrict__ G, int ldg, float *__restrict__ Y, int ldy) {
+  const int nt_live = (n_out + 31) >> 5;          // output tiles that hold anything (wave-uniform)
+#pragma unroll
+  for (int t0 = 0; t0 < 4; t0 += 2) {              // two output tiles at a time
+    if (t0 >= nt_live) continue;
+    // the mask's 8 pieces of the pair are requested before the first is used (one exposed wait each otherwise)
+    float4 gm[2][4];
+    if (G) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int c0 = 32 * (t0 + t) + 8 * q + 4 * h;
+          gm[t][q] = *(const float4 *)(G + s * ldg + (c0 < n_out ? c0 : n_out - 4));
+        }
+    }
+#pragma unroll
+    for (int t = t0; t < t0 + 2; ++t) {
+      if (t >= nt_live) continue;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c0 = 32 * t + 8 * q + 4 * h;     // outputs c0 .. c0 + 3 of sample s (n_out % 4 == 0: all four or none)
+        if (c0 >= n_out) continue;
+        float r[4] = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+        if (bias) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r[j] = r[j] + bias[c0 + j];
+        }
+        if (relu) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) r[j] = fmaxf(r[j], 0.f);
+        }
+        if (G) {
+          const float4 g = gm[t - t0][q];
+          if (!(g.x > 0.f)) r[0] = 0.f;
+          if (!(g.y > 0.f)) r[1] = 0.f;
+          if (!(g.z > 0.f)) r[2] = 0.f;
+          if (!(g.w > 0.f)) r[3] = 0.f;
+        }
+        *(float4 *)(Y + s * ldy + c0) = make_float4(r[0], r[1], r[2], r[3]);
+      }
+    }
+  }
+}
+
+// Y^T tile = W . X^T: D[m = output][n = sample] -- the weights are the A operands (LDS image, 16-byte records of 8 bf16), the sample's
+// inputs the B operand, and a lane ends up with FOUR CONSECUTIVE outputs of its sample per accumulator quad: 16 float4 stores per tile
+// and lane instead of 64 scalar ones.  KS = k-steps of 16 inputs (zero padded); in k-step ks lane half h multiplies inputs
 // 16 ks + 8 h .. + 7 of its sample.  n_out in (32, 128], a multiple of 4.
-// LDS image: rec[((ks * 3 + part) * 2 + h) * 128 + n] = parts of W[n][16 ks + 8 h + e], e = 0..7 (zero beyond K / n_out).
-// VEC (K = 16 KS, 16-byte aligned rows): the sample rows reach their lanes THROUGH LDS.  A lane reading its own row makes every load
-// instruction touch 64 different cache lines -- 66 tag look-ups per instruction and the vector-memory path busy for 29 of the kernel's
-// 50 us (profiles/r06/klin_b3_pmc.txt); here a k-step's 32 x 64 bytes are fetched by two COALESCED dwordx4 per lane (four lanes per
-// 64-byte piece: 16 pieces per instruction), written to the wave's own 2.5 KB staging tile (rows padded to 80 bytes: the transposed
-// reads are conflict-free) and read back in operand order.
+// The sample rows reach their lanes THROUGH LDS: a lane reading its own row makes every load instruction touch 64 different cache
+// lines (66 tag look-ups per instruction, profiles/r06/klin_b3_pmc.txt).
+//   k_lin_b3<KS>        K = 16 KS, 16-byte aligned rows: a k-step's 32 x 64 bytes are fetched by two coalesced dwordx4 per lane (four
+//                       lanes per 64-byte piece), four k-steps ahead, written to the wave's staging tile (rows padded to 80 bytes: the
+//                       transposed reads are conflict-free) and read back in operand order;
+//   k_lin_b3_dense<KS>  any K <= 16 KS <= 64 with ldx == K: the tile's 32 rows are ONE contiguous run of 32 K floats, fetched whole by
+//                       coalesced dword loads (the next tile's before this tile's MFMAs), rows padded to 16 KS + 1 floats in LDS.
+// Every load is unconditional on a clamped address -- rows past the end repeat the last row and feed output columns that are never
+// stored: with loads under exec branches hipcc cannot count them and waits vmcnt(0) right behind the look-ahead it has just issued.
 #define UG_LINB_THREADS 512
-#define UG_LINB_XT_FLOATS (2 * 32 * 20)      /* per wave: two staging tiles of 32 rows x 20 floats */
-template <int KS, bool VEC>
+#define UG_LINB_XT_FLOATS (2 * 32 * 20)      /* k_lin_b3, per wave: two staging tiles of 32 rows x 20 floats */
+template <int KS>
 __global__ void __launch_bounds__(UG_LINB_THREADS)
 k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__restrict__ W, int ldw, int n_out, int w_in_major,
          const float *__restrict__ bias, int relu, const float *__restrict__ G, int ldg, float *__restrict__ Y, int ldy,
          const int64_t *__restrict__ n_dev) {
   UG_DEVN_CLAMP(M, n_dev);
+  if (M <= 0) return;                              // (a device count of zero)
   extern __shared__ float lds[];
   mlp_bf16x8 *img = (mlp_bf16x8 *)lds;
-  constexpr int N_REC = 2 * KS * 128;
   const int lane = ug_lane(), h = lane >> 5, col = lane & 31;
   const int64_t n_tiles = (M + 31) >> 5;
   constexpr int WAVES = UG_LINB_THREADS / 64;
-  float *xt = lds + N_REC * 3 * 4 + (threadIdx.x >> 6) * UG_LINB_XT_FLOATS;      // (VEC) this wave's staging tiles
+  float *xt = lds + 2 * KS * 128 * 3 * 4 + (threadIdx.x >> 6) * UG_LINB_XT_FLOATS;      // this wave's staging tiles
   struct f8 { float v[8]; };
-  // what a lane fetches per k-step: VEC -- 16 bytes of row (lane >> 2) and of row 16 + (lane >> 2) of the tile, piece lane & 3;
-  // otherwise its own 8 inputs
-  struct rowctx { const float *p0, *p1; int64_t s; bool ok, ok0, ok1; };
+  // per k-step a lane fetches 16 bytes of row (lane >> 2) and of row 16 + (lane >> 2) of the tile, piece lane & 3
+  struct rowctx { const float *p0, *p1; };
   auto ctx_of = [&](int64_t tile) -> rowctx {
     rowctx r;
-    r.s = tile * 32 + col;
-    r.ok = tile < n_tiles && r.s < M;
-    if (VEC) {
-      const int64_t r0 = tile * 32 + (lane >> 2);
-      r.ok0 = tile < n_tiles && r0 < M;
-      r.ok1 = tile < n_tiles && r0 + 16 < M;
-      r.p0 = X + (r.ok0 ? r0 : 0) * ldx + 4 * (lane & 3);
-      r.p1 = X + (r.ok1 ? r0 + 16 : 0) * ldx + 4 * (lane & 3);
-    } else {
-      r.ok0 = r.ok1 = r.ok;
-      r.p0 = r.p1 = X + (r.ok ? r.s : 0) * ldx + 8 * h;
-    }
+    const int64_t last = M - 1, r0 = tile * 32 + (lane >> 2), r1 = r0 + 16;
+    r.p0 = X + (r0 < last ? r0 : last) * ldx + 4 * (lane & 3);
+    r.p1 = X + (r1 < last ? r1 : last) * ldx + 4 * (lane & 3);
     return r;
   };
   auto load8 = [&](const rowctx &rc, int ks) -> f8 {
     f8 r;
-    if (VEC) {
-      const float4 a = rc.ok0 ? *(const float4 *)(rc.p0 + 16 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
-      const float4 b = rc.ok1 ? *(const float4 *)(rc.p1 + 16 * ks) : make_float4(0.f, 0.f, 0.f, 0.f);
-      r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) r.v[e] = (rc.ok && 16 * ks + 8 * h + e < K) ? rc.p0[16 * ks + e] : 0.f;
-    }
+    const float4 a = *(const float4 *)(rc.p0 + 16 * ks);
+    const float4 b = *(const float4 *)(rc.p1 + 16 * ks);
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
     return r;
   };
   constexpr int AHEAD = KS < 4 ? KS : 4;           // k-steps in flight
@@ -333,25 +420,11 @@ k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__
   f8 xq[AHEAD];
 #pragma unroll
   for (int a = 0; a < AHEAD; ++a) xq[a] = load8(rc, a);
-  for (int r = threadIdx.x; r < N_REC; r += UG_LINB_THREADS) {
-    int n, kq;                                     // kq = 2 ks + h: the record's first input is 8 kq
-    if (w_in_major) { n = r & 127; kq = r >> 7; } else { kq = r % (2 * KS); n = r / (2 * KS); }
-    const int k0 = 8 * kq, ks = kq >> 1, hh = kq & 1;
-    float v[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      v[e] = (k0 + e < K && n < n_out) ? (w_in_major ? W[(int64_t)(k0 + e) * ldw + n] : W[(int64_t)n * ldw + k0 + e]) : 0.f;
-    const mlp_split3 sp = mlp_split8(v);
-    img[((ks * 3 + 0) * 2 + hh) * 128 + n] = sp.h;
-    img[((ks * 3 + 1) * 2 + hh) * 128 + n] = sp.m;
-    img[((ks * 3 + 2) * 2 + hh) * 128 + n] = sp.l;
-  }
+  mlp_b3_stage_weights<KS, UG_LINB_THREADS>(img, W, ldw, K, n_out, w_in_major);
   __syncthreads();
   const mlp_bf16x8 *__restrict__ wl = img + h * 128 + col;
-  const int nt_live = (n_out + 31) >> 5;          // output tiles that hold anything (wave-uniform)
   for (; tile < n_tiles; ) {
-    const int64_t s = rc.s;
-    const bool row_ok = rc.ok;
+    const int64_t s = tile * 32 + col;
     mlp_f32x16 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -359,73 +432,88 @@ k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      f8 xv = xq[ks % AHEAD];
+      const f8 xv = xq[ks % AHEAD];
       if (ks + AHEAD < KS) xq[ks % AHEAD] = load8(rc, ks + AHEAD);
-      if (VEC) {                                   // coalesced pieces -> staging tile -> the lane's own 8 inputs
-        float *buf = xt + (ks & 1) * (32 * 20);
-        *(float4 *)(buf + (lane >> 2) * 20 + 4 * (lane & 3)) = make_float4(xv.v[0], xv.v[1], xv.v[2], xv.v[3]);
-        *(float4 *)(buf + (16 + (lane >> 2)) * 20 + 4 * (lane & 3)) = make_float4(xv.v[4], xv.v[5], xv.v[6], xv.v[7]);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        const float4 a = *(const float4 *)(buf + col * 20 + 8 * h), b = *(const float4 *)(buf + col * 20 + 8 * h + 4);
-        xv.v[0] = a.x; xv.v[1] = a.y; xv.v[2] = a.z; xv.v[3] = a.w; xv.v[4] = b.x; xv.v[5] = b.y; xv.v[6] = b.z; xv.v[7] = b.w;
-      }
-      const mlp_split3 xs = mlp_split8(xv.v);
-      const mlp_bf16x8 *wp = wl + (ks * 3) * 2 * 128;
-      mlp_bf16x8 wm[4], wlo[4], wh[4];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) wm[t] = wp[(1 * 2) * 128 + 32 * t];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) wlo[t] = wp[(2 * 2) * 128 + 32 * t];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wm[t], xs.m); }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) wh[t] = wp[(0 * 2) * 128 + 32 * t];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wlo[t], xs.h); }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wh[t], xs.l); }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wm[t], xs.h); }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wh[t], xs.m); }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wh[t], xs.h); }
+      // coalesced pieces -> staging tile -> the lane's own 8 inputs
+      float *buf = xt + (ks & 1) * (32 * 20);
+      *(float4 *)(buf + (lane >> 2) * 20 + 4 * (lane & 3)) = make_float4(xv.v[0], xv.v[1], xv.v[2], xv.v[3]);
+      *(float4 *)(buf + (16 + (lane >> 2)) * 20 + 4 * (lane & 3)) = make_float4(xv.v[4], xv.v[5], xv.v[6], xv.v[7]);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      const float4 a = *(const float4 *)(buf + col * 20 + 8 * h), b = *(const float4 *)(buf + col * 20 + 8 * h + 4);
+      const float own[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+      mlp_b3_kstep(acc, wl, ks, own);
     }
     tile += (int64_t)gridDim.x * WAVES;
     rc = ctx_of(tile);
 #pragma unroll
-    for (int a = 0; a < AHEAD; ++a) xq[a] = load8(rc, a);      // (past the last tile: nothing is loaded)
-    if (row_ok) {
+    for (int a = 0; a < AHEAD; ++a) xq[a] = load8(rc, a);      // (past the last tile: the last row again, never used)
+    if (s < M) mlp_b3_store(acc, s, h, n_out, bias, relu, G, ldg, Y, ldy);
+  }
+}
+
+template <int KS>
+__global__ void __launch_bounds__(UG_LINB_THREADS)
+k_lin_b3_dense(const float *__restrict__ X, int64_t M, int K, const float *__restrict__ W, int ldw, int n_out, int w_in_major,
+               const float *__restrict__ bias, int relu, const float *__restrict__ G, int ldg, float *__restrict__ Y, int ldy,
+               const int64_t *__restrict__ n_dev) {
+  UG_DEVN_CLAMP(M, n_dev);
+  if (M <= 0) return;
+  extern __shared__ float lds[];
+  mlp_bf16x8 *img = (mlp_bf16x8 *)lds;
+  constexpr int RP = 16 * KS + 1;                  // staged row pitch in floats: odd, so that the 32 lanes of a transposed read hit 32 banks
+  constexpr int NL = (32 * 16 * KS + 63) / 64;     // dwords per lane that cover a tile of 32 rows x K <= 16 KS floats
+  const int lane = ug_lane(), h = lane >> 5, col = lane & 31;
+  const int64_t n_tiles = (M + 31) >> 5;
+  constexpr int WAVES = UG_LINB_THREADS / 64;
+  float *xt = lds + 2 * KS * 128 * 3 * 4 + (threadIdx.x >> 6) * (32 * RP);
+  // where element lane + 64 j of a tile's contiguous run lands in the staging tile (the same for every tile)
+  int off[NL];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        if (t >= nt_live) continue;
+  for (int j = 0; j < NL; ++j) {
+    const int i = lane + 64 * j, row = i / K;
+    off[j] = row < 32 ? row * RP + (i - row * K) : -1;
+  }
+  for (int i = lane; i < 32 * RP; i += 64) xt[i] = 0.f;      // the pad columns K .. 16 KS - 1 stay zero for the whole kernel
+  const int64_t total = M * K;
+  auto load_tile = [&](int64_t tile, float (&v)[NL]) {
+    const int64_t base = tile * 32 * K;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int c0 = 32 * t + 8 * q + 4 * h;   // outputs c0 .. c0 + 3 of sample s (n_out % 4 == 0: all four or none)
-          if (c0 >= n_out) continue;
-          float r[4] = {acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
-          if (bias) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = r[j] + bias[c0 + j];
-          }
-          if (relu) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) r[j] = fmaxf(r[j], 0.f);
-          }
-          if (G) {
-            const float4 g = *(const float4 *)(G + s * ldg + c0);
-            if (!(g.x > 0.f)) r[0] = 0.f;
-            if (!(g.y > 0.f)) r[1] = 0.f;
-            if (!(g.z > 0.f)) r[2] = 0.f;
-            if (!(g.w > 0.f)) r[3] = 0.f;
-          }
-          *(float4 *)(Y + s * ldy + c0) = make_float4(r[0], r[1], r[2], r[3]);
-        }
-      }
+    for (int j = 0; j < NL; ++j) {
+      const int64_t i = base + lane + 64 * j;
+      v[j] = X[i < total ? i : total - 1];
     }
+  };
+  int64_t tile = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
+  float cur[NL];
+  load_tile(tile < n_tiles ? tile : n_tiles - 1, cur);
+  mlp_b3_stage_weights<KS, UG_LINB_THREADS>(img, W, ldw, K, n_out, w_in_major);
+  __syncthreads();
+  const mlp_bf16x8 *__restrict__ wl = img + h * 128 + col;
+  for (; tile < n_tiles; ) {
+    const int64_t s = tile * 32 + col;
+#pragma unroll
+    for (int j = 0; j < NL; ++j)
+      if (off[j] >= 0) xt[off[j]] = cur[j];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    tile += (int64_t)gridDim.x * WAVES;
+    load_tile(tile < n_tiles ? tile : n_tiles - 1, cur);      // the next tile's run, under this tile's MFMAs
+    mlp_f32x16 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+    const float *rp = xt + col * RP + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float own[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) own[e] = rp[16 * ks + e];
+      mlp_b3_kstep(acc, wl, ks, own);
+    }
+    __builtin_amdgcn_wave_barrier();               // (the next tile's writes follow this tile's reads in the wave's own LDS order)
+    if (s < M) mlp_b3_store(acc, s, h, n_out, bias, relu, G, ldg, Y, ldy);
   }
 }
 
@@ -454,8 +542,15 @@ k_wgrad_b3(const float *__restrict__ dY, int ldd, int n_out, const float *__rest
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   float bsum = 0.f;
   bool k_ok[NT];
+  int kc[NT];                                      // clamped column of every tile (loads are unconditional)
 #pragma unroll
-  for (int t = 0; t < NT; ++t) k_ok[t] = kcol0 + 32 * t < K;
+  for (int t = 0; t < NT; ++t) { k_ok[t] = kcol0 + 32 * t < K; kc[t] = k_ok[t] ? kcol0 + 32 * t : K - 1; }
+  const int cc = c_ok ? c : n_out - 1;
+  const float mc = c_ok ? 1.f : 0.f;
+  const bool all_cols = (n_out & 31) == 0 && 32 * NT * (kt + 1) <= K;      // (wave-uniform) every lane's columns exist
+  float mk[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) mk[t] = k_ok[t] ? 1.f : 0.f;
   struct opnd { float a[8], b[NT][8]; };
   // The wave's work as ONE sequence of 16-sample steps: step t = rows 16 (t & 7) .. + 15 of chunk (t >> 3) of its slab (chunks slab,
   // slab + n_slabs, ...).  Operands are fetched FOUR steps ahead (a ring of four register sets): with two waves per SIMD a step's
@@ -463,34 +558,35 @@ k_wgrad_b3(const float *__restrict__ dY, int ldd, int n_out, const float *__rest
   // M = 1.2e5, round 6 visit I).
   const int64_t n_chunks = (M + UG_WG_CHUNK - 1) / UG_WG_CHUNK;
   const int64_t T = slab < n_chunks ? ((n_chunks - slab + n_slabs - 1) / n_slabs) * (UG_WG_CHUNK / 16) : 0;
-  auto fetch = [&](int64_t t) -> opnd {
+  auto fetch = [&](int64_t t) -> opnd {            // (only called with T > 0, hence M > 0; steps past the end load row M - 1 and select zeros)
     opnd o;
-    if (t >= T) {                                   // (wave-uniform) past the end: zeros, no loads
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        o.a[e] = 0.f;
-#pragma unroll
-        for (int q = 0; q < NT; ++q) o.b[q][e] = 0.f;
-      }
-      return o;
-    }
+    const bool live = t < T;
     const int64_t sb = ((int64_t)slab + (t >> 3) * n_slabs) * UG_WG_CHUNK + 16 * (t & 7) + 8 * h;
-    const float *__restrict__ pa = dY + sb * ldd + c;
-    const float *__restrict__ pb = X + sb * ldx + kcol0;
-    if (sb - 8 * h + 16 <= M) {                     // (wave-uniform) every row of the step exists: no row predicates
+    // Unconditional loads everywhere: hipcc turns `cond ? load : 0` back into a branch around the load, and a load under an exec branch
+    // is followed by vmcnt(0) -- each of the 24 loads of a step waited for in turn.  One 64-bit base per operand and step, 32-bit row
+    // offsets (a 64-bit multiply-add per load made the kernel VALU-bound).
+    if (live && all_cols && sb - 8 * h + 16 <= M) {   // (wave-uniform) the common step: every row and every column exists -- no masks
+      const float *__restrict__ pa = dY + sb * ldd + c;
+      const float *__restrict__ pb = X + sb * ldx + kcol0;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        o.a[e] = c_ok ? pa[(int64_t)e * ldd] : 0.f;
+        o.a[e] = pa[e * ldd];
 #pragma unroll
-        for (int q = 0; q < NT; ++q) o.b[q][e] = k_ok[q] ? pb[(int64_t)e * ldx + 32 * q] : 0.f;
+        for (int q = 0; q < NT; ++q) o.b[q][e] = pb[e * ldx + 32 * q];
       }
-    } else {
+    } else {                                          // edges: rows past the end re-read row M - 1, zeros by a mask PRODUCT
+      const int64_t sbc = sb < M - 1 ? sb : M - 1;
+      const float *__restrict__ pa = dY + sbc * ldd + cc;
+      const float *__restrict__ pb = X + sbc * ldx;
+      const int room = (int)(M - 1 - sbc);           // rows after sbc that exist (>= 0)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        const bool on = sb + e < M;
-        o.a[e] = (on && c_ok) ? pa[(int64_t)e * ldd] : 0.f;
+        const bool on = live && sb + e < M;
+        const int ec = e <= room ? e : room;
+        const float mrow = on ? 1.f : 0.f;
+        o.a[e] = pa[ec * ldd] * (mrow * mc);
 #pragma unroll
-        for (int q = 0; q < NT; ++q) o.b[q][e] = (on && k_ok[q]) ? pb[(int64_t)e * ldx + 32 * q] : 0.f;
+        for (int q = 0; q < NT; ++q) o.b[q][e] = pb[ec * ldx + kc[q]] * (mrow * mk[q]);
       }
     }
     return o;
@@ -517,12 +613,14 @@ k_wgrad_b3(const float *__restrict__ dY, int ldd, int n_out, const float *__rest
 #pragma unroll
     for (int t = 0; t < NT; ++t) { MLP_MFMA_BF16(acc[t], as.h, bs[t].h); }
   };
-  opnd q0 = fetch(0), q1 = fetch(1), q2 = fetch(2), q3 = fetch(3);
-  for (int64_t t = 0; t < T; t += 4) {              // (T is a multiple of 8)
-    consume(q0); q0 = fetch(t + 4);
-    consume(q1); q1 = fetch(t + 5);
-    consume(q2); q2 = fetch(t + 6);
-    consume(q3); q3 = fetch(t + 7);
+  if (T > 0) {
+    opnd q0 = fetch(0), q1 = fetch(1), q2 = fetch(2), q3 = fetch(3);
+    for (int64_t t = 0; t < T; t += 4) {            // (T is a multiple of 8)
+      consume(q0); q0 = fetch(t + 4);
+      consume(q1); q1 = fetch(t + 5);
+      consume(q2); q2 = fetch(t + 6);
+      consume(q3); q3 = fetch(t + 7);
+    }
   }
   float *__restrict__ pw = partial_w + (int64_t)slab * n_out * K;
 #pragma unroll
@@ -602,22 +700,37 @@ static inline int ug_lin_launch(const float *X, int64_t M, int K, int ldx, const
     constexpr int WB = UG_LINB_THREADS / 64;
     int64_t wgb = (tiles + WB - 1) / WB;
     if (wgb > 256) wgb = 256;                      // one persistent 8-wave workgroup per CU (the image is 12 KB per k-step)
-#define UG_LINB_GO(KS_, VEC_)                                                                                                    \
+#define UG_LINB_GO(KS_)                                                                                                          \
   {                                                                                                                              \
     constexpr int lds = KS_ * 2 * 128 * 3 * 16 + (UG_LINB_THREADS / 64) * UG_LINB_XT_FLOATS * 4;                                 \
-    UG_SET_DYN_LDS((k_lin_b3<KS_, VEC_>), lds);                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lin_b3<KS_, VEC_>), dim3((unsigned)wgb), dim3(UG_LINB_THREADS), lds, st, X, M, K, ldx, W, ldw,  \
+    UG_SET_DYN_LDS((k_lin_b3<KS_>), lds);                                                                                        \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lin_b3<KS_>), dim3((unsigned)wgb), dim3(UG_LINB_THREADS), lds, st, X, M, K, ldx, W, ldw,  \
                        n_out, w_in_major, bias, relu, G, ldg, Y, ldy, ug_tl_devn.ptr);                                           \
+    UG_LAUNCH_CHECK();                                                                                                           \
+    return 0;                                                                                                                    \
+  }
+#define UG_LINB_DENSE(KS_)                                                                                                       \
+  {                                                                                                                              \
+    constexpr int lds = KS_ * 2 * 128 * 3 * 16 + (UG_LINB_THREADS / 64) * 32 * (16 * KS_ + 1) * 4;                               \
+    UG_SET_DYN_LDS((k_lin_b3_dense<KS_>), lds);                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lin_b3_dense<KS_>), dim3((unsigned)wgb), dim3(UG_LINB_THREADS), lds, st, X, M, K, W, ldw, \
+                       n_out, w_in_major, bias, relu, G, ldg, Y, ldy, ug_tl_devn.ptr);                                           \
+    UG_LAUNCH_CHECK();                                                                                                           \
+    return 0;                                                                                                                    \
   }
     const bool al = (ldx & 3) == 0 && ((uintptr_t)X & 15) == 0;
-    if (kh <= 16) { if (al && K == 32) UG_LINB_GO(2, true) else UG_LINB_GO(2, false) }
-    else if (kh <= 24) UG_LINB_GO(3, false)
-    else if (kh <= 32) { if (al && K == 64) UG_LINB_GO(4, true) else UG_LINB_GO(4, false) }
-    else if (kh <= 48) UG_LINB_GO(6, false)
-    else { if (al && K == 128) UG_LINB_GO(8, true) else UG_LINB_GO(8, false) }
+    if (al && K == 128) UG_LINB_GO(8)
+    if (al && K == 64) UG_LINB_GO(4)
+    if (al && K == 32) UG_LINB_GO(2)
+    if (ldx == K && K <= 64) {                     // dense rows of any length up to 64 (the rgbnet's first layer: K = C + 3 + 6 pe)
+      if (K <= 16) UG_LINB_DENSE(1)
+      if (K <= 32) UG_LINB_DENSE(2)
+      if (K <= 48) UG_LINB_DENSE(3)
+      UG_LINB_DENSE(4)
+    }
+    // (other shapes -- unaligned rows longer than 64, strided rows -- take the fp32-MFMA kernels below)
 #undef UG_LINB_GO
-    UG_LAUNCH_CHECK();
-    return 0;
+#undef UG_LINB_DENSE
   }
   if (nt == 4) {
     if (kh <= 12) UG_LIN_GO(12, 4, false)
