@@ -167,31 +167,67 @@ __device__ __forceinline__ void ug_grid_query_one(int64_t tid, const float *__re
   const int64_t vol = (int64_t)X * Y * Z;
   if (CL) {
     const int ch = (int)(tid - p * C);
-    float sum = 0.f;
-    for (int l = 0; l < P; ++l) {
-      float cx, cy, cz;
-      ug_level_coords(l, ux, uy, uz, cx, cy, cz);
+    auto level = [&](int l, float cx, float cy, float cz) -> float {
       const ug_taps t = ug_tap_setup_ld(X, Y, Z, cx, cy, cz);
       const float *__restrict__ g = grid + (int64_t)l * vol * C + ch;
       float acc = 0.f;
 #pragma unroll
       for (int c = 0; c < 8; ++c) acc += g[t.off[c] * C] * t.w[c];
-      sum = (l == 0) ? acc : sum + acc;
+      return acc;
+    };
+    // level 0, then the sin and the cos level of every frequency TOGETHER: one sin / cos evaluation serves both (ug_level_coords formed it
+    // once per level) and their 16 corner loads are in flight at once; the level sums are added in level order as before: bit-identical
+    float sum = level(0, ux, uy, uz);
+    for (int k = 0; 2 * k + 2 < P; ++k) {
+      const float f = (float)(1 << k);
+      float sx, kx, sy, ky, sz, kz;
+      ug_sincos(f * ux, &sx, &kx);
+      ug_sincos(f * uy, &sy, &ky);
+      ug_sincos(f * uz, &sz, &kz);
+      const ug_taps ts = ug_tap_setup_ld(X, Y, Z, sx, sy, sz), tc = ug_tap_setup_ld(X, Y, Z, kx, ky, kz);
+      const float *__restrict__ gs = grid + (int64_t)(2 * k + 1) * vol * C + ch, *__restrict__ gc = grid + (int64_t)(2 * k + 2) * vol * C + ch;
+      float vs[8], vc[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) vs[c] = gs[ts.off[c] * C];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) vc[c] = gc[tc.off[c] * C];
+      float as = 0.f, ac = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) as += vs[c] * ts.w[c];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ac += vc[c] * tc.w[c];
+      sum = sum + as;
+      sum = sum + ac;
     }
     out[tid] = (F > 0) ? sum / (float)P : sum;
     return;
   }
   float *__restrict__ row = out + p * C;
-  for (int l = 0; l < P; ++l) {
-    float cx, cy, cz;
-    ug_level_coords(l, ux, uy, uz, cx, cy, cz);
-    const ug_taps t = ug_tap_setup_ld(X, Y, Z, cx, cy, cz);
+  {
+    const ug_taps t = ug_tap_setup_ld(X, Y, Z, ux, uy, uz);
     for (int ch = 0; ch < C; ++ch) {
-      const float *__restrict__ g = grid + ((int64_t)l * C + ch) * vol;
+      const float *__restrict__ g = grid + (int64_t)ch * vol;
       float acc = 0.f;
 #pragma unroll
       for (int c = 0; c < 8; ++c) acc += g[t.off[c]] * t.w[c];
-      row[ch] = (l == 0) ? acc : row[ch] + acc;
+      row[ch] = acc;
+    }
+  }
+  for (int k = 0; 2 * k + 2 < P; ++k) {          // the sin and the cos level of a frequency together (one sin / cos evaluation, 16 loads in flight)
+    const float f = (float)(1 << k);
+    float sx, kx, sy, ky, sz, kz;
+    ug_sincos(f * ux, &sx, &kx);
+    ug_sincos(f * uy, &sy, &ky);
+    ug_sincos(f * uz, &sz, &kz);
+    const ug_taps ts = ug_tap_setup_ld(X, Y, Z, sx, sy, sz), tc = ug_tap_setup_ld(X, Y, Z, kx, ky, kz);
+    for (int ch = 0; ch < C; ++ch) {
+      const float *__restrict__ gs = grid + ((int64_t)(2 * k + 1) * C + ch) * vol, *__restrict__ gc = grid + ((int64_t)(2 * k + 2) * C + ch) * vol;
+      float as = 0.f, ac = 0.f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) as += gs[ts.off[c]] * ts.w[c];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) ac += gc[tc.off[c]] * tc.w[c];
+      row[ch] = (row[ch] + as) + ac;
     }
   }
   if (F > 0)
@@ -387,15 +423,37 @@ k_train_march(ug_train_args a, const float *__restrict__ grid, const float *__re
         px = px / nrm * sc; py = py / nrm * sc; pz = pz / nrm * sc;
       }
       const float ux = ug_unorm(px, lox, hix), uy = ug_unorm(py, loy, hiy), uz = ug_unorm(pz, loz, hiz);
-      for (int l = 0; l < a.P; ++l) {
-        float cx, cy, cz;
-        ug_level_coords(l, ux, uy, uz, cx, cy, cz);
+      auto level = [&](int l, float cx, float cy, float cz) -> float {
         const ug_taps tp = ug_tap_setup_ld(a.X, a.Y, a.Z, cx, cy, cz);
         const float *__restrict__ g = grid + (int64_t)l * vol;
         float acc = 0.f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) acc += g[tp.off[c]] * tp.w[c];
-        dens = (l == 0) ? acc : dens + acc;
+        return acc;
+      };
+      // as k_grid_query: level 0, then the sin and the cos level of a frequency together (one sin / cos evaluation for both, 16 corner
+      // loads in flight), sums added in level order: the densities stay bit-identical to the composed path's
+      dens = level(0, ux, uy, uz);
+      for (int k = 0; 2 * k + 2 < a.P; ++k) {
+        const float f = (float)(1 << k);
+        float sx, kx, sy, ky, sz, kz;
+        ug_sincos(f * ux, &sx, &kx);
+        ug_sincos(f * uy, &sy, &ky);
+        ug_sincos(f * uz, &sz, &kz);
+        const ug_taps ts = ug_tap_setup_ld(a.X, a.Y, a.Z, sx, sy, sz), tc = ug_tap_setup_ld(a.X, a.Y, a.Z, kx, ky, kz);
+        const float *__restrict__ gs = grid + (int64_t)(2 * k + 1) * vol, *__restrict__ gc = grid + (int64_t)(2 * k + 2) * vol;
+        float vs[8], vc[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) vs[c] = gs[ts.off[c]];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) vc[c] = gc[tc.off[c]];
+        float as = 0.f, ac = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) as += vs[c] * ts.w[c];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) ac += vc[c] * tc.w[c];
+        dens = dens + as;
+        dens = dens + ac;
       }
       if (a.F > 0) dens = dens / (float)a.P;
       float e;

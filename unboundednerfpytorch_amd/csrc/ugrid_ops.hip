@@ -406,13 +406,18 @@ __global__ void k_tv(const float *__restrict__ param, float *__restrict__ grad, 
   const int64_t i = idx / sz_k / sz_j % sz_i;
   const int64_t sj = sz_k, si = sz_k * sz_j;
   const float p = param[idx];
+  // unconditional neighbour loads (a missing neighbour re-reads the element itself) with the missing terms switched off by a zero weight:
+  // loads under their own exec branches are waited for one by one (see ug_tv_cl_one below); bit-identical (0 * clamp(p - p) = 0)
+  const float n0 = param[idx - (k == 0 ? 0 : 1)], n1 = param[idx + (k == sz_k - 1 ? 0 : 1)];
+  const float n2 = param[idx - (j == 0 ? 0 : sj)], n3 = param[idx + (j == sz_j - 1 ? 0 : sj)];
+  const float n4 = param[idx - (i == 0 ? 0 : si)], n5 = param[idx + (i == sz_i - 1 ? 0 : si)];
   float g = 0;
-  g += (k == 0 ? 0.f : wz * ug_clamp1(p - param[idx - 1]));
-  g += (k == sz_k - 1 ? 0.f : wz * ug_clamp1(p - param[idx + 1]));
-  g += (j == 0 ? 0.f : wy * ug_clamp1(p - param[idx - sj]));
-  g += (j == sz_j - 1 ? 0.f : wy * ug_clamp1(p - param[idx + sj]));
-  g += (i == 0 ? 0.f : wz * ug_clamp1(p - param[idx - si]));
-  g += (i == sz_i - 1 ? 0.f : wz * ug_clamp1(p - param[idx + si]));
+  g += (k == 0 ? 0.f : wz) * ug_clamp1(p - n0);
+  g += (k == sz_k - 1 ? 0.f : wz) * ug_clamp1(p - n1);
+  g += (j == 0 ? 0.f : wy) * ug_clamp1(p - n2);
+  g += (j == sz_j - 1 ? 0.f : wy) * ug_clamp1(p - n3);
+  g += (i == 0 ? 0.f : wz) * ug_clamp1(p - n4);
+  g += (i == sz_i - 1 ? 0.f : wz) * ug_clamp1(p - n5);
   grad[idx] = g0 + g;
 }
 
