@@ -423,6 +423,29 @@ k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__
   mlp_b3_stage_weights<KS, UG_LINB_THREADS>(img, W, ldw, K, n_out, w_in_major);
   __syncthreads();
   const mlp_bf16x8 *__restrict__ wl = img + h * 128 + col;
+  // The k-step loop is software-pipelined by hand (an in-order wave only overlaps what is issued BEHIND an MFMA that occupies the pipe):
+  //   * the weight parts live in three register sets that are reloaded IN PLACE right after their last use, for the next k-step
+  //     (circularly: after the tile's last k-step comes k-step 0 of the next tile -- the same weights);
+  //   * the next k-step's inputs go through the staging tile (write, wave sync, transposed read) and are split into their bf16 parts
+  //     between this k-step's MFMA groups.
+  // Same products in the same order per accumulator as mlp_b3_kstep: the results do not change.
+  auto wpart = [&](int ks, int part, mlp_bf16x8 (&w)[4]) {
+    const mlp_bf16x8 *wp = wl + ((ks % KS) * 3 + part) * 2 * 128;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) w[t] = wp[32 * t];
+  };
+  auto stage_write = [&](int ks, const f8 &xv) {
+    float *buf = xt + (ks & 1) * (32 * 20);
+    *(float4 *)(buf + (lane >> 2) * 20 + 4 * (lane & 3)) = make_float4(xv.v[0], xv.v[1], xv.v[2], xv.v[3]);
+    *(float4 *)(buf + (16 + (lane >> 2)) * 20 + 4 * (lane & 3)) = make_float4(xv.v[4], xv.v[5], xv.v[6], xv.v[7]);
+  };
+  auto stage_read = [&](int ks, float (&own)[8]) {
+    const float *buf = xt + (ks & 1) * (32 * 20) + col * 20 + 8 * h;
+    const float4 a = *(const float4 *)buf, b = *(const float4 *)(buf + 4);
+    own[0] = a.x; own[1] = a.y; own[2] = a.z; own[3] = a.w; own[4] = b.x; own[5] = b.y; own[6] = b.z; own[7] = b.w;
+  };
+  mlp_bf16x8 wh[4], wm[4], wlo[4];                 // parts 0, 1, 2 of the current k-step
+  wpart(0, 1, wm); wpart(0, 2, wlo); wpart(0, 0, wh);
   for (; tile < n_tiles; ) {
     const int64_t s = tile * 32 + col;
     mlp_f32x16 acc[4];
@@ -430,19 +453,54 @@ k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__
     for (int t = 0; t < 4; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const f8 xv = xq[ks % AHEAD];
-      if (ks + AHEAD < KS) xq[ks % AHEAD] = load8(rc, ks + AHEAD);
-      // coalesced pieces -> staging tile -> the lane's own 8 inputs
-      float *buf = xt + (ks & 1) * (32 * 20);
-      *(float4 *)(buf + (lane >> 2) * 20 + 4 * (lane & 3)) = make_float4(xv.v[0], xv.v[1], xv.v[2], xv.v[3]);
-      *(float4 *)(buf + (16 + (lane >> 2)) * 20 + 4 * (lane & 3)) = make_float4(xv.v[4], xv.v[5], xv.v[6], xv.v[7]);
+    // k-step 0's inputs: through the staging tile, not overlapped (once per tile)
+    mlp_split3 xs;
+    {
+      stage_write(0, xq[0]);
+      if (AHEAD < KS) xq[0] = load8(rc, AHEAD);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
-      const float4 a = *(const float4 *)(buf + col * 20 + 8 * h), b = *(const float4 *)(buf + col * 20 + 8 * h + 4);
-      const float own[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-      mlp_b3_kstep(acc, wl, ks, own);
+      float own[8];
+      stage_read(0, own);
+      xs = mlp_split8(own);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const bool more = ks + 1 < KS;
+      float own_n[8];
+      mlp_split3 xn;
+      if (more) {                                  // the next k-step's coalesced pieces -> staging tile (no wait yet)
+        stage_write(ks + 1, xq[(ks + 1) % AHEAD]);
+        if (ks + 1 + AHEAD < KS) xq[(ks + 1) % AHEAD] = load8(rc, ks + 1 + AHEAD);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wm[t], xs.m); }
+      if (more) {                                  // the writes have landed behind four MFMAs: transposed read of the wave's own rows
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        stage_read(ks + 1, own_n);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wlo[t], xs.h); }
+      wpart(ks + 1, 2, wlo);                       // part l: last use was the group above
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wh[t], xs.l); }
+      if (more) xn = mlp_split8(own_n);            // (VALU behind the MFMAs)
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wm[t], xs.h); }
+      wpart(ks + 1, 1, wm);                        // part m: last use was the group above
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wh[t], xs.m); }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { MLP_MFMA_BF16(acc[t], wh[t], xs.h); }
+      wpart(ks + 1, 0, wh);                        // part h
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) xs = xn;
     }
     tile += (int64_t)gridDim.x * WAVES;
     rc = ctx_of(tile);
