@@ -274,7 +274,8 @@ def test_product_kernels_fit_their_register_budget_without_scratch(lib_path):
         assert ks, prefix
         return ks
     budget = {"_Z7k_marchILi": 80, "_Z11k_shade_mlpILi": 256, "_Z10k_shade_pcILi": 256, "_Z17k_train_march_voxILi": 128, "_Z14k_shade_direct": 128, "_Z13k_train_march": 128,
-              "_Z15k_train_compact": 64, "_Z12k_grid_queryILb": 64, "_Z21k_grid_query_backwardILb": 64, "_Z12k_tv_cl_vec4ILb": 64, "_Z12k_tv_cl_slabILi": 64, "_Z12k_adam_multiILi": 32,
+              "_Z15k_train_compact": 64, "_Z12k_grid_queryILb": 128,      # (round 6: the sin and cos level of a frequency gathered together, 16 loads in flight: 78 / 124)
+                  "_Z8k_lin_b3ILi": 256, "_Z14k_lin_b3_denseILi": 256, "_Z10k_wgrad_b3ILi": 256, "_Z21k_grid_query_backwardILb": 64, "_Z12k_tv_cl_vec4ILb": 64, "_Z12k_tv_cl_slabILi": 64, "_Z12k_adam_multiILi": 32,
               "_Z14k_tv_adam_vec4ILb": 64, "_Z9k_tv_vec4ILb": 64, "_Z11k_adam_vec4ILi": 64, "_Z17k_render_loss_fwd": 64,
               "_Z17k_render_loss_bwd": 64, "_Z14k_alpha2weight": 64, "_Z18k_alpha2weight_bwd": 64, "_Z16k_rays_of_a_view": 64,
               "_Z11k_pack_quad": 128, "_Z5k_linILi": 128, "_Z7k_wgradILi": 256, "_Z16k_train_compact2": 64, "_Z18k_train_sample_bwd": 64,

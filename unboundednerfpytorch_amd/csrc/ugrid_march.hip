@@ -219,15 +219,16 @@ __device__ __forceinline__ void ug_grid_query_one(int64_t tid, const float *__re
     ug_sincos(f * ux, &sx, &kx);
     ug_sincos(f * uy, &sy, &ky);
     ug_sincos(f * uz, &sz, &kz);
-    const ug_taps ts = ug_tap_setup_ld(X, Y, Z, sx, sy, sz), tc = ug_tap_setup_ld(X, Y, Z, kx, ky, kz);
-    for (int ch = 0; ch < C; ++ch) {
-      const float *__restrict__ gs = grid + ((int64_t)(2 * k + 1) * C + ch) * vol, *__restrict__ gc = grid + ((int64_t)(2 * k + 2) * C + ch) * vol;
-      float as = 0.f, ac = 0.f;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) as += gs[ts.off[c]] * ts.w[c];
+    for (int half = 0; half < 2; ++half) {          // the sin level, then the cos level (one sin / cos evaluation serves both)
+      const ug_taps t = half == 0 ? ug_tap_setup_ld(X, Y, Z, sx, sy, sz) : ug_tap_setup_ld(X, Y, Z, kx, ky, kz);
+      for (int ch = 0; ch < C; ++ch) {
+        const float *__restrict__ g = grid + ((int64_t)(2 * k + 1 + half) * C + ch) * vol;
+        float acc = 0.f;
 #pragma unroll
-      for (int c = 0; c < 8; ++c) ac += gc[tc.off[c]] * tc.w[c];
-      row[ch] = (row[ch] + as) + ac;
+        for (int c = 0; c < 8; ++c) acc += g[t.off[c]] * t.w[c];
+        row[ch] = row[ch] + acc;
+      }
     }
   }
   if (F > 0)

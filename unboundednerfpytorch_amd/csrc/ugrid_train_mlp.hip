@@ -376,7 +376,7 @@ __device__ __forceinline__ void mlp_b3_store(const mlp_f32x16 (&acc)[4], int64_t
 //   k_lin_b3<KS>        K = 16 KS, 16-byte aligned rows: a k-step's 32 x 64 bytes are fetched by two coalesced dwordx4 per lane (four
 //                       lanes per 64-byte piece), four k-steps ahead, written to the wave's staging tile (rows padded to 80 bytes: the
 //                       transposed reads are conflict-free) and read back in operand order;
-//   k_lin_b3_dense<KS>  any K <= 16 KS <= 64 with ldx == K: the tile's 32 rows are ONE contiguous run of 32 K floats, fetched whole by
+//   k_lin_b3_dense<KS>  any K <= 16 KS <= 48 with ldx == K: the tile's 32 rows are ONE contiguous run of 32 K floats, fetched whole by
 //                       coalesced dword loads (the next tile's before this tile's MFMAs), rows padded to 16 KS + 1 floats in LDS.
 // Every load is unconditional on a clamped address -- rows past the end repeat the last row and feed output columns that are never
 // stored: with loads under exec branches hipcc cannot count them and waits vmcnt(0) right behind the look-ahead it has just issued.
@@ -412,7 +412,7 @@ k_lin_b3(const float *__restrict__ X, int64_t M, int K, int ldx, const float *__
     r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w; r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
     return r;
   };
-  constexpr int AHEAD = KS < 4 ? KS : 4;           // k-steps in flight
+  constexpr int AHEAD = KS < 2 ? KS : 2;           // k-steps of rows in flight
   // the first tile's rows are requested BEFORE the weights are staged (an HBM round trip beside the 96 KB of split + LDS writes),
   // every later tile's before the previous tile's stores
   int64_t tile = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
@@ -524,23 +524,22 @@ k_lin_b3_dense(const float *__restrict__ X, int64_t M, int K, const float *__res
   const int lane = ug_lane(), h = lane >> 5, col = lane & 31;
   const int64_t n_tiles = (M + 31) >> 5;
   constexpr int WAVES = UG_LINB_THREADS / 64;
-  float *xt = lds + 2 * KS * 128 * 3 * 4 + (threadIdx.x >> 6) * (32 * RP);
+  float *xt = lds + 2 * KS * 128 * 3 * 4 + (threadIdx.x >> 6) * (32 * RP + 4);     // (+ a dump slot for the elements past row 31)
   // where element lane + 64 j of a tile's contiguous run lands in the staging tile (the same for every tile)
   int off[NL];
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
     const int i = lane + 64 * j, row = i / K;
-    off[j] = row < 32 ? row * RP + (i - row * K) : -1;
+    off[j] = row < 32 ? row * RP + (i - row * K) : 32 * RP;      // (past the tile: the dump slot -- unconditional writes, no lane masks to keep)
   }
   for (int i = lane; i < 32 * RP; i += 64) xt[i] = 0.f;      // the pad columns K .. 16 KS - 1 stay zero for the whole kernel
   const int64_t total = M * K;
   auto load_tile = [&](int64_t tile, float (&v)[NL]) {
-    const int64_t base = tile * 32 * K;
+    const int64_t base = tile * 32 * K, left = total - base;            // (tile < n_tiles: left >= 1)
+    const int last = left > (int64_t)(64 * NL) ? 64 * NL - 1 : (int)left - 1;      // 32-bit clamp: no 64-bit compare (= an SGPR pair) per load
+    const float *__restrict__ xb = X + base;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      const int64_t i = base + lane + 64 * j;
-      v[j] = X[i < total ? i : total - 1];
-    }
+    for (int j = 0; j < NL; ++j) v[j] = xb[min(lane + 64 * j, last)];
   };
   int64_t tile = (int64_t)blockIdx.x * WAVES + (threadIdx.x >> 6);
   float cur[NL];
@@ -551,8 +550,7 @@ k_lin_b3_dense(const float *__restrict__ X, int64_t M, int K, const float *__res
   for (; tile < n_tiles; ) {
     const int64_t s = tile * 32 + col;
 #pragma unroll
-    for (int j = 0; j < NL; ++j)
-      if (off[j] >= 0) xt[off[j]] = cur[j];
+    for (int j = 0; j < NL; ++j) xt[off[j]] = cur[j];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     tile += (int64_t)gridDim.x * WAVES;
@@ -769,7 +767,7 @@ static inline int ug_lin_launch(const float *X, int64_t M, int K, int ldx, const
   }
 #define UG_LINB_DENSE(KS_)                                                                                                       \
   {                                                                                                                              \
-    constexpr int lds = KS_ * 2 * 128 * 3 * 16 + (UG_LINB_THREADS / 64) * 32 * (16 * KS_ + 1) * 4;                               \
+    constexpr int lds = KS_ * 2 * 128 * 3 * 16 + (UG_LINB_THREADS / 64) * (32 * (16 * KS_ + 1) + 4) * 4;                         \
     UG_SET_DYN_LDS((k_lin_b3_dense<KS_>), lds);                                                                                  \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_lin_b3_dense<KS_>), dim3((unsigned)wgb), dim3(UG_LINB_THREADS), lds, st, X, M, K, W, ldw, \
                        n_out, w_in_major, bias, relu, G, ldg, Y, ldy, ug_tl_devn.ptr);                                           \
@@ -780,13 +778,11 @@ static inline int ug_lin_launch(const float *X, int64_t M, int K, int ldx, const
     if (al && K == 128) UG_LINB_GO(8)
     if (al && K == 64) UG_LINB_GO(4)
     if (al && K == 32) UG_LINB_GO(2)
-    if (ldx == K && K <= 64) {                     // dense rows of any length up to 64 (the rgbnet's first layer: K = C + 3 + 6 pe)
-      if (K <= 16) UG_LINB_DENSE(1)
+    if (ldx == K && K <= 48) {                     // dense rows of any length up to 48 (the rgbnet's first layer: K = C + 3 + 6 pe = 39)
       if (K <= 32) UG_LINB_DENSE(2)
-      if (K <= 48) UG_LINB_DENSE(3)
-      UG_LINB_DENSE(4)
+      UG_LINB_DENSE(3)
     }
-    // (other shapes -- unaligned rows longer than 64, strided rows -- take the fp32-MFMA kernels below)
+    // (other shapes -- unaligned rows longer than 48, strided rows -- take the fp32-MFMA kernels below)
 #undef UG_LINB_GO
 #undef UG_LINB_DENSE
   }
