@@ -313,7 +313,9 @@ class FrameBench:
         """strong (default): this rank's shard of THE frame; weak: a whole frame of its own camera.  With a stream pair (--frame-pair) the
         whole step -- ray generation, march, shade, exchange -- is issued on stream k & 1 with work list k & 1: two frames are in flight,
         nothing of frame k + 1 waits for frame k except the exchange's own hand-over (the frames of a view list are independent)."""
-        if self.pair is None:
+        if self.pair is None or weak:      # (a weak-scaled step is a WHOLE frame of the rank's own: it fills the chip by itself, like N = 1)
+            if self.pair is not None:
+                self.rend.use_workspace_slot(0)
             return self._step(timing, weak)
         k = self.n_step & 1
         self.n_step += 1

@@ -608,22 +608,39 @@ k_adam_vec4(float4 *__restrict__ param, const float4 *__restrict__ grad, float4 
     ug_adam_vec4_one<MODE, RZ>(param, grad, exp_avg, exp_avg_sq, perlr, i, step_size, beta1, beta2, eps);
 }
 
-// Walk over the touched-line bitmap of a recycled gradient (k_grid_query_backward): one wave per 32-bit word = 32 lines of
-// 256 bytes; the word's set bits are dealt to the wave's four 16-lane quarters, so a word with <= 4 marked lines (the usual
-// case at a few per cent of lines marked) costs one round.  `q` handed to the body is the float4 index of the lane.
-#define UG_TOUCH_WALK(touch, n_words, n4, BODY)                                                                        \
+// Walk over the touched-line bitmap of a recycled gradient (k_grid_query_backward).  One wave owns 64 consecutive 32-bit words
+// (= 2 048 lines of 256 bytes): every lane fetches one word, a ballot finds the words that hold anything, and the wave visits those in
+// turn -- a word's set bits dealt to the wave's four 16-lane quarters, so a word with <= 4 marked lines costs one round.  `q` handed to
+// the body is the float4 index of the lane.  (Until round 6 a wave owned ONE word: at a few per cent of the lines marked most of the
+// 4e5 waves of S3's k0 grid lived for one load and an exit, and the kernel's time was its wave count times a memory latency.)
+// wpw = words per wave (1..64): ug_touch_wpw keeps >= ~16 k waves in the launch (a small grid must not be walked by a handful of waves)
+static inline int ug_touch_wpw(int64_t n_words) {
+  int w = 64;
+  while (w > 1 && n_words / w < 16384) w >>= 1;
+  return w;
+}
+#define UG_TOUCH_WALK(touch, n_words, n4, wpw, BODY)                                                                   \
   {                                                                                                                    \
-    const int64_t word = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;                                        \
-    if (word >= (n_words)) return;                                                                                     \
-    const uint32_t mask = __builtin_amdgcn_readfirstlane((touch)[word]);                                               \
-    if (mask == 0u) return;                                                                                            \
-    const int cnt = __popc(mask), quarter = ug_lane() >> 4;                                                            \
-    for (int base = 0; base < cnt; base += 4) {                                                                        \
-      const int k = base + quarter;                                                                                    \
-      uint32_t m = mask;                                                                                               \
-      for (int i = 0; i < k; ++i) m &= m - 1u;                                                                         \
-      const int64_t q = ((word << 5) + (int64_t)(__ffs(m) - 1)) * 16 + (ug_lane() & 15);                               \
-      if (k < cnt && q < (int64_t)(n4)) { BODY }                                                                       \
+    const int64_t w0 = (((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6) * (wpw);                                \
+    if (w0 >= (n_words)) return;                                                                                       \
+    const int64_t wi = w0 + ug_lane();                                                                                 \
+    const bool have = ug_lane() < (wpw) && wi < (n_words);                                                             \
+    const uint32_t mine = (touch)[have ? wi : w0] * (have ? 1u : 0u);                                                  \
+    unsigned long long nz = __ballot(mine != 0u);                                                                      \
+    const int quarter = ug_lane() >> 4;                                                                                \
+    while (nz != 0ull) {                                                                                               \
+      const int src = __builtin_ctzll(nz);                                                                             \
+      nz &= nz - 1ull;                                                                                                 \
+      const uint32_t mask = (uint32_t)__builtin_amdgcn_readlane((int)mine, src);                                       \
+      const int64_t word = w0 + src;                                                                                   \
+      const int cnt = __popc(mask);                                                                                    \
+      for (int base = 0; base < cnt; base += 4) {                                                                      \
+        const int k = base + quarter;                                                                                  \
+        uint32_t m = mask;                                                                                             \
+        for (int i = 0; i < k; ++i) m &= m - 1u;                                                                       \
+        const int64_t q = ((word << 5) + (int64_t)(__ffs(m) - 1)) * 16 + (ug_lane() & 15);                             \
+        if (k < cnt && q < (int64_t)(n4)) { BODY }                                                                     \
+      }                                                                                                                \
     }                                                                                                                  \
   }
 
@@ -631,8 +648,8 @@ k_adam_vec4(float4 *__restrict__ param, const float4 *__restrict__ grad, float4 
 __global__ void __launch_bounds__(256)
 k_adam_vec4_touch(float4 *__restrict__ param, const float4 *__restrict__ grad, float4 *__restrict__ exp_avg,
                   float4 *__restrict__ exp_avg_sq, int64_t n4, float step_size, float beta1, float beta2, float eps,
-                  const uint32_t *__restrict__ touch, int64_t n_words) {
-  UG_TOUCH_WALK(touch, n_words, n4, (ug_adam_vec4_one<1, true>(param, grad, exp_avg, exp_avg_sq, nullptr, q, step_size, beta1, beta2, eps));)
+                  const uint32_t *__restrict__ touch, int64_t n_words, int wpw) {
+  UG_TOUCH_WALK(touch, n_words, n4, wpw, (ug_adam_vec4_one<1, true>(param, grad, exp_avg, exp_avg_sq, nullptr, q, step_size, beta1, beta2, eps));)
 }
 
 template <int MODE, bool RZ = false>
@@ -895,8 +912,8 @@ k_tv_cl_slab(const float *__restrict__ param, float *__restrict__ param_out, flo
 // masked TV gradient on the marked lines of a recycled gradient (UG_TOUCH_WALK)
 __global__ void __launch_bounds__(256)
 k_tv_cl_touch(const float *__restrict__ param, float *__restrict__ grad, float wy, float wz, int sz_i, int sz_j, int sz_k, int C,
-              unsigned n4, const uint32_t *__restrict__ touch, int64_t n_words) {
-  UG_TOUCH_WALK(touch, n_words, n4, (ug_tv_cl_one<false, 0, 0>(param, nullptr, grad, nullptr, nullptr, wy, wz, sz_i, sz_j, sz_k, C,
+              unsigned n4, const uint32_t *__restrict__ touch, int64_t n_words, int wpw) {
+  UG_TOUCH_WALK(touch, n_words, n4, wpw, (ug_tv_cl_one<false, 0, 0>(param, nullptr, grad, nullptr, nullptr, wy, wz, sz_i, sz_j, sz_k, C,
                                                                (unsigned)q, 0.f, 0.f, 0.f, 0.f, 0, true));)
 }
 
@@ -1134,8 +1151,9 @@ static int ug_tv_cl(const float *param, float *grad, float wx, float wy, float w
                        nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f, 0, (const uint32_t *)nullptr);
   else if (touch) {
     const int64_t n_words = ugrid_touch_words(N);
-    hipLaunchKernelGGL(k_tv_cl_touch, dim3(ug_blocks(n_words * UG_WAVE, 256)), dim3(256), 0, ST(s), param, grad, wy, wz, (int)sz_i,
-                       (int)sz_j, (int)sz_k, (int)C, n4, touch, n_words);
+    const int wpw = ug_touch_wpw(n_words);
+    hipLaunchKernelGGL(k_tv_cl_touch, dim3(ug_blocks((n_words + wpw - 1) / wpw * UG_WAVE, 256)), dim3(256), 0, ST(s), param, grad, wy, wz, (int)sz_i,
+                       (int)sz_j, (int)sz_k, (int)C, n4, touch, n_words, wpw);
   } else
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_tv_cl_vec4<false, 0>), dim3((n4 + 255) / 256), dim3(256), 0, ST(s), param, nullptr, grad,
                        nullptr, nullptr, wy, wz, (int)sz_i, (int)sz_j, (int)sz_k, (int)C, n4, 0.f, 0.f, 0.f, 0.f, 0, (const uint32_t *)nullptr);
@@ -1274,9 +1292,10 @@ extern "C" int ugrid_masked_adam_upd_touch(float *param, float *grad, float *exp
   const uintptr_t al = (uintptr_t)param | (uintptr_t)grad | (uintptr_t)exp_avg | (uintptr_t)exp_avg_sq;
   if ((al & 15) != 0) return (int)hipErrorNotSupported;
   const int64_t n4 = N / 4, n_words = ugrid_touch_words(N);
+  const int wpw = ug_touch_wpw(n_words);
   if (n4 > 0)
-    hipLaunchKernelGGL(k_adam_vec4_touch, dim3(ug_blocks(n_words * UG_WAVE, 256)), dim3(256), 0, ST(s), (float4 *)param,
-                       (const float4 *)grad, (float4 *)exp_avg, (float4 *)exp_avg_sq, n4, step_size, beta1, beta2, eps, touch, n_words);
+    hipLaunchKernelGGL(k_adam_vec4_touch, dim3(ug_blocks((n_words + wpw - 1) / wpw * UG_WAVE, 256)), dim3(256), 0, ST(s), (float4 *)param,
+                       (const float4 *)grad, (float4 *)exp_avg, (float4 *)exp_avg_sq, n4, step_size, beta1, beta2, eps, touch, n_words, wpw);
   if (n4 * 4 < N)      // the last 1-3 elements, whatever their line says
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_adam_scalar<1, true>), dim3(1), dim3(256), 0, ST(s), param, grad, exp_avg, exp_avg_sq,
                        (const float *)nullptr, n4 * 4, N, step_size, beta1, beta2, eps);
