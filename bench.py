@@ -74,7 +74,8 @@ def parse():
     ap.add_argument("--pipeline", type=int, default=0, help="ray chunks software-pipelined over two streams (0 = off)")
     ap.add_argument("--frame-pair", type=int, default=-1, help="consecutive frames alternate between two streams, each with a work list of its own: "
                     "the march of frame k+1 runs beside the shade of frame k (a 1/N share alone fills 0.66 of a wave per slot and stages 93 KB "
-                    "of weights per shade launch).  -1 = on for --gpus N > 1, off for 1 GPU (a whole frame fills the chip; measured no gain)")
+                    "of weights per shade launch; whole frames: 8.75 -> 8.40 ms on S1, 13.98 -> 12.68 ms on the truck shape, frames bit-identical, "
+                    "profiles/r06/frame_pair_n1.txt).  -1 / 1 = on (the per-kernel durations then come from a second, one-stream timed region), 0 = one stream")
     ap.add_argument("--tune", action="append", default=[], help="key=value speed knob (ugrid_tune), repeatable")
     ap.add_argument("--shuffle-rays", action="store_true", help="render the frame's rays in a random order (incoherent 64-ray tiles, "
                     "like a training batch): shows what the kernels owe to neighbouring pixels sharing cells")
@@ -270,8 +271,9 @@ class FrameBench:
         self.inflight = {"work": None, "n": 0, "tile": None}
         fp = int(getattr(args, "frame_pair", -1))
         self.pair = None
-        if (fp == 1 or (fp < 0 and world > 1)) and device.type == "cuda" and hasattr(self.rend, "use_workspace_slot"):
+        if fp != 0 and device.type == "cuda" and hasattr(self.rend, "use_workspace_slot"):      # (default: on; --frame-pair 0 = one stream)
             self.pair = [torch.cuda.Stream(device), torch.cuda.Stream(device)]      # frames alternate between them (step)
+        self.single_stream = False      # timed(single_stream=True): the pair switched off for one timed region
         self.n_step = 0
         self.last_out = None
         self.frame = None
@@ -313,7 +315,8 @@ class FrameBench:
         """strong (default): this rank's shard of THE frame; weak: a whole frame of its own camera.  With a stream pair (--frame-pair) the
         whole step -- ray generation, march, shade, exchange -- is issued on stream k & 1 with work list k & 1: two frames are in flight,
         nothing of frame k + 1 waits for frame k except the exchange's own hand-over (the frames of a view list are independent)."""
-        if self.pair is None or weak:      # (a weak-scaled step is a WHOLE frame of the rank's own: it fills the chip by itself, like N = 1)
+        if self.pair is None or self.single_stream or (weak and os.environ.get("UGRID_BENCH_SHARE_GPU") == "1"):
+            # (ranks SHARING one GPU -- debugging runs -- keep one work list for their whole weak-scaled frame: N x 2 x 8.4 GB do not fit)
             if self.pair is not None:
                 self.rend.use_workspace_slot(0)
             return self._step(timing, weak)
@@ -374,7 +377,18 @@ class FrameBench:
         inside the timed step by _assemble()."""
         return self.frame
 
-    def timed(self, steps, warmup, weak=False):
+    def timed(self, steps, warmup, weak=False, single_stream=False):
+        """K steps between two barriers.  single_stream: the same K steps issued on ONE stream with ONE work list (each kernel has the
+        chip to itself: what the per-kernel HIP-event durations and the roofline are quoted on when the frames of the headline region
+        overlap on the stream pair)."""
+        self.barrier()
+        self.single_stream = bool(single_stream)
+        try:
+            return self._timed(steps, warmup, weak)
+        finally:
+            self.single_stream = False
+
+    def _timed(self, steps, warmup, weak):
         for _ in range(warmup):
             self.step(weak=weak)
         self.barrier()
@@ -412,6 +426,17 @@ class FrameBench:
             M += self.rend.survivors_of_last_chunk()
         out = {k: torch.cat([o[k] for o in outs]) for k in ("rgb_marched", "depth", "alphainv_last")}
         return (ro, rd, vd), out, M
+
+
+def timed_with_kernels(fb, steps, warmup):
+    """(seconds of the K-step region, per-kernel ms, seconds of the one-stream region or None): the throughput region as configured
+    (two frames in flight by default) and, when that overlaps launches, a second region of the same K steps on one stream for the
+    per-kernel HIP-event durations."""
+    dt, timing = fb.timed(steps, warmup)
+    dt1 = None
+    if fb.pair is not None:
+        dt1, timing = fb.timed(steps, 1, single_stream=True)
+    return dt, kernel_ms(timing, steps), dt1
 
 
 def kernel_ms(timing, steps):
@@ -641,7 +666,7 @@ def s3_train_step_block(device):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
-def scaling_proxy(args, rend, device, t1_ms, steps=6):
+def scaling_proxy(args, rend, device, t1_ms, steps=6, t1_pair_ms=None):
     """What a 1-GPU box can say about N > 1: rank r's share of an N-way deal of THE frame rendered ALONE on this
     device -- same kernels, same rays, same bricks as rank r of an N-GPU run (the tile exchange, 5.2 MB per rank at N = 8, is the only
     thing missing) -- for every rank of N = 2, 4, 8 and three deals: single 64-ray tiles round-robin, block ROWS of the image
@@ -652,7 +677,8 @@ def scaling_proxy(args, rend, device, t1_ms, steps=6):
     not idle.)  The slowest share is the frame time an N-GPU run cannot beat; t(1 GPU) / (N x slowest share) is the efficiency it
     predicts.  Per-share HBM bytes come from a PMC pass (tools/gpu_rank_share.sh -> profiles/r05/rank_share_pmc.jsonl)."""
     try:
-        out = {"t1_ms": t1_ms, "note": "share r of an N-way deal rendered alone on this GPU (no exchange); GPU time per step between HIP events, "
+        t1p = t1_pair_ms or t1_ms        # (a frame-pair share is compared with the frame-pair whole frame, a one-stream share with the one-stream frame)
+        out = {"t1_ms": t1_ms, "t1_frame_pair_ms": t1_pair_ms, "note": "share r of an N-way deal rendered alone on this GPU (no exchange); GPU time per step between HIP events, "
                                        "median of %d back-to-back steps; predicted_efficiency = t1 / (N * slowest share)" % steps}
         W = args.width
         deals = (("tiles_round_robin", dict(contiguous=False, deal="tiles", deal_group=0)),
@@ -710,8 +736,8 @@ def scaling_proxy(args, rend, device, t1_ms, steps=6):
                              "imbalance_max_over_mean": max(ms) / (sum(ms) / N)}
                 if len(ms_pair) == N:
                     row[name].update({"frame_pair_share_ms": [round(x, 4) for x in ms_pair], "frame_pair_slowest_share_ms": max(ms_pair),
-                                      "frame_pair_predicted_speedup": t1_ms / max(ms_pair),
-                                      "frame_pair_predicted_efficiency": t1_ms / (N * max(ms_pair))})
+                                      "frame_pair_predicted_speedup": t1p / max(ms_pair),
+                                      "frame_pair_predicted_efficiency": t1p / (N * max(ms_pair))})
             out["N=%d" % N] = row
         return out
     except Exception as e:          # noqa: BLE001
@@ -737,8 +763,7 @@ def truck_render_block(args, device, want_cpu):
         del state
         torch.cuda.empty_cache()
         steps = max(4, args.steps // 2)
-        dt, timing = fb.timed(steps, 1)
-        kern = kernel_ms(timing, steps)
+        dt, kern, dt1 = timed_with_kernels(fb, steps, 1)
         rays, out, M = fb.full_frame()
         R, S, P = fb.R, fb.S, 1 + 2 * F
         t = dt / steps
@@ -746,9 +771,9 @@ def truck_render_block(args, device, want_cpu):
         res = {"workload": "truck_single.py-shaped render: F = 4 (P = 9), G = %d^3, C = 12, rgbnet 39-128-128-3, stepsize 0.5 -> S = %d, thres 1e-4, "
                            "%dx%d rays, trained-like synthetic fields (make_state_surfaces)" % (G, S, fb.W, fb.H),
                "value": R * S / t / 1e6, "unit": "Msamples/s", "ms_per_step": t * 1e3, "steps": steps, "rays_per_sec": R / t,
+               "frames_in_flight": 2 if fb.pair is not None else 1, "ms_per_step_single_stream": (dt1 / steps * 1e3) if dt1 else None,
                "samples_per_ray": S, "survivors_M": M, "survivor_frac": M / float(R * S),
                "terminated_ray_frac": float((out["alphainv_last"] < 1e-3).float().mean()),
-               "chunks_per_frame": len(timing) // steps,
                "kernels": {k: {"ms": v, "algorithmic_bytes": alg.get(k), "algorithmic_GBps": (alg[k] / (v * 1e-3) / 1e9) if k in alg and v > 0 else None}
                            for k, v in kern.items()},
                "shade_kernel": "k_shade_pc<4,4,6,2,3,1,true> (12 waves: 6 gather + 6 rgbnet; F >= 4 enters the 12-wave geometry through the rolling cell set-up)"}
@@ -882,6 +907,12 @@ def main():
 
     dt, timing = fb.timed(args.steps, args.warmup)
     fb.check_exchange()
+    # with two frames in flight (the stream pair, default) the march of frame k + 1 runs beside the shade of frame k: the HIP-event duration
+    # of a launch then includes its neighbour's work.  The per-kernel durations (`kernels`, `roofline`) come from a SECOND timed region of the
+    # same K steps on one stream, every launch alone on the chip -- the regime `rocprofv3 --stats` of `bench.py --frame-pair 0` reproduces.
+    dt_single = None
+    if fb.pair is not None:
+        dt_single, timing = fb.timed(args.steps, 1, single_stream=True)
     kern = kernel_ms(timing, args.steps)
     n_chunks = len(timing) // max(1, args.steps)
     rays_this_rank = sum(n for _, n in timing) // max(1, args.steps)
@@ -902,7 +933,7 @@ def main():
                 "note": "every rank renders its own full frame (own camera); no exchange"}
     proxy = None
     if world == 1 and not use_dist and not standin and not args.no_proxy and args.height % 8 == 0 and args.width % 8 == 0:
-        proxy = scaling_proxy(args, fb.rend, device, dt / args.steps * 1e3)
+        proxy = scaling_proxy(args, fb.rend, device, (dt_single or dt) / args.steps * 1e3, t1_pair_ms=dt / args.steps * 1e3 if dt_single else None)
     # survivor statistics + parity inputs from one extra, untimed full frame on this rank
     rays_full, out_full, M = fb.full_frame()
     R, S = fb.R, fb.S
@@ -941,6 +972,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rays_per_sec": R / (dt / args.steps),
+            "frames_in_flight": 2 if fb.pair is not None else 1,
+            "ms_per_step_single_stream": (dt_single / args.steps * 1e3) if dt_single else None,
             "config": {"workload": "%s %dx%dx%d G%d F%d(P%d) C12 rgbnet 39-128-128-3 f32 stepsize %.3g thres 1e-4 %s"
                                    % (args.scene.upper(), fb.W, fb.H, S, G, args.freq, 1 + 2 * args.freq, fb.stepsize,
                                       {"s1": "white-noise grids", "s1b": "trained-like fields"}[args.scene]),
@@ -949,8 +982,9 @@ def main():
                                         % (args.scene.upper(), fb.W, fb.H, S, G, args.freq, 1 + 2 * args.freq, fb.stepsize, scene_desc[args.scene]),
                        "rays": R, "samples_per_ray": S, "survivors_M": M, "survivor_frac": M / float(R * S),
                        "terminated_ray_frac": term_frac, "chunks_per_frame": n_chunks,
-                       "step": "ray generation + march + shade + %s" % (
-                           "all-gather of the tiles + frame assembly (un-deal, un-tile)" if use_dist else "un-tiling to image order"),
+                       "step": "ray generation + march + shade + %s%s" % (
+                           "all-gather of the tiles + frame assembly (un-deal, un-tile)" if use_dist else "un-tiling to image order",
+                           "; 2 frames in flight" if fb.pair is not None else ""),
                        "ray_order": "shuffled (incoherent tiles)" if args.shuffle_rays else (
                            "%dx%d pixel blocks (one 8x8 block per 64-ray wave), results back in image order" % (args.ray_tile, args.ray_tile)
                            if fb.order is not None else "image order (64-pixel row segments per wave)"),
@@ -973,7 +1007,10 @@ def main():
                 default_s1 = (args.scene == "s1" and args.freq == 3 and not args.stepsize and G == 200 and (fb.H, fb.W) == (1080, 1920)
                               and not args.shuffle_rays and args.ray_tile == 8)
                 res["roofline"] = roofline_block(kern, M_rank, rays_this_rank, S, shade_passes, frame_rays=R, P=1 + 2 * args.freq,
-                                                 ms_per_step=ms_step if world == 1 else None, pmc_workload_ok=default_s1)
+                                                 ms_per_step=((dt_single / args.steps * 1e3) if dt_single else ms_step) if world == 1 else None,
+                                                 pmc_workload_ok=default_s1)
+                if dt_single and isinstance(res["roofline"], dict):
+                    res["roofline"]["region"] = "single_stream"
             else:
                 res["roofline"] = None
         if proxy is not None:
@@ -1004,11 +1041,11 @@ def main():
         del state
         torch.cuda.empty_cache()
         steps2 = max(3, args.steps // 2)
-        dt2, timing2 = fb2.timed(steps2, 1)
-        kern2 = kernel_ms(timing2, steps2)
+        dt2, kern2, dt2s = timed_with_kernels(fb2, steps2, 1)
         rays2, out2, M2 = fb2.full_frame()
         sec = {"workload": "S1b: same model shape, smooth fields with opaque surfaces (make_state_surfaces)",
                "value": fb2.R * fb2.S / (dt2 / steps2) / 1e6, "unit": "Msamples/s", "ms_per_step": dt2 / steps2 * 1e3, "steps": steps2,
+               "ms_per_step_single_stream": (dt2s / steps2 * 1e3) if dt2s else None,
                "survivor_frac": M2 / float(fb2.R * fb2.S), "terminated_ray_frac": float((out2["alphainv_last"] < 1e-3).float().mean()),
                "kernels": {k: {"ms": v} for k, v in kern2.items()}}
         res["secondary"] = sec
@@ -1019,12 +1056,12 @@ def main():
             g_args = argparse.Namespace(**dict(vars(args), stepsize=0.5))
             fb3 = FrameBench(g_args, None, device, 1, 0, None, renderer=fb2.rend)       # same packed bricks
             steps3 = max(4, args.steps // 2)
-            dt3, timing3 = fb3.timed(steps3, 1)
-            kern3 = kernel_ms(timing3, steps3)
+            dt3, kern3, dt3s = timed_with_kernels(fb3, steps3, 1)
             _, out3, M3 = fb3.full_frame()
             res["secondary_garden_single_sampling"] = {
                 "workload": "S1b scene at garden_single.py's sampling: stepsize 0.5 -> S = %d samples per ray, fast_color_thres 1e-4" % fb3.S,
                 "value": fb3.R * fb3.S / (dt3 / steps3) / 1e6, "unit": "Msamples/s", "ms_per_step": dt3 / steps3 * 1e3, "steps": steps3,
+                "ms_per_step_single_stream": (dt3s / steps3 * 1e3) if dt3s else None,
                 "rays_per_sec": fb3.R / (dt3 / steps3), "samples_per_ray": fb3.S, "survivor_frac": M3 / float(fb3.R * fb3.S),
                 "terminated_ray_frac": float((out3["alphainv_last"] < 1e-3).float().mean()),
                 "kernels": {k: {"ms": v} for k, v in kern3.items()}}
@@ -1090,7 +1127,8 @@ def compact_line(res, detail_path=None):
     number (ms per step) per secondary, and where the rest went (`detail`: bench_detail.json + its sha16).  Always < LINE_BUDGET
     bytes (tests/test_host_logic.py::test_bench_line_fits_the_driver)."""
     line = {k: _num(res.get(k), 6) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                                             "scaling", "vs_baseline", "dtype", "data", "rays_per_sec")}
+                                             "scaling", "vs_baseline", "dtype", "data", "rays_per_sec", "frames_in_flight",
+                                             "ms_per_step_single_stream") if k in res}
     cfg = res.get("config") or {}
     line["config"] = {"workload": str(cfg.get("workload", ""))[:119]}
     line["config"].update(_pick(cfg, ("rays", "samples_per_ray", "survivors_M", "survivor_frac", "chunks_per_frame")))
@@ -1103,7 +1141,7 @@ def compact_line(res, detail_path=None):
     rf = res.get("roofline")
     if isinstance(rf, dict):
         line["roofline"] = _pick(rf, ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "ta_busy_measured", "hbm_frac_measured",
-                                      "frac_of_hbm_algorithmic"))
+                                      "frac_of_hbm_algorithmic", "region"))
         pk = rf.get("per_kernel") or {}
         line["roofline"]["per_kernel"] = {k: _pick(v, ("ms", "l1_frac", "hbm_frac", "mfma_frac", "ta_busy_measured", "mfma_pipe_busy", "valu_issue_busy",
                                                        "rocprofv3_avg_ms"), 3) for k, v in pk.items()}
@@ -1137,6 +1175,10 @@ def compact_line(res, detail_path=None):
     put("s1b_render", res.get("secondary"))
     put("s1b_s668_render", res.get("secondary_garden_single_sampling"))
     put("truck_render", res.get("secondary_truck_render"))
+    for name, key in (("s1b_render_1stream", "secondary"), ("truck_render_1stream", "secondary_truck_render")):
+        d = res.get(key)
+        if isinstance(d, dict) and d.get("ms_per_step_single_stream"):
+            sec[name] = _num(d["ms_per_step_single_stream"])
     tr = res.get("secondary_truck_render")
     if isinstance(tr, dict) and isinstance(tr.get("kernels"), dict):
         for k, v in tr["kernels"].items():

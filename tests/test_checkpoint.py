@@ -85,6 +85,10 @@ def test_render_viewpoints_frame_loop(golden_dir):
         assert np.array_equal(rgbs[i], r.cpu().numpy()) and np.array_equal(depths[i][..., 0], d.cpu().numpy())
         assert np.array_equal(bgmaps[i][..., 0], b.cpu().numpy())
     assert not np.array_equal(rgbs[0], rgbs[1])
+    # (the default keeps two views in flight on two streams / two work lists; one stream returns the same bits)
+    one = render_viewpoints(model, poses, [(H, W)] * N, [K] * N, kw, frames_in_flight=1)
+    assert all(np.array_equal(a, b) for a, b in zip(one, (rgbs, depths, bgmaps)))
+    assert getattr(model, "_ws_slot", 0) == 0
     gt = [np.clip(rgbs[i] + 0.01, 0, 1) for i in range(N)]
     out = render_viewpoints(model, poses, [(H, W)] * N, [K] * N, kw, gt_imgs=gt)
     assert len(out) == 4 and all(35.0 < p < 45.0 for p in out[3])     # 0.01 offset -> 40 dB

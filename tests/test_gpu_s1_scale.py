@@ -402,6 +402,32 @@ def test_truck_shape_f4_p9_g200_s668_frame_parity():
     _dump("truck_f4_frame_parity.json", {"rays": int(idx.numel()), "survivors_frame": M, "outputs": res})
 
 
+def test_frame_loop_two_views_in_flight_equals_one_stream_at_1080p():
+    """Row f1 at frame scale (run_render.py:54-66): run_render.render_viewpoints over four 1080p views of the trained-like scene with
+    consecutive views alternating between two streams / two work lists (the default: the march of view k + 1 runs beside the shade of
+    view k) returns, bit for bit, what the one-stream loop returns and what a stand-alone render_view of each pose returns."""
+    import numpy as np
+    import bench
+    from unboundednerfpytorch_amd.fourier_render import FourierGridRenderer
+    from unboundednerfpytorch_amd.run_render import render_viewpoints
+    dev = torch.device("cuda", 0)
+    rend = FourierGridRenderer(bench.make_state_surfaces(G, dev, seed=0), dev)
+    K = np.array([[1600.0, 0, W / 2.0], [0, 1600.0, H / 2.0], [0, 0, 1]])
+    poses = [bench.camera(i, dev).cpu().numpy() for i in range(4)]
+    kw = {"stepsize": 0.5, "inverse_y": False}
+    two = render_viewpoints(rend, poses, [(H, W)] * 4, [K] * 4, kw)
+    one = render_viewpoints(rend, poses, [(H, W)] * 4, [K] * 4, kw, frames_in_flight=1)
+    for a, b in zip(two, one):
+        assert a.shape[:3] == (4, H, W) and np.array_equal(a, b)
+    assert not np.array_equal(two[0][0], two[0][1]) and np.isfinite(two[0]).all()
+    r, d, b = rend.render_view(H, W, K, poses[3], 0.5)
+    assert np.array_equal(two[0][3], r.cpu().numpy()) and np.array_equal(two[1][3][..., 0], d.cpu().numpy())
+    assert np.array_equal(two[2][3][..., 0], b.cpu().numpy())
+    assert float((two[2] < 1e-3).mean()) > 0.2                # (the scene has surfaces: rays end on them)
+    del rend
+    torch.cuda.empty_cache()
+
+
 def test_viewbase_pe8_bf16x3_g100_parity():
     """viewbase_pe = 8 (configs/waymo/waymo_base.py, configs/mega/*.py): the 51-wide view embedding does not fit the fp16x2 kernels'
     LDS budget, ugrid_pack_mlp reports bf16x3 and k_shade_mlp<3,12,8,8,1> renders it -- checked so far on small goldens only.

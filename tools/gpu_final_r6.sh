@@ -20,10 +20,10 @@ bash tools/gpu_pmc.sh $TAG "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE TCC_HIT_sum 
   "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum" > $OUT/pmc_log.txt 2>&1
 tail -4 $OUT/pmc_log.txt
 # 2. kernel trace + stats of the bench command, and of the truck-shaped frame
-( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o s1 -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-proxy > $R/$OUT/prof_bench.log 2>&1 < /dev/null )
+( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o s1 -- python $R/bench.py --steps 5 --warmup 2 --frame-pair 0 --no-cpu-baseline --no-secondary --no-proxy > $R/$OUT/prof_bench.log 2>&1 < /dev/null )
 f=$(find $OUT/prof -name "s1_kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/s1_kernel_stats.csv
 rm -rf $OUT/prof; mkdir -p $OUT/prof
-( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o truck -- python $R/bench.py --scene s1b --freq 4 --stepsize 0.5 --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-proxy > $R/$OUT/prof_truck.log 2>&1 < /dev/null )
+( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o truck -- python $R/bench.py --scene s1b --freq 4 --stepsize 0.5 --steps 5 --warmup 2 --frame-pair 0 --no-cpu-baseline --no-secondary --no-proxy > $R/$OUT/prof_truck.log 2>&1 < /dev/null )
 f=$(find $OUT/prof -name "truck_kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/truck_kernel_stats.csv
 rm -rf $OUT/prof
 head -4 $OUT/s1_kernel_stats.csv | cut -c1-200; grep "k_shade_pc\|k_march" $OUT/truck_kernel_stats.csv | cut -c1-200

@@ -10,7 +10,7 @@ i=0
 for ctrs in "$@"; do
   i=$((i+1))
   ( cd /tmp && timeout 120 rocprofv3 --kernel-trace --pmc $ctrs --output-format csv -d $GRAFT_REPO_ROOT/$OUT/pmc_$i -o p -- \
-      python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary --no-proxy $BENCH_FLAGS > $GRAFT_REPO_ROOT/$OUT/pmc_$i.log 2>&1 )
+      python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --frame-pair 0 --no-cpu-baseline --no-secondary --no-proxy $BENCH_FLAGS > $GRAFT_REPO_ROOT/$OUT/pmc_$i.log 2>&1 )
   f=$(find $OUT/pmc_$i -name "*counter_collection.csv" | head -1)
   if [ -n "$f" ]; then
     # keep the per-dispatch csv small: only our kernels

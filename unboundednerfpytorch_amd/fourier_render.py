@@ -262,6 +262,8 @@ class FourierGridRenderer:
     def _workspace(self, n_rays, S):
         need = _L.ugrid_render_ws_bytes(n_rays, S)
         if self._ws is None or self._ws.numel() < need:
+            if self._ws is not None and self._ws.is_cuda:      # (a work list may have been used on another stream than the one it was allocated on)
+                self._ws.record_stream(torch.cuda.current_stream(self.device))
             self._ws = None
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
@@ -657,6 +659,8 @@ def pixel_tile_order(H, W, device, tile=None):
             p = a.view(H // tile, tile, W // tile, tile).permute(0, 2, 1, 3).reshape(-1).contiguous()
         if len(_TILE_ORDER) > 8:
             _TILE_ORDER.clear()
+        if p.is_cuda and not torch.cuda.is_current_stream_capturing():
+            torch.cuda.current_stream(p.device).synchronize()      # cached for EVERY stream (run_render keeps two views in flight): built once, complete
         _TILE_ORDER[key] = p
     return p
 
