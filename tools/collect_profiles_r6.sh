@@ -13,6 +13,7 @@ cp $T/s1_kernel_stats.csv $P/bench_s1_kernel_stats.csv
 cp $T/truck_kernel_stats.csv $P/bench_truck_kernel_stats.csv
 tail -1 $T/bench_line.json > $P/bench_s1_line.json
 cp $T/bench_detail.json $P/bench_s1_detail.json
+[ -s $T/s1_two_frames_in_flight_kernel_stats.csv ] && cp $T/s1_two_frames_in_flight_kernel_stats.csv $P/bench_s1_two_frames_in_flight_kernel_stats.csv
 for f in bench_2rank_shared_gpu.json bench_8rank_shared_gpu.json train_steps.jsonl tv_adam_dense.jsonl pytest_gpu.log smoke.log device_code_sha16.txt; do
   [ -s $T/$f ] && cp $T/$f $P/$f
 done

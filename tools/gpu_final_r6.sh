@@ -25,6 +25,10 @@ f=$(find $OUT/prof -name "s1_kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f
 rm -rf $OUT/prof; mkdir -p $OUT/prof
 ( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o truck -- python $R/bench.py --scene s1b --freq 4 --stepsize 0.5 --steps 5 --warmup 2 --frame-pair 0 --no-cpu-baseline --no-secondary --no-proxy > $R/$OUT/prof_truck.log 2>&1 < /dev/null )
 f=$(find $OUT/prof -name "truck_kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/truck_kernel_stats.csv
+rm -rf $OUT/prof; mkdir -p $OUT/prof
+# (the same command with its default two frames in flight: launches of consecutive frames overlap, durations include the neighbour's work)
+( cd /tmp && timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$OUT/prof -o s1pair -- python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-proxy > $R/$OUT/prof_bench_pair.log 2>&1 < /dev/null )
+f=$(find $OUT/prof -name "s1pair_kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/s1_two_frames_in_flight_kernel_stats.csv
 rm -rf $OUT/prof
 head -4 $OUT/s1_kernel_stats.csv | cut -c1-200; grep "k_shade_pc\|k_march" $OUT/truck_kernel_stats.csv | cut -c1-200
 # 3. the dense TV + Adam pass alone: time, HBM bytes by request counters
