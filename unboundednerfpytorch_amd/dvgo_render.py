@@ -104,17 +104,8 @@ class DirectVoxGORenderer:
                 and w[0].shape[1] == c_in + 3 + 6 * int(s['viewbase_pe'])
                 and bool(_lib.load().ugrid_shade_supported(0, C, int(s['viewbase_pe']))))
 
-    @torch.no_grad()
-    def render_rays(self, rays_o, rays_d, viewdirs, **render_kwargs):
-        """Per-ray outputs of forward() -- rgb_marched, depth, alphainv_last (what the render program consumes,
-        run_render.py:46) -- through the FUSED kernels: the whole chain of dvgo.py:306-425 in two launches.  The reference
-        (and forward()) size the sample list by a count kernel, a cumsum and a HOST READ of the total before the fill
-        (render_utils_kernel.cu:100-260, `.item()` in sample_pts_on_rays); here a lane marches its ray to the ray's own
-        step count, so nothing is read back.  Falls back to forward() for models outside fused_supported().
-        render_kwargs as forward(): near, stepsize, bg, render_depth, plus FourierGridRenderer's ray_order."""
-        if not self.fused_supported():
-            out = self.forward(rays_o, rays_d, viewdirs, **render_kwargs)
-            return {k: out[k] for k in ('rgb_marched', 'depth', 'alphainv_last') if k in out}
+    def _fused_renderer(self):
+        """the fused march + shade renderer over this model's grids (built on first use)"""
         if self._fused is None:
             from .fourier_render import FourierGridRenderer
             s = self.s
@@ -128,10 +119,32 @@ class DirectVoxGORenderer:
                   'dvgo': {'mask': s['mask'], 'xyz2ijk_scale': s['xyz2ijk_scale'], 'xyz2ijk_shift': s['xyz2ijk_shift'],
                            'voxel_size': s['voxel_size']}}
             self._fused = FourierGridRenderer(st, self.device)
+        return self._fused
+
+    def use_workspace_slot(self, k):
+        """Views in flight on two streams take a work list each (run_render.render_viewpoints, FourierGridRenderer.use_workspace_slot);
+        False: this model renders through the composed forward, one stream."""
+        if not self.fused_supported():
+            return False
+        self._fused_renderer().use_workspace_slot(k)
+        return True
+
+    @torch.no_grad()
+    def render_rays(self, rays_o, rays_d, viewdirs, **render_kwargs):
+        """Per-ray outputs of forward() -- rgb_marched, depth, alphainv_last (what the render program consumes,
+        run_render.py:46) -- through the FUSED kernels: the whole chain of dvgo.py:306-425 in two launches.  The reference
+        (and forward()) size the sample list by a count kernel, a cumsum and a HOST READ of the total before the fill
+        (render_utils_kernel.cu:100-260, `.item()` in sample_pts_on_rays); here a lane marches its ray to the ray's own
+        step count, so nothing is read back.  Falls back to forward() for models outside fused_supported().
+        render_kwargs as forward(): near, stepsize, bg, render_depth, plus FourierGridRenderer's ray_order."""
+        if not self.fused_supported():
+            out = self.forward(rays_o, rays_d, viewdirs, **render_kwargs)
+            return {k: out[k] for k in ('rgb_marched', 'depth', 'alphainv_last') if k in out}
+        fused = self._fused_renderer()
         kw = dict(render_kwargs)
         if 'bg' in kw and torch.is_tensor(kw['bg']):
             kw['bg'] = kw['bg'].to(self.device)
-        out = self._fused(rays_o.contiguous(), rays_d.contiguous(), viewdirs.contiguous(), **kw)
+        out = fused(rays_o.contiguous(), rays_d.contiguous(), viewdirs.contiguous(), **kw)
         return {k: out[k] for k in ('rgb_marched', 'depth', 'alphainv_last') if k in out}
 
     def render_view(self, H, W, K, c2w, inverse_y=False, flip_x=False, flip_y=False, **render_kwargs):
