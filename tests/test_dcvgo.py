@@ -138,6 +138,21 @@ def test_dcvgo_render_view_equals_render_rays_on_the_image_rays():
     assert set(img) == {"rgb_marched", "depth", "alphainv_last", "wsum_mid"} and img["rgb_marched"].shape == (H, W, 3)
     for k in img:
         assert torch.equal(img[k].reshape(ref[k].shape), ref[k]), k
+    # the frame loop over a FRESH renderer (its fused renderer is built inside the loop, before the two view streams start): three views,
+    # two in flight, equal bit for bit to the one-stream loop and to render_view
+    import numpy as np
+    from unboundednerfpytorch_amd.run_render import render_viewpoints
+    fresh = DirectContractedVoxGORenderer(state, "cuda:0")
+    c2 = c2w.clone()
+    c2[:, 3] += torch.tensor([0.05, -0.02, 0.04])
+    poses = [c2w.numpy(), c2.numpy(), c2w.numpy()]
+    kw = dict(stepsize=0.5, bg=bg, render_depth=True)
+    two = render_viewpoints(fresh, poses, [[H, W]] * 3, [K] * 3, kw)
+    one = render_viewpoints(fresh, poses, [[H, W]] * 3, [K] * 3, kw, frames_in_flight=1)
+    assert all(np.array_equal(a, b) for a, b in zip(two, one))
+    assert np.array_equal(two[0][0], img["rgb_marched"].cpu().numpy()) and np.array_equal(two[0][2], two[0][0])
+    assert not np.array_equal(two[0][1], two[0][0])
+    assert np.array_equal(two[1][0][..., 0], img["depth"].cpu().numpy())
 
 
 def test_dcvgo_state_from_reference_checkpoint_equals_state_from_params():

@@ -33,10 +33,9 @@ def render_viewpoints(model, render_poses, HW, Ks, render_kwargs, gt_imgs=None, 
     copy_stream = torch.cuda.Stream(dev)
     caller = torch.cuda.current_stream(dev)
     pair = None
-    if frames_in_flight >= 2 and hasattr(model, "use_workspace_slot") and len(render_poses) > 1:
+    if (frames_in_flight >= 2 and hasattr(model, "use_workspace_slot") and len(render_poses) > 1
+            and model.use_workspace_slot(0) is not False):      # (False: a model outside the fused shapes, composed forward, one stream)
         pair = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-        for st in pair:
-            st.wait_stream(caller)            # (whatever prepared the model ran on the caller's stream)
     n = len(render_poses)
     host = [None, None]           # pinned double buffer, re-allocated when the frame size changes
     done = [None, None]
@@ -54,6 +53,8 @@ def render_viewpoints(model, render_poses, HW, Ks, render_kwargs, gt_imgs=None, 
         if pair is not None:
             stream = pair[i & 1]
             model.use_workspace_slot(i & 1)
+            if i < 2:
+                stream.wait_stream(caller)        # (whatever prepared the model -- bricks, weight images -- ran on the caller's stream)
         with torch.cuda.stream(stream):
             packed = _render_packed(model, H, W, Ks[i], render_poses[i], render_kwargs, flip_x, flip_y, group)
             ready = stream.record_event()
