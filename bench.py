@@ -76,6 +76,7 @@ def parse():
                     "the march of frame k+1 runs beside the shade of frame k (a 1/N share alone fills 0.66 of a wave per slot and stages 93 KB "
                     "of weights per shade launch; whole frames: 8.75 -> 8.40 ms on S1, 13.98 -> 12.68 ms on the truck shape, frames bit-identical, "
                     "profiles/r06/frame_pair_n1.txt).  -1 / 1 = on (the per-kernel durations then come from a second, one-stream timed region), 0 = one stream")
+    ap.add_argument("--frames-in-flight", type=int, default=2, help="streams / work lists the frames take in turn when --frame-pair is on")
     ap.add_argument("--tune", action="append", default=[], help="key=value speed knob (ugrid_tune), repeatable")
     ap.add_argument("--shuffle-rays", action="store_true", help="render the frame's rays in a random order (incoherent 64-ray tiles, "
                     "like a training batch): shows what the kernels owe to neighbouring pixels sharing cells")
@@ -272,7 +273,7 @@ class FrameBench:
         fp = int(getattr(args, "frame_pair", -1))
         self.pair = None
         if fp != 0 and device.type == "cuda" and hasattr(self.rend, "use_workspace_slot"):      # (default: on; --frame-pair 0 = one stream)
-            self.pair = [torch.cuda.Stream(device), torch.cuda.Stream(device)]      # frames alternate between them (step)
+            self.pair = [torch.cuda.Stream(device) for _ in range(max(2, int(getattr(args, "frames_in_flight", 2))))]      # frames take them in turn (step)
         self.single_stream = False      # timed(single_stream=True): the pair switched off for one timed region
         self.n_step = 0
         self.last_out = None
@@ -320,9 +321,9 @@ class FrameBench:
             if self.pair is not None:
                 self.rend.use_workspace_slot(0)
             return self._step(timing, weak)
-        k = self.n_step & 1
+        k = self.n_step % len(self.pair)
         self.n_step += 1
-        if self.n_step <= 2:
+        if self.n_step <= len(self.pair):
             self.pair[k].wait_stream(torch.cuda.current_stream(self.device))      # (what set up the inputs ran on the caller's stream)
         self.rend.use_workspace_slot(k)
         with torch.cuda.stream(self.pair[k]):
@@ -771,7 +772,7 @@ def truck_render_block(args, device, want_cpu):
         res = {"workload": "truck_single.py-shaped render: F = 4 (P = 9), G = %d^3, C = 12, rgbnet 39-128-128-3, stepsize 0.5 -> S = %d, thres 1e-4, "
                            "%dx%d rays, trained-like synthetic fields (make_state_surfaces)" % (G, S, fb.W, fb.H),
                "value": R * S / t / 1e6, "unit": "Msamples/s", "ms_per_step": t * 1e3, "steps": steps, "rays_per_sec": R / t,
-               "frames_in_flight": 2 if fb.pair is not None else 1, "ms_per_step_single_stream": (dt1 / steps * 1e3) if dt1 else None,
+               "frames_in_flight": len(fb.pair) if fb.pair is not None else 1, "ms_per_step_single_stream": (dt1 / steps * 1e3) if dt1 else None,
                "samples_per_ray": S, "survivors_M": M, "survivor_frac": M / float(R * S),
                "terminated_ray_frac": float((out["alphainv_last"] < 1e-3).float().mean()),
                "kernels": {k: {"ms": v, "algorithmic_bytes": alg.get(k), "algorithmic_GBps": (alg[k] / (v * 1e-3) / 1e9) if k in alg and v > 0 else None}
@@ -972,7 +973,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "rays_per_sec": R / (dt / args.steps),
-            "frames_in_flight": 2 if fb.pair is not None else 1,
+            "frames_in_flight": len(fb.pair) if fb.pair is not None else 1,
             "ms_per_step_single_stream": (dt_single / args.steps * 1e3) if dt_single else None,
             "config": {"workload": "%s %dx%dx%d G%d F%d(P%d) C12 rgbnet 39-128-128-3 f32 stepsize %.3g thres 1e-4 %s"
                                    % (args.scene.upper(), fb.W, fb.H, S, G, args.freq, 1 + 2 * args.freq, fb.stepsize,
@@ -984,7 +985,7 @@ def main():
                        "terminated_ray_frac": term_frac, "chunks_per_frame": n_chunks,
                        "step": "ray generation + march + shade + %s%s" % (
                            "all-gather of the tiles + frame assembly (un-deal, un-tile)" if use_dist else "un-tiling to image order",
-                           "; 2 frames in flight" if fb.pair is not None else ""),
+                           "; %d frames in flight" % len(fb.pair) if fb.pair is not None else ""),
                        "ray_order": "shuffled (incoherent tiles)" if args.shuffle_rays else (
                            "%dx%d pixel blocks (one 8x8 block per 64-ray wave), results back in image order" % (args.ray_tile, args.ray_tile)
                            if fb.order is not None else "image order (64-pixel row segments per wave)"),

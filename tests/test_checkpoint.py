@@ -89,6 +89,8 @@ def test_render_viewpoints_frame_loop(golden_dir):
     one = render_viewpoints(model, poses, [(H, W)] * N, [K] * N, kw, frames_in_flight=1)
     assert all(np.array_equal(a, b) for a, b in zip(one, (rgbs, depths, bgmaps)))
     assert getattr(model, "_ws_slot", 0) == 0
+    three = render_viewpoints(model, poses, [(H, W)] * N, [K] * N, kw, frames_in_flight=3)      # (more views than streams: slots are re-used)
+    assert all(np.array_equal(a, b) for a, b in zip(three, one)) and getattr(model, "_ws_slot", 0) == 0
     gt = [np.clip(rgbs[i] + 0.01, 0, 1) for i in range(N)]
     out = render_viewpoints(model, poses, [(H, W)] * N, [K] * N, kw, gt_imgs=gt)
     assert len(out) == 4 and all(35.0 < p < 45.0 for p in out[3])     # 0.01 offset -> 40 dB

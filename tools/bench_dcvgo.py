@@ -39,9 +39,9 @@ def make_dcvgo_state(G, device, seed=0):
     return out
 
 
-def two_in_flight(rend, frame, steps, dev):
+def two_in_flight(rend, frame, steps, dev, n=2):
     """seconds per frame with consecutive frames alternating between two streams / two work lists (run_render.render_viewpoints' default)"""
-    pair = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    pair = [torch.cuda.Stream(dev) for _ in range(n)]
     for st in pair:
         st.wait_stream(torch.cuda.current_stream(dev))
     best = None
@@ -49,8 +49,8 @@ def two_in_flight(rend, frame, steps, dev):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(2 * steps):
-            rend.use_workspace_slot(i & 1)
-            with torch.cuda.stream(pair[i & 1]):
+            rend.use_workspace_slot(i % n)
+            with torch.cuda.stream(pair[i % n]):
                 frame()
         torch.cuda.synchronize()
         best = (time.perf_counter() - t0) / (2 * steps)
@@ -95,6 +95,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     dt2 = two_in_flight(rend, frame, args.steps, dev)
+    dtn = {n: two_in_flight(rend, frame, args.steps, dev, n) * 1e3 for n in (3, 4)}
     fr = rend._fused
     S = fr.tables(0.5)[2]
     M = fr.survivors_of_last_chunk()
@@ -126,7 +127,7 @@ def main():
     line = json.dumps({
         "workload": "DirectContractedVoxGO render, %dx%d rays x S=%d samples, G=%d^3 single-level grids, C=12, rgbnet 39-128-128-3, "
                     "stepsize 0.5, thres 1e-4, mask cache, trained-like synthetic fields (tools/bench_dcvgo.make_dcvgo_state)" % (W, H, S, G),
-        "path": "fused: ugrid_render_march_dcvgo + ugrid_render_shade (F = 0)", "ms_per_frame": dt * 1e3, "ms_per_frame_two_in_flight": dt2 * 1e3,
+        "path": "fused: ugrid_render_march_dcvgo + ugrid_render_shade (F = 0)", "ms_per_frame": dt * 1e3, "ms_per_frame_two_in_flight": dt2 * 1e3, "ms_n_in_flight": dtn,
         "kernels_ms": {"march_dcvgo": march, "shade": shade}, "value": R * S / dt / 1e6, "unit": "Msamples/s", "rays_per_sec": R / dt,
         "survivors_M": M, "survivor_frac": M / float(R * S), "terminated_ray_frac": float((out["alphainv_last"] < 1e-3).float().mean()),
         "vs_composed_forward": {"rays": 4 * 8192, "linf": worst, "rays_above_1e-4": n_bad,

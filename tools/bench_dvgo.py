@@ -60,9 +60,9 @@ def make_dvgo_state(G, device, seed=0):
     return out
 
 
-def two_in_flight(rend, frame, steps, dev):
+def two_in_flight(rend, frame, steps, dev, n=2):
     """seconds per frame with consecutive frames alternating between two streams / two work lists (run_render.render_viewpoints' default)"""
-    pair = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    pair = [torch.cuda.Stream(dev) for _ in range(n)]
     for st in pair:
         st.wait_stream(torch.cuda.current_stream(dev))
     best = None
@@ -70,8 +70,8 @@ def two_in_flight(rend, frame, steps, dev):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(2 * steps):
-            rend.use_workspace_slot(i & 1)
-            with torch.cuda.stream(pair[i & 1]):
+            rend.use_workspace_slot(i % n)
+            with torch.cuda.stream(pair[i % n]):
                 frame()
         torch.cuda.synchronize()
         best = (time.perf_counter() - t0) / (2 * steps)
@@ -116,6 +116,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     dt2 = two_in_flight(rend, view, args.steps, dev)
+    dtn = {n: two_in_flight(rend, view, args.steps, dev, n) * 1e3 for n in (3, 4)}
     fr = rend._fused
     M = fr.survivors_of_last_chunk()
     R = H * W
@@ -149,7 +150,7 @@ def main():
         "workload": "DirectVoxGO render (configs[0] shape), %dx%d rays, lego box, G=%d^3 -> world size %s, C=12, rgbnet_direct "
                     "39-128-128-3, stepsize 0.5, near 2, thres 1e-4, mask cache, trained-like synthetic fields "
                     "(tools/bench_dvgo.make_dvgo_state)" % (W, H, G, s["world_size"].tolist()),
-        "path": "fused: ugrid_render_march_dvgo + ugrid_render_shade (F = 0)", "ms_per_view": dt * 1e3, "ms_per_view_two_in_flight": dt2 * 1e3,
+        "path": "fused: ugrid_render_march_dvgo + ugrid_render_shade (F = 0)", "ms_per_view": dt * 1e3, "ms_per_view_two_in_flight": dt2 * 1e3, "ms_n_in_flight": dtn,
         "kernels_ms": {"march_dvgo": march, "shade": shade}, "rays_per_sec": R / dt, "steps_marched_M": n_steps / 1e6,
         "value": n_steps / dt / 1e6, "unit": "Msamples/s", "survivors_M": M / 1e6,
         "terminated_ray_frac": float((out["alphainv_last"] < 1e-3).float().mean()),
