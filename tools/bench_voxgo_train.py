@@ -107,7 +107,12 @@ def main():
                     "(the reference reads psnr.item() every step; a caller that logs every N steps need not)")
     ap.add_argument("--sync-free", type=int, default=0, help="1: the native step without its mid-forward host read (capacity-sized per-sample arrays, counts on "
                     "the device: include/ugrid_hip.h ugrid_voxgo_step.sync_free); with --lazy-loss 1 the loop makes no host read at all")
+    ap.add_argument("--tune", action="append", default=[], help="key=value for ugrid_tune (A/B switches), repeatable")
     args = ap.parse_args()
+    from unboundednerfpytorch_amd import _lib
+    for kv in args.tune:
+        k, v = kv.split("=")
+        _lib.check(_lib.load().ugrid_tune(k.encode(), int(v)), "tune " + kv)
     kinds = ["dvgo", "dcvgo"] if args.model == "both" else [args.model]
     for kind in kinds:
         phases = [1] if CFG[kind]["weight_tv_k0"] == 0 else {"dense": [1], "masked": [10001]}.get(args.phase, [1, 10001])
