@@ -32,6 +32,8 @@ class _CountTracker:
         self.host, self.event, self.last, self.cap2 = None, None, (0, 0), None
 
     def poll(self):
+        if torch.cuda.is_current_stream_capturing():      # (an event query is not allowed while a hipGraph capture is open: the last known counts)
+            return self.last
         if self.event is not None and self.event.query():
             self.last = (int(self.host[0]), int(self.host[1]))
             self.event = None
