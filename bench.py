@@ -816,6 +816,29 @@ def voxgo_train_block():
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def voxgo_render_block(steps):
+    """BASELINE.json configs[0] / configs[1] as worded, the RENDER halves: one DirectVoxGO view of the lego box at 800 x 800 (160^3) and one
+    DirectContractedVoxGO 1080p frame (320^3, S = 1068) through the fused renderers -- tools/bench_dvgo.py, tools/bench_dcvgo.py: ms per view on
+    one stream and with two / four views in flight (run_render.render_viewpoints), agreement with the composed forward.  Secondary."""
+    res = {}
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_dcvgo
+        import bench_dvgo
+        d = bench_dvgo.main(["--steps", str(max(10, steps))], quiet=True)
+        n4 = (d.get("ms_n_in_flight") or {}).get("4")
+        res["dvgo_lego_800_view"] = dict(d, ms_per_step=n4 or d["ms_per_view_two_in_flight"], frames_in_flight=4 if n4 else 2,
+                                         ms_per_step_single_stream=d["ms_per_view"])
+        torch.cuda.empty_cache()
+        c = bench_dcvgo.main(["--steps", str(max(5, steps // 2))], quiet=True)
+        res["dcvgo_1080p_frame"] = dict(c, ms_per_step=c["ms_per_frame_two_in_flight"], frames_in_flight=2, ms_per_step_single_stream=c["ms_per_frame"])
+        torch.cuda.empty_cache()
+    except Exception as e:          # noqa: BLE001
+        torch.cuda.empty_cache()
+        res["error"] = "%s: %s" % (type(e).__name__, e)
+    return res
+
+
 def self_launch(args):
     """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): start the N ranks ourselves through
     torch.distributed.run on 127.0.0.1 -- the command the driver uses for N > 1 -- and pass their exit code on.  On a box
@@ -1086,6 +1109,7 @@ def main():
             if isinstance(s3.get("roofline_tv_adam_dense"), dict):
                 res["roofline_hbm"] = hbm_roofline_entry(s3["roofline_tv_adam_dense"])
         res["secondary_voxgo_train_steps"] = voxgo_train_block()
+        res["secondary_voxgo_renders"] = voxgo_render_block(args.steps)
     if rank == 0:
         line = compact_line(res)
         print(json.dumps(line, separators=(",", ":")))
@@ -1199,6 +1223,14 @@ def compact_line(res, detail_path=None):
             sec["voxgo_train"] = "error"
         for k in vg:
             put(k, vg, k)
+    vr = res.get("secondary_voxgo_renders")
+    if isinstance(vr, dict):
+        if "error" in vr:
+            sec["voxgo_render"] = "error"
+        for k in ("dvgo_lego_800_view", "dcvgo_1080p_frame"):
+            put(k, vr, k)
+            if isinstance(vr.get(k), dict) and vr[k].get("ms_per_step_single_stream"):
+                sec[k + "_1stream"] = _num(vr[k]["ms_per_step_single_stream"])
     if sec:
         line["secondary_ms"] = sec
     px = res.get("scaling_proxy")

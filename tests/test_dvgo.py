@@ -218,6 +218,19 @@ def test_dvgo_render_view_equals_render_rays_on_the_image_rays(C):
         assert rgbs.shape == (2, H, W, 3) and depths.shape == (2, H, W, 1) and bgmaps.shape == (2, H, W, 1)
         assert np.array_equal(rgbs[0], img["rgb_marched"].cpu().numpy()) and np.array_equal(rgbs[1], rgbs[0])
         assert np.array_equal(bgmaps[0][..., 0], img["alphainv_last"].cpu().numpy())
+        # five different views through the renderer's own default (four in flight: the fifth re-uses the first stream and work list)
+        poses = []
+        for i in range(5):
+            p = c2w.clone()
+            p[:, 3] += torch.tensor([0.03 * i, -0.02 * i, 0.01 * i])
+            poses.append(p.numpy())
+        assert rend.frames_in_flight == 4
+        many = render_viewpoints(rend, poses, [[H, W]] * 5, [K] * 5, kw)
+        one = render_viewpoints(rend, poses, [[H, W]] * 5, [K] * 5, kw, frames_in_flight=1)
+        assert all(np.array_equal(a, b) for a, b in zip(many, one))
+        assert not np.array_equal(many[0][1], many[0][0]) and not np.array_equal(many[0][4], many[0][0])
+        ref4 = rend.render_view(H, W, K, poses[4], **kw)
+        assert np.array_equal(many[0][4], ref4["rgb_marched"].cpu().numpy())
     for k in img:
         a, b = img[k].reshape(ref[k].shape), ref[k]
         assert torch.equal(a, b), k               # fused path: per-ray results do not depend on the ray order

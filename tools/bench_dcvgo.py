@@ -58,7 +58,7 @@ def two_in_flight(rend, frame, steps, dev, n=2):
     return best
 
 
-def main():
+def main(argv=None, quiet=False):
     ap = argparse.ArgumentParser()
     ap.add_argument("--grid", type=int, default=320)
     ap.add_argument("--steps", type=int, default=5)
@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--out", default=None)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     import bench
     from unboundednerfpytorch_amd.dcvgo_render import DirectContractedVoxGORenderer
     from unboundednerfpytorch_amd.fourier_render import get_rays_of_pixel_index, pixel_tile_order, untile
@@ -134,10 +134,12 @@ def main():
                                 "composed_us_per_ray": t_comp / (4 * 8192) * 1e6, "fused_us_per_ray": dt / R * 1e6,
                                 "composed_survivors": kept},
         "finite": bool(torch.isfinite(out["rgb_marched"]).all())})
-    print(line)
+    if not quiet:
+        print(line)
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         open(args.out, "w").write(line + "\n")
+    return json.loads(line)
 
 
 if __name__ == "__main__":

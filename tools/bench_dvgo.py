@@ -79,7 +79,7 @@ def two_in_flight(rend, frame, steps, dev, n=2):
     return best
 
 
-def main():
+def main(argv=None, quiet=False):
     ap = argparse.ArgumentParser()
     ap.add_argument("--grid", type=int, default=160)
     ap.add_argument("--steps", type=int, default=5)
@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--out", default=None)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     from unboundednerfpytorch_amd.dvgo_render import DirectVoxGORenderer
     from unboundednerfpytorch_amd.fourier_render import get_rays_of_pixel_index, pixel_tile_order, untile
     dev = torch.device("cuda", 0)
@@ -158,10 +158,12 @@ def main():
         "vs_composed_forward": {"rays": R, "linf": worst, "rays_outside_tol(1e-4 rgb/alphainv, 1e-2 depth)": n_bad,
                                 "composed_ms_per_view": t_comp * 1e3, "speedup": t_comp / dt, "composed_survivors": kept},
         "finite": bool(torch.isfinite(out["rgb_marched"]).all())})
-    print(line)
+    if not quiet:
+        print(line)
     if args.out:
         os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
         open(args.out, "w").write(line + "\n")
+    return json.loads(line)
 
 
 if __name__ == "__main__":

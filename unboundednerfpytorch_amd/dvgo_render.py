@@ -104,6 +104,9 @@ class DirectVoxGORenderer:
                 and w[0].shape[1] == c_in + 3 + 6 * int(s['viewbase_pe'])
                 and bool(_lib.load().ugrid_shade_supported(0, C, int(s['viewbase_pe']))))
 
+    frames_in_flight = 4      # run_render.render_viewpoints: a bounded scene's view (800 x 800 on the lego box: two launches of ~0.9 ms that leave most of
+                              # the chip idle) gains from four views in flight -- 1.88 / 1.03 / 0.78 ms per view at 1 / 2 / 4 (profiles/r06/frames_in_flight_sweep.txt)
+
     def _fused_renderer(self):
         """the fused march + shade renderer over this model's grids (built on first use)"""
         if self._fused is None:

@@ -16,11 +16,11 @@ import torch
 
 @torch.no_grad()
 def render_viewpoints(model, render_poses, HW, Ks, render_kwargs, gt_imgs=None, render_factor=0,
-                      flip_x=False, flip_y=False, group=None, verbose=False, frames_in_flight=2):
+                      flip_x=False, flip_y=False, group=None, verbose=False, frames_in_flight=None):
     """model: FourierGridRenderer, or a DirectVoxGORenderer / DirectContractedVoxGORenderer (their render_view takes the
     reference's render_kwargs 'near', 'far', 'bg' as well); render_poses [N,3or4,4] camera-to-world; HW [N,2]; Ks [N,3,3];
     render_kwargs: needs 'stepsize', may carry 'inverse_y' (the keys run_render.py passes; others are ignored).
-    frames_in_flight: n >= 2 = consecutive views take n streams / n work lists in turn (renderers with use_workspace_slot; every
+    frames_in_flight (default: the model's own `frames_in_flight` attribute, else 2): n >= 2 = consecutive views take n streams / n work lists in turn (renderers with use_workspace_slot; every
     further work list costs up to 8.4 GB at 1080p x 256 samples), 1 = one stream.  2 is within 2 % of the best for 1080p frames; a
     view that leaves most of the chip idle gains from 4 (DirectVoxGO, 800 x 800: 1.88 / 1.03 / 0.78 ms per view at 1 / 2 / 4).
     Returns (rgbs, depths, bgmaps) or (rgbs, depths, bgmaps, psnrs) when gt_imgs is given."""
@@ -31,12 +31,14 @@ def render_viewpoints(model, render_poses, HW, Ks, render_kwargs, gt_imgs=None, 
         HW = (HW / render_factor).astype(int)
         Ks[:, :2, :3] /= render_factor
     dev = model.device
+    if frames_in_flight is None:
+        frames_in_flight = int(getattr(model, "frames_in_flight", 2))
     copy_stream = torch.cuda.Stream(dev)
     caller = torch.cuda.current_stream(dev)
     pair = None
     if (frames_in_flight >= 2 and hasattr(model, "use_workspace_slot") and len(render_poses) > 1
             and model.use_workspace_slot(0) is not False):      # (False: a model outside the fused shapes, composed forward, one stream)
-        pair = [torch.cuda.Stream(dev) for _ in range(int(frames_in_flight))]
+        pair = [torch.cuda.Stream(dev) for _ in range(min(int(frames_in_flight), len(render_poses)))]
     n = len(render_poses)
     n_slots = len(pair) if pair is not None else 2
     host = [None] * n_slots       # pinned buffers (one per view in flight), re-allocated when the frame size changes
