@@ -270,6 +270,7 @@ class FrameBench:
             self.px = self.order[self.px].contiguous()
         self.gathered = [torch.empty(world * self.per, 5, device=device) for _ in range(2)] if self.use_dist else None
         self.inflight = {"work": None, "n": 0, "tile": None}
+        self.assembled_ev = [None, None]      # gathered[i] may be overwritten by the next exchange only after its frame has been assembled
         fp = int(getattr(args, "frame_pair", -1))
         self.pair = None
         if fp != 0 and device.type == "cuda" and hasattr(self.rend, "use_workspace_slot"):      # (default: on; --frame-pair 0 = one stream)
@@ -353,6 +354,9 @@ class FrameBench:
             if fl["work"] is not None:
                 fl["work"].wait()                # stream-level wait for the previous frame's exchange
                 self._assemble()                 # ... whose image is put together while this frame's exchange runs
+            ev = self.assembled_ev[fl["n"] & 1]
+            if ev is not None:               # (with frames on two streams the assembly of frame k - 2 ran on the OTHER stream)
+                torch.cuda.current_stream(self.device).wait_event(ev)
             fl["work"] = self.dist.all_gather_into_tensor(self.gathered[fl["n"] & 1], tile, async_op=True)
             fl["tile"] = tile                    # keep the send buffer alive until the collective has run
             fl["n"] += 1
@@ -362,6 +366,8 @@ class FrameBench:
         """gathered tiles -> the frame in image order [R,5] (un-deal + un-tile: one index_select), part of the step"""
         full = self.gathered[(self.inflight["n"] - 1) & 1]
         self.frame = torch.index_select(full, 0, self.src_index)
+        if self.device.type == "cuda":
+            self.assembled_ev[(self.inflight["n"] - 1) & 1] = torch.cuda.current_stream(self.device).record_event()
 
     def barrier(self):
         if self.use_dist:
