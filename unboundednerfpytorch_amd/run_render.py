@@ -7,7 +7,7 @@ device, ONE fused march + shade pass over all H*W rays (sharded over the process
 dist.render_sharded), and ONE asynchronous device-to-host copy of the packed [H,W,5] result into pinned memory on
 a side stream, overlapped with the next frame's render.  The views of a list are independent frames: consecutive ones are
 issued on two alternating streams, each with a work list of its own (frames_in_flight = 2), so that the march of view k + 1
-runs beside the shade of view k -- whole frames at 1080p: 8.75 -> 8.40 ms per view on white-noise grids, 13.98 -> 12.68 ms on
+runs beside the shade of view k -- whole frames at 1080p: 8.8 -> 8.4 ms per view on white-noise grids, 14.0 -> 12.4 ms on
 a trained-like truck-shaped scene, every frame bit-identical (profiles/r06/frame_pair_n1.txt).  Same return values as the
 reference: numpy arrays rgbs [N,H,W,3], depths [N,H,W,1], bgmaps [N,H,W,1] (+ PSNRs when ground truth is given)."""
 import numpy as np
@@ -20,9 +20,10 @@ def render_viewpoints(model, render_poses, HW, Ks, render_kwargs, gt_imgs=None, 
     """model: FourierGridRenderer, or a DirectVoxGORenderer / DirectContractedVoxGORenderer (their render_view takes the
     reference's render_kwargs 'near', 'far', 'bg' as well); render_poses [N,3or4,4] camera-to-world; HW [N,2]; Ks [N,3,3];
     render_kwargs: needs 'stepsize', may carry 'inverse_y' (the keys run_render.py passes; others are ignored).
-    frames_in_flight (default: the model's own `frames_in_flight` attribute, else 2): n >= 2 = consecutive views take n streams / n work lists in turn (renderers with use_workspace_slot; every
-    further work list costs up to 8.4 GB at 1080p x 256 samples), 1 = one stream.  2 is within 2 % of the best for 1080p frames; a
-    view that leaves most of the chip idle gains from 4 (DirectVoxGO, 800 x 800: 1.88 / 1.03 / 0.78 ms per view at 1 / 2 / 4).
+    frames_in_flight (default: the model's own `frames_in_flight` attribute, else 2): n >= 2 = consecutive views take n streams and
+    n work lists in turn (renderers with use_workspace_slot; every further work list costs up to 8.4 GB at 1080p x 256 samples),
+    1 = one stream.  2 is within 2 % of the best for 1080p frames; a view that leaves most of the chip idle gains from 4
+    (DirectVoxGO, 800 x 800: 1.88 / 1.03 / 0.78 ms per view at 1 / 2 / 4; profiles/r06/frames_in_flight_sweep.txt).
     Returns (rgbs, depths, bgmaps) or (rgbs, depths, bgmaps, psnrs) when gt_imgs is given."""
     assert len(render_poses) == len(HW) and len(HW) == len(Ks)
     HW = np.asarray(HW).copy()
