@@ -76,7 +76,8 @@ def parse():
                     "the march of frame k+1 runs beside the shade of frame k (a 1/N share alone fills 0.66 of a wave per slot and stages 93 KB "
                     "of weights per shade launch; whole frames: 8.75 -> 8.40 ms on S1, 13.98 -> 12.68 ms on the truck shape, frames bit-identical, "
                     "profiles/r06/frame_pair_n1.txt).  -1 / 1 = on (the per-kernel durations then come from a second, one-stream timed region), 0 = one stream")
-    ap.add_argument("--frames-in-flight", type=int, default=2, help="streams / work lists the frames take in turn when --frame-pair is on")
+    ap.add_argument("--frames-in-flight", type=int, default=3, help="streams / work lists the frames take in turn when --frame-pair is on (3: 2 % faster than 2 on "
+                    "S1, S1b at S = 668 and the truck shape, three repetitions each on two boards; 4 is no better: profiles/r06/frames_in_flight_sweep.txt)")
     ap.add_argument("--tune", action="append", default=[], help="key=value speed knob (ugrid_tune), repeatable")
     ap.add_argument("--shuffle-rays", action="store_true", help="render the frame's rays in a random order (incoherent 64-ray tiles, "
                     "like a training batch): shows what the kernels owe to neighbouring pixels sharing cells")
@@ -274,7 +275,14 @@ class FrameBench:
         fp = int(getattr(args, "frame_pair", -1))
         self.pair = None
         if fp != 0 and device.type == "cuda" and hasattr(self.rend, "use_workspace_slot"):      # (default: on; --frame-pair 0 = one stream)
-            self.pair = [torch.cuda.Stream(device) for _ in range(max(2, int(getattr(args, "frames_in_flight", 2))))]      # frames take them in turn (step)
+            self.pair = [torch.cuda.Stream(device) for _ in range(max(2, int(getattr(args, "frames_in_flight", 3))))]      # frames take them in turn (step)
+            # every stream's work list is resident before anything is timed (an 8.4 GiB allocation is set-up, not a step): the frame's
+            # size at N = 1 and for a rank's own whole frames, a rank's share of it when ranks share one GPU (debugging runs)
+            n_rays = self.per if (world > 1 and os.environ.get("UGRID_BENCH_SHARE_GPU") == "1") else self.R
+            for k in range(len(self.pair)):
+                self.rend.use_workspace_slot(k)
+                self.rend._workspace(min(n_rays, self.rend.rays_per_chunk(self.S)), self.S)
+            self.rend.use_workspace_slot(0)
         self.single_stream = False      # timed(single_stream=True): the pair switched off for one timed region
         self.n_step = 0
         self.last_out = None

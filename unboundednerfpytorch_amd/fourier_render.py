@@ -249,6 +249,9 @@ class FourierGridRenderer:
         n = max(64, (self.max_ws_bytes // per_ray) // 64 * 64)
         return n
 
+    frames_in_flight = 3      # run_render.render_viewpoints' default for this renderer (three views on three streams / work lists: 2 % faster than two at
+                              # 1080p, four is no better; profiles/r06/frames_in_flight_sweep.txt)
+
     def use_workspace_slot(self, k):
         """Frames in flight on different streams need work lists of their own -- the march of one fills its list while the shade of the
         other drains its (bench.py --frame-pair; run_render's views are independent frames): slot k's workspace becomes the current one."""
