@@ -664,7 +664,7 @@ def s3_train_step_block(device):
         import bench_train_step as bts
         out = {}
         for phase, first in (("dense_tv", 1), ("masked_tv", 10001)):
-            r = bts.run(bts.parse(["--steps", "20", "--warmup", "4", "--first-step", str(first)]))
+            r = bts.run(bts.parse(["--steps", "24", "--blocks", "3", "--warmup", "4", "--first-step", str(first)]))
             out[phase] = {k: r[k] for k in ("ms_per_step", "phases_ms", "survivors_M", "samples", "rays_per_sec", "tv_phase", "loss", "psnr")}
             out["workload"] = r["workload"]
             if phase == "dense_tv" and r.get("roofline_tv_adam_dense"):
@@ -673,7 +673,7 @@ def s3_train_step_block(device):
             torch.cuda.empty_cache()
         # round 6: the same masked-TV step with NO host read in the loop -- the sync-free native step (counts stay on the device) and the
         # loss handed back as a tensor (train_iteration(return_tensors=True): a caller that logs every N steps)
-        r = bts.run(bts.parse(["--steps", "20", "--warmup", "4", "--first-step", "10001", "--sync-free", "1", "--lazy-loss", "1"]))
+        r = bts.run(bts.parse(["--steps", "24", "--blocks", "3", "--warmup", "4", "--first-step", "10001", "--sync-free", "1", "--lazy-loss", "1"]))
         out["masked_tv_sync_free"] = {k: r[k] for k in ("ms_per_step", "survivors_M", "rays_per_sec", "tv_phase")}
         torch.cuda.empty_cache()
         return out
@@ -813,7 +813,7 @@ def voxgo_train_block():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import argparse
         import bench_voxgo_train as bvt
-        a = argparse.Namespace(steps=40, warmup=8, grid=0, fused=1, overlap=1, lazy_loss=0, native=1)      # (8 warm-up steps: the first launches of the backward kernels load their code objects)
+        a = argparse.Namespace(steps=45, warmup=8, blocks=3, grid=0, fused=1, overlap=1, lazy_loss=0, native=1)      # (8 warm-up steps: the first launches of the backward kernels load their code objects)
         out = {}
         for kind, first, tag in (("dvgo", 1, "dvgo_lego_fine"), ("dcvgo", 1, "dcvgo_mip360_fine_dense_tv"), ("dcvgo", 10001, "dcvgo_mip360_fine_masked_tv")):
             r = bvt.run(kind, a, first)

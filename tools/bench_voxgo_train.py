@@ -73,22 +73,36 @@ def run(kind, args, first_step):
     rk = dict(stepsize=0.5, bg=1, near=0.2, far=6.0) if kind == "dvgo" else dict(stepsize=0.5, bg=1, rand_bkgd=True)
     n = cfg["N_rand"]
     batches = [random_rays(n, dev, seed=s) for s in range(1, args.warmup + args.steps + 1)]
+    # --blocks B: B equal blocks, the median block is reported (tools/bench_train_step.py: the queue's idle -> busy glitch)
+    n_blocks = max(1, int(getattr(args, "blocks", 1)))
+    per_block = max(1, args.steps // n_blocks)
+    block_ms = []
     for step in range(1, args.warmup + args.steps + 1):
-        if step == args.warmup + 1:
+        k = step - args.warmup - 1
+        if k >= 0 and k % per_block == 0 and k // per_block < n_blocks:
             torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            now = time.perf_counter()
+            if k == 0:
+                t0 = now
+            else:
+                block_ms.append((now - tb) * 1e3 / per_block)
+            tb = now
         o, d, v, rgb = batches[step - 1]
         loss, psnr = ts.train_iteration(m, opt, o, d, v, rgb, cfg, first_step - 1 + step, rk, overlap_k0_update=bool(args.overlap),
                                         return_tensors=bool(args.lazy_loss))
     torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) * 1e3 / args.steps
+    now = time.perf_counter()
+    ms = (now - t0) * 1e3 / args.steps
+    if n_blocks > 1 and args.steps == per_block * n_blocks:
+        block_ms.append((now - tb) * 1e3 / per_block)
+        ms = sorted(block_ms)[len(block_ms) // 2]
     with torch.no_grad():
         out = m(o, d, v, global_step=step, is_train=True, **rk)
     tv_on = cfg["weight_tv_k0"] > 0
     return {"model": kind, "workload": "%s train step: G=%s, C=12, %d random rays, stepsize 0.5%s" % (
                 "DirectVoxGO (lego fine-stage shape)" if kind == "dvgo" else "DirectContractedVoxGO (mip-360 fine-stage shape)",
                 m.world_size.tolist(), n, "" if not tv_on else ", TV " + ("dense" if first_step < cfg["tv_dense_before"] else "masked")),
-            "fused": bool(args.fused), "native_step": bool(m.native_step and args.fused), "sync_free": bool(m.native_sync_free), "lazy_loss": bool(args.lazy_loss), "ms_per_step": ms, "rays_per_sec": n / (ms * 1e-3), "survivors_M": int(out["weights"].numel()),
+            "fused": bool(args.fused), "native_step": bool(m.native_step and args.fused), "sync_free": bool(m.native_sync_free), "lazy_loss": bool(args.lazy_loss), "ms_per_step": ms, "block_ms": [round(x, 4) for x in block_ms] if n_blocks > 1 else None, "rays_per_sec": n / (ms * 1e-3), "survivors_M": int(out["weights"].numel()),
             "mask_cache_occupied_frac": float(m.mask_cache.mask.float().mean()), "steps": args.steps, "loss": float(loss), "psnr": float(psnr)}
 
 
@@ -107,6 +121,7 @@ def main():
                     "(the reference reads psnr.item() every step; a caller that logs every N steps need not)")
     ap.add_argument("--sync-free", type=int, default=0, help="1: the native step without its mid-forward host read (capacity-sized per-sample arrays, counts on "
                     "the device: include/ugrid_hip.h ugrid_voxgo_step.sync_free); with --lazy-loss 1 the loop makes no host read at all")
+    ap.add_argument("--blocks", type=int, default=1, help="clock the timed steps in B equal blocks and report the median block")
     ap.add_argument("--tune", action="append", default=[], help="key=value for ugrid_tune (A/B switches), repeatable")
     args = ap.parse_args()
     from unboundednerfpytorch_amd import _lib

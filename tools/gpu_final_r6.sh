@@ -81,8 +81,8 @@ PY
 # 6. training steps: host-counted / sync-free, per-step loss read / deferred
 : > $OUT/train_steps.jsonl
 for sf in 0 1; do
-  timeout 600 python tools/bench_voxgo_train.py --model both --steps 100 --warmup 10 --sync-free $sf --lazy-loss $sf 2>/dev/null | grep '^{' >> $OUT/train_steps.jsonl
-  for ph in 1 10001; do timeout 600 python tools/bench_train_step.py --steps 30 --first-step $ph --sync-free $sf --lazy-loss $sf 2>/dev/null | grep '^{' >> $OUT/train_steps.jsonl; done
+  timeout 600 python tools/bench_voxgo_train.py --model both --steps 100 --blocks 4 --warmup 10 --sync-free $sf --lazy-loss $sf 2>/dev/null | grep '^{' >> $OUT/train_steps.jsonl
+  for ph in 1 10001; do timeout 600 python tools/bench_train_step.py --steps 30 --blocks 3 --first-step $ph --sync-free $sf --lazy-loss $sf 2>/dev/null | grep '^{' >> $OUT/train_steps.jsonl; done
 done
 python - $OUT/train_steps.jsonl <<'PY'
 import json, sys
