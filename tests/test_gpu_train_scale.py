@@ -647,3 +647,26 @@ def test_training_trajectory_matches_the_oracle_backend():
         assert abs(la - lb) <= 1e-2 * abs(lb) and abs(pa - pb) <= 0.05, (s, la, lb, pa, pb)
     (la, pa), (lb, pb) = traj[0]
     assert abs(la - lb) <= 1e-5 * abs(lb), (la, lb)              # the first step sees identical parameters
+
+
+def test_side_stream_is_chosen_so_that_its_low_priority_is_honoured():
+    """sharded_adam._low_priority_stream: the stream the overlapped k0 update runs on is picked by a one-off probe (the caller's stream kept
+    busy, one long kernel on the candidate) among up to eight pool streams -- on this hardware only some pairs of queues honour the low
+    priority, and which pair a process gets depends on how many streams it created before (profiles/r06/side_stream_queues.txt).  After
+    handing out 6 / 32 streams (two of the counts that gave a sharing pair) the probe must have run and either found a pair on which
+    the caller's queue drained first or tried all eight candidates."""
+    from unboundednerfpytorch_amd import sharded_adam
+    dev = torch.device("cuda", 0)
+    for burn in (6, 26):           # (6 and 6 + 26 = 32 streams handed out in total)
+        for _ in range(burn):
+            with torch.cuda.stream(torch.cuda.Stream(dev)):
+                torch.zeros(1, device=dev)
+        main = torch.cuda.Stream(dev, priority=-1)
+        with torch.cuda.stream(main):
+            s = sharded_adam._low_priority_stream()
+        assert isinstance(s, torch.cuda.Stream)
+        v = sharded_adam._low_priority_stream.last
+        assert 1 <= len(v) <= 8
+        assert v[-1][0] >= v[-1][1] or len(v) == 8, v
+        assert all(a < b for a, b in v[:-1]), v      # every rejected candidate shared the chip with the caller's queue
+        torch.cuda.synchronize()

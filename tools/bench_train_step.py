@@ -66,6 +66,8 @@ def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--burn-streams", type=int, default=0, help="diagnostic: take this many streams from torch's pool first (which pool stream, "
+                    "hence which hardware queue, the step's side stream lands on depends on how many were handed out before)")
     ap.add_argument("--blocks", type=int, default=1, help="clock the timed steps in B equal blocks and report the median block (steps must be a multiple)")
     ap.add_argument("--grid", type=int, default=200)
     ap.add_argument("--freq", type=int, default=4)
@@ -94,6 +96,9 @@ def run(args):
         _lib.check(_lib.load().ugrid_tune(k.encode(), int(v)), "tune " + kv)
     _gradpool.touch_enabled = bool(getattr(args, "touch", 1))
     dev = torch.device("cuda", 0)
+    for _ in range(int(getattr(args, "burn_streams", 0))):
+        with torch.cuda.stream(torch.cuda.Stream(dev)):
+            torch.zeros(1, device=dev)
     model = make_model(args.grid, args.freq, dev, args.fused, args.channels_last)
     model.fused_loss = bool(args.fused_loss)
     model.native_sync_free = bool(getattr(args, "sync_free", 0))
@@ -168,6 +173,7 @@ def run(args):
            "k0_channels_last": not model.k0.grid.is_contiguous(), "fused_loss": bool(args.fused_loss), "overlap_k0_update": bool(args.overlap),
            "tv_phase": "dense" if args.first_step + args.warmup + args.steps - 1 < TRUCK_CFG["tv_dense_before"] else "masked",
            "touch_bitmap": bool(_gradpool.touch_enabled), "lazy_loss": bool(getattr(args, "lazy_loss", 0)), "sync_free": bool(getattr(args, "sync_free", 0)), "k0_grad_lines_touched_frac": touched,
+           "side_stream_pick": getattr(__import__("unboundednerfpytorch_amd.sharded_adam", fromlist=["x"])._low_priority_stream, "last", None),
            "ms_per_step": total, "block_ms": [round(x, 4) for x in block_ms] if n_blocks > 1 else None, "phases_ms": ms, "steps": args.steps, "survivors_M": M, "samples": args.rays * S,
            "rays_per_sec": args.rays / (total * 1e-3), "k0_voxels": n_k0,
            "k0_streaming_floor_ms": {"note": "compulsory HBM passes over the 3.46 GB k0-sized arrays per step at 6.3 TB/s achievable: "

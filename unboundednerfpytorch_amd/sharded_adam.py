@@ -35,8 +35,52 @@ from ._lib import wait_pending as _lib_wait
 def _low_priority_stream():
     """the side stream of step(overlap=...): the lowest priority the device offers (torch maps an out-of-range value to
     the nearest valid one), so that the caller's stream -- the next forward's latency-bound kernels -- is served first
-    and the bandwidth-bound update fills what is left"""
-    return torch.cuda.Stream(priority=1)
+    and the bandwidth-bound update fills what is left.
+
+    WHICH of torch's pool streams it gets matters on this hardware: the runtime spreads streams over a few hardware queues, and only
+    on some pairs of queues is the low priority HONOURED (the caller's kernels dispatched first, the update filling what is left); on
+    the others the two streams simply share the chip, and the bandwidth-bound update slows the caller's chain of short kernels -- the
+    step's critical path: the S3 masked step reads 3.2 instead of 2.25 ms, the dense one 7.6 instead of 5.8, depending on nothing but
+    how many streams the process had created before (profiles/r06/side_stream_queues.txt).  So the stream is CHOSEN: up to eight
+    candidates, each tried once the way the loop uses it -- the caller's stream kept busy with ~1.2 ms of back-to-back kernels, one
+    ~0.4 ms streaming kernel on the candidate beside them; the first candidate beside which the caller's queue drains FIRST (its
+    kernels were not held up: 1.1-1.2 ms against 1.5 ms shared) is kept (a few ms, once per optimizer).  UGRID_SIDE_STREAM_PICK=0
+    takes the first candidate."""
+    import os
+    first = torch.cuda.Stream(priority=1)
+    if os.environ.get("UGRID_SIDE_STREAM_PICK", "1") == "0" or torch.cuda.is_current_stream_capturing():
+        return first
+    main = torch.cuda.current_stream()
+    dev = main.device
+    try:
+        big = torch.empty(256 << 20, device=dev)          # 1 GiB: one launch of ~10^6 workgroups, ~0.4 ms
+        mid = torch.empty(8 << 20, device=dev)            # 32 MB: the caller's back-to-back kernels, ~15 us each
+    except RuntimeError:
+        return first
+    cand, verdicts = first, []
+    for trial in range(8):
+        if trial:
+            cand = torch.cuda.Stream(priority=1)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        cand.wait_stream(main)
+        torch.cuda.synchronize(dev)
+        ev[0].record(main)                                 # (the clock both sides are read against)
+        for _ in range(120):
+            mid.mul_(1.0)                                  # the caller's queue: issued faster than it executes
+        with torch.cuda.stream(cand):
+            big.mul_(1.0)                                  # the candidate's one long kernel, issued while ~3/4 of that is still queued
+            ev[1].record(cand)
+        ev[2].record(main)
+        torch.cuda.synchronize(dev)
+        t_side, t_main = ev[0].elapsed_time(ev[1]), ev[0].elapsed_time(ev[2])
+        verdicts.append((round(t_side, 3), round(t_main, 3)))
+        if t_side >= t_main:                               # the caller's queue drained first: the priority is honoured on this pair
+            break
+    else:
+        cand = first
+    big.record_stream(cand)
+    _low_priority_stream.last = verdicts                   # (diagnostics: tools/bench_train_step.py prints it)
+    return cand
 
 
 class ShardedMaskedAdam(torch.optim.Optimizer):
