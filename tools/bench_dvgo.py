@@ -87,10 +87,14 @@ def main(argv=None, quiet=False):
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=800)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--burn-streams", type=int, default=0, help="diagnostic: take this many pool streams first (profiles/r06/side_stream_queues.txt)")
     args = ap.parse_args(argv)
     from unboundednerfpytorch_amd.dvgo_render import DirectVoxGORenderer
     from unboundednerfpytorch_amd.fourier_render import get_rays_of_pixel_index, pixel_tile_order, untile
     dev = torch.device("cuda", 0)
+    for _ in range(int(getattr(args, "burn_streams", 0))):
+        with torch.cuda.stream(torch.cuda.Stream(dev)):
+            torch.zeros(1, device=dev)
     G, H, W = args.grid, args.height, args.width
     rend = DirectVoxGORenderer(make_dvgo_state(G, dev), dev)
     assert rend.fused_supported()
