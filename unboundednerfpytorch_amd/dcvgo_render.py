@@ -111,7 +111,8 @@ class DirectContractedVoxGORenderer:
         return (rgbnet_fits_fused(w) and w[0].shape[1] == C + 3 + 6 * int(s['viewbase_pe'])
                 and bool(_lib.load().ugrid_shade_supported(0, C, int(s['viewbase_pe']))))
 
-    frames_in_flight = 2      # run_render.render_viewpoints: even counts suit the dense-grid renderers (1080p frame: 6.92 / 5.85 / 6.26 / 5.87 ms at 1 / 2 / 3 / 4)
+    frames_in_flight = 2      # run_render.render_viewpoints: 1080p frame 6.92 / 5.85 / 6.26 / 5.87 ms at 1 / 2 / 3 / 4 views in flight in the one sweep (the
+                              # three-stream run probably had two streams on one hardware queue, profiles/r06/side_stream_queues.txt): nothing beyond two
 
     def _fused_renderer(self):
         """the fused march + shade renderer over this model's grids (built on first use)"""
