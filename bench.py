@@ -25,7 +25,8 @@ import os
 import sys
 import time
 
-import torch
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")      # (unboundednerfpytorch_amd/__init__.py: a hardware queue per stream in flight; before the runtime starts)
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
