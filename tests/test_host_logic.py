@@ -1127,3 +1127,17 @@ def test_fouriergrid_model_has_the_method_the_reference_program_calls():
         assert seen["args"] == (m, "dd", "im", "cfg", "it", "ct", "po", "hw", "ks", "rk")
     finally:
         train_rays.gather_training_rays = orig
+
+
+def test_package_import_sets_the_hardware_queue_default_unless_given():
+    """unboundednerfpytorch_amd/__init__.py: GPU_MAX_HW_QUEUES = 16 by setdefault (streams in flight need hardware queues of their own,
+    profiles/r06/side_stream_queues.txt); an explicit setting of the caller's wins."""
+    import subprocess
+    code = "import os, unboundednerfpytorch_amd; print(os.environ['GPU_MAX_HW_QUEUES'])"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for given, want in ((None, "16"), ("4", "4")):
+        env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+        if given is not None:
+            env["GPU_MAX_HW_QUEUES"] = given
+        out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == want, (out.stdout, out.stderr[-300:])
