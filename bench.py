@@ -284,6 +284,12 @@ class FrameBench:
                 self.rend.use_workspace_slot(k)
                 self.rend._workspace(min(n_rays, self.rend.rays_per_chunk(self.S)), self.S)
             self.rend.use_workspace_slot(0)
+            # ... and every stream has its hardware queue (created on a stream's first use, ~10 ms): with fewer warm-up steps than streams
+            # that first use would fall inside the timed region (steps 10 / warmup 2: 9.8 instead of 8.2 ms per frame)
+            for st in self.pair:
+                with torch.cuda.stream(st):
+                    torch.zeros(1, device=device)
+            torch.cuda.synchronize(device)
         self.single_stream = False      # timed(single_stream=True): the pair switched off for one timed region
         self.n_step = 0
         self.last_out = None
